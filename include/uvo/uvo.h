@@ -1,0 +1,188 @@
+/*
+ * uvo.h -- C ABI of the MI355X-native ORB feature front-end (extract + match).
+ *
+ * This is the drop-in boundary for the hot path of chintha/U-VIP-SLAM.  The reference has no FFI layer:
+ * the path is entered through two concrete C++ classes.  Each entry point below names the reference
+ * interface it replaces (file:line relative to the reference tree); include/uvo/compat/ holds C++
+ * adaptors with the reference's own class/method signatures on top of this ABI, and INTEGRATION.md shows
+ * the binding a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 (UVO_OK) or a negative UVO_E_* code; nothing throws across the ABI.
+ *   - plain pointers and sizes only; "host" pointers are ordinary CPU memory, "device" pointers are HBM
+ *     addresses on the handle's GPU (hipMalloc / torch.cuda tensors).
+ *   - a handle owns all device scratch (sized at create time), one HIP stream and its pinned staging;
+ *     one handle = one in-flight call; use one handle per GPU / per host thread.
+ *   - there is NO CPU fallback: if no gfx950 device is usable, create() fails with UVO_E_NODEVICE.
+ */
+#ifndef UVO_UVO_H_
+#define UVO_UVO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UVO_OK 0
+#define UVO_E_BADARG (-1)      /* null pointer, non-positive size, image larger than the handle was sized for */
+#define UVO_E_NODEVICE (-2)    /* no usable HIP device / kernels not loadable */
+#define UVO_E_HIP (-3)         /* a HIP runtime call failed; see uvo_last_error() */
+#define UVO_E_CAPACITY (-4)    /* caller's output capacity too small (n_out still reports what was needed) */
+#define UVO_E_UNSUPPORTED (-5) /* geometry outside the supported envelope (see uvo_extractor_create) */
+#define UVO_E_NOMEM (-6)
+
+/* Layout-identical to cv::KeyPoint (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id. */
+typedef struct uvo_keypoint {
+  float x, y;
+  float size;
+  float angle;
+  float response;
+  int32_t octave;
+  int32_t class_id;
+} uvo_keypoint;
+
+/* ------------------------------------------------------------------------------------------------
+ * Extractor -- replaces USLAM::ORBextractor (include/ORBextractor.h:47-95, src/ORBextractor.cc).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct uvo_extractor uvo_extractor;
+
+typedef struct uvo_extractor_cfg {
+  /* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, scoreType, fastTh): include/ORBextractor.h:51 */
+  int32_t nfeatures;
+  float scale_factor;
+  int32_t nlevels;
+  int32_t score_type; /* accepted and ignored, exactly like the live reference path */
+  int32_t fast_th;
+  /* sizing of the device scratch owned by the handle */
+  int32_t max_width, max_height; /* largest frame; every pyramid level must keep >= 56 px per side */
+  int32_t max_batch;             /* frames per uvo_extract_batch* call */
+  int32_t max_input_keypoints;   /* per frame: caller keypoints passed through level 0 (top-up mode) */
+  int32_t device;                /* HIP device ordinal */
+} uvo_extractor_cfg;
+
+int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out);
+void uvo_extractor_destroy(uvo_extractor* h);
+
+/* ORBextractor::GetLevels / GetScaleFactor: include/ORBextractor.h:60-64 */
+int uvo_extractor_levels(const uvo_extractor* h);
+float uvo_extractor_scale_factor(const uvo_extractor* h);
+/* constructor tables (mvScaleFactor, mvInvScaleFactor, mnFeaturesPerLevel, umax[16]): src/ORBextractor.cc:463-511 */
+int uvo_extractor_tables(const uvo_extractor* h, float* scale, float* inv_scale, int32_t* quota, int32_t* umax16);
+
+/*
+ * ORBextractor::operator()(image, mask, keypoints, descriptors, grid_2d, min_px_dist, FullDetect,
+ * num_featsneeded): include/ORBextractor.h:56-58, src/ORBextractor.cc:849-961; call site src/Tracking.cc:946.
+ *   img/width/height/stride : CV_8UC1 host image
+ *   in_kp/n_in              : caller keypoints (reference: `keypoints` on entry); passed through level 0
+ *                             with recomputed angle when full_detect == 0, dropped when full_detect != 0
+ *   grid2d                  : Eigen::MatrixXi::data() -- column-major int32, grid_rows x grid_cols,
+ *                             read and MUTATED when full_detect == 0 (may be NULL when full_detect != 0)
+ *   out_kp/out_desc/cap     : caller buffers for up to `cap` keypoints (28 B) and descriptors (32 B)
+ *   n_out                   : number of keypoints produced (reference: keypoints.size() on return)
+ * Keypoints come out level-major in the reference's list order; nothing is truncated to nfeatures.
+ */
+int uvo_extract(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdiff_t stride, const uvo_keypoint* in_kp, int n_in,
+                int32_t* grid2d, int grid_rows, int grid_cols, int min_px_dist, int full_detect, int num_feats_needed,
+                uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int* n_out);
+
+/*
+ * Batched form of the same call (B independent frames, one launch per stage).  Host buffers:
+ *   imgs           : frame b at imgs + b*frame_stride, rows `stride` bytes apart
+ *   in_kp / n_in   : [B][max_input_keypoints] / [B]   (NULL / NULL when there are none)
+ *   grid2d         : [B][grid_rows*grid_cols] column-major each (NULL when full_detect != 0)
+ *   num_feats_needed : [B] (ignored when full_detect != 0; may be NULL then)
+ *   out_kp/out_desc: [B][cap] / [B][cap][32];  n_out: [B]
+ */
+int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
+                      const uvo_keypoint* in_kp, const int32_t* n_in, int32_t* grid2d, int grid_rows, int grid_cols, int min_px_dist,
+                      int full_detect, const int32_t* num_feats_needed, uvo_keypoint* out_kp, uint8_t* out_desc, int cap,
+                      int32_t* n_out);
+
+/*
+ * HBM-resident form: every pointer is a device pointer on the handle's GPU and the call only enqueues work
+ * on the handle's stream (uvo_extractor_synchronize() waits for it).  Same argument meaning as above.
+ * d_n_out[b] may exceed `cap`; only the first `cap` records of a frame are written in that case.
+ */
+int uvo_extract_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, int width, int height, ptrdiff_t stride,
+                             ptrdiff_t frame_stride, const uvo_keypoint* d_in_kp, const int32_t* d_n_in, int32_t* d_grid2d, int grid_rows,
+                             int grid_cols, int min_px_dist, int full_detect, const int32_t* d_num_feats_needed, uvo_keypoint* d_out_kp,
+                             uint8_t* d_out_desc, int cap, int32_t* d_n_out);
+int uvo_extractor_synchronize(uvo_extractor* h);
+
+/* Stage taps for the parity tests (valid after a completed extract call; host destination buffers). */
+int uvo_extractor_level_dims(const uvo_extractor* h, int level, int* width, int* height);
+/* padded plane (width+32) x (height+32), tight rows; which: 0 = pyramid level, 1 = blurred level */
+int uvo_extractor_read_plane(uvo_extractor* h, int frame, int level, int which, uint8_t* dst);
+/* FAST candidates of one level: (x, y, score) int32 triples relative to the (13,13) detection border,
+ * unordered; returns count via n */
+int uvo_extractor_read_candidates(uvo_extractor* h, int frame, int level, int32_t* dst_xys, int cap, int* n);
+
+/*
+ * Per-kernel device timing of the last batch call, measured with HIP events on the handle's stream.
+ * names: '\n'-separated kernel names into `names` (cap bytes); ms[i]: summed duration of that kernel's launches;
+ * launches[i]: number of launches.  Enabled with uvo_extractor_profile(h, 1) (adds event overhead).
+ */
+int uvo_extractor_profile(uvo_extractor* h, int enable);
+int uvo_extractor_kernel_times(uvo_extractor* h, char* names, int names_cap, float* ms, int32_t* launches, int cap, int* n);
+
+/* ------------------------------------------------------------------------------------------------
+ * Matcher -- replaces the arithmetic + search cores of USLAM::ORBmatcher (include/ORBmatcher.h:41-88,
+ * src/ORBmatcher.cc) and the all-pairs knn-2 matcher of include/utils.h:81-111.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct uvo_matcher uvo_matcher;
+
+typedef struct uvo_matcher_cfg {
+  int32_t max_query, max_train; /* descriptors per set */
+  int32_t max_batch;            /* descriptor-set pairs per batched call */
+  int32_t max_map_points;       /* uvo_search_by_projection */
+  int32_t device;
+} uvo_matcher_cfg;
+
+int uvo_matcher_create(const uvo_matcher_cfg* cfg, uvo_matcher** out);
+void uvo_matcher_destroy(uvo_matcher* m);
+int uvo_matcher_synchronize(uvo_matcher* m);
+
+/*
+ * All-pairs 256-bit Hamming knn-2: Utils::ratioMatching's knnMatch(desc1, desc2, knn=2, mask)
+ * (include/utils.h:100-101); distance = ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1794-1810).
+ * mask: nq x nt bytes, non-zero = pair allowed, or NULL.  Ties keep the lower train index.
+ * idx = -1, d = 0xFFFF where fewer than one / two train rows are allowed.  Host buffers.
+ */
+int uvo_hamming_knn2(uvo_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* mask, int32_t* idx0, uint16_t* d0,
+                     int32_t* idx1, uint16_t* d1);
+/*
+ * Batched, HBM-resident: pair p matches d_q[p*q_stride ...] (d_nq[p] rows) against d_t[p*t_stride ...]
+ * (d_nt[p] rows); strides in descriptors; outputs [P][max_query].  Enqueues on the matcher's stream.
+ */
+int uvo_hamming_knn2_batch_device(uvo_matcher* m, int pairs, const uint8_t* d_q, const int32_t* d_nq, int q_stride, const uint8_t* d_t,
+                                  const int32_t* d_nt, int t_stride, int32_t* d_idx0, uint16_t* d_d0, int32_t* d_idx1, uint16_t* d_d1);
+/* Full nq x nt distance matrix (uint16), the core of MapPoint::ComputeDistinctiveDescriptors
+ * (src/MapPoint.cc:236-247).  Host buffers. */
+int uvo_hamming_matrix(uvo_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* dist);
+
+/*
+ * ORBmatcher::SearchByProjection(FrameKTL&, const vector<MapPoint*>&, th): src/ORBmatcher.cc:49-125, with the
+ * frame grid of src/FrameKTL.cc:250-264,359-436 (64 x 48 cells, PosInGrid uses round()).  Host buffers.
+ *   frame : kp[n] (undistorted keypoints: x, y, octave are read), desc[n][32], image bounds min/max x/y
+ *   map   : per map point the values FrameKTL::isInFrustum left on it (src/FrameKTL.cc:346-352):
+ *           proj_x, proj_y, level (mnTrackScaleLevel), view_cos, in_view (mbTrackInView && !isBad), desc[nmp][32]
+ *   assigned[n] : in/out, index of the map point held by keypoint i or -1 (reference: F.mvpMapPoints[i] != NULL)
+ *   th, nnratio : call-site values (src/Tracking.cc:2222-2228);  scale_factors[nlevels] = F.mvScaleFactors
+ * The greedy, order-dependent assignment of the reference is reproduced exactly.
+ */
+int uvo_search_by_projection(uvo_matcher* m, const uvo_keypoint* kp, int n, const uint8_t* desc, int min_x, int min_y, int max_x, int max_y,
+                             int32_t* assigned, int nmp, const float* proj_x, const float* proj_y, const int32_t* level,
+                             const float* view_cos, const uint8_t* in_view, const uint8_t* mp_desc, const float* scale_factors,
+                             int nlevels, float th, float nnratio, int* n_matches);
+
+/* last HIP / argument error text for the calling thread's most recent failing call (never NULL) */
+const char* uvo_last_error(void);
+/* library + device description, e.g. "uvo 0.1 gfx950 AMD Instinct MI355X" */
+int uvo_device_info(int device, char* dst, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UVO_UVO_H_ */

@@ -1,0 +1,140 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see orb_oracle.hpp header).  PARITY UNPINNED.
+// Plain C entry points so tests/ and bench.py's cpu_baseline leg can drive the oracle through ctypes.
+#include <cmath>
+#include <cstring>
+
+#include "orb_oracle.hpp"
+
+using namespace orc;
+
+extern "C" {
+
+void* orc_extractor_create(int nfeatures, float scaleFactor, int nlevels, int fastTh) { return new Extractor(nfeatures, scaleFactor, nlevels, fastTh); }
+void orc_extractor_destroy(void* h) { delete (Extractor*)h; }
+
+void orc_extractor_tables(void* h, float* scale, float* invscale, int* quota, int* umax16) {
+  Extractor* e = (Extractor*)h;
+  for (int i = 0; i < e->nlevels; ++i) {
+    scale[i] = e->mvScaleFactor[i];
+    invscale[i] = e->mvInvScaleFactor[i];
+    quota[i] = e->mnFeaturesPerLevel[i];
+  }
+  for (int i = 0; i < 16; ++i) umax16[i] = e->umax[i];
+}
+
+// returns number of keypoints written (<= cap) or -needed if cap is too small
+int orc_extract(void* h, const uint8_t* img, int w, int hgt, long stride, const KeyPoint* in_kp, int n_in, int32_t* grid2d, int grid_rows,
+                int grid_cols, int min_px_dist, int full_detect, int num_feats_needed, KeyPoint* out_kp, uint8_t* out_desc, int cap) {
+  Extractor* e = (Extractor*)h;
+  std::vector<KeyPoint> kps(in_kp, in_kp + n_in);
+  std::vector<uint8_t> desc;
+  e->extract(View{(uint8_t*)img, w, hgt, stride}, kps, desc, grid2d, grid_rows, grid_cols, min_px_dist, full_detect != 0, num_feats_needed);
+  if ((int)kps.size() > cap) return -(int)kps.size();
+  if (!kps.empty()) {
+    memcpy(out_kp, kps.data(), kps.size() * sizeof(KeyPoint));
+    memcpy(out_desc, desc.data(), desc.size());
+  }
+  return (int)kps.size();
+}
+
+// --- taps into the last extract() call ---
+int orc_level_dims(void* h, int level, int* w, int* hgt) {
+  Extractor* e = (Extractor*)h;
+  if (level < 0 || level >= (int)e->pyr.size()) return -1;
+  *w = e->pyr[level].w, *hgt = e->pyr[level].h;
+  return 0;
+}
+// copy the padded plane ((w+32) x (h+32), tight rows); which: 0 = unblurred snapshot, 1 = current (blurred where blurred)
+int orc_level_plane(void* h, int level, int which, uint8_t* out) {
+  Extractor* e = (Extractor*)h;
+  const std::vector<uint8_t>& p = which ? e->planes[level] : e->planes_unblurred[level];
+  memcpy(out, p.data(), p.size());
+  return (int)p.size();
+}
+int orc_level_candidates(void* h, int level, KeyPoint* out, int cap) {
+  Extractor* e = (Extractor*)h;
+  const auto& v = e->dbg_candidates[level];
+  int n = (int)v.size();
+  for (int i = 0; i < n && i < cap; ++i) out[i] = v[i];
+  return n;
+}
+int orc_level_keypoints(void* h, int level, KeyPoint* out, int cap) {
+  Extractor* e = (Extractor*)h;
+  const auto& v = e->dbg_level_kps[level];
+  int n = (int)v.size();
+  for (int i = 0; i < n && i < cap; ++i) out[i] = v[i];
+  return n;
+}
+
+// --- primitives ---
+void orc_border101(const uint8_t* src, int w, int hgt, long stride, uint8_t* dst, int pad) {
+  copy_make_border_reflect101(View{(uint8_t*)src, w, hgt, stride}, dst, w + 2 * pad, pad, pad, pad, pad);
+}
+void orc_resize_linear(const uint8_t* src, int sw, int sh, long sstride, uint8_t* dst, int dw, int dh) {
+  resize_linear_u8(View{(uint8_t*)src, sw, sh, sstride}, View{dst, dw, dh, dw});
+}
+int orc_fast(const uint8_t* img, int w, int hgt, long stride, int threshold, int nms, KeyPoint* out, int cap) {
+  std::vector<KeyPoint> v;
+  fast9_16(View{(uint8_t*)img, w, hgt, stride}, threshold, nms != 0, v);
+  for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
+  return (int)v.size();
+}
+void orc_gauss_taps(int* taps7) { gaussian_taps_7_sigma2(taps7); }
+// plane = padded buffer (w+2*pad) x (h+2*pad) tight; blurs the interior in place
+void orc_gauss7_padded(uint8_t* plane, int w, int hgt, int pad) {
+  View full{plane, w + 2 * pad, hgt + 2 * pad, w + 2 * pad};
+  gaussian_blur7_roi_inplace(full.roi(pad, pad, pad + w, pad + hgt));
+}
+float orc_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+float orc_ic_angle(void* h, const uint8_t* plane, int w, int hgt, int pad, float x, float y) {
+  Extractor* e = (Extractor*)h;
+  View full{(uint8_t*)plane, w + 2 * pad, hgt + 2 * pad, w + 2 * pad};
+  return ic_angle(full.roi(pad, pad, pad + w, pad + hgt), x, y, e->umax);
+}
+void orc_descriptor(void* h, const uint8_t* plane, int w, int hgt, int pad, float x, float y, float angle_deg, uint8_t* desc32) {
+  Extractor* e = (Extractor*)h;
+  View full{(uint8_t*)plane, w + 2 * pad, hgt + 2 * pad, w + 2 * pad};
+  KeyPoint kp{x, y, 31.f, angle_deg, 0.f, 0, -1};
+  compute_orb_descriptor(kp, full.roi(pad, pad, pad + w, pad + hgt), e->pattern, desc32);
+}
+void orc_sincosf(float a, float* s, float* c) {
+  *s = sinf(a);
+  *c = cosf(a);
+}
+int orc_octree(void* h, const KeyPoint* cand, int n, int minX, int maxX, int minY, int maxY, int N, KeyPoint* out, int cap) {
+  Extractor* e = (Extractor*)h;
+  std::vector<KeyPoint> v(cand, cand + n);
+  std::vector<KeyPoint> r = e->DistributeOctTree(v, minX, maxX, minY, maxY, N);
+  for (int i = 0; i < (int)r.size() && i < cap; ++i) out[i] = r[i];
+  return (int)r.size();
+}
+int orc_grider_fast(const uint8_t* img, int w, int hgt, long stride, int num_features, int grid_x, int grid_y, int threshold, int nms,
+                    KeyPoint* out, int cap) {
+  std::vector<KeyPoint> v;
+  grider_fast(View{(uint8_t*)img, w, hgt, stride}, v, num_features, grid_x, grid_y, threshold, nms != 0);
+  for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
+  return (int)v.size();
+}
+
+// --- matcher ---
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
+void orc_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* mask, int32_t* idx0, int32_t* d0, int32_t* idx1, int32_t* d1) {
+  knn2(q, nq, t, nt, mask, idx0, d0, idx1, d1);
+}
+int orc_features_in_area(const KeyPoint* kps, int n, int minX, int minY, int maxX, int maxY, float x, float y, float r, int minLevel,
+                         int maxLevel, int32_t* out, int cap) {
+  FrameGrid g;
+  g.build(kps, n, minX, minY, maxX, maxY);
+  std::vector<int> v = g.GetFeaturesInArea(x, y, r, minLevel, maxLevel);
+  for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
+  return (int)v.size();
+}
+int orc_search_by_projection(const KeyPoint* kps, int n, const uint8_t* fdesc, int minX, int minY, int maxX, int maxY, int32_t* assigned,
+                             int nmp, const float* projx, const float* projy, const int32_t* level, const float* viewcos,
+                             const uint8_t* inview, const uint8_t* mpdesc, const float* scaleFactors, float th, float nnratio) {
+  FrameGrid g;
+  g.build(kps, n, minX, minY, maxX, maxY);
+  return search_by_projection(g, fdesc, assigned, nmp, projx, projy, level, viewcos, inview, mpdesc, scaleFactors, th, nnratio);
+}
+
+}  // extern "C"

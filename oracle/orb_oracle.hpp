@@ -1,0 +1,109 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY.  Nothing in the product path may include,
+// link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg use it, and only as the checker / the reported CPU baseline.
+//
+// CPU restatement of the ORB front-end of chintha/U-VIP-SLAM
+// (src/ORBextractor.cc, src/ORBmatcher.cc, src/FrameKTL.cc grid part,
+// include/Grider_FAST.h, include/utils.h:81-111).
+//
+// PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for
+// this path, and its pixel arithmetic lives in OpenCV (3.4.x, un-vendored,
+// absent from this image), so the OpenCV primitives below (copyMakeBorder,
+// resize INTER_LINEAR, FAST, GaussianBlur, fastAtan2, cvRound) are restated from
+// the published generic (non-IPP, non-OpenCL) C++ algorithms of OpenCV 3.4.x.
+// The glue (pyramid sizing, cells, quad-tree, filter, steering, assembly,
+// matching rules) follows the reference sources line by line; each function
+// cites the file:line it restates.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace orc {
+
+// cv::KeyPoint layout (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id
+struct KeyPoint {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+};
+
+struct View {  // 8-bit single channel image view (cv::Mat ROI stand-in)
+  uint8_t* p;
+  int w, h;
+  ptrdiff_t step;
+  uint8_t* row(int y) const { return p + (ptrdiff_t)y * step; }
+  View roi(int x0, int y0, int x1, int y1) const { return View{p + (ptrdiff_t)y0 * step + x0, x1 - x0, y1 - y0, step}; }
+};
+
+constexpr int EDGE_THRESHOLD = 16;   // src/ORBextractor.cc:78
+constexpr int HALF_PATCH_SIZE = 15;  // :77
+constexpr int PATCH_SIZE = 31;       // :76
+
+int cv_round_f(float v);   // cvRound(float): round half to even
+int cv_round_d(double v);  // cvRound(double)
+
+// ---- OpenCV primitives (restated, [OCV-RECALL]) ----
+void copy_make_border_reflect101(const View& src, uint8_t* dst, ptrdiff_t dstep, int top, int bottom, int left, int right);
+void resize_linear_u8(const View& src, const View& dst);
+void fast9_16(const View& img, int threshold, bool nms, std::vector<KeyPoint>& out);
+void gaussian_taps_7_sigma2(int taps[7]);
+// blur the ROI `roi` (which must sit >= 3 px inside its parent buffer) in place,
+// border taps read the parent's pixels (non-isolated sub-matrix semantics)
+void gaussian_blur7_roi_inplace(const View& roi);
+float fast_atan2(float y, float x);
+
+// ---- reference glue ----
+struct Extractor {
+  // ctor: src/ORBextractor.cc:458-512
+  Extractor(int nfeatures, float scaleFactor, int nlevels, int fastTh);
+  int nfeatures;
+  double scaleFactor;  // member is `double` in include/ORBextractor.h:79
+  int nlevels, fastTh;
+  std::vector<float> mvScaleFactor, mvInvScaleFactor;
+  std::vector<int> mnFeaturesPerLevel;
+  std::vector<int> umax;
+  int pattern[1024];  // 512 (x,y) points
+
+  // pyramid storage: padded planes, ROI at (16,16)
+  std::vector<std::vector<uint8_t>> planes;
+  std::vector<View> pyr;  // ROI views (mvImagePyramid)
+  // debugging / test taps
+  std::vector<std::vector<uint8_t>> planes_unblurred;  // snapshot taken before the blur step
+  std::vector<std::vector<KeyPoint>> dbg_candidates;   // vToDistributeKeys per level (coords relative to minBorder)
+  std::vector<std::vector<KeyPoint>> dbg_level_kps;    // after DistributeOctTree + orientation, level coords
+
+  void ComputePyramid(const View& image);                                       // :963-1004
+  void ComputeKeyPointsOctTree(std::vector<std::vector<KeyPoint>>& all);         // :748-836
+  std::vector<KeyPoint> DistributeOctTree(const std::vector<KeyPoint>& v, int minX, int maxX, int minY, int maxY, int N);  // :1006-1230
+  // operator(): :849-961.  grid2d is column-major (Eigen::MatrixXi::data()), rows x cols.
+  void extract(const View& image, std::vector<KeyPoint>& keypoints, std::vector<uint8_t>& descriptors,
+               int32_t* grid2d, int grid_rows, int grid_cols, int min_px_dist, bool fullDetect, int num_featsneeded);
+};
+
+float ic_angle(const View& image, float ptx, float pty, const std::vector<int>& umax);               // :125-152
+void compute_orb_descriptor(const KeyPoint& kpt, const View& img, const int* pattern, uint8_t* desc);  // :156-195
+
+// include/Grider_FAST.h:81-137 with the declared tie-break (response desc, then y, then x)
+void grider_fast(const View& img, std::vector<KeyPoint>& pts, int num_features, int grid_x, int grid_y, int threshold, bool nms);
+
+// ---- matcher (src/ORBmatcher.cc) ----
+int descriptor_distance(const uint8_t* a, const uint8_t* b);  // :1794-1810
+void knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* mask, int32_t* idx0, int32_t* d0, int32_t* idx1, int32_t* d1);
+
+struct FrameGrid {  // src/FrameKTL.cc:83-84,250-264,359-436
+  int minX, minY, maxX, maxY;
+  float invW, invH;
+  std::vector<std::vector<int>> cells;  // [ix*48+iy]
+  const KeyPoint* kps;
+  int n;
+  void build(const KeyPoint* kps, int n, int minX, int minY, int maxX, int maxY);
+  std::vector<int> GetFeaturesInArea(float x, float y, float r, int minLevel, int maxLevel) const;
+};
+
+// SearchByProjection(FrameKTL&, vector<MapPoint*>&, th): src/ORBmatcher.cc:49-125.
+// assigned[i] = index of the map point assigned to frame keypoint i, or -1 (in/out).
+int search_by_projection(const FrameGrid& g, const uint8_t* fdesc, int32_t* assigned,
+                         int nmp, const float* projx, const float* projy, const int32_t* level, const float* viewcos,
+                         const uint8_t* inview, const uint8_t* mpdesc, const float* scaleFactors, float th, float nnratio);
+
+}  // namespace orc

@@ -1,0 +1,101 @@
+// Shared host/device declarations of the extractor pipeline: per-level geometry, scratch layout, launch
+// wrappers.  Data layout in HBM (see DESIGN.md "Data layout"):
+//   pyramid  : [frame][level] padded u8 planes, row pitch = (w+32) rounded up to 64 B, ROI origin at (16,16)
+//   blurred  : same geometry, 7x7 sigma-2 blurred interior + un-blurred reflected pad ring
+//   cand     : [frame][level][cap_l] 8-byte FAST candidates {x | y<<16, score}, count in cand_count[frame][level]
+//   sel      : [frame][level][quota_l+4] quad-tree survivors in the reference's list order
+//   flist    : [frame][flist_cap] final (level, x, y, aux) slots in output order
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/uvo/uvo.h"
+
+namespace uvo {
+
+constexpr int kMaxLevels = 16;
+constexpr int kPad = 16;         // EDGE_THRESHOLD, src/ORBextractor.cc:78
+constexpr int kMinBorder = 13;   // EDGE_THRESHOLD-3, src/ORBextractor.cc:756
+constexpr int kMaxOctN = 4000;   // largest per-level quota the quad-tree kernel is sized for
+
+struct LevelGeom {
+  int w, h;            // ROI size
+  int pw, ph, pitch;   // padded width/height, row pitch in bytes
+  int64_t plane_off;   // byte offset of the padded plane inside a frame's pyramid block
+  int bw, bh;          // detection window size: (w-26) x (h-26)   (maxBorder - minBorder)
+  int nCols, nRows, wCell, hCell;
+  int cell_base;       // index of this level's first cell in the per-frame cell table
+  int n_cells;
+  int quota;           // mnFeaturesPerLevel
+  int cand_cap;        // worst-case FAST survivors
+  int64_t cand_off;    // element offset into a frame's candidate block
+  int sel_cap;         // quota + 4
+  int sel_off;         // element offset into a frame's sel block
+  int nIni;            // quad-tree roots
+  float hX;
+  float scale;         // mvScaleFactor[level]
+  float patch_size;    // (float)(int)(31*scale)
+  int tab_off;         // offset of this level's resize tables (level >= 1)
+};
+
+struct CellDesc {  // one FAST cell (src/ORBextractor.cc:773-790)
+  int16_t level;
+  int16_t x0, y0;    // ROI origin in level coordinates (iniX, iniY)
+  int16_t rw, rh;    // ROI size (maxX-iniX, maxY-iniY)
+  int16_t ox, oy;    // j*wCell, i*hCell: shift applied to ROI coords -> coords relative to minBorder
+  int16_t pad;
+};
+
+struct Geom {
+  int width, height, nlevels;
+  int total_cells;
+  int64_t pyr_block;    // bytes per frame
+  int64_t cand_block;   // candidates per frame
+  int sel_block;        // sel entries per frame
+  int flist_cap;        // final-list slots per frame
+  LevelGeom lv[kMaxLevels];
+};
+
+struct Cand {
+  uint32_t xy;     // x | y << 16, relative to (minBorder, minBorder)
+  uint32_t score;  // FAST score (cornerScore), 1..254
+};
+
+struct FinalSlot {  // 16 B
+  float x, y;       // level coordinates
+  int32_t level;    // bit 31 set: caller keypoint, aux = index into in_kp
+  int32_t aux;      // FAST score for detected points
+};
+
+const char* hip_err_set(hipError_t e, const char* what);
+
+#define UVO_HIP_CHECK(expr)                                   \
+  do {                                                        \
+    hipError_t _e = (expr);                                   \
+    if (_e != hipSuccess) {                                   \
+      uvo::hip_err_set(_e, #expr);                            \
+      return UVO_E_HIP;                                       \
+    }                                                         \
+  } while (0)
+
+// ---- kernel launch wrappers (defined in the .hip files) ----
+struct DevTables;  // device-resident constant tables, owned by the extractor
+
+void launch_pad_level0(hipStream_t s, const uint8_t* d_img, int w, int h, int64_t stride, int64_t frame_stride, uint8_t* d_pyr,
+                       int64_t pyr_block, const LevelGeom& g0, int batch);
+void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const LevelGeom& src, const LevelGeom& dst, const int32_t* d_xofs,
+                         const int16_t* d_xalpha, const int32_t* d_yofs, const int16_t* d_ybeta, int batch);
+void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g, int4 taps,
+                   int batch);
+void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const LevelGeom* d_lv, const CellDesc* d_cells, int total_cells,
+                       int fast_th, Cand* d_cand, int64_t cand_block, int32_t* d_cand_count, int nlevels, int batch);
+void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const Cand* d_cand, int64_t cand_block, const int32_t* d_cand_count,
+                   uint32_t* d_pstate, Cand* d_sel, int32_t* d_sel_count, int batch);
+void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const Cand* d_sel, const int32_t* d_sel_count,
+                     const uvo_keypoint* d_in_kp, const int32_t* d_n_in, int in_cap, int32_t* d_grid, int grid_rows, int grid_cols,
+                     int min_px_dist, int full_detect, const int32_t* d_nfn, FinalSlot* d_flist, int32_t* d_n_final, int batch);
+void launch_describe(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, const uint8_t* d_blur, int64_t pyr_block,
+                     const FinalSlot* d_flist, const int32_t* d_n_final, const uvo_keypoint* d_in_kp, int in_cap, const int8_t* d_pattern,
+                     const int32_t* d_umax, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch);
+
+}  // namespace uvo

@@ -1,0 +1,80 @@
+"""Synthetic mono frames for the parity tests and bench.py.
+
+A frame is the sum of (a) 3-octave value noise (smooth texture, amplitude 60), (b) random bright/dark
+rectangles and discs (4-40 px, contrast +-30..+-90) that give FAST corners at several scales and
+(c) N(0,3) pixel noise, clipped to [0,255].  `warp_frame` makes the "next" frame of a sequence by a small
+random affine (<= 3 px shift, <= 2 deg rotation) so consecutive-frame matching has true correspondences.
+Pure numpy; deterministic per seed.
+"""
+import numpy as np
+
+
+def _value_noise(rng, h, w, cell):
+    gh, gw = h // cell + 3, w // cell + 3
+    g = rng.random((gh, gw)).astype(np.float32)
+    ys = np.arange(h, dtype=np.float32) / cell
+    xs = np.arange(w, dtype=np.float32) / cell
+    y0 = ys.astype(np.int32)
+    x0 = xs.astype(np.int32)
+    fy = (ys - y0)[:, None]
+    fx = (xs - x0)[None, :]
+    a = g[y0][:, x0]
+    b = g[y0][:, x0 + 1]
+    c = g[y0 + 1][:, x0]
+    d = g[y0 + 1][:, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def make_frame(seed, w=640, h=512, n_shapes=400):
+    rng = np.random.default_rng(seed)
+    img = np.full((h, w), 110.0, dtype=np.float32)
+    for cell, amp in ((64, 30.0), (32, 20.0), (16, 10.0)):
+        img += (_value_noise(rng, h, w, cell) - 0.5) * 2 * amp
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(n_shapes):
+        cx, cy = rng.integers(0, w), rng.integers(0, h)
+        sz = int(rng.integers(4, 41))
+        contrast = float(rng.integers(30, 91)) * (1 if rng.random() < 0.5 else -1)
+        kind = rng.integers(0, 3)
+        x0, x1 = max(cx - sz, 0), min(cx + sz + 1, w)
+        y0, y1 = max(cy - sz, 0), min(cy + sz + 1, h)
+        if x1 <= x0 or y1 <= y0:
+            continue
+        sub = img[y0:y1, x0:x1]
+        lx = xx[y0:y1, x0:x1] - cx
+        ly = yy[y0:y1, x0:x1] - cy
+        if kind == 0:  # axis-aligned rectangle
+            hw, hh = sz / 2, max(2, sz / 2 * rng.uniform(0.4, 1.0))
+            m = (np.abs(lx) <= hw) & (np.abs(ly) <= hh)
+        elif kind == 1:  # rotated rectangle
+            th = rng.uniform(0, np.pi)
+            c, s = np.cos(th), np.sin(th)
+            u = lx * c + ly * s
+            v = -lx * s + ly * c
+            m = (np.abs(u) <= sz / 2) & (np.abs(v) <= max(2, sz / 3))
+        else:  # disc
+            m = lx * lx + ly * ly <= (sz / 2) ** 2
+        sub[m] += contrast
+    img += rng.normal(0.0, 3.0, size=(h, w)).astype(np.float32)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def warp_frame(img, seed):
+    """Previous frame warped by a small random affine (nearest-neighbour resample + fresh N(0,2) noise)."""
+    rng = np.random.default_rng(seed)
+    h, w = img.shape
+    ang = np.deg2rad(rng.uniform(-2, 2))
+    tx, ty = rng.uniform(-3, 3, size=2)
+    c, s = np.cos(ang), np.sin(ang)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    cx, cy = w / 2, h / 2
+    sx = c * (xx - cx) + s * (yy - cy) + cx - tx
+    sy = -s * (xx - cx) + c * (yy - cy) + cy - ty
+    sx = np.clip(np.rint(sx), 0, w - 1).astype(np.int32)
+    sy = np.clip(np.rint(sy), 0, h - 1).astype(np.int32)
+    out = img[sy, sx].astype(np.float32) + rng.normal(0, 2.0, size=(h, w)).astype(np.float32)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def make_batch(n, w=640, h=512, seed0=1000):
+    return np.stack([make_frame(seed0 + i, w, h) for i in range(n)])
