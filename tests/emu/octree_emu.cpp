@@ -1,0 +1,36 @@
+// Host execution of the quad-tree kernel body (u-vip-slam_amd/csrc/octree_core.hpp): the OCT_* phase macros run
+// the 256 "threads" of each phase one after another, so the exact selection logic that the HIP kernel runs can
+// be checked against the oracle on a machine without a GPU.  Test scaffolding only.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../u-vip-slam_amd/csrc/octree_core.hpp"
+
+extern "C" int emu_octree(const uint32_t* cand_xy, const uint32_t* cand_score, int P, int N, int W, int H, int nCols, int nRows, int wCell,
+                          int hCell, uint32_t* sel_xy, uint32_t* sel_score, int sel_cap) {
+  using namespace uvo::oct;
+  if (P == 0) return 0;
+  Params pr;
+  pr.P = P, pr.N = N, pr.W = W, pr.H = H;
+  pr.nIni = (int)roundf((float)W / (float)H);
+  pr.hX = (float)W / (float)pr.nIni;
+  pr.nCols = nCols, pr.nRows = nRows, pr.wCell = wCell, pr.hCell = hCell;
+  int M = (N > 4 * pr.nIni ? N : 4 * pr.nIni) + 8;
+  int Mp2 = 1;
+  while (Mp2 < M) Mp2 <<= 1;
+  pr.M = M, pr.Mp2 = Mp2;
+  std::vector<uint64_t> ccnt(2 * (size_t)M + Mp2);  // 8-byte aligned, >= 4M u32
+  std::vector<Box> boxA(M), boxB(M);
+  std::vector<uint32_t> cntA(M), cntB(M), nodeOfRank(M), baseOfRank(M), sortbuf(Mp2), outKey(M), outPt(M), part(2 * OCT_THREADS);
+  std::vector<int32_t> procRank(M);
+  std::vector<int> sc(16, 0);
+  std::vector<uint32_t> pstate(P);
+  Work w;
+  w.boxA = boxA.data(), w.boxB = boxB.data(), w.cntA = cntA.data(), w.cntB = cntB.data(), w.procRank = procRank.data();
+  w.ccnt = reinterpret_cast<uint32_t*>(ccnt.data());
+  w.nodeOfRank = nodeOfRank.data(), w.baseOfRank = baseOfRank.data(), w.sortbuf = sortbuf.data();
+  w.outKey = outKey.data(), w.outPt = outPt.data(), w.part = part.data(), w.sc = sc.data();
+  return run(pr, w, cand_xy, cand_score, pstate.data(), sel_xy, sel_score, sel_cap);
+}

@@ -1,0 +1,216 @@
+"""ctypes front-end of the CPU oracle (oracle/liborb_oracle.so).  Test infrastructure only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "liborb_oracle.so")
+
+KP = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+
+def build_oracle():
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".hpp", ".inc"))]
+    if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liborb_oracle.so"])
+    return LIB
+
+
+class Oracle:
+    def __init__(self):
+        self.L = L = ctypes.CDLL(build_oracle())
+        vp, ci, cf, cl = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long
+        L.orc_extractor_create.restype = vp
+        L.orc_extractor_create.argtypes = [ci, cf, ci, ci]
+        L.orc_extractor_destroy.argtypes = [vp]
+        L.orc_extractor_tables.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_extract.argtypes = [vp, vp, ci, ci, cl, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, ci]
+        L.orc_level_dims.argtypes = [vp, ci, vp, vp]
+        L.orc_level_plane.argtypes = [vp, ci, ci, vp]
+        L.orc_level_candidates.argtypes = [vp, ci, vp, ci]
+        L.orc_level_keypoints.argtypes = [vp, ci, vp, ci]
+        L.orc_border101.argtypes = [vp, ci, ci, cl, vp, ci]
+        L.orc_resize_linear.argtypes = [vp, ci, ci, cl, vp, ci, ci]
+        L.orc_fast.argtypes = [vp, ci, ci, cl, ci, ci, vp, ci]
+        L.orc_gauss_taps.argtypes = [vp]
+        L.orc_gauss7_padded.argtypes = [vp, ci, ci, ci]
+        L.orc_fast_atan2.restype = cf
+        L.orc_fast_atan2.argtypes = [cf, cf]
+        L.orc_ic_angle.restype = cf
+        L.orc_ic_angle.argtypes = [vp, vp, ci, ci, ci, cf, cf]
+        L.orc_descriptor.argtypes = [vp, vp, ci, ci, ci, cf, cf, cf, vp]
+        L.orc_sincosf.argtypes = [cf, vp, vp]
+        L.orc_octree.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp, ci]
+        L.orc_grider_fast.argtypes = [vp, ci, ci, cl, ci, ci, ci, ci, ci, vp, ci]
+        L.orc_descriptor_distance.argtypes = [vp, vp]
+        L.orc_knn2.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp]
+        L.orc_features_in_area.argtypes = [vp, ci, ci, ci, ci, ci, cf, cf, cf, ci, ci, vp, ci]
+        L.orc_search_by_projection.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, cf]
+
+    # ---- extractor ----
+    def extractor(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, fastTh=20):
+        return OracleExtractor(self, nfeatures, scaleFactor, nlevels, fastTh)
+
+    # ---- primitives ----
+    def border101(self, img, pad=16):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.zeros((h + 2 * pad, w + 2 * pad), np.uint8)
+        self.L.orc_border101(img.ctypes.data, w, h, img.strides[0], out.ctypes.data, pad)
+        return out
+
+    def resize_linear(self, img, dw, dh):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.zeros((dh, dw), np.uint8)
+        self.L.orc_resize_linear(img.ctypes.data, w, h, img.strides[0], out.ctypes.data, dw, dh)
+        return out
+
+    def fast(self, img, threshold, nms=True):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.zeros(w * h, KP)
+        n = self.L.orc_fast(img.ctypes.data, w, h, img.strides[0], threshold, 1 if nms else 0, out.ctypes.data, len(out))
+        return out[:n].copy()
+
+    def gauss_taps(self):
+        t = np.zeros(7, np.int32)
+        self.L.orc_gauss_taps(t.ctypes.data)
+        return t
+
+    def gauss7_padded(self, plane, pad=16):
+        plane = np.array(plane, np.uint8, copy=True, order="C")
+        ph, pw = plane.shape
+        self.L.orc_gauss7_padded(plane.ctypes.data, pw - 2 * pad, ph - 2 * pad, pad)
+        return plane
+
+    def fast_atan2(self, y, x):
+        return float(self.L.orc_fast_atan2(float(y), float(x)))
+
+    def sincosf(self, a):
+        s, c = ctypes.c_float(), ctypes.c_float()
+        self.L.orc_sincosf(float(a), ctypes.byref(s), ctypes.byref(c))
+        return s.value, c.value
+
+    def descriptor_distance(self, a, b):
+        a, b = np.ascontiguousarray(a, np.uint8), np.ascontiguousarray(b, np.uint8)
+        return self.L.orc_descriptor_distance(a.ctypes.data, b.ctypes.data)
+
+    def knn2(self, q, t, mask=None):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        nq = len(q)
+        o = [np.zeros(nq, np.int32) for _ in range(4)]
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.L.orc_knn2(q.ctypes.data, nq, t.ctypes.data, len(t), None if m is None else m.ctypes.data, *[a.ctypes.data for a in o])
+        return o  # idx0, d0, idx1, d1
+
+    def features_in_area(self, kps, bounds, x, y, r, min_level, max_level):
+        kps = np.ascontiguousarray(kps, KP)
+        out = np.zeros(max(len(kps), 1), np.int32)
+        n = self.L.orc_features_in_area(kps.ctypes.data, len(kps), *[int(b) for b in bounds], float(x), float(y), float(r), min_level, max_level,
+                                        out.ctypes.data, len(out))
+        return out[:n].copy()
+
+    def search_by_projection(self, kps, desc, bounds, assigned, proj_x, proj_y, level, view_cos, in_view, mp_desc, scale_factors, th, nnratio):
+        kps = np.ascontiguousarray(kps, KP)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        a = [np.ascontiguousarray(proj_x, np.float32), np.ascontiguousarray(proj_y, np.float32), np.ascontiguousarray(level, np.int32),
+             np.ascontiguousarray(view_cos, np.float32), np.ascontiguousarray(in_view, np.uint8), np.ascontiguousarray(mp_desc, np.uint8),
+             np.ascontiguousarray(scale_factors, np.float32)]
+        assert assigned.dtype == np.int32
+        return self.L.orc_search_by_projection(kps.ctypes.data, len(kps), desc.ctypes.data, *[int(b) for b in bounds], assigned.ctypes.data,
+                                               len(a[0]), *[v.ctypes.data for v in a], float(th), float(nnratio))
+
+    def grider_fast(self, img, num_features, grid_x, grid_y, threshold, nms=True):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.zeros(w * h // 4 + 16, KP)
+        n = self.L.orc_grider_fast(img.ctypes.data, w, h, img.strides[0], num_features, grid_x, grid_y, threshold, 1 if nms else 0,
+                                   out.ctypes.data, len(out))
+        return out[:n].copy()
+
+
+class OracleExtractor:
+    def __init__(self, o, nfeatures, scaleFactor, nlevels, fastTh):
+        self.o, self.L = o, o.L
+        self.nlevels = nlevels
+        self.h = self.L.orc_extractor_create(nfeatures, scaleFactor, nlevels, fastTh)
+        self.scale = np.zeros(nlevels, np.float32)
+        self.inv_scale = np.zeros(nlevels, np.float32)
+        self.quota = np.zeros(nlevels, np.int32)
+        self.umax = np.zeros(16, np.int32)
+        self.L.orc_extractor_tables(self.h, self.scale.ctypes.data, self.inv_scale.ctypes.data, self.quota.ctypes.data, self.umax.ctypes.data)
+
+    def __del__(self):
+        try:
+            self.L.orc_extractor_destroy(self.h)
+        except Exception:
+            pass
+
+    def __call__(self, image, keypoints=None, grid_2d=None, min_px_dist=20, FullDetect=True, num_featsneeded=0, cap=20000):
+        image = np.ascontiguousarray(image, np.uint8)
+        h, w = image.shape
+        n_in = 0 if keypoints is None else len(keypoints)
+        kin = None if n_in == 0 else np.ascontiguousarray(keypoints, KP)
+        rows = cols = 0
+        if grid_2d is not None:
+            assert grid_2d.dtype == np.int32 and grid_2d.flags.f_contiguous
+            rows, cols = grid_2d.shape
+        out_kp = np.zeros(cap, KP)
+        out_desc = np.zeros((cap, 32), np.uint8)
+        n = self.L.orc_extract(self.h, image.ctypes.data, w, h, image.strides[0], None if kin is None else kin.ctypes.data, n_in,
+                               None if grid_2d is None else grid_2d.ctypes.data, rows, cols, int(min_px_dist), 1 if FullDetect else 0,
+                               int(num_featsneeded), out_kp.ctypes.data, out_desc.ctypes.data, cap)
+        assert n >= 0, "oracle capacity"
+        return out_kp[:n].copy(), out_desc[:n].copy()
+
+    def level_dims(self, level):
+        w, h = ctypes.c_int(), ctypes.c_int()
+        self.L.orc_level_dims(self.h, level, ctypes.byref(w), ctypes.byref(h))
+        return w.value, h.value
+
+    def level_plane(self, level, blurred=False):
+        w, h = self.level_dims(level)
+        out = np.zeros((h + 32, w + 32), np.uint8)
+        self.L.orc_level_plane(self.h, level, 1 if blurred else 0, out.ctypes.data)
+        return out
+
+    def level_candidates(self, level):
+        n = self.L.orc_level_candidates(self.h, level, None, 0)
+        out = np.zeros(max(n, 1), KP)
+        self.L.orc_level_candidates(self.h, level, out.ctypes.data, n)
+        return out[:n]
+
+    def level_keypoints(self, level):
+        n = self.L.orc_level_keypoints(self.h, level, None, 0)
+        out = np.zeros(max(n, 1), KP)
+        self.L.orc_level_keypoints(self.h, level, out.ctypes.data, n)
+        return out[:n]
+
+    def ic_angle(self, plane, x, y, pad=16):
+        plane = np.ascontiguousarray(plane, np.uint8)
+        ph, pw = plane.shape
+        return float(self.L.orc_ic_angle(self.h, plane.ctypes.data, pw - 2 * pad, ph - 2 * pad, pad, float(x), float(y)))
+
+    def descriptor(self, plane, x, y, angle_deg, pad=16):
+        plane = np.ascontiguousarray(plane, np.uint8)
+        ph, pw = plane.shape
+        d = np.zeros(32, np.uint8)
+        self.L.orc_descriptor(self.h, plane.ctypes.data, pw - 2 * pad, ph - 2 * pad, pad, float(x), float(y), float(angle_deg), d.ctypes.data)
+        return d
+
+    def octree(self, cand_xyr, W, H, N):
+        """cand_xyr: (P,3) ints (x, y, response) relative to minBorder, in candidate order."""
+        P = len(cand_xyr)
+        kp = np.zeros(max(P, 1), KP)
+        kp["x"][:P] = cand_xyr[:, 0]
+        kp["y"][:P] = cand_xyr[:, 1]
+        kp["response"][:P] = cand_xyr[:, 2]
+        out = np.zeros(N + P + 8, KP)
+        n = self.L.orc_octree(self.h, kp.ctypes.data, P, 13, 13 + W, 13, 13 + H, N, out.ctypes.data, len(out))
+        r = out[:n]
+        return np.stack([r["x"], r["y"], r["response"]], 1).astype(np.int64)

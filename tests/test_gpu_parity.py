@@ -1,0 +1,201 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+Bit-exact bar: pyramid / blurred planes, FAST candidates (as sets), keypoints (x, y, size, angle, response, octave,
+class_id as raw bytes) and 256-bit descriptors."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _kp_bytes(kp):
+    return np.ascontiguousarray(kp).view(np.uint8).reshape(len(kp), -1)
+
+
+def _assert_same_features(kp_g, de_g, kp_o, de_o, what=""):
+    assert len(kp_g) == len(kp_o), "%s: %d keypoints on GPU, %d in oracle" % (what, len(kp_g), len(kp_o))
+    if len(kp_g) == 0:
+        return
+    bad = np.nonzero((_kp_bytes(kp_g) != _kp_bytes(kp_o)).any(1))[0]
+    assert len(bad) == 0, "%s: %d keypoints differ, first %d: gpu=%s oracle=%s" % (what, len(bad), bad[0], kp_g[bad[0]], kp_o[bad[0]])
+    badd = np.nonzero((de_g != de_o).any(1))[0]
+    assert len(badd) == 0, "%s: %d descriptors differ, first at %d" % (what, len(badd), badd[0])
+
+
+@pytest.fixture(scope="module")
+def frames(synth):
+    return [synth.make_frame(1000 + i) for i in range(3)]
+
+
+@pytest.mark.parametrize("fast_th", [20, 7])
+def test_stages_and_full_detect_640x512(uvo, oracle, frames, fast_th):
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, fast_th, max_width=640, max_height=512)
+    oe = oracle.extractor(1000, 1.2, 8, fast_th)
+    np.testing.assert_array_equal(ex.mvScaleFactor, oe.scale)
+    np.testing.assert_array_equal(ex.mvInvScaleFactor, oe.inv_scale)
+    np.testing.assert_array_equal(ex.mnFeaturesPerLevel, oe.quota)
+    np.testing.assert_array_equal(ex.umax, oe.umax)
+    for fi, img in enumerate(frames):
+        kp_g, de_g = ex(img)
+        kp_o, de_o = oe(img)
+        for l in range(8):
+            assert ex.level_dims(l) == oe.level_dims(l)
+            np.testing.assert_array_equal(ex.read_plane(l), oe.level_plane(l), err_msg="pyramid level %d frame %d" % (l, fi))
+            c_g = ex.read_candidates(l)
+            c_o = oe.level_candidates(l)
+            set_g = sorted(map(tuple, c_g.tolist()))
+            set_o = sorted(zip(c_o["x"].astype(int).tolist(), c_o["y"].astype(int).tolist(), c_o["response"].astype(int).tolist()))
+            assert set_g == set_o, "FAST candidates level %d frame %d: %d vs %d" % (l, fi, len(set_g), len(set_o))
+            # the oracle blurs only levels that kept keypoints; compare the interior + the 2-px ring the descriptor can reach
+            bo = oe.level_plane(l, blurred=True)
+            bg = ex.read_plane(l, blurred=True)
+            if (kp_o["octave"] == l).any():
+                np.testing.assert_array_equal(bg[14:-14, 14:-14], bo[14:-14, 14:-14], err_msg="blurred level %d frame %d" % (l, fi))
+        _assert_same_features(kp_g, de_g, kp_o, de_o, "frame %d fastTh %d" % (fi, fast_th))
+    ex.close()
+
+
+def test_batch_equals_single(uvo, oracle, synth):
+    imgs = synth.make_batch(6, 640, 512, seed0=2000)
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=640, max_height=512, max_batch=6)
+    oe = oracle.extractor(1000, 1.2, 8, 20)
+    res = ex.extract_batch(imgs)
+    for i, (kp_g, de_g) in enumerate(res):
+        kp_o, de_o = oe(imgs[i])
+        _assert_same_features(kp_g, de_g, kp_o, de_o, "batch frame %d" % i)
+    ex.close()
+
+
+@pytest.mark.parametrize("shape,nfeat,th", [((480, 752), 1000, 7), ((376, 1241), 1500, 12), ((600, 420), 500, 20), ((96, 128), 300, 10)])
+def test_other_resolutions(uvo, oracle, synth, shape, nfeat, th):
+    h, w = shape
+    img = synth.make_frame(77, w, h, n_shapes=max(40, w * h // 800))
+    nlev = 8 if min(h, w) >= 300 else 3
+    ex = uvo.ORBextractor(nfeat, 1.2, nlev, 0, th, max_width=w, max_height=h)
+    oe = oracle.extractor(nfeat, 1.2, nlev, th)
+    kp_g, de_g = ex(img)
+    kp_o, de_o = oe(img)
+    _assert_same_features(kp_g, de_g, kp_o, de_o, "%dx%d" % (w, h))
+    ex.close()
+
+
+def test_degenerate_images(uvo, oracle):
+    ex = uvo.ORBextractor(500, 1.2, 8, 0, 20, max_width=640, max_height=512)
+    oe = oracle.extractor(500, 1.2, 8, 20)
+    rng = np.random.default_rng(5)
+    flat = np.full((512, 640), 128, np.uint8)
+    noise = rng.integers(0, 256, (512, 640), dtype=np.uint8)            # corner everywhere: stresses candidate capacity + NMS ties
+    checker = ((np.indices((512, 640)).sum(0) // 2) % 2 * 255).astype(np.uint8)
+    low = (rng.integers(0, 12, (512, 640)) + 100).astype(np.uint8)     # only the threshold-7 fallback can fire
+    for name, img in (("flat", flat), ("noise", noise), ("checker", checker), ("lowcontrast", low)):
+        kp_g, de_g = ex(img)
+        kp_o, de_o = oe(img)
+        _assert_same_features(kp_g, de_g, kp_o, de_o, name)
+    ex.close()
+
+
+def test_topup_mode(uvo, oracle, frames):
+    """FullDetect=false: caller keypoints pass through level 0, occupancy grid filters and is mutated (src/ORBextractor.cc:872-909)."""
+    img = frames[0]
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=640, max_height=512, max_input_keypoints=600)
+    oe = oracle.extractor(1000, 1.2, 8, 20)
+    rng = np.random.default_rng(11)
+    min_px = 20
+    rows, cols = 512 // min_px + 2, 640 // min_px + 2
+    for n_in, need in ((0, 1000), (300, 700), (550, 450), (5, 40)):
+        kin = np.zeros(n_in, uvo.KEYPOINT_DTYPE)
+        kin["x"] = rng.uniform(20, 619, n_in).astype(np.float32)
+        kin["y"] = rng.uniform(20, 491, n_in).astype(np.float32)
+        kin["size"], kin["angle"], kin["response"], kin["octave"], kin["class_id"] = 31, -1, rng.uniform(0, 99, n_in), 0, np.arange(n_in)
+        grid = np.zeros((rows, cols), np.int32, order="F")
+        for k in kin:
+            grid[int(k["y"] / min_px), int(k["x"] / min_px)] += 1
+        g_gpu, g_orc = grid.copy(order="F"), grid.copy(order="F")
+        kp_g, de_g = ex(img, kin.copy(), g_gpu, min_px, False, need)
+        kp_o, de_o = oe(img, kin.copy(), g_orc, min_px, False, need)
+        _assert_same_features(kp_g, de_g, kp_o, de_o, "topup n_in=%d need=%d" % (n_in, need))
+        np.testing.assert_array_equal(g_gpu, g_orc)
+    ex.close()
+
+
+def test_hamming_knn2_and_matrix(uvo, oracle):
+    rng = np.random.default_rng(3)
+    m = uvo.ORBmatcher(0.8, max_query=2048, max_train=2048)
+    for nq, nt in ((1000, 1000), (1, 1), (257, 3), (5, 0), (0, 7), (64, 2000)):
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        if nq and nt > 4:
+            t[: min(nt, nq) // 2] = q[: min(nt, nq) // 2]       # exact matches
+            t[1] = t[0]                                         # duplicated train rows: tie must keep the lower index
+            q[-1] = 0
+            t[-1] = 255                                         # distance 256
+        idx0, d0, idx1, d1 = m.knn2(q, t)
+        o = oracle.knn2(q, t)
+        np.testing.assert_array_equal(idx0, o[0])
+        np.testing.assert_array_equal(idx1, o[2])
+        np.testing.assert_array_equal(d0.astype(np.int32), np.where(o[0] < 0, 0xFFFF, o[1]))
+        np.testing.assert_array_equal(d1.astype(np.int32), np.where(o[2] < 0, 0xFFFF, o[3]))
+        if nq and nt:
+            dm = m.distance_matrix(q, t)
+            ref = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
+            np.testing.assert_array_equal(dm, ref)
+    # masked
+    q = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (200, 32), dtype=np.uint8)
+    mask = (rng.random((300, 200)) < 0.3).astype(np.uint8)
+    mask[7] = 0
+    mask[8] = 0
+    mask[8, 5] = 1
+    idx0, d0, idx1, d1 = m.knn2(q, t, mask)
+    o = oracle.knn2(q, t, mask)
+    np.testing.assert_array_equal(idx0, o[0])
+    np.testing.assert_array_equal(idx1, o[2])
+    m.close()
+
+
+def test_extract_then_match_consecutive_frames(uvo, oracle, synth):
+    a = synth.make_frame(4242)
+    b = synth.warp_frame(a, 1)
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=640, max_height=512, max_batch=2)
+    (kp_a, de_a), (kp_b, de_b) = ex.extract_batch(np.stack([a, b]))
+    m = uvo.ORBmatcher(0.8)
+    got = m.ratio_matching(de_a, de_b, 0.8)
+    o = oracle.knn2(de_a, de_b)
+    ok = (o[2] >= 0) & (o[1].astype(np.float64) <= o[3].astype(np.float64) * 0.8)
+    ref = np.stack([np.nonzero(ok)[0], o[0][ok], o[1][ok]], 1)
+    np.testing.assert_array_equal(got, ref)
+    assert len(got) > 100  # the warp is small: most features must find their partner
+    ex.close()
+    m.close()
+
+
+def test_search_by_projection(uvo, oracle, synth):
+    rng = np.random.default_rng(9)
+    img = synth.make_frame(31337, 752, 480)
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 7, max_width=752, max_height=480)
+    kp, de = ex(img)
+    n = len(kp)
+    # synthetic local map: 5000 points, 40 % true correspondences with ~6 % bit flips
+    M = 5000
+    src = rng.integers(0, n, M)
+    true = rng.random(M) < 0.4
+    mp_desc = rng.integers(0, 256, (M, 32), dtype=np.uint8)
+    flips = (rng.random((M, 256)) < 0.06)
+    noisy = np.packbits(np.unpackbits(de[src], axis=1) ^ flips, axis=1)
+    mp_desc[true] = noisy[true]
+    px = (kp["x"][src] + rng.normal(0, 1.5, M)).astype(np.float32)
+    py = (kp["y"][src] + rng.normal(0, 1.5, M)).astype(np.float32)
+    level = np.clip(kp["octave"][src] + rng.integers(-1, 2, M), 0, 7).astype(np.int32)
+    vc = np.where(rng.random(M) < 0.5, 0.999, 0.9).astype(np.float32)
+    inview = (rng.random(M) < 0.9).astype(np.uint8)
+    m = uvo.ORBmatcher(0.8, max_query=4096, max_map_points=8192)
+    for th in (1.0, 5.0):
+        a_g = np.full(n, -1, np.int32)
+        a_g[rng.integers(0, n, 30)] = 123456  # some keypoints already hold a map point
+        a_o = a_g.copy()
+        nm_g = m.SearchByProjection(kp, de, (0, 0, 752, 480), a_g, px, py, level, vc, inview, mp_desc, ex.mvScaleFactor, th)
+        nm_o = oracle.search_by_projection(kp, de, (0, 0, 752, 480), a_o, px, py, level, vc, inview, mp_desc, ex.mvScaleFactor, th, 0.8)
+        assert nm_g == nm_o
+        np.testing.assert_array_equal(a_g, a_o)
+        assert nm_g > 300
+    ex.close()
+    m.close()

@@ -1,0 +1,325 @@
+"""uvo -- MI355X-native ORB feature front-end (extract + match), Python plumbing over the C ABI.
+
+The product is `libuvo.so` (hand-written HIP for gfx950 behind include/uvo/uvo.h).  This module only loads it with
+ctypes and mirrors the reference's two entry classes (USLAM::ORBextractor, include/ORBextractor.h:47-95;
+USLAM::ORBmatcher, include/ORBmatcher.h:41-88) so the parity tests and bench.py read like calls into the
+reference.  There is no CPU fallback: importing fails loudly when the library is missing, and creating an
+extractor / matcher fails when no HIP device is usable.
+
+The package directory is not a valid Python identifier; import it with
+    importlib.import_module("u-vip-slam_amd")
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuvo.so")
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"),
+                           ("class_id", "<i4")])
+assert KEYPOINT_DTYPE.itemsize == 28
+
+UVO_OK, UVO_E_BADARG, UVO_E_NODEVICE, UVO_E_HIP, UVO_E_CAPACITY, UVO_E_UNSUPPORTED, UVO_E_NOMEM = 0, -1, -2, -3, -4, -5, -6
+
+# every symbol include/uvo/uvo.h declares
+ABI_SYMBOLS = [
+    "uvo_extractor_create", "uvo_extractor_destroy", "uvo_extractor_levels", "uvo_extractor_scale_factor", "uvo_extractor_tables",
+    "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_extractor_synchronize", "uvo_extractor_level_dims",
+    "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
+    "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
+    "uvo_hamming_matrix", "uvo_search_by_projection", "uvo_last_error", "uvo_device_info",
+]
+
+
+class UvoError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__("%s failed with code %d: %s" % (where, code, last_error()))
+
+
+class ExtractorCfg(ctypes.Structure):
+    _fields_ = [("nfeatures", ctypes.c_int32), ("scale_factor", ctypes.c_float), ("nlevels", ctypes.c_int32), ("score_type", ctypes.c_int32),
+                ("fast_th", ctypes.c_int32), ("max_width", ctypes.c_int32), ("max_height", ctypes.c_int32), ("max_batch", ctypes.c_int32),
+                ("max_input_keypoints", ctypes.c_int32), ("device", ctypes.c_int32)]
+
+
+class MatcherCfg(ctypes.Structure):
+    _fields_ = [("max_query", ctypes.c_int32), ("max_train", ctypes.c_int32), ("max_batch", ctypes.c_int32), ("max_map_points", ctypes.c_int32),
+                ("device", ctypes.c_int32)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libuvo.so not built (%s); run `python u-vip-slam_amd/build.py` -- there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci, cf, cl = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_ssize_t
+    lib.uvo_last_error.restype = ctypes.c_char_p
+    lib.uvo_device_info.argtypes = [ci, ctypes.c_char_p, ci]
+    lib.uvo_extractor_create.argtypes = [ctypes.POINTER(ExtractorCfg), ctypes.POINTER(vp)]
+    lib.uvo_extractor_destroy.argtypes = [vp]
+    lib.uvo_extractor_destroy.restype = None
+    lib.uvo_extractor_levels.argtypes = [vp]
+    lib.uvo_extractor_scale_factor.argtypes = [vp]
+    lib.uvo_extractor_scale_factor.restype = cf
+    lib.uvo_extractor_tables.argtypes = [vp, vp, vp, vp, vp]
+    lib.uvo_extract.argtypes = [vp, vp, ci, ci, cl, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp]
+    lib.uvo_extract_batch.argtypes = [vp, ci, vp, ci, ci, cl, cl, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
+    lib.uvo_extract_batch_device.argtypes = [vp, ci, vp, ci, ci, cl, cl, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
+    lib.uvo_extractor_synchronize.argtypes = [vp]
+    lib.uvo_extractor_level_dims.argtypes = [vp, ci, vp, vp]
+    lib.uvo_extractor_read_plane.argtypes = [vp, ci, ci, ci, vp]
+    lib.uvo_extractor_read_candidates.argtypes = [vp, ci, ci, vp, ci, vp]
+    lib.uvo_extractor_profile.argtypes = [vp, ci]
+    lib.uvo_extractor_kernel_times.argtypes = [vp, ctypes.c_char_p, ci, vp, vp, ci, vp]
+    lib.uvo_matcher_create.argtypes = [ctypes.POINTER(MatcherCfg), ctypes.POINTER(vp)]
+    lib.uvo_matcher_destroy.argtypes = [vp]
+    lib.uvo_matcher_destroy.restype = None
+    lib.uvo_matcher_synchronize.argtypes = [vp]
+    lib.uvo_hamming_knn2.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, vp, vp]
+    lib.uvo_hamming_knn2_batch_device.argtypes = [vp, ci, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp]
+    lib.uvo_hamming_matrix.argtypes = [vp, vp, ci, vp, ci, vp]
+    lib.uvo_search_by_projection.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp]
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    return lib.uvo_last_error().decode("utf-8", "replace")
+
+
+def device_info(device=0):
+    buf = ctypes.create_string_buffer(256)
+    rc = lib.uvo_device_info(device, buf, 256)
+    if rc:
+        raise UvoError(rc, "uvo_device_info")
+    return buf.value.decode()
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class ORBextractor:
+    """Mirror of USLAM::ORBextractor (include/ORBextractor.h:47-95).
+
+    ctor args follow the reference (nfeatures, scaleFactor, nlevels, scoreType, fastTh); the extra keyword
+    arguments size the device scratch the handle owns.
+    """
+    HARRIS_SCORE, FAST_SCORE = 0, 1
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, scoreType=0, fastTh=7, *, max_width=640, max_height=512, max_batch=1,
+                 max_input_keypoints=0, device=0):
+        self.cfg = ExtractorCfg(nfeatures, scaleFactor, nlevels, scoreType, fastTh, max_width, max_height, max_batch, max_input_keypoints,
+                                device)
+        self._h = ctypes.c_void_p()
+        rc = lib.uvo_extractor_create(ctypes.byref(self.cfg), ctypes.byref(self._h))
+        if rc:
+            self._h = None
+            raise UvoError(rc, "uvo_extractor_create")
+        scale = np.zeros(nlevels, np.float32)
+        inv = np.zeros(nlevels, np.float32)
+        quota = np.zeros(nlevels, np.int32)
+        umax = np.zeros(16, np.int32)
+        lib.uvo_extractor_tables(self._h, _ptr(scale), _ptr(inv), _ptr(quota), _ptr(umax))
+        self.mvScaleFactor, self.mvInvScaleFactor, self.mnFeaturesPerLevel, self.umax = scale, inv, quota, umax
+        # upper bound of keypoints per frame: sum(quota + 4) + pass-through keypoints
+        self.cap = int(quota.sum()) + 4 * nlevels + max_input_keypoints
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.uvo_extractor_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def GetLevels(self):
+        return lib.uvo_extractor_levels(self._h)
+
+    def GetScaleFactor(self):
+        return lib.uvo_extractor_scale_factor(self._h)
+
+    def __call__(self, image, keypoints=None, grid_2d=None, min_px_dist=20, FullDetect=True, num_featsneeded=0):
+        """operator()(image, mask, keypoints, descriptors, grid_2d, min_px_dist, FullDetect, num_featsneeded).
+
+        image: HxW uint8.  keypoints: KEYPOINT_DTYPE array (the reference's in/out vector on entry) or None.
+        grid_2d: int32 array of shape (rows, cols) in Fortran (column-major) order, mutated in place like the
+        reference's Eigen::MatrixXi&.  Returns (keypoints, descriptors).
+        """
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        h, w = image.shape
+        n_in = 0 if keypoints is None else len(keypoints)
+        kin = None if n_in == 0 else np.ascontiguousarray(keypoints, dtype=KEYPOINT_DTYPE)
+        rows = cols = 0
+        if grid_2d is not None:
+            if not (grid_2d.dtype == np.int32 and grid_2d.flags.f_contiguous):
+                raise ValueError("grid_2d must be int32 and column-major (np.asfortranarray)")
+            rows, cols = grid_2d.shape
+        out_kp = np.zeros(self.cap, KEYPOINT_DTYPE)
+        out_desc = np.zeros((self.cap, 32), np.uint8)
+        n_out = ctypes.c_int(0)
+        rc = lib.uvo_extract(self._h, image.ctypes.data, w, h, image.strides[0], _ptr(kin), n_in, _ptr(grid_2d), rows, cols, int(min_px_dist),
+                             1 if FullDetect else 0, int(num_featsneeded), out_kp.ctypes.data, out_desc.ctypes.data, self.cap,
+                             ctypes.byref(n_out))
+        if rc:
+            raise UvoError(rc, "uvo_extract")
+        n = n_out.value
+        return out_kp[:n].copy(), out_desc[:n].copy()
+
+    def extract_batch(self, images):
+        """FullDetect extraction of a (B, H, W) uint8 stack; returns list of (keypoints, descriptors)."""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        b, h, w = images.shape
+        out_kp = np.zeros((b, self.cap), KEYPOINT_DTYPE)
+        out_desc = np.zeros((b, self.cap, 32), np.uint8)
+        n_out = np.zeros(b, np.int32)
+        rc = lib.uvo_extract_batch(self._h, b, images.ctypes.data, w, h, images.strides[1], images.strides[0], None, None, None, 0, 0, 0, 1,
+                                   None, out_kp.ctypes.data, out_desc.ctypes.data, self.cap, n_out.ctypes.data)
+        if rc:
+            raise UvoError(rc, "uvo_extract_batch")
+        return [(out_kp[i, :n_out[i]].copy(), out_desc[i, :n_out[i]].copy()) for i in range(b)]
+
+    def extract_batch_device(self, d_imgs, batch, width, height, d_out_kp, d_out_desc, d_n_out, cap=None):
+        """HBM-resident FullDetect extraction; all arguments are integer device addresses.  Asynchronous."""
+        rc = lib.uvo_extract_batch_device(self._h, batch, d_imgs, width, height, width, width * height, None, None, None, 0, 0, 0, 1, None,
+                                          d_out_kp, d_out_desc, cap or self.cap, d_n_out)
+        if rc:
+            raise UvoError(rc, "uvo_extract_batch_device")
+
+    def synchronize(self):
+        rc = lib.uvo_extractor_synchronize(self._h)
+        if rc:
+            raise UvoError(rc, "uvo_extractor_synchronize")
+
+    # ---- stage taps used by the parity tests ----
+    def level_dims(self, level):
+        w, h = ctypes.c_int(), ctypes.c_int()
+        rc = lib.uvo_extractor_level_dims(self._h, level, ctypes.byref(w), ctypes.byref(h))
+        if rc:
+            raise UvoError(rc, "uvo_extractor_level_dims")
+        return w.value, h.value
+
+    def read_plane(self, level, blurred=False, frame=0):
+        w, h = self.level_dims(level)
+        out = np.zeros((h + 32, w + 32), np.uint8)
+        rc = lib.uvo_extractor_read_plane(self._h, frame, level, 1 if blurred else 0, out.ctypes.data)
+        if rc:
+            raise UvoError(rc, "uvo_extractor_read_plane")
+        return out
+
+    def read_candidates(self, level, frame=0, cap=1 << 20):
+        buf = np.zeros((cap, 3), np.int32)
+        n = ctypes.c_int()
+        rc = lib.uvo_extractor_read_candidates(self._h, frame, level, buf.ctypes.data, cap, ctypes.byref(n))
+        if rc:
+            raise UvoError(rc, "uvo_extractor_read_candidates")
+        return buf[:min(n.value, cap)].copy()
+
+    def profile(self, enable=True):
+        lib.uvo_extractor_profile(self._h, 1 if enable else 0)
+
+    def kernel_times(self):
+        names = ctypes.create_string_buffer(4096)
+        ms = np.zeros(64, np.float32)
+        launches = np.zeros(64, np.int32)
+        n = ctypes.c_int()
+        rc = lib.uvo_extractor_kernel_times(self._h, names, 4096, ms.ctypes.data, launches.ctypes.data, 64, ctypes.byref(n))
+        if rc:
+            raise UvoError(rc, "uvo_extractor_kernel_times")
+        nm = names.value.decode().split("\n")[:n.value]
+        return {nm[i]: (float(ms[i]), int(launches[i])) for i in range(n.value)}
+
+
+class ORBmatcher:
+    """Mirror of the USLAM::ORBmatcher surface on the hot path (include/ORBmatcher.h:41-88)."""
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, *, max_query=4096, max_train=4096, max_batch=1, max_map_points=8192, device=0):
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+        self.cfg = MatcherCfg(max_query, max_train, max_batch, max_map_points, device)
+        self._h = ctypes.c_void_p()
+        rc = lib.uvo_matcher_create(ctypes.byref(self.cfg), ctypes.byref(self._h))
+        if rc:
+            self._h = None
+            raise UvoError(rc, "uvo_matcher_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.uvo_matcher_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def knn2(self, q, t, mask=None):
+        """All-pairs knn-2 (include/utils.h:100-101).  Returns idx0, d0, idx1, d1."""
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        nq, nt = len(q), len(t)
+        idx0 = np.full(nq, -1, np.int32)
+        idx1 = np.full(nq, -1, np.int32)
+        d0 = np.full(nq, 0xFFFF, np.uint16)
+        d1 = np.full(nq, 0xFFFF, np.uint16)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        rc = lib.uvo_hamming_knn2(self._h, _ptr(q), nq, _ptr(t), nt, _ptr(m), _ptr(idx0), _ptr(d0), _ptr(idx1), _ptr(d1))
+        if rc:
+            raise UvoError(rc, "uvo_hamming_knn2")
+        return idx0, d0, idx1, d1
+
+    def ratio_matching(self, q, t, ratio, mask=None):
+        """Utils::ratioMatching (include/utils.h:81-111): (queryIdx, trainIdx, distance) of accepted matches."""
+        if len(q) == 0 or len(t) == 0:
+            return np.zeros((0, 3), np.int32)
+        idx0, d0, idx1, d1 = self.knn2(q, t, mask)
+        ok = (idx1 >= 0) & (d0.astype(np.float32).astype(np.float64) <= d1.astype(np.float32).astype(np.float64) * float(ratio))
+        qi = np.nonzero(ok)[0].astype(np.int32)
+        return np.stack([qi, idx0[qi], d0[qi].astype(np.int32)], 1)
+
+    def distance_matrix(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        out = np.zeros((len(q), len(t)), np.uint16)
+        rc = lib.uvo_hamming_matrix(self._h, _ptr(q), len(q), _ptr(t), len(t), _ptr(out))
+        if rc:
+            raise UvoError(rc, "uvo_hamming_matrix")
+        return out
+
+    def knn2_batch_device(self, pairs, d_q, d_nq, q_stride, d_t, d_nt, t_stride, d_idx0, d_d0, d_idx1, d_d1):
+        rc = lib.uvo_hamming_knn2_batch_device(self._h, pairs, d_q, d_nq, q_stride, d_t, d_nt, t_stride, d_idx0, d_d0, d_idx1, d_d1)
+        if rc:
+            raise UvoError(rc, "uvo_hamming_knn2_batch_device")
+
+    def synchronize(self):
+        rc = lib.uvo_matcher_synchronize(self._h)
+        if rc:
+            raise UvoError(rc, "uvo_matcher_synchronize")
+
+    def SearchByProjection(self, kp, desc, bounds, assigned, proj_x, proj_y, level, view_cos, in_view, mp_desc, scale_factors, th=1.0):
+        """SearchByProjection(FrameKTL&, vector<MapPoint*>&, th) (src/ORBmatcher.cc:49-125).
+
+        kp/desc: frame keypoints (KEYPOINT_DTYPE) and descriptors; bounds = (mnMinX, mnMinY, mnMaxX, mnMaxY);
+        assigned: int32[n] in/out (-1 = F.mvpMapPoints[i] is NULL).  Returns nmatches.
+        """
+        kp = np.ascontiguousarray(kp, KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        px, py = np.ascontiguousarray(proj_x, np.float32), np.ascontiguousarray(proj_y, np.float32)
+        lv, vc = np.ascontiguousarray(level, np.int32), np.ascontiguousarray(view_cos, np.float32)
+        iv, md = np.ascontiguousarray(in_view, np.uint8), np.ascontiguousarray(mp_desc, np.uint8)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        assert assigned.dtype == np.int32 and assigned.flags.c_contiguous
+        nm = ctypes.c_int()
+        rc = lib.uvo_search_by_projection(self._h, _ptr(kp), len(kp), _ptr(desc), int(bounds[0]), int(bounds[1]), int(bounds[2]), int(bounds[3]),
+                                          _ptr(assigned), len(px), _ptr(px), _ptr(py), _ptr(lv), _ptr(vc), _ptr(iv), _ptr(md), _ptr(sf), len(sf),
+                                          float(th), self.mfNNratio, ctypes.byref(nm))
+        if rc:
+            raise UvoError(rc, "uvo_search_by_projection")
+        return nm.value
+
+
+def DescriptorDistance(a, b):
+    """ORBmatcher::DescriptorDistance for one pair (src/ORBmatcher.cc:1794-1810); host convenience for scripts.
+    Bulk distances go through ORBmatcher.knn2 / distance_matrix on the GPU."""
+    return int(np.unpackbits(np.bitwise_xor(np.asarray(a, np.uint8), np.asarray(b, np.uint8))).sum())

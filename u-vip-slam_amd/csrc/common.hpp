@@ -2,7 +2,7 @@
 // wrappers.  Data layout in HBM (see DESIGN.md "Data layout"):
 //   pyramid  : [frame][level] padded u8 planes, row pitch = (w+32) rounded up to 64 B, ROI origin at (16,16)
 //   blurred  : same geometry, 7x7 sigma-2 blurred interior + un-blurred reflected pad ring
-//   cand     : [frame][level][cap_l] 8-byte FAST candidates {x | y<<16, score}, count in cand_count[frame][level]
+//   cand     : [frame][level][cap_l] FAST candidates, SoA words {x | y<<16} and {score}, count in cand_count[frame][level]
 //   sel      : [frame][level][quota_l+4] quad-tree survivors in the reference's list order
 //   flist    : [frame][flist_cap] final (level, x, y, aux) slots in output order
 #pragma once
@@ -16,7 +16,7 @@ namespace uvo {
 constexpr int kMaxLevels = 16;
 constexpr int kPad = 16;         // EDGE_THRESHOLD, src/ORBextractor.cc:78
 constexpr int kMinBorder = 13;   // EDGE_THRESHOLD-3, src/ORBextractor.cc:756
-constexpr int kMaxOctN = 4000;   // largest per-level quota the quad-tree kernel is sized for
+constexpr int kMaxOctN = 2000;   // largest per-level quota the quad-tree kernel is sized for (LDS budget)
 
 struct LevelGeom {
   int w, h;            // ROI size
@@ -35,7 +35,8 @@ struct LevelGeom {
   float hX;
   float scale;         // mvScaleFactor[level]
   float patch_size;    // (float)(int)(31*scale)
-  int tab_off;         // offset of this level's resize tables (level >= 1)
+  int xtab_off;        // element offset of this level's x resize tables (level >= 1), in dst-pixel units
+  int ytab_off;        // same for the y tables
 };
 
 struct CellDesc {  // one FAST cell (src/ORBextractor.cc:773-790)
@@ -56,10 +57,8 @@ struct Geom {
   LevelGeom lv[kMaxLevels];
 };
 
-struct Cand {
-  uint32_t xy;     // x | y << 16, relative to (minBorder, minBorder)
-  uint32_t score;  // FAST score (cornerScore), 1..254
-};
+// FAST candidates and quad-tree survivors are SoA: xy word = x | y << 16 relative to (minBorder, minBorder),
+// score word = FAST score (cornerScore), 1..254.
 
 struct FinalSlot {  // 16 B
   float x, y;       // level coordinates
@@ -68,6 +67,7 @@ struct FinalSlot {  // 16 B
 };
 
 const char* hip_err_set(hipError_t e, const char* what);
+int fail(int code, const char* msg);  // records msg for uvo_last_error() and returns code
 
 #define UVO_HIP_CHECK(expr)                                   \
   do {                                                        \
@@ -79,8 +79,6 @@ const char* hip_err_set(hipError_t e, const char* what);
   } while (0)
 
 // ---- kernel launch wrappers (defined in the .hip files) ----
-struct DevTables;  // device-resident constant tables, owned by the extractor
-
 void launch_pad_level0(hipStream_t s, const uint8_t* d_img, int w, int h, int64_t stride, int64_t frame_stride, uint8_t* d_pyr,
                        int64_t pyr_block, const LevelGeom& g0, int batch);
 void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const LevelGeom& src, const LevelGeom& dst, const int32_t* d_xofs,
@@ -88,12 +86,19 @@ void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const
 void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g, int4 taps,
                    int batch);
 void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const LevelGeom* d_lv, const CellDesc* d_cells, int total_cells,
-                       int fast_th, Cand* d_cand, int64_t cand_block, int32_t* d_cand_count, int nlevels, int batch);
-void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const Cand* d_cand, int64_t cand_block, const int32_t* d_cand_count,
-                   uint32_t* d_pstate, Cand* d_sel, int32_t* d_sel_count, int batch);
-void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const Cand* d_sel, const int32_t* d_sel_count,
+                       int fast_th, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, int nlevels,
+                       int batch);
+void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_xy, const uint32_t* d_cand_sc,
+                   int64_t cand_block, const int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
+                   int32_t* d_sel_count, int batch);
+void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_sel_xy, const uint32_t* d_sel_sc,
+                     const int32_t* d_sel_count,
                      const uvo_keypoint* d_in_kp, const int32_t* d_n_in, int in_cap, int32_t* d_grid, int grid_rows, int grid_cols,
                      int min_px_dist, int full_detect, const int32_t* d_nfn, FinalSlot* d_flist, int32_t* d_n_final, int batch);
+void launch_knn2(hipStream_t s, int pairs, int max_q, const uint8_t* d_q, const int32_t* d_nq, int nq_fixed, int q_stride, const uint8_t* d_t,
+                 const int32_t* d_nt, int nt_fixed, int t_stride, const uint8_t* d_mask, int out_stride, int32_t* d_idx0, uint16_t* d_d0,
+                 int32_t* d_idx1, uint16_t* d_d1);
+void launch_matrix(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, uint16_t* d_dist);
 void launch_describe(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, const uint8_t* d_blur, int64_t pyr_block,
                      const FinalSlot* d_flist, const int32_t* d_n_final, const uvo_keypoint* d_in_kp, int in_cap, const int8_t* d_pattern,
                      const int32_t* d_umax, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch);

@@ -1,0 +1,668 @@
+// Host side of the extractor: constructor tables, per-resolution geometry, device scratch, the launch sequence and
+// the C-ABI entry points of include/uvo/uvo.h that replace USLAM::ORBextractor (src/ORBextractor.cc).
+// No CPU fallback: every entry point needs a usable HIP device.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "uvo_math.hpp"
+
+namespace uvo {
+
+static thread_local char g_err[512] = "";
+const char* hip_err_set(hipError_t e, const char* what) {
+  snprintf(g_err, sizeof(g_err), "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+  return g_err;
+}
+int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+static const int8_t kPattern[1024] = {
+#include "rbrief_pattern.inc"
+};
+
+static inline int cv_round_host(float v) { return (int)lrintf(v); }
+static inline int cv_floor_host(float v) {
+  int i = (int)v;
+  return i - (i > v);
+}
+
+struct ProfRec {
+  const char* name;
+  hipEvent_t a, b;
+};
+
+}  // namespace uvo
+
+using namespace uvo;
+
+struct uvo_extractor {
+  uvo_extractor_cfg cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // constructor tables (src/ORBextractor.cc:463-511)
+  std::vector<float> scale, inv_scale;
+  std::vector<int> quota;
+  int umax[16];
+  int gtaps[4];
+  // current geometry
+  Geom geom;
+  bool have_geom = false;
+  std::vector<CellDesc> cells;
+  // capacities fixed at create time (from max_width x max_height)
+  int64_t cap_pyr_block = 0, cap_cand_block = 0;
+  int cap_cells = 0, cap_sel_block = 0, cap_flist = 0, cap_xtab = 0, cap_ytab = 0;
+  int last_batch = 0;
+  // device memory
+  uint8_t *d_pyr = nullptr, *d_blur = nullptr;
+  uint32_t *d_cand_xy = nullptr, *d_cand_sc = nullptr, *d_pstate = nullptr, *d_sel_xy = nullptr, *d_sel_sc = nullptr;
+  int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_n_final = nullptr;
+  FinalSlot* d_flist = nullptr;
+  LevelGeom* d_lv = nullptr;
+  CellDesc* d_cells = nullptr;
+  int32_t *d_xofs = nullptr, *d_yofs = nullptr;
+  int16_t *d_xalpha = nullptr, *d_ybeta = nullptr;
+  int8_t* d_pattern = nullptr;
+  int32_t* d_umax = nullptr;
+  // staging for the host-buffer entry points
+  uint8_t* d_imgs = nullptr;
+  uvo_keypoint *d_out_kp = nullptr, *d_in_kp = nullptr;
+  uint8_t* d_out_desc = nullptr;
+  int32_t *d_n_out = nullptr, *d_n_in = nullptr, *d_nfn = nullptr, *d_grid = nullptr;
+  size_t grid_bytes = 0;
+  // profiling
+  bool profile = false;
+  std::vector<ProfRec> prof;
+};
+
+namespace uvo {
+
+// ORBextractor::ORBextractor: src/ORBextractor.cc:458-512
+static void build_ctor_tables(uvo_extractor* h) {
+  const int nl = h->cfg.nlevels;
+  const double scaleFactor = (double)h->cfg.scale_factor;  // member is double (include/ORBextractor.h:79)
+  h->scale.assign(nl, 1.f);
+  h->inv_scale.assign(nl, 1.f);
+  for (int i = 1; i < nl; ++i) h->scale[i] = (float)(h->scale[i - 1] * scaleFactor);
+  const float invScaleFactor = (float)(1.0f / scaleFactor);
+  for (int i = 1; i < nl; ++i) h->inv_scale[i] = h->inv_scale[i - 1] * invScaleFactor;
+  h->quota.assign(nl, 0);
+  const float factor = (float)(1.0 / scaleFactor);
+  float nDesired = h->cfg.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nl));
+  int sum = 0;
+  for (int l = 0; l < nl - 1; ++l) {
+    h->quota[l] = cv_round_host(nDesired);
+    sum += h->quota[l];
+    nDesired *= factor;
+  }
+  h->quota[nl - 1] = std::max(h->cfg.nfeatures - sum, 0);
+  // umax (:494-511), HALF_PATCH_SIZE = 15
+  const int HP = 15;
+  int v, v0, vmax = cv_floor_host(HP * sqrtf(2.f) / 2 + 1);
+  int vmin = (int)ceilf(HP * sqrtf(2.f) / 2);
+  const double hp2 = HP * HP;
+  for (v = 0; v <= vmax; ++v) h->umax[v] = (int)lrint(sqrt(hp2 - v * v));
+  for (v = HP, v0 = 0; v >= vmin; --v) {
+    while (h->umax[v0] == h->umax[v0 + 1]) ++v0;
+    h->umax[v] = v0;
+    ++v0;
+  }
+  // Gaussian taps: cv::getGaussianKernel(7, 2, CV_32F) then convertTo(CV_32S, 256)
+  float cf[7];
+  double s = 0;
+  for (int i = 0; i < 7; ++i) {
+    double x = i - 3.0;
+    cf[i] = (float)std::exp(-0.5 / 4.0 * x * x);
+    s += cf[i];
+  }
+  s = 1. / s;
+  for (int i = 0; i < 4; ++i) h->gtaps[i] = cv_round_host((float)(cf[i] * s) * 256.f);
+}
+
+// Geometry of one resolution: pyramid sizes (:966-969), detection window and FAST cells (:755-790),
+// quad-tree roots (:1010-1012), scratch offsets.
+static int build_geom(const uvo_extractor* h, int width, int height, Geom& g, std::vector<CellDesc>& cells) {
+  const int nl = h->cfg.nlevels;
+  memset(&g, 0, sizeof(g));
+  g.width = width, g.height = height, g.nlevels = nl;
+  cells.clear();
+  int64_t off = 0, coff = 0;
+  int soff = 0, xt = 0, yt = 0;
+  for (int l = 0; l < nl; ++l) {
+    LevelGeom& L = g.lv[l];
+    L.w = cv_round_host((float)width * h->inv_scale[l]);
+    L.h = cv_round_host((float)height * h->inv_scale[l]);
+    if (L.w < 56 || L.h < 56 || L.w > 16384 || L.h > 16384) return fail(UVO_E_UNSUPPORTED, "pyramid level outside 56..16384 px");
+    L.pw = L.w + 2 * kPad, L.ph = L.h + 2 * kPad;
+    L.pitch = (L.pw + 63) / 64 * 64;
+    L.plane_off = off;
+    off += (int64_t)L.pitch * L.ph;
+    off = (off + 255) / 256 * 256;
+    L.bw = L.w - 2 * kMinBorder, L.bh = L.h - 2 * kMinBorder;
+    const float fw = (float)L.bw, fh = (float)L.bh;
+    L.nCols = (int)(fw / 30.f), L.nRows = (int)(fh / 30.f);
+    L.wCell = (int)ceilf(fw / L.nCols), L.hCell = (int)ceilf(fh / L.nRows);
+    L.cell_base = (int)cells.size();
+    const int maxBX = L.w - kMinBorder, maxBY = L.h - kMinBorder;
+    int cap = 0;
+    for (int i = 0; i < L.nRows; ++i) {
+      const int iniY = kMinBorder + i * L.hCell;
+      int maxY = iniY + L.hCell + 6;
+      if (iniY >= maxBY - 3) continue;
+      if (maxY > maxBY) maxY = maxBY;
+      for (int j = 0; j < L.nCols; ++j) {
+        const int iniX = kMinBorder + j * L.wCell;
+        int maxX = iniX + L.wCell + 6;
+        if (iniX >= maxBX - 6) continue;
+        if (maxX > maxBX) maxX = maxBX;
+        CellDesc c;
+        c.level = (int16_t)l;
+        c.x0 = (int16_t)iniX, c.y0 = (int16_t)iniY;
+        c.rw = (int16_t)(maxX - iniX), c.rh = (int16_t)(maxY - iniY);
+        c.ox = (int16_t)(j * L.wCell), c.oy = (int16_t)(i * L.hCell);
+        c.pad = 0;
+        if (c.rw > 66 || c.rh > 66) return fail(UVO_E_UNSUPPORTED, "FAST cell larger than 66 px");
+        const int iw = c.rw - 6, ih = c.rh - 6;
+        if (iw <= 0 || ih <= 0) continue;  // FAST on an ROI without interior finds nothing
+        cap += ((iw + 1) / 2) * ((ih + 1) / 2);
+        cells.push_back(c);
+      }
+    }
+    L.n_cells = (int)cells.size() - L.cell_base;
+    L.quota = h->quota[l];
+    if (L.quota > kMaxOctN) return fail(UVO_E_UNSUPPORTED, "per-level feature quota above the quad-tree kernel's capacity");
+    L.cand_cap = cap;
+    L.cand_off = coff;
+    coff += (cap + 63) / 64 * 64;
+    L.sel_cap = L.quota + 4;
+    L.sel_off = soff;
+    soff += L.sel_cap;
+    L.nIni = (int)roundf((float)L.bw / (float)L.bh);
+    if (L.nIni < 1 || L.nIni > 64) return fail(UVO_E_UNSUPPORTED, "image aspect ratio outside the quad-tree's range");
+    L.hX = (float)L.bw / (float)L.nIni;
+    L.scale = h->scale[l];
+    L.patch_size = (float)(int)(31 * h->scale[l]);
+    L.xtab_off = xt, L.ytab_off = yt;
+    if (l > 0) xt += L.w, yt += L.h;
+  }
+  g.total_cells = (int)cells.size();
+  g.pyr_block = off;
+  g.cand_block = coff;
+  g.sel_block = soff;
+  g.flist_cap = soff + h->cfg.max_input_keypoints;
+  return UVO_OK;
+}
+
+// cv::resize INTER_LINEAR coefficient tables exactly as resizeGeneric_ builds them:
+// fx = (float)((dx+0.5)*scale_x - 0.5), sx = floor(fx), weights saturate_cast<short>(w * 2048)
+static void build_resize_tables(const Geom& g, std::vector<int32_t>& xofs, std::vector<int16_t>& xalpha, std::vector<int32_t>& yofs,
+                                std::vector<int16_t>& ybeta) {
+  xofs.clear(), xalpha.clear(), yofs.clear(), ybeta.clear();
+  for (int l = 1; l < g.nlevels; ++l) {
+    const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h, dw = g.lv[l].w, dh = g.lv[l].h;
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    for (int dx = 0; dx < dw; ++dx) {
+      float fx = (float)((dx + 0.5) * scale_x - 0.5);
+      int sx = cv_floor_host(fx);
+      fx -= sx;
+      if (sx < 0) fx = 0, sx = 0;
+      if (sx >= sw - 1) fx = 0, sx = sw - 1;
+      xofs.push_back(sx);
+      xalpha.push_back((int16_t)cv_round_host((1.f - fx) * 2048.f));
+      xalpha.push_back((int16_t)cv_round_host(fx * 2048.f));
+    }
+    for (int dy = 0; dy < dh; ++dy) {
+      float fy = (float)((dy + 0.5) * scale_y - 0.5);
+      int sy = cv_floor_host(fy);
+      fy -= sy;
+      yofs.push_back(sy);
+      ybeta.push_back((int16_t)cv_round_host((1.f - fy) * 2048.f));
+      ybeta.push_back((int16_t)cv_round_host(fy * 2048.f));
+    }
+  }
+}
+
+template <class T>
+static int dev_alloc(T** p, size_t n) {
+  if (n == 0) n = 1;
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  if (e != hipSuccess) {
+    hip_err_set(e, "hipMalloc");
+    return e == hipErrorOutOfMemory ? UVO_E_NOMEM : UVO_E_HIP;
+  }
+  return UVO_OK;
+}
+
+static int set_geometry(uvo_extractor* h, int width, int height) {
+  if (h->have_geom && h->geom.width == width && h->geom.height == height) return UVO_OK;
+  Geom g;
+  std::vector<CellDesc> cells;
+  int rc = build_geom(h, width, height, g, cells);
+  if (rc) return rc;
+  if (g.pyr_block > h->cap_pyr_block || g.cand_block > h->cap_cand_block || g.total_cells > h->cap_cells || g.sel_block > h->cap_sel_block)
+    return fail(UVO_E_BADARG, "image larger than the handle was sized for");
+  std::vector<int32_t> xofs, yofs;
+  std::vector<int16_t> xalpha, ybeta;
+  build_resize_tables(g, xofs, xalpha, yofs, ybeta);
+  if ((int)xofs.size() > h->cap_xtab || (int)yofs.size() > h->cap_ytab) return fail(UVO_E_BADARG, "image larger than the handle was sized for");
+  // in-flight work may still read the old tables
+  UVO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  UVO_HIP_CHECK(hipMemcpy(h->d_lv, g.lv, sizeof(LevelGeom) * g.nlevels, hipMemcpyHostToDevice));
+  UVO_HIP_CHECK(hipMemcpy(h->d_cells, cells.data(), sizeof(CellDesc) * cells.size(), hipMemcpyHostToDevice));
+  if (!xofs.empty()) {
+    UVO_HIP_CHECK(hipMemcpy(h->d_xofs, xofs.data(), xofs.size() * 4, hipMemcpyHostToDevice));
+    UVO_HIP_CHECK(hipMemcpy(h->d_xalpha, xalpha.data(), xalpha.size() * 2, hipMemcpyHostToDevice));
+    UVO_HIP_CHECK(hipMemcpy(h->d_yofs, yofs.data(), yofs.size() * 4, hipMemcpyHostToDevice));
+    UVO_HIP_CHECK(hipMemcpy(h->d_ybeta, ybeta.data(), ybeta.size() * 2, hipMemcpyHostToDevice));
+  }
+  h->geom = g;
+  h->cells = cells;
+  h->have_geom = true;
+  return UVO_OK;
+}
+
+struct ProfScope {
+  uvo_extractor* h;
+  ProfRec r;
+  ProfScope(uvo_extractor* h_, const char* name) : h(h_) {
+    r.name = name;
+    r.a = r.b = nullptr;
+    if (h->profile) {
+      hipEventCreate(&r.a);
+      hipEventCreate(&r.b);
+      hipEventRecord(r.a, h->stream);
+    }
+  }
+  ~ProfScope() {
+    if (h->profile) {
+      hipEventRecord(r.b, h->stream);
+      h->prof.push_back(r);
+    }
+  }
+};
+
+static void prof_clear(uvo_extractor* h) {
+  for (auto& r : h->prof) {
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  h->prof.clear();
+}
+
+// The launch sequence of one batch (everything on h->stream, nothing synchronous).
+static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
+                            const uvo_keypoint* d_in_kp, const int32_t* d_n_in, int32_t* d_grid2d, int grid_rows, int grid_cols,
+                            int min_px_dist, int full_detect, const int32_t* d_nfn, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap,
+                            int32_t* d_n_out) {
+  if (!h || !d_imgs || !d_out_kp || !d_out_desc || !d_n_out) return fail(UVO_E_BADARG, "null pointer");
+  if (batch < 1 || batch > h->cfg.max_batch) return fail(UVO_E_BADARG, "batch outside 1..max_batch");
+  if (width < 1 || height < 1 || stride < width || cap < 1) return fail(UVO_E_BADARG, "bad image size / stride / cap");
+  if (!full_detect && (!d_grid2d || !d_nfn || min_px_dist < 1 || grid_rows < 1 || grid_cols < 1))
+    return fail(UVO_E_BADARG, "top-up mode needs grid2d, num_feats_needed and min_px_dist >= 1");
+  UVO_HIP_CHECK(hipSetDevice(h->device));
+  int rc = set_geometry(h, width, height);
+  if (rc) return rc;
+  const Geom& g = h->geom;
+  hipStream_t s = h->stream;
+  if (h->profile) prof_clear(h);
+  h->last_batch = batch;
+  UVO_HIP_CHECK(hipMemsetAsync(h->d_cand_count, 0, sizeof(int32_t) * batch * g.nlevels, s));
+  {
+    ProfScope p(h, "k_pad_level0");
+    launch_pad_level0(s, d_imgs, width, height, stride, frame_stride, h->d_pyr, g.pyr_block, g.lv[0], batch);
+  }
+  for (int l = 1; l < g.nlevels; ++l) {
+    ProfScope p(h, "k_resize_level");
+    launch_resize_level(s, h->d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_xofs + g.lv[l].xtab_off, h->d_xalpha + 2 * g.lv[l].xtab_off,
+                        h->d_yofs + g.lv[l].ytab_off, h->d_ybeta + 2 * g.lv[l].ytab_off, batch);
+  }
+  {
+    ProfScope p(h, "k_fast_cells");
+    launch_fast_cells(s, h->d_pyr, g.pyr_block, h->d_lv, h->d_cells, g.total_cells, h->cfg.fast_th, h->d_cand_xy, h->d_cand_sc, g.cand_block,
+                      h->d_cand_count, g.nlevels, batch);
+  }
+  {
+    ProfScope p(h, "k_gauss7");
+    launch_gauss7(s, h->d_pyr, h->d_blur, g.pyr_block, h->d_lv, g, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), batch);
+  }
+  {
+    ProfScope p(h, "k_octree");
+    launch_octree(s, h->d_lv, g, h->d_cand_xy, h->d_cand_sc, g.cand_block, h->d_cand_count, h->d_pstate, h->d_sel_xy, h->d_sel_sc,
+                  h->d_sel_count, batch);
+  }
+  {
+    ProfScope p(h, "k_assemble");
+    launch_assemble(s, h->d_lv, g, h->d_sel_xy, h->d_sel_sc, h->d_sel_count, d_in_kp, d_n_in, h->cfg.max_input_keypoints, d_grid2d, grid_rows,
+                    grid_cols, min_px_dist, full_detect, d_nfn, h->d_flist, h->d_n_final, batch);
+  }
+  {
+    ProfScope p(h, "k_describe");
+    launch_describe(s, h->d_lv, g, h->d_pyr, h->d_blur, g.pyr_block, h->d_flist, h->d_n_final, d_in_kp, h->cfg.max_input_keypoints,
+                    h->d_pattern, h->d_umax, d_out_kp, d_out_desc, cap, d_n_out, batch);
+  }
+  UVO_HIP_CHECK(hipGetLastError());
+  return UVO_OK;
+}
+
+}  // namespace uvo
+
+extern "C" {
+
+const char* uvo_last_error(void) { return uvo::g_err; }
+
+int uvo_device_info(int device, char* dst, int cap) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(UVO_E_NODEVICE, "no HIP device");
+  if (device < 0 || device >= n) return fail(UVO_E_BADARG, "device ordinal out of range");
+  hipDeviceProp_t p;
+  UVO_HIP_CHECK(hipGetDeviceProperties(&p, device));
+  snprintf(dst, cap, "uvo 0.1 %s %s CUs=%d", p.gcnArchName, p.name, p.multiProcessorCount);
+  return UVO_OK;
+}
+
+int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
+  if (!cfg || !out) return fail(UVO_E_BADARG, "null pointer");
+  *out = nullptr;
+  if (cfg->nfeatures < 1 || cfg->nlevels < 1 || cfg->nlevels > kMaxLevels || !(cfg->scale_factor > 1.0f) || cfg->fast_th < 0 ||
+      cfg->max_width < 1 || cfg->max_height < 1 || cfg->max_batch < 1 || cfg->max_input_keypoints < 0)
+    return fail(UVO_E_BADARG, "bad extractor configuration");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(UVO_E_NODEVICE, "no HIP device available (no CPU fallback exists)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(UVO_E_BADARG, "device ordinal out of range");
+  uvo_extractor* h = new uvo_extractor();
+  h->cfg = *cfg;
+  h->device = cfg->device;
+  build_ctor_tables(h);
+  Geom g;
+  std::vector<CellDesc> cells;
+  int rc = build_geom(h, cfg->max_width, cfg->max_height, g, cells);
+  if (rc) {
+    delete h;
+    return rc;
+  }
+  // capacities: computed at the maximum size, padded for the small non-monotonicities of the cell grid
+  h->cap_pyr_block = g.pyr_block;
+  h->cap_cand_block = g.cand_block + g.cand_block / 16 + 4096;
+  h->cap_cells = g.total_cells + g.total_cells / 8 + 64;
+  h->cap_sel_block = g.sel_block;
+  h->cap_flist = g.flist_cap;
+  h->cap_xtab = 0, h->cap_ytab = 0;
+  for (int l = 1; l < g.nlevels; ++l) h->cap_xtab += g.lv[l].w + 1, h->cap_ytab += g.lv[l].h + 1;
+  const size_t B = (size_t)cfg->max_batch;
+  hipError_t e = hipSetDevice(h->device);
+  if (e != hipSuccess) {
+    hip_err_set(e, "hipSetDevice");
+    delete h;
+    return UVO_E_NODEVICE;
+  }
+  e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    hip_err_set(e, "hipStreamCreate");
+    delete h;
+    return UVO_E_HIP;
+  }
+#define A(call)                    \
+  if ((rc = (call)) != UVO_OK) {   \
+    uvo_extractor_destroy(h);      \
+    return rc;                     \
+  }
+  A(dev_alloc(&h->d_pyr, B * h->cap_pyr_block));
+  A(dev_alloc(&h->d_blur, B * h->cap_pyr_block));
+  A(dev_alloc(&h->d_cand_xy, B * h->cap_cand_block));
+  A(dev_alloc(&h->d_cand_sc, B * h->cap_cand_block));
+  A(dev_alloc(&h->d_pstate, B * h->cap_cand_block));
+  A(dev_alloc(&h->d_sel_xy, B * h->cap_sel_block));
+  A(dev_alloc(&h->d_sel_sc, B * h->cap_sel_block));
+  A(dev_alloc(&h->d_cand_count, B * kMaxLevels));
+  A(dev_alloc(&h->d_sel_count, B * kMaxLevels));
+  A(dev_alloc(&h->d_n_final, B));
+  A(dev_alloc(&h->d_flist, B * h->cap_flist));
+  A(dev_alloc(&h->d_lv, (size_t)kMaxLevels));
+  A(dev_alloc(&h->d_cells, (size_t)h->cap_cells));
+  A(dev_alloc(&h->d_xofs, (size_t)h->cap_xtab));
+  A(dev_alloc(&h->d_xalpha, (size_t)2 * h->cap_xtab));
+  A(dev_alloc(&h->d_yofs, (size_t)h->cap_ytab));
+  A(dev_alloc(&h->d_ybeta, (size_t)2 * h->cap_ytab));
+  A(dev_alloc(&h->d_pattern, (size_t)1024));
+  A(dev_alloc(&h->d_umax, (size_t)16));
+  // staging for host-buffer calls
+  A(dev_alloc(&h->d_imgs, B * (size_t)cfg->max_width * cfg->max_height));
+  A(dev_alloc(&h->d_out_kp, B * h->cap_flist));
+  A(dev_alloc(&h->d_out_desc, B * h->cap_flist * 32));
+  A(dev_alloc(&h->d_n_out, B));
+  A(dev_alloc(&h->d_in_kp, B * std::max(cfg->max_input_keypoints, 1)));
+  A(dev_alloc(&h->d_n_in, B));
+  A(dev_alloc(&h->d_nfn, B));
+#undef A
+  if (hipMemcpy(h->d_pattern, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(h->d_umax, h->umax, 64, hipMemcpyHostToDevice) != hipSuccess) {
+    uvo_extractor_destroy(h);
+    return fail(UVO_E_HIP, "table upload failed");
+  }
+  *out = h;
+  return UVO_OK;
+}
+
+void uvo_extractor_destroy(uvo_extractor* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  prof_clear(h);
+  void* ptrs[] = {h->d_pyr,    h->d_blur,   h->d_cand_xy, h->d_cand_sc, h->d_pstate, h->d_sel_xy,  h->d_sel_sc,  h->d_cand_count, h->d_sel_count,
+                  h->d_n_final, h->d_flist, h->d_lv,      h->d_cells,   h->d_xofs,   h->d_xalpha,  h->d_yofs,    h->d_ybeta,      h->d_pattern,
+                  h->d_umax,   h->d_imgs,   h->d_out_kp,  h->d_out_desc, h->d_n_out, h->d_in_kp,   h->d_n_in,    h->d_nfn,        h->d_grid};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int uvo_extractor_levels(const uvo_extractor* h) { return h ? h->cfg.nlevels : UVO_E_BADARG; }
+float uvo_extractor_scale_factor(const uvo_extractor* h) { return h ? (float)(double)h->cfg.scale_factor : 0.f; }
+
+int uvo_extractor_tables(const uvo_extractor* h, float* scale, float* inv_scale, int32_t* quota, int32_t* umax16) {
+  if (!h) return fail(UVO_E_BADARG, "null handle");
+  for (int i = 0; i < h->cfg.nlevels; ++i) {
+    if (scale) scale[i] = h->scale[i];
+    if (inv_scale) inv_scale[i] = h->inv_scale[i];
+    if (quota) quota[i] = h->quota[i];
+  }
+  if (umax16)
+    for (int i = 0; i < 16; ++i) umax16[i] = h->umax[i];
+  return UVO_OK;
+}
+
+int uvo_extract_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, int width, int height, ptrdiff_t stride,
+                             ptrdiff_t frame_stride, const uvo_keypoint* d_in_kp, const int32_t* d_n_in, int32_t* d_grid2d, int grid_rows,
+                             int grid_cols, int min_px_dist, int full_detect, const int32_t* d_num_feats_needed, uvo_keypoint* d_out_kp,
+                             uint8_t* d_out_desc, int cap, int32_t* d_n_out) {
+  if (!h) return fail(UVO_E_BADARG, "null handle");
+  return run_batch_device(h, batch, d_imgs, width, height, stride, frame_stride, d_in_kp, d_n_in, d_grid2d, grid_rows, grid_cols, min_px_dist,
+                          full_detect, d_num_feats_needed, d_out_kp, d_out_desc, cap, d_n_out);
+}
+
+int uvo_extractor_synchronize(uvo_extractor* h) {
+  if (!h) return fail(UVO_E_BADARG, "null handle");
+  UVO_HIP_CHECK(hipSetDevice(h->device));
+  UVO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return UVO_OK;
+}
+
+int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
+                      const uvo_keypoint* in_kp, const int32_t* n_in, int32_t* grid2d, int grid_rows, int grid_cols, int min_px_dist,
+                      int full_detect, const int32_t* num_feats_needed, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out) {
+  if (!h || !imgs || !out_kp || !out_desc || !n_out) return fail(UVO_E_BADARG, "null pointer");
+  if (batch < 1 || batch > h->cfg.max_batch) return fail(UVO_E_BADARG, "batch outside 1..max_batch");
+  if (width < 1 || height < 1 || width > h->cfg.max_width || height > h->cfg.max_height || stride < width)
+    return fail(UVO_E_BADARG, "image size outside what the handle was sized for");
+  if ((int64_t)width * height > (int64_t)h->cfg.max_width * h->cfg.max_height) return fail(UVO_E_BADARG, "image too large");
+  UVO_HIP_CHECK(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const int in_cap = h->cfg.max_input_keypoints;
+  // the reference reads the centre pixel row of a caller keypoint without any bounds check; reject what would
+  // leave the padded plane (patch radius 15 + descriptor reach 18 against a 16 px pad)
+  if (!full_detect && in_kp && n_in) {
+    for (int b = 0; b < batch; ++b) {
+      if (n_in[b] < 0 || n_in[b] > in_cap) return fail(UVO_E_BADARG, "n_in outside 0..max_input_keypoints");
+      for (int i = 0; i < n_in[b]; ++i) {
+        const uvo_keypoint& k = in_kp[(size_t)b * in_cap + i];
+        const int cx = (int)lrintf(k.x), cy = (int)lrintf(k.y);
+        if (!(cx >= 2 && cx <= width - 3 && cy >= 2 && cy <= height - 3)) return fail(UVO_E_BADARG, "caller keypoint too close to the border");
+      }
+    }
+  }
+  // stage inputs (tight rows on the device)
+  UVO_HIP_CHECK(hipMemcpy2DAsync(h->d_imgs, width, imgs, stride, width, (size_t)height, hipMemcpyHostToDevice, s));
+  for (int b = 1; b < batch; ++b)
+    UVO_HIP_CHECK(hipMemcpy2DAsync(h->d_imgs + (size_t)b * width * height, width, imgs + (size_t)b * frame_stride, stride, width, (size_t)height,
+                                   hipMemcpyHostToDevice, s));
+  const bool topup = !full_detect;
+  const bool have_in = topup && in_kp && n_in && in_cap > 0;
+  if (topup) {
+    if (!grid2d || !num_feats_needed) return fail(UVO_E_BADARG, "top-up mode needs grid2d and num_feats_needed");
+    const size_t gb = (size_t)batch * grid_rows * grid_cols * sizeof(int32_t);
+    if (gb > h->grid_bytes) {
+      UVO_HIP_CHECK(hipStreamSynchronize(s));
+      if (h->d_grid) hipFree(h->d_grid);
+      h->d_grid = nullptr;
+      int rc = dev_alloc(&h->d_grid, gb / sizeof(int32_t));
+      if (rc) return rc;
+      h->grid_bytes = gb;
+    }
+    UVO_HIP_CHECK(hipMemcpyAsync(h->d_grid, grid2d, gb, hipMemcpyHostToDevice, s));
+    UVO_HIP_CHECK(hipMemcpyAsync(h->d_nfn, num_feats_needed, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+    if (have_in) {
+      UVO_HIP_CHECK(hipMemcpyAsync(h->d_in_kp, in_kp, sizeof(uvo_keypoint) * (size_t)batch * in_cap, hipMemcpyHostToDevice, s));
+      UVO_HIP_CHECK(hipMemcpyAsync(h->d_n_in, n_in, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+    }
+  }
+  const int dcap = h->cap_flist;  // device staging capacity per frame
+  int rc = run_batch_device(h, batch, h->d_imgs, width, height, width, (ptrdiff_t)width * height, have_in ? h->d_in_kp : nullptr,
+                            have_in ? h->d_n_in : nullptr, topup ? h->d_grid : nullptr, grid_rows, grid_cols, min_px_dist, full_detect,
+                            topup ? h->d_nfn : nullptr, h->d_out_kp, h->d_out_desc, dcap, h->d_n_out);
+  if (rc) return rc;
+  UVO_HIP_CHECK(hipMemcpyAsync(n_out, h->d_n_out, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipStreamSynchronize(s));
+  int status = UVO_OK;
+  for (int b = 0; b < batch; ++b) {
+    int n = n_out[b];
+    if (n > cap) {
+      status = fail(UVO_E_CAPACITY, "output capacity too small; n_out holds the required size");
+      n = cap;
+    }
+    if (n > 0) {
+      UVO_HIP_CHECK(hipMemcpyAsync(out_kp + (size_t)b * cap, h->d_out_kp + (size_t)b * dcap, sizeof(uvo_keypoint) * n, hipMemcpyDeviceToHost, s));
+      UVO_HIP_CHECK(hipMemcpyAsync(out_desc + (size_t)b * cap * 32, h->d_out_desc + (size_t)b * dcap * 32, (size_t)32 * n, hipMemcpyDeviceToHost, s));
+    }
+  }
+  if (topup) UVO_HIP_CHECK(hipMemcpyAsync(grid2d, h->d_grid, (size_t)batch * grid_rows * grid_cols * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipStreamSynchronize(s));
+  return status;
+}
+
+int uvo_extract(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdiff_t stride, const uvo_keypoint* in_kp, int n_in,
+                int32_t* grid2d, int grid_rows, int grid_cols, int min_px_dist, int full_detect, int num_feats_needed, uvo_keypoint* out_kp,
+                uint8_t* out_desc, int cap, int* n_out) {
+  if (!h || !n_out) return fail(UVO_E_BADARG, "null pointer");
+  if (n_in < 0 || n_in > h->cfg.max_input_keypoints) return fail(UVO_E_BADARG, "n_in outside 0..max_input_keypoints");
+  int32_t nin = n_in, nfn = num_feats_needed, nout = 0;
+  std::vector<uvo_keypoint> padded;
+  const uvo_keypoint* ik = in_kp;
+  if (!full_detect && n_in > 0 && in_kp) {
+    padded.assign(std::max(h->cfg.max_input_keypoints, 1), uvo_keypoint{});
+    std::copy(in_kp, in_kp + n_in, padded.begin());
+    ik = padded.data();
+  }
+  int rc = uvo_extract_batch(h, 1, img, width, height, stride, (ptrdiff_t)stride * height, ik, &nin, grid2d, grid_rows, grid_cols, min_px_dist,
+                             full_detect, &nfn, out_kp, out_desc, cap, &nout);
+  *n_out = nout;
+  return rc;
+}
+
+int uvo_extractor_level_dims(const uvo_extractor* h, int level, int* width, int* height) {
+  if (!h || !h->have_geom || level < 0 || level >= h->geom.nlevels) return fail(UVO_E_BADARG, "no geometry / bad level");
+  *width = h->geom.lv[level].w, *height = h->geom.lv[level].h;
+  return UVO_OK;
+}
+
+int uvo_extractor_read_plane(uvo_extractor* h, int frame, int level, int which, uint8_t* dst) {
+  if (!h || !h->have_geom || level < 0 || level >= h->geom.nlevels || frame < 0 || frame >= h->last_batch || !dst)
+    return fail(UVO_E_BADARG, "bad plane request");
+  UVO_HIP_CHECK(hipSetDevice(h->device));
+  UVO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  const LevelGeom& L = h->geom.lv[level];
+  const uint8_t* src = (which ? h->d_blur : h->d_pyr) + (size_t)frame * h->geom.pyr_block + L.plane_off;
+  UVO_HIP_CHECK(hipMemcpy2D(dst, L.pw, src, L.pitch, L.pw, L.ph, hipMemcpyDeviceToHost));
+  return UVO_OK;
+}
+
+int uvo_extractor_read_candidates(uvo_extractor* h, int frame, int level, int32_t* dst_xys, int cap, int* n) {
+  if (!h || !h->have_geom || level < 0 || level >= h->geom.nlevels || frame < 0 || frame >= h->last_batch || !n)
+    return fail(UVO_E_BADARG, "bad candidate request");
+  UVO_HIP_CHECK(hipSetDevice(h->device));
+  UVO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  const LevelGeom& L = h->geom.lv[level];
+  int32_t cnt = 0;
+  UVO_HIP_CHECK(hipMemcpy(&cnt, h->d_cand_count + (size_t)frame * h->geom.nlevels + level, 4, hipMemcpyDeviceToHost));
+  *n = cnt;
+  cnt = std::min(cnt, L.cand_cap);
+  const int m = std::min(cnt, cap);
+  if (m > 0 && dst_xys) {
+    std::vector<uint32_t> xy(m), sc(m);
+    const size_t off = (size_t)frame * h->geom.cand_block + L.cand_off;
+    UVO_HIP_CHECK(hipMemcpy(xy.data(), h->d_cand_xy + off, (size_t)4 * m, hipMemcpyDeviceToHost));
+    UVO_HIP_CHECK(hipMemcpy(sc.data(), h->d_cand_sc + off, (size_t)4 * m, hipMemcpyDeviceToHost));
+    for (int i = 0; i < m; ++i) {
+      dst_xys[3 * i] = (int32_t)(xy[i] & 0xffff);
+      dst_xys[3 * i + 1] = (int32_t)(xy[i] >> 16);
+      dst_xys[3 * i + 2] = (int32_t)sc[i];
+    }
+  }
+  return UVO_OK;
+}
+
+int uvo_extractor_profile(uvo_extractor* h, int enable) {
+  if (!h) return fail(UVO_E_BADARG, "null handle");
+  h->profile = enable != 0;
+  if (!h->profile) prof_clear(h);
+  return UVO_OK;
+}
+
+int uvo_extractor_kernel_times(uvo_extractor* h, char* names, int names_cap, float* ms, int32_t* launches, int cap, int* n) {
+  if (!h || !names || !ms || !launches || !n) return fail(UVO_E_BADARG, "null pointer");
+  UVO_HIP_CHECK(hipSetDevice(h->device));
+  UVO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  std::vector<std::string> nm;
+  std::vector<float> tt;
+  std::vector<int> cc;
+  for (auto& r : h->prof) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    size_t k = 0;
+    for (; k < nm.size(); ++k)
+      if (nm[k] == r.name) break;
+    if (k == nm.size()) nm.push_back(r.name), tt.push_back(0.f), cc.push_back(0);
+    tt[k] += t;
+    cc[k] += 1;
+  }
+  std::string joined;
+  int m = 0;
+  for (size_t k = 0; k < nm.size() && (int)k < cap; ++k, ++m) {
+    joined += nm[k];
+    joined += '\n';
+    ms[k] = tt[k];
+    launches[k] = cc[k];
+  }
+  snprintf(names, names_cap, "%s", joined.c_str());
+  *n = m;
+  return UVO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// 256-bit Hamming matching kernels.
+//   k_knn2   : all-pairs best / second-best per query -- cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) as used by
+//              Utils::ratioMatching (include/utils.h:81-111); distance = ORBmatcher::DescriptorDistance
+//              (src/ORBmatcher.cc:1794-1810: popcount of the XOR over 8 x 32 bits).
+//   k_matrix : full distance matrix (MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:236-247).
+// Integer VALU work (v_xor_b32 + v_bcnt_u32_b32), no MFMA: nothing here is a dense contraction.
+// One lane owns one query descriptor in 8 VGPRs; train descriptors are staged through LDS in tiles of 128 and
+// read back as wave-uniform broadcasts (every lane reads the same 16 bytes: conflict free).
+#include "common.hpp"
+
+namespace uvo {
+
+constexpr int HM_TILE = 128;  // train descriptors per LDS tile (4 KiB)
+
+__device__ __forceinline__ int popc256(const uint4& qa, const uint4& qb, const uint4& ta, const uint4& tb) {
+  int d = __popc(qa.x ^ ta.x);
+  d += __popc(qa.y ^ ta.y);
+  d += __popc(qa.z ^ ta.z);
+  d += __popc(qa.w ^ ta.w);
+  d += __popc(qb.x ^ tb.x);
+  d += __popc(qb.y ^ tb.y);
+  d += __popc(qb.z ^ tb.z);
+  d += __popc(qb.w ^ tb.w);
+  return d;
+}
+
+// grid: (ceil(max_query/256), pairs).  Ties keep the lower train index (strict <, ascending scan).
+__global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, const int32_t* __restrict__ nq_arr, int nq_fixed, int q_stride,
+                                              const uint8_t* __restrict__ t, const int32_t* __restrict__ nt_arr, int nt_fixed, int t_stride,
+                                              const uint8_t* __restrict__ mask, int out_stride, int32_t* __restrict__ idx0,
+                                              uint16_t* __restrict__ d0, int32_t* __restrict__ idx1, uint16_t* __restrict__ d1) {
+  __shared__ uint4 s_t[HM_TILE * 2];
+  const int pair = blockIdx.y;
+  const int nq = nq_arr ? nq_arr[pair] : nq_fixed;
+  const int nt = nt_arr ? nt_arr[pair] : nt_fixed;
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= nq) return;
+  const uint4* Q = reinterpret_cast<const uint4*>(q + (int64_t)pair * q_stride * 32);
+  const uint4* T = reinterpret_cast<const uint4*>(t + (int64_t)pair * t_stride * 32);
+  const bool live = qi < nq;
+  uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+  if (live) {
+    qa = Q[2 * qi];
+    qb = Q[2 * qi + 1];
+  }
+  int bd0 = 0x7fffffff, bi0 = -1, bd1 = 0x7fffffff, bi1 = -1;
+  const uint8_t* mrow = mask ? mask + (int64_t)qi * nt : nullptr;
+  for (int base = 0; base < nt; base += HM_TILE) {
+    const int cnt = nt - base < HM_TILE ? nt - base : HM_TILE;
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * cnt) s_t[threadIdx.x] = T[2 * base + threadIdx.x];
+    __syncthreads();
+    if (live) {
+      for (int j = 0; j < cnt; ++j) {
+        if (mrow && !mrow[base + j]) continue;
+        const int d = popc256(qa, qb, s_t[2 * j], s_t[2 * j + 1]);
+        if (d < bd0) {
+          bd1 = bd0, bi1 = bi0;
+          bd0 = d, bi0 = base + j;
+        } else if (d < bd1) {
+          bd1 = d, bi1 = base + j;
+        }
+      }
+    }
+  }
+  if (live) {
+    const int64_t o = (int64_t)pair * out_stride + qi;
+    idx0[o] = bi0;
+    d0[o] = bi0 < 0 ? (uint16_t)0xFFFF : (uint16_t)bd0;
+    idx1[o] = bi1;
+    d1[o] = bi1 < 0 ? (uint16_t)0xFFFF : (uint16_t)bd1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_matrix(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
+                                                uint16_t* __restrict__ dist) {
+  __shared__ uint4 s_t[HM_TILE * 2];
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  const uint4* Q = reinterpret_cast<const uint4*>(q);
+  const uint4* T = reinterpret_cast<const uint4*>(t);
+  const bool live = qi < nq;
+  uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+  if (live) {
+    qa = Q[2 * qi];
+    qb = Q[2 * qi + 1];
+  }
+  const int base = blockIdx.y * HM_TILE;
+  const int cnt = nt - base < HM_TILE ? nt - base : HM_TILE;
+  if ((int)threadIdx.x < 2 * cnt) s_t[threadIdx.x] = T[2 * base + threadIdx.x];
+  __syncthreads();
+  if (!live) return;
+  for (int j = 0; j < cnt; ++j) dist[(int64_t)qi * nt + base + j] = (uint16_t)popc256(qa, qb, s_t[2 * j], s_t[2 * j + 1]);
+}
+
+void launch_knn2(hipStream_t s, int pairs, int max_q, const uint8_t* d_q, const int32_t* d_nq, int nq_fixed, int q_stride, const uint8_t* d_t,
+                 const int32_t* d_nt, int nt_fixed, int t_stride, const uint8_t* d_mask, int out_stride, int32_t* d_idx0, uint16_t* d_d0,
+                 int32_t* d_idx1, uint16_t* d_d1) {
+  hipLaunchKernelGGL(k_knn2, dim3((max_q + 255) / 256, pairs), dim3(256), 0, s, d_q, d_nq, nq_fixed, q_stride, d_t, d_nt, nt_fixed, t_stride,
+                     d_mask, out_stride, d_idx0, d_d0, d_idx1, d_d1);
+}
+
+void launch_matrix(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, uint16_t* d_dist) {
+  hipLaunchKernelGGL(k_matrix, dim3((nq + 255) / 256, (nt + HM_TILE - 1) / HM_TILE), dim3(256), 0, s, d_q, nq, d_t, nt, d_dist);
+}
+
+}  // namespace uvo

@@ -1,0 +1,254 @@
+// Host side of the matcher entry points of include/uvo/uvo.h (replacing the arithmetic and search cores of
+// USLAM::ORBmatcher, src/ORBmatcher.cc, and Utils::ratioMatching, include/utils.h:81-111).
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+
+namespace uvo {
+void launch_sbp(hipStream_t s, const uvo_keypoint* d_kp, int n, const uint8_t* d_desc, int min_x, int min_y, int max_x, int max_y,
+                int32_t* d_assigned, int nmp, const float* d_px, const float* d_py, const int32_t* d_level, const float* d_vc,
+                const uint8_t* d_inview, const uint8_t* d_mpdesc, const float* d_scale, float th, float nnratio, int32_t* d_cell_start,
+                int32_t* d_cell_items, int32_t* d_cell_of_kp, int32_t* d_cand_cnt, int32_t* d_cand_start, uint32_t* d_cand, int32_t* d_owner,
+                int32_t* d_owner_next, int32_t* d_choice, int32_t* d_n_matches, int stage);
+int matcher_fail(int code, const char* msg);
+}  // namespace uvo
+
+using namespace uvo;
+
+struct uvo_matcher {
+  uvo_matcher_cfg cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // knn2 staging
+  uint8_t *d_q = nullptr, *d_t = nullptr, *d_mask = nullptr;
+  size_t mask_bytes = 0;
+  int32_t *d_idx0 = nullptr, *d_idx1 = nullptr;
+  uint16_t *d_d0 = nullptr, *d_d1 = nullptr, *d_dist = nullptr;
+  size_t dist_elems = 0;
+  // search-by-projection
+  uvo_keypoint* d_kp = nullptr;
+  float *d_px = nullptr, *d_py = nullptr, *d_vc = nullptr, *d_scale = nullptr;
+  int32_t *d_level = nullptr, *d_assigned = nullptr, *d_cell_start = nullptr, *d_cell_items = nullptr, *d_cell_of_kp = nullptr;
+  int32_t *d_cand_cnt = nullptr, *d_cand_start = nullptr, *d_owner = nullptr, *d_owner_next = nullptr, *d_choice = nullptr, *d_nm = nullptr;
+  uint8_t *d_inview = nullptr, *d_mpdesc = nullptr;
+  uint32_t* d_cand = nullptr;
+  size_t cand_elems = 0;
+};
+
+namespace uvo {
+int matcher_fail(int code, const char* msg) { return fail(code, msg); }
+template <class T>
+static int m_alloc(T** p, size_t n) {
+  if (n == 0) n = 1;
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  if (e != hipSuccess) {
+    hip_err_set(e, "hipMalloc");
+    return e == hipErrorOutOfMemory ? UVO_E_NOMEM : UVO_E_HIP;
+  }
+  return UVO_OK;
+}
+}  // namespace uvo
+
+extern "C" {
+
+int uvo_matcher_create(const uvo_matcher_cfg* cfg, uvo_matcher** out) {
+  if (!cfg || !out) return matcher_fail(UVO_E_BADARG, "null pointer");
+  *out = nullptr;
+  if (cfg->max_query < 1 || cfg->max_train < 1 || cfg->max_batch < 1 || cfg->max_map_points < 0 || cfg->max_query > 65535 ||
+      cfg->max_train > (1 << 24))
+    return matcher_fail(UVO_E_BADARG, "bad matcher configuration");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return matcher_fail(UVO_E_NODEVICE, "no HIP device available (no CPU fallback exists)");
+  if (cfg->device < 0 || cfg->device >= ndev) return matcher_fail(UVO_E_BADARG, "device ordinal out of range");
+  uvo_matcher* m = new uvo_matcher();
+  m->cfg = *cfg;
+  m->device = cfg->device;
+  if (hipSetDevice(m->device) != hipSuccess || hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete m;
+    return matcher_fail(UVO_E_HIP, "stream creation failed");
+  }
+  const size_t B = cfg->max_batch, Q = cfg->max_query, T = cfg->max_train, MP = std::max(cfg->max_map_points, 1);
+  int rc;
+#define A(call)                  \
+  if ((rc = (call)) != UVO_OK) { \
+    uvo_matcher_destroy(m);      \
+    return rc;                   \
+  }
+  A(m_alloc(&m->d_q, Q * 32));
+  A(m_alloc(&m->d_t, T * 32));
+  A(m_alloc(&m->d_idx0, B * Q));
+  A(m_alloc(&m->d_idx1, B * Q));
+  A(m_alloc(&m->d_d0, B * Q));
+  A(m_alloc(&m->d_d1, B * Q));
+  A(m_alloc(&m->d_kp, Q));
+  A(m_alloc(&m->d_assigned, Q));
+  A(m_alloc(&m->d_cell_start, (size_t)64 * 48 + 1));
+  A(m_alloc(&m->d_cell_items, Q));
+  A(m_alloc(&m->d_cell_of_kp, Q));
+  A(m_alloc(&m->d_owner, Q));
+  A(m_alloc(&m->d_owner_next, Q));
+  A(m_alloc(&m->d_px, MP));
+  A(m_alloc(&m->d_py, MP));
+  A(m_alloc(&m->d_vc, MP));
+  A(m_alloc(&m->d_level, MP));
+  A(m_alloc(&m->d_inview, MP));
+  A(m_alloc(&m->d_mpdesc, MP * 32));
+  A(m_alloc(&m->d_cand_cnt, MP + 1));
+  A(m_alloc(&m->d_cand_start, MP + 1));
+  A(m_alloc(&m->d_choice, MP));
+  A(m_alloc(&m->d_scale, (size_t)kMaxLevels * 4));
+  A(m_alloc(&m->d_nm, (size_t)1));
+#undef A
+  *out = m;
+  return UVO_OK;
+}
+
+void uvo_matcher_destroy(uvo_matcher* m) {
+  if (!m) return;
+  hipSetDevice(m->device);
+  if (m->stream) hipStreamSynchronize(m->stream);
+  void* ptrs[] = {m->d_q,      m->d_t,     m->d_mask,       m->d_idx0,       m->d_idx1,       m->d_d0,    m->d_d1,         m->d_dist,  m->d_kp,
+                  m->d_px,     m->d_py,    m->d_vc,         m->d_scale,      m->d_level,      m->d_assigned, m->d_cell_start, m->d_cell_items,
+                  m->d_cell_of_kp, m->d_cand_cnt, m->d_cand_start, m->d_owner, m->d_owner_next, m->d_choice, m->d_nm, m->d_inview, m->d_mpdesc,
+                  m->d_cand};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  if (m->stream) hipStreamDestroy(m->stream);
+  delete m;
+}
+
+int uvo_matcher_synchronize(uvo_matcher* m) {
+  if (!m) return matcher_fail(UVO_E_BADARG, "null handle");
+  UVO_HIP_CHECK(hipSetDevice(m->device));
+  UVO_HIP_CHECK(hipStreamSynchronize(m->stream));
+  return UVO_OK;
+}
+
+int uvo_hamming_knn2(uvo_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* mask, int32_t* idx0, uint16_t* d0,
+                     int32_t* idx1, uint16_t* d1) {
+  if (!m || !idx0 || !d0 || !idx1 || !d1) return matcher_fail(UVO_E_BADARG, "null pointer");
+  if (nq < 0 || nt < 0 || nq > m->cfg.max_query || nt > m->cfg.max_train) return matcher_fail(UVO_E_BADARG, "descriptor count outside handle capacity");
+  if (nq == 0) return UVO_OK;  // ratioMatching returns early on empty inputs (include/utils.h:85-86)
+  if (!q || (nt > 0 && !t)) return matcher_fail(UVO_E_BADARG, "null descriptor pointer");
+  UVO_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  UVO_HIP_CHECK(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+  if (nt > 0) UVO_HIP_CHECK(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+  const uint8_t* dmask = nullptr;
+  if (mask && nt > 0) {
+    const size_t mb = (size_t)nq * nt;
+    if (mb > m->mask_bytes) {
+      UVO_HIP_CHECK(hipStreamSynchronize(s));
+      if (m->d_mask) hipFree(m->d_mask);
+      m->d_mask = nullptr;
+      int rc = m_alloc(&m->d_mask, mb);
+      if (rc) return rc;
+      m->mask_bytes = mb;
+    }
+    UVO_HIP_CHECK(hipMemcpyAsync(m->d_mask, mask, mb, hipMemcpyHostToDevice, s));
+    dmask = m->d_mask;
+  }
+  launch_knn2(s, 1, nq, m->d_q, nullptr, nq, 0, m->d_t, nullptr, nt, 0, dmask, m->cfg.max_query, m->d_idx0, m->d_d0, m->d_idx1, m->d_d1);
+  UVO_HIP_CHECK(hipGetLastError());
+  UVO_HIP_CHECK(hipMemcpyAsync(idx0, m->d_idx0, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(idx1, m->d_idx1, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(d0, m->d_d0, (size_t)nq * 2, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(d1, m->d_d1, (size_t)nq * 2, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipStreamSynchronize(s));
+  return UVO_OK;
+}
+
+int uvo_hamming_knn2_batch_device(uvo_matcher* m, int pairs, const uint8_t* d_q, const int32_t* d_nq, int q_stride, const uint8_t* d_t,
+                                  const int32_t* d_nt, int t_stride, int32_t* d_idx0, uint16_t* d_d0, int32_t* d_idx1, uint16_t* d_d1) {
+  if (!m || !d_q || !d_t || !d_nq || !d_nt || !d_idx0 || !d_d0 || !d_idx1 || !d_d1) return matcher_fail(UVO_E_BADARG, "null pointer");
+  if (pairs < 1 || pairs > m->cfg.max_batch || q_stride < 1 || t_stride < 1) return matcher_fail(UVO_E_BADARG, "bad batch / stride");
+  UVO_HIP_CHECK(hipSetDevice(m->device));
+  launch_knn2(m->stream, pairs, m->cfg.max_query, d_q, d_nq, 0, q_stride, d_t, d_nt, 0, t_stride, nullptr, m->cfg.max_query, d_idx0, d_d0, d_idx1,
+              d_d1);
+  UVO_HIP_CHECK(hipGetLastError());
+  return UVO_OK;
+}
+
+int uvo_hamming_matrix(uvo_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* dist) {
+  if (!m || !dist) return matcher_fail(UVO_E_BADARG, "null pointer");
+  if (nq < 0 || nt < 0 || nq > m->cfg.max_query || nt > m->cfg.max_train) return matcher_fail(UVO_E_BADARG, "descriptor count outside handle capacity");
+  if (nq == 0 || nt == 0) return UVO_OK;
+  if (!q || !t) return matcher_fail(UVO_E_BADARG, "null descriptor pointer");
+  UVO_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  const size_t need = (size_t)nq * nt;
+  if (need > m->dist_elems) {
+    UVO_HIP_CHECK(hipStreamSynchronize(s));
+    if (m->d_dist) hipFree(m->d_dist);
+    m->d_dist = nullptr;
+    int rc = m_alloc(&m->d_dist, need);
+    if (rc) return rc;
+    m->dist_elems = need;
+  }
+  UVO_HIP_CHECK(hipMemcpyAsync(m->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(m->d_t, t, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+  launch_matrix(s, m->d_q, nq, m->d_t, nt, m->d_dist);
+  UVO_HIP_CHECK(hipGetLastError());
+  UVO_HIP_CHECK(hipMemcpyAsync(dist, m->d_dist, need * 2, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipStreamSynchronize(s));
+  return UVO_OK;
+}
+
+int uvo_search_by_projection(uvo_matcher* m, const uvo_keypoint* kp, int n, const uint8_t* desc, int min_x, int min_y, int max_x, int max_y,
+                             int32_t* assigned, int nmp, const float* proj_x, const float* proj_y, const int32_t* level,
+                             const float* view_cos, const uint8_t* in_view, const uint8_t* mp_desc, const float* scale_factors,
+                             int nlevels, float th, float nnratio, int* n_matches) {
+  if (!m || !n_matches) return matcher_fail(UVO_E_BADARG, "null pointer");
+  *n_matches = 0;
+  if (n < 0 || nmp < 0 || n > m->cfg.max_query || nmp > m->cfg.max_map_points || nlevels < 1 || nlevels > kMaxLevels * 4 || max_x <= min_x ||
+      max_y <= min_y)
+    return matcher_fail(UVO_E_BADARG, "sizes outside handle capacity");
+  if (n == 0 || nmp == 0) return UVO_OK;
+  if (!kp || !desc || !assigned || !proj_x || !proj_y || !level || !view_cos || !in_view || !mp_desc || !scale_factors)
+    return matcher_fail(UVO_E_BADARG, "null pointer");
+  for (int i = 0; i < nmp; ++i)
+    if (in_view[i] && (level[i] < 0 || level[i] >= nlevels)) return matcher_fail(UVO_E_BADARG, "map point level outside 0..nlevels-1");
+  UVO_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  UVO_HIP_CHECK(hipMemcpyAsync(m->d_kp, kp, sizeof(uvo_keypoint) * n, hipMemcpyHostToDevice, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(m->d_q, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(m->d_assigned, assigned, (size_t)n * 4, hipMemcpyHostToDevice, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(m->d_px, proj_x, (size_t)nmp * 4, hipMemcpyHostToDevice, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(m->d_py, proj_y, (size_t)nmp * 4, hipMemcpyHostToDevice, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(m->d_vc, view_cos, (size_t)nmp * 4, hipMemcpyHostToDevice, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(m->d_level, level, (size_t)nmp * 4, hipMemcpyHostToDevice, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(m->d_inview, in_view, (size_t)nmp, hipMemcpyHostToDevice, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(m->d_mpdesc, mp_desc, (size_t)nmp * 32, hipMemcpyHostToDevice, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(m->d_scale, scale_factors, (size_t)nlevels * 4, hipMemcpyHostToDevice, s));
+  auto go = [&](int stage) {
+    launch_sbp(s, m->d_kp, n, m->d_q, min_x, min_y, max_x, max_y, m->d_assigned, nmp, m->d_px, m->d_py, m->d_level, m->d_vc, m->d_inview,
+               m->d_mpdesc, m->d_scale, th, nnratio, m->d_cell_start, m->d_cell_items, m->d_cell_of_kp, m->d_cand_cnt, m->d_cand_start,
+               m->d_cand, m->d_owner, m->d_owner_next, m->d_choice, m->d_nm, stage);
+  };
+  go(0);
+  UVO_HIP_CHECK(hipGetLastError());
+  int32_t total = 0;
+  UVO_HIP_CHECK(hipMemcpyAsync(&total, m->d_cand_start + nmp, 4, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipStreamSynchronize(s));
+  if ((size_t)total > m->cand_elems) {
+    if (m->d_cand) hipFree(m->d_cand);
+    m->d_cand = nullptr;
+    const size_t want = (size_t)total + total / 2 + 1024;
+    int rc = m_alloc(&m->d_cand, want);
+    if (rc) return rc;
+    m->cand_elems = want;
+  }
+  go(1);
+  UVO_HIP_CHECK(hipGetLastError());
+  int32_t nm = 0;
+  UVO_HIP_CHECK(hipMemcpyAsync(assigned, m->d_assigned, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(&nm, m->d_nm, 4, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipStreamSynchronize(s));
+  *n_matches = nm;
+  return UVO_OK;
+}
+
+}  // extern "C"

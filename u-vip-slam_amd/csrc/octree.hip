@@ -1,0 +1,94 @@
+// Kernel wrapper of the quad-tree selection (octree_core.hpp): one 256-thread workgroup per (frame, level),
+// node state carved out of dynamic LDS, candidate state words in HBM scratch.
+#include "common.hpp"
+#include "octree_core.hpp"
+
+namespace uvo {
+
+static inline int oct_capacity(int N, int nIni) {
+  int m = N > 4 * nIni ? N : 4 * nIni;
+  return m + 8;
+}
+static inline int pow2_ge(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+// bytes of LDS for node capacity M (layout must match the carve in k_octree)
+static inline size_t oct_lds_bytes(int M, int Mp2) {
+  size_t b = 0;
+  b += (size_t)16 * M;                      // ccnt[4M] (aliased by best64[2M] / sort64[Mp2])
+  b += (size_t)8 * M * 2;                   // boxA, boxB
+  b += (size_t)4 * M * 7;                   // cntA, cntB, procRank, nodeOfRank, baseOfRank, outKey, outPt
+  b += (size_t)4 * Mp2;                     // sortbuf
+  b += (size_t)4 * (2 * OCT_THREADS + 16);  // part, sc
+  return b;
+}
+
+__global__ __launch_bounds__(OCT_THREADS) void k_octree(const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max,
+                                                        const uint32_t* __restrict__ cand_xy, const uint32_t* __restrict__ cand_sc,
+                                                        int64_t cand_block, const int32_t* __restrict__ cand_count,
+                                                        uint32_t* __restrict__ pstate, uint32_t* __restrict__ sel_xy,
+                                                        uint32_t* __restrict__ sel_sc, int sel_block, int32_t* __restrict__ sel_count) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int level = blockIdx.x, f = blockIdx.y;
+  const LevelGeom& g = lv[level];
+  int P = cand_count[f * nlevels + level];
+  P = P > g.cand_cap ? g.cand_cap : P;
+  int32_t* out_n = sel_count + f * nlevels + level;
+  if (P == 0) {
+    if (threadIdx.x == 0) *out_n = 0;
+    return;
+  }
+  oct::Params pr;
+  pr.P = P;
+  pr.N = g.quota;
+  pr.W = g.bw;
+  pr.H = g.bh;
+  pr.nIni = g.nIni;
+  pr.hX = g.hX;
+  pr.nCols = g.nCols, pr.nRows = g.nRows, pr.wCell = g.wCell, pr.hCell = g.hCell;
+  pr.M = Mmax;
+  pr.Mp2 = Mp2max;
+  oct::Work w;
+  uint8_t* p = lds;
+  w.ccnt = reinterpret_cast<uint32_t*>(p), p += (size_t)16 * Mmax;
+  w.boxA = reinterpret_cast<oct::Box*>(p), p += (size_t)8 * Mmax;
+  w.boxB = reinterpret_cast<oct::Box*>(p), p += (size_t)8 * Mmax;
+  w.cntA = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mmax;
+  w.cntB = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mmax;
+  w.procRank = reinterpret_cast<int32_t*>(p), p += (size_t)4 * Mmax;
+  w.nodeOfRank = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mmax;
+  w.baseOfRank = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mmax;
+  w.outKey = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mmax;
+  w.outPt = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mmax;
+  w.sortbuf = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mp2max;
+  w.part = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * 2 * OCT_THREADS;
+  w.sc = reinterpret_cast<int*>(p);
+
+  const int64_t co = f * cand_block + g.cand_off;
+  const int64_t so = (int64_t)f * sel_block + g.sel_off;
+  const int n = oct::run(pr, w, cand_xy + co, cand_sc + co, pstate + co, sel_xy + so, sel_sc + so, g.sel_cap);
+  if (threadIdx.x == 0) *out_n = n;
+}
+
+void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_xy, const uint32_t* d_cand_sc,
+                   int64_t cand_block, const int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
+                   int32_t* d_sel_count, int batch) {
+  int M = 0;
+  for (int l = 0; l < g.nlevels; ++l) {
+    const int m = oct_capacity(g.lv[l].quota, g.lv[l].nIni);
+    M = m > M ? m : M;
+  }
+  const int Mp2 = pow2_ge(M);
+  const size_t lds = oct_lds_bytes(M, Mp2);
+  static size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured = lds;
+  }
+  hipLaunchKernelGGL(k_octree, dim3(g.nlevels, batch), dim3(OCT_THREADS), lds, s, d_lv, g.nlevels, M, Mp2, d_cand_xy, d_cand_sc, cand_block,
+                     d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count);
+}
+
+}  // namespace uvo

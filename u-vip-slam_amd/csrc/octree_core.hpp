@@ -1,0 +1,448 @@
+// Quad-tree keypoint selection, one workgroup per (frame, level).
+// Replaces ORBextractor::DistributeOctTree + ExtractorNode::DivideNode (src/ORBextractor.cc:1006-1287).
+//
+// The reference is a sequential std::list algorithm.  It is reformulated here as a sequence of data-parallel
+// *passes* over "generations" of nodes (tools/octree_proto.py is the executable derivation, checked against the
+// literal restatement in oracle/):
+//   * a generation A is the set of nodes created by one pass, stored in the reference's list order
+//     (front -> back = newest -> oldest); older nodes that survive are frozen single-point nodes, which always
+//     sit behind A in the list, generation by generation;
+//   * a full pass (:1061-1132) splits every multi-point node of A; children are created in (parent list order,
+//     n1..n4) order and push_front'ed, so the new generation in list order is the reverse creation order;
+//   * a careful round (:1143-1204) does the same but visits parents by (size desc, newest first) -- the declared
+//     deterministic replacement of the reference's pointer-valued tie-break -- and stops at
+//     the first split that reaches N nodes; parents it did not reach stay where they are;
+//   * the result (:1208-1229) is one point per surviving node: max response, first in candidate order on ties,
+//     emitted in list order = (generation desc, position asc).
+// A pass is: per-point child digit + histogram (LDS atomics), a scan over <= N parents, and for careful rounds a
+// bitonic sort of <= N keys.  Point state lives in HBM scratch (L2 resident), node state in LDS.
+//
+// The body is written against the OCT_* phase macros so that tests/emu/octree_emu.cpp can run the *same* logic on
+// the CPU (threads of a phase executed one after another) against the oracle; on the GPU a phase ends in a
+// workgroup barrier.
+#pragma once
+#include <stdint.h>
+
+#ifndef OCT_THREADS
+#define OCT_THREADS 256
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OCT_DEVICE 1
+#define OCT_FN __device__ __forceinline__
+#define OCT_PHASE_BEGIN \
+  {                     \
+    const int tid = threadIdx.x;
+#define OCT_PHASE_END \
+  }                   \
+  __syncthreads();
+#define OCT_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define OCT_ATOMIC_MIN(p, v) atomicMin((p), (v))
+#define OCT_ATOMIC_MAX64(p, v) atomicMax((unsigned long long*)(p), (unsigned long long)(v))
+#else
+#define OCT_DEVICE 0
+#define OCT_FN static inline
+#define OCT_PHASE_BEGIN for (int tid = 0; tid < OCT_THREADS; ++tid) {
+#define OCT_PHASE_END }
+template <class T, class U>
+static inline T oct_host_add(T* p, U v) {
+  T o = *p;
+  *p = (T)(o + v);
+  return o;
+}
+#define OCT_ATOMIC_ADD(p, v) oct_host_add((p), (v))
+#define OCT_ATOMIC_MIN(p, v)        \
+  do {                              \
+    if ((v) < *(p)) *(p) = (v);     \
+  } while (0)
+#define OCT_ATOMIC_MAX64(p, v)                            \
+  do {                                                    \
+    if ((uint64_t)(v) > *(p)) *(p) = (uint64_t)(v);       \
+  } while (0)
+#endif
+
+namespace uvo {
+namespace oct {
+
+struct Params {
+  int P;            // candidates
+  int N;            // target node count (level quota)
+  int W, H;         // detection window (maxBorder - minBorder)
+  int nIni;
+  float hX;
+  int nCols, nRows, wCell, hCell;  // FAST cell grid, for the candidate-order key
+  int M;            // node capacity of the LDS arrays
+  int Mp2;          // power of two >= M
+};
+
+struct Box {
+  uint16_t ulx, urx, uly, bry;
+};
+
+// LDS (or host) working set; all arrays sized by Params::M unless noted
+struct Work {
+  Box* boxA;
+  Box* boxB;
+  uint32_t* cntA;
+  uint32_t* cntB;
+  int32_t* procRank;     // per node of A: rank in processing order, or -1
+  uint32_t* ccnt;        // [4*M] child histogram of A  (aliased later by best64 / sort64)
+  uint32_t* nodeOfRank;  // processing rank -> node position in A
+  uint32_t* baseOfRank;  // exclusive scan of non-empty child counts in processing order
+  uint32_t* sortbuf;     // [Mp2]
+  uint32_t* outKey;      // per emitted node: ((GEN_MAX - gen) << 16) | pos
+  uint32_t* outPt;       // candidate index
+  uint32_t* part;        // [OCT_THREADS] scan partials
+  // shared scalars
+  int* sc;               // [16]
+};
+
+enum { SC_NA = 0, SC_NOUT, SC_NEXP, SC_NPROC, SC_T, SC_NTOEXP, SC_M, SC_TMP };
+
+constexpr uint32_t ST_FROZEN = 0xFFFFFFFFu;
+constexpr uint32_t ST_UNPROC = 0x80000000u;
+constexpr int GEN_MAX = 60;
+
+OCT_FN int oct_bcast(const int* p) {
+  int v = *p;
+#if OCT_DEVICE
+  __syncthreads();
+#endif
+  return v;
+}
+
+// in-place exclusive scan of a[0..n) (n <= a few thousand); returns the total.  Blocked per thread + a
+// Kogge-Stone pass over the OCT_THREADS partial sums.
+OCT_FN uint32_t block_scan_excl(uint32_t* a, int n, uint32_t* part, int* sc) {
+  const int per = (n + OCT_THREADS - 1) / OCT_THREADS;
+  OCT_PHASE_BEGIN
+  uint32_t s = 0;
+  const int b = tid * per, e = (b + per < n) ? b + per : n;
+  for (int i = b; i < e; ++i) s += a[i];
+  part[tid] = s;
+  OCT_PHASE_END
+  for (int off = 1; off < OCT_THREADS; off <<= 1) {
+    // two-phase step so that every thread reads before anyone writes
+    uint32_t* tmp = part + OCT_THREADS;
+    OCT_PHASE_BEGIN
+    tmp[tid] = part[tid] + (tid >= off ? part[tid - off] : 0u);
+    OCT_PHASE_END
+    OCT_PHASE_BEGIN
+    part[tid] = tmp[tid];
+    OCT_PHASE_END
+  }
+  OCT_PHASE_BEGIN
+  uint32_t run = tid ? part[tid - 1] : 0u;
+  const int b = tid * per, e = (b + per < n) ? b + per : n;
+  for (int i = b; i < e; ++i) {
+    const uint32_t v = a[i];
+    a[i] = run;
+    run += v;
+  }
+  if (tid == OCT_THREADS - 1) sc[SC_TMP] = (int)part[OCT_THREADS - 1];
+  OCT_PHASE_END
+  return (uint32_t)oct_bcast(&sc[SC_TMP]);
+}
+
+// ascending bitonic sort of a[0..n2), n2 a power of two
+template <class T>
+OCT_FN void block_bitonic(T* a, int n2) {
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      OCT_PHASE_BEGIN
+      for (int i = tid; i < n2; i += OCT_THREADS) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const T x = a[i], y = a[ixj];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) {
+            a[i] = y;
+            a[ixj] = x;
+          }
+        }
+      }
+      OCT_PHASE_END
+    }
+  }
+}
+
+OCT_FN int half_ceil(int a) { return (a + 1) >> 1; }  // ceil(a/2.f) for a >= 0 (DivideNode :1233-1234)
+
+// cand_xy / cand_score: candidate coordinates (x | y<<16, relative to minBorder) and FAST scores
+// pstate: per-candidate scratch word.  sel_*: output in list order.  returns number of selected points.
+OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const uint32_t* cand_score, uint32_t* pstate, uint32_t* sel_xy,
+               uint32_t* sel_score, int sel_cap) {
+  const int P = pr.P, N = pr.N;
+  int* sc = w.sc;
+  Box* A = w.boxA;
+  Box* B = w.boxB;
+  uint32_t* cA = w.cntA;
+  uint32_t* cB = w.cntB;
+
+  // ---- roots (:1010-1052) ----
+  OCT_PHASE_BEGIN
+  for (int i = tid; i < pr.nIni; i += OCT_THREADS) w.ccnt[i] = 0;
+  if (tid == 0) sc[SC_NOUT] = 0;
+  OCT_PHASE_END
+  OCT_PHASE_BEGIN
+  for (int p = tid; p < P; p += OCT_THREADS) {
+    const float x = (float)(cand_xy[p] & 0xffff);
+    const int r = (int)(x / pr.hX);
+    OCT_ATOMIC_ADD(&w.ccnt[r], 1u);
+    pstate[p] = (uint32_t)r;
+  }
+  OCT_PHASE_END
+  OCT_PHASE_BEGIN
+  if (tid == 0) {
+    int na = 0;
+    for (int r = 0; r < pr.nIni; ++r) {
+      if (w.ccnt[r] == 0) {
+        w.nodeOfRank[r] = 0;
+        continue;
+      }
+      w.nodeOfRank[r] = (uint32_t)na;
+      Box b;
+      b.ulx = (uint16_t)(int)(pr.hX * (float)r);
+      b.urx = (uint16_t)(int)(pr.hX * (float)(r + 1));
+      b.uly = 0;
+      b.bry = (uint16_t)pr.H;
+      A[na] = b;
+      cA[na] = w.ccnt[r];
+      ++na;
+    }
+    sc[SC_NA] = na;
+  }
+  OCT_PHASE_END
+  OCT_PHASE_BEGIN
+  for (int p = tid; p < P; p += OCT_THREADS) {
+    const uint32_t a = w.nodeOfRank[pstate[p]];
+    if (cA[a] == 1) {
+      const int slot = OCT_ATOMIC_ADD(&sc[SC_NOUT], 1);
+      w.outKey[slot] = ((uint32_t)(GEN_MAX - 0) << 16) | a;
+      w.outPt[slot] = (uint32_t)p;
+      pstate[p] = ST_FROZEN;
+    } else {
+      pstate[p] = a;
+    }
+  }
+  OCT_PHASE_END
+
+  int na = oct_bcast(&sc[SC_NA]);
+  int size = na;
+  int gen = 0;
+  bool careful = false;
+  int na_prev = 0;          // node count of the previous generation (only meaningful after a truncated round)
+  bool truncated = false;
+
+  for (;;) {
+    const int prev_size = size;
+    // ---- which nodes of A are expandable; default processing order = list order ----
+    OCT_PHASE_BEGIN
+    for (int a = tid; a < na; a += OCT_THREADS) w.baseOfRank[a] = cA[a] > 1 ? 1u : 0u;
+    OCT_PHASE_END
+    const int nExp = (int)block_scan_excl(w.baseOfRank, na, w.part, sc);
+    if (nExp == 0) break;
+    OCT_PHASE_BEGIN
+    for (int a = tid; a < na; a += OCT_THREADS) {
+      if (cA[a] > 1) {
+        const uint32_t r = w.baseOfRank[a];
+        w.procRank[a] = (int32_t)r;
+        w.nodeOfRank[r] = (uint32_t)a;
+      } else {
+        w.procRank[a] = -1;
+      }
+    }
+    for (int i = tid; i < 4 * na; i += OCT_THREADS) w.ccnt[i] = 0;
+    OCT_PHASE_END
+    // ---- child digit + histogram (DivideNode :1262-1276) ----
+    OCT_PHASE_BEGIN
+    for (int p = tid; p < P; p += OCT_THREADS) {
+      const uint32_t st = pstate[p];
+      if (st == ST_FROZEN) continue;
+      const uint32_t a = st & 0xffffu;
+      const Box b = A[a];
+      const int x = (int)(cand_xy[p] & 0xffff), y = (int)(cand_xy[p] >> 16);
+      const int d = (x < (int)b.ulx + half_ceil((int)b.urx - (int)b.ulx) ? 0 : 1) + (y < (int)b.uly + half_ceil((int)b.bry - (int)b.uly) ? 0 : 2);
+      OCT_ATOMIC_ADD(&w.ccnt[4 * a + d], 1u);
+      pstate[p] = a | ((uint32_t)d << 16);
+    }
+    OCT_PHASE_END
+    int nProc = nExp;
+    if (careful) {
+      // ---- order parents by (size desc, list position asc) and cut at the first split reaching N (:1151-1199) ----
+      OCT_PHASE_BEGIN
+      for (int i = tid; i < pr.Mp2; i += OCT_THREADS) {
+        uint32_t key = 0xFFFFFFFFu;
+        if (i < nExp) {
+          const uint32_t a = w.nodeOfRank[i];
+          uint32_t c = cA[a];
+          c = c > 0xFFFFFu ? 0xFFFFFu : c;
+          key = ((0xFFFFFu - c) << 12) | a;
+        }
+        w.sortbuf[i] = key;
+      }
+      OCT_PHASE_END
+      int n2 = 1;
+      while (n2 < nExp) n2 <<= 1;
+      block_bitonic(w.sortbuf, n2);
+      OCT_PHASE_BEGIN
+      for (int i = tid; i < nExp; i += OCT_THREADS) {
+        const uint32_t a = w.sortbuf[i] & 0xfffu;
+        w.nodeOfRank[i] = a;
+        const uint32_t* c = &w.ccnt[4 * a];
+        w.baseOfRank[i] = (uint32_t)((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0)) - 1u;  // net nodes added by this split
+      }
+      if (tid == 0) sc[SC_M] = nExp;
+      OCT_PHASE_END
+      (void)block_scan_excl(w.baseOfRank, nExp, w.part, sc);
+      OCT_PHASE_BEGIN
+      for (int i = tid; i < nExp; i += OCT_THREADS) {
+        const uint32_t a = w.nodeOfRank[i];
+        const uint32_t* c = &w.ccnt[4 * a];
+        const int add = (int)((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0)) - 1;
+        if (size + (int)w.baseOfRank[i] + add >= N) OCT_ATOMIC_MIN(&sc[SC_M], i + 1);
+      }
+      OCT_PHASE_END
+      nProc = oct_bcast(&sc[SC_M]);
+      OCT_PHASE_BEGIN
+      for (int i = tid; i < nExp; i += OCT_THREADS) w.procRank[w.nodeOfRank[i]] = i < nProc ? i : -1;
+      OCT_PHASE_END
+    }
+    // ---- creation rank of every child: exclusive scan of non-empty-child counts in processing order ----
+    OCT_PHASE_BEGIN
+    for (int i = tid; i < nProc; i += OCT_THREADS) {
+      const uint32_t* c = &w.ccnt[4 * w.nodeOfRank[i]];
+      w.baseOfRank[i] = (uint32_t)((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0));
+    }
+    OCT_PHASE_END
+    const int T = (int)block_scan_excl(w.baseOfRank, nProc, w.part, sc);
+    // ---- build the new generation B in list order: position = T-1-creation rank ----
+    OCT_PHASE_BEGIN
+    if (tid == 0) sc[SC_NTOEXP] = 0;
+    OCT_PHASE_END
+    OCT_PHASE_BEGIN
+    for (int i = tid; i < nProc; i += OCT_THREADS) {
+      const uint32_t a = w.nodeOfRank[i];
+      const Box b = A[a];
+      const int hx = half_ceil((int)b.urx - (int)b.ulx), hy = half_ceil((int)b.bry - (int)b.uly);
+      uint32_t rank = w.baseOfRank[i];
+      int nmulti = 0;
+      for (int d = 0; d < 4; ++d) {
+        const uint32_t c = w.ccnt[4 * a + d];
+        if (c == 0) continue;
+        const int pos = T - 1 - (int)rank;
+        Box nb;
+        nb.ulx = (uint16_t)((d & 1) ? b.ulx + hx : b.ulx);
+        nb.urx = (uint16_t)((d & 1) ? b.urx : b.ulx + hx);
+        nb.uly = (uint16_t)((d & 2) ? b.uly + hy : b.uly);
+        nb.bry = (uint16_t)((d & 2) ? b.bry : b.uly + hy);
+        B[pos] = nb;
+        cB[pos] = c;
+        nmulti += c > 1;
+        ++rank;
+      }
+      if (nmulti) OCT_ATOMIC_ADD(&sc[SC_NTOEXP], nmulti);
+    }
+    OCT_PHASE_END
+    // ---- move points to their child node; freeze single-point children ----
+    const int newgen = gen + 1;
+    OCT_PHASE_BEGIN
+    for (int p = tid; p < P; p += OCT_THREADS) {
+      const uint32_t st = pstate[p];
+      if (st == ST_FROZEN) continue;
+      const uint32_t a = st & 0xffffu;
+      const int d = (int)(st >> 16);
+      const int r = w.procRank[a];
+      if (r < 0) {
+        pstate[p] = ST_UNPROC | a;  // parent not reached by a truncated careful round
+        continue;
+      }
+      const uint32_t* c = &w.ccnt[4 * a];
+      int lower = 0;
+      for (int dd = 0; dd < d; ++dd) lower += c[dd] > 0;
+      const int pos = T - 1 - ((int)w.baseOfRank[r] + lower);
+      if (cB[pos] == 1) {
+        const int slot = OCT_ATOMIC_ADD(&sc[SC_NOUT], 1);
+        w.outKey[slot] = ((uint32_t)(GEN_MAX - newgen) << 16) | (uint32_t)pos;
+        w.outPt[slot] = (uint32_t)p;
+        pstate[p] = ST_FROZEN;
+      } else {
+        pstate[p] = (uint32_t)pos;
+      }
+    }
+    OCT_PHASE_END
+    const int nToExpand = oct_bcast(&sc[SC_NTOEXP]);
+    size = prev_size - nProc + T;
+    truncated = nProc < nExp;
+    na_prev = na;
+    na = T;
+    gen = newgen;
+    {
+      Box* tb = A;
+      A = B;
+      B = tb;
+      uint32_t* tc = cA;
+      cA = cB;
+      cB = tc;
+    }
+    if (size >= N || size == prev_size) break;  // :1136-1139 / :1201-1202
+    if (!careful && size + 3 * nToExpand > N) careful = true;  // :1140
+  }
+
+  // ---- surviving multi-point nodes: best response, first in candidate order (:1208-1226) ----
+  uint64_t* best = reinterpret_cast<uint64_t*>(w.ccnt);
+  const int nslots = na + (truncated ? na_prev : 0);
+  OCT_PHASE_BEGIN
+  for (int i = tid; i < nslots; i += OCT_THREADS) best[i] = 0;
+  OCT_PHASE_END
+  auto point_key = [&](int p) -> uint64_t {
+    const int x = (int)(cand_xy[p] & 0xffff), y = (int)(cand_xy[p] >> 16);
+    int j = (x - 3) / pr.wCell, i = (y - 3) / pr.hCell;
+    j = j > pr.nCols - 1 ? pr.nCols - 1 : j;
+    i = i > pr.nRows - 1 ? pr.nRows - 1 : i;
+    const uint32_t ord = ((uint32_t)(i * pr.nCols + j) * 128u + (uint32_t)(y - i * pr.hCell)) * 128u + (uint32_t)(x - j * pr.wCell);
+    return ((uint64_t)cand_score[p] << 32) | (uint64_t)(0xFFFFFFFFu - ord);
+  };
+  OCT_PHASE_BEGIN
+  for (int p = tid; p < P; p += OCT_THREADS) {
+    const uint32_t st = pstate[p];
+    if (st == ST_FROZEN) continue;
+    const int slot = (st & ST_UNPROC) ? na + (int)(st & 0xffffu) : (int)st;
+    OCT_ATOMIC_MAX64(&best[slot], point_key(p));
+  }
+  OCT_PHASE_END
+  OCT_PHASE_BEGIN
+  for (int p = tid; p < P; p += OCT_THREADS) {
+    const uint32_t st = pstate[p];
+    if (st == ST_FROZEN) continue;
+    const bool un = (st & ST_UNPROC) != 0;
+    const int slot = un ? na + (int)(st & 0xffffu) : (int)st;
+    if (best[slot] == point_key(p)) {
+      const int o = OCT_ATOMIC_ADD(&sc[SC_NOUT], 1);
+      w.outKey[o] = ((uint32_t)(GEN_MAX - (un ? gen - 1 : gen)) << 16) | (st & 0xffffu);
+      w.outPt[o] = (uint32_t)p;
+    }
+  }
+  OCT_PHASE_END
+
+  // ---- list order = (generation desc, position asc) ----
+  const int nOut = oct_bcast(&sc[SC_NOUT]);
+  uint64_t* srt = reinterpret_cast<uint64_t*>(w.ccnt);
+  int n2 = 1;
+  while (n2 < nOut) n2 <<= 1;
+  OCT_PHASE_BEGIN
+  for (int i = tid; i < n2; i += OCT_THREADS) srt[i] = i < nOut ? (((uint64_t)w.outKey[i] << 32) | w.outPt[i]) : ~0ull;
+  OCT_PHASE_END
+  block_bitonic(srt, n2);
+  OCT_PHASE_BEGIN
+  for (int i = tid; i < nOut && i < sel_cap; i += OCT_THREADS) {
+    const uint32_t p = (uint32_t)(srt[i] & 0xffffffffu);
+    sel_xy[i] = cand_xy[p];
+    sel_score[i] = cand_score[p];
+  }
+  OCT_PHASE_END
+  return nOut;
+}
+
+}  // namespace oct
+}  // namespace uvo
