@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of ORB extract + match on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over one batch of synthetic frames, all inputs already resident in HBM:
+  uvo_extract_batch_device  (pyramid -> per-cell FAST -> quad-tree -> IC angle -> blur -> rBRIEF, B frames)
+  uvo_hamming_knn2_batch_device (frame i vs frame i+1, all-pairs 256-bit Hamming knn-2, B pairs)
+Workload at N=1: BASELINE.json configs[2] -- batch=256 synthetic 640x512 mono frames, 1000 features, 8 levels,
+fastTh 20.  With N GPUs every rank owns its own batch of 256 frames (frame batches shard embarrassingly; weak
+scaling, no data-path collective: torch.distributed/RCCL is used for the timing barrier and the max-over-ranks only).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the kernel with the largest share of device time, its duration
+measured live with HIP events on the library's own stream inside the timed region; `cpu_baseline` is the CPU
+oracle (a line-by-line port of the reference path) timed on this host's cores on a bounded sample of the same frames.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H, NFEAT, NLEVELS, FAST_TH = 640, 512, 1000, 8, 20
+BATCH = 256
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy kernel reaches
+
+
+def level_sizes(w, h, nlevels=NLEVELS, sf=1.2):
+    inv = np.float32(1.0)
+    step = np.float32(np.float32(1.0) / np.float64(np.float32(sf)))
+    out = []
+    for _ in range(nlevels):
+        out.append((int(np.rint(np.float32(w) * inv)), int(np.rint(np.float32(h) * inv))))
+        inv = np.float32(inv * step)
+    return out
+
+
+def algorithmic_bytes_per_frame(w, h, k):
+    """per-kernel algorithmic HBM bytes of one frame (each level materialised once, read once per
+    consuming stage; per-keypoint stages read their footprint once)."""
+    s = [a * b for a, b in level_sizes(w, h)]
+    tot = sum(s)
+    return {
+        "k_pad_level0": 2 * s[0],                       # not in the survey's model (a design that reads the input in place needs none)
+        "k_resize_level": sum(s[:-1]) + sum(s[1:]),     # reads S0..S6, writes S1..S7 (all 7 launches)
+        "k_fast_cells": tot,
+        "k_gauss7": 2 * tot,
+        "k_octree": 0,
+        "k_assemble": 0,
+        "k_describe": 749 * k + (512 + 32) * k + 20 * k,
+        "k_knn2": 64 * k + 12 * k,
+    }
+
+
+def gen_frames(synth, n, seed0):
+    """n frames: chains of a base frame followed by small-affine warps, so consecutive frames truly correspond."""
+    chain = 32
+    out = []
+    for i in range(n):
+        if i % chain == 0:
+            out.append(synth.make_frame(seed0 + i, W, H))
+        else:
+            out.append(synth.warp_frame(out[-1], seed0 + i))
+    return np.stack(out)
+
+
+def cpu_baseline(frames, budget_s=20.0):
+    """The oracle (kind 'port') on one host core: extract every sample frame, knn-2 match consecutive ones."""
+    import oracle_lib
+    o = oracle_lib.Oracle()
+    oe = o.extractor(NFEAT, 1.2, NLEVELS, FAST_TH)
+    t0 = time.perf_counter()
+    prev = None
+    n = 0
+    for img in frames:
+        kp, de = oe(img)
+        if prev is not None and len(prev) and len(de):
+            o.knn2(prev, de)
+        prev = de
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d of this run's 640x512 frames: oracle extract (1000 feats, 8 levels, fastTh 20) + knn-2 match of consecutive "
+                      "frames, 1 thread, g++ -O3 without -march=native" % n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    uvo = importlib.import_module("u-vip-slam_amd")
+    synth = importlib.import_module("u-vip-slam_amd.synth")
+    B = args.batch
+    dev = torch.device("cuda", local_rank)
+
+    frames = gen_frames(synth, B, 1000 + rank * B)   # every rank its own shard of the sequence
+    d_imgs = torch.from_numpy(frames).to(dev)
+
+    ex = uvo.ORBextractor(NFEAT, 1.2, NLEVELS, 0, FAST_TH, max_width=W, max_height=H, max_batch=B, device=local_rank)
+    cap = ex.cap
+    mt = uvo.ORBmatcher(0.8, max_query=cap, max_train=cap, max_batch=B, device=local_rank)
+    # outputs stay in HBM; one extra descriptor slot holds a copy of frame 0 so that pair B-1 = (frame B-1, frame 0)
+    d_kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    d_idx0 = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    d_idx1 = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    d_d0 = torch.zeros((B, cap), dtype=torch.int16, device=dev)
+    d_d1 = torch.zeros((B, cap), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        ex.extract_batch_device(d_imgs.data_ptr(), B, W, H, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap)
+        mt.wait_extractor(ex)
+        mt.knn2_batch_device(B, d_desc.data_ptr(), d_n.data_ptr(), cap, d_desc.data_ptr() + cap * 32, d_n.data_ptr() + 4, cap,
+                             d_idx0.data_ptr(), d_d0.data_ptr(), d_idx1.data_ptr(), d_d1.data_ptr())
+        mt.release_to_extractor(ex)
+
+    def sync_all():
+        ex.synchronize()
+        mt.synchronize()
+        torch.cuda.synchronize()
+
+    # frame 0's descriptors into slot B (halo for the wrap-around pair); they do not change between steps
+    step()
+    sync_all()
+    d_desc[B].copy_(d_desc[0])
+    d_n[B] = d_n[0]
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+
+    ex.profile(True)
+    mt.profile(True)
+    if dist is not None:
+        dist.barrier()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ktimes = dict(ex.kernel_times())
+    ktimes.update(mt.kernel_times())
+    ex.profile(False)
+    mt.profile(False)
+
+    n_kp = d_n[:B].cpu().numpy()
+    matches = int((d_idx1.cpu().numpy() >= 0).sum())
+
+    if rank == 0:
+        frames_total = B * args.steps * world
+        value = frames_total / dt
+        k_mean = float(n_kp.mean())
+        alg = algorithmic_bytes_per_frame(W, H, k_mean)
+        # dominant kernel by device time (all launches of a name together)
+        dom = max(ktimes.items(), key=lambda kv: kv[1][0])[0]
+        dom_ms, dom_launches = ktimes[dom]
+        # per launch: k_resize_level is launched once per level, its model is for all 7 together
+        launches_per_step = dom_launches / args.steps
+        avg_launch_s = dom_ms * 1e-3 / dom_launches
+        bytes_per_launch = alg.get(dom, 0) * B / launches_per_step
+        achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        total_alg = sum(v for kname, v in alg.items() if kname != "k_pad_level0")
+        out = {
+            "metric": "frames/sec ORB extract+match, 640x512 @1000 kp",
+            "value": round(value, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: 1xMI355X per rank, batch=%d synthetic %dx%d mono frames, %d feats, %d levels, "
+                                   "fastTh %d, FullDetect extract + all-pairs 256-bit Hamming knn-2 of consecutive frames, HBM-resident I/O"
+                                   % (B, W, H, NFEAT, NLEVELS, FAST_TH),
+                       "batch_per_gpu": B, "sharding": "frames, no collective", "mean_keypoints_per_frame": round(k_mean, 1),
+                       "knn2_second_neighbours_found": matches},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "avg_launch_ms": round(avg_launch_s * 1e3, 5), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                         "whole_path_GBps": round(total_alg * value / world / 1e9, 2),
+                         "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(ktimes.items())}},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

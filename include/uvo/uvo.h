@@ -120,9 +120,11 @@ int uvo_extractor_read_plane(uvo_extractor* h, int frame, int level, int which, 
 int uvo_extractor_read_candidates(uvo_extractor* h, int frame, int level, int32_t* dst_xys, int cap, int* n);
 
 /*
- * Per-kernel device timing of the last batch call, measured with HIP events on the handle's stream.
+ * Per-kernel device timing, measured with HIP events on the handle's stream around every launch made while
+ * profiling is enabled (uvo_extractor_profile(h, 1); adds two event records per launch).
+ * uvo_extractor_kernel_times() waits for the stream, then reports and clears what was recorded:
  * names: '\n'-separated kernel names into `names` (cap bytes); ms[i]: summed duration of that kernel's launches;
- * launches[i]: number of launches.  Enabled with uvo_extractor_profile(h, 1) (adds event overhead).
+ * launches[i]: number of launches.
  */
 int uvo_extractor_profile(uvo_extractor* h, int enable);
 int uvo_extractor_kernel_times(uvo_extractor* h, char* names, int names_cap, float* ms, int32_t* launches, int cap, int* n);
@@ -176,6 +178,18 @@ int uvo_search_by_projection(uvo_matcher* m, const uvo_keypoint* kp, int n, cons
                              int32_t* assigned, int nmp, const float* proj_x, const float* proj_y, const int32_t* level,
                              const float* view_cos, const uint8_t* in_view, const uint8_t* mp_desc, const float* scale_factors,
                              int nlevels, float th, float nnratio, int* n_matches);
+
+/*
+ * Device-side ordering between the two handles' streams (no host synchronisation): work enqueued on the
+ * matcher after uvo_matcher_wait_extractor() starts only when everything enqueued on the extractor so far
+ * has finished, and vice versa.  Used when descriptors produced by uvo_extract_batch_device() feed
+ * uvo_hamming_knn2_batch_device() directly in HBM.
+ */
+int uvo_matcher_wait_extractor(uvo_matcher* m, uvo_extractor* h);
+int uvo_extractor_wait_matcher(uvo_extractor* h, uvo_matcher* m);
+/* per-kernel timing of the matcher, same contract as uvo_extractor_profile / uvo_extractor_kernel_times */
+int uvo_matcher_profile(uvo_matcher* m, int enable);
+int uvo_matcher_kernel_times(uvo_matcher* m, char* names, int names_cap, float* ms, int32_t* launches, int cap, int* n);
 
 /* last HIP / argument error text for the calling thread's most recent failing call (never NULL) */
 const char* uvo_last_error(void);

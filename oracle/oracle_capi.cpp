@@ -79,6 +79,12 @@ int orc_fast(const uint8_t* img, int w, int hgt, long stride, int threshold, int
   for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
   return (int)v.size();
 }
+int orc_fast_bruteforce(const uint8_t* img, int w, int hgt, long stride, int threshold, int nms, KeyPoint* out, int cap) {
+  std::vector<KeyPoint> v;
+  fast9_16_bruteforce(View{(uint8_t*)img, w, hgt, stride}, threshold, nms != 0, v);
+  for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
+  return (int)v.size();
+}
 void orc_gauss_taps(int* taps7) { gaussian_taps_7_sigma2(taps7); }
 // plane = padded buffer (w+2*pad) x (h+2*pad) tight; blurs the interior in place
 void orc_gauss7_padded(uint8_t* plane, int w, int hgt, int pad) {

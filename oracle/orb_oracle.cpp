@@ -140,7 +140,9 @@ static bool fast_corner(const View& img, int x, int y, int t, int* score) {
   return corner;
 }
 
-void fast9_16(const View& img, int threshold, bool nms, std::vector<KeyPoint>& out) {
+// `quick` enables FAST_t's cheap necessary conditions (any 9-arc contains one pixel of every opposite pair
+// (k, k+8)) before the definitional test; results are identical with and without it (tests check that).
+static void fast9_16_impl(const View& img, int threshold, bool nms, std::vector<KeyPoint>& out, bool quick) {
   out.clear();
   const int w = img.w, h = img.h;
   if (w < 7 || h < 7) return;
@@ -149,6 +151,24 @@ void fast9_16(const View& img, int threshold, bool nms, std::vector<KeyPoint>& o
   std::vector<uint8_t> is((size_t)w * h, 0);
   for (int y = 3; y < h - 3; ++y)
     for (int x = 3; x < w - 3; ++x) {
+      if (quick) {
+        const int v = img.row(y)[x];
+        auto cls = [&](int k) {
+          const int p = img.row(y + kCircle[k][1])[x + kCircle[k][0]];
+          return p < v - threshold ? 1 : (p > v + threshold ? 2 : 0);
+        };
+        int d = cls(0) | cls(8);
+        if (!d) continue;
+        d &= cls(2) | cls(10);
+        d &= cls(4) | cls(12);
+        d &= cls(6) | cls(14);
+        if (!d) continue;
+        d &= cls(1) | cls(9);
+        d &= cls(3) | cls(11);
+        d &= cls(5) | cls(13);
+        d &= cls(7) | cls(15);
+        if (!d) continue;
+      }
       int s;
       if (fast_corner(img, x, y, threshold, &s)) {
         is[(size_t)y * w + x] = 1;
@@ -174,6 +194,11 @@ void fast9_16(const View& img, int threshold, bool nms, std::vector<KeyPoint>& o
       }
       out.push_back(KeyPoint{(float)x, (float)y, 7.f, -1.f, (float)s, 0, -1});
     }
+}
+
+void fast9_16(const View& img, int threshold, bool nms, std::vector<KeyPoint>& out) { fast9_16_impl(img, threshold, nms, out, true); }
+void fast9_16_bruteforce(const View& img, int threshold, bool nms, std::vector<KeyPoint>& out) {
+  fast9_16_impl(img, threshold, nms, out, false);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -46,6 +46,7 @@ int cv_round_d(double v);  // cvRound(double)
 void copy_make_border_reflect101(const View& src, uint8_t* dst, ptrdiff_t dstep, int top, int bottom, int left, int right);
 void resize_linear_u8(const View& src, const View& dst);
 void fast9_16(const View& img, int threshold, bool nms, std::vector<KeyPoint>& out);
+void fast9_16_bruteforce(const View& img, int threshold, bool nms, std::vector<KeyPoint>& out);  // no early rejection
 void gaussian_taps_7_sigma2(int taps[7]);
 // blur the ROI `roi` (which must sit >= 3 px inside its parent buffer) in place,
 // border taps read the parent's pixels (non-isolated sub-matrix semantics)

@@ -35,6 +35,7 @@ class Oracle:
         L.orc_border101.argtypes = [vp, ci, ci, cl, vp, ci]
         L.orc_resize_linear.argtypes = [vp, ci, ci, cl, vp, ci, ci]
         L.orc_fast.argtypes = [vp, ci, ci, cl, ci, ci, vp, ci]
+        L.orc_fast_bruteforce.argtypes = [vp, ci, ci, cl, ci, ci, vp, ci]
         L.orc_gauss_taps.argtypes = [vp]
         L.orc_gauss7_padded.argtypes = [vp, ci, ci, ci]
         L.orc_fast_atan2.restype = cf
@@ -69,11 +70,12 @@ class Oracle:
         self.L.orc_resize_linear(img.ctypes.data, w, h, img.strides[0], out.ctypes.data, dw, dh)
         return out
 
-    def fast(self, img, threshold, nms=True):
+    def fast(self, img, threshold, nms=True, bruteforce=False):
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
         out = np.zeros(w * h, KP)
-        n = self.L.orc_fast(img.ctypes.data, w, h, img.strides[0], threshold, 1 if nms else 0, out.ctypes.data, len(out))
+        fn = self.L.orc_fast_bruteforce if bruteforce else self.L.orc_fast
+        n = fn(img.ctypes.data, w, h, img.strides[0], threshold, 1 if nms else 0, out.ctypes.data, len(out))
         return out[:n].copy()
 
     def gauss_taps(self):

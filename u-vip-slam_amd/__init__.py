@@ -29,7 +29,8 @@ ABI_SYMBOLS = [
     "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_extractor_synchronize", "uvo_extractor_level_dims",
     "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
-    "uvo_hamming_matrix", "uvo_search_by_projection", "uvo_last_error", "uvo_device_info",
+    "uvo_hamming_matrix", "uvo_search_by_projection", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
+    "uvo_matcher_kernel_times", "uvo_last_error", "uvo_device_info",
 ]
 
 
@@ -81,6 +82,10 @@ def _load():
     lib.uvo_hamming_knn2_batch_device.argtypes = [vp, ci, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp]
     lib.uvo_hamming_matrix.argtypes = [vp, vp, ci, vp, ci, vp]
     lib.uvo_search_by_projection.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp]
+    lib.uvo_matcher_wait_extractor.argtypes = [vp, vp]
+    lib.uvo_extractor_wait_matcher.argtypes = [vp, vp]
+    lib.uvo_matcher_profile.argtypes = [vp, ci]
+    lib.uvo_matcher_kernel_times.argtypes = [vp, ctypes.c_char_p, ci, vp, vp, ci, vp]
     return lib
 
 
@@ -296,6 +301,30 @@ class ORBmatcher:
         rc = lib.uvo_matcher_synchronize(self._h)
         if rc:
             raise UvoError(rc, "uvo_matcher_synchronize")
+
+    def wait_extractor(self, ex):
+        rc = lib.uvo_matcher_wait_extractor(self._h, ex._h)
+        if rc:
+            raise UvoError(rc, "uvo_matcher_wait_extractor")
+
+    def release_to_extractor(self, ex):
+        rc = lib.uvo_extractor_wait_matcher(ex._h, self._h)
+        if rc:
+            raise UvoError(rc, "uvo_extractor_wait_matcher")
+
+    def profile(self, enable=True):
+        lib.uvo_matcher_profile(self._h, 1 if enable else 0)
+
+    def kernel_times(self):
+        names = ctypes.create_string_buffer(4096)
+        ms = np.zeros(64, np.float32)
+        launches = np.zeros(64, np.int32)
+        n = ctypes.c_int()
+        rc = lib.uvo_matcher_kernel_times(self._h, names, 4096, ms.ctypes.data, launches.ctypes.data, 64, ctypes.byref(n))
+        if rc:
+            raise UvoError(rc, "uvo_matcher_kernel_times")
+        nm = names.value.decode().split("\n")[:n.value]
+        return {nm[i]: (float(ms[i]), int(launches[i])) for i in range(n.value)}
 
     def SearchByProjection(self, kp, desc, bounds, assigned, proj_x, proj_y, level, view_cos, in_view, mp_desc, scale_factors, th=1.0):
         """SearchByProjection(FrameKTL&, vector<MapPoint*>&, th) (src/ORBmatcher.cc:49-125).

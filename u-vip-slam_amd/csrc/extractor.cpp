@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "profiler.hpp"
 #include "uvo_math.hpp"
 
 namespace uvo {
@@ -33,11 +34,6 @@ static inline int cv_floor_host(float v) {
   int i = (int)v;
   return i - (i > v);
 }
-
-struct ProfRec {
-  const char* name;
-  hipEvent_t a, b;
-};
 
 }  // namespace uvo
 
@@ -77,9 +73,7 @@ struct uvo_extractor {
   uint8_t* d_out_desc = nullptr;
   int32_t *d_n_out = nullptr, *d_n_in = nullptr, *d_nfn = nullptr, *d_grid = nullptr;
   size_t grid_bytes = 0;
-  // profiling
-  bool profile = false;
-  std::vector<ProfRec> prof;
+  Profiler prof;
 };
 
 namespace uvo {
@@ -268,33 +262,9 @@ static int set_geometry(uvo_extractor* h, int width, int height) {
   return UVO_OK;
 }
 
-struct ProfScope {
-  uvo_extractor* h;
-  ProfRec r;
-  ProfScope(uvo_extractor* h_, const char* name) : h(h_) {
-    r.name = name;
-    r.a = r.b = nullptr;
-    if (h->profile) {
-      hipEventCreate(&r.a);
-      hipEventCreate(&r.b);
-      hipEventRecord(r.a, h->stream);
-    }
-  }
-  ~ProfScope() {
-    if (h->profile) {
-      hipEventRecord(r.b, h->stream);
-      h->prof.push_back(r);
-    }
-  }
+struct ProfScope : Profiler::Scope {
+  ProfScope(uvo_extractor* h, const char* name) : Profiler::Scope(&h->prof, name, h->stream) {}
 };
-
-static void prof_clear(uvo_extractor* h) {
-  for (auto& r : h->prof) {
-    hipEventDestroy(r.a);
-    hipEventDestroy(r.b);
-  }
-  h->prof.clear();
-}
 
 // The launch sequence of one batch (everything on h->stream, nothing synchronous).
 static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
@@ -311,7 +281,6 @@ static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, 
   if (rc) return rc;
   const Geom& g = h->geom;
   hipStream_t s = h->stream;
-  if (h->profile) prof_clear(h);
   h->last_batch = batch;
   UVO_HIP_CHECK(hipMemsetAsync(h->d_cand_count, 0, sizeof(int32_t) * batch * g.nlevels, s));
   {
@@ -454,7 +423,7 @@ void uvo_extractor_destroy(uvo_extractor* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
-  prof_clear(h);
+  h->prof.clear();
   void* ptrs[] = {h->d_pyr,    h->d_blur,   h->d_cand_xy, h->d_cand_sc, h->d_pstate, h->d_sel_xy,  h->d_sel_sc,  h->d_cand_count, h->d_sel_count,
                   h->d_n_final, h->d_flist, h->d_lv,      h->d_cells,   h->d_xofs,   h->d_xalpha,  h->d_yofs,    h->d_ybeta,      h->d_pattern,
                   h->d_umax,   h->d_imgs,   h->d_out_kp,  h->d_out_desc, h->d_n_out, h->d_in_kp,   h->d_n_in,    h->d_nfn,        h->d_grid};
@@ -630,8 +599,10 @@ int uvo_extractor_read_candidates(uvo_extractor* h, int frame, int level, int32_
 
 int uvo_extractor_profile(uvo_extractor* h, int enable) {
   if (!h) return fail(UVO_E_BADARG, "null handle");
-  h->profile = enable != 0;
-  if (!h->profile) prof_clear(h);
+  UVO_HIP_CHECK(hipSetDevice(h->device));
+  UVO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  h->prof.on = enable != 0;
+  h->prof.clear();
   return UVO_OK;
 }
 
@@ -639,30 +610,11 @@ int uvo_extractor_kernel_times(uvo_extractor* h, char* names, int names_cap, flo
   if (!h || !names || !ms || !launches || !n) return fail(UVO_E_BADARG, "null pointer");
   UVO_HIP_CHECK(hipSetDevice(h->device));
   UVO_HIP_CHECK(hipStreamSynchronize(h->stream));
-  std::vector<std::string> nm;
-  std::vector<float> tt;
-  std::vector<int> cc;
-  for (auto& r : h->prof) {
-    float t = 0;
-    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
-    size_t k = 0;
-    for (; k < nm.size(); ++k)
-      if (nm[k] == r.name) break;
-    if (k == nm.size()) nm.push_back(r.name), tt.push_back(0.f), cc.push_back(0);
-    tt[k] += t;
-    cc[k] += 1;
-  }
-  std::string joined;
-  int m = 0;
-  for (size_t k = 0; k < nm.size() && (int)k < cap; ++k, ++m) {
-    joined += nm[k];
-    joined += '\n';
-    ms[k] = tt[k];
-    launches[k] = cc[k];
-  }
-  snprintf(names, names_cap, "%s", joined.c_str());
-  *n = m;
+  *n = h->prof.report(names, names_cap, ms, launches, cap);
   return UVO_OK;
 }
+
+hipStream_t uvo_extractor_stream_internal(uvo_extractor* h) { return h->stream; }
+int uvo_extractor_device_internal(uvo_extractor* h) { return h->device; }
 
 }  // extern "C"

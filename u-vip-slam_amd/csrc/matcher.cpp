@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "profiler.hpp"
 
 namespace uvo {
 void launch_sbp(hipStream_t s, const uvo_keypoint* d_kp, int n, const uint8_t* d_desc, int min_x, int min_y, int max_x, int max_y,
@@ -15,6 +16,8 @@ void launch_sbp(hipStream_t s, const uvo_keypoint* d_kp, int n, const uint8_t* d
                 int32_t* d_owner_next, int32_t* d_choice, int32_t* d_n_matches, int stage);
 int matcher_fail(int code, const char* msg);
 }  // namespace uvo
+extern "C" hipStream_t uvo_extractor_stream_internal(uvo_extractor* h);
+extern "C" int uvo_extractor_device_internal(uvo_extractor* h);
 
 using namespace uvo;
 
@@ -36,6 +39,8 @@ struct uvo_matcher {
   uint8_t *d_inview = nullptr, *d_mpdesc = nullptr;
   uint32_t* d_cand = nullptr;
   size_t cand_elems = 0;
+  hipEvent_t ev = nullptr;
+  Profiler prof;
 };
 
 namespace uvo {
@@ -102,6 +107,10 @@ int uvo_matcher_create(const uvo_matcher_cfg* cfg, uvo_matcher** out) {
   A(m_alloc(&m->d_scale, (size_t)kMaxLevels * 4));
   A(m_alloc(&m->d_nm, (size_t)1));
 #undef A
+  if (hipEventCreateWithFlags(&m->ev, hipEventDisableTiming) != hipSuccess) {
+    uvo_matcher_destroy(m);
+    return matcher_fail(UVO_E_HIP, "event creation failed");
+  }
   *out = m;
   return UVO_OK;
 }
@@ -116,6 +125,8 @@ void uvo_matcher_destroy(uvo_matcher* m) {
                   m->d_cand};
   for (void* p : ptrs)
     if (p) hipFree(p);
+  m->prof.clear();
+  if (m->ev) (void)hipEventDestroy(m->ev);
   if (m->stream) hipStreamDestroy(m->stream);
   delete m;
 }
@@ -166,8 +177,11 @@ int uvo_hamming_knn2_batch_device(uvo_matcher* m, int pairs, const uint8_t* d_q,
   if (!m || !d_q || !d_t || !d_nq || !d_nt || !d_idx0 || !d_d0 || !d_idx1 || !d_d1) return matcher_fail(UVO_E_BADARG, "null pointer");
   if (pairs < 1 || pairs > m->cfg.max_batch || q_stride < 1 || t_stride < 1) return matcher_fail(UVO_E_BADARG, "bad batch / stride");
   UVO_HIP_CHECK(hipSetDevice(m->device));
-  launch_knn2(m->stream, pairs, m->cfg.max_query, d_q, d_nq, 0, q_stride, d_t, d_nt, 0, t_stride, nullptr, m->cfg.max_query, d_idx0, d_d0, d_idx1,
-              d_d1);
+  {
+    Profiler::Scope ps(&m->prof, "k_knn2", m->stream);
+    launch_knn2(m->stream, pairs, m->cfg.max_query, d_q, d_nq, 0, q_stride, d_t, d_nt, 0, t_stride, nullptr, m->cfg.max_query, d_idx0, d_d0,
+                d_idx1, d_d1);
+  }
   UVO_HIP_CHECK(hipGetLastError());
   return UVO_OK;
 }
@@ -248,6 +262,41 @@ int uvo_search_by_projection(uvo_matcher* m, const uvo_keypoint* kp, int n, cons
   UVO_HIP_CHECK(hipMemcpyAsync(&nm, m->d_nm, 4, hipMemcpyDeviceToHost, s));
   UVO_HIP_CHECK(hipStreamSynchronize(s));
   *n_matches = nm;
+  return UVO_OK;
+}
+
+int uvo_matcher_wait_extractor(uvo_matcher* m, uvo_extractor* h) {
+  if (!m || !h) return matcher_fail(UVO_E_BADARG, "null handle");
+  if (uvo_extractor_device_internal(h) != m->device) return matcher_fail(UVO_E_BADARG, "handles live on different devices");
+  UVO_HIP_CHECK(hipSetDevice(m->device));
+  UVO_HIP_CHECK(hipEventRecord(m->ev, uvo_extractor_stream_internal(h)));
+  UVO_HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev, 0));
+  return UVO_OK;
+}
+
+int uvo_extractor_wait_matcher(uvo_extractor* h, uvo_matcher* m) {
+  if (!m || !h) return matcher_fail(UVO_E_BADARG, "null handle");
+  if (uvo_extractor_device_internal(h) != m->device) return matcher_fail(UVO_E_BADARG, "handles live on different devices");
+  UVO_HIP_CHECK(hipSetDevice(m->device));
+  UVO_HIP_CHECK(hipEventRecord(m->ev, m->stream));
+  UVO_HIP_CHECK(hipStreamWaitEvent(uvo_extractor_stream_internal(h), m->ev, 0));
+  return UVO_OK;
+}
+
+int uvo_matcher_profile(uvo_matcher* m, int enable) {
+  if (!m) return matcher_fail(UVO_E_BADARG, "null handle");
+  UVO_HIP_CHECK(hipSetDevice(m->device));
+  UVO_HIP_CHECK(hipStreamSynchronize(m->stream));
+  m->prof.on = enable != 0;
+  m->prof.clear();
+  return UVO_OK;
+}
+
+int uvo_matcher_kernel_times(uvo_matcher* m, char* names, int names_cap, float* ms, int32_t* launches, int cap, int* n) {
+  if (!m || !names || !ms || !launches || !n) return matcher_fail(UVO_E_BADARG, "null pointer");
+  UVO_HIP_CHECK(hipSetDevice(m->device));
+  UVO_HIP_CHECK(hipStreamSynchronize(m->stream));
+  *n = m->prof.report(names, names_cap, ms, launches, cap);
   return UVO_OK;
 }
 
