@@ -69,6 +69,31 @@ def gen_frames(synth, n, seed0):
     return np.stack(out)
 
 
+def shard_seed0(rank, batch):
+    """Frames shard embarrassingly: rank r owns frames [r*batch, (r+1)*batch) of the synthetic sequence."""
+    return 1000 + rank * batch
+
+
+def timed_steps(step, sync, steps, dist=None, device=None):
+    """Time exactly `steps` steps bracketed by barrier + full device sync on both sides; returns the MAX over ranks (s)."""
+    import torch
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
 def cpu_baseline(frames, budget_s=20.0):
     """The oracle (kind 'port') on one host core: extract every sample frame, knn-2 match consecutive ones."""
     import oracle_lib
@@ -118,7 +143,7 @@ def main():
     B = args.batch
     dev = torch.device("cuda", local_rank)
 
-    frames = gen_frames(synth, B, 1000 + rank * B)   # every rank its own shard of the sequence
+    frames = gen_frames(synth, B, shard_seed0(rank, B))   # every rank its own shard of the sequence
     d_imgs = torch.from_numpy(frames).to(dev)
 
     ex = uvo.ORBextractor(NFEAT, 1.2, NLEVELS, 0, FAST_TH, max_width=W, max_height=H, max_batch=B, device=local_rank)
@@ -157,20 +182,7 @@ def main():
 
     ex.profile(True)
     mt.profile(True)
-    if dist is not None:
-        dist.barrier()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed_steps(step, sync_all, args.steps, dist, dev)
     ktimes = dict(ex.kernel_times())
     ktimes.update(mt.kernel_times())
     ex.profile(False)

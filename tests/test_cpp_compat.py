@@ -1,0 +1,68 @@
+"""The C++ adaptors with the reference's class signatures (include/uvo/compat/) driven from a C++ program, the way
+src/Tracking.cc drives USLAM::ORBextractor / USLAM::ORBmatcher; results checked against the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "tests", "cpp", "compat_driver")
+
+
+def build_driver():
+    src = os.path.join(ROOT, "tests", "cpp", "compat_driver.cpp")
+    hdrs = [os.path.join(ROOT, "include", "uvo", "compat", f) for f in ("ORBextractor.h", "ORBmatcher.h")] + [os.path.join(ROOT, "include", "uvo", "uvo.h")]
+    if not os.path.exists(DRIVER) or max(os.path.getmtime(p) for p in [src] + hdrs) > os.path.getmtime(DRIVER):
+        subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-o", DRIVER,
+                               "-L" + os.path.join(ROOT, "u-vip-slam_amd"), "-luvo", "-Wl,-rpath,$ORIGIN/../../u-vip-slam_amd"])
+    return DRIVER
+
+
+def test_adaptor_headers_compile_as_cxx11():
+    """The reference is built as C++11 (CMakeLists.txt:16); the adaptors must compile in that dialect with plain g++."""
+    build_driver()
+    assert os.path.exists(DRIVER)
+
+
+@pytest.mark.gpu
+def test_cpp_adaptors_match_oracle(tmp_path, oracle, synth):
+    build_driver()
+    w, h = 752, 480
+    img = synth.make_frame(31337, w, h)
+    oe = oracle.extractor(1000, 1.2, 8, 7)
+    kp_o, de_o = oe(img)
+    n = len(kp_o)
+    rng = np.random.default_rng(2)
+    M = 3000
+    src = rng.integers(0, n, M)
+    mp_desc = rng.integers(0, 256, (M, 32), dtype=np.uint8)
+    true = rng.random(M) < 0.5
+    flips = rng.random((M, 256)) < 0.05
+    mp_desc[true] = np.packbits(np.unpackbits(de_o[src], axis=1) ^ flips, axis=1)[true]
+    px = (kp_o["x"][src] + rng.normal(0, 1.5, M)).astype(np.float32)
+    py = (kp_o["y"][src] + rng.normal(0, 1.5, M)).astype(np.float32)
+    level = np.clip(kp_o["octave"][src] + rng.integers(-1, 2, M), 0, 7).astype(np.int32)
+    vc = np.where(rng.random(M) < 0.5, 0.999, 0.9).astype(np.float32)
+    inview = (rng.random(M) < 0.9).astype(np.uint8)
+    img_p, mp_p, out_p = tmp_path / "img.raw", tmp_path / "mp.bin", tmp_path / "out.bin"
+    img.tofile(img_p)
+    with open(mp_p, "wb") as f:
+        for i in range(M):
+            f.write(struct.pack("<ffifB", px[i], py[i], level[i], vc[i], inview[i]) + mp_desc[i].tobytes())
+    r = subprocess.run([DRIVER, str(img_p), str(w), str(h), str(mp_p), str(out_p)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(out_p, "rb").read()
+    n_g = struct.unpack_from("<i", raw, 0)[0]
+    assert n_g == n
+    kp_g = np.frombuffer(raw, oracle_lib.KP, n, 4)
+    de_g = np.frombuffer(raw, np.uint8, n * 32, 4 + 28 * n).reshape(n, 32)
+    nm_g = struct.unpack_from("<i", raw, 4 + 60 * n)[0]
+    a_g = np.frombuffer(raw, np.int32, n, 8 + 60 * n)
+    assert kp_g.tobytes() == kp_o.tobytes() and (de_g == de_o).all()
+    a_o = np.full(n, -1, np.int32)
+    nm_o = oracle.search_by_projection(kp_o, de_o, (0, 0, w, h), a_o, px, py, level, vc, inview, mp_desc, oe.scale, 1.0, 0.8)
+    assert nm_g == nm_o and (a_g == a_o).all() and nm_g > 200

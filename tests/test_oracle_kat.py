@@ -1,0 +1,426 @@
+"""Known-answer tests that pin the CPU oracle (the reference has no tests or fixtures of its own,
+so every answer here is hand-derivable from the reference sources, or cross-checked by an independent numpy
+formulation written in this file)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- E1: constructor tables (src/ORBextractor.cc:458-512) ----------------------------------------------------
+def test_ctor_tables(oracle):
+    e = oracle.extractor(1000, 1.2, 8, 20)
+    assert e.quota.tolist() == [217, 181, 151, 126, 105, 87, 73, 60]
+    assert e.umax.tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    s = np.float32(1.0)
+    for i in range(8):
+        assert e.scale[i] == s
+        s = np.float32(np.float64(s) * np.float64(np.float32(1.2)))
+    assert oracle.extractor(400, 1.2, 8, 20).quota.tolist() == [87, 72, 60, 50, 42, 35, 29, 25]
+    assert oracle.extractor(2000, 1.2, 8, 20).quota.tolist() == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert int(oracle.extractor(1000, 1.2, 8, 20).quota.sum()) == 1000
+
+
+# ---- E2: pyramid geometry (Appendix B) -----------------------------------------------------------------------
+@pytest.mark.parametrize("wh,expect", [
+    ((640, 512), [(640, 512), (533, 427), (444, 356), (370, 296), (309, 247), (257, 206), (214, 171), (179, 143)]),
+    ((1920, 1080), [(1920, 1080), (1600, 900), (1333, 750), (1111, 625), (926, 521), (772, 434), (643, 362), (536, 301)]),
+    ((752, 480), [(752, 480), (627, 400), (522, 333), (435, 278), (363, 231), (302, 193), (252, 161), (210, 134)]),
+])
+def test_pyramid_sizes(oracle, wh, expect):
+    e = oracle.extractor(1000, 1.2, 8, 20)
+    e(np.zeros((wh[1], wh[0]), np.uint8))
+    assert [e.level_dims(l) for l in range(8)] == expect
+
+
+def test_border_reflect101(oracle):
+    img = np.arange(7 * 9, dtype=np.uint8).reshape(7, 9)
+    out = oracle.border101(img, pad=3)
+    ref = np.pad(img, 3, mode="reflect")  # numpy 'reflect' == BORDER_REFLECT_101 (edge not repeated)
+    np.testing.assert_array_equal(out, ref)
+
+
+# ---- A.2 resize -----------------------------------------------------------------------------------------------
+def test_resize_constant_and_identity(oracle):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (40, 50), dtype=np.uint8)
+    np.testing.assert_array_equal(oracle.resize_linear(img, 50, 40), img)  # scale 1: fx = fy = 0
+    c = np.full((37, 53), 137, np.uint8)
+    assert (oracle.resize_linear(c, 44, 31) == 137).all()
+
+
+def test_resize_against_float_bilinear(oracle):
+    rng = np.random.default_rng(1)
+    src = rng.integers(0, 256, (96, 120), dtype=np.uint8)
+    dw, dh = 100, 80
+    got = oracle.resize_linear(src, dw, dh).astype(np.float64)
+    sx, sy = 120 / dw, 96 / dh
+    fx = (np.arange(dw) + 0.5) * sx - 0.5
+    fy = (np.arange(dh) + 0.5) * sy - 0.5
+    x0 = np.floor(fx).astype(int)
+    y0 = np.floor(fy).astype(int)
+    ax, ay = fx - x0, fy - y0
+    s = src.astype(np.float64)
+    x1, y1 = np.minimum(x0 + 1, 119), np.minimum(y0 + 1, 95)
+    ref = (s[y0][:, x0] * (1 - ax) + s[y0][:, x1] * ax) * (1 - ay)[:, None] + (s[y1][:, x0] * (1 - ax) + s[y1][:, x1] * ax) * ay[:, None]
+    assert np.abs(got - ref).max() <= 1.0  # 11-bit fixed point vs exact bilinear
+
+
+def test_resize_fixed_point_formula_by_hand(oracle):
+    # 4x1 -> 2x1: fx = (dx+0.5)*2-0.5 = 0.5, 2.5 -> weights 1024/1024 on pixels (0,1) and (2,3); single row -> beta = (2048, 0)
+    src = np.array([[10, 20, 200, 101]], np.uint8)
+    out = oracle.resize_linear(src, 2, 1)
+    for k, (a, b) in enumerate(((10, 20), (200, 101))):
+        r = a * 1024 + b * 1024
+        assert out[0, k] == ((((2048 * (r >> 4)) >> 16) + ((0 * (r >> 4)) >> 16) + 2) >> 2)
+
+
+# ---- A.3 FAST -------------------------------------------------------------------------------------------------
+CIRCLE = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2),
+          (-1, 3)]
+
+
+def _fast_numpy(img, t, nms=True):
+    """Independent formulation: score = max over 9-arcs of the minimum signed contrast, minus 1; corner iff score >= t
+    ... computed per pixel with plain python/numpy, no early exits."""
+    h, w = img.shape
+    I = img.astype(np.int32)
+    score = np.zeros((h, w), np.int32)
+    corner = np.zeros((h, w), bool)
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            d = np.array([I[y + dy, x + dx] - I[y, x] for dx, dy in CIRCLE])
+            dd = np.concatenate([d, d])
+            best = -10 ** 9
+            for s in range(16):
+                arc = dd[s:s + 9]
+                best = max(best, arc.min(), (-arc).min())
+            if best > t:
+                corner[y, x] = True
+                score[y, x] = best - 1
+    pts = []
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            if not corner[y, x]:
+                continue
+            s = score[y, x]
+            nb = score[y - 1:y + 2, x - 1:x + 2].copy()
+            nb[1, 1] = -1
+            if nms and not (s > nb.max()):
+                continue
+            pts.append((x, y, s))
+    return pts
+
+
+@pytest.mark.parametrize("seed,t", [(0, 20), (1, 7), (2, 40), (3, 0)])
+def test_fast_matches_independent_bruteforce(oracle, seed, t):
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (37, 41), dtype=np.uint8)
+    if seed == 1:  # smoother content: blocks + noise
+        img = (np.kron(rng.integers(0, 2, (10, 11)), np.ones((4, 4))) * 120 + rng.integers(0, 30, (40, 44)))[:37, :41].astype(np.uint8)
+    ref = _fast_numpy(img, t)
+    for brute in (False, True):
+        got = oracle.fast(img, t, True, bruteforce=brute)
+        assert [(int(k["x"]), int(k["y"]), int(k["response"])) for k in got] == ref
+        assert (got["size"] == 7).all() and (got["angle"] == -1).all() and (got["octave"] == 0).all() and (got["class_id"] == -1).all()
+    ref_nonms = _fast_numpy(img, t, nms=False)
+    got = oracle.fast(img, t, False)
+    assert [(int(k["x"]), int(k["y"]), int(k["response"])) for k in got] == ref_nonms
+
+
+def test_fast_too_small_roi(oracle):
+    assert len(oracle.fast(np.full((6, 40), 9, np.uint8), 5)) == 0
+    assert len(oracle.fast(np.full((40, 6), 9, np.uint8), 5)) == 0
+
+
+def test_fast_single_bright_dot_is_a_dark_ring_corner(oracle):
+    img = np.full((15, 15), 50, np.uint8)
+    img[7, 7] = 200  # centre brighter than the whole ring: all 16 ring pixels are darker by 150
+    got = oracle.fast(img, 20)
+    assert len(got) == 1 and (int(got[0]["x"]), int(got[0]["y"]), int(got[0]["response"])) == (7, 7, 149)
+
+
+# ---- A.4 Gaussian ---------------------------------------------------------------------------------------------
+def test_gauss_taps_and_constant(oracle):
+    assert oracle.gauss_taps().tolist() == [18, 34, 49, 55, 49, 34, 18]  # sums to 257: OpenCV's integer engine brightens slightly
+    plane = np.full((40 + 32, 50 + 32), 100, np.uint8)
+    out = oracle.gauss7_padded(plane)
+    assert (out[16:-16, 16:-16] == ((100 * 257 * 257 + 32768) >> 16)).all()
+    assert (out[:16] == 100).all()  # pad untouched
+    sat = oracle.gauss7_padded(np.full((72, 82), 255, np.uint8))
+    assert (sat[16:-16, 16:-16] == 255).all()  # saturate_cast
+
+
+def test_gauss_impulse_and_border_reads_real_pad(oracle):
+    taps = np.array([18, 34, 49, 55, 49, 34, 18])
+    plane = np.zeros((30 + 32, 30 + 32), np.uint8)
+    plane[16 + 10, 16 + 12] = 200
+    out = oracle.gauss7_padded(plane)[16:-16, 16:-16].astype(int)
+    ref = (np.outer(taps, taps) * 200 + 32768) >> 16
+    np.testing.assert_array_equal(out[7:14, 9:16], ref)
+    # a bright pixel that exists ONLY in the pad (not the reflection of anything) must leak into the blurred interior
+    plane = np.zeros((62, 62), np.uint8)
+    plane[16 + 5, 15] = 255  # x = -1
+    out = oracle.gauss7_padded(plane)[16:-16, 16:-16].astype(int)
+    assert out[5, 0] == (49 * 55 * 255 + 32768) >> 16 and out[5, 2] == (18 * 55 * 255 + 32768) >> 16 and out[5, 3] == 0
+
+
+# ---- A.5 fastAtan2 / E6 IC_Angle ------------------------------------------------------------------------------
+def test_fast_atan2(oracle):
+    assert oracle.fast_atan2(0, 0) == 0.0
+    assert oracle.fast_atan2(0, 5) == 0.0
+    assert oracle.fast_atan2(5, 0) == 90.0
+    assert abs(oracle.fast_atan2(0, -5) - 180.0) < 1e-4
+    assert oracle.fast_atan2(-5, 0) == 270.0
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        y, x = rng.integers(-20000, 20000, 2)
+        if x == 0 and y == 0:
+            continue
+        ref = np.degrees(np.arctan2(float(y), float(x))) % 360.0
+        got = oracle.fast_atan2(float(y), float(x))
+        assert min(abs(got - ref), 360 - abs(got - ref)) < 0.3  # documented accuracy of the polynomial
+        assert 0.0 <= got <= 360.0
+
+
+def test_ic_angle_analytic(oracle):
+    e = oracle.extractor(1000, 1.2, 8, 20)
+    yy, xx = np.mgrid[0:96, 0:96]
+    const = np.full((96, 96), 77, np.uint8)
+    assert e.ic_angle(const, 30, 30) == 0.0                          # m01 = m10 = 0 by symmetry
+    assert e.ic_angle((xx * 2).astype(np.uint8), 30, 30) == 0.0      # +x ramp
+    assert e.ic_angle((yy * 2).astype(np.uint8), 30, 30) == 90.0     # +y ramp
+    assert abs(e.ic_angle((200 - xx * 2).astype(np.uint8), 30, 30) - 180.0) < 1e-4
+    assert e.ic_angle((200 - yy * 2).astype(np.uint8), 30, 30) == 270.0
+    # moments of the 749-pixel circular patch, by hand
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (96, 96), dtype=np.uint8)
+    umax = e.umax
+    m01 = m10 = 0
+    for v in range(-15, 16):
+        for u in range(-umax[abs(v)], umax[abs(v)] + 1):
+            m10 += u * int(img[16 + 40 + v, 16 + 45 + u])
+            m01 += v * int(img[16 + 40 + v, 16 + 45 + u])
+    assert sum(2 * umax[abs(v)] + 1 for v in range(-15, 16)) == 749
+    assert e.ic_angle(img, 45, 40) == oracle.fast_atan2(float(m01), float(m10))
+    assert e.ic_angle(img, 45.4, 39.5) == e.ic_angle(img, 45, 40)   # cvRound: 39.5 -> 40 (half to even), 45.4 -> 45
+    assert e.ic_angle(img, 44.5, 40.5) == e.ic_angle(img, 44, 40)   # 44.5 -> 44, 40.5 -> 40
+
+
+# ---- E9 steered BRIEF -----------------------------------------------------------------------------------------
+def _pattern():
+    vals = []
+    for line in open(os.path.join(ROOT, "oracle", "rbrief_pattern.inc")):
+        if line.startswith("//"):
+            continue
+        vals += [int(v) for v in line.strip().rstrip(",").split(",")]
+    return np.array(vals).reshape(256, 4)
+
+
+def test_pattern_table_identical_in_product_and_oracle():
+    a = open(os.path.join(ROOT, "oracle", "rbrief_pattern.inc")).read()
+    b = open(os.path.join(ROOT, "u-vip-slam_amd", "csrc", "rbrief_pattern.inc")).read()
+    assert a == b
+    p = _pattern()
+    assert p.shape == (256, 4) and np.abs(p).max() == 13
+    assert p[0].tolist() == [8, -3, 9, 5] and p[255].tolist() == [-1, -6, 0, -11]
+
+
+@pytest.mark.parametrize("angle,rot", [(0.0, lambda x, y: (x, y)), (90.0, lambda x, y: (-y, x)), (180.0, lambda x, y: (-x, -y)),
+                                       (270.0, lambda x, y: (y, -x))])
+def test_rbrief_axis_aligned_by_hand(oracle, angle, rot):
+    e = oracle.extractor(1000, 1.2, 8, 20)
+    rng = np.random.default_rng(4)
+    plane = rng.integers(0, 256, (100 + 32, 100 + 32), dtype=np.uint8)
+    cx, cy = 50, 47
+    d = e.descriptor(plane, cx, cy, angle)
+    p = _pattern()
+    bits = []
+    for x0, y0, x1, y1 in p:
+        rx0, ry0 = rot(x0, y0)
+        rx1, ry1 = rot(x1, y1)
+        bits.append(int(plane[16 + cy + ry0, 16 + cx + rx0]) < int(plane[16 + cy + ry1, 16 + cx + rx1]))
+    ref = np.packbits(np.array(bits, np.uint8), bitorder="little")
+    np.testing.assert_array_equal(d, ref)
+
+
+def test_rbrief_generic_angle_float_steps(oracle):
+    e = oracle.extractor(1000, 1.2, 8, 20)
+    rng = np.random.default_rng(5)
+    plane = rng.integers(0, 256, (132, 132), dtype=np.uint8)
+    p = _pattern()
+    for ang in (33.3, 123.456, 359.99, 45.0):
+        a32 = np.float32(ang) * np.float32(np.pi / np.float32(180.0))
+        s, c = oracle.sincosf(float(a32))
+        a, b = np.float32(c), np.float32(s)
+        bits = []
+        for x0, y0, x1, y1 in p.astype(np.float32):
+            def px(x, y):
+                yy = int(np.rint(np.float32(np.float32(x * b) + np.float32(y * a))))
+                xx = int(np.rint(np.float32(np.float32(x * a) - np.float32(y * b))))
+                return int(plane[16 + 60 + yy, 16 + 61 + xx])
+            bits.append(px(x0, y0) < px(x1, y1))
+        np.testing.assert_array_equal(e.descriptor(plane, 61, 60, ang), np.packbits(np.array(bits, np.uint8), bitorder="little"))
+
+
+# ---- E5 quad tree ---------------------------------------------------------------------------------------------
+def test_octree_toy_cases(oracle):
+    e = oracle.extractor(1000, 1.2, 8, 20)
+    W = H = 100
+    # one point per quadrant, N = 4: root splits once, children are push_front'ed n1..n4 -> list reads n4, n3, n2, n1
+    pts = np.array([[10, 10, 5], [80, 12, 6], [12, 85, 7], [90, 90, 8]])
+    assert e.octree(pts, W, H, 4).tolist() == [[90, 90, 8], [12, 85, 7], [80, 12, 6], [10, 10, 5]]
+    # a single point: root is flagged bNoMore and returned
+    assert e.octree(pts[:1], W, H, 10).tolist() == [[10, 10, 5]]
+    assert e.octree(pts[:0], W, H, 10).tolist() == []
+    # N = 1 still performs the first split of a multi-point root (:1058 loop runs before any size test)
+    assert len(e.octree(pts, W, H, 1)) == 4
+    # best response per node, first in candidate order wins ties (:1211-1226)
+    pts = np.array([[10, 10, 5], [11, 11, 9], [12, 12, 9], [80, 80, 1]])
+    out = e.octree(pts, W, H, 2).tolist()
+    assert out == [[80, 80, 1], [11, 11, 9]]
+    # careful phase: sizes differ -> the larger node is split first and the walk stops at the first split reaching N
+    pts = np.array([[5, 5, 1], [40, 5, 2], [5, 40, 3], [40, 40, 4],          # TL quadrant: 4 points, one per sub-quadrant
+                    [60, 5, 1], [90, 5, 2], [60, 40, 3],                      # TR quadrant: 3 points
+                    [5, 60, 9]])                                              # BL quadrant: single
+    # pass 1: list = [BL(1), TR(3), TL(4)]: 3 nodes < 5 and 3 + 3*2 > 5 -> careful: TL (size 4) first -> 3 - 1 + 4 = 6 >= 5 -> stop
+    assert e.octree(pts, W, H, 5).tolist() == [[40, 40, 4], [5, 40, 3], [40, 5, 2], [5, 5, 1], [5, 60, 9], [60, 40, 3]]
+    # same, but TL's points all fall into one child: that split gains nothing, so TR is split too (3 - 1 + 1 - 1 + 3 = 5)
+    pts = np.array([[5, 5, 1], [20, 5, 2], [5, 20, 3], [20, 20, 4], [60, 5, 1], [90, 5, 2], [60, 40, 3], [5, 60, 9]])
+    assert e.octree(pts, W, H, 5).tolist() == [[60, 40, 3], [90, 5, 2], [60, 5, 1], [20, 20, 4], [5, 60, 9]]
+    # equal sizes in the careful phase: the most recently created node (front of the list) is split first
+    pts = np.array([[5, 5, 1], [40, 40, 2],        # TL: 2 points
+                    [60, 5, 3], [90, 40, 4],       # TR: 2 points
+                    [5, 60, 5], [40, 90, 6]])      # BL: 2 points
+    # pass 1: list = [BL, TR, TL] (3 nodes), N = 4: 3 + 9 > 4 -> careful, all sizes 2 -> newest = BL first: 3 - 1 + 2 = 4 -> stop
+    assert e.octree(pts, W, H, 4).tolist() == [[40, 90, 6], [5, 60, 5], [90, 40, 4], [40, 40, 2]]
+
+
+def test_octree_kernel_body_matches_oracle_on_random_sets(oracle):
+    """The HIP kernel's selection logic (csrc/octree_core.hpp), executed on the host through the phase macros."""
+    lib = os.path.join(ROOT, "tests", "emu", "liboctree_emu.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", lib, os.path.join(ROOT, "tests", "emu", "octree_emu.cpp")])
+    E = ctypes.CDLL(lib)
+    E.emu_octree.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    e = oracle.extractor(1000, 1.2, 8, 20)
+    rng = np.random.default_rng(123)
+    done = 0
+    for trial in range(160):
+        W = int(rng.integers(30, 900))
+        H = int(rng.integers(max(30, W // 3), min(900, 2 * W - 1)))
+        if round(W / H) < 1:
+            continue
+        nCols, nRows = W // 30, H // 30
+        wCell, hCell = -(-W // nCols), -(-H // nRows)
+        P, N, mode = int(rng.integers(0, 2500)), int(rng.integers(1, 450)), trial % 4
+        if mode == 1:
+            cx, cy = rng.integers(3, W - 3), rng.integers(3, H - 3)
+            xs = np.clip(cx + rng.normal(0, 8, P).astype(int), 3, W - 4)
+            ys = np.clip(cy + rng.normal(0, 8, P).astype(int), 3, H - 4)
+        elif mode == 3:
+            xs, ys = rng.integers(3, W - 3, size=P), np.full(P, rng.integers(3, H - 3))
+        else:
+            xs, ys = rng.integers(3, W - 3, size=P), rng.integers(3, H - 3, size=P)
+        pts = np.unique(np.stack([xs, ys], 1), axis=0).reshape(-1, 2)
+        j = np.minimum((pts[:, 0] - 3) // wCell, nCols - 1)
+        i = np.minimum((pts[:, 1] - 3) // hCell, nRows - 1)
+        pts = pts[np.lexsort((pts[:, 0], pts[:, 1], j, i))]   # reference candidate order: cell-major, raster inside a cell
+        P = len(pts)
+        resp = rng.integers(1, 4 if mode == 2 else 200, size=P)
+        ref = e.octree(np.concatenate([pts, resp[:, None]], 1), W, H, N).tolist()
+        perm = rng.permutation(P)                              # the GPU candidate array is in arbitrary order
+        xy = (pts[perm, 0].astype(np.uint32) | (pts[perm, 1].astype(np.uint32) << 16)).astype(np.uint32)
+        sc = resp[perm].astype(np.uint32)
+        sxy, ssc = np.zeros(N + 16 + P, np.uint32), np.zeros(N + 16 + P, np.uint32)
+        m = E.emu_octree(xy.ctypes.data, sc.ctypes.data, P, N, W, H, nCols, nRows, wCell, hCell, sxy.ctypes.data, ssc.ctypes.data, len(sxy))
+        got = [[int(v & 0xffff), int(v >> 16), int(s)] for v, s in zip(sxy[:m], ssc[:m])]
+        assert got == ref, "trial %d W=%d H=%d P=%d N=%d" % (trial, W, H, P, N)
+        done += 1
+    assert done > 100
+
+
+# ---- extractor glue -------------------------------------------------------------------------------------------
+def test_extract_properties(oracle, synth):
+    img = synth.make_frame(501, 320, 256, n_shapes=120)
+    e = oracle.extractor(300, 1.2, 4, 20)
+    kp, de = e(img)
+    assert len(kp) == len(de) > 250
+    assert (np.diff(kp["octave"]) >= 0).all()                       # level-major
+    for l in range(4):
+        m = kp["octave"] == l
+        assert m.sum() <= e.quota[l] + 2                            # careful phase adds at most 3 per split, stops at >= N
+        assert (kp["size"][m] == np.float32(int(np.float32(31) * e.scale[l]))).all()
+        lev = kp[m]
+        x = lev["x"] / e.scale[l]
+        w, h = e.level_dims(l)
+        assert (np.rint(x) >= 16).all() and (np.rint(x) < w - 16).all()
+    assert (kp["class_id"] == -1).all() and (kp["angle"] >= 0).all() and (kp["angle"] <= 360).all()
+    assert (kp["response"] >= 7).all()                              # fastTh 20 or the literal-7 fallback
+    # per-level stage taps agree with the final output
+    n0 = (kp["octave"] == 0).sum()
+    lk = e.level_keypoints(0)
+    assert len(lk) == n0 and (lk["x"] == kp["x"][:n0]).all()
+
+
+def test_topup_filter_semantics(oracle, synth):
+    img = synth.make_frame(501, 320, 256, n_shapes=120)
+    e = oracle.extractor(300, 1.2, 4, 20)
+    full_kp, _ = e(img)
+    rows, cols = 256 // 20 + 2, 320 // 20 + 2
+    grid = np.zeros((rows, cols), np.int32, order="F")
+    kp, de = e(img, None, grid, 20, False, 10 ** 6)   # caps never reached, numofpoint huge
+    # every accepted point marks its own cell exactly once, and is the first of the full list to fall into it
+    assert grid.sum() == len(kp) and grid.max() == 1
+    # a fully occupied grid rejects everything
+    g2 = np.ones((rows, cols), np.int32, order="F")
+    kp2, de2 = e(img, None, g2, 20, False, 100)
+    assert len(kp2) == 0 and (g2 == 1).all()
+    # global cap: Total_counter == num_featsneeded stops the walk (:898-901)
+    g3 = np.zeros((rows, cols), np.int32, order="F")
+    kp3, _ = e(img, None, g3, 20, False, 7)
+    # per-level cap: num_featsneeded*(8-level)/30 = 1 for level 0..3 -> KP_counter resets per level; total stops at 7 or earlier
+    assert 0 < len(kp3) <= 7
+    # caller keypoints pass through level 0 first, angles recomputed, other fields untouched
+    kin = np.zeros(3, oracle_kp_dtype())
+    kin["x"], kin["y"], kin["size"], kin["angle"], kin["response"], kin["octave"], kin["class_id"] = [50, 100.4, 200], [60, 80.5, 90], 9, -1, 3, 0, [7, 8, 9]
+    g4 = np.zeros((rows, cols), np.int32, order="F")
+    kp4, de4 = e(img, kin, g4, 20, False, 50)
+    assert (kp4["class_id"][:3] == [7, 8, 9]).all() and (kp4["size"][:3] == 9).all() and (kp4["x"][:3] == kin["x"]).all()
+    assert (kp4["angle"][:3] >= 0).all()
+    # FullDetect drops caller keypoints (:911)
+    kp5, _ = e(img, kin, None, 20, True, 0)
+    assert len(kp5) == len(full_kp)
+
+
+def oracle_kp_dtype():
+    import oracle_lib
+    return oracle_lib.KP
+
+
+def test_golden_fixtures(oracle, synth):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "extract_golden.npz"))
+    for name, seed, w, h, ns, nf, nl, th in (("full_320x256", 501, 320, 256, 120, 300, 4, 20), ("full_640x512", 1000, 640, 512, 400, 1000, 8, 20),
+                                             ("full_752x480_th7", 502, 752, 480, 400, 1000, 8, 7)):
+        img = synth.make_frame(seed, w, h, n_shapes=ns)
+        assert [int(img.astype(np.int64).sum()), int((img.astype(np.int64) * np.arange(w)).sum() % (1 << 31))] == g[name + "_imgsum"].tolist(), \
+            "synthetic generator drifted"
+        kp, de = oracle.extractor(nf, 1.2, nl, th)(img)
+        np.testing.assert_array_equal(kp.view(np.uint8).reshape(len(kp), 28), g[name + "_kp"])
+        np.testing.assert_array_equal(de, g[name + "_desc"])
+
+
+def test_grider_fast(oracle, synth):
+    img = synth.make_frame(9, 320, 256, n_shapes=120)
+    pts = oracle.grider_fast(img, 200, 8, 5, 20)
+    per_cell = 200 // 40 + 1
+    cx, cy = (pts["x"] // (320 // 8)).astype(int), (pts["y"] // (256 // 5)).astype(int)
+    counts = np.bincount(cy * 8 + cx, minlength=40)
+    assert counts.max() <= per_cell and len(pts) > 40
+    for c in range(40):  # inside a cell: response descending
+        r = pts["response"][(cy * 8 + cx) == c]
+        assert (np.diff(r) <= 0).all()

@@ -3,7 +3,7 @@
 //
 // The reference is a sequential std::list algorithm.  It is reformulated here as a sequence of data-parallel
 // *passes* over "generations" of nodes (tools/octree_proto.py is the executable derivation, checked against the
-// literal restatement in oracle/):
+// literal std::list restatement the tests use as checker):
 //   * a generation A is the set of nodes created by one pass, stored in the reference's list order
 //     (front -> back = newest -> oldest); older nodes that survive are frozen single-point nodes, which always
 //     sit behind A in the list, generation by generation;
@@ -18,7 +18,7 @@
 // bitonic sort of <= N keys.  Point state lives in HBM scratch (L2 resident), node state in LDS.
 //
 // The body is written against the OCT_* phase macros so that tests/emu/octree_emu.cpp can run the *same* logic on
-// the CPU (threads of a phase executed one after another) against the oracle; on the GPU a phase ends in a
+// the CPU (threads of a phase executed one after another) against that checker; on the GPU a phase ends in a
 // workgroup barrier.
 #pragma once
 #include <stdint.h>
