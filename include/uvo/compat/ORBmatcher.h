@@ -24,16 +24,22 @@
 #include <opencv2/core/core.hpp>
 #endif
 
+/* Inside the reference tree the class name USLAM::ORBmatcher is already taken by include/ORBmatcher.h; define
+ * UVO_COMPAT_MATCHER_NAME (e.g. ORBmatcherGPU) before including this header there and forward the GPU-backed members. */
+#ifndef UVO_COMPAT_MATCHER_NAME
+#define UVO_COMPAT_MATCHER_NAME ORBmatcher
+#endif
+
 namespace USLAM {
 
-class ORBmatcher {
+class UVO_COMPAT_MATCHER_NAME {
  public:
   static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;  // src/ORBmatcher.cc:40-42
 
-  ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
-  ~ORBmatcher() { uvo_matcher_destroy(m_); }
-  ORBmatcher(const ORBmatcher&) = delete;
-  ORBmatcher& operator=(const ORBmatcher&) = delete;
+  UVO_COMPAT_MATCHER_NAME(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+  ~UVO_COMPAT_MATCHER_NAME() { uvo_matcher_destroy(m_); }
+  UVO_COMPAT_MATCHER_NAME(const UVO_COMPAT_MATCHER_NAME&) = delete;
+  UVO_COMPAT_MATCHER_NAME& operator=(const UVO_COMPAT_MATCHER_NAME&) = delete;
 
   /* ORBmatcher::DescriptorDistance for one pair (src/ORBmatcher.cc:1794-1810): 8 x 32-bit popcount of the XOR.
    * A single 32-byte pair is host work in the reference too (src/MapPoint.cc:244); bulk distances go through
