@@ -8,83 +8,108 @@
 // Arithmetic is OpenCV's symmetric-smooth integer engine: taps round(g*256) per pass (18,34,49,55,49,34,18),
 // row pass u8 -> int, column pass (sum + 2^15) >> 16 saturated to u8.
 //
-// One workgroup = 64x16 output pixels.  The 72x22 source window is staged once in LDS with aligned dword
-// loads, the row pass result (<= 65535, kept as u16) goes back to LDS, and each thread then emits one dword.
+// Streaming stencil without LDS: one wavefront owns a vertical strip of 64 lanes x 4 pixels (lanes 0 and 63 are halo,
+// 248 useful columns) and walks down the rows.  Per row a lane issues ONE aligned dword load, takes its neighbours'
+// dwords by cross-lane shifts, does the row pass for its 4 pixels in registers and keeps the last 7 row-pass results in
+// a register ring (the loop is unrolled by 7 so ring slots are compile-time); the column pass then emits one dword.
+// Every byte of a level is loaded once per strip segment (+6 halo rows per GS_ROWS) and written once.
 #include "common.hpp"
 
 namespace uvo {
 
-constexpr int GT_W = 64, GT_H = 16;
+constexpr int GS_COLS = 248;  // useful columns per wavefront strip
+
+__device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t R, const int4& t, int* h) {
+  // 12-byte window [L0..L3 C0..C3 R0..R3]; pixel k sits at window index 4+k and needs indices k+1 .. k+7
+  int b[12];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    b[i] = (L >> (8 * i)) & 0xff;
+    b[4 + i] = (C >> (8 * i)) & 0xff;
+    b[8 + i] = (R >> (8 * i)) & 0xff;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) h[k] = t.x * (b[k + 1] + b[k + 7]) + t.y * (b[k + 2] + b[k + 6]) + t.z * (b[k + 3] + b[k + 5]) + t.w * b[k + 4];
+}
 
 __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int64_t pyr_block,
-                                                const LevelGeom* __restrict__ lv, int nlevels, int4 taps) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_src[GT_H + 6][GT_W + 8];
-  __shared__ __attribute__((aligned(16))) uint16_t s_row[GT_H + 6][GT_W];
-
-  // tile -> level
-  int level = 0, tile = blockIdx.x;
-  int tx_n = 0;
+                                                const LevelGeom* __restrict__ lv, int nlevels, int4 taps, int rows_per_seg) {
+  // work item (one per wavefront) -> (level, strip, segment)
+  int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  int level = 0, nstrip = 0, nseg = 0;
   for (;; ++level) {
-    tx_n = (lv[level].w + 8 + GT_W - 1) / GT_W;
-    const int ty_n = (lv[level].h + 8 + GT_H - 1) / GT_H;
-    if (tile < tx_n * ty_n || level == nlevels - 1) break;
-    tile -= tx_n * ty_n;
+    nstrip = (lv[level].w + 8 + GS_COLS - 1) / GS_COLS;
+    nseg = (lv[level].h + 8 + rows_per_seg - 1) / rows_per_seg;
+    if (item < nstrip * nseg) break;
+    item -= nstrip * nseg;
+    if (level == nlevels - 1) return;
   }
   const LevelGeom g = lv[level];
   const int f = blockIdx.y;
-  const int ox = -4 + (tile % tx_n) * GT_W;  // tile origin in ROI coordinates
-  const int oy = -4 + (tile / tx_n) * GT_H;
+  const int strip = item % nstrip, seg = item / nstrip;
   const uint8_t* src = pyr + f * pyr_block + g.plane_off;
   uint8_t* dst = blur + f * pyr_block + g.plane_off;
-  const int tid = threadIdx.x;
 
-  // stage rows oy-3 .. oy+GT_H+2, columns ox-4 .. ox+GT_W+3 (dword aligned: ROI origin is at byte 16 of a 64-B pitched row)
-  for (int i = tid; i < (GT_H + 6) * ((GT_W + 8) / 4); i += 256) {
-    const int r = i / ((GT_W + 8) / 4), c4 = i % ((GT_W + 8) / 4);
-    int py = oy - 3 + r + kPad;
-    py = py < 0 ? 0 : (py >= g.ph ? g.ph - 1 : py);
-    int px = ox - 4 + c4 * 4 + kPad;
-    px = px < 0 ? 0 : (px > g.pitch - 4 ? g.pitch - 4 : px);
-    *reinterpret_cast<uint32_t*>(&s_src[r][c4 * 4]) = *reinterpret_cast<const uint32_t*>(src + (int64_t)py * g.pitch + px);
-  }
-  __syncthreads();
-  // row pass: s_row[r][c] = sum_i k[i] * src(ox + c - 3 + i) ; source column ox+c-3+i sits at s_src[r][c+1+i]
-  for (int i = tid; i < (GT_H + 6) * GT_W; i += 256) {
-    const int r = i / GT_W, c = i % GT_W;
-    const uint8_t* p = &s_src[r][c + 1];
-    const int s = taps.x * (p[0] + p[6]) + taps.y * (p[1] + p[5]) + taps.z * (p[2] + p[4]) + taps.w * p[3];
-    s_row[r][c] = (uint16_t)s;
-  }
-  __syncthreads();
-  // column pass, 4 pixels per thread
-  const int r = tid / 16, c0 = (tid % 16) * 4;
-  const int y = oy + r;
-  if (y >= g.h + 4) return;
-  uint32_t out = 0;
+  // padded-plane column of this lane's dword; lane 0 is the left halo of the strip.  Region = padded cols [12, w+20).
+  const int X = 8 + strip * GS_COLS + lane * 4;
+  const int Xc = X > g.pitch - 4 ? g.pitch - 4 : X;  // clamp loads into the row (only halo / out-of-region lanes)
+  const bool lane_out = lane >= 1 && lane <= 62 && X >= 12 && X < g.w + 20;
+  // padded-plane rows: region rows [12, h+20); segment rows [py0, py1)
+  const int py0 = 12 + seg * rows_per_seg;
+  const int py1 = min(py0 + rows_per_seg, g.h + 20);
+  const int nsrc = py1 - py0 + 6;  // source rows py0-3 .. py1+2
+
+  int hring[7][4];
+  uint32_t cring[7];
+  for (int base = 0; base < nsrc; base += 7) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = c0 + i;
-    const int x = ox + c;
-    int v;
-    if (x >= 0 && x < g.w && y >= 0 && y < g.h) {
-      const int s = taps.x * (s_row[r][c] + s_row[r + 6][c]) + taps.y * (s_row[r + 1][c] + s_row[r + 5][c]) +
-                    taps.z * (s_row[r + 2][c] + s_row[r + 4][c]) + taps.w * s_row[r + 3][c];
-      v = (s + (1 << 15)) >> 16;
-      v = v > 255 ? 255 : v;
-    } else {
-      v = s_src[r + 3][c + 4];  // pad ring: un-blurred copy
+    for (int u = 0; u < 7; ++u) {
+      const int j = base + u;
+      if (j < nsrc) {
+        int prow = py0 - 3 + j;
+        prow = prow > g.ph - 1 ? g.ph - 1 : prow;  // rows past the plane are never used by a valid output
+        const uint32_t C = *reinterpret_cast<const uint32_t*>(src + (int64_t)prow * g.pitch + Xc);
+        const uint32_t L = (uint32_t)__shfl_up((int)C, 1, 64);
+        const uint32_t R = (uint32_t)__shfl_down((int)C, 1, 64);
+        gauss_row_pass(L, C, R, taps, hring[u]);
+        cring[u] = C;
+        if (j >= 6) {
+          const int py = py0 + j - 6;  // output row; its 7 source rows sit in ring slots (u+1)%7 .. (u+7)%7
+          const int* r0 = hring[(u + 1) % 7];
+          const int* r1 = hring[(u + 2) % 7];
+          const int* r2 = hring[(u + 3) % 7];
+          const int* r3 = hring[(u + 4) % 7];
+          const int* r4 = hring[(u + 5) % 7];
+          const int* r5 = hring[(u + 6) % 7];
+          const int* r6 = hring[u];
+          const uint32_t centre = cring[(u + 4) % 7];
+          const bool row_in = py >= kPad && py < g.h + kPad;
+          uint32_t out = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int s = taps.x * (r0[k] + r6[k]) + taps.y * (r1[k] + r5[k]) + taps.z * (r2[k] + r4[k]) + taps.w * r3[k];
+            int v = (s + (1 << 15)) >> 16;
+            v = v > 255 ? 255 : v;
+            const int px = X + k;
+            const bool inside = row_in && px >= kPad && px < g.w + kPad;
+            v = inside ? v : (int)((centre >> (8 * k)) & 0xff);  // pad ring: un-blurred copy
+            out |= (uint32_t)v << (8 * k);
+          }
+          if (lane_out) *reinterpret_cast<uint32_t*>(dst + (int64_t)py * g.pitch + X) = out;
+        }
+      }
     }
-    out |= (uint32_t)v << (8 * i);
   }
-  const int x0 = ox + c0;
-  if (x0 < g.w + 4) *reinterpret_cast<uint32_t*>(dst + (int64_t)(y + kPad) * g.pitch + (x0 + kPad)) = out;
 }
 
 void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g, int4 taps,
                    int batch) {
-  int tiles = 0;
-  for (int l = 0; l < g.nlevels; ++l) tiles += ((g.lv[l].w + 8 + GT_W - 1) / GT_W) * ((g.lv[l].h + 8 + GT_H - 1) / GT_H);
-  hipLaunchKernelGGL(k_gauss7, dim3(tiles, batch), dim3(256), 0, s, d_pyr, d_blur, pyr_block, d_lv, g.nlevels, taps);
+  // fewer, longer segments when the batch already fills the chip (6 halo rows are re-read per segment)
+  const int rows_per_seg = batch >= 16 ? 64 : 16;
+  int items = 0;
+  for (int l = 0; l < g.nlevels; ++l) items += ((g.lv[l].w + 8 + GS_COLS - 1) / GS_COLS) * ((g.lv[l].h + 8 + rows_per_seg - 1) / rows_per_seg);
+  hipLaunchKernelGGL(k_gauss7, dim3((items + 3) / 4, batch), dim3(256), 0, s, d_pyr, d_blur, pyr_block, d_lv, g.nlevels, taps, rows_per_seg);
 }
 
 }  // namespace uvo
