@@ -35,8 +35,8 @@ struct LevelGeom {
   float hX;
   float scale;         // mvScaleFactor[level]
   float patch_size;    // (float)(int)(31*scale)
-  int xtab_off;        // element offset of this level's x resize tables (level >= 1), in dst-pixel units
-  int ytab_off;        // same for the y tables
+  int xtab_off;        // element offset of this level's column resize table (level >= 1; one entry per padded column, pitch entries)
+  int ytab_off;        // same for the row table (ph entries)
 };
 
 struct CellDesc {  // one FAST cell (src/ORBextractor.cc:773-790)
@@ -60,6 +60,14 @@ struct Geom {
 // FAST candidates and quad-tree survivors are SoA: xy word = x | y << 16 relative to (minBorder, minBorder),
 // score word = FAST score (cornerScore), 1..254.
 
+// resize coefficient tables, indexed by padded output coordinates (border reflection folded in)
+struct ResizeCol {  // 8 B
+  int16_t sx, a0, a1, pad;
+};
+struct ResizeRow {  // 8 B
+  int16_t sy0, sy1, b0, b1;
+};
+
 struct FinalSlot {  // 16 B
   float x, y;       // level coordinates
   int32_t level;    // bit 31 set: caller keypoint, aux = index into in_kp
@@ -81,8 +89,8 @@ int fail(int code, const char* msg);  // records msg for uvo_last_error() and re
 // ---- kernel launch wrappers (defined in the .hip files) ----
 void launch_pad_level0(hipStream_t s, const uint8_t* d_img, int w, int h, int64_t stride, int64_t frame_stride, uint8_t* d_pyr,
                        int64_t pyr_block, const LevelGeom& g0, int batch);
-void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const LevelGeom& src, const LevelGeom& dst, const int32_t* d_xofs,
-                         const int16_t* d_xalpha, const int32_t* d_yofs, const int16_t* d_ybeta, int batch);
+void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const LevelGeom& src, const LevelGeom& dst, const ResizeCol* d_ctab,
+                         const ResizeRow* d_rtab, int fast_ok, int batch);
 void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g, int4 taps,
                    int batch);
 void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const LevelGeom* d_lv, const CellDesc* d_cells, int total_cells,
@@ -101,6 +109,6 @@ void launch_knn2(hipStream_t s, int pairs, int max_q, const uint8_t* d_q, const 
 void launch_matrix(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, uint16_t* d_dist);
 void launch_describe(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, const uint8_t* d_blur, int64_t pyr_block,
                      const FinalSlot* d_flist, const int32_t* d_n_final, const uvo_keypoint* d_in_kp, int in_cap, const int8_t* d_pattern,
-                     const int32_t* d_umax, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch);
+                     const uint16_t* d_patch, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch);
 
 }  // namespace uvo

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
                                                   const uint8_t* __restrict__ blur, int64_t pyr_block,
                                                   const FinalSlot* __restrict__ flist, int flist_cap, const int32_t* __restrict__ n_final,
                                                   const uvo_keypoint* __restrict__ in_kp, int in_cap, const int8_t* __restrict__ pattern,
-                                                  const int32_t* __restrict__ umax, uvo_keypoint* __restrict__ out_kp,
+                                                  const uint16_t* __restrict__ patch, uvo_keypoint* __restrict__ out_kp,
                                                   uint8_t* __restrict__ out_desc, int cap, int32_t* __restrict__ n_out) {
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63;
@@ -133,18 +133,23 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
   const int cx = cv_round(kp.x), cy = cv_round(kp.y);
   const int64_t center_off = f * pyr_block + g.plane_off + (int64_t)(cy + kPad) * g.pitch + (cx + kPad);
 
-  // ---- IC_Angle: circular patch rows v in [-15,15], |u| <= umax[|v|] ----
+  // ---- IC_Angle: the 749 (u, v) offsets of the circular patch (rows v in [-15,15], |u| <= umax[|v|]) come from a
+  // table padded to 768 entries with (0,0) (contributes nothing); 12 independent byte loads per lane ----
   {
     const uint8_t* center = pyr + center_off;
     int m01 = 0, m10 = 0;
-    for (int t = lane; t < 31 * 31; t += 64) {
-      const int v = t / 31 - 15, u = t % 31 - 15;
-      const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-      if (au <= umax[av]) {
-        const int I = center[(int64_t)v * g.pitch + u];
-        m10 += u * I;
-        m01 += v * I;
-      }
+    int pix[12], uu[12], vv[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int uv = patch[lane + 64 * i];  // u in the low byte, v in the high byte (both int8)
+      uu[i] = (int)(int8_t)(uv & 0xff);
+      vv[i] = (int)(int8_t)(uv >> 8);
+      pix[i] = center[(int64_t)vv[i] * g.pitch + uu[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      m10 += uu[i] * pix[i];
+      m01 += vv[i] * pix[i];
     }
     m01 = wave_sum(m01);
     m10 = wave_sum(m10);
@@ -160,8 +165,9 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
   uint64_t words[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int idx = (j * 64 + lane) * 4;
-    const float x0 = (float)pattern[idx], y0 = (float)pattern[idx + 1], x1 = (float)pattern[idx + 2], y1 = (float)pattern[idx + 3];
+    const uint32_t pq = reinterpret_cast<const uint32_t*>(pattern)[j * 64 + lane];  // (x0, y0, x1, y1) int8
+    const float x0 = (float)(int8_t)(pq & 0xff), y0 = (float)(int8_t)((pq >> 8) & 0xff), x1 = (float)(int8_t)((pq >> 16) & 0xff),
+                y1 = (float)(int8_t)(pq >> 24);
     const int t0 = bc[(int64_t)cv_round(x0 * b + y0 * a) * g.pitch + cv_round(x0 * a - y0 * b)];
     const int t1 = bc[(int64_t)cv_round(x1 * b + y1 * a) * g.pitch + cv_round(x1 * a - y1 * b)];
     words[j] = __ballot(t0 < t1);
@@ -189,10 +195,10 @@ void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const 
 
 void launch_describe(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, const uint8_t* d_blur, int64_t pyr_block,
                      const FinalSlot* d_flist, const int32_t* d_n_final, const uvo_keypoint* d_in_kp, int in_cap, const int8_t* d_pattern,
-                     const int32_t* d_umax, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch) {
+                     const uint16_t* d_patch, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch) {
   const int slots = g.flist_cap < cap ? g.flist_cap : cap;
   hipLaunchKernelGGL(k_describe, dim3((slots + 3) / 4, batch), dim3(256), 0, s, d_lv, g.nlevels, d_pyr, d_blur, pyr_block, d_flist,
-                     g.flist_cap, d_n_final, d_in_kp, in_cap, d_pattern, d_umax, d_out_kp, d_out_desc, cap, d_n_out);
+                     g.flist_cap, d_n_final, d_in_kp, in_cap, d_pattern, d_patch, d_out_kp, d_out_desc, cap, d_n_out);
 }
 
 }  // namespace uvo

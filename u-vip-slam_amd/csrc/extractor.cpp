@@ -63,10 +63,10 @@ struct uvo_extractor {
   FinalSlot* d_flist = nullptr;
   LevelGeom* d_lv = nullptr;
   CellDesc* d_cells = nullptr;
-  int32_t *d_xofs = nullptr, *d_yofs = nullptr;
-  int16_t *d_xalpha = nullptr, *d_ybeta = nullptr;
+  ResizeCol* d_ctab = nullptr;
+  ResizeRow* d_rtab = nullptr;
   int8_t* d_pattern = nullptr;
-  int32_t* d_umax = nullptr;
+  uint16_t* d_patch = nullptr;  // 768 packed (u,v) offsets of the orientation patch
   // staging for the host-buffer entry points
   uint8_t* d_imgs = nullptr;
   uvo_keypoint *d_out_kp = nullptr, *d_in_kp = nullptr;
@@ -184,7 +184,7 @@ static int build_geom(const uvo_extractor* h, int width, int height, Geom& g, st
     L.scale = h->scale[l];
     L.patch_size = (float)(int)(31 * h->scale[l]);
     L.xtab_off = xt, L.ytab_off = yt;
-    if (l > 0) xt += L.w, yt += L.h;
+    if (l > 0) xt += L.pitch, yt += L.ph;
   }
   g.total_cells = (int)cells.size();
   g.pyr_block = off;
@@ -195,31 +195,40 @@ static int build_geom(const uvo_extractor* h, int width, int height, Geom& g, st
 }
 
 // cv::resize INTER_LINEAR coefficient tables exactly as resizeGeneric_ builds them:
-// fx = (float)((dx+0.5)*scale_x - 0.5), sx = floor(fx), weights saturate_cast<short>(w * 2048)
-static void build_resize_tables(const Geom& g, std::vector<int32_t>& xofs, std::vector<int16_t>& xalpha, std::vector<int32_t>& yofs,
-                                std::vector<int16_t>& ybeta) {
-  xofs.clear(), xalpha.clear(), yofs.clear(), ybeta.clear();
+// fx = (float)((dx+0.5)*scale_x - 0.5), sx = floor(fx), weights saturate_cast<short>(w * 2048); then re-indexed by
+// padded output coordinate with the REFLECT_101 border folded in (copyMakeBorder of the level, src/ORBextractor.cc:988).
+static inline int reflect101_host(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+  return p;
+}
+static void build_resize_tables(const Geom& g, std::vector<ResizeCol>& ctab, std::vector<ResizeRow>& rtab) {
+  ctab.clear(), rtab.clear();
   for (int l = 1; l < g.nlevels; ++l) {
     const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h, dw = g.lv[l].w, dh = g.lv[l].h;
     const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    std::vector<ResizeCol> col(dw);
+    std::vector<ResizeRow> row(dh);
     for (int dx = 0; dx < dw; ++dx) {
       float fx = (float)((dx + 0.5) * scale_x - 0.5);
       int sx = cv_floor_host(fx);
       fx -= sx;
       if (sx < 0) fx = 0, sx = 0;
       if (sx >= sw - 1) fx = 0, sx = sw - 1;
-      xofs.push_back(sx);
-      xalpha.push_back((int16_t)cv_round_host((1.f - fx) * 2048.f));
-      xalpha.push_back((int16_t)cv_round_host(fx * 2048.f));
+      col[dx] = ResizeCol{(int16_t)sx, (int16_t)cv_round_host((1.f - fx) * 2048.f), (int16_t)cv_round_host(fx * 2048.f), 0};
     }
     for (int dy = 0; dy < dh; ++dy) {
       float fy = (float)((dy + 0.5) * scale_y - 0.5);
       int sy = cv_floor_host(fy);
       fy -= sy;
-      yofs.push_back(sy);
-      ybeta.push_back((int16_t)cv_round_host((1.f - fy) * 2048.f));
-      ybeta.push_back((int16_t)cv_round_host(fy * 2048.f));
+      const int sy0 = std::min(std::max(sy, 0), sh - 1), sy1 = std::min(std::max(sy + 1, 0), sh - 1);
+      row[dy] = ResizeRow{(int16_t)sy0, (int16_t)sy1, (int16_t)cv_round_host((1.f - fy) * 2048.f), (int16_t)cv_round_host(fy * 2048.f)};
     }
+    for (int px = 0; px < g.lv[l].pitch; ++px) {
+      int x = reflect101_host(px - kPad, dw);  // columns in the pitch slack map to something valid too
+      ctab.push_back(col[x]);
+    }
+    for (int py = 0; py < g.lv[l].ph; ++py) rtab.push_back(row[reflect101_host(py - kPad, dh)]);
   }
 }
 
@@ -242,19 +251,17 @@ static int set_geometry(uvo_extractor* h, int width, int height) {
   if (rc) return rc;
   if (g.pyr_block > h->cap_pyr_block || g.cand_block > h->cap_cand_block || g.total_cells > h->cap_cells || g.sel_block > h->cap_sel_block)
     return fail(UVO_E_BADARG, "image larger than the handle was sized for");
-  std::vector<int32_t> xofs, yofs;
-  std::vector<int16_t> xalpha, ybeta;
-  build_resize_tables(g, xofs, xalpha, yofs, ybeta);
-  if ((int)xofs.size() > h->cap_xtab || (int)yofs.size() > h->cap_ytab) return fail(UVO_E_BADARG, "image larger than the handle was sized for");
+  std::vector<ResizeCol> ctab;
+  std::vector<ResizeRow> rtab;
+  build_resize_tables(g, ctab, rtab);
+  if ((int)ctab.size() > h->cap_xtab || (int)rtab.size() > h->cap_ytab) return fail(UVO_E_BADARG, "image larger than the handle was sized for");
   // in-flight work may still read the old tables
   UVO_HIP_CHECK(hipStreamSynchronize(h->stream));
   UVO_HIP_CHECK(hipMemcpy(h->d_lv, g.lv, sizeof(LevelGeom) * g.nlevels, hipMemcpyHostToDevice));
   UVO_HIP_CHECK(hipMemcpy(h->d_cells, cells.data(), sizeof(CellDesc) * cells.size(), hipMemcpyHostToDevice));
-  if (!xofs.empty()) {
-    UVO_HIP_CHECK(hipMemcpy(h->d_xofs, xofs.data(), xofs.size() * 4, hipMemcpyHostToDevice));
-    UVO_HIP_CHECK(hipMemcpy(h->d_xalpha, xalpha.data(), xalpha.size() * 2, hipMemcpyHostToDevice));
-    UVO_HIP_CHECK(hipMemcpy(h->d_yofs, yofs.data(), yofs.size() * 4, hipMemcpyHostToDevice));
-    UVO_HIP_CHECK(hipMemcpy(h->d_ybeta, ybeta.data(), ybeta.size() * 2, hipMemcpyHostToDevice));
+  if (!ctab.empty()) {
+    UVO_HIP_CHECK(hipMemcpy(h->d_ctab, ctab.data(), ctab.size() * sizeof(ResizeCol), hipMemcpyHostToDevice));
+    UVO_HIP_CHECK(hipMemcpy(h->d_rtab, rtab.data(), rtab.size() * sizeof(ResizeRow), hipMemcpyHostToDevice));
   }
   h->geom = g;
   h->cells = cells;
@@ -289,8 +296,8 @@ static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, 
   }
   for (int l = 1; l < g.nlevels; ++l) {
     ProfScope p(h, "k_resize_level");
-    launch_resize_level(s, h->d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_xofs + g.lv[l].xtab_off, h->d_xalpha + 2 * g.lv[l].xtab_off,
-                        h->d_yofs + g.lv[l].ytab_off, h->d_ybeta + 2 * g.lv[l].ytab_off, batch);
+    launch_resize_level(s, h->d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_ctab + g.lv[l].xtab_off, h->d_rtab + g.lv[l].ytab_off,
+                        h->cfg.scale_factor <= 2.0f ? 1 : 0, batch);
   }
   {
     ProfScope p(h, "k_fast_cells");
@@ -314,7 +321,7 @@ static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, 
   {
     ProfScope p(h, "k_describe");
     launch_describe(s, h->d_lv, g, h->d_pyr, h->d_blur, g.pyr_block, h->d_flist, h->d_n_final, d_in_kp, h->cfg.max_input_keypoints,
-                    h->d_pattern, h->d_umax, d_out_kp, d_out_desc, cap, d_n_out, batch);
+                    h->d_pattern, h->d_patch, d_out_kp, d_out_desc, cap, d_n_out, batch);
   }
   UVO_HIP_CHECK(hipGetLastError());
   return UVO_OK;
@@ -363,7 +370,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   h->cap_sel_block = g.sel_block;
   h->cap_flist = g.flist_cap;
   h->cap_xtab = 0, h->cap_ytab = 0;
-  for (int l = 1; l < g.nlevels; ++l) h->cap_xtab += g.lv[l].w + 1, h->cap_ytab += g.lv[l].h + 1;
+  for (int l = 1; l < g.nlevels; ++l) h->cap_xtab += g.lv[l].pitch + 64, h->cap_ytab += g.lv[l].ph + 1;
   const size_t B = (size_t)cfg->max_batch;
   hipError_t e = hipSetDevice(h->device);
   if (e != hipSuccess) {
@@ -395,12 +402,10 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   A(dev_alloc(&h->d_flist, B * h->cap_flist));
   A(dev_alloc(&h->d_lv, (size_t)kMaxLevels));
   A(dev_alloc(&h->d_cells, (size_t)h->cap_cells));
-  A(dev_alloc(&h->d_xofs, (size_t)h->cap_xtab));
-  A(dev_alloc(&h->d_xalpha, (size_t)2 * h->cap_xtab));
-  A(dev_alloc(&h->d_yofs, (size_t)h->cap_ytab));
-  A(dev_alloc(&h->d_ybeta, (size_t)2 * h->cap_ytab));
+  A(dev_alloc(&h->d_ctab, (size_t)h->cap_xtab));
+  A(dev_alloc(&h->d_rtab, (size_t)h->cap_ytab));
   A(dev_alloc(&h->d_pattern, (size_t)1024));
-  A(dev_alloc(&h->d_umax, (size_t)16));
+  A(dev_alloc(&h->d_patch, (size_t)768));
   // staging for host-buffer calls
   A(dev_alloc(&h->d_imgs, B * (size_t)cfg->max_width * cfg->max_height));
   A(dev_alloc(&h->d_out_kp, B * h->cap_flist));
@@ -410,8 +415,13 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   A(dev_alloc(&h->d_n_in, B));
   A(dev_alloc(&h->d_nfn, B));
 #undef A
+  // circular orientation patch (IC_Angle, src/ORBextractor.cc:125-152): rows v in [-15,15], |u| <= umax[|v|] -> 749 offsets
+  std::vector<uint16_t> patch;
+  for (int v = -15; v <= 15; ++v)
+    for (int u = -h->umax[v < 0 ? -v : v]; u <= h->umax[v < 0 ? -v : v]; ++u) patch.push_back((uint16_t)((uint8_t)(int8_t)u | ((uint8_t)(int8_t)v << 8)));
+  patch.resize(768, 0);
   if (hipMemcpy(h->d_pattern, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(h->d_umax, h->umax, 64, hipMemcpyHostToDevice) != hipSuccess) {
+      hipMemcpy(h->d_patch, patch.data(), 768 * 2, hipMemcpyHostToDevice) != hipSuccess) {
     uvo_extractor_destroy(h);
     return fail(UVO_E_HIP, "table upload failed");
   }
@@ -425,8 +435,8 @@ void uvo_extractor_destroy(uvo_extractor* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   h->prof.clear();
   void* ptrs[] = {h->d_pyr,    h->d_blur,   h->d_cand_xy, h->d_cand_sc, h->d_pstate, h->d_sel_xy,  h->d_sel_sc,  h->d_cand_count, h->d_sel_count,
-                  h->d_n_final, h->d_flist, h->d_lv,      h->d_cells,   h->d_xofs,   h->d_xalpha,  h->d_yofs,    h->d_ybeta,      h->d_pattern,
-                  h->d_umax,   h->d_imgs,   h->d_out_kp,  h->d_out_desc, h->d_n_out, h->d_in_kp,   h->d_n_in,    h->d_nfn,        h->d_grid};
+                  h->d_n_final, h->d_flist, h->d_lv,      h->d_cells,   h->d_ctab,   h->d_rtab,      h->d_pattern,
+                  h->d_patch,   h->d_imgs,   h->d_out_kp,  h->d_out_desc, h->d_n_out, h->d_in_kp,   h->d_n_in,    h->d_nfn,        h->d_grid};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (h->stream) hipStreamDestroy(h->stream);

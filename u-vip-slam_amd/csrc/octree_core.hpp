@@ -29,6 +29,7 @@
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define OCT_DEVICE 1
+#define OCT_NT ((int)blockDim.x)  // workgroup size chosen at launch: 256 (latency) or 64 (one wavefront per problem, throughput)
 #define OCT_FN __device__ __forceinline__
 #define OCT_PHASE_BEGIN \
   {                     \
@@ -41,6 +42,7 @@
 #define OCT_ATOMIC_MAX64(p, v) atomicMax((unsigned long long*)(p), (unsigned long long)(v))
 #else
 #define OCT_DEVICE 0
+#define OCT_NT OCT_THREADS
 #define OCT_FN static inline
 #define OCT_PHASE_BEGIN for (int tid = 0; tid < OCT_THREADS; ++tid) {
 #define OCT_PHASE_END }
@@ -111,10 +113,41 @@ OCT_FN int oct_bcast(const int* p) {
   return v;
 }
 
-// in-place exclusive scan of a[0..n) (n <= a few thousand); returns the total.  Blocked per thread + a
-// Kogge-Stone pass over the OCT_THREADS partial sums.
+// in-place exclusive scan of a[0..n) (n <= a few thousand); returns the total.
+// Same result on both builds; the device build scans the per-thread partial sums with wavefront shuffles
+// (2 workgroup barriers), the host build (test emulation) with a Kogge-Stone pass over the OCT_NT partials.
 OCT_FN uint32_t block_scan_excl(uint32_t* a, int n, uint32_t* part, int* sc) {
-  const int per = (n + OCT_THREADS - 1) / OCT_THREADS;
+  const int per = (n + OCT_NT - 1) / OCT_NT;
+#if OCT_DEVICE
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  uint32_t s = 0;
+  const int b = tid * per, e = (b + per < n) ? b + per : n;
+  for (int i = b; i < e; ++i) s += a[i];
+  uint32_t incl = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) part[wv] = incl;
+  __syncthreads();
+  uint32_t woff = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < OCT_NT / 64; ++k) {
+    const uint32_t t = part[k];
+    if (k < wv) woff += t;
+    total += t;
+  }
+  uint32_t run = woff + incl - s;
+  for (int i = b; i < e; ++i) {
+    const uint32_t v = a[i];
+    a[i] = run;
+    run += v;
+  }
+  __syncthreads();
+  (void)sc;
+  return total;
+#else
   OCT_PHASE_BEGIN
   uint32_t s = 0;
   const int b = tid * per, e = (b + per < n) ? b + per : n;
@@ -122,7 +155,6 @@ OCT_FN uint32_t block_scan_excl(uint32_t* a, int n, uint32_t* part, int* sc) {
   part[tid] = s;
   OCT_PHASE_END
   for (int off = 1; off < OCT_THREADS; off <<= 1) {
-    // two-phase step so that every thread reads before anyone writes
     uint32_t* tmp = part + OCT_THREADS;
     OCT_PHASE_BEGIN
     tmp[tid] = part[tid] + (tid >= off ? part[tid - off] : 0u);
@@ -142,15 +174,32 @@ OCT_FN uint32_t block_scan_excl(uint32_t* a, int n, uint32_t* part, int* sc) {
   if (tid == OCT_THREADS - 1) sc[SC_TMP] = (int)part[OCT_THREADS - 1];
   OCT_PHASE_END
   return (uint32_t)oct_bcast(&sc[SC_TMP]);
+#endif
 }
 
-// ascending bitonic sort of a[0..n2), n2 a power of two
+// ascending sort of the n distinct keys a[0..n); a[n..n2) must be padded with the maximum value (n2 = power of two).
+// Device: rank sort (every key counts the keys below it -- LDS broadcast reads, one pass, two barriers);
+// host emulation: bitonic network.  tmp holds n elements.
 template <class T>
-OCT_FN void block_bitonic(T* a, int n2) {
+OCT_FN void block_sort(T* a, int n, int n2, T* tmp) {
+#if OCT_DEVICE
+  (void)n2;
+  for (int i = threadIdx.x; i < n; i += OCT_NT) {
+    const T x = a[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += a[j] < x;
+    tmp[rank] = x;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += OCT_NT) a[i] = tmp[i];
+  __syncthreads();
+#else
+  (void)tmp;
+  (void)n;
   for (int k = 2; k <= n2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       OCT_PHASE_BEGIN
-      for (int i = tid; i < n2; i += OCT_THREADS) {
+      for (int i = tid; i < n2; i += OCT_NT) {
         const int ixj = i ^ j;
         if (ixj > i) {
           const T x = a[i], y = a[ixj];
@@ -164,6 +213,7 @@ OCT_FN void block_bitonic(T* a, int n2) {
       OCT_PHASE_END
     }
   }
+#endif
 }
 
 OCT_FN int half_ceil(int a) { return (a + 1) >> 1; }  // ceil(a/2.f) for a >= 0 (DivideNode :1233-1234)
@@ -181,11 +231,11 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
 
   // ---- roots (:1010-1052) ----
   OCT_PHASE_BEGIN
-  for (int i = tid; i < pr.nIni; i += OCT_THREADS) w.ccnt[i] = 0;
+  for (int i = tid; i < pr.nIni; i += OCT_NT) w.ccnt[i] = 0;
   if (tid == 0) sc[SC_NOUT] = 0;
   OCT_PHASE_END
   OCT_PHASE_BEGIN
-  for (int p = tid; p < P; p += OCT_THREADS) {
+  for (int p = tid; p < P; p += OCT_NT) {
     const float x = (float)(cand_xy[p] & 0xffff);
     const int r = (int)(x / pr.hX);
     OCT_ATOMIC_ADD(&w.ccnt[r], 1u);
@@ -214,7 +264,7 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
   }
   OCT_PHASE_END
   OCT_PHASE_BEGIN
-  for (int p = tid; p < P; p += OCT_THREADS) {
+  for (int p = tid; p < P; p += OCT_NT) {
     const uint32_t a = w.nodeOfRank[pstate[p]];
     if (cA[a] == 1) {
       const int slot = OCT_ATOMIC_ADD(&sc[SC_NOUT], 1);
@@ -238,12 +288,12 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
     const int prev_size = size;
     // ---- which nodes of A are expandable; default processing order = list order ----
     OCT_PHASE_BEGIN
-    for (int a = tid; a < na; a += OCT_THREADS) w.baseOfRank[a] = cA[a] > 1 ? 1u : 0u;
+    for (int a = tid; a < na; a += OCT_NT) w.baseOfRank[a] = cA[a] > 1 ? 1u : 0u;
     OCT_PHASE_END
     const int nExp = (int)block_scan_excl(w.baseOfRank, na, w.part, sc);
     if (nExp == 0) break;
     OCT_PHASE_BEGIN
-    for (int a = tid; a < na; a += OCT_THREADS) {
+    for (int a = tid; a < na; a += OCT_NT) {
       if (cA[a] > 1) {
         const uint32_t r = w.baseOfRank[a];
         w.procRank[a] = (int32_t)r;
@@ -252,11 +302,11 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
         w.procRank[a] = -1;
       }
     }
-    for (int i = tid; i < 4 * na; i += OCT_THREADS) w.ccnt[i] = 0;
+    for (int i = tid; i < 4 * na; i += OCT_NT) w.ccnt[i] = 0;
     OCT_PHASE_END
     // ---- child digit + histogram (DivideNode :1262-1276) ----
     OCT_PHASE_BEGIN
-    for (int p = tid; p < P; p += OCT_THREADS) {
+    for (int p = tid; p < P; p += OCT_NT) {
       const uint32_t st = pstate[p];
       if (st == ST_FROZEN) continue;
       const uint32_t a = st & 0xffffu;
@@ -271,7 +321,7 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
     if (careful) {
       // ---- order parents by (size desc, list position asc) and cut at the first split reaching N (:1151-1199) ----
       OCT_PHASE_BEGIN
-      for (int i = tid; i < pr.Mp2; i += OCT_THREADS) {
+      for (int i = tid; i < pr.Mp2; i += OCT_NT) {
         uint32_t key = 0xFFFFFFFFu;
         if (i < nExp) {
           const uint32_t a = w.nodeOfRank[i];
@@ -284,9 +334,9 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
       OCT_PHASE_END
       int n2 = 1;
       while (n2 < nExp) n2 <<= 1;
-      block_bitonic(w.sortbuf, n2);
+      block_sort(w.sortbuf, nExp, n2, w.baseOfRank);
       OCT_PHASE_BEGIN
-      for (int i = tid; i < nExp; i += OCT_THREADS) {
+      for (int i = tid; i < nExp; i += OCT_NT) {
         const uint32_t a = w.sortbuf[i] & 0xfffu;
         w.nodeOfRank[i] = a;
         const uint32_t* c = &w.ccnt[4 * a];
@@ -296,7 +346,7 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
       OCT_PHASE_END
       (void)block_scan_excl(w.baseOfRank, nExp, w.part, sc);
       OCT_PHASE_BEGIN
-      for (int i = tid; i < nExp; i += OCT_THREADS) {
+      for (int i = tid; i < nExp; i += OCT_NT) {
         const uint32_t a = w.nodeOfRank[i];
         const uint32_t* c = &w.ccnt[4 * a];
         const int add = (int)((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0)) - 1;
@@ -305,12 +355,12 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
       OCT_PHASE_END
       nProc = oct_bcast(&sc[SC_M]);
       OCT_PHASE_BEGIN
-      for (int i = tid; i < nExp; i += OCT_THREADS) w.procRank[w.nodeOfRank[i]] = i < nProc ? i : -1;
+      for (int i = tid; i < nExp; i += OCT_NT) w.procRank[w.nodeOfRank[i]] = i < nProc ? i : -1;
       OCT_PHASE_END
     }
     // ---- creation rank of every child: exclusive scan of non-empty-child counts in processing order ----
     OCT_PHASE_BEGIN
-    for (int i = tid; i < nProc; i += OCT_THREADS) {
+    for (int i = tid; i < nProc; i += OCT_NT) {
       const uint32_t* c = &w.ccnt[4 * w.nodeOfRank[i]];
       w.baseOfRank[i] = (uint32_t)((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0));
     }
@@ -321,7 +371,7 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
     if (tid == 0) sc[SC_NTOEXP] = 0;
     OCT_PHASE_END
     OCT_PHASE_BEGIN
-    for (int i = tid; i < nProc; i += OCT_THREADS) {
+    for (int i = tid; i < nProc; i += OCT_NT) {
       const uint32_t a = w.nodeOfRank[i];
       const Box b = A[a];
       const int hx = half_ceil((int)b.urx - (int)b.ulx), hy = half_ceil((int)b.bry - (int)b.uly);
@@ -347,7 +397,7 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
     // ---- move points to their child node; freeze single-point children ----
     const int newgen = gen + 1;
     OCT_PHASE_BEGIN
-    for (int p = tid; p < P; p += OCT_THREADS) {
+    for (int p = tid; p < P; p += OCT_NT) {
       const uint32_t st = pstate[p];
       if (st == ST_FROZEN) continue;
       const uint32_t a = st & 0xffffu;
@@ -393,7 +443,7 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
   uint64_t* best = reinterpret_cast<uint64_t*>(w.ccnt);
   const int nslots = na + (truncated ? na_prev : 0);
   OCT_PHASE_BEGIN
-  for (int i = tid; i < nslots; i += OCT_THREADS) best[i] = 0;
+  for (int i = tid; i < nslots; i += OCT_NT) best[i] = 0;
   OCT_PHASE_END
   auto point_key = [&](int p) -> uint64_t {
     const int x = (int)(cand_xy[p] & 0xffff), y = (int)(cand_xy[p] >> 16);
@@ -404,7 +454,7 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
     return ((uint64_t)cand_score[p] << 32) | (uint64_t)(0xFFFFFFFFu - ord);
   };
   OCT_PHASE_BEGIN
-  for (int p = tid; p < P; p += OCT_THREADS) {
+  for (int p = tid; p < P; p += OCT_NT) {
     const uint32_t st = pstate[p];
     if (st == ST_FROZEN) continue;
     const int slot = (st & ST_UNPROC) ? na + (int)(st & 0xffffu) : (int)st;
@@ -412,7 +462,7 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
   }
   OCT_PHASE_END
   OCT_PHASE_BEGIN
-  for (int p = tid; p < P; p += OCT_THREADS) {
+  for (int p = tid; p < P; p += OCT_NT) {
     const uint32_t st = pstate[p];
     if (st == ST_FROZEN) continue;
     const bool un = (st & ST_UNPROC) != 0;
@@ -431,11 +481,11 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
   int n2 = 1;
   while (n2 < nOut) n2 <<= 1;
   OCT_PHASE_BEGIN
-  for (int i = tid; i < n2; i += OCT_THREADS) srt[i] = i < nOut ? (((uint64_t)w.outKey[i] << 32) | w.outPt[i]) : ~0ull;
+  for (int i = tid; i < n2; i += OCT_NT) srt[i] = i < nOut ? (((uint64_t)w.outKey[i] << 32) | w.outPt[i]) : ~0ull;
   OCT_PHASE_END
-  block_bitonic(srt, n2);
+  block_sort(srt, nOut, n2, reinterpret_cast<uint64_t*>(B));  // both box buffers are dead by now
   OCT_PHASE_BEGIN
-  for (int i = tid; i < nOut && i < sel_cap; i += OCT_THREADS) {
+  for (int i = tid; i < nOut && i < sel_cap; i += OCT_NT) {
     const uint32_t p = (uint32_t)(srt[i] & 0xffffffffu);
     sel_xy[i] = cand_xy[p];
     sel_score[i] = cand_score[p];

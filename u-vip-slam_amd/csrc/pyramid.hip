@@ -37,36 +37,68 @@ __global__ __launch_bounds__(256) void k_pad_level0(const uint8_t* __restrict__ 
 }
 
 // cv::resize INTER_LINEAR, 8-bit generic path: horizontal pass in 11-bit fixed point (INTER_RESIZE_COEF_SCALE
-// = 2048) into int, vertical pass ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2.  The coefficient tables
-// (xofs/ialpha, yofs/ibeta) are built on the host exactly as resizeGeneric_ builds them (extractor.cpp).
+// = 2048) into int, vertical pass ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2.  The coefficient tables are built
+// on the host exactly as resizeGeneric_ builds them (extractor.cpp) and are indexed by *padded* output coordinates,
+// i.e. the REFLECT_101 border is already folded into them: entry px of the column table holds (sx, a0, a1) of the
+// level column reflect(px-16), entry py of the row table (sy0, sy1, b0, b1).
+// One thread = 4 output bytes.  Interior threads fetch each of the two source rows as three aligned dwords (the four
+// taps span <= 12 bytes for scale factors <= 2) and pick bytes with v_alignbyte; pad threads (reflected, decreasing
+// source order) take the scalar byte path.
+__device__ __forceinline__ uint32_t pick2(uint32_t d0, uint32_t d1, uint32_t d2, int o) {
+  // bytes o and o+1 of the 12-byte window, in bits [0,16)
+  const uint32_t lo = o < 4 ? d0 : (o < 8 ? d1 : d2);
+  const uint32_t hi = o < 4 ? d1 : d2;
+  return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(o & 3));
+}
+
 __global__ __launch_bounds__(256) void k_resize_level(uint8_t* __restrict__ pyr, int64_t pyr_block, int64_t src_off, int src_pitch, int sw,
-                                                      int sh, int64_t dst_off, int dst_pitch, int dw, int dh,
-                                                      const int32_t* __restrict__ xofs, const int16_t* __restrict__ xalpha,
-                                                      const int32_t* __restrict__ yofs, const int16_t* __restrict__ ybeta) {
-  const int wx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int py = blockIdx.y;
+                                                      int64_t dst_off, int dst_pitch, int dst_ph, int dw, int fast_ok,
+                                                      const ResizeCol* __restrict__ ctab, const ResizeRow* __restrict__ rtab) {
+  const int wx = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int f = blockIdx.z;
-  if (wx * 4 >= dst_pitch) return;
-  const int y = reflect101(py - kPad, dh);
-  int sy0 = yofs[y], sy1 = sy0 + 1;
-  sy0 = sy0 < 0 ? 0 : (sy0 >= sh ? sh - 1 : sy0);
-  sy1 = sy1 < 0 ? 0 : (sy1 >= sh ? sh - 1 : sy1);
-  const int b0 = ybeta[2 * y], b1 = ybeta[2 * y + 1];
+  if (wx * 4 >= dst_pitch || py >= dst_ph) return;
+  const ResizeRow rr = rtab[py];
+  const int b0 = rr.b0, b1 = rr.b1;
   const uint8_t* S = pyr + f * pyr_block + src_off + (int64_t)kPad * src_pitch + kPad;  // ROI origin of the source level
-  const uint8_t* S0 = S + (int64_t)sy0 * src_pitch;
-  const uint8_t* S1 = S + (int64_t)sy1 * src_pitch;
-  uint32_t v = 0;
+  const uint8_t* S0 = S + (int64_t)rr.sy0 * src_pitch;
+  const uint8_t* S1 = S + (int64_t)rr.sy1 * src_pitch;
+  const uint4 c01 = reinterpret_cast<const uint4*>(ctab)[wx * 2];      // columns 4wx, 4wx+1
+  const uint4 c23 = reinterpret_cast<const uint4*>(ctab)[wx * 2 + 1];  // columns 4wx+2, 4wx+3
+  const uint32_t cw[8] = {c01.x, c01.y, c01.z, c01.w, c23.x, c23.y, c23.z, c23.w};
+  int sx[4], a0[4], a1[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int x = reflect101(wx * 4 + i - kPad, dw);
-    x = x < 0 ? 0 : (x >= dw ? dw - 1 : x);
-    const int sx = xofs[x];
-    const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
-    const int a0 = xalpha[2 * x], a1 = xalpha[2 * x + 1];
-    const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-    const int r1 = S1[sx] * a0 + S1[sx1] * a1;
-    const int o = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-    v |= (uint32_t)(o & 0xff) << (8 * i);
+    sx[i] = (int)(int16_t)(cw[2 * i] & 0xffff);
+    a0[i] = (int)(int16_t)(cw[2 * i] >> 16);
+    a1[i] = (int)(int16_t)(cw[2 * i + 1] & 0xffff);
+  }
+  uint32_t v = 0;
+  const bool interior = fast_ok && wx * 4 >= kPad && wx * 4 + 3 < kPad + dw;  // monotone source columns
+  if (interior) {
+    const int base = sx[0] & ~3;
+    const uint32_t* p0 = reinterpret_cast<const uint32_t*>(S0 + base);
+    const uint32_t* p1 = reinterpret_cast<const uint32_t*>(S1 + base);
+    const uint32_t u0 = p0[0], u1 = p0[1], u2 = p0[2];
+    const uint32_t w0 = p1[0], w1 = p1[1], w2 = p1[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = sx[i] - base;
+      const uint32_t t0 = pick2(u0, u1, u2, o), t1 = pick2(w0, w1, w2, o);
+      const int r0 = (int)(t0 & 0xff) * a0[i] + (int)((t0 >> 8) & 0xff) * a1[i];
+      const int r1 = (int)(t1 & 0xff) * a0[i] + (int)((t1 >> 8) & 0xff) * a1[i];
+      const int o8 = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+      v |= (uint32_t)(o8 & 0xff) << (8 * i);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int sx1 = sx[i] + 1 < sw ? sx[i] + 1 : sw - 1;
+      const int r0 = S0[sx[i]] * a0[i] + S0[sx1] * a1[i];
+      const int r1 = S1[sx[i]] * a0[i] + S1[sx1] * a1[i];
+      const int o8 = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+      v |= (uint32_t)(o8 & 0xff) << (8 * i);
+    }
   }
   uint8_t* dst = pyr + f * pyr_block + dst_off + (int64_t)py * dst_pitch;
   *reinterpret_cast<uint32_t*>(dst + wx * 4) = v;
@@ -79,12 +111,12 @@ void launch_pad_level0(hipStream_t s, const uint8_t* d_img, int w, int h, int64_
   hipLaunchKernelGGL(k_pad_level0, grid, block, 0, s, d_img, w, h, stride, frame_stride, d_pyr, pyr_block, g0.plane_off, g0.pitch, g0.ph);
 }
 
-void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const LevelGeom& src, const LevelGeom& dst, const int32_t* d_xofs,
-                         const int16_t* d_xalpha, const int32_t* d_yofs, const int16_t* d_ybeta, int batch) {
+void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const LevelGeom& src, const LevelGeom& dst, const ResizeCol* d_ctab,
+                         const ResizeRow* d_rtab, int fast_ok, int batch) {
   dim3 block(256);
-  dim3 grid((dst.pitch / 4 + 255) / 256, dst.ph, batch);
-  hipLaunchKernelGGL(k_resize_level, grid, block, 0, s, d_pyr, pyr_block, src.plane_off, src.pitch, src.w, src.h, dst.plane_off, dst.pitch,
-                     dst.w, dst.h, d_xofs, d_xalpha, d_yofs, d_ybeta);
+  dim3 grid((dst.pitch / 4 + 63) / 64, (dst.ph + 3) / 4, batch);
+  hipLaunchKernelGGL(k_resize_level, grid, block, 0, s, d_pyr, pyr_block, src.plane_off, src.pitch, src.w, dst.plane_off, dst.pitch, dst.ph,
+                     dst.w, fast_ok, d_ctab, d_rtab);
 }
 
 }  // namespace uvo
