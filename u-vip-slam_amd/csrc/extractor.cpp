@@ -57,9 +57,12 @@ struct uvo_extractor {
   int cap_cells = 0, cap_sel_block = 0, cap_flist = 0, cap_xtab = 0, cap_ytab = 0;
   int last_batch = 0;
   // device memory
-  uint8_t *d_pyr = nullptr, *d_blur = nullptr;
+  uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_score = nullptr;
   uint32_t *d_cand_xy = nullptr, *d_cand_sc = nullptr, *d_pstate = nullptr, *d_sel_xy = nullptr, *d_sel_sc = nullptr;
-  int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_n_final = nullptr;
+  int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_n_final = nullptr, *d_cor_n = nullptr;
+  uint32_t* d_cor = nullptr;   // FAST corner lists, one region per k_fast_score wavefront
+  uint8_t* d_cell_hi = nullptr;  // per cell: owns an NMS survivor >= fastTh
+  size_t cap_cor = 0, cap_cor_n = 0, cap_flags = 0;
   FinalSlot* d_flist = nullptr;
   LevelGeom* d_lv = nullptr;
   CellDesc* d_cells = nullptr;
@@ -133,7 +136,7 @@ static int build_geom(const uvo_extractor* h, int width, int height, Geom& g, st
     LevelGeom& L = g.lv[l];
     L.w = cv_round_host((float)width * h->inv_scale[l]);
     L.h = cv_round_host((float)height * h->inv_scale[l]);
-    if (L.w < 56 || L.h < 56 || L.w > 16384 || L.h > 16384) return fail(UVO_E_UNSUPPORTED, "pyramid level outside 56..16384 px");
+    if (L.w < 56 || L.h < 56 || L.w > 4096 || L.h > 4096) return fail(UVO_E_UNSUPPORTED, "pyramid level outside 56..4096 px");
     L.pw = L.w + 2 * kPad, L.ph = L.h + 2 * kPad;
     L.pitch = (L.pw + 63) / 64 * 64;
     L.plane_off = off;
@@ -251,6 +254,13 @@ static int set_geometry(uvo_extractor* h, int width, int height) {
   if (rc) return rc;
   if (g.pyr_block > h->cap_pyr_block || g.cand_block > h->cap_cand_block || g.total_cells > h->cap_cells || g.sel_block > h->cap_sel_block)
     return fail(UVO_E_BADARG, "image larger than the handle was sized for");
+  for (int b : {1, std::min(h->cfg.max_batch, 15), h->cfg.max_batch}) {
+    const int rps = fast_rows_per_seg(b);
+    const size_t it = (size_t)fast_items_per_frame(g, rps);
+    if ((size_t)b * it * (size_t)fast_region_entries(rps) > h->cap_cor || (size_t)b * it > h->cap_cor_n ||
+        (size_t)h->cfg.max_batch * fast_flags_per_frame(g) > h->cap_flags)
+      return fail(UVO_E_BADARG, "image larger than the handle was sized for");
+  }
   std::vector<ResizeCol> ctab;
   std::vector<ResizeRow> rtab;
   build_resize_tables(g, ctab, rtab);
@@ -301,8 +311,8 @@ static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, 
   }
   {
     ProfScope p(h, "k_fast_cells");
-    launch_fast_cells(s, h->d_pyr, g.pyr_block, h->d_lv, h->d_cells, g.total_cells, h->cfg.fast_th, h->d_cand_xy, h->d_cand_sc, g.cand_block,
-                      h->d_cand_count, g.nlevels, batch);
+    launch_fast_cells(s, h->d_pyr, h->d_score, g.pyr_block, h->d_lv, g, h->cfg.fast_th, h->d_cor, h->d_cor_n, h->d_cell_hi, h->d_cand_xy,
+                      h->d_cand_sc, g.cand_block, h->d_cand_count, batch);
   }
   {
     ProfScope p(h, "k_gauss7");
@@ -391,6 +401,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   }
   A(dev_alloc(&h->d_pyr, B * h->cap_pyr_block));
   A(dev_alloc(&h->d_blur, B * h->cap_pyr_block));
+  A(dev_alloc(&h->d_score, B * h->cap_pyr_block));
   A(dev_alloc(&h->d_cand_xy, B * h->cap_cand_block));
   A(dev_alloc(&h->d_cand_sc, B * h->cap_cand_block));
   A(dev_alloc(&h->d_pstate, B * h->cap_cand_block));
@@ -400,6 +411,30 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   A(dev_alloc(&h->d_sel_count, B * kMaxLevels));
   A(dev_alloc(&h->d_n_final, B));
   A(dev_alloc(&h->d_flist, B * h->cap_flist));
+  {
+    // corner-list regions: sized for both segment heights the launcher may pick, at the maximum resolution
+    size_t ce = 0, cn = 0;
+    for (int b : {1, (int)B}) {
+      if (b > (int)B) continue;
+      const int rps = fast_rows_per_seg(b);
+      const size_t it = (size_t)fast_items_per_frame(g, rps) + 8;
+      ce = std::max(ce, (size_t)b * it * (size_t)fast_region_entries(rps));
+      cn = std::max(cn, (size_t)b * it);
+    }
+    // the small-batch segment height may be used up to batch 15
+    {
+      const int b = (int)std::min<size_t>(B, 15);
+      const int rps = fast_rows_per_seg(b);
+      const size_t it = (size_t)fast_items_per_frame(g, rps) + 8;
+      ce = std::max(ce, (size_t)b * it * (size_t)fast_region_entries(rps));
+      cn = std::max(cn, (size_t)b * it);
+    }
+    h->cap_cor = ce + ce / 8, h->cap_cor_n = cn + cn / 8 + 64;
+    h->cap_flags = (size_t)B * ((size_t)fast_flags_per_frame(g) + fast_flags_per_frame(g) / 8 + 64);
+  }
+  A(dev_alloc(&h->d_cor, h->cap_cor));
+  A(dev_alloc(&h->d_cor_n, h->cap_cor_n));
+  A(dev_alloc(&h->d_cell_hi, h->cap_flags));
   A(dev_alloc(&h->d_lv, (size_t)kMaxLevels));
   A(dev_alloc(&h->d_cells, (size_t)h->cap_cells));
   A(dev_alloc(&h->d_ctab, (size_t)h->cap_xtab));
@@ -434,7 +469,7 @@ void uvo_extractor_destroy(uvo_extractor* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   h->prof.clear();
-  void* ptrs[] = {h->d_pyr,    h->d_blur,   h->d_cand_xy, h->d_cand_sc, h->d_pstate, h->d_sel_xy,  h->d_sel_sc,  h->d_cand_count, h->d_sel_count,
+  void* ptrs[] = {h->d_pyr,    h->d_blur,   h->d_score,  h->d_cor, h->d_cor_n, h->d_cell_hi,   h->d_cand_xy, h->d_cand_sc, h->d_pstate, h->d_sel_xy,  h->d_sel_sc,  h->d_cand_count, h->d_sel_count,
                   h->d_n_final, h->d_flist, h->d_lv,      h->d_cells,   h->d_ctab,   h->d_rtab,      h->d_pattern,
                   h->d_patch,   h->d_imgs,   h->d_out_kp,  h->d_out_desc, h->d_n_out, h->d_in_kp,   h->d_n_in,    h->d_nfn,        h->d_grid};
   for (void* p : ptrs)

@@ -5,23 +5,29 @@
 // threshold that keeps the pixel a corner; NMS keeps strict 8-neighbour maxima, neighbours outside the ROI's
 // 3-px-inset interior or that are not corners count as 0.)
 //
-// One workgroup = one cell, three phases over an LDS copy of the (wCell+6)x(hCell+6) ROI (<= 66x66):
-//   1. screen : every interior pixel, 4 per lane from aligned LDS dwords, with the two cheapest necessary conditions
-//               (any 9-arc contains ring pixel 0 or 8, and 4 or 12, with one polarity); survivors (a few %) are
-//               compacted into an LDS list -- the expensive test never runs on diverged, mostly idle waves;
-//   2. score  : full segment test + cornerScore for the listed pixels, once, at t_min = min(fastTh, 7) (the score is
-//               threshold independent and a neighbour below the active threshold can never beat a pixel at or above
-//               it -- SURVEY.md A.3), into a zero-initialised LDS score plane;
-//   3. select : in-cell NMS on the score plane, one workgroup vote between fastTh and the literal 7, append to the
-//               (frame, level) candidate list.  Candidate order in HBM is arbitrary: the quad-tree orders by coordinates.
+// The cells' interiors tile the detection window [16, w-16) x [16, h-16) exactly once and the corner score does not
+// depend on the threshold, so the work is split in two:
+//   k_fast_score  : a streaming pass over each level that writes the score plane (0 = not a corner at
+//                   t_min = min(fastTh, 7)).  One wavefront owns a strip of 64 lanes x 4 pixels and walks down the
+//                   rows with the last 7 rows (own dword + both neighbours' dwords) in a register ring -- one aligned
+//                   dword load per lane per row, no LDS tile, no barriers.  Every pixel is screened with the two
+//                   cheapest necessary conditions (any 9-arc contains ring pixel 0 or 8, and 4 or 12, of one
+//                   polarity); the few percent that pass are compacted, with their 16 ring pixels, into a wavefront-
+//                   private LDS queue and the full segment test + cornerScore runs on full 64-lane batches of it.
+//                   Corners (3-4 % of the pixels) are also appended to a list private to the wavefront's
+//                   (strip, segment) region -- no atomics, the count lives in a scalar register.
+//   k_fast_nms    : sparse: one lane per listed corner checks its 8 neighbours in the score plane (neighbours outside
+//                   the corner's own cell interior count as 0), compacts the survivors in place and marks cells that
+//                   own a survivor >= fastTh.
+//   k_fast_emit   : per survivor, the cell's vote picks fastTh or the literal-7 fallback; kept points are appended to
+//                   the (frame, level) candidate list (one wave-aggregated atomic per 64).  Candidate order in HBM is
+//                   arbitrary: the quad-tree orders by coordinates.
 #include "common.hpp"
 
 namespace uvo {
 
-constexpr int FT_MAX = 66;      // max ROI edge: wCell < 60, + 6
-constexpr int FT_DW = 19;       // LDS row pitch in dwords (76 B >= 3 + 66 + 3)
-constexpr int FT_PITCH = FT_DW * 4;
-constexpr int FT_LIST = 60 * 60;
+constexpr int FS_COLS = 248;  // useful columns per wavefront strip (lanes 1..62)
+constexpr int FQ_CAP = 320;   // queue entries per wavefront: < 64 left over + <= 256 pushed per row
 
 __device__ __forceinline__ int max16(const int* a) {
   int m = a[0];
@@ -44,159 +50,337 @@ __device__ __forceinline__ int arc9_maxmin(const int* d) {
   return max16(a9);
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, int64_t pyr_block, const LevelGeom* __restrict__ lv,
-                                                    const CellDesc* __restrict__ cells, int fast_th, int t_min,
-                                                    uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc, int64_t cand_block,
-                                                    int32_t* __restrict__ cand_count, int nlevels) {
-  __shared__ uint32_t s_img32[FT_MAX * FT_DW];
-  __shared__ uint32_t s_sc32[FT_MAX * FT_DW];
-  __shared__ uint16_t s_list[FT_LIST];
-  __shared__ int s_nlist, s_any;
-  const uint8_t* s_img = reinterpret_cast<const uint8_t*>(s_img32);
-  uint8_t* s_sc = reinterpret_cast<uint8_t*>(s_sc32);
+// byte I (0..11, compile time) of the 12-byte window [L C R]
+template <int I>
+__device__ __forceinline__ uint32_t win(uint32_t L, uint32_t C, uint32_t R) {
+  static_assert(I >= 0 && I < 12, "window index");
+  return ((I < 4 ? L : (I < 8 ? C : R)) >> (8 * (I & 3))) & 0xffu;
+}
 
-  const CellDesc cd = cells[blockIdx.x];
+// full segment test + cornerScore of the queued pixels [first, first+count), one per lane
+__device__ __forceinline__ void fast_score_chunk(const uint32_t* q, int first, int count, int lane, int t_min, uint8_t* __restrict__ splane,
+                                                 int pitch, int X0, int py0, uint32_t* __restrict__ region, int& ncorner) {
+  bool corner = false;
+  uint32_t packed = 0;
+  if (lane < count) {
+  const int e = first + lane;
+  const uint32_t r0 = q[e], r1 = q[FQ_CAP + e], r2 = q[2 * FQ_CAP + e], r3 = q[3 * FQ_CAP + e], meta = q[4 * FQ_CAP + e];
+  const int v = (int)(meta & 0xff);
+  int d[16];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    d[k] = (int)((r0 >> (8 * k)) & 0xff) - v;
+    d[4 + k] = (int)((r1 >> (8 * k)) & 0xff) - v;
+    d[8 + k] = (int)((r2 >> (8 * k)) & 0xff) - v;
+    d[12 + k] = (int)((r3 >> (8 * k)) & 0xff) - v;
+  }
+  uint32_t mb = 0, md = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    mb |= (uint32_t)(d[k] > t_min) << k;
+    md |= (uint32_t)(d[k] < -t_min) << k;
+  }
+  auto run9 = [](uint32_t m) {  // 9 contiguous set bits in the circular 16-bit mask
+    m |= m << 16;
+    uint32_t x = m & (m >> 1);
+    x &= x >> 2;
+    x &= x >> 4;
+    x &= m >> 8;
+    return (x & 0xffffu) != 0;
+  };
+  const bool cb = run9(mb), cdk = run9(md);
+  if (cb || cdk) {
+    int sb = 0, sd = 0;
+    if (cb) sb = arc9_maxmin(d);
+    if (cdk) {
+      int nd[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) nd[k] = -d[k];
+      sd = arc9_maxmin(nd);
+    }
+    const int row = (int)(meta >> 16), xl = (int)((meta >> 8) & 0xff);
+    const int sc = max(sb, sd) - 1;
+    splane[(int64_t)row * pitch + X0 + xl] = (uint8_t)sc;
+    corner = sc > 0;  // a score of 0 (only possible at t_min = 0) can never survive NMS
+    packed = (uint32_t)xl | ((uint32_t)(row - py0) << 8) | ((uint32_t)sc << 16);
+  }
+  }
+  const uint64_t m = __ballot(corner);
+  if (m) {
+    if (corner) region[ncorner + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = packed;
+    ncorner += (int)__popcll(m);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score, int64_t pyr_block,
+                                                    const LevelGeom* __restrict__ lv, int nlevels, int t_min, int rows_per_seg,
+                                                    uint32_t* __restrict__ cor, int32_t* __restrict__ cor_n, int items_per_frame) {
+  __shared__ uint32_t s_q[4][5 * FQ_CAP];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t* q = s_q[wv];
+  // work item (one per wavefront) -> (level, strip, segment); window = padded cols [32, w) x rows [32, h)
+  int item = blockIdx.x * 4 + wv;
+  const int64_t region_id = (int64_t)blockIdx.y * items_per_frame + item;
+  uint32_t* region = cor + region_id * ((int64_t)FS_COLS * rows_per_seg);
+  int ncorner = 0;
+  int level = 0, nstrip = 0, nseg = 0;
+  for (;; ++level) {
+    nstrip = (lv[level].w - 32 + FS_COLS - 1) / FS_COLS;
+    nseg = (lv[level].h - 32 + rows_per_seg - 1) / rows_per_seg;
+    if (item < nstrip * nseg) break;
+    item -= nstrip * nseg;
+    if (level == nlevels - 1) return;
+  }
+  const LevelGeom g = lv[level];
   const int f = blockIdx.y;
-  const LevelGeom& g = lv[cd.level];
-  const int rw = cd.rw, rh = cd.rh;
-  const int tid = threadIdx.x;
-  // ROI origin in the padded plane; rows are 64-B pitched and plane offsets 256-B aligned, so (x & ~3) is dword aligned
-  const int px0 = cd.x0 + kPad;
-  const int a = px0 & 3;
-  const uint8_t* src = pyr + f * pyr_block + g.plane_off + (int64_t)(cd.y0 + kPad) * g.pitch + (px0 - a);
-  const int ndw = (a + rw + 3) >> 2;
-  if (tid == 0) {
-    s_nlist = 0;
-    s_any = 0;
-  }
-  for (int i = tid; i < rh * ndw; i += 256) {
-    const int r = i / ndw, d = i - r * ndw;
-    s_img32[r * FT_DW + d] = *reinterpret_cast<const uint32_t*>(src + (int64_t)r * g.pitch + d * 4);
-  }
-  for (int i = tid; i < rh * FT_DW; i += 256) s_sc32[i] = 0;
-  __syncthreads();
+  const int strip = item % nstrip, seg = item / nstrip;
+  const uint8_t* src = pyr + f * pyr_block + g.plane_off;
+  uint8_t* sp = score + f * pyr_block + g.plane_off;
+  const int X0 = 28 + strip * FS_COLS;  // padded column of lane 0 (halo lane)
+  const int X = X0 + lane * 4;
+  const int Xc = X > g.pitch - 4 ? g.pitch - 4 : X;
+  const bool lane_ok = lane >= 1 && lane <= 62 && X < g.w;
+  const int py0 = 32 + seg * rows_per_seg;
+  const int py1 = min(py0 + rows_per_seg, g.h);
+  const int nsrc = py1 - py0 + 6;  // source rows py0-3 .. py1+2
+  int qn = 0;                      // wavefront-uniform queue length
 
-  const int iw = rw - 6, ih = rh - 6;  // interior
-  if (iw <= 0 || ih <= 0) return;
-
-  // ---- phase 1: screen, 4 pixels (one LDS dword) per work item ----
-  const int g0 = (a + 3) >> 2, g1 = (a + rw - 4) >> 2;  // dword columns that touch the interior
-  const int ngr = g1 - g0 + 1;
-  for (int i = tid; i < ih * ngr; i += 256) {
-    const int r = 3 + i / ngr, gq = g0 + i % ngr;
-    const uint32_t* row = &s_img32[r * FT_DW];
-    const uint32_t C = row[gq];
-    const uint32_t L = gq > 0 ? row[gq - 1] : 0u, R = gq + 1 < FT_DW ? row[gq + 1] : 0u;
-    const uint32_t U = s_img32[(r - 3) * FT_DW + gq], D = s_img32[(r + 3) * FT_DW + gq];
-    const uint32_t P12 = (L >> 8) | (C << 24);  // bytes x-3
-    const uint32_t P4 = (C >> 24) | (R << 8);   // bytes x+3
+  uint32_t Cr[7], Lr[7], Rr[7];
+  for (int base = 0; base < nsrc; base += 7) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = gq * 4 + k - a;  // ROI column
-      const int v = (C >> (8 * k)) & 0xff;
-      const int p0 = (D >> (8 * k)) & 0xff, p8 = (U >> (8 * k)) & 0xff, p4 = (P4 >> (8 * k)) & 0xff, p12 = (P12 >> (8 * k)) & 0xff;
-      const int hi = v + t_min, lo = v - t_min;
-      const bool bright = ((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi));
-      const bool dark = ((p0 < lo) | (p8 < lo)) & ((p4 < lo) | (p12 < lo));
-      const bool pass = (bright | dark) & (c >= 3) & (c < rw - 3);
-      // wave-aggregated append
-      const uint64_t m = __ballot(pass);
-      if (m) {
-        const int lane = tid & 63;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&s_nlist, __popcll(m));
-        base = __shfl(base, 0, 64);
-        if (pass) s_list[base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)((r << 8) | c);
+    for (int u = 0; u < 7; ++u) {
+      const int j = base + u;
+      if (j < nsrc) {
+        const int prow = py0 - 3 + j;
+        const uint32_t C = *reinterpret_cast<const uint32_t*>(src + (int64_t)prow * g.pitch + Xc);
+        Cr[u] = C;
+        Lr[u] = (uint32_t)__shfl_up((int)C, 1, 64);
+        Rr[u] = (uint32_t)__shfl_down((int)C, 1, 64);
+        if (j >= 6) {
+          const int pc = prow - 3;  // centre row; rows pc-3 .. pc+3 sit in slots (u+1)%7 .. u
+          const int sm3 = (u + 1) % 7, sm2 = (u + 2) % 7, sm1 = (u + 3) % 7, s0 = (u + 4) % 7, sp1 = (u + 5) % 7, sp2 = (u + 6) % 7, sp3 = u;
+          if (lane_ok) *reinterpret_cast<uint32_t*>(sp + (int64_t)pc * g.pitch + X) = 0u;
+          const uint32_t Cc = Cr[s0], Lc = Lr[s0], Rc = Rr[s0], Cu = Cr[sm3], Cd = Cr[sp3];
+          // ---- screen the lane's 4 pixels, queue the ones that pass ----
+#define UVO_FAST_PIXEL(K)                                                                                                          \
+  {                                                                                                                                \
+    const int v = (int)win<4 + K>(Lc, Cc, Rc);                                                                                      \
+    const int p0 = (int)win<4 + K>(0u, Cd, 0u), p8 = (int)win<4 + K>(0u, Cu, 0u);                                                  \
+    const int p4 = (int)win<7 + K>(Lc, Cc, Rc), p12 = (int)win<1 + K>(Lc, Cc, Rc);                                                 \
+    const int hi = v + t_min, lo = v - t_min;                                                                                      \
+    const bool bright = ((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi));                                                        \
+    const bool dark = ((p0 < lo) | (p8 < lo)) & ((p4 < lo) | (p12 < lo));                                                          \
+    const bool pass = (bright | dark) & lane_ok & (X + K < g.w);                                                                   \
+    const uint64_t m = __ballot(pass);                                                                                             \
+    if (m) {                                                                                                                       \
+      if (pass) {                                                                                                                  \
+        const int e = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));        \
+        const uint32_t Ld = Lr[sp3], Rd = Rr[sp3], Lu = Lr[sm3], Ru = Rr[sm3];                                                     \
+        const uint32_t L2 = Lr[sp2], C2 = Cr[sp2], R2 = Rr[sp2], L1 = Lr[sp1], C1 = Cr[sp1], R1 = Rr[sp1];                         \
+        const uint32_t Lm1 = Lr[sm1], Cm1 = Cr[sm1], Rm1 = Rr[sm1], Lm2 = Lr[sm2], Cm2 = Cr[sm2], Rm2 = Rr[sm2];                   \
+        q[e] = win<4 + K>(Ld, Cd, Rd) | (win<5 + K>(Ld, Cd, Rd) << 8) | (win<6 + K>(L2, C2, R2) << 16) |                           \
+               (win<7 + K>(L1, C1, R1) << 24);                                                                                     \
+        q[FQ_CAP + e] = win<7 + K>(Lc, Cc, Rc) | (win<7 + K>(Lm1, Cm1, Rm1) << 8) | (win<6 + K>(Lm2, Cm2, Rm2) << 16) |            \
+                        (win<5 + K>(Lu, Cu, Ru) << 24);                                                                            \
+        q[2 * FQ_CAP + e] = win<4 + K>(Lu, Cu, Ru) | (win<3 + K>(Lu, Cu, Ru) << 8) | (win<2 + K>(Lm2, Cm2, Rm2) << 16) |           \
+                            (win<1 + K>(Lm1, Cm1, Rm1) << 24);                                                                     \
+        q[3 * FQ_CAP + e] = win<1 + K>(Lc, Cc, Rc) | (win<1 + K>(L1, C1, R1) << 8) | (win<2 + K>(L2, C2, R2) << 16) |              \
+                            (win<3 + K>(Ld, Cd, Rd) << 24);                                                                        \
+        q[4 * FQ_CAP + e] = (uint32_t)v | ((uint32_t)(lane * 4 + K) << 8) | ((uint32_t)pc << 16);                                  \
+      }                                                                                                                            \
+      qn += __popcll(m);                                                                                                           \
+    }                                                                                                                              \
+  }
+          UVO_FAST_PIXEL(0)
+          UVO_FAST_PIXEL(1)
+          UVO_FAST_PIXEL(2)
+          UVO_FAST_PIXEL(3)
+#undef UVO_FAST_PIXEL
+          // ---- drain full batches ----
+          while (qn >= 64) {
+            qn -= 64;
+            fast_score_chunk(q, qn, 64, lane, t_min, sp, g.pitch, X0, py0, region, ncorner);
+          }
+        }
       }
     }
   }
-  __syncthreads();
-  const int nlist = s_nlist;
+  if (qn > 0) fast_score_chunk(q, 0, qn, lane, t_min, sp, g.pitch, X0, py0, region, ncorner);
+  if (lane == 0) cor_n[region_id] = ncorner;
+}
 
-  // ---- phase 2: full segment test + score for the screened pixels ----
-  for (int i = tid; i < nlist; i += 256) {
-    const int rc = s_list[i];
-    const int r = rc >> 8, c = rc & 0xff;
-    const uint8_t* p = s_img + r * FT_PITCH + a + c;
-    const int v = p[0];
-    int d[16];
-    d[0] = p[3 * FT_PITCH], d[1] = p[3 * FT_PITCH + 1], d[2] = p[2 * FT_PITCH + 2], d[3] = p[FT_PITCH + 3];
-    d[4] = p[3], d[5] = p[-FT_PITCH + 3], d[6] = p[-2 * FT_PITCH + 2], d[7] = p[-3 * FT_PITCH + 1];
-    d[8] = p[-3 * FT_PITCH], d[9] = p[-3 * FT_PITCH - 1], d[10] = p[-2 * FT_PITCH - 2], d[11] = p[-FT_PITCH - 3];
-    d[12] = p[-3], d[13] = p[FT_PITCH - 3], d[14] = p[2 * FT_PITCH - 2], d[15] = p[3 * FT_PITCH - 1];
-    uint32_t mb = 0, md = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      d[k] -= v;
-      mb |= (uint32_t)(d[k] > t_min) << k;
-      md |= (uint32_t)(d[k] < -t_min) << k;
+// ---------------------------------------------------------------------------------------------------------
+struct FastLevel {  // per-level values of the sparse stages, passed in the kernel argument block (scalar loads)
+  int64_t plane_off, cand_off;
+  int pitch, cand_cap;
+  int w, h, bw, bh;
+  int nCols, nRows, wCell, hCell;
+  int flag_base;  // first entry of this level in the per-frame cell-flag array (full nRows x nCols grid)
+  int pad;
+};
+struct FastLevels {
+  FastLevel l[kMaxLevels];
+  int nlevels, rows_per_seg, items_per_frame, flags_per_frame;
+};
+
+// region id -> (level, strip, segment); false when the wavefront has no region
+__device__ __forceinline__ bool fast_region(const FastLevels& L, int item, int& level, int& X0, int& py0) {
+  for (level = 0; level < L.nlevels; ++level) {
+    const int nstrip = (L.l[level].w - 32 + FS_COLS - 1) / FS_COLS;
+    const int nseg = (L.l[level].h - 32 + L.rows_per_seg - 1) / L.rows_per_seg;
+    if (item < nstrip * nseg) {
+      X0 = 28 + (item % nstrip) * FS_COLS;
+      py0 = 32 + (item / nstrip) * L.rows_per_seg;
+      return true;
     }
-    // 9 contiguous set bits in the circular 16-bit mask
-    auto run9 = [](uint32_t m) {
-      m |= m << 16;
-      uint32_t x = m & (m >> 1);
-      x &= x >> 2;
-      x &= x >> 4;
-      x &= m >> 8;
-      return (x & 0xffffu) != 0;
-    };
-    const bool cb = run9(mb), cdk = run9(md);
-    if (cb || cdk) {
-      int sb = 0, sd = 0;
-      if (cb) sb = arc9_maxmin(d);
-      if (cdk) {
-        int nd[16];
+    item -= nstrip * nseg;
+  }
+  return false;
+}
+
+// One wavefront per (strip, segment) region of k_fast_score; one lane per listed corner.
+__global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ score, int64_t pyr_block, FastLevels L, int fast_th,
+                                                  uint32_t* __restrict__ cor, int32_t* __restrict__ cor_n, uint8_t* __restrict__ cell_hi) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + wv;
+  int level, X0, py0;
+  if (!fast_region(L, item, level, X0, py0)) return;
+  const FastLevel g = L.l[level];
+  const int f = blockIdx.y;
+  const int64_t region_id = (int64_t)f * L.items_per_frame + item;
+  uint32_t* region = cor + region_id * ((int64_t)FS_COLS * L.rows_per_seg);
+  const int n = cor_n[region_id];
+  const uint8_t* sp = score + f * pyr_block + g.plane_off;
+  uint8_t* hi = cell_hi + (int64_t)f * L.flags_per_frame + g.flag_base;
+  int nkeep = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    bool keep = false;
+    uint32_t out = 0;
+    if (i < n) {
+      const uint32_t e = region[i];
+      const int px = X0 + (int)(e & 0xff), py = py0 + (int)((e >> 8) & 0xff), s = (int)(e >> 16);
+      // coordinates relative to (minBorder, minBorder), as the candidate list wants them
+      const int xr = px - kPad - kMinBorder, yr = py - kPad - kMinBorder;
+      int cj = (xr - 3) / g.wCell, ci = (yr - 3) / g.hCell;
+      cj = cj > g.nCols - 1 ? g.nCols - 1 : cj;
+      ci = ci > g.nRows - 1 ? g.nRows - 1 : ci;
+      // interior of the owning cell: [j*wCell + 3, min(j*wCell + wCell + 6, bw) - 3) and the same in y
+      const int cx0 = cj * g.wCell + 3, cx1 = min(cj * g.wCell + g.wCell + 6, g.bw) - 3;
+      const int cy0 = ci * g.hCell + 3, cy1 = min(ci * g.hCell + g.hCell + 6, g.bh) - 3;
+      const uint8_t* c = sp + (int64_t)py * g.pitch + px;
+      keep = true;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) nd[k] = -d[k];
-        sd = arc9_maxmin(nd);
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          if (dx == 0 && dy == 0) continue;
+          const bool inside = xr + dx >= cx0 && xr + dx < cx1 && yr + dy >= cy0 && yr + dy < cy1;
+          const int nb = inside ? (int)c[(int64_t)dy * g.pitch + dx] : 0;
+          keep = keep && s > nb;
+        }
+      if (keep) {
+        out = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)s << 24);
+        if (s >= fast_th) hi[ci * g.nCols + cj] = 1;  // idempotent plain store: every writer stores the same value
       }
-      s_sc[r * FT_PITCH + c] = (uint8_t)(max(sb, sd) - 1);
+    }
+    // in-place compaction: survivors of this batch land at or before the batch's own start
+    const uint64_t m = __ballot(keep);
+    if (m) {
+      if (keep) region[nkeep + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = out;
+      nkeep += (int)__popcll(m);
     }
   }
-  __syncthreads();
+  if (lane == 0) cor_n[region_id] = nkeep;
+}
 
-  // ---- phase 3: in-cell NMS; survivors kept in registers (<= ceil(3600/256) = 15 per thread) ----
-  uint32_t keep_xy[15];
-  uint8_t keep_s[15];
-  int nk = 0;
-  bool any_hi = false;
-  for (int i = tid; i < nlist; i += 256) {
-    const int rc = s_list[i];
-    const int r = rc >> 8, c = rc & 0xff;
-    const uint8_t* q = s_sc + r * FT_PITCH + c;
-    const int s = q[0];
-    if (s == 0) continue;
-    const bool keep = s > q[-FT_PITCH - 1] && s > q[-FT_PITCH] && s > q[-FT_PITCH + 1] && s > q[-1] && s > q[1] && s > q[FT_PITCH - 1] &&
-                      s > q[FT_PITCH] && s > q[FT_PITCH + 1];
-    if (!keep) continue;
-    keep_xy[nk] = (uint32_t)(c + cd.ox) | ((uint32_t)(r + cd.oy) << 16);
-    keep_s[nk] = (uint8_t)s;
-    ++nk;
-    any_hi |= s >= fast_th;
-  }
-  if (any_hi) s_any = 1;
-  __syncthreads();
-  const int th = s_any ? fast_th : 7;
+__global__ __launch_bounds__(256) void k_fast_emit(FastLevels L, int fast_th, const uint32_t* __restrict__ cor, const int32_t* __restrict__ cor_n,
+                                                   const uint8_t* __restrict__ cell_hi, uint32_t* __restrict__ cand_xy,
+                                                   uint32_t* __restrict__ cand_sc, int64_t cand_block, int32_t* __restrict__ cand_count) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + wv;
+  int level, X0, py0;
+  if (!fast_region(L, item, level, X0, py0)) return;
+  const FastLevel g = L.l[level];
+  const int f = blockIdx.y;
+  const int64_t region_id = (int64_t)f * L.items_per_frame + item;
+  const uint32_t* region = cor + region_id * ((int64_t)FS_COLS * L.rows_per_seg);
+  const int n = cor_n[region_id];
+  const uint8_t* hi = cell_hi + (int64_t)f * L.flags_per_frame + g.flag_base;
   uint32_t* out_xy = cand_xy + f * cand_block + g.cand_off;
   uint32_t* out_sc = cand_sc + f * cand_block + g.cand_off;
-  int32_t* cnt = cand_count + f * nlevels + cd.level;
-  for (int k = 0; k < nk; ++k) {
-    if (keep_s[k] >= th) {
-      const int pos = atomicAdd(cnt, 1);
+  int32_t* cnt = cand_count + f * L.nlevels + level;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    bool emit = false;
+    int xr = 0, yr = 0, s = 0;
+    if (i < n) {
+      const uint32_t e = region[i];
+      xr = (int)(e & 0xfff), yr = (int)((e >> 12) & 0xfff), s = (int)(e >> 24);
+      int cj = (xr - 3) / g.wCell, ci = (yr - 3) / g.hCell;
+      cj = cj > g.nCols - 1 ? g.nCols - 1 : cj;
+      ci = ci > g.nRows - 1 ? g.nRows - 1 : ci;
+      const int th = hi[ci * g.nCols + cj] ? fast_th : 7;  // FAST(cell, fastTh) empty -> FAST(cell, 7)  (:792-799)
+      emit = s >= th;
+    }
+    const uint64_t m = __ballot(emit);
+    if (m == 0) continue;
+    int gbase = 0;
+    if (lane == 0) gbase = atomicAdd(cnt, (int)__popcll(m));
+    gbase = __shfl(gbase, 0, 64);
+    if (emit) {
+      const int pos = gbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       if (pos < g.cand_cap) {
-        out_xy[pos] = keep_xy[k];
-        out_sc[pos] = keep_s[k];
+        out_xy[pos] = (uint32_t)xr | ((uint32_t)yr << 16);
+        out_sc[pos] = (uint32_t)s;
       }
     }
   }
 }
 
-void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const LevelGeom* d_lv, const CellDesc* d_cells, int total_cells,
-                       int fast_th, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, int nlevels,
-                       int batch) {
+int fast_rows_per_seg(int batch) { return batch >= 16 ? 96 : 24; }
+int fast_items_per_frame(const Geom& g, int rows_per_seg) {
+  int items = 0;
+  for (int l = 0; l < g.nlevels; ++l) items += ((g.lv[l].w - 32 + FS_COLS - 1) / FS_COLS) * ((g.lv[l].h - 32 + rows_per_seg - 1) / rows_per_seg);
+  return items;
+}
+int64_t fast_region_entries(int rows_per_seg) { return (int64_t)FS_COLS * rows_per_seg; }
+int fast_flags_per_frame(const Geom& g) {
+  int n = 0;
+  for (int l = 0; l < g.nlevels; ++l) n += g.lv[l].nRows * g.lv[l].nCols;
+  return n;
+}
+
+void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_score, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g,
+                       int fast_th, uint32_t* d_cor, int32_t* d_cor_n, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc,
+                       int64_t cand_block, int32_t* d_cand_count, int batch) {
   const int t_min = fast_th < 7 ? fast_th : 7;
-  hipLaunchKernelGGL(k_fast_cells, dim3(total_cells, batch), dim3(256), 0, s, d_pyr, pyr_block, d_lv, d_cells, fast_th, t_min, d_cand_xy,
-                     d_cand_sc, cand_block, d_cand_count, nlevels);
+  FastLevels L;
+  L.nlevels = g.nlevels;
+  L.rows_per_seg = fast_rows_per_seg(batch);
+  L.items_per_frame = fast_items_per_frame(g, L.rows_per_seg);
+  L.flags_per_frame = fast_flags_per_frame(g);
+  int fb = 0;
+  for (int l = 0; l < kMaxLevels; ++l) {
+    FastLevel& F = L.l[l];
+    if (l < g.nlevels) {
+      const LevelGeom& G = g.lv[l];
+      F.plane_off = G.plane_off, F.cand_off = G.cand_off, F.pitch = G.pitch, F.cand_cap = G.cand_cap;
+      F.w = G.w, F.h = G.h, F.bw = G.bw, F.bh = G.bh, F.nCols = G.nCols, F.nRows = G.nRows, F.wCell = G.wCell, F.hCell = G.hCell;
+      F.flag_base = fb;
+      fb += G.nRows * G.nCols;
+    } else {
+      F = FastLevel{};
+      F.w = F.h = 32;
+    }
+    F.pad = 0;
+  }
+  const dim3 grid((L.items_per_frame + 3) / 4, batch);
+  (void)hipMemsetAsync(d_cell_hi, 0, (size_t)batch * L.flags_per_frame, s);
+  hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, s, d_pyr, d_score, pyr_block, d_lv, g.nlevels, t_min, L.rows_per_seg, d_cor, d_cor_n,
+                     L.items_per_frame);
+  hipLaunchKernelGGL(k_fast_nms, grid, dim3(256), 0, s, d_score, pyr_block, L, fast_th, d_cor, d_cor_n, d_cell_hi);
+  hipLaunchKernelGGL(k_fast_emit, grid, dim3(256), 0, s, L, fast_th, d_cor, d_cor_n, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count);
 }
 
 }  // namespace uvo
