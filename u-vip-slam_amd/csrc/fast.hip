@@ -57,53 +57,61 @@ __device__ __forceinline__ uint32_t win(uint32_t L, uint32_t C, uint32_t R) {
   return ((I < 4 ? L : (I < 8 ? C : R)) >> (8 * (I & 3))) & 0xffu;
 }
 
-// full segment test + cornerScore of the queued pixels [first, first+count), one per lane
-__device__ __forceinline__ void fast_score_chunk(const uint32_t* q, int first, int count, int lane, int t_min, uint8_t* __restrict__ splane,
-                                                 int pitch, int X0, int py0, uint32_t* __restrict__ region, int& ncorner) {
+constexpr int FR_ROWS = 16;         // LDS row ring depth per wavefront (rows of 64 dwords)
+constexpr int FR_MAXAGE = FR_ROWS - 8;  // a queued pixel needs rows -3..+3 around it: drain before they are overwritten
+
+// Full segment test + cornerScore of the queued pixels [first, first+count), one per lane.  The 16 ring pixels are read
+// back from the wavefront's LDS row ring (byte reads with immediate offsets).
+__device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_t* rows, int first, int count, int lane, int t_min,
+                                                 uint8_t* __restrict__ splane, int pitch, int X0, int py0, uint32_t* __restrict__ region,
+                                                 int& ncorner) {
   bool corner = false;
   uint32_t packed = 0;
   if (lane < count) {
-  const int e = first + lane;
-  const uint32_t r0 = q[e], r1 = q[FQ_CAP + e], r2 = q[2 * FQ_CAP + e], r3 = q[3 * FQ_CAP + e], meta = q[4 * FQ_CAP + e];
-  const int v = (int)(meta & 0xff);
-  int d[16];
+    const uint32_t meta = q[first + lane];  // xl | row << 8
+    const int xl = (int)(meta & 0xff), row = (int)(meta >> 8);
+    // row ring slot of row r is r & 15; base pointers 3 bytes left of the pixel so that every offset is >= 0
+    const uint8_t* r0 = rows + ((row & (FR_ROWS - 1)) << 8) + xl - 3;
+    const uint8_t* rp1 = rows + (((row + 1) & (FR_ROWS - 1)) << 8) + xl - 3;
+    const uint8_t* rp2 = rows + (((row + 2) & (FR_ROWS - 1)) << 8) + xl - 3;
+    const uint8_t* rp3 = rows + (((row + 3) & (FR_ROWS - 1)) << 8) + xl - 3;
+    const uint8_t* rm1 = rows + (((row - 1) & (FR_ROWS - 1)) << 8) + xl - 3;
+    const uint8_t* rm2 = rows + (((row - 2) & (FR_ROWS - 1)) << 8) + xl - 3;
+    const uint8_t* rm3 = rows + (((row - 3) & (FR_ROWS - 1)) << 8) + xl - 3;
+    const int v = r0[3];
+    int d[16];
+    d[0] = rp3[3], d[1] = rp3[4], d[2] = rp2[5], d[3] = rp1[6], d[4] = r0[6], d[5] = rm1[6], d[6] = rm2[5], d[7] = rm3[4];
+    d[8] = rm3[3], d[9] = rm3[2], d[10] = rm2[1], d[11] = rm1[0], d[12] = r0[0], d[13] = rp1[0], d[14] = rp2[1], d[15] = rp3[2];
+    uint32_t mb = 0, md = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    d[k] = (int)((r0 >> (8 * k)) & 0xff) - v;
-    d[4 + k] = (int)((r1 >> (8 * k)) & 0xff) - v;
-    d[8 + k] = (int)((r2 >> (8 * k)) & 0xff) - v;
-    d[12 + k] = (int)((r3 >> (8 * k)) & 0xff) - v;
-  }
-  uint32_t mb = 0, md = 0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    mb |= (uint32_t)(d[k] > t_min) << k;
-    md |= (uint32_t)(d[k] < -t_min) << k;
-  }
-  auto run9 = [](uint32_t m) {  // 9 contiguous set bits in the circular 16-bit mask
-    m |= m << 16;
-    uint32_t x = m & (m >> 1);
-    x &= x >> 2;
-    x &= x >> 4;
-    x &= m >> 8;
-    return (x & 0xffffu) != 0;
-  };
-  const bool cb = run9(mb), cdk = run9(md);
-  if (cb || cdk) {
-    int sb = 0, sd = 0;
-    if (cb) sb = arc9_maxmin(d);
-    if (cdk) {
-      int nd[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) nd[k] = -d[k];
-      sd = arc9_maxmin(nd);
+    for (int k = 0; k < 16; ++k) {
+      d[k] -= v;
+      mb |= (uint32_t)(d[k] > t_min) << k;
+      md |= (uint32_t)(d[k] < -t_min) << k;
     }
-    const int row = (int)(meta >> 16), xl = (int)((meta >> 8) & 0xff);
-    const int sc = max(sb, sd) - 1;
-    splane[(int64_t)row * pitch + X0 + xl] = (uint8_t)sc;
-    corner = sc > 0;  // a score of 0 (only possible at t_min = 0) can never survive NMS
-    packed = (uint32_t)xl | ((uint32_t)(row - py0) << 8) | ((uint32_t)sc << 16);
-  }
+    auto run9 = [](uint32_t m) {  // 9 contiguous set bits in the circular 16-bit mask
+      m |= m << 16;
+      uint32_t x = m & (m >> 1);
+      x &= x >> 2;
+      x &= x >> 4;
+      x &= m >> 8;
+      return (x & 0xffffu) != 0;
+    };
+    const bool cb = run9(mb), cdk = run9(md);
+    if (cb || cdk) {
+      int sb = 0, sd = 0;
+      if (cb) sb = arc9_maxmin(d);
+      if (cdk) {
+        int nd[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) nd[k] = -d[k];
+        sd = arc9_maxmin(nd);
+      }
+      const int sc = max(sb, sd) - 1;
+      splane[(int64_t)row * pitch + X0 + xl] = (uint8_t)sc;
+      corner = sc > 0;  // a score of 0 (only possible at t_min = 0) can never survive NMS
+      packed = (uint32_t)xl | ((uint32_t)(row - py0) << 8) | ((uint32_t)sc << 16);
+    }
   }
   const uint64_t m = __ballot(corner);
   if (m) {
@@ -115,9 +123,12 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, int first, i
 __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score, int64_t pyr_block,
                                                     const LevelGeom* __restrict__ lv, int nlevels, int t_min, int rows_per_seg,
                                                     uint32_t* __restrict__ cor, int32_t* __restrict__ cor_n, int items_per_frame) {
-  __shared__ uint32_t s_q[4][5 * FQ_CAP];
+  __shared__ uint32_t s_q[4][FQ_CAP];
+  __shared__ uint32_t s_rows[4][FR_ROWS * 64];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint32_t* q = s_q[wv];
+  uint32_t* rows32 = s_rows[wv];
+  const uint8_t* rows8 = reinterpret_cast<const uint8_t*>(rows32);
   // work item (one per wavefront) -> (level, strip, segment); window = padded cols [32, w) x rows [32, h)
   int item = blockIdx.x * 4 + wv;
   const int64_t region_id = (int64_t)blockIdx.y * items_per_frame + item;
@@ -144,8 +155,10 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
   const int py1 = min(py0 + rows_per_seg, g.h);
   const int nsrc = py1 - py0 + 6;  // source rows py0-3 .. py1+2
   int qn = 0;                      // wavefront-uniform queue length
+  int qoldest = 0;                 // centre row of the oldest queued pixel (valid while qn > 0)
+  const int lm = lane > 0 ? lane - 1 : 0, lp = lane < 63 ? lane + 1 : 63;
 
-  uint32_t Cr[7], Lr[7], Rr[7];
+  uint32_t Cr[7];
   for (int base = 0; base < nsrc; base += 7) {
 #pragma unroll
     for (int u = 0; u < 7; ++u) {
@@ -154,40 +167,35 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
         const int prow = py0 - 3 + j;
         const uint32_t C = *reinterpret_cast<const uint32_t*>(src + (int64_t)prow * g.pitch + Xc);
         Cr[u] = C;
-        Lr[u] = (uint32_t)__shfl_up((int)C, 1, 64);
-        Rr[u] = (uint32_t)__shfl_down((int)C, 1, 64);
+        rows32[((prow & (FR_ROWS - 1)) << 6) + lane] = C;
         if (j >= 6) {
-          const int pc = prow - 3;  // centre row; rows pc-3 .. pc+3 sit in slots (u+1)%7 .. u
-          const int sm3 = (u + 1) % 7, sm2 = (u + 2) % 7, sm1 = (u + 3) % 7, s0 = (u + 4) % 7, sp1 = (u + 5) % 7, sp2 = (u + 6) % 7, sp3 = u;
+          const int pc = prow - 3;  // centre row; rows pc-3 .. pc+3 sit in register slots (u+1)%7 .. u
+          const int sm3 = (u + 1) % 7, sm2 = (u + 2) % 7, s0 = (u + 4) % 7, sp2 = (u + 6) % 7, sp3 = u;
           if (lane_ok) *reinterpret_cast<uint32_t*>(sp + (int64_t)pc * g.pitch + X) = 0u;
-          const uint32_t Cc = Cr[s0], Lc = Lr[s0], Rc = Rr[s0], Cu = Cr[sm3], Cd = Cr[sp3];
-          // ---- screen the lane's 4 pixels, queue the ones that pass ----
+          const uint32_t Cc = Cr[s0], Cu = Cr[sm3], Cd = Cr[sp3], C2 = Cr[sp2], Cm2 = Cr[sm2];
+          // neighbour dwords of rows pc, pc+2, pc-2 from the LDS row ring (written by this wavefront, in order)
+          const uint32_t* rc = rows32 + ((pc & (FR_ROWS - 1)) << 6);
+          const uint32_t* r2 = rows32 + (((pc + 2) & (FR_ROWS - 1)) << 6);
+          const uint32_t* rm = rows32 + (((pc - 2) & (FR_ROWS - 1)) << 6);
+          const uint32_t Lc = rc[lm], Rc = rc[lp], L2 = r2[lm], R2 = r2[lp], Lm2 = rm[lm], Rm2 = rm[lp];
+          // ---- screen the lane's 4 pixels with four opposite ring pairs, queue the ones that pass ----
 #define UVO_FAST_PIXEL(K)                                                                                                          \
   {                                                                                                                                \
     const int v = (int)win<4 + K>(Lc, Cc, Rc);                                                                                      \
+    const int hi = v + t_min, lo = v - t_min;                                                                                      \
     const int p0 = (int)win<4 + K>(0u, Cd, 0u), p8 = (int)win<4 + K>(0u, Cu, 0u);                                                  \
     const int p4 = (int)win<7 + K>(Lc, Cc, Rc), p12 = (int)win<1 + K>(Lc, Cc, Rc);                                                 \
-    const int hi = v + t_min, lo = v - t_min;                                                                                      \
-    const bool bright = ((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi));                                                        \
-    const bool dark = ((p0 < lo) | (p8 < lo)) & ((p4 < lo) | (p12 < lo));                                                          \
+    const int p2 = (int)win<6 + K>(L2, C2, R2), p10 = (int)win<2 + K>(Lm2, Cm2, Rm2);                                              \
+    const int p6 = (int)win<6 + K>(Lm2, Cm2, Rm2), p14 = (int)win<2 + K>(L2, C2, R2);                                              \
+    const bool bright = ((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi)) & ((p2 > hi) | (p10 > hi)) & ((p6 > hi) | (p14 > hi));  \
+    const bool dark = ((p0 < lo) | (p8 < lo)) & ((p4 < lo) | (p12 < lo)) & ((p2 < lo) | (p10 < lo)) & ((p6 < lo) | (p14 < lo));    \
     const bool pass = (bright | dark) & lane_ok & (X + K < g.w);                                                                   \
     const uint64_t m = __ballot(pass);                                                                                             \
     if (m) {                                                                                                                       \
-      if (pass) {                                                                                                                  \
-        const int e = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));        \
-        const uint32_t Ld = Lr[sp3], Rd = Rr[sp3], Lu = Lr[sm3], Ru = Rr[sm3];                                                     \
-        const uint32_t L2 = Lr[sp2], C2 = Cr[sp2], R2 = Rr[sp2], L1 = Lr[sp1], C1 = Cr[sp1], R1 = Rr[sp1];                         \
-        const uint32_t Lm1 = Lr[sm1], Cm1 = Cr[sm1], Rm1 = Rr[sm1], Lm2 = Lr[sm2], Cm2 = Cr[sm2], Rm2 = Rr[sm2];                   \
-        q[e] = win<4 + K>(Ld, Cd, Rd) | (win<5 + K>(Ld, Cd, Rd) << 8) | (win<6 + K>(L2, C2, R2) << 16) |                           \
-               (win<7 + K>(L1, C1, R1) << 24);                                                                                     \
-        q[FQ_CAP + e] = win<7 + K>(Lc, Cc, Rc) | (win<7 + K>(Lm1, Cm1, Rm1) << 8) | (win<6 + K>(Lm2, Cm2, Rm2) << 16) |            \
-                        (win<5 + K>(Lu, Cu, Ru) << 24);                                                                            \
-        q[2 * FQ_CAP + e] = win<4 + K>(Lu, Cu, Ru) | (win<3 + K>(Lu, Cu, Ru) << 8) | (win<2 + K>(Lm2, Cm2, Rm2) << 16) |           \
-                            (win<1 + K>(Lm1, Cm1, Rm1) << 24);                                                                     \
-        q[3 * FQ_CAP + e] = win<1 + K>(Lc, Cc, Rc) | (win<1 + K>(L1, C1, R1) << 8) | (win<2 + K>(L2, C2, R2) << 16) |              \
-                            (win<3 + K>(Ld, Cd, Rd) << 24);                                                                        \
-        q[4 * FQ_CAP + e] = (uint32_t)v | ((uint32_t)(lane * 4 + K) << 8) | ((uint32_t)pc << 16);                                  \
-      }                                                                                                                            \
+      if (qn == 0) qoldest = pc;                                                                                                   \
+      if (pass)                                                                                                                    \
+        q[qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =                  \
+            (uint32_t)(lane * 4 + K) | ((uint32_t)pc << 8);                                                                        \
       qn += __popcll(m);                                                                                                           \
     }                                                                                                                              \
   }
@@ -196,16 +204,20 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
           UVO_FAST_PIXEL(2)
           UVO_FAST_PIXEL(3)
 #undef UVO_FAST_PIXEL
-          // ---- drain full batches ----
+          // ---- drain full batches (newest first); a stale remainder is flushed before its rows leave the ring ----
           while (qn >= 64) {
             qn -= 64;
-            fast_score_chunk(q, qn, 64, lane, t_min, sp, g.pitch, X0, py0, region, ncorner);
+            fast_score_chunk(q, rows8, qn, 64, lane, t_min, sp, g.pitch, X0, py0, region, ncorner);
+          }
+          if (qn > 0 && pc - qoldest >= FR_MAXAGE) {
+            fast_score_chunk(q, rows8, 0, qn, lane, t_min, sp, g.pitch, X0, py0, region, ncorner);
+            qn = 0;
           }
         }
       }
     }
   }
-  if (qn > 0) fast_score_chunk(q, 0, qn, lane, t_min, sp, g.pitch, X0, py0, region, ncorner);
+  if (qn > 0) fast_score_chunk(q, rows8, 0, qn, lane, t_min, sp, g.pitch, X0, py0, region, ncorner);
   if (lane == 0) cor_n[region_id] = ncorner;
 }
 
