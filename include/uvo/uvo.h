@@ -110,6 +110,13 @@ int uvo_extract_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs,
                              int grid_cols, int min_px_dist, int full_detect, const int32_t* d_num_feats_needed, uvo_keypoint* d_out_kp,
                              uint8_t* d_out_desc, int cap, int32_t* d_n_out);
 int uvo_extractor_synchronize(uvo_extractor* h);
+/*
+ * Pipeline depth of the HBM-resident form (default 1).  With depth 2 the handle owns two scratch sets and two
+ * streams and consecutive uvo_extract_batch_device() calls alternate between them, so the latency-bound stages of one
+ * batch overlap with the streaming stages of the next.  The caller must then give consecutive calls different output
+ * buffers.  uvo_matcher_wait_extractor() / uvo_extractor_wait_matcher() refer to the most recently used stream.
+ */
+int uvo_extractor_set_pipeline(uvo_extractor* h, int depth);
 
 /* Stage taps for the parity tests (valid after a completed extract call; host destination buffers). */
 int uvo_extractor_level_dims(const uvo_extractor* h, int level, int* width, int* height);

@@ -199,3 +199,51 @@ def test_search_by_projection(uvo, oracle, synth):
         assert nm_g > 300
     ex.close()
     m.close()
+
+
+def test_hbm_resident_pipeline_depth2(uvo, oracle, synth):
+    """uvo_extract_batch_device with two alternating scratch sets / streams feeding the batched HBM-resident matcher."""
+    import torch
+    B, W, H = 4, 640, 512
+    batches = [synth.make_batch(B, W, H, seed0=3000 + 10 * k) for k in range(3)]
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=W, max_height=H, max_batch=B)
+    ex.set_pipeline(2)
+    cap = ex.cap
+    mt = uvo.ORBmatcher(0.8, max_query=cap, max_train=cap, max_batch=B)
+    dev = torch.device("cuda", 0)
+    outs = []
+    for k in range(3):
+        d_img = torch.from_numpy(batches[k]).to(dev)
+        kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+        de = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        n = torch.zeros(B, dtype=torch.int32, device=dev)
+        i0 = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+        i1 = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+        d0 = torch.zeros((B, cap), dtype=torch.int16, device=dev)
+        d1 = torch.zeros((B, cap), dtype=torch.int16, device=dev)
+        outs.append((d_img, kp, de, n, i0, i1, d0, d1))
+    torch.cuda.synchronize()
+    for d_img, kp, de, n, i0, i1, d0, d1 in outs:   # three calls back to back, no host sync in between
+        ex.extract_batch_device(d_img.data_ptr(), B, W, H, kp.data_ptr(), de.data_ptr(), n.data_ptr(), cap)
+        mt.wait_extractor(ex)
+        # pair p = (frame p, frame p+1) for p < B-1
+        mt.knn2_batch_device(B - 1, de.data_ptr(), n.data_ptr(), cap, de.data_ptr() + cap * 32, n.data_ptr() + 4, cap, i0.data_ptr(),
+                             d0.data_ptr(), i1.data_ptr(), d1.data_ptr())
+        mt.release_to_extractor(ex)
+    ex.synchronize()
+    mt.synchronize()
+    oe = oracle.extractor(1000, 1.2, 8, 20)
+    for k, (d_img, kp, de, n, i0, i1, d0, d1) in enumerate(outs):
+        n_h = n.cpu().numpy()
+        ref = [oe(batches[k][b]) for b in range(B)]
+        for b in range(B):
+            kp_g = kp[b, :n_h[b]].cpu().numpy().view(uvo.KEYPOINT_DTYPE).reshape(-1)
+            _assert_same_features(kp_g, de[b, :n_h[b]].cpu().numpy(), ref[b][0], ref[b][1], "call %d frame %d" % (k, b))
+        for b in range(B - 1):
+            o = oracle.knn2(ref[b][1], ref[b + 1][1])
+            nq = len(ref[b][1])
+            np.testing.assert_array_equal(i0[b, :nq].cpu().numpy(), o[0])
+            np.testing.assert_array_equal(i1[b, :nq].cpu().numpy(), o[2])
+            np.testing.assert_array_equal(d0[b, :nq].cpu().numpy().astype(np.uint16).astype(np.int32), o[1])
+    ex.close()
+    mt.close()

@@ -26,7 +26,7 @@ UVO_OK, UVO_E_BADARG, UVO_E_NODEVICE, UVO_E_HIP, UVO_E_CAPACITY, UVO_E_UNSUPPORT
 # every symbol include/uvo/uvo.h declares
 ABI_SYMBOLS = [
     "uvo_extractor_create", "uvo_extractor_destroy", "uvo_extractor_levels", "uvo_extractor_scale_factor", "uvo_extractor_tables",
-    "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_extractor_synchronize", "uvo_extractor_level_dims",
+    "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_level_dims",
     "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_search_by_projection", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
@@ -69,6 +69,7 @@ def _load():
     lib.uvo_extract_batch.argtypes = [vp, ci, vp, ci, ci, cl, cl, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
     lib.uvo_extract_batch_device.argtypes = [vp, ci, vp, ci, ci, cl, cl, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
     lib.uvo_extractor_synchronize.argtypes = [vp]
+    lib.uvo_extractor_set_pipeline.argtypes = [vp, ci]
     lib.uvo_extractor_level_dims.argtypes = [vp, ci, vp, vp]
     lib.uvo_extractor_read_plane.argtypes = [vp, ci, ci, ci, vp]
     lib.uvo_extractor_read_candidates.argtypes = [vp, ci, ci, vp, ci, vp]
@@ -198,6 +199,11 @@ class ORBextractor:
         rc = lib.uvo_extractor_synchronize(self._h)
         if rc:
             raise UvoError(rc, "uvo_extractor_synchronize")
+
+    def set_pipeline(self, depth):
+        rc = lib.uvo_extractor_set_pipeline(self._h, depth)
+        if rc:
+            raise UvoError(rc, "uvo_extractor_set_pipeline")
 
     # ---- stage taps used by the parity tests ----
     def level_dims(self, level):

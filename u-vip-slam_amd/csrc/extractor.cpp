@@ -39,10 +39,25 @@ static inline int cv_floor_host(float v) {
 
 using namespace uvo;
 
+// Per-batch scratch + stream.  With pipeline depth 2 consecutive uvo_extract_batch_device calls alternate between two
+// lanes, so the latency-bound stages of one batch (quad-tree, sparse NMS, small pyramid levels) overlap with the
+// throughput stages of the next.
+struct Lane {
+  hipStream_t stream = nullptr;
+  uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_score = nullptr;
+  uint32_t *d_cand_xy = nullptr, *d_cand_sc = nullptr, *d_pstate = nullptr, *d_sel_xy = nullptr, *d_sel_sc = nullptr;
+  int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_n_final = nullptr, *d_cor_n = nullptr;
+  uint32_t* d_cor = nullptr;     // FAST corner lists, one region per k_fast_score wavefront
+  uint8_t* d_cell_hi = nullptr;  // per cell: owns an NMS survivor >= fastTh
+  FinalSlot* d_flist = nullptr;
+  Profiler prof;
+};
+
 struct uvo_extractor {
   uvo_extractor_cfg cfg;
   int device = 0;
-  hipStream_t stream = nullptr;
+  Lane lane[2];
+  int nlanes = 1, cur = 0;
   // constructor tables (src/ORBextractor.cc:463-511)
   std::vector<float> scale, inv_scale;
   std::vector<int> quota;
@@ -55,15 +70,9 @@ struct uvo_extractor {
   // capacities fixed at create time (from max_width x max_height)
   int64_t cap_pyr_block = 0, cap_cand_block = 0;
   int cap_cells = 0, cap_sel_block = 0, cap_flist = 0, cap_xtab = 0, cap_ytab = 0;
-  int last_batch = 0;
-  // device memory
-  uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_score = nullptr;
-  uint32_t *d_cand_xy = nullptr, *d_cand_sc = nullptr, *d_pstate = nullptr, *d_sel_xy = nullptr, *d_sel_sc = nullptr;
-  int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_n_final = nullptr, *d_cor_n = nullptr;
-  uint32_t* d_cor = nullptr;   // FAST corner lists, one region per k_fast_score wavefront
-  uint8_t* d_cell_hi = nullptr;  // per cell: owns an NMS survivor >= fastTh
   size_t cap_cor = 0, cap_cor_n = 0, cap_flags = 0;
-  FinalSlot* d_flist = nullptr;
+  int last_batch = 0;
+  // shared read-only tables
   LevelGeom* d_lv = nullptr;
   CellDesc* d_cells = nullptr;
   ResizeCol* d_ctab = nullptr;
@@ -76,10 +85,12 @@ struct uvo_extractor {
   uint8_t* d_out_desc = nullptr;
   int32_t *d_n_out = nullptr, *d_n_in = nullptr, *d_nfn = nullptr, *d_grid = nullptr;
   size_t grid_bytes = 0;
-  Profiler prof;
 };
 
 namespace uvo {
+
+static int sync_all_lanes(uvo_extractor* h);
+static int alloc_lane(uvo_extractor* h, int li);
 
 // ORBextractor::ORBextractor: src/ORBextractor.cc:458-512
 static void build_ctor_tables(uvo_extractor* h) {
@@ -266,7 +277,10 @@ static int set_geometry(uvo_extractor* h, int width, int height) {
   build_resize_tables(g, ctab, rtab);
   if ((int)ctab.size() > h->cap_xtab || (int)rtab.size() > h->cap_ytab) return fail(UVO_E_BADARG, "image larger than the handle was sized for");
   // in-flight work may still read the old tables
-  UVO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  {
+    int rcs = sync_all_lanes(h);
+    if (rcs) return rcs;
+  }
   UVO_HIP_CHECK(hipMemcpy(h->d_lv, g.lv, sizeof(LevelGeom) * g.nlevels, hipMemcpyHostToDevice));
   UVO_HIP_CHECK(hipMemcpy(h->d_cells, cells.data(), sizeof(CellDesc) * cells.size(), hipMemcpyHostToDevice));
   if (!ctab.empty()) {
@@ -280,10 +294,10 @@ static int set_geometry(uvo_extractor* h, int width, int height) {
 }
 
 struct ProfScope : Profiler::Scope {
-  ProfScope(uvo_extractor* h, const char* name) : Profiler::Scope(&h->prof, name, h->stream) {}
+  ProfScope(uvo_extractor* h, const char* name) : Profiler::Scope(&h->lane[h->cur].prof, name, h->lane[h->cur].stream) {}
 };
 
-// The launch sequence of one batch (everything on h->stream, nothing synchronous).
+// The launch sequence of one batch (everything on h->lane[h->cur].stream, nothing synchronous).
 static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
                             const uvo_keypoint* d_in_kp, const int32_t* d_n_in, int32_t* d_grid2d, int grid_rows, int grid_cols,
                             int min_px_dist, int full_detect, const int32_t* d_nfn, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap,
@@ -297,46 +311,85 @@ static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, 
   int rc = set_geometry(h, width, height);
   if (rc) return rc;
   const Geom& g = h->geom;
-  hipStream_t s = h->stream;
+  if (h->nlanes > 1) h->cur = (h->cur + 1) % h->nlanes;  // pipeline depth 2: alternate lanes
+  hipStream_t s = h->lane[h->cur].stream;
   h->last_batch = batch;
-  UVO_HIP_CHECK(hipMemsetAsync(h->d_cand_count, 0, sizeof(int32_t) * batch * g.nlevels, s));
+  UVO_HIP_CHECK(hipMemsetAsync(h->lane[h->cur].d_cand_count, 0, sizeof(int32_t) * batch * g.nlevels, s));
   {
     ProfScope p(h, "k_pad_level0");
-    launch_pad_level0(s, d_imgs, width, height, stride, frame_stride, h->d_pyr, g.pyr_block, g.lv[0], batch);
+    launch_pad_level0(s, d_imgs, width, height, stride, frame_stride, h->lane[h->cur].d_pyr, g.pyr_block, g.lv[0], batch);
   }
   for (int l = 1; l < g.nlevels; ++l) {
     ProfScope p(h, "k_resize_level");
-    launch_resize_level(s, h->d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_ctab + g.lv[l].xtab_off, h->d_rtab + g.lv[l].ytab_off,
+    launch_resize_level(s, h->lane[h->cur].d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_ctab + g.lv[l].xtab_off, h->d_rtab + g.lv[l].ytab_off,
                         h->cfg.scale_factor <= 2.0f ? 1 : 0, batch);
   }
   {
     ProfScope p(h, "k_fast_cells");
-    launch_fast_cells(s, h->d_pyr, h->d_score, g.pyr_block, h->d_lv, g, h->cfg.fast_th, h->d_cor, h->d_cor_n, h->d_cell_hi, h->d_cand_xy,
-                      h->d_cand_sc, g.cand_block, h->d_cand_count, batch);
+    launch_fast_cells(s, h->lane[h->cur].d_pyr, h->lane[h->cur].d_score, g.pyr_block, h->d_lv, g, h->cfg.fast_th, h->lane[h->cur].d_cor, h->lane[h->cur].d_cor_n, h->lane[h->cur].d_cell_hi, h->lane[h->cur].d_cand_xy,
+                      h->lane[h->cur].d_cand_sc, g.cand_block, h->lane[h->cur].d_cand_count, batch);
   }
   {
     ProfScope p(h, "k_gauss7");
-    launch_gauss7(s, h->d_pyr, h->d_blur, g.pyr_block, h->d_lv, g, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), batch);
+    launch_gauss7(s, h->lane[h->cur].d_pyr, h->lane[h->cur].d_blur, g.pyr_block, h->d_lv, g, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), batch);
   }
   {
     ProfScope p(h, "k_octree");
-    launch_octree(s, h->d_lv, g, h->d_cand_xy, h->d_cand_sc, g.cand_block, h->d_cand_count, h->d_pstate, h->d_sel_xy, h->d_sel_sc,
-                  h->d_sel_count, batch);
+    launch_octree(s, h->d_lv, g, h->lane[h->cur].d_cand_xy, h->lane[h->cur].d_cand_sc, g.cand_block, h->lane[h->cur].d_cand_count, h->lane[h->cur].d_pstate, h->lane[h->cur].d_sel_xy, h->lane[h->cur].d_sel_sc,
+                  h->lane[h->cur].d_sel_count, batch);
   }
   {
     ProfScope p(h, "k_assemble");
-    launch_assemble(s, h->d_lv, g, h->d_sel_xy, h->d_sel_sc, h->d_sel_count, d_in_kp, d_n_in, h->cfg.max_input_keypoints, d_grid2d, grid_rows,
-                    grid_cols, min_px_dist, full_detect, d_nfn, h->d_flist, h->d_n_final, batch);
+    launch_assemble(s, h->d_lv, g, h->lane[h->cur].d_sel_xy, h->lane[h->cur].d_sel_sc, h->lane[h->cur].d_sel_count, d_in_kp, d_n_in, h->cfg.max_input_keypoints, d_grid2d, grid_rows,
+                    grid_cols, min_px_dist, full_detect, d_nfn, h->lane[h->cur].d_flist, h->lane[h->cur].d_n_final, batch);
   }
   {
     ProfScope p(h, "k_describe");
-    launch_describe(s, h->d_lv, g, h->d_pyr, h->d_blur, g.pyr_block, h->d_flist, h->d_n_final, d_in_kp, h->cfg.max_input_keypoints,
+    launch_describe(s, h->d_lv, g, h->lane[h->cur].d_pyr, h->lane[h->cur].d_blur, g.pyr_block, h->lane[h->cur].d_flist, h->lane[h->cur].d_n_final, d_in_kp, h->cfg.max_input_keypoints,
                     h->d_pattern, h->d_patch, d_out_kp, d_out_desc, cap, d_n_out, batch);
   }
   UVO_HIP_CHECK(hipGetLastError());
   return UVO_OK;
 }
 
+}  // namespace uvo
+
+namespace uvo {
+static int alloc_lane(uvo_extractor* h, int li) {
+  Lane& L = h->lane[li];
+  if (L.stream) return UVO_OK;
+  const size_t B = (size_t)h->cfg.max_batch;
+  hipError_t e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    hip_err_set(e, "hipStreamCreate");
+    return UVO_E_HIP;
+  }
+  int rc;
+#define AL(call) \
+  if ((rc = (call)) != UVO_OK) return rc;
+  AL(dev_alloc(&L.d_pyr, B * h->cap_pyr_block));
+  AL(dev_alloc(&L.d_blur, B * h->cap_pyr_block));
+  AL(dev_alloc(&L.d_score, B * h->cap_pyr_block));
+  AL(dev_alloc(&L.d_cand_xy, B * h->cap_cand_block));
+  AL(dev_alloc(&L.d_cand_sc, B * h->cap_cand_block));
+  AL(dev_alloc(&L.d_pstate, B * h->cap_cand_block));
+  AL(dev_alloc(&L.d_sel_xy, B * h->cap_sel_block));
+  AL(dev_alloc(&L.d_sel_sc, B * h->cap_sel_block));
+  AL(dev_alloc(&L.d_cand_count, B * kMaxLevels));
+  AL(dev_alloc(&L.d_sel_count, B * kMaxLevels));
+  AL(dev_alloc(&L.d_n_final, B));
+  AL(dev_alloc(&L.d_flist, B * h->cap_flist));
+  AL(dev_alloc(&L.d_cor, h->cap_cor));
+  AL(dev_alloc(&L.d_cor_n, h->cap_cor_n));
+  AL(dev_alloc(&L.d_cell_hi, h->cap_flags));
+#undef AL
+  return UVO_OK;
+}
+static int sync_all_lanes(uvo_extractor* h) {
+  for (int i = 0; i < 2; ++i)
+    if (h->lane[i].stream) UVO_HIP_CHECK(hipStreamSynchronize(h->lane[i].stream));
+  return UVO_OK;
+}
 }  // namespace uvo
 
 extern "C" {
@@ -388,29 +441,11 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
     delete h;
     return UVO_E_NODEVICE;
   }
-  e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) {
-    hip_err_set(e, "hipStreamCreate");
-    delete h;
-    return UVO_E_HIP;
-  }
 #define A(call)                    \
   if ((rc = (call)) != UVO_OK) {   \
     uvo_extractor_destroy(h);      \
     return rc;                     \
   }
-  A(dev_alloc(&h->d_pyr, B * h->cap_pyr_block));
-  A(dev_alloc(&h->d_blur, B * h->cap_pyr_block));
-  A(dev_alloc(&h->d_score, B * h->cap_pyr_block));
-  A(dev_alloc(&h->d_cand_xy, B * h->cap_cand_block));
-  A(dev_alloc(&h->d_cand_sc, B * h->cap_cand_block));
-  A(dev_alloc(&h->d_pstate, B * h->cap_cand_block));
-  A(dev_alloc(&h->d_sel_xy, B * h->cap_sel_block));
-  A(dev_alloc(&h->d_sel_sc, B * h->cap_sel_block));
-  A(dev_alloc(&h->d_cand_count, B * kMaxLevels));
-  A(dev_alloc(&h->d_sel_count, B * kMaxLevels));
-  A(dev_alloc(&h->d_n_final, B));
-  A(dev_alloc(&h->d_flist, B * h->cap_flist));
   {
     // corner-list regions: sized for both segment heights the launcher may pick, at the maximum resolution
     size_t ce = 0, cn = 0;
@@ -432,9 +467,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
     h->cap_cor = ce + ce / 8, h->cap_cor_n = cn + cn / 8 + 64;
     h->cap_flags = (size_t)B * ((size_t)fast_flags_per_frame(g) + fast_flags_per_frame(g) / 8 + 64);
   }
-  A(dev_alloc(&h->d_cor, h->cap_cor));
-  A(dev_alloc(&h->d_cor_n, h->cap_cor_n));
-  A(dev_alloc(&h->d_cell_hi, h->cap_flags));
+  A(alloc_lane(h, 0));
   A(dev_alloc(&h->d_lv, (size_t)kMaxLevels));
   A(dev_alloc(&h->d_cells, (size_t)h->cap_cells));
   A(dev_alloc(&h->d_ctab, (size_t)h->cap_xtab));
@@ -466,15 +499,21 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
 
 void uvo_extractor_destroy(uvo_extractor* h) {
   if (!h) return;
-  hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
-  h->prof.clear();
-  void* ptrs[] = {h->d_pyr,    h->d_blur,   h->d_score,  h->d_cor, h->d_cor_n, h->d_cell_hi,   h->d_cand_xy, h->d_cand_sc, h->d_pstate, h->d_sel_xy,  h->d_sel_sc,  h->d_cand_count, h->d_sel_count,
-                  h->d_n_final, h->d_flist, h->d_lv,      h->d_cells,   h->d_ctab,   h->d_rtab,      h->d_pattern,
-                  h->d_patch,   h->d_imgs,   h->d_out_kp,  h->d_out_desc, h->d_n_out, h->d_in_kp,   h->d_n_in,    h->d_nfn,        h->d_grid};
+  (void)hipSetDevice(h->device);
+  for (int i = 0; i < 2; ++i) {
+    Lane& L = h->lane[i];
+    if (L.stream) (void)hipStreamSynchronize(L.stream);
+    L.prof.clear();
+    void* lp[] = {L.d_pyr,   L.d_blur,   L.d_score,      L.d_cand_xy,   L.d_cand_sc, L.d_pstate, L.d_sel_xy, L.d_sel_sc,
+                  L.d_cand_count, L.d_sel_count, L.d_n_final, L.d_cor_n, L.d_cor, L.d_cell_hi, L.d_flist};
+    for (void* p : lp)
+      if (p) (void)hipFree(p);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
+  }
+  void* ptrs[] = {h->d_lv, h->d_cells, h->d_ctab, h->d_rtab, h->d_pattern, h->d_patch, h->d_imgs, h->d_out_kp,
+                  h->d_out_desc, h->d_n_out, h->d_in_kp, h->d_n_in, h->d_nfn, h->d_grid};
   for (void* p : ptrs)
-    if (p) hipFree(p);
-  if (h->stream) hipStreamDestroy(h->stream);
+    if (p) (void)hipFree(p);
   delete h;
 }
 
@@ -505,7 +544,20 @@ int uvo_extract_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs,
 int uvo_extractor_synchronize(uvo_extractor* h) {
   if (!h) return fail(UVO_E_BADARG, "null handle");
   UVO_HIP_CHECK(hipSetDevice(h->device));
-  UVO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return sync_all_lanes(h);
+}
+
+int uvo_extractor_set_pipeline(uvo_extractor* h, int depth) {
+  if (!h || depth < 1 || depth > 2) return fail(UVO_E_BADARG, "pipeline depth must be 1 or 2");
+  UVO_HIP_CHECK(hipSetDevice(h->device));
+  int rc = sync_all_lanes(h);
+  if (rc) return rc;
+  if (depth == 2) {
+    rc = alloc_lane(h, 1);
+    if (rc) return rc;
+  }
+  h->nlanes = depth;
+  if (depth == 1) h->cur = 0;
   return UVO_OK;
 }
 
@@ -518,7 +570,7 @@ int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int widt
     return fail(UVO_E_BADARG, "image size outside what the handle was sized for");
   if ((int64_t)width * height > (int64_t)h->cfg.max_width * h->cfg.max_height) return fail(UVO_E_BADARG, "image too large");
   UVO_HIP_CHECK(hipSetDevice(h->device));
-  hipStream_t s = h->stream;
+  hipStream_t s = h->lane[h->cur].stream;
   const int in_cap = h->cfg.max_input_keypoints;
   // the reference reads the centre pixel row of a caller keypoint without any bounds check; reject what would
   // leave the padded plane (patch radius 15 + descriptor reach 18 against a 16 px pad)
@@ -610,9 +662,9 @@ int uvo_extractor_read_plane(uvo_extractor* h, int frame, int level, int which, 
   if (!h || !h->have_geom || level < 0 || level >= h->geom.nlevels || frame < 0 || frame >= h->last_batch || !dst)
     return fail(UVO_E_BADARG, "bad plane request");
   UVO_HIP_CHECK(hipSetDevice(h->device));
-  UVO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  UVO_HIP_CHECK(hipStreamSynchronize(h->lane[h->cur].stream));
   const LevelGeom& L = h->geom.lv[level];
-  const uint8_t* src = (which ? h->d_blur : h->d_pyr) + (size_t)frame * h->geom.pyr_block + L.plane_off;
+  const uint8_t* src = (which ? h->lane[h->cur].d_blur : h->lane[h->cur].d_pyr) + (size_t)frame * h->geom.pyr_block + L.plane_off;
   UVO_HIP_CHECK(hipMemcpy2D(dst, L.pw, src, L.pitch, L.pw, L.ph, hipMemcpyDeviceToHost));
   return UVO_OK;
 }
@@ -621,18 +673,18 @@ int uvo_extractor_read_candidates(uvo_extractor* h, int frame, int level, int32_
   if (!h || !h->have_geom || level < 0 || level >= h->geom.nlevels || frame < 0 || frame >= h->last_batch || !n)
     return fail(UVO_E_BADARG, "bad candidate request");
   UVO_HIP_CHECK(hipSetDevice(h->device));
-  UVO_HIP_CHECK(hipStreamSynchronize(h->stream));
+  UVO_HIP_CHECK(hipStreamSynchronize(h->lane[h->cur].stream));
   const LevelGeom& L = h->geom.lv[level];
   int32_t cnt = 0;
-  UVO_HIP_CHECK(hipMemcpy(&cnt, h->d_cand_count + (size_t)frame * h->geom.nlevels + level, 4, hipMemcpyDeviceToHost));
+  UVO_HIP_CHECK(hipMemcpy(&cnt, h->lane[h->cur].d_cand_count + (size_t)frame * h->geom.nlevels + level, 4, hipMemcpyDeviceToHost));
   *n = cnt;
   cnt = std::min(cnt, L.cand_cap);
   const int m = std::min(cnt, cap);
   if (m > 0 && dst_xys) {
     std::vector<uint32_t> xy(m), sc(m);
     const size_t off = (size_t)frame * h->geom.cand_block + L.cand_off;
-    UVO_HIP_CHECK(hipMemcpy(xy.data(), h->d_cand_xy + off, (size_t)4 * m, hipMemcpyDeviceToHost));
-    UVO_HIP_CHECK(hipMemcpy(sc.data(), h->d_cand_sc + off, (size_t)4 * m, hipMemcpyDeviceToHost));
+    UVO_HIP_CHECK(hipMemcpy(xy.data(), h->lane[h->cur].d_cand_xy + off, (size_t)4 * m, hipMemcpyDeviceToHost));
+    UVO_HIP_CHECK(hipMemcpy(sc.data(), h->lane[h->cur].d_cand_sc + off, (size_t)4 * m, hipMemcpyDeviceToHost));
     for (int i = 0; i < m; ++i) {
       dst_xys[3 * i] = (int32_t)(xy[i] & 0xffff);
       dst_xys[3 * i + 1] = (int32_t)(xy[i] >> 16);
@@ -645,21 +697,28 @@ int uvo_extractor_read_candidates(uvo_extractor* h, int frame, int level, int32_
 int uvo_extractor_profile(uvo_extractor* h, int enable) {
   if (!h) return fail(UVO_E_BADARG, "null handle");
   UVO_HIP_CHECK(hipSetDevice(h->device));
-  UVO_HIP_CHECK(hipStreamSynchronize(h->stream));
-  h->prof.on = enable != 0;
-  h->prof.clear();
+  int rc = sync_all_lanes(h);
+  if (rc) return rc;
+  for (int i = 0; i < 2; ++i) {
+    h->lane[i].prof.on = enable != 0;
+    h->lane[i].prof.clear();
+  }
   return UVO_OK;
 }
 
 int uvo_extractor_kernel_times(uvo_extractor* h, char* names, int names_cap, float* ms, int32_t* launches, int cap, int* n) {
   if (!h || !names || !ms || !launches || !n) return fail(UVO_E_BADARG, "null pointer");
   UVO_HIP_CHECK(hipSetDevice(h->device));
-  UVO_HIP_CHECK(hipStreamSynchronize(h->stream));
-  *n = h->prof.report(names, names_cap, ms, launches, cap);
+  int rc = sync_all_lanes(h);
+  if (rc) return rc;
+  // fold lane 1's records into lane 0's report
+  for (auto& r : h->lane[1].prof.recs) h->lane[0].prof.recs.push_back(r);
+  h->lane[1].prof.recs.clear();
+  *n = h->lane[0].prof.report(names, names_cap, ms, launches, cap);
   return UVO_OK;
 }
 
-hipStream_t uvo_extractor_stream_internal(uvo_extractor* h) { return h->stream; }
+hipStream_t uvo_extractor_stream_internal(uvo_extractor* h) { return h->lane[h->cur].stream; }
 int uvo_extractor_device_internal(uvo_extractor* h) { return h->device; }
 
 }  // extern "C"
