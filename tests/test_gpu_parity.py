@@ -247,3 +247,41 @@ def test_hbm_resident_pipeline_depth2(uvo, oracle, synth):
             np.testing.assert_array_equal(d0[b, :nq].cpu().numpy().astype(np.uint16).astype(np.int32), o[1])
     ex.close()
     mt.close()
+
+
+def test_config4_hd_1920x1080_2000_features(uvo, oracle, synth):
+    """BASELINE.json configs[3] geometry: 1920x1080 @ 2000 features (two quad-tree roots per level, 6594 FAST cells)."""
+    imgs = np.stack([synth.make_frame(7000 + i, 1920, 1080, n_shapes=2500) for i in range(2)])
+    ex = uvo.ORBextractor(2000, 1.2, 8, 0, 20, max_width=1920, max_height=1080, max_batch=2)
+    oe = oracle.extractor(2000, 1.2, 8, 20)
+    assert ex.mnFeaturesPerLevel.tolist() == [434, 362, 302, 251, 209, 175, 145, 122]
+    for i, (kp_g, de_g) in enumerate(ex.extract_batch(imgs)):
+        kp_o, de_o = oe(imgs[i])
+        _assert_same_features(kp_g, de_g, kp_o, de_o, "HD frame %d" % i)
+        assert len(kp_g) >= 2000
+    ex.close()
+
+
+def test_config1_harbor_parameters(uvo, oracle, synth):
+    """Data/Settings_VI_Aqualoc_harbor.yaml:67-79 as shipped: nFeatures 400, scaleFactor 1.2, nLevels 8, fastTh 20, Px_distance 20;
+    top-up call as src/Tracking.cc:946 makes it in WORKING state (FullDetect = false)."""
+    img = synth.make_frame(4711, 640, 512)
+    ex = uvo.ORBextractor(400, 1.2, 8, 0, 20, max_width=640, max_height=512, max_input_keypoints=800)
+    oe = oracle.extractor(400, 1.2, 8, 20)
+    assert ex.mnFeaturesPerLevel.tolist() == [87, 72, 60, 50, 42, 35, 29, 25]
+    rng = np.random.default_rng(1)
+    n_in = 330                                   # tracked points; 70 missing (> 5 % of 400, src/Tracking.cc:931-935)
+    kin = np.zeros(n_in, uvo.KEYPOINT_DTYPE)
+    kin["x"], kin["y"] = rng.uniform(20, 619, n_in).astype(np.float32), rng.uniform(20, 491, n_in).astype(np.float32)
+    kin["size"], kin["angle"], kin["octave"], kin["class_id"] = 31, -1, 0, -1
+    rows, cols = 512 // 20 + 2, 640 // 20 + 2
+    grid = np.zeros((rows, cols), np.int32, order="F")
+    for k in kin:
+        grid[int(k["y"] / 20), int(k["x"] / 20)] += 1
+    g1, g2 = grid.copy(order="F"), grid.copy(order="F")
+    kp_g, de_g = ex(img, kin.copy(), g1, 20, False, 400 - n_in)
+    kp_o, de_o = oe(img, kin.copy(), g2, 20, False, 400 - n_in)
+    _assert_same_features(kp_g, de_g, kp_o, de_o, "harbor top-up")
+    np.testing.assert_array_equal(g1, g2)
+    assert n_in < len(kp_g) <= 400
+    ex.close()
