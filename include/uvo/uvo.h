@@ -118,6 +118,16 @@ int uvo_extractor_synchronize(uvo_extractor* h);
  */
 int uvo_extractor_set_pipeline(uvo_extractor* h, int depth);
 
+/*
+ * Grid-bucketed FAST -- Grider_FAST::perform_griding(img, pts, num_features, grid_x, grid_y, threshold, nonmaxSuppression)
+ * (include/Grider_FAST.h:81-137; the OpenVINS helper north_star names; its only call, src/Tracking.cc:940, is commented
+ * out in the reference, so this is the alternative bucketing mode).  Host buffers; keypoints come out ROI-major, inside
+ * a ROI by response descending, then y, then x (the reference's std::sort leaves ties unspecified).  Uses the
+ * extractor handle's device scratch; the image must fit max_width x max_height.
+ */
+int uvo_grider_fast(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdiff_t stride, int num_features, int grid_x, int grid_y,
+                    int threshold, int nonmax_suppression, uvo_keypoint* out_kp, int cap, int* n_out);
+
 /* Stage taps for the parity tests (valid after a completed extract call; host destination buffers). */
 int uvo_extractor_level_dims(const uvo_extractor* h, int level, int* width, int* height);
 /* padded plane (width+32) x (height+32), tight rows; which: 0 = pyramid level, 1 = blurred level */

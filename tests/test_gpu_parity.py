@@ -285,3 +285,15 @@ def test_config1_harbor_parameters(uvo, oracle, synth):
     np.testing.assert_array_equal(g1, g2)
     assert n_in < len(kp_g) <= 400
     ex.close()
+
+
+@pytest.mark.parametrize("grid,nfeat,th,nms", [((8, 5), 200, 20, True), ((5, 3), 400, 10, True), ((4, 4), 100, 15, False), ((1, 1), 50, 25, True)])
+def test_grider_fast_bucketing(uvo, oracle, synth, grid, nfeat, th, nms):
+    """Grider_FAST::perform_griding (include/Grider_FAST.h:81-137) -- the alternative bucketing mode."""
+    img = synth.make_frame(99, 320, 256, n_shapes=120)
+    ex = uvo.ORBextractor(1000, 1.2, 4, 0, 20, max_width=320, max_height=256)   # output staging scales with nfeatures
+    got = ex.grider_fast(img, nfeat, grid[0], grid[1], th, nms)
+    ref = oracle.grider_fast(img, nfeat, grid[0], grid[1], th, nms)
+    assert len(got) == len(ref) > 0
+    assert got.tobytes() == ref.tobytes()
+    ex.close()

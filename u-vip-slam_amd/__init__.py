@@ -27,7 +27,7 @@ UVO_OK, UVO_E_BADARG, UVO_E_NODEVICE, UVO_E_HIP, UVO_E_CAPACITY, UVO_E_UNSUPPORT
 ABI_SYMBOLS = [
     "uvo_extractor_create", "uvo_extractor_destroy", "uvo_extractor_levels", "uvo_extractor_scale_factor", "uvo_extractor_tables",
     "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_level_dims",
-    "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
+    "uvo_grider_fast", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_search_by_projection", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
     "uvo_matcher_kernel_times", "uvo_last_error", "uvo_device_info",
@@ -71,6 +71,7 @@ def _load():
     lib.uvo_extractor_synchronize.argtypes = [vp]
     lib.uvo_extractor_set_pipeline.argtypes = [vp, ci]
     lib.uvo_extractor_level_dims.argtypes = [vp, ci, vp, vp]
+    lib.uvo_grider_fast.argtypes = [vp, vp, ci, ci, cl, ci, ci, ci, ci, ci, vp, ci, vp]
     lib.uvo_extractor_read_plane.argtypes = [vp, ci, ci, ci, vp]
     lib.uvo_extractor_read_candidates.argtypes = [vp, ci, ci, vp, ci, vp]
     lib.uvo_extractor_profile.argtypes = [vp, ci]
@@ -194,6 +195,19 @@ class ORBextractor:
                                           d_out_kp, d_out_desc, cap or self.cap, d_n_out)
         if rc:
             raise UvoError(rc, "uvo_extract_batch_device")
+
+    def grider_fast(self, image, num_features, grid_x, grid_y, threshold, nms=True):
+        """Grider_FAST::perform_griding (include/Grider_FAST.h:81-137)."""
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        h, w = image.shape
+        cap = num_features + grid_x * grid_y + 64
+        out = np.zeros(cap, KEYPOINT_DTYPE)
+        n = ctypes.c_int()
+        rc = lib.uvo_grider_fast(self._h, image.ctypes.data, w, h, image.strides[0], num_features, grid_x, grid_y, threshold,
+                                 1 if nms else 0, out.ctypes.data, cap, ctypes.byref(n))
+        if rc:
+            raise UvoError(rc, "uvo_grider_fast")
+        return out[:n.value].copy()
 
     def synchronize(self):
         rc = lib.uvo_extractor_synchronize(self._h)

@@ -98,6 +98,8 @@ void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t
 void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_score, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g,
                        int fast_th, uint32_t* d_cor, int32_t* d_cor_n, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc,
                        int64_t cand_block, int32_t* d_cand_count, int batch);
+void launch_grider(hipStream_t s, const uint8_t* d_img, int w, int h, int64_t stride, int num_features, int grid_x, int grid_y, int threshold,
+                   int nms, uint8_t* d_score, uint32_t* d_lists, int32_t* d_counts, uvo_keypoint* d_out, int cap, int32_t* d_n_out);
 int fast_rows_per_seg(int batch);
 int fast_items_per_frame(const Geom& g, int rows_per_seg);
 int64_t fast_region_entries(int rows_per_seg);

@@ -652,6 +652,44 @@ int uvo_extract(uvo_extractor* h, const uint8_t* img, int width, int height, ptr
   return rc;
 }
 
+int uvo_grider_fast(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdiff_t stride, int num_features, int grid_x, int grid_y,
+                    int threshold, int nonmax_suppression, uvo_keypoint* out_kp, int cap, int* n_out) {
+  if (!h || !img || !out_kp || !n_out) return fail(UVO_E_BADARG, "null pointer");
+  *n_out = 0;
+  if (width < 7 || height < 7 || width > 4096 || height > 4096 || stride < width || grid_x < 1 || grid_y < 1 || num_features < 0 || cap < 1)
+    return fail(UVO_E_BADARG, "bad image size / grid");
+  if ((int64_t)width * height > (int64_t)h->cfg.max_width * h->cfg.max_height) return fail(UVO_E_BADARG, "image larger than the handle was sized for");
+  const int size_x = width / grid_x, size_y = height / grid_y;
+  if (size_x < 1 || size_y < 1) return fail(UVO_E_BADARG, "grid finer than the image (the reference asserts size > 0)");
+  const int rois = (width / size_x) * (height / size_y);
+  const int keep = num_features / (grid_x * grid_y) + 1;
+  Lane& L = h->lane[0];
+  if ((size_t)width * height > h->cap_cor || (size_t)rois > h->cap_cor_n || (int64_t)width * height > (int64_t)h->cfg.max_batch * h->cap_pyr_block)
+    return fail(UVO_E_BADARG, "image / grid larger than the handle's scratch");
+  const int64_t dcap = (int64_t)h->cfg.max_batch * h->cap_flist;
+  if ((int64_t)rois * keep > dcap) return fail(UVO_E_CAPACITY, "num_features + cells exceeds the handle's output staging");
+  UVO_HIP_CHECK(hipSetDevice(h->device));
+  int rcs = sync_all_lanes(h);
+  if (rcs) return rcs;
+  hipStream_t s = L.stream;
+  UVO_HIP_CHECK(hipMemcpy2DAsync(h->d_imgs, width, img, stride, width, (size_t)height, hipMemcpyHostToDevice, s));
+  UVO_HIP_CHECK(hipMemsetAsync(h->d_n_out, 0, sizeof(int32_t), s));
+  launch_grider(s, h->d_imgs, width, height, width, num_features, grid_x, grid_y, threshold, nonmax_suppression ? 1 : 0, L.d_score, L.d_cor,
+                L.d_cor_n, h->d_out_kp, (int)std::min<int64_t>(dcap, 1 << 30), h->d_n_out);
+  UVO_HIP_CHECK(hipGetLastError());
+  int32_t n = 0;
+  UVO_HIP_CHECK(hipMemcpyAsync(&n, h->d_n_out, 4, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipStreamSynchronize(s));
+  *n_out = n;
+  int status = UVO_OK;
+  if (n > cap) {
+    status = fail(UVO_E_CAPACITY, "output capacity too small; n_out holds the required size");
+    n = cap;
+  }
+  if (n > 0) UVO_HIP_CHECK(hipMemcpy(out_kp, h->d_out_kp, sizeof(uvo_keypoint) * n, hipMemcpyDeviceToHost));
+  return status;
+}
+
 int uvo_extractor_level_dims(const uvo_extractor* h, int level, int* width, int* height) {
   if (!h || !h->have_geom || level < 0 || level >= h->geom.nlevels) return fail(UVO_E_BADARG, "no geometry / bad level");
   *width = h->geom.lv[level].w, *height = h->geom.lv[level].h;
