@@ -162,13 +162,14 @@ def main():
             self.d0 = torch.zeros((B, cap), dtype=torch.int16, device=dev)
             self.d1 = torch.zeros((B, cap), dtype=torch.int16, device=dev)
 
-    outs = [Out(), Out()]
-    ex.set_pipeline(2)
+    DEPTH = int(os.environ.get("UVO_PIPELINE_DEPTH", "2"))
+    outs = [Out() for _ in range(DEPTH)]
+    ex.set_pipeline(DEPTH)
     torch.cuda.synchronize()
     counter = [0]
 
     def step():
-        o = outs[counter[0] % 2]
+        o = outs[counter[0] % DEPTH]
         counter[0] += 1
         ex.extract_batch_device(d_imgs.data_ptr(), B, W, H, o.kp.data_ptr(), o.desc.data_ptr(), o.n.data_ptr(), cap)
         mt.wait_extractor(ex)
@@ -182,8 +183,8 @@ def main():
         torch.cuda.synchronize()
 
     # frame 0's descriptors into slot B of each buffer (halo for the wrap-around pair); they do not change between steps
-    step()
-    step()
+    for _ in range(DEPTH):
+        step()
     sync_all()
     for o in outs:
         o.desc[B].copy_(o.desc[0])
@@ -205,7 +206,7 @@ def main():
     sync_all()
     serial = dict(ex.kernel_times())
     serial.update(mt.kernel_times())
-    ex.set_pipeline(2)
+    ex.set_pipeline(DEPTH)
     ex.profile(False)
     mt.profile(False)
 
@@ -242,7 +243,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: 1xMI355X per rank, batch=%d synthetic %dx%d mono frames, %d feats, %d levels, "
                                    "fastTh %d, FullDetect extract + all-pairs 256-bit Hamming knn-2 of consecutive frames, HBM-resident I/O"
                                    % (B, W, H, NFEAT, NLEVELS, FAST_TH),
-                       "batch_per_gpu": B, "sharding": "frames, no collective", "pipeline_depth": 2, "mean_keypoints_per_frame": round(k_mean, 1),
+                       "batch_per_gpu": B, "sharding": "frames, no collective", "pipeline_depth": DEPTH, "mean_keypoints_per_frame": round(k_mean, 1),
                        "knn2_second_neighbours_found": matches},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,

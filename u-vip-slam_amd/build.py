@@ -38,7 +38,7 @@ def build(force=False, verbose=True):
 
     def cc(src):
         obj = os.path.join(OBJ, src + ".o")
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC] + FLAGS + os.environ.get("UVO_EXTRA_FLAGS", "").split() + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr[-6000:]))

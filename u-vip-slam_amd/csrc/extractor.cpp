@@ -42,6 +42,8 @@ using namespace uvo;
 // Per-batch scratch + stream.  With pipeline depth 2 consecutive uvo_extract_batch_device calls alternate between two
 // lanes, so the latency-bound stages of one batch (quad-tree, sparse NMS, small pyramid levels) overlap with the
 // throughput stages of the next.
+constexpr int kMaxLanes = 4;
+
 struct Lane {
   hipStream_t stream = nullptr;
   uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_score = nullptr;
@@ -56,7 +58,7 @@ struct Lane {
 struct uvo_extractor {
   uvo_extractor_cfg cfg;
   int device = 0;
-  Lane lane[2];
+  Lane lane[kMaxLanes];
   int nlanes = 1, cur = 0;
   // constructor tables (src/ORBextractor.cc:463-511)
   std::vector<float> scale, inv_scale;
@@ -386,7 +388,7 @@ static int alloc_lane(uvo_extractor* h, int li) {
   return UVO_OK;
 }
 static int sync_all_lanes(uvo_extractor* h) {
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < kMaxLanes; ++i)
     if (h->lane[i].stream) UVO_HIP_CHECK(hipStreamSynchronize(h->lane[i].stream));
   return UVO_OK;
 }
@@ -500,7 +502,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
 void uvo_extractor_destroy(uvo_extractor* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < kMaxLanes; ++i) {
     Lane& L = h->lane[i];
     if (L.stream) (void)hipStreamSynchronize(L.stream);
     L.prof.clear();
@@ -548,12 +550,12 @@ int uvo_extractor_synchronize(uvo_extractor* h) {
 }
 
 int uvo_extractor_set_pipeline(uvo_extractor* h, int depth) {
-  if (!h || depth < 1 || depth > 2) return fail(UVO_E_BADARG, "pipeline depth must be 1 or 2");
+  if (!h || depth < 1 || depth > kMaxLanes) return fail(UVO_E_BADARG, "pipeline depth must be 1..4");
   UVO_HIP_CHECK(hipSetDevice(h->device));
   int rc = sync_all_lanes(h);
   if (rc) return rc;
-  if (depth == 2) {
-    rc = alloc_lane(h, 1);
+  for (int i = 1; i < depth; ++i) {
+    rc = alloc_lane(h, i);
     if (rc) return rc;
   }
   h->nlanes = depth;
@@ -737,7 +739,7 @@ int uvo_extractor_profile(uvo_extractor* h, int enable) {
   UVO_HIP_CHECK(hipSetDevice(h->device));
   int rc = sync_all_lanes(h);
   if (rc) return rc;
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < kMaxLanes; ++i) {
     h->lane[i].prof.on = enable != 0;
     h->lane[i].prof.clear();
   }
@@ -750,8 +752,10 @@ int uvo_extractor_kernel_times(uvo_extractor* h, char* names, int names_cap, flo
   int rc = sync_all_lanes(h);
   if (rc) return rc;
   // fold lane 1's records into lane 0's report
-  for (auto& r : h->lane[1].prof.recs) h->lane[0].prof.recs.push_back(r);
-  h->lane[1].prof.recs.clear();
+  for (int i = 1; i < kMaxLanes; ++i) {
+    for (auto& r : h->lane[i].prof.recs) h->lane[0].prof.recs.push_back(r);
+    h->lane[i].prof.recs.clear();
+  }
   *n = h->lane[0].prof.report(names, names_cap, ms, launches, cap);
   return UVO_OK;
 }

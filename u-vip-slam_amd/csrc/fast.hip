@@ -29,25 +29,19 @@ namespace uvo {
 constexpr int FS_COLS = 248;  // useful columns per wavefront strip (lanes 1..62)
 constexpr int FQ_CAP = 320;   // queue entries per wavefront: < 64 left over + <= 256 pushed per row
 
-__device__ __forceinline__ int max16(const int* a) {
-  int m = a[0];
-#pragma unroll
-  for (int k = 1; k < 16; ++k) m = max(m, a[k]);
-  return m;
-}
-
-// max over the 16 arcs of 9 contiguous ring pixels of min(d) -- sliding minimum by doubling
+// max over the 16 arcs of 9 contiguous ring pixels of min(d): a 9-window minimum is the min3 of three 3-window minima
+// (v_min3_i32), the 16 results are folded with v_max3_i32 -- 40 instructions per polarity, branch free.
 __device__ __forceinline__ int arc9_maxmin(const int* d) {
-  int a1[16], a2[16], a4[16], a9[16];
+  int m3[16], m9[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) a1[k] = min(d[k], d[(k + 1) & 15]);
+  for (int k = 0; k < 16; ++k) m3[k] = min(d[k], min(d[(k + 1) & 15], d[(k + 2) & 15]));
 #pragma unroll
-  for (int k = 0; k < 16; ++k) a2[k] = min(a1[k], a1[(k + 2) & 15]);
+  for (int k = 0; k < 16; ++k) m9[k] = min(m3[k], min(m3[(k + 3) & 15], m3[(k + 6) & 15]));
+  int r[6];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) a4[k] = min(a2[k], a2[(k + 4) & 15]);
-#pragma unroll
-  for (int k = 0; k < 16; ++k) a9[k] = min(a4[k], d[(k + 8) & 15]);
-  return max16(a9);
+  for (int k = 0; k < 5; ++k) r[k] = max(m9[3 * k], max(m9[3 * k + 1], m9[3 * k + 2]));
+  r[5] = m9[15];
+  return max(max(r[0], max(r[1], r[2])), max(r[3], max(r[4], r[5])));
 }
 
 // byte I (0..11, compile time) of the 12-byte window [L C R]
@@ -57,7 +51,8 @@ __device__ __forceinline__ uint32_t win(uint32_t L, uint32_t C, uint32_t R) {
   return ((I < 4 ? L : (I < 8 ? C : R)) >> (8 * (I & 3))) & 0xffu;
 }
 
-constexpr int FR_ROWS = 16;         // LDS row ring depth per wavefront (rows of 64 dwords)
+constexpr int FR_ROWS = 16;         // LDS row ring depth per wavefront
+constexpr int FR_PITCH = 66;        // row pitch in dwords: 64 + 2 so that the same column of consecutive rows hits different banks
 constexpr int FR_MAXAGE = FR_ROWS - 8;  // a queued pixel needs rows -3..+3 around it: drain before they are overwritten
 
 // Full segment test + cornerScore of the queued pixels [first, first+count), one per lane.  The 16 ring pixels are read
@@ -71,43 +66,27 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
     const uint32_t meta = q[first + lane];  // xl | row << 8
     const int xl = (int)(meta & 0xff), row = (int)(meta >> 8);
     // row ring slot of row r is r & 15; base pointers 3 bytes left of the pixel so that every offset is >= 0
-    const uint8_t* r0 = rows + ((row & (FR_ROWS - 1)) << 8) + xl - 3;
-    const uint8_t* rp1 = rows + (((row + 1) & (FR_ROWS - 1)) << 8) + xl - 3;
-    const uint8_t* rp2 = rows + (((row + 2) & (FR_ROWS - 1)) << 8) + xl - 3;
-    const uint8_t* rp3 = rows + (((row + 3) & (FR_ROWS - 1)) << 8) + xl - 3;
-    const uint8_t* rm1 = rows + (((row - 1) & (FR_ROWS - 1)) << 8) + xl - 3;
-    const uint8_t* rm2 = rows + (((row - 2) & (FR_ROWS - 1)) << 8) + xl - 3;
-    const uint8_t* rm3 = rows + (((row - 3) & (FR_ROWS - 1)) << 8) + xl - 3;
+    const uint8_t* r0 = rows + (row & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
+    const uint8_t* rp1 = rows + ((row + 1) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
+    const uint8_t* rp2 = rows + ((row + 2) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
+    const uint8_t* rp3 = rows + ((row + 3) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
+    const uint8_t* rm1 = rows + ((row - 1) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
+    const uint8_t* rm2 = rows + ((row - 2) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
+    const uint8_t* rm3 = rows + ((row - 3) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
     const int v = r0[3];
-    int d[16];
+    int d[16], nd[16];
     d[0] = rp3[3], d[1] = rp3[4], d[2] = rp2[5], d[3] = rp1[6], d[4] = r0[6], d[5] = rm1[6], d[6] = rm2[5], d[7] = rm3[4];
     d[8] = rm3[3], d[9] = rm3[2], d[10] = rm2[1], d[11] = rm1[0], d[12] = r0[0], d[13] = rp1[0], d[14] = rp2[1], d[15] = rp3[2];
-    uint32_t mb = 0, md = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       d[k] -= v;
-      mb |= (uint32_t)(d[k] > t_min) << k;
-      md |= (uint32_t)(d[k] < -t_min) << k;
+      nd[k] = -d[k];
     }
-    auto run9 = [](uint32_t m) {  // 9 contiguous set bits in the circular 16-bit mask
-      m |= m << 16;
-      uint32_t x = m & (m >> 1);
-      x &= x >> 2;
-      x &= x >> 4;
-      x &= m >> 8;
-      return (x & 0xffffu) != 0;
-    };
-    const bool cb = run9(mb), cdk = run9(md);
-    if (cb || cdk) {
-      int sb = 0, sd = 0;
-      if (cb) sb = arc9_maxmin(d);
-      if (cdk) {
-        int nd[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) nd[k] = -d[k];
-        sd = arc9_maxmin(nd);
-      }
-      const int sc = max(sb, sd) - 1;
+    // corner at t  <=>  some 9-arc has all diffs > t (brighter) or all < -t (darker)  <=>  max(sb, sd) > t;
+    // cornerScore = max(sb, sd) - 1.  No masks, no divergent branches.
+    const int best = max(arc9_maxmin(d), arc9_maxmin(nd));
+    if (best > t_min) {
+      const int sc = best - 1;
       splane[(int64_t)row * pitch + X0 + xl] = (uint8_t)sc;
       corner = sc > 0;  // a score of 0 (only possible at t_min = 0) can never survive NMS
       packed = (uint32_t)xl | ((uint32_t)(row - py0) << 8) | ((uint32_t)sc << 16);
@@ -124,7 +103,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
                                                     const LevelGeom* __restrict__ lv, int nlevels, int t_min, int rows_per_seg,
                                                     uint32_t* __restrict__ cor, int32_t* __restrict__ cor_n, int items_per_frame) {
   __shared__ uint32_t s_q[4][FQ_CAP];
-  __shared__ uint32_t s_rows[4][FR_ROWS * 64];
+  __shared__ uint32_t s_rows[4][FR_ROWS * FR_PITCH];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint32_t* q = s_q[wv];
   uint32_t* rows32 = s_rows[wv];
@@ -167,16 +146,16 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
         const int prow = py0 - 3 + j;
         const uint32_t C = *reinterpret_cast<const uint32_t*>(src + (int64_t)prow * g.pitch + Xc);
         Cr[u] = C;
-        rows32[((prow & (FR_ROWS - 1)) << 6) + lane] = C;
+        rows32[(prow & (FR_ROWS - 1)) * FR_PITCH + lane] = C;
         if (j >= 6) {
           const int pc = prow - 3;  // centre row; rows pc-3 .. pc+3 sit in register slots (u+1)%7 .. u
           const int sm3 = (u + 1) % 7, sm2 = (u + 2) % 7, s0 = (u + 4) % 7, sp2 = (u + 6) % 7, sp3 = u;
           if (lane_ok) *reinterpret_cast<uint32_t*>(sp + (int64_t)pc * g.pitch + X) = 0u;
           const uint32_t Cc = Cr[s0], Cu = Cr[sm3], Cd = Cr[sp3], C2 = Cr[sp2], Cm2 = Cr[sm2];
           // neighbour dwords of rows pc, pc+2, pc-2 from the LDS row ring (written by this wavefront, in order)
-          const uint32_t* rc = rows32 + ((pc & (FR_ROWS - 1)) << 6);
-          const uint32_t* r2 = rows32 + (((pc + 2) & (FR_ROWS - 1)) << 6);
-          const uint32_t* rm = rows32 + (((pc - 2) & (FR_ROWS - 1)) << 6);
+          const uint32_t* rc = rows32 + (pc & (FR_ROWS - 1)) * FR_PITCH;
+          const uint32_t* r2 = rows32 + ((pc + 2) & (FR_ROWS - 1)) * FR_PITCH;
+          const uint32_t* rm = rows32 + ((pc - 2) & (FR_ROWS - 1)) * FR_PITCH;
           const uint32_t Lc = rc[lm], Rc = rc[lp], L2 = r2[lm], R2 = r2[lp], Lm2 = rm[lm], Rm2 = rm[lp];
           // ---- screen the lane's 4 pixels with four opposite ring pairs, queue the ones that pass ----
 #define UVO_FAST_PIXEL(K)                                                                                                          \
@@ -207,7 +186,9 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
           // ---- drain full batches (newest first); a stale remainder is flushed before its rows leave the ring ----
           while (qn >= 64) {
             qn -= 64;
+#ifndef UVO_EXP_NOCHUNK
             fast_score_chunk(q, rows8, qn, 64, lane, t_min, sp, g.pitch, X0, py0, region, ncorner);
+#endif
           }
           if (qn > 0 && pc - qoldest >= FR_MAXAGE) {
             fast_score_chunk(q, rows8, 0, qn, lane, t_min, sp, g.pitch, X0, py0, region, ncorner);
@@ -265,13 +246,16 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ sc
   const uint8_t* sp = score + f * pyr_block + g.plane_off;
   uint8_t* hi = cell_hi + (int64_t)f * L.flags_per_frame + g.flag_base;
   int nkeep = 0;
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    bool keep = false;
-    uint32_t out = 0;
-    if (i < n) {
-      const uint32_t e = region[i];
-      const int px = X0 + (int)(e & 0xff), py = py0 + (int)((e >> 8) & 0xff), s = (int)(e >> 16);
+  constexpr int U = 4;  // corners per lane per iteration: 4 independent load chains hide the two memory round trips
+  for (int base = 0; base < n; base += 64 * U) {
+    uint32_t e[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) e[u] = base + u * 64 + lane < n ? region[base + u * 64 + lane] : 0u;
+    int nb[U][8], ss[U], xr_[U], yr_[U], cell_[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int px = X0 + (int)(e[u] & 0xff), py = py0 + (int)((e[u] >> 8) & 0xff);
+      ss[u] = (int)(e[u] >> 16);
       // coordinates relative to (minBorder, minBorder), as the candidate list wants them
       const int xr = px - kPad - kMinBorder, yr = py - kPad - kMinBorder;
       int cj = (xr - 3) / g.wCell, ci = (yr - 3) / g.hCell;
@@ -281,26 +265,31 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ sc
       const int cx0 = cj * g.wCell + 3, cx1 = min(cj * g.wCell + g.wCell + 6, g.bw) - 3;
       const int cy0 = ci * g.hCell + 3, cy1 = min(ci * g.hCell + g.hCell + 6, g.bh) - 3;
       const uint8_t* c = sp + (int64_t)py * g.pitch + px;
-      keep = true;
+      xr_[u] = xr, yr_[u] = yr, cell_[u] = ci * g.nCols + cj;
+      int q = 0;
 #pragma unroll
       for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
           if (dx == 0 && dy == 0) continue;
-          const bool inside = xr + dx >= cx0 && xr + dx < cx1 && yr + dy >= cy0 && yr + dy < cy1;
-          const int nb = inside ? (int)c[(int64_t)dy * g.pitch + dx] : 0;
-          keep = keep && s > nb;
+          const bool inside = ss[u] > 0 && xr + dx >= cx0 && xr + dx < cx1 && yr + dy >= cy0 && yr + dy < cy1;
+          nb[u][q++] = inside ? (int)c[(int64_t)dy * g.pitch + dx] : 0;
         }
-      if (keep) {
-        out = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)s << 24);
-        if (s >= fast_th) hi[ci * g.nCols + cj] = 1;  // idempotent plain store: every writer stores the same value
-      }
     }
-    // in-place compaction: survivors of this batch land at or before the batch's own start
-    const uint64_t m = __ballot(keep);
-    if (m) {
-      if (keep) region[nkeep + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = out;
-      nkeep += (int)__popcll(m);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bool keep = ss[u] > 0;  // padding entries (beyond n) carry score 0
+#pragma unroll
+      for (int q = 0; q < 8; ++q) keep = keep && ss[u] > nb[u][q];
+      if (keep && ss[u] >= fast_th) hi[cell_[u]] = 1;  // idempotent plain store: every writer stores the same value
+      // in-place compaction: survivors land at or before the start of the batch that was just read
+      const uint64_t m = __ballot(keep);
+      if (m) {
+        if (keep)
+          region[nkeep + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+              (uint32_t)xr_[u] | ((uint32_t)yr_[u] << 12) | ((uint32_t)ss[u] << 24);
+        nkeep += (int)__popcll(m);
+      }
     }
   }
   if (lane == 0) cor_n[region_id] = nkeep;

@@ -19,17 +19,25 @@ namespace uvo {
 
 constexpr int GS_COLS = 248;  // useful columns per wavefront strip
 
-__device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t R, const int4& t, int* h) {
-  // 12-byte window [L0..L3 C0..C3 R0..R3]; pixel k sits at window index 4+k and needs indices k+1 .. k+7
-  int b[12];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    b[i] = (L >> (8 * i)) & 0xff;
-    b[4 + i] = (C >> (8 * i)) & 0xff;
-    b[8 + i] = (R >> (8 * i)) & 0xff;
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) h[k] = t.x * (b[k + 1] + b[k + 7]) + t.y * (b[k + 2] + b[k + 6]) + t.z * (b[k + 3] + b[k + 5]) + t.w * b[k + 4];
+// Row pass for the lane's 4 pixels with the packed-byte dot product (v_dot4_u32_u8): pixel k needs window bytes
+// k+1 .. k+7 of [L C R]; they are fetched as two byte-aligned dwords (v_alignbyte) and multiplied with the taps packed as
+// (t0,t1,t2,t3) and (t2,t1,t0,0).  Exact integer arithmetic, 4 instructions per pixel.
+template <int S>
+__device__ __forceinline__ uint32_t win4(uint32_t L, uint32_t C, uint32_t R) {  // bytes S..S+3 of the 12-byte window
+  if (S < 4) return S == 0 ? L : __builtin_amdgcn_alignbyte(C, L, (uint32_t)S);
+  if (S < 8) return S == 4 ? C : __builtin_amdgcn_alignbyte(R, C, (uint32_t)(S - 4));
+  return R;
+}
+template <int K>
+__device__ __forceinline__ int gauss_row1(uint32_t L, uint32_t C, uint32_t R, uint32_t T1, uint32_t T2) {
+  const uint32_t a = win4<K + 1>(L, C, R), b = win4<K + 5>(L, C, R);
+  return (int)__builtin_amdgcn_udot4(b, T2, __builtin_amdgcn_udot4(a, T1, 0u, false), false);
+}
+__device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t R, uint32_t T1, uint32_t T2, int* h) {
+  h[0] = gauss_row1<0>(L, C, R, T1, T2);
+  h[1] = gauss_row1<1>(L, C, R, T1, T2);
+  h[2] = gauss_row1<2>(L, C, R, T1, T2);
+  h[3] = gauss_row1<3>(L, C, R, T1, T2);
 }
 
 __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int64_t pyr_block,
@@ -60,19 +68,31 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
   const int py1 = min(py0 + rows_per_seg, g.h + 20);
   const int nsrc = py1 - py0 + 6;  // source rows py0-3 .. py1+2
 
+  const uint32_t T1 = (uint32_t)taps.x | ((uint32_t)taps.y << 8) | ((uint32_t)taps.z << 16) | ((uint32_t)taps.w << 24);
+  const uint32_t T2 = (uint32_t)taps.z | ((uint32_t)taps.y << 8) | ((uint32_t)taps.x << 16);
   int hring[7][4];
   uint32_t cring[7];
+  // Row loads are issued one unrolled block (7 rows) ahead of their use: a wavefront walks ~70 rows one after another, so
+  // without the prefetch every row would expose a full memory round trip.
+  auto load_row = [&](int j) -> uint32_t {
+    int prow = py0 - 3 + j;
+    prow = prow > g.ph - 1 ? g.ph - 1 : prow;  // rows past the plane are never used by a valid output
+    return *reinterpret_cast<const uint32_t*>(src + (int64_t)prow * g.pitch + Xc);
+  };
+  uint32_t cur[7], nxt[7];
+#pragma unroll
+  for (int u = 0; u < 7; ++u) cur[u] = u < nsrc ? load_row(u) : 0u;
   for (int base = 0; base < nsrc; base += 7) {
+#pragma unroll
+    for (int u = 0; u < 7; ++u) nxt[u] = base + 7 + u < nsrc ? load_row(base + 7 + u) : 0u;
 #pragma unroll
     for (int u = 0; u < 7; ++u) {
       const int j = base + u;
       if (j < nsrc) {
-        int prow = py0 - 3 + j;
-        prow = prow > g.ph - 1 ? g.ph - 1 : prow;  // rows past the plane are never used by a valid output
-        const uint32_t C = *reinterpret_cast<const uint32_t*>(src + (int64_t)prow * g.pitch + Xc);
+        const uint32_t C = cur[u];
         const uint32_t L = (uint32_t)__shfl_up((int)C, 1, 64);
         const uint32_t R = (uint32_t)__shfl_down((int)C, 1, 64);
-        gauss_row_pass(L, C, R, taps, hring[u]);
+        gauss_row_pass(L, C, R, T1, T2, hring[u]);
         cring[u] = C;
         if (j >= 6) {
           const int py = py0 + j - 6;  // output row; its 7 source rows sit in ring slots (u+1)%7 .. (u+7)%7
@@ -88,7 +108,7 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
           uint32_t out = 0;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int s = taps.x * (r0[k] + r6[k]) + taps.y * (r1[k] + r5[k]) + taps.z * (r2[k] + r4[k]) + taps.w * r3[k];
+            const int s = __mul24(taps.x, r0[k] + r6[k]) + __mul24(taps.y, r1[k] + r5[k]) + __mul24(taps.z, r2[k] + r4[k]) + __mul24(taps.w, r3[k]);
             int v = (s + (1 << 15)) >> 16;
             v = v > 255 ? 255 : v;
             const int px = X + k;
@@ -100,6 +120,8 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
         }
       }
     }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) cur[u] = nxt[u];
   }
 }
 

@@ -85,18 +85,18 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t* __restrict__ pyr,
     for (int i = 0; i < 4; ++i) {
       const int o = sx[i] - base;
       const uint32_t t0 = pick2(u0, u1, u2, o), t1 = pick2(w0, w1, w2, o);
-      const int r0 = (int)(t0 & 0xff) * a0[i] + (int)((t0 >> 8) & 0xff) * a1[i];
-      const int r1 = (int)(t1 & 0xff) * a0[i] + (int)((t1 >> 8) & 0xff) * a1[i];
-      const int o8 = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+      const int r0 = __mul24((int)(t0 & 0xff), a0[i]) + __mul24((int)((t0 >> 8) & 0xff), a1[i]);
+      const int r1 = __mul24((int)(t1 & 0xff), a0[i]) + __mul24((int)((t1 >> 8) & 0xff), a1[i]);
+      const int o8 = ((__mul24(b0, r0 >> 4) >> 16) + (__mul24(b1, r1 >> 4) >> 16) + 2) >> 2;  // all operands < 2^24
       v |= (uint32_t)(o8 & 0xff) << (8 * i);
     }
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int sx1 = sx[i] + 1 < sw ? sx[i] + 1 : sw - 1;
-      const int r0 = S0[sx[i]] * a0[i] + S0[sx1] * a1[i];
-      const int r1 = S1[sx[i]] * a0[i] + S1[sx1] * a1[i];
-      const int o8 = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+      const int r0 = __mul24((int)S0[sx[i]], a0[i]) + __mul24((int)S0[sx1], a1[i]);
+      const int r1 = __mul24((int)S1[sx[i]], a0[i]) + __mul24((int)S1[sx1], a1[i]);
+      const int o8 = ((__mul24(b0, r0 >> 4) >> 16) + (__mul24(b1, r1 >> 4) >> 16) + 2) >> 2;
       v |= (uint32_t)(o8 & 0xff) << (8 * i);
     }
   }
