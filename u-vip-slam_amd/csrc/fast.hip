@@ -75,8 +75,13 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
     const uint8_t* rm3 = rows + ((row - 3) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
     const int v = r0[3];
     int d[16], nd[16];
+#ifdef UVO_EXP_NOGATHER
+    for (int k = 0; k < 16; ++k) d[k] = (int)((meta >> k) & 0xff) + (k * 37 & 63);
+    (void)rp1, (void)rp2, (void)rp3, (void)rm1, (void)rm2, (void)rm3;
+#else
     d[0] = rp3[3], d[1] = rp3[4], d[2] = rp2[5], d[3] = rp1[6], d[4] = r0[6], d[5] = rm1[6], d[6] = rm2[5], d[7] = rm3[4];
     d[8] = rm3[3], d[9] = rm3[2], d[10] = rm2[1], d[11] = rm1[0], d[12] = r0[0], d[13] = rp1[0], d[14] = rp2[1], d[15] = rp3[2];
+#endif
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       d[k] -= v;
@@ -84,7 +89,14 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
     }
     // corner at t  <=>  some 9-arc has all diffs > t (brighter) or all < -t (darker)  <=>  max(sb, sd) > t;
     // cornerScore = max(sb, sd) - 1.  No masks, no divergent branches.
+#ifdef UVO_EXP_NOARC
+    int best = d[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) best ^= d[k];
+    best &= 31;
+#else
     const int best = max(arc9_maxmin(d), arc9_maxmin(nd));
+#endif
     if (best > t_min) {
       const int sc = best - 1;
       splane[(int64_t)row * pitch + X0 + xl] = (uint8_t)sc;
@@ -266,14 +278,19 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ sc
       const int cy0 = ci * g.hCell + 3, cy1 = min(ci * g.hCell + g.hCell + 6, g.bh) - 3;
       const uint8_t* c = sp + (int64_t)py * g.pitch + px;
       xr_[u] = xr, yr_[u] = yr, cell_[u] = ci * g.nCols + cj;
+      // three unaligned dword loads fetch the 3x3 neighbourhood (bytes x-1 .. x+2 of rows y-1, y, y+1)
+      typedef uint32_t u32_any __attribute__((aligned(1)));
+      uint32_t rw[3];
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) rw[dy + 1] = ss[u] > 0 ? *reinterpret_cast<const u32_any*>(c + (int64_t)dy * g.pitch - 1) : 0u;
       int q = 0;
 #pragma unroll
       for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
           if (dx == 0 && dy == 0) continue;
-          const bool inside = ss[u] > 0 && xr + dx >= cx0 && xr + dx < cx1 && yr + dy >= cy0 && yr + dy < cy1;
-          nb[u][q++] = inside ? (int)c[(int64_t)dy * g.pitch + dx] : 0;
+          const bool inside = xr + dx >= cx0 && xr + dx < cx1 && yr + dy >= cy0 && yr + dy < cy1;
+          nb[u][q++] = inside ? (int)((rw[dy + 1] >> (8 * (dx + 1))) & 0xff) : 0;
         }
     }
 #pragma unroll
