@@ -48,7 +48,9 @@ def algorithmic_bytes_per_frame(w, h, k):
     return {
         "k_pad_level0": 2 * s[0],                       # not in the survey's model (a design that reads the input in place needs none)
         "k_resize_level": sum(s[:-1]) + sum(s[1:]),     # reads S0..S6, writes S1..S7 (all 7 launches)
-        "k_fast_cells": tot,                            # k_fast_score + k_fast_nms + k_fast_emit, timed together
+        "k_fast_score": tot,                            # reads every level once (the score plane it writes is scratch)
+        "k_fast_nms": 0,
+        "k_fast_emit": 0,
         "k_gauss7": 2 * tot,
         "k_octree": 0,
         "k_assemble": 0,
@@ -251,8 +253,8 @@ def main():
                          "whole_path_GBps": round(total_alg * value / world / 1e9, 2),
                          "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(ktimes.items())},
                          "kernel_ms_per_step_unoverlapped": {k: round(v[0] / 3, 4) for k, v in sorted(serial.items())},
-                         "note": "k_fast_cells (FAST segment test) is integer-VALU bound, not HBM bound: ~80 lane-ops per pixel; "
-                                 "the HBM fraction is reported because the contract asks for it"},
+                         "note": "k_fast_score (FAST segment test) is integer-VALU bound, not HBM bound (~60 lane-ops per pixel, see "
+                                 "DESIGN.md section 7); the HBM fraction is reported because the contract asks for it"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames)

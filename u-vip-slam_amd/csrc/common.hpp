@@ -95,7 +95,7 @@ void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const
                          const ResizeRow* d_rtab, int fast_ok, int batch);
 void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g, int4 taps,
                    int batch);
-void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_score, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g,
+void launch_fast_stage(hipStream_t s, int stage, const uint8_t* d_pyr, uint8_t* d_score, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g,
                        int fast_th, uint32_t* d_cor, int32_t* d_cor_n, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc,
                        int64_t cand_block, int32_t* d_cand_count, int batch);
 void launch_grider(hipStream_t s, const uint8_t* d_img, int w, int h, int64_t stride, int num_features, int grid_x, int grid_y, int threshold,

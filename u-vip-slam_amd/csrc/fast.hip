@@ -369,10 +369,7 @@ int fast_flags_per_frame(const Geom& g) {
   return n;
 }
 
-void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_score, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g,
-                       int fast_th, uint32_t* d_cor, int32_t* d_cor_n, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc,
-                       int64_t cand_block, int32_t* d_cand_count, int batch) {
-  const int t_min = fast_th < 7 ? fast_th : 7;
+static FastLevels fast_levels(const Geom& g, int batch) {
   FastLevels L;
   L.nlevels = g.nlevels;
   L.rows_per_seg = fast_rows_per_seg(batch);
@@ -393,12 +390,25 @@ void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_score, in
     }
     F.pad = 0;
   }
+  return L;
+}
+
+// stage 0: score plane + corner regions, 1: sparse NMS, 2: vote + emit (timed separately by the caller)
+void launch_fast_stage(hipStream_t s, int stage, const uint8_t* d_pyr, uint8_t* d_score, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g,
+                       int fast_th, uint32_t* d_cor, int32_t* d_cor_n, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc,
+                       int64_t cand_block, int32_t* d_cand_count, int batch) {
+  const int t_min = fast_th < 7 ? fast_th : 7;
+  const FastLevels L = fast_levels(g, batch);
   const dim3 grid((L.items_per_frame + 3) / 4, batch);
-  (void)hipMemsetAsync(d_cell_hi, 0, (size_t)batch * L.flags_per_frame, s);
-  hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, s, d_pyr, d_score, pyr_block, d_lv, g.nlevels, t_min, L.rows_per_seg, d_cor, d_cor_n,
-                     L.items_per_frame);
-  hipLaunchKernelGGL(k_fast_nms, grid, dim3(256), 0, s, d_score, pyr_block, L, fast_th, d_cor, d_cor_n, d_cell_hi);
-  hipLaunchKernelGGL(k_fast_emit, grid, dim3(256), 0, s, L, fast_th, d_cor, d_cor_n, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count);
+  if (stage == 0) {
+    (void)hipMemsetAsync(d_cell_hi, 0, (size_t)batch * L.flags_per_frame, s);
+    hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, s, d_pyr, d_score, pyr_block, d_lv, g.nlevels, t_min, L.rows_per_seg, d_cor, d_cor_n,
+                       L.items_per_frame);
+  } else if (stage == 1) {
+    hipLaunchKernelGGL(k_fast_nms, grid, dim3(256), 0, s, d_score, pyr_block, L, fast_th, d_cor, d_cor_n, d_cell_hi);
+  } else {
+    hipLaunchKernelGGL(k_fast_emit, grid, dim3(256), 0, s, L, fast_th, d_cor, d_cor_n, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count);
+  }
 }
 
 }  // namespace uvo
