@@ -297,3 +297,20 @@ def test_grider_fast_bucketing(uvo, oracle, synth, grid, nfeat, th, nms):
     assert len(got) == len(ref) > 0
     assert got.tobytes() == ref.tobytes()
     ex.close()
+
+
+@pytest.mark.parametrize("fast_th", [3, 5, 40, 0])
+def test_threshold_extremes(uvo, oracle, synth, fast_th):
+    """fastTh below the literal-7 fallback (t_min = fastTh, the fallback can then only shrink the set), far above it
+    (most cells fall back to 7) and 0 (score-0 corners exist and must never survive NMS)."""
+    img = synth.make_frame(424242, 320, 256, n_shapes=100)
+    ex = uvo.ORBextractor(500, 1.2, 4, 0, fast_th, max_width=320, max_height=256)
+    oe = oracle.extractor(500, 1.2, 4, fast_th)
+    kp_g, de_g = ex(img)
+    kp_o, de_o = oe(img)
+    for l in range(4):
+        c_g = sorted(map(tuple, ex.read_candidates(l).tolist()))
+        c_o = oe.level_candidates(l)
+        assert c_g == sorted(zip(c_o["x"].astype(int).tolist(), c_o["y"].astype(int).tolist(), c_o["response"].astype(int).tolist()))
+    _assert_same_features(kp_g, de_g, kp_o, de_o, "fastTh %d" % fast_th)
+    ex.close()

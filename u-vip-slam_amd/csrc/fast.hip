@@ -6,14 +6,15 @@
 // 3-px-inset interior or that are not corners count as 0.)
 //
 // The cells' interiors tile the detection window [16, w-16) x [16, h-16) exactly once and the corner score does not
-// depend on the threshold, so the work is split in two:
+// depend on the threshold, so the work is split in three:
 //   k_fast_score  : a streaming pass over each level that writes the score plane (0 = not a corner at
 //                   t_min = min(fastTh, 7)).  One wavefront owns a strip of 64 lanes x 4 pixels and walks down the
-//                   rows with the last 7 rows (own dword + both neighbours' dwords) in a register ring -- one aligned
-//                   dword load per lane per row, no LDS tile, no barriers.  Every pixel is screened with the two
-//                   cheapest necessary conditions (any 9-arc contains ring pixel 0 or 8, and 4 or 12, of one
-//                   polarity); the few percent that pass are compacted, with their 16 ring pixels, into a wavefront-
-//                   private LDS queue and the full segment test + cornerScore runs on full 64-lane batches of it.
+//                   rows with the last 7 row dwords in a register ring (one aligned dword load per lane per row, also
+//                   kept in a 16-row wavefront-private LDS ring) -- no workgroup barriers.  Every pixel is screened
+//                   with four opposite ring pairs (any 9-arc contains one pixel of every opposite pair, of one
+//                   polarity): min/max only.  The ~11 % that pass are compacted into a wavefront-private LDS queue and
+//                   the exact test runs on full 64-lane batches of it: max over the 16 arcs of the arc minimum
+//                   (v_min3 / v_max3, branch free) is both the corner test (> t) and cornerScore + 1.
 //                   Corners (3-4 % of the pixels) are also appended to a list private to the wavefront's
 //                   (strip, segment) region -- no atomics, the count lives in a scalar register.
 //   k_fast_nms    : sparse: one lane per listed corner checks its 8 neighbours in the score plane (neighbours outside
@@ -75,13 +76,8 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
     const uint8_t* rm3 = rows + ((row - 3) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
     const int v = r0[3];
     int d[16], nd[16];
-#ifdef UVO_EXP_NOGATHER
-    for (int k = 0; k < 16; ++k) d[k] = (int)((meta >> k) & 0xff) + (k * 37 & 63);
-    (void)rp1, (void)rp2, (void)rp3, (void)rm1, (void)rm2, (void)rm3;
-#else
     d[0] = rp3[3], d[1] = rp3[4], d[2] = rp2[5], d[3] = rp1[6], d[4] = r0[6], d[5] = rm1[6], d[6] = rm2[5], d[7] = rm3[4];
     d[8] = rm3[3], d[9] = rm3[2], d[10] = rm2[1], d[11] = rm1[0], d[12] = r0[0], d[13] = rp1[0], d[14] = rp2[1], d[15] = rp3[2];
-#endif
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       d[k] -= v;
@@ -89,14 +85,7 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
     }
     // corner at t  <=>  some 9-arc has all diffs > t (brighter) or all < -t (darker)  <=>  max(sb, sd) > t;
     // cornerScore = max(sb, sd) - 1.  No masks, no divergent branches.
-#ifdef UVO_EXP_NOARC
-    int best = d[0];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) best ^= d[k];
-    best &= 31;
-#else
     const int best = max(arc9_maxmin(d), arc9_maxmin(nd));
-#endif
     if (best > t_min) {
       const int sc = best - 1;
       splane[(int64_t)row * pitch + X0 + xl] = (uint8_t)sc;
@@ -198,9 +187,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
           // ---- drain full batches (newest first); a stale remainder is flushed before its rows leave the ring ----
           while (qn >= 64) {
             qn -= 64;
-#ifndef UVO_EXP_NOCHUNK
             fast_score_chunk(q, rows8, qn, 64, lane, t_min, sp, g.pitch, X0, py0, region, ncorner);
-#endif
           }
           if (qn > 0 && pc - qoldest >= FR_MAXAGE) {
             fast_score_chunk(q, rows8, 0, qn, lane, t_min, sp, g.pitch, X0, py0, region, ncorner);

@@ -43,7 +43,9 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
     qa = Q[2 * qi];
     qb = Q[2 * qi + 1];
   }
-  int bd0 = 0x7fffffff, bi0 = -1, bd1 = 0x7fffffff, bi1 = -1;
+  // best two as packed keys (distance << 16 | train index): the two smallest keys are the two nearest neighbours with
+  // ties resolved to the lower train index, exactly the ascending strict-< scan; update = two v_min_u32 + one v_max_u32.
+  uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
   const uint8_t* mrow = mask ? mask + (int64_t)qi * nt : nullptr;
   for (int base = 0; base < nt; base += HM_TILE) {
     const int cnt = nt - base < HM_TILE ? nt - base : HM_TILE;
@@ -52,23 +54,21 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
     __syncthreads();
     if (live) {
       for (int j = 0; j < cnt; ++j) {
-        if (mrow && !mrow[base + j]) continue;
-        const int d = popc256(qa, qb, s_t[2 * j], s_t[2 * j + 1]);
-        if (d < bd0) {
-          bd1 = bd0, bi1 = bi0;
-          bd0 = d, bi0 = base + j;
-        } else if (d < bd1) {
-          bd1 = d, bi1 = base + j;
-        }
+        const uint32_t d = (uint32_t)popc256(qa, qb, s_t[2 * j], s_t[2 * j + 1]);
+        uint32_t key = (d << 16) | (uint32_t)(base + j);
+        if (mrow && !mrow[base + j]) key = 0xFFFFFFFFu;
+        const uint32_t lo = min(k0, key);
+        k1 = min(k1, max(k0, key));  // k0 <= k1: second smallest of {k0, k1, key}
+        k0 = lo;
       }
     }
   }
   if (live) {
     const int64_t o = (int64_t)pair * out_stride + qi;
-    idx0[o] = bi0;
-    d0[o] = bi0 < 0 ? (uint16_t)0xFFFF : (uint16_t)bd0;
-    idx1[o] = bi1;
-    d1[o] = bi1 < 0 ? (uint16_t)0xFFFF : (uint16_t)bd1;
+    idx0[o] = k0 == 0xFFFFFFFFu ? -1 : (int32_t)(k0 & 0xffffu);
+    d0[o] = k0 == 0xFFFFFFFFu ? (uint16_t)0xFFFF : (uint16_t)(k0 >> 16);
+    idx1[o] = k1 == 0xFFFFFFFFu ? -1 : (int32_t)(k1 & 0xffffu);
+    d1[o] = k1 == 0xFFFFFFFFu ? (uint16_t)0xFFFF : (uint16_t)(k1 >> 16);
   }
 }
 

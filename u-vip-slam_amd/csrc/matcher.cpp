@@ -63,7 +63,7 @@ int uvo_matcher_create(const uvo_matcher_cfg* cfg, uvo_matcher** out) {
   if (!cfg || !out) return matcher_fail(UVO_E_BADARG, "null pointer");
   *out = nullptr;
   if (cfg->max_query < 1 || cfg->max_train < 1 || cfg->max_batch < 1 || cfg->max_map_points < 0 || cfg->max_query > 65535 ||
-      cfg->max_train > (1 << 24))
+      cfg->max_train > 65535)
     return matcher_fail(UVO_E_BADARG, "bad matcher configuration");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return matcher_fail(UVO_E_NODEVICE, "no HIP device available (no CPU fallback exists)");
