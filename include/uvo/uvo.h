@@ -182,6 +182,15 @@ int uvo_hamming_knn2_batch_device(uvo_matcher* m, int pairs, const uint8_t* d_q,
 int uvo_hamming_matrix(uvo_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, uint16_t* dist);
 
 /*
+ * MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:197-270) for a batch of map points: desc holds the observed
+ * descriptors of all points back to back, point p owns rows offsets[p] .. offsets[p+1]-1 (at most 65535 each).  Per point:
+ * best_idx = row (relative to offsets[p]) with the least median Hamming distance to the point's rows, itself included,
+ * median = sorted[int(0.5*(N-1))], first index on ties; best_median = that median; -1 / -1 for an empty point.  Host buffers.
+ */
+int uvo_distinctive_descriptors(uvo_matcher* m, const uint8_t* desc, const int32_t* offsets, int npoints, int32_t* best_idx,
+                                int32_t* best_median);
+
+/*
  * ORBmatcher::SearchByProjection(FrameKTL&, const vector<MapPoint*>&, th): src/ORBmatcher.cc:49-125, with the
  * frame grid of src/FrameKTL.cc:250-264,359-436 (64 x 48 cells, PosInGrid uses round()).  Host buffers.
  *   frame : kp[n] (undistorted keypoints: x, y, octave are read), desc[n][32], image bounds min/max x/y

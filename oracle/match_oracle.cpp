@@ -46,6 +46,35 @@ void knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* mas
   }
 }
 
+// MapPoint::ComputeDistinctiveDescriptors: src/MapPoint.cc:197-270 (distance matrix :236-247, least-median pick :250-263)
+int distinctive_descriptor(const uint8_t* desc, int N, int* best_median) {
+  if (N <= 0) {
+    *best_median = -1;
+    return -1;
+  }
+  std::vector<std::vector<float>> Distances(N, std::vector<float>(N));
+  for (int i = 0; i < N; i++) {
+    Distances[i][i] = 0;
+    for (int j = i + 1; j < N; j++) {
+      int distij = descriptor_distance(desc + (size_t)i * 32, desc + (size_t)j * 32);
+      Distances[i][j] = (float)distij;
+      Distances[j][i] = (float)distij;
+    }
+  }
+  int BestMedian = 0x7fffffff, BestIdx = 0;
+  for (int i = 0; i < N; i++) {
+    std::vector<int> vDists(Distances[i].begin(), Distances[i].end());
+    std::sort(vDists.begin(), vDists.end());
+    int median = vDists[(size_t)(0.5 * (N - 1))];
+    if (median < BestMedian) {
+      BestMedian = median;
+      BestIdx = i;
+    }
+  }
+  *best_median = BestMedian;
+  return BestIdx;
+}
+
 // grid constants: include/FrameKTL.h:45-46
 static const int GRID_ROWS = 48, GRID_COLS = 64;
 

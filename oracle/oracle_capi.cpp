@@ -127,6 +127,7 @@ int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) { return descrip
 void orc_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* mask, int32_t* idx0, int32_t* d0, int32_t* idx1, int32_t* d1) {
   knn2(q, nq, t, nt, mask, idx0, d0, idx1, d1);
 }
+int orc_distinctive_descriptor(const uint8_t* desc, int n, int* best_median) { return distinctive_descriptor(desc, n, best_median); }
 int orc_features_in_area(const KeyPoint* kps, int n, int minX, int minY, int maxX, int maxY, float x, float y, float r, int minLevel,
                          int maxLevel, int32_t* out, int cap) {
   FrameGrid g;

@@ -91,6 +91,8 @@ void grider_fast(const View& img, std::vector<KeyPoint>& pts, int num_features, 
 int descriptor_distance(const uint8_t* a, const uint8_t* b);  // :1794-1810
 void knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* mask, int32_t* idx0, int32_t* d0, int32_t* idx1, int32_t* d1);
 
+int distinctive_descriptor(const uint8_t* desc, int N, int* best_median);  // src/MapPoint.cc:197-270
+
 struct FrameGrid {  // src/FrameKTL.cc:83-84,250-264,359-436
   int minX, minY, maxX, maxY;
   float invW, invH;

@@ -48,6 +48,7 @@ class Oracle:
         L.orc_grider_fast.argtypes = [vp, ci, ci, cl, ci, ci, ci, ci, ci, vp, ci]
         L.orc_descriptor_distance.argtypes = [vp, vp]
         L.orc_knn2.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp]
+        L.orc_distinctive_descriptor.argtypes = [vp, ci, vp]
         L.orc_features_in_area.argtypes = [vp, ci, ci, ci, ci, ci, cf, cf, cf, ci, ci, vp, ci]
         L.orc_search_by_projection.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, cf]
 
@@ -109,6 +110,12 @@ class Oracle:
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         self.L.orc_knn2(q.ctypes.data, nq, t.ctypes.data, len(t), None if m is None else m.ctypes.data, *[a.ctypes.data for a in o])
         return o  # idx0, d0, idx1, d1
+
+    def distinctive_descriptor(self, desc):
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        med = ctypes.c_int()
+        idx = self.L.orc_distinctive_descriptor(desc.ctypes.data, len(desc), ctypes.byref(med))
+        return idx, med.value
 
     def features_in_area(self, kps, bounds, x, y, r, min_level, max_level):
         kps = np.ascontiguousarray(kps, KP)

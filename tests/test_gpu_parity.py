@@ -314,3 +314,23 @@ def test_threshold_extremes(uvo, oracle, synth, fast_th):
         assert c_g == sorted(zip(c_o["x"].astype(int).tolist(), c_o["y"].astype(int).tolist(), c_o["response"].astype(int).tolist()))
     _assert_same_features(kp_g, de_g, kp_o, de_o, "fastTh %d" % fast_th)
     ex.close()
+
+
+def test_distinctive_descriptors_batch(uvo, oracle):
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:197-270): least-median-distance observation per map point."""
+    rng = np.random.default_rng(17)
+    lists = []
+    for n in [1, 2, 3, 7, 20, 64, 257, 300, 0, 5]:
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        d = np.repeat(base[None, :], n, 0)
+        flips = rng.random((n, 256)) < rng.uniform(0.02, 0.3)
+        d = np.packbits(np.unpackbits(d, axis=1) ^ flips, axis=1) if n else d
+        if n >= 3:
+            d[2] = d[1]  # duplicated observation: ties in the medians, first index must win
+        lists.append(d)
+    m = uvo.ORBmatcher(0.8)
+    idx, med = m.distinctive_descriptors(lists)
+    for p, d in enumerate(lists):
+        ref = oracle.distinctive_descriptor(d) if len(d) else (-1, -1)
+        assert (int(idx[p]), int(med[p])) == ref, "point %d (N=%d)" % (p, len(d))
+    m.close()

@@ -137,3 +137,25 @@ def test_search_by_projection_rules(oracle):
     pre = np.array([77, -1, -1, -1], np.int32)
     n, a = _sbp(oracle, kp, d, one(x=100.5, y=100, l=2, d=d[0]), assigned=pre)
     assert n == 1 and a.tolist()[:2] == [77, 0]
+
+
+def test_distinctive_descriptor_by_hand(oracle):
+    """src/MapPoint.cc:250-263: median = sorted row [int(0.5*(N-1))] with the self distance 0 included; first index wins ties."""
+    z = np.zeros(32, np.uint8)
+    def bits(n):
+        d = z.copy()
+        d[: n // 8] = 0xFF
+        if n % 8:
+            d[n // 8] = (1 << (n % 8)) - 1
+        return d
+    # four descriptors on a line: 0, 10, 20, 100 bits set (nested) -> distances are differences
+    D = np.stack([bits(0), bits(10), bits(20), bits(100)])
+    # rows sorted: [0,10,20,100] [0,10,10,90] [0,10,20,80] [0,80,90,100]; index int(0.5*3) = 1 -> medians 10,10,10,80 -> first = 0
+    assert oracle.distinctive_descriptor(D) == (0, 10)
+    # N = 3: index 1 of the sorted row: [0,10,20] -> 10, [0,10,10] -> 10, [0,10,20] -> 10 -> first
+    assert oracle.distinctive_descriptor(D[:3]) == (0, 10)
+    # N = 5 with a clear centre: index 2
+    D5 = np.stack([bits(0), bits(40), bits(50), bits(60), bits(100)])
+    # row of bits(50): [0,10,10,50,50] -> median 10; others: bits(40): [0,10,20,40,60] -> 20; bits(60): 20; ends: 50
+    assert oracle.distinctive_descriptor(D5) == (2, 10)
+    assert oracle.distinctive_descriptor(D[:1]) == (0, 0)

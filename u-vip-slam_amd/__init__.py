@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_level_dims",
     "uvo_grider_fast", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
-    "uvo_hamming_matrix", "uvo_search_by_projection", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
+    "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
     "uvo_matcher_kernel_times", "uvo_last_error", "uvo_device_info",
 ]
 
@@ -83,6 +83,7 @@ def _load():
     lib.uvo_hamming_knn2.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, vp, vp]
     lib.uvo_hamming_knn2_batch_device.argtypes = [vp, ci, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp]
     lib.uvo_hamming_matrix.argtypes = [vp, vp, ci, vp, ci, vp]
+    lib.uvo_distinctive_descriptors.argtypes = [vp, vp, vp, ci, vp, vp]
     lib.uvo_search_by_projection.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp]
     lib.uvo_matcher_wait_extractor.argtypes = [vp, vp]
     lib.uvo_extractor_wait_matcher.argtypes = [vp, vp]
@@ -311,6 +312,20 @@ class ORBmatcher:
         if rc:
             raise UvoError(rc, "uvo_hamming_matrix")
         return out
+
+    def distinctive_descriptors(self, desc_lists):
+        """MapPoint::ComputeDistinctiveDescriptors for a batch of map points (src/MapPoint.cc:197-270).
+        desc_lists: list of (n_i, 32) uint8 arrays.  Returns (best_idx, best_median) int32 arrays."""
+        offs = np.zeros(len(desc_lists) + 1, np.int32)
+        offs[1:] = np.cumsum([len(d) for d in desc_lists])
+        allv = [np.ascontiguousarray(d, np.uint8).reshape(-1, 32) for d in desc_lists if len(d)]
+        allv = np.concatenate(allv) if allv else np.zeros((0, 32), np.uint8)
+        idx = np.zeros(len(desc_lists), np.int32)
+        med = np.zeros(len(desc_lists), np.int32)
+        rc = lib.uvo_distinctive_descriptors(self._h, _ptr(allv) if len(allv) else None, _ptr(offs), len(desc_lists), _ptr(idx), _ptr(med))
+        if rc:
+            raise UvoError(rc, "uvo_distinctive_descriptors")
+        return idx, med
 
     def knn2_batch_device(self, pairs, d_q, d_nq, q_stride, d_t, d_nt, t_stride, d_idx0, d_d0, d_idx1, d_d1):
         rc = lib.uvo_hamming_knn2_batch_device(self._h, pairs, d_q, d_nq, q_stride, d_t, d_nt, t_stride, d_idx0, d_d0, d_idx1, d_d1)

@@ -92,6 +92,46 @@ __global__ __launch_bounds__(256) void k_matrix(const uint8_t* __restrict__ q, i
   for (int j = 0; j < cnt; ++j) dist[(int64_t)qi * nt + base + j] = (uint16_t)popc256(qa, qb, s_t[2 * j], s_t[2 * j + 1]);
 }
 
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:197-270): among the N observations of a map point take the
+// descriptor whose median distance to all of them (itself included: distance 0) is smallest; median = sorted[int(0.5*(N-1))];
+// first index wins ties (:257-261).  One workgroup per map point, one thread per observation (strided for N > 256).
+// The k-th smallest of a row is found by bisection on the distance value (9 rounds of N popcounts) -- no sort, no storage.
+__global__ __launch_bounds__(256) void k_medoid(const uint8_t* __restrict__ desc, const int32_t* __restrict__ offsets, int32_t* __restrict__ best_idx,
+                                                int32_t* __restrict__ best_median) {
+  __shared__ uint32_t s_best;
+  const int p = blockIdx.x;
+  const int o0 = offsets[p], n = offsets[p + 1] - o0;
+  if (threadIdx.x == 0) s_best = 0xFFFFFFFFu;
+  __syncthreads();
+  if (n > 0) {
+    const uint4* D = reinterpret_cast<const uint4*>(desc + (int64_t)o0 * 32);
+    const int k = (int)(0.5 * (n - 1));
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const uint4 qa = D[2 * i], qb = D[2 * i + 1];
+      int lo = 0, hi = 256;  // smallest v with #{j : d(i,j) <= v} >= k+1
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        int c = 0;
+        for (int j = 0; j < n; ++j) c += popc256(qa, qb, D[2 * j], D[2 * j + 1]) <= mid;
+        if (c >= k + 1)
+          hi = mid;
+        else
+          lo = mid + 1;
+      }
+      atomicMin(&s_best, ((uint32_t)lo << 16) | (uint32_t)i);  // smallest median, then smallest index
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    best_idx[p] = n > 0 ? (int32_t)(s_best & 0xffffu) : -1;
+    best_median[p] = n > 0 ? (int32_t)(s_best >> 16) : -1;
+  }
+}
+
+void launch_medoid(hipStream_t s, const uint8_t* d_desc, const int32_t* d_offsets, int npoints, int32_t* d_idx, int32_t* d_med) {
+  hipLaunchKernelGGL(k_medoid, dim3(npoints), dim3(256), 0, s, d_desc, d_offsets, d_idx, d_med);
+}
+
 void launch_knn2(hipStream_t s, int pairs, int max_q, const uint8_t* d_q, const int32_t* d_nq, int nq_fixed, int q_stride, const uint8_t* d_t,
                  const int32_t* d_nt, int nt_fixed, int t_stride, const uint8_t* d_mask, int out_stride, int32_t* d_idx0, uint16_t* d_d0,
                  int32_t* d_idx1, uint16_t* d_d1) {

@@ -39,6 +39,9 @@ struct uvo_matcher {
   uint8_t *d_inview = nullptr, *d_mpdesc = nullptr;
   uint32_t* d_cand = nullptr;
   size_t cand_elems = 0;
+  uint8_t* d_md = nullptr;  // medoid staging: descriptors, offsets, results
+  int32_t *d_moff = nullptr, *d_mres = nullptr;
+  size_t md_rows = 0, md_points = 0;
   hipEvent_t ev = nullptr;
   Profiler prof;
 };
@@ -122,7 +125,7 @@ void uvo_matcher_destroy(uvo_matcher* m) {
   void* ptrs[] = {m->d_q,      m->d_t,     m->d_mask,       m->d_idx0,       m->d_idx1,       m->d_d0,    m->d_d1,         m->d_dist,  m->d_kp,
                   m->d_px,     m->d_py,    m->d_vc,         m->d_scale,      m->d_level,      m->d_assigned, m->d_cell_start, m->d_cell_items,
                   m->d_cell_of_kp, m->d_cand_cnt, m->d_cand_start, m->d_owner, m->d_owner_next, m->d_choice, m->d_nm, m->d_inview, m->d_mpdesc,
-                  m->d_cand};
+                  m->d_cand, m->d_md, m->d_moff, m->d_mres};
   for (void* p : ptrs)
     if (p) hipFree(p);
   m->prof.clear();
@@ -207,6 +210,38 @@ int uvo_hamming_matrix(uvo_matcher* m, const uint8_t* q, int nq, const uint8_t* 
   launch_matrix(s, m->d_q, nq, m->d_t, nt, m->d_dist);
   UVO_HIP_CHECK(hipGetLastError());
   UVO_HIP_CHECK(hipMemcpyAsync(dist, m->d_dist, need * 2, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipStreamSynchronize(s));
+  return UVO_OK;
+}
+
+int uvo_distinctive_descriptors(uvo_matcher* m, const uint8_t* desc, const int32_t* offsets, int npoints, int32_t* best_idx,
+                                int32_t* best_median) {
+  if (!m || !offsets || !best_idx || !best_median) return matcher_fail(UVO_E_BADARG, "null pointer");
+  if (npoints < 0) return matcher_fail(UVO_E_BADARG, "negative point count");
+  if (npoints == 0) return UVO_OK;
+  if (offsets[0] != 0) return matcher_fail(UVO_E_BADARG, "offsets[0] must be 0");
+  for (int p = 0; p < npoints; ++p)
+    if (offsets[p + 1] < offsets[p] || offsets[p + 1] - offsets[p] > 65535) return matcher_fail(UVO_E_BADARG, "offsets must be non-decreasing, <= 65535 rows per point");
+  const size_t rows = (size_t)offsets[npoints];
+  if (rows > 0 && !desc) return matcher_fail(UVO_E_BADARG, "null descriptor pointer");
+  UVO_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  if (rows > m->md_rows || (size_t)npoints > m->md_points) {
+    UVO_HIP_CHECK(hipStreamSynchronize(s));
+    for (void* p : {(void*)m->d_md, (void*)m->d_moff, (void*)m->d_mres})
+      if (p) hipFree(p);
+    m->d_md = nullptr, m->d_moff = nullptr, m->d_mres = nullptr;
+    const size_t r2 = std::max(rows, m->md_rows) * 2 + 1024, p2 = std::max((size_t)npoints, m->md_points) * 2 + 256;
+    int rc;
+    if ((rc = m_alloc(&m->d_md, r2 * 32)) || (rc = m_alloc(&m->d_moff, p2 + 1)) || (rc = m_alloc(&m->d_mres, 2 * p2))) return rc;
+    m->md_rows = r2, m->md_points = p2;
+  }
+  if (rows) UVO_HIP_CHECK(hipMemcpyAsync(m->d_md, desc, rows * 32, hipMemcpyHostToDevice, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(m->d_moff, offsets, (size_t)(npoints + 1) * 4, hipMemcpyHostToDevice, s));
+  launch_medoid(s, m->d_md, m->d_moff, npoints, m->d_mres, m->d_mres + npoints);
+  UVO_HIP_CHECK(hipGetLastError());
+  UVO_HIP_CHECK(hipMemcpyAsync(best_idx, m->d_mres, (size_t)npoints * 4, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(best_median, m->d_mres + npoints, (size_t)npoints * 4, hipMemcpyDeviceToHost, s));
   UVO_HIP_CHECK(hipStreamSynchronize(s));
   return UVO_OK;
 }
