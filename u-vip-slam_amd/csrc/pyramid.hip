@@ -16,24 +16,39 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return p;
 }
 
+// thread = 16 output bytes (one dwordx4 store).  Threads whose 16 columns lie inside the image copy one aligned
+// dwordx4 (when the caller's rows are 16-B aligned, `vec_ok`); border / unaligned threads gather byte by byte with
+// the reflected index.
 __global__ __launch_bounds__(256) void k_pad_level0(const uint8_t* __restrict__ img, int w, int h, int64_t stride, int64_t frame_stride,
-                                                    uint8_t* __restrict__ pyr, int64_t pyr_block, int64_t plane_off, int pitch, int ph) {
-  const int wx = blockIdx.x * blockDim.x + threadIdx.x;  // dword index in the padded row
-  const int py = blockIdx.y;
+                                                    uint8_t* __restrict__ pyr, int64_t pyr_block, int64_t plane_off, int pitch, int ph,
+                                                    int vec_ok) {
+  const int qx = blockIdx.x * 64 + (threadIdx.x & 63);  // 16-byte group in the padded row
+  const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int f = blockIdx.z;
-  if (wx * 4 >= pitch) return;
+  if (qx * 16 >= pitch || py >= ph) return;
   const int y = reflect101(py - kPad, h);
   const uint8_t* src = img + f * frame_stride + (int64_t)y * stride;
-  uint32_t v = 0;
+  const int x0 = qx * 16 - kPad;  // image column of byte 0
+  uint4 v;
+  if (vec_ok && x0 >= 0 && x0 + 16 <= w) {
+    v = *reinterpret_cast<const uint4*>(src + x0);
+  } else {
+    uint32_t d[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int x = reflect101(wx * 4 + i - kPad, w);
-    x = x < 0 ? 0 : (x >= w ? w - 1 : x);  // columns past pw (row pitch slack) stay in range
-    v |= (uint32_t)src[x] << (8 * i);
+    for (int j = 0; j < 4; ++j) {
+      uint32_t t = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int x = reflect101(x0 + j * 4 + i, w);
+        x = x < 0 ? 0 : (x >= w ? w - 1 : x);  // columns past pw (row pitch slack) stay in range
+        t |= (uint32_t)src[x] << (8 * i);
+      }
+      d[j] = t;
+    }
+    v = make_uint4(d[0], d[1], d[2], d[3]);
   }
   uint8_t* dst = pyr + f * pyr_block + plane_off + (int64_t)py * pitch;
-  *reinterpret_cast<uint32_t*>(dst + wx * 4) = v;
-  (void)ph;
+  *reinterpret_cast<uint4*>(dst + qx * 16) = v;
 }
 
 // cv::resize INTER_LINEAR, 8-bit generic path: horizontal pass in 11-bit fixed point (INTER_RESIZE_COEF_SCALE
@@ -107,8 +122,10 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t* __restrict__ pyr,
 void launch_pad_level0(hipStream_t s, const uint8_t* d_img, int w, int h, int64_t stride, int64_t frame_stride, uint8_t* d_pyr,
                        int64_t pyr_block, const LevelGeom& g0, int batch) {
   dim3 block(256);
-  dim3 grid((g0.pitch / 4 + 255) / 256, g0.ph, batch);
-  hipLaunchKernelGGL(k_pad_level0, grid, block, 0, s, d_img, w, h, stride, frame_stride, d_pyr, pyr_block, g0.plane_off, g0.pitch, g0.ph);
+  dim3 grid((g0.pitch / 16 + 63) / 64, (g0.ph + 3) / 4, batch);
+  const int vec_ok = ((uintptr_t)d_img % 16 == 0 && stride % 16 == 0 && frame_stride % 16 == 0) ? 1 : 0;
+  hipLaunchKernelGGL(k_pad_level0, grid, block, 0, s, d_img, w, h, stride, frame_stride, d_pyr, pyr_block, g0.plane_off, g0.pitch, g0.ph,
+                     vec_ok);
 }
 
 void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const LevelGeom& src, const LevelGeom& dst, const ResizeCol* d_ctab,
