@@ -77,6 +77,12 @@ struct FinalSlot {  // 16 B
 };
 
 const char* hip_err_set(hipError_t e, const char* what);
+#ifdef __HIPCC__
+// index of the calling wavefront inside its workgroup, as a scalar: the compiler cannot prove threadIdx.x >> 6 wave-uniform by
+// itself, and everything derived from it (row counters, queue lengths, addresses) would otherwise live in vector registers.
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+#endif
+
 int fail(int code, const char* msg);  // records msg for uvo_last_error() and returns code
 
 #define UVO_HIP_CHECK(expr)                                   \

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
                                                   uint8_t* __restrict__ out_desc, int cap, int32_t* __restrict__ n_out) {
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int slot = blockIdx.x * 4 + wave_in_block();
   int n = n_final[f];
   if (blockIdx.x == 0 && threadIdx.x == 0) n_out[f] = n;
   n = n > flist_cap ? flist_cap : n;

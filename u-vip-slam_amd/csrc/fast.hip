@@ -45,12 +45,40 @@ __device__ __forceinline__ int arc9_maxmin(const int* d) {
   return max(max(r[0], max(r[1], r[2])), max(r[3], max(r[4], r[5])));
 }
 
+// min over the 16 arcs of max(d): the darker polarity without negating d (max over arcs of min(-d) = -this)
+__device__ __forceinline__ int arc9_minmax(const int* d) {
+  int m3[16], m9[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m3[k] = max(d[k], max(d[(k + 1) & 15], d[(k + 2) & 15]));
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m9[k] = max(m3[k], max(m3[(k + 3) & 15], m3[(k + 6) & 15]));
+  int r[6];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) r[k] = min(m9[3 * k], min(m9[3 * k + 1], m9[3 * k + 2]));
+  r[5] = m9[15];
+  return min(min(r[0], min(r[1], r[2])), min(r[3], min(r[4], r[5])));
+}
+
 // byte I (0..11, compile time) of the 12-byte window [L C R]
 template <int I>
 __device__ __forceinline__ uint32_t win(uint32_t L, uint32_t C, uint32_t R) {
   static_assert(I >= 0 && I < 12, "window index");
   return ((I < 4 ? L : (I < 8 ? C : R)) >> (8 * (I & 3))) & 0xffu;
 }
+
+// Screening of two pixels packed as 16-bit halves (see k_fast_score): non-zero half <=> that pixel may be a corner.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 pk(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
+__device__ __forceinline__ uint32_t screen2(uint32_t v, uint32_t p0, uint32_t p8, uint32_t p4, uint32_t p12, uint32_t p2, uint32_t p10,
+                                            uint32_t p6, uint32_t p14, uint32_t t2) {
+  const u16x2 mx = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(pk(p0), pk(p8)), __builtin_elementwise_max(pk(p4), pk(p12))),
+                                             __builtin_elementwise_min(__builtin_elementwise_max(pk(p2), pk(p10)), __builtin_elementwise_max(pk(p6), pk(p14))));
+  const u16x2 mn = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(pk(p0), pk(p8)), __builtin_elementwise_min(pk(p4), pk(p12))),
+                                             __builtin_elementwise_max(__builtin_elementwise_min(pk(p2), pk(p10)), __builtin_elementwise_min(pk(p6), pk(p14))));
+  const u16x2 hi = __builtin_elementwise_add_sat(pk(v), pk(t2)), lo = __builtin_elementwise_sub_sat(pk(v), pk(t2));
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mx, hi)) | __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(lo, mn));
+}
+constexpr uint32_t kEven = 0x00ff00ffu, kOdd = 0xff00ff00u;
 
 constexpr int FR_ROWS = 16;         // LDS row ring depth per wavefront
 constexpr int FR_PITCH = 66;        // row pitch in dwords: 64 + 2 so that the same column of consecutive rows hits different banks
@@ -75,17 +103,14 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
     const uint8_t* rm2 = rows + ((row - 2) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
     const uint8_t* rm3 = rows + ((row - 3) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
     const int v = r0[3];
-    int d[16], nd[16];
+    int d[16];
     d[0] = rp3[3], d[1] = rp3[4], d[2] = rp2[5], d[3] = rp1[6], d[4] = r0[6], d[5] = rm1[6], d[6] = rm2[5], d[7] = rm3[4];
     d[8] = rm3[3], d[9] = rm3[2], d[10] = rm2[1], d[11] = rm1[0], d[12] = r0[0], d[13] = rp1[0], d[14] = rp2[1], d[15] = rp3[2];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      d[k] -= v;
-      nd[k] = -d[k];
-    }
+    for (int k = 0; k < 16; ++k) d[k] -= v;
     // corner at t  <=>  some 9-arc has all diffs > t (brighter) or all < -t (darker)  <=>  max(sb, sd) > t;
     // cornerScore = max(sb, sd) - 1.  No masks, no divergent branches.
-    const int best = max(arc9_maxmin(d), arc9_maxmin(nd));
+    const int best = max(arc9_maxmin(d), -arc9_minmax(d));
     if (best > t_min) {
       const int sc = best - 1;
       splane[(int64_t)row * pitch + X0 + xl] = (uint8_t)sc;
@@ -105,7 +130,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
                                                     uint32_t* __restrict__ cor, int32_t* __restrict__ cor_n, int items_per_frame) {
   __shared__ uint32_t s_q[4][FQ_CAP];
   __shared__ uint32_t s_rows[4][FR_ROWS * FR_PITCH];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = wave_in_block(), lane = threadIdx.x & 63;
   uint32_t* q = s_q[wv];
   uint32_t* rows32 = s_rows[wv];
   const uint8_t* rows8 = reinterpret_cast<const uint8_t*>(rows32);
@@ -137,6 +162,8 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
   int qn = 0;                      // wavefront-uniform queue length
   int qoldest = 0;                 // centre row of the oldest queued pixel (valid while qn > 0)
   const int lm = lane > 0 ? lane - 1 : 0, lp = lane < 63 ? lane + 1 : 63;
+  const bool ok0 = lane_ok && X + 0 < g.w, ok1 = lane_ok && X + 1 < g.w, ok2 = lane_ok && X + 2 < g.w, ok3 = lane_ok && X + 3 < g.w;
+  const uint32_t t_even = (uint32_t)t_min * 0x00010001u, t_odd = t_even << 8;
 
   uint32_t Cr[7];
   for (int base = 0; base < nsrc; base += 7) {
@@ -159,31 +186,34 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
           const uint32_t* rm = rows32 + ((pc - 2) & (FR_ROWS - 1)) * FR_PITCH;
           const uint32_t Lc = rc[lm], Rc = rc[lp], L2 = r2[lm], R2 = r2[lp], Lm2 = rm[lm], Rm2 = rm[lp];
           // ---- screen the lane's 4 pixels with four opposite ring pairs, queue the ones that pass ----
-#define UVO_FAST_PIXEL(K)                                                                                                          \
-  {                                                                                                                                \
-    const int v = (int)win<4 + K>(Lc, Cc, Rc);                                                                                      \
-    const int hi = v + t_min, lo = v - t_min;                                                                                      \
-    const int p0 = (int)win<4 + K>(0u, Cd, 0u), p8 = (int)win<4 + K>(0u, Cu, 0u);                                                  \
-    const int p4 = (int)win<7 + K>(Lc, Cc, Rc), p12 = (int)win<1 + K>(Lc, Cc, Rc);                                                 \
-    const int p2 = (int)win<6 + K>(L2, C2, R2), p10 = (int)win<2 + K>(Lm2, Cm2, Rm2);                                              \
-    const int p6 = (int)win<6 + K>(Lm2, Cm2, Rm2), p14 = (int)win<2 + K>(L2, C2, R2);                                              \
-    const bool bright = ((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi)) & ((p2 > hi) | (p10 > hi)) & ((p6 > hi) | (p14 > hi));  \
-    const bool dark = ((p0 < lo) | (p8 < lo)) & ((p4 < lo) | (p12 < lo)) & ((p2 < lo) | (p10 < lo)) & ((p6 < lo) | (p14 < lo));    \
-    const bool pass = (bright | dark) & lane_ok & (X + K < g.w);                                                                   \
-    const uint64_t m = __ballot(pass);                                                                                             \
-    if (m) {                                                                                                                       \
-      if (qn == 0) qoldest = pc;                                                                                                   \
-      if (pass)                                                                                                                    \
-        q[qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =                  \
-            (uint32_t)(lane * 4 + K) | ((uint32_t)pc << 8);                                                                        \
-      qn += __popcll(m);                                                                                                           \
-    }                                                                                                                              \
+          // Packed 16-bit arithmetic, two pixels per instruction: the even bytes of a pixel dword sit in the two 16-bit
+          // halves as they are (x & 0x00ff00ff), the odd bytes scaled by 256 (x & 0xff00ff00); all compares are unsigned.
+          // bright <=> min over the pairs of max(pair) > v + t ; dark <=> max over the pairs of min(pair) < v - t
+          // (saturating add / sub keep v +- t in range; a saturated bound can never be crossed by a pixel value).
+          const uint32_t P4 = __builtin_amdgcn_alignbyte(Rc, Cc, 3), P12 = __builtin_amdgcn_alignbyte(Cc, Lc, 1);
+          const uint32_t P2 = __builtin_amdgcn_alignbyte(R2, C2, 2), P14 = __builtin_amdgcn_alignbyte(C2, L2, 2);
+          const uint32_t P6 = __builtin_amdgcn_alignbyte(Rm2, Cm2, 2), P10 = __builtin_amdgcn_alignbyte(Cm2, Lm2, 2);
+          const uint32_t re = screen2(Cc & kEven, Cd & kEven, Cu & kEven, P4 & kEven, P12 & kEven, P2 & kEven, P10 & kEven, P6 & kEven,
+                                      P14 & kEven, t_even);
+          const uint32_t ro = screen2(Cc & kOdd, Cd & kOdd, Cu & kOdd, P4 & kOdd, P12 & kOdd, P2 & kOdd, P10 & kOdd, P6 & kOdd, P14 & kOdd,
+                                      t_odd);
+#define UVO_FAST_PUSH(K, COND)                                                                                    \
+  {                                                                                                               \
+    const bool pass = (COND) & ok##K;                                                                             \
+    const uint64_t m = __ballot(pass);                                                                            \
+    if (m) {                                                                                                      \
+      if (qn == 0) qoldest = pc;                                                                                  \
+      if (pass)                                                                                                   \
+        q[qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = \
+            (uint32_t)(lane * 4 + K) | ((uint32_t)pc << 8);                                                       \
+      qn += __popcll(m);                                                                                          \
+    }                                                                                                             \
   }
-          UVO_FAST_PIXEL(0)
-          UVO_FAST_PIXEL(1)
-          UVO_FAST_PIXEL(2)
-          UVO_FAST_PIXEL(3)
-#undef UVO_FAST_PIXEL
+          UVO_FAST_PUSH(0, (re & 0xffffu) != 0u)
+          UVO_FAST_PUSH(1, (ro & 0xffffu) != 0u)
+          UVO_FAST_PUSH(2, re > 0xffffu)
+          UVO_FAST_PUSH(3, ro > 0xffffu)
+#undef UVO_FAST_PUSH
           // ---- drain full batches (newest first); a stale remainder is flushed before its rows leave the ring ----
           while (qn >= 64) {
             qn -= 64;
@@ -233,7 +263,7 @@ __device__ __forceinline__ bool fast_region(const FastLevels& L, int item, int& 
 // One wavefront per (strip, segment) region of k_fast_score; one lane per listed corner.
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ score, int64_t pyr_block, FastLevels L, int fast_th,
                                                   uint32_t* __restrict__ cor, int32_t* __restrict__ cor_n, uint8_t* __restrict__ cell_hi) {
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = wave_in_block(), lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + wv;
   int level, X0, py0;
   if (!fast_region(L, item, level, X0, py0)) return;
@@ -302,7 +332,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ sc
 __global__ __launch_bounds__(256) void k_fast_emit(FastLevels L, int fast_th, const uint32_t* __restrict__ cor, const int32_t* __restrict__ cor_n,
                                                    const uint8_t* __restrict__ cell_hi, uint32_t* __restrict__ cand_xy,
                                                    uint32_t* __restrict__ cand_sc, int64_t cand_block, int32_t* __restrict__ cand_count) {
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = wave_in_block(), lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + wv;
   int level, X0, py0;
   if (!fast_region(L, item, level, X0, py0)) return;

@@ -43,7 +43,7 @@ __device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t 
 __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int64_t pyr_block,
                                                 const LevelGeom* __restrict__ lv, int nlevels, int4 taps, int rows_per_seg) {
   // work item (one per wavefront) -> (level, strip, segment)
-  int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int item = blockIdx.x * 4 + wave_in_block();
   const int lane = threadIdx.x & 63;
   int level = 0, nstrip = 0, nseg = 0;
   for (;; ++level) {

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_pad_level0(const uint8_t* __restrict__ 
                                                     uint8_t* __restrict__ pyr, int64_t pyr_block, int64_t plane_off, int pitch, int ph,
                                                     int vec_ok) {
   const int qx = blockIdx.x * 64 + (threadIdx.x & 63);  // 16-byte group in the padded row
-  const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int py = blockIdx.y * 4 + wave_in_block();
   const int f = blockIdx.z;
   if (qx * 16 >= pitch || py >= ph) return;
   const int y = reflect101(py - kPad, h);
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t* __restrict__ pyr,
                                                       int64_t dst_off, int dst_pitch, int dst_ph, int dw, int fast_ok,
                                                       const ResizeCol* __restrict__ ctab, const ResizeRow* __restrict__ rtab) {
   const int wx = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int py = blockIdx.y * 4 + wave_in_block();
   const int f = blockIdx.z;
   if (wx * 4 >= dst_pitch || py >= dst_ph) return;
   const ResizeRow rr = rtab[py];
