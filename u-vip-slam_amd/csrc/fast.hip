@@ -81,27 +81,25 @@ __device__ __forceinline__ uint32_t screen2(uint32_t v, uint32_t p0, uint32_t p8
 constexpr uint32_t kEven = 0x00ff00ffu, kOdd = 0xff00ff00u;
 
 constexpr int FR_ROWS = 16;         // LDS row ring depth per wavefront
+constexpr int FR_MIRROR = 6;        // ring slots 0..5 are mirrored into slots 16..21 (see fast_score_chunk)
 constexpr int FR_PITCH = 66;        // row pitch in dwords: 64 + 2 so that the same column of consecutive rows hits different banks
 constexpr int FR_MAXAGE = FR_ROWS - 8;  // a queued pixel needs rows -3..+3 around it: drain before they are overwritten
 
 // Full segment test + cornerScore of the queued pixels [first, first+count), one per lane.  The 16 ring pixels are read
-// back from the wavefront's LDS row ring (byte reads with immediate offsets).
+// back from the wavefront's LDS row ring: the queue entry carries the byte address of the pixel in the ring (rows 0..5 are
+// mirrored into slots 16..21, so the seven rows around any centre are consecutive slots and every read is base + immediate).
+// entry = ring byte address | xl << 13 | (row - py0) << 21
 __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_t* rows, int first, int count, int lane, int t_min,
                                                  uint8_t* __restrict__ splane, int pitch, int X0, int py0, uint32_t* __restrict__ region,
                                                  int& ncorner) {
   bool corner = false;
   uint32_t packed = 0;
   if (lane < count) {
-    const uint32_t meta = q[first + lane];  // xl | row << 8
-    const int xl = (int)(meta & 0xff), row = (int)(meta >> 8);
-    // row ring slot of row r is r & 15; base pointers 3 bytes left of the pixel so that every offset is >= 0
-    const uint8_t* r0 = rows + (row & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
-    const uint8_t* rp1 = rows + ((row + 1) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
-    const uint8_t* rp2 = rows + ((row + 2) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
-    const uint8_t* rp3 = rows + ((row + 3) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
-    const uint8_t* rm1 = rows + ((row - 1) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
-    const uint8_t* rm2 = rows + ((row - 2) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
-    const uint8_t* rm3 = rows + ((row - 3) & (FR_ROWS - 1)) * (FR_PITCH * 4) + xl - 3;
+    const uint32_t meta = q[first + lane];
+    const int xl = (int)((meta >> 13) & 0xff), rr = (int)(meta >> 21);
+    constexpr int RB = FR_PITCH * 4;
+    const uint8_t* r0 = rows + (meta & 0x1fffu) - 3;  // 3 bytes left of the pixel
+    const uint8_t *rp1 = r0 + RB, *rp2 = r0 + 2 * RB, *rp3 = r0 + 3 * RB, *rm1 = r0 - RB, *rm2 = r0 - 2 * RB, *rm3 = r0 - 3 * RB;
     const int v = r0[3];
     int d[16];
     d[0] = rp3[3], d[1] = rp3[4], d[2] = rp2[5], d[3] = rp1[6], d[4] = r0[6], d[5] = rm1[6], d[6] = rm2[5], d[7] = rm3[4];
@@ -113,9 +111,9 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
     const int best = max(arc9_maxmin(d), -arc9_minmax(d));
     if (best > t_min) {
       const int sc = best - 1;
-      splane[(int64_t)row * pitch + X0 + xl] = (uint8_t)sc;
+      splane[(int64_t)(py0 + rr) * pitch + X0 + xl] = (uint8_t)sc;
       corner = sc > 0;  // a score of 0 (only possible at t_min = 0) can never survive NMS
-      packed = (uint32_t)xl | ((uint32_t)(row - py0) << 8) | ((uint32_t)sc << 16);
+      packed = (uint32_t)xl | ((uint32_t)rr << 8) | ((uint32_t)sc << 16);
     }
   }
   const uint64_t m = __ballot(corner);
@@ -129,7 +127,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
                                                     const LevelGeom* __restrict__ lv, int nlevels, int t_min, int rows_per_seg,
                                                     uint32_t* __restrict__ cor, int32_t* __restrict__ cor_n, int items_per_frame) {
   __shared__ uint32_t s_q[4][FQ_CAP];
-  __shared__ uint32_t s_rows[4][FR_ROWS * FR_PITCH];
+  __shared__ uint32_t s_rows[4][(FR_ROWS + FR_MIRROR) * FR_PITCH];
   const int wv = wave_in_block(), lane = threadIdx.x & 63;
   uint32_t* q = s_q[wv];
   uint32_t* rows32 = s_rows[wv];
@@ -165,16 +163,28 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
   const bool ok0 = lane_ok && X + 0 < g.w, ok1 = lane_ok && X + 1 < g.w, ok2 = lane_ok && X + 2 < g.w, ok3 = lane_ok && X + 3 < g.w;
   const uint32_t t_even = (uint32_t)t_min * 0x00010001u, t_odd = t_even << 8;
 
-  uint32_t Cr[7];
+  // Row loads run one unrolled block (7 rows) ahead of their use so that a wavefront never waits on the row it needs next.
+  auto load_row = [&](int j) -> uint32_t { return *reinterpret_cast<const uint32_t*>(src + (int64_t)(py0 - 3 + j) * g.pitch + Xc); };
+  const uint32_t lane_entry = (uint32_t)(lane * 4) * ((1u << 13) + 1u);
+  uint32_t Cr[7], nxt[7];
+#pragma unroll
+  for (int u = 0; u < 7; ++u) nxt[u] = u < nsrc ? load_row(u) : 0u;
   for (int base = 0; base < nsrc; base += 7) {
+    uint32_t cur[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) cur[u] = nxt[u];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) nxt[u] = base + 7 + u < nsrc ? load_row(base + 7 + u) : 0u;
 #pragma unroll
     for (int u = 0; u < 7; ++u) {
       const int j = base + u;
       if (j < nsrc) {
         const int prow = py0 - 3 + j;
-        const uint32_t C = *reinterpret_cast<const uint32_t*>(src + (int64_t)prow * g.pitch + Xc);
+        const uint32_t C = cur[u];
         Cr[u] = C;
-        rows32[(prow & (FR_ROWS - 1)) * FR_PITCH + lane] = C;
+        const int slot = prow & (FR_ROWS - 1);
+        rows32[slot * FR_PITCH + lane] = C;
+        if (slot < FR_MIRROR) rows32[(slot + FR_ROWS) * FR_PITCH + lane] = C;
         if (j >= 6) {
           const int pc = prow - 3;  // centre row; rows pc-3 .. pc+3 sit in register slots (u+1)%7 .. u
           const int sm3 = (u + 1) % 7, sm2 = (u + 2) % 7, s0 = (u + 4) % 7, sp2 = (u + 6) % 7, sp3 = u;
@@ -185,6 +195,8 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
           const uint32_t* r2 = rows32 + ((pc + 2) & (FR_ROWS - 1)) * FR_PITCH;
           const uint32_t* rm = rows32 + ((pc - 2) & (FR_ROWS - 1)) * FR_PITCH;
           const uint32_t Lc = rc[lm], Rc = rc[lp], L2 = r2[lm], R2 = r2[lp], Lm2 = rm[lm], Rm2 = rm[lp];
+          const int cslot = (pc & (FR_ROWS - 1)) < 3 ? (pc & (FR_ROWS - 1)) + FR_ROWS : (pc & (FR_ROWS - 1));
+          const uint32_t row_entry = (uint32_t)(cslot * (FR_PITCH * 4)) | ((uint32_t)(pc - py0) << 21);
           // ---- screen the lane's 4 pixels with four opposite ring pairs, queue the ones that pass ----
           // Packed 16-bit arithmetic, two pixels per instruction: the even bytes of a pixel dword sit in the two 16-bit
           // halves as they are (x & 0x00ff00ff), the odd bytes scaled by 256 (x & 0xff00ff00); all compares are unsigned.
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
       if (qn == 0) qoldest = pc;                                                                                  \
       if (pass)                                                                                                   \
         q[qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = \
-            (uint32_t)(lane * 4 + K) | ((uint32_t)pc << 8);                                                       \
+            lane_entry + (row_entry + (uint32_t)K * ((1u << 13) + 1u));                                           \
       qn += __popcll(m);                                                                                          \
     }                                                                                                             \
   }
@@ -373,7 +385,9 @@ __global__ __launch_bounds__(256) void k_fast_emit(FastLevels L, int fast_th, co
   }
 }
 
-int fast_rows_per_seg(int batch) { return batch >= 16 ? 96 : 24; }
+// Rows per (strip, segment) work item.  A wavefront lives for the whole item, so long segments leave a long under-filled
+// tail at the end of the launch: 32 rows measured best for full batches (96: +20 % kernel time), 24 for small ones.
+int fast_rows_per_seg(int batch) { return batch >= 16 ? 32 : 24; }
 int fast_items_per_frame(const Geom& g, int rows_per_seg) {
   int items = 0;
   for (int l = 0; l < g.nlevels; ++l) items += ((g.lv[l].w - 32 + FS_COLS - 1) / FS_COLS) * ((g.lv[l].h - 32 + rows_per_seg - 1) / rows_per_seg);
