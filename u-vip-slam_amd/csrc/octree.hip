@@ -1,5 +1,6 @@
 // Kernel wrapper of the quad-tree selection (octree_core.hpp): one 256-thread workgroup per (frame, level),
 // node state carved out of dynamic LDS, candidate state words in HBM scratch.
+#include <cstdio>
 #include "common.hpp"
 #include "octree_core.hpp"
 
@@ -35,7 +36,17 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(const LevelGeom* __restr
                                                         uint32_t* __restrict__ sel_sc, int sel_block, int32_t* __restrict__ sel_count,
                                                         int lds_points) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  const int level = blockIdx.x, f = blockIdx.y;
+  const int level = blockIdx.y, f = blockIdx.x;  // level-major dispatch: the long level-0 problems start first
+#ifdef UVO_OCT_TRACE
+  const unsigned long long t_begin = wall_clock64();
+  struct Stamp {
+    unsigned long long t0;
+    int slot;
+    __device__ ~Stamp() {
+      if (threadIdx.x == 0 && slot < 2048) g_oct_blocks[2 * slot] = t0, g_oct_blocks[2 * slot + 1] = wall_clock64();
+    }
+  } stamp{t_begin, (int)(blockIdx.x * gridDim.y + blockIdx.y)};
+#endif
   const LevelGeom& g = lv[level];
   int P = cand_count[f * nlevels + level];
   P = P > g.cand_cap ? g.cand_cap : P;
@@ -107,8 +118,39 @@ void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const ui
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = lds;
   }
-  hipLaunchKernelGGL(k_octree, dim3(g.nlevels, batch), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, d_cand_xy, d_cand_sc, cand_block,
+#ifdef UVO_OCT_TRACE
+  {
+    static bool once = false;
+    if (!once) {
+      once = true;
+      int nb = -1;
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_octree), threads, lds);
+      hipFuncAttributes fa;
+      hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_octree));
+      fprintf(stderr, "[oct] M=%d Mp2=%d lds=%zu occupancy blocks/CU=%d regs=%d static_lds=%zu\n", M, Mp2, lds, nb, fa.numRegs, fa.sharedSizeBytes);
+    }
+  }
+#endif
+  hipLaunchKernelGGL(k_octree, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, d_cand_xy, d_cand_sc, cand_block,
                      d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count, throughput ? 0 : 1);
 }
 
 }  // namespace uvo
+
+#ifdef UVO_OCT_TRACE
+extern "C" int uvo_debug_oct_blocks(unsigned long long* out) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_oct_blocks), sizeof(unsigned long long) * 4096);
+  return 2048;
+}
+extern "C" int uvo_debug_oct_trace(unsigned long long* out, int cap) {
+  int n = 0;
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_oct_trace_n), sizeof(int));
+  n = n < cap ? n : cap;
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_oct_trace), sizeof(unsigned long long) * 2 * n);
+  int zero = 0;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_oct_trace_n), &zero, sizeof(int));
+  return n;
+}
+#endif

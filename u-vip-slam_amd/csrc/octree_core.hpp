@@ -27,6 +27,12 @@
 #define OCT_THREADS 256
 #endif
 
+#if defined(UVO_OCT_TRACE) && defined(__HIPCC__)
+__device__ unsigned long long g_oct_trace[2048];
+__device__ int g_oct_trace_n;
+__device__ unsigned long long g_oct_blocks[4096];
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define OCT_DEVICE 1
 #define OCT_NT ((int)blockDim.x)  // workgroup size chosen at launch: 256 (latency) or 64 (one wavefront per problem, throughput)
@@ -34,9 +40,20 @@
 #define OCT_PHASE_BEGIN \
   {                     \
     const int tid = threadIdx.x;
+#ifdef UVO_OCT_TRACE  // developer build only (UVO_EXTRA_FLAGS=-DUVO_OCT_TRACE): per-phase time stamps of one workgroup
+#define OCT_TRACE_MARK()                                                                              \
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && g_oct_trace_n < 1024) { \
+    g_oct_trace[2 * g_oct_trace_n] = __LINE__;                                                        \
+    g_oct_trace[2 * g_oct_trace_n + 1] = wall_clock64();                                              \
+    ++g_oct_trace_n;                                                                                  \
+  }
+#else
+#define OCT_TRACE_MARK()
+#endif
 #define OCT_PHASE_END \
   }                   \
-  __syncthreads();
+  __syncthreads();    \
+  OCT_TRACE_MARK()
 #define OCT_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define OCT_ATOMIC_MIN(p, v) atomicMin((p), (v))
 #define OCT_ATOMIC_MAX64(p, v) atomicMax((unsigned long long*)(p), (unsigned long long)(v))
@@ -145,6 +162,7 @@ OCT_FN uint32_t block_scan_excl(uint32_t* a, int n, uint32_t* part, int* sc) {
     run += v;
   }
   __syncthreads();
+  OCT_TRACE_MARK()
   (void)sc;
   return total;
 #else
@@ -193,6 +211,7 @@ OCT_FN void block_sort(T* a, int n, int n2, T* tmp) {
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += OCT_NT) a[i] = tmp[i];
   __syncthreads();
+  OCT_TRACE_MARK()
 #else
   (void)tmp;
   (void)n;
