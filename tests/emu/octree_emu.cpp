@@ -8,8 +8,10 @@
 
 #include "../../u-vip-slam_amd/csrc/octree_core.hpp"
 
-extern "C" int emu_octree(const uint32_t* cand_xy, const uint32_t* cand_score, int P, int N, int W, int H, int nCols, int nRows, int wCell,
-                          int hCell, uint32_t* sel_xy, uint32_t* sel_score, int sel_cap) {
+// k_regs: candidates per thread held in "registers" (8 or 32, as the kernel instantiates), 0 = memory-resident state,
+// -1 = pick like the kernel does.
+extern "C" int emu_octree_k(const uint32_t* cand_xy, const uint32_t* cand_score, int P, int N, int W, int H, int nCols, int nRows, int wCell,
+                            int hCell, uint32_t* sel_xy, uint32_t* sel_score, int sel_cap, int k_regs) {
   using namespace uvo::oct;
   if (P == 0) return 0;
   Params pr;
@@ -21,7 +23,7 @@ extern "C" int emu_octree(const uint32_t* cand_xy, const uint32_t* cand_score, i
   int Mp2 = 1;
   while (Mp2 < M) Mp2 <<= 1;
   pr.M = M, pr.Mp2 = Mp2;
-  std::vector<uint64_t> ccnt(2 * (size_t)M + Mp2);  // 8-byte aligned, >= 4M u32
+  std::vector<uint64_t> ccnt(2 * (size_t)M + Mp2), ccnt2(2 * (size_t)M + Mp2);  // 8-byte aligned, >= 4M u32
   std::vector<Box> boxA(M), boxB(M);
   std::vector<uint32_t> cntA(M), cntB(M), nodeOfRank(M), baseOfRank(M), sortbuf(Mp2), outKey(M), outPt(M), part(2 * OCT_THREADS);
   std::vector<int32_t> procRank(M);
@@ -30,7 +32,17 @@ extern "C" int emu_octree(const uint32_t* cand_xy, const uint32_t* cand_score, i
   Work w;
   w.boxA = boxA.data(), w.boxB = boxB.data(), w.cntA = cntA.data(), w.cntB = cntB.data(), w.procRank = procRank.data();
   w.ccnt = reinterpret_cast<uint32_t*>(ccnt.data());
+  w.ccnt2 = reinterpret_cast<uint32_t*>(ccnt2.data());
   w.nodeOfRank = nodeOfRank.data(), w.baseOfRank = baseOfRank.data(), w.sortbuf = sortbuf.data();
   w.outKey = outKey.data(), w.outPt = outPt.data(), w.part = part.data(), w.sc = sc.data();
-  return run(pr, w, cand_xy, cand_score, pstate.data(), sel_xy, sel_score, sel_cap);
+  if (k_regs < 0) k_regs = P <= 8 * OCT_THREADS ? 8 : (P <= 32 * OCT_THREADS ? 32 : 0);
+  if (k_regs > 0 && P > k_regs * OCT_THREADS) return -1;
+  if (k_regs == 8) return run<8>(pr, w, cand_xy, cand_score, pstate.data(), sel_xy, sel_score, sel_cap);
+  if (k_regs == 32) return run<32>(pr, w, cand_xy, cand_score, pstate.data(), sel_xy, sel_score, sel_cap);
+  return run<0>(pr, w, cand_xy, cand_score, pstate.data(), sel_xy, sel_score, sel_cap);
+}
+
+extern "C" int emu_octree(const uint32_t* cand_xy, const uint32_t* cand_score, int P, int N, int W, int H, int nCols, int nRows, int wCell,
+                          int hCell, uint32_t* sel_xy, uint32_t* sel_score, int sel_cap) {
+  return emu_octree_k(cand_xy, cand_score, P, N, W, H, nCols, nRows, wCell, hCell, sel_xy, sel_score, sel_cap, -1);
 }

@@ -302,11 +302,12 @@ def test_octree_toy_cases(oracle):
 def test_octree_kernel_body_matches_oracle_on_random_sets(oracle):
     """The HIP kernel's selection logic (csrc/octree_core.hpp), executed on the host through the phase macros."""
     lib = os.path.join(ROOT, "tests", "emu", "liboctree_emu.so")
-    if not os.path.exists(lib):
+    srcs = [os.path.join(ROOT, "tests", "emu", "octree_emu.cpp"), os.path.join(ROOT, "u-vip-slam_amd", "csrc", "octree_core.hpp")]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(f) for f in srcs):
         import subprocess
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", lib, os.path.join(ROOT, "tests", "emu", "octree_emu.cpp")])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", lib, srcs[0]])
     E = ctypes.CDLL(lib)
-    E.emu_octree.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    E.emu_octree_k.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     e = oracle.extractor(1000, 1.2, 8, 20)
     rng = np.random.default_rng(123)
     done = 0
@@ -337,9 +338,14 @@ def test_octree_kernel_body_matches_oracle_on_random_sets(oracle):
         xy = (pts[perm, 0].astype(np.uint32) | (pts[perm, 1].astype(np.uint32) << 16)).astype(np.uint32)
         sc = resp[perm].astype(np.uint32)
         sxy, ssc = np.zeros(N + 16 + P, np.uint32), np.zeros(N + 16 + P, np.uint32)
-        m = E.emu_octree(xy.ctypes.data, sc.ctypes.data, P, N, W, H, nCols, nRows, wCell, hCell, sxy.ctypes.data, ssc.ctypes.data, len(sxy))
-        got = [[int(v & 0xffff), int(v >> 16), int(s)] for v, s in zip(sxy[:m], ssc[:m])]
-        assert got == ref, "trial %d W=%d H=%d P=%d N=%d" % (trial, W, H, P, N)
+        # every instantiation the kernel has: candidate state in registers (8 or 32 per thread) or in memory (0)
+        for k_regs in (8, 32, 0):
+            if k_regs and P > k_regs * 256:
+                continue
+            m = E.emu_octree_k(xy.ctypes.data, sc.ctypes.data, P, N, W, H, nCols, nRows, wCell, hCell, sxy.ctypes.data, ssc.ctypes.data, len(sxy),
+                               k_regs)
+            got = [[int(v & 0xffff), int(v >> 16), int(s)] for v, s in zip(sxy[:m], ssc[:m])]
+            assert got == ref, "trial %d W=%d H=%d P=%d N=%d k_regs=%d" % (trial, W, H, P, N, k_regs)
         done += 1
     assert done > 100
 

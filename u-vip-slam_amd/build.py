@@ -32,7 +32,10 @@ def _newer(src_list, target):
 
 def build(force=False, verbose=True):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "uvo", "uvo.h"), __file__]
-    if not force and not _newer(deps, OUT):
+    extra = os.environ.get("UVO_EXTRA_FLAGS", "")
+    stamp = os.path.join(OBJ, "flags.txt")
+    same_flags = os.path.exists(stamp) and open(stamp).read() == extra
+    if not force and same_flags and not _newer(deps, OUT):
         return OUT
     os.makedirs(OBJ, exist_ok=True)
 
@@ -52,6 +55,8 @@ def build(force=False, verbose=True):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr[-6000:])
+    with open(stamp, "w") as fh:
+        fh.write(extra)
     return OUT
 
 

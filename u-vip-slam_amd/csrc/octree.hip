@@ -6,8 +6,6 @@
 
 namespace uvo {
 
-constexpr int OCT_LDS_P = 4096;  // candidate lists up to this length are staged in LDS (coordinates + state words)
-
 static inline int oct_capacity(int N, int nIni) {
   int m = N > 4 * nIni ? N : 4 * nIni;
   return m + 8;
@@ -18,23 +16,21 @@ static inline int pow2_ge(int v) {
   return p;
 }
 // bytes of LDS for node capacity M (layout must match the carve in k_octree)
-static inline size_t oct_lds_bytes(int M, int Mp2, bool lds_points) {
+static inline size_t oct_lds_bytes(int M, int Mp2) {
   size_t b = 0;
-  b += (size_t)16 * M;                      // ccnt[4M] (aliased by best64[2M] / sort64[Mp2])
+  b += (size_t)16 * M * 2;                  // ccnt[4M], ccnt2[4M] (aliased at the end by best64[2M] / sort64[Mp2])
   b += (size_t)8 * M * 2;                   // boxA, boxB
   b += (size_t)4 * M * 7;                   // cntA, cntB, procRank, nodeOfRank, baseOfRank, outKey, outPt
   b += (size_t)4 * Mp2;                     // sortbuf
   b += (size_t)4 * (2 * OCT_THREADS + 16);  // part, sc
-  if (lds_points) b += (size_t)4 * 2 * OCT_LDS_P;  // staged candidate xy + state
   return b;
 }
 
-__global__ __launch_bounds__(OCT_THREADS) void k_octree(const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max,
+__global__ __launch_bounds__(OCT_THREADS, 4) void k_octree(const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max,
                                                         const uint32_t* __restrict__ cand_xy, const uint32_t* __restrict__ cand_sc,
                                                         int64_t cand_block, const int32_t* __restrict__ cand_count,
                                                         uint32_t* __restrict__ pstate, uint32_t* __restrict__ sel_xy,
-                                                        uint32_t* __restrict__ sel_sc, int sel_block, int32_t* __restrict__ sel_count,
-                                                        int lds_points) {
+                                                        uint32_t* __restrict__ sel_sc, int sel_block, int32_t* __restrict__ sel_count) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int level = blockIdx.y, f = blockIdx.x;  // level-major dispatch: the long level-0 problems start first
 #ifdef UVO_OCT_TRACE
@@ -68,6 +64,7 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(const LevelGeom* __restr
   oct::Work w;
   uint8_t* p = lds;
   w.ccnt = reinterpret_cast<uint32_t*>(p), p += (size_t)16 * Mmax;
+  w.ccnt2 = reinterpret_cast<uint32_t*>(p), p += (size_t)16 * Mmax;
   w.boxA = reinterpret_cast<oct::Box*>(p), p += (size_t)8 * Mmax;
   w.boxB = reinterpret_cast<oct::Box*>(p), p += (size_t)8 * Mmax;
   w.cntA = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mmax;
@@ -80,20 +77,17 @@ __global__ __launch_bounds__(OCT_THREADS) void k_octree(const LevelGeom* __restr
   w.sortbuf = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mp2max;
   w.part = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * 2 * OCT_THREADS;
   w.sc = reinterpret_cast<int*>(p), p += (size_t)4 * 16;
-  uint32_t* l_xy = reinterpret_cast<uint32_t*>(p);
-  uint32_t* l_st = l_xy + OCT_LDS_P;
 
   const int64_t co = f * cand_block + g.cand_off;
   const int64_t so = (int64_t)f * sel_block + g.sel_off;
+  // candidate state in registers when the list fits 8 / 32 candidates per thread, else in the HBM scratch words
   int n;
-  if (lds_points && P <= OCT_LDS_P) {
-    // typical case: the whole candidate list lives in LDS for the duration of the passes
-    for (int i = threadIdx.x; i < P; i += (int)blockDim.x) l_xy[i] = cand_xy[co + i];
-    __syncthreads();
-    n = oct::run(pr, w, l_xy, cand_sc + co, l_st, sel_xy + so, sel_sc + so, g.sel_cap);
-  } else {
-    n = oct::run(pr, w, cand_xy + co, cand_sc + co, pstate + co, sel_xy + so, sel_sc + so, g.sel_cap);
-  }
+  if (P <= 8 * OCT_THREADS)
+    n = oct::run<8>(pr, w, cand_xy + co, cand_sc + co, pstate + co, sel_xy + so, sel_sc + so, g.sel_cap);
+  else if (P <= 32 * OCT_THREADS)
+    n = oct::run<32>(pr, w, cand_xy + co, cand_sc + co, pstate + co, sel_xy + so, sel_sc + so, g.sel_cap);
+  else
+    n = oct::run<0>(pr, w, cand_xy + co, cand_sc + co, pstate + co, sel_xy + so, sel_sc + so, g.sel_cap);
   if (threadIdx.x == 0) *out_n = n;
 }
 
@@ -106,13 +100,10 @@ void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const ui
     M = m > M ? m : M;
   }
   const int Mp2 = pow2_ge(M);
-  // The kernel is latency bound (a few hundred dependent phases per problem), so every (frame, level) problem should
-  // be resident at once: with many problems keep the candidate state in HBM/L2 (8 workgroups per CU); with few
-  // (latency path) stage the candidate list in LDS.  Measured at batch 256: 64-thread workgroups 1.02 ms,
-  // 256 threads + LDS staging 0.58 ms (3 per CU), 256 threads without staging fastest.
-  const bool throughput = batch * g.nlevels >= 512;
+  // The kernel is latency bound (a few dozen dependent phases per problem): the per-candidate state lives in registers,
+  // the node tables in LDS, and the grid is level-major so that the long level-0 problems are dispatched first.
   const int threads = OCT_THREADS;
-  const size_t lds = oct_lds_bytes(M, Mp2, !throughput);
+  const size_t lds = oct_lds_bytes(M, Mp2);
   static size_t configured = 0;
   if (lds > 64 * 1024 && lds > configured) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -132,7 +123,7 @@ void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const ui
   }
 #endif
   hipLaunchKernelGGL(k_octree, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, d_cand_xy, d_cand_sc, cand_block,
-                     d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count, throughput ? 0 : 1);
+                     d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count);
 }
 
 }  // namespace uvo

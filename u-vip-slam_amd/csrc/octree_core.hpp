@@ -60,7 +60,11 @@ __device__ unsigned long long g_oct_blocks[4096];
 #else
 #define OCT_DEVICE 0
 #define OCT_NT OCT_THREADS
+#if defined(__HIPCC__)  // host pass of a HIP translation unit: the kernel body naming these functions is still parsed
+#define OCT_FN __host__ __device__ static inline
+#else
 #define OCT_FN static inline
+#endif
 #define OCT_PHASE_BEGIN for (int tid = 0; tid < OCT_THREADS; ++tid) {
 #define OCT_PHASE_END }
 template <class T, class U>
@@ -105,7 +109,8 @@ struct Work {
   uint32_t* cntA;
   uint32_t* cntB;
   int32_t* procRank;     // per node of A: rank in processing order, or -1
-  uint32_t* ccnt;        // [4*M] child histogram of A  (aliased later by best64 / sort64)
+  uint32_t* ccnt;        // [4*M] child histogram (two buffers, swapped every generation; aliased later by best64 / sort64)
+  uint32_t* ccnt2;       // [4*M]
   uint32_t* nodeOfRank;  // processing rank -> node position in A
   uint32_t* baseOfRank;  // exclusive scan of non-empty child counts in processing order
   uint32_t* sortbuf;     // [Mp2]
@@ -237,35 +242,93 @@ OCT_FN void block_sort(T* a, int n, int n2, T* tmp) {
 
 OCT_FN int half_ceil(int a) { return (a + 1) >> 1; }  // ceil(a/2.f) for a >= 0 (DivideNode :1233-1234)
 
+// Per-candidate state.  K > 0: candidate p = tid + k * OCT_NT lives in slot k of the owning thread's register arrays (the
+// kernel picks the smallest K with P <= K * OCT_NT), so a pass over the points touches no memory but the LDS node tables.
+// K == 0: fallback for longer lists -- coordinates are re-read from cand_xy and the state word lives in pstate (HBM/L2).
+// State word of a live point: node position | child digit << 16; ST_UNPROC | position; ST_FROZEN.
+template <int K>
+struct PointRegs {
+#if OCT_DEVICE
+  uint32_t xy[K > 0 ? K : 1], st[K > 0 ? K : 1];
+#else
+  uint32_t xy[OCT_THREADS][K > 0 ? K : 1], st[OCT_THREADS][K > 0 ? K : 1];
+#endif
+};
+#if OCT_DEVICE
+#define OCT_PR(arr, k) arr[k]
+#else
+#define OCT_PR(arr, k) arr[tid][k]
+#endif
+// loop over the calling thread's candidates: k = slot, p = candidate index
+#define OCT_POINTS_BEGIN                                           \
+  _Pragma("unroll") for (int k = 0; k < (K > 0 ? K : kRt); ++k) { \
+    const int p = tid + k * OCT_NT;                                \
+    if (p >= P) break;
+#define OCT_POINTS_END }
+#define PT_XY() (K > 0 ? OCT_PR(R.xy, k) : cand_xy[p])
+#define PT_ST() (K > 0 ? OCT_PR(R.st, k) : pstate[p])
+#define PT_SET(v)                \
+  do {                           \
+    if (K > 0)                   \
+      OCT_PR(R.st, k) = (v);     \
+    else                         \
+      pstate[p] = (v);           \
+  } while (0)
+
+OCT_FN uint32_t child_digit(const Box& b, uint32_t xy) {
+  const int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
+  return (uint32_t)((x < (int)b.ulx + half_ceil((int)b.urx - (int)b.ulx) ? 0 : 1) + (y < (int)b.uly + half_ceil((int)b.bry - (int)b.uly) ? 0 : 2));
+}
+
 // cand_xy / cand_score: candidate coordinates (x | y<<16, relative to minBorder) and FAST scores
-// pstate: per-candidate scratch word.  sel_*: output in list order.  returns number of selected points.
+// pstate: per-candidate scratch word (used by K == 0 only).  sel_*: output in list order.  returns number of selected points.
+template <int K>
 OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const uint32_t* cand_score, uint32_t* pstate, uint32_t* sel_xy,
                uint32_t* sel_score, int sel_cap) {
   const int P = pr.P, N = pr.N;
+  const int kRt = (P + OCT_NT - 1) / OCT_NT;
+  (void)kRt;
   int* sc = w.sc;
   Box* A = w.boxA;
   Box* B = w.boxB;
   uint32_t* cA = w.cntA;
   uint32_t* cB = w.cntB;
+  uint32_t* H = w.ccnt;    // child histogram of the current generation A (filled by the previous pass over the points)
+  uint32_t* Hn = w.ccnt2;  // child histogram of the generation being built
+  PointRegs<K> R;
 
   // ---- roots (:1010-1052) ----
   OCT_PHASE_BEGIN
-  for (int i = tid; i < pr.nIni; i += OCT_NT) w.ccnt[i] = 0;
+  for (int i = tid; i < pr.nIni; i += OCT_NT) Hn[i] = 0;
+  for (int i = tid; i < 4 * pr.M; i += OCT_NT) H[i] = 0;
   if (tid == 0) sc[SC_NOUT] = 0;
   OCT_PHASE_END
   OCT_PHASE_BEGIN
-  for (int p = tid; p < P; p += OCT_NT) {
-    const float x = (float)(cand_xy[p] & 0xffff);
-    const int r = (int)(x / pr.hX);
-    OCT_ATOMIC_ADD(&w.ccnt[r], 1u);
-    pstate[p] = (uint32_t)r;
+  // every candidate falls into one of very few roots (nIni = round(W/H)): count the first four per thread and add once,
+  // instead of P atomics serialising on the same LDS word
+  uint32_t loc[4] = {0, 0, 0, 0};
+  OCT_POINTS_BEGIN
+  const uint32_t xy = cand_xy[p];
+  if (K > 0) OCT_PR(R.xy, k) = xy;
+  const float x = (float)(xy & 0xffff);
+  const int r = (int)(x / pr.hX);
+  if (r < 4) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) loc[q] += r == q;
+  } else {
+    OCT_ATOMIC_ADD(&Hn[r], 1u);
   }
+  PT_SET((uint32_t)r);
+  OCT_POINTS_END
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (loc[q]) OCT_ATOMIC_ADD(&Hn[q], loc[q]);
   OCT_PHASE_END
   OCT_PHASE_BEGIN
   if (tid == 0) {
     int na = 0;
     for (int r = 0; r < pr.nIni; ++r) {
-      if (w.ccnt[r] == 0) {
+      if (Hn[r] == 0) {
         w.nodeOfRank[r] = 0;
         continue;
       }
@@ -276,24 +339,37 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
       b.uly = 0;
       b.bry = (uint16_t)pr.H;
       A[na] = b;
-      cA[na] = w.ccnt[r];
+      cA[na] = Hn[r];
       ++na;
     }
     sc[SC_NA] = na;
   }
   OCT_PHASE_END
+  // root assignment, fused with the child digit + histogram of generation 0 (DivideNode :1262-1276)
   OCT_PHASE_BEGIN
-  for (int p = tid; p < P; p += OCT_NT) {
-    const uint32_t a = w.nodeOfRank[pstate[p]];
-    if (cA[a] == 1) {
-      const int slot = OCT_ATOMIC_ADD(&sc[SC_NOUT], 1);
-      w.outKey[slot] = ((uint32_t)(GEN_MAX - 0) << 16) | a;
-      w.outPt[slot] = (uint32_t)p;
-      pstate[p] = ST_FROZEN;
+  uint32_t loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // children of root nodes 0 and 1, counted per thread (see above)
+  OCT_POINTS_BEGIN
+  const uint32_t a = w.nodeOfRank[PT_ST()];
+  if (cA[a] == 1) {
+    const int slot = OCT_ATOMIC_ADD(&sc[SC_NOUT], 1);
+    w.outKey[slot] = ((uint32_t)(GEN_MAX - 0) << 16) | a;
+    w.outPt[slot] = (uint32_t)p;
+    PT_SET(ST_FROZEN);
+  } else {
+    const uint32_t d = child_digit(A[a], PT_XY());
+    const uint32_t h = 4 * a + d;
+    if (h < 8) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) loc[q] += h == (uint32_t)q;
     } else {
-      pstate[p] = a;
+      OCT_ATOMIC_ADD(&H[h], 1u);
     }
+    PT_SET(a | (d << 16));
   }
+  OCT_POINTS_END
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (loc[q]) OCT_ATOMIC_ADD(&H[q], loc[q]);
   OCT_PHASE_END
 
   int na = oct_bcast(&sc[SC_NA]);
@@ -308,6 +384,7 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
     // ---- which nodes of A are expandable; default processing order = list order ----
     OCT_PHASE_BEGIN
     for (int a = tid; a < na; a += OCT_NT) w.baseOfRank[a] = cA[a] > 1 ? 1u : 0u;
+    for (int i = tid; i < 4 * pr.M; i += OCT_NT) Hn[i] = 0;
     OCT_PHASE_END
     const int nExp = (int)block_scan_excl(w.baseOfRank, na, w.part, sc);
     if (nExp == 0) break;
@@ -320,20 +397,6 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
       } else {
         w.procRank[a] = -1;
       }
-    }
-    for (int i = tid; i < 4 * na; i += OCT_NT) w.ccnt[i] = 0;
-    OCT_PHASE_END
-    // ---- child digit + histogram (DivideNode :1262-1276) ----
-    OCT_PHASE_BEGIN
-    for (int p = tid; p < P; p += OCT_NT) {
-      const uint32_t st = pstate[p];
-      if (st == ST_FROZEN) continue;
-      const uint32_t a = st & 0xffffu;
-      const Box b = A[a];
-      const int x = (int)(cand_xy[p] & 0xffff), y = (int)(cand_xy[p] >> 16);
-      const int d = (x < (int)b.ulx + half_ceil((int)b.urx - (int)b.ulx) ? 0 : 1) + (y < (int)b.uly + half_ceil((int)b.bry - (int)b.uly) ? 0 : 2);
-      OCT_ATOMIC_ADD(&w.ccnt[4 * a + d], 1u);
-      pstate[p] = a | ((uint32_t)d << 16);
     }
     OCT_PHASE_END
     int nProc = nExp;
@@ -358,7 +421,7 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
       for (int i = tid; i < nExp; i += OCT_NT) {
         const uint32_t a = w.sortbuf[i] & 0xfffu;
         w.nodeOfRank[i] = a;
-        const uint32_t* c = &w.ccnt[4 * a];
+        const uint32_t* c = &H[4 * a];
         w.baseOfRank[i] = (uint32_t)((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0)) - 1u;  // net nodes added by this split
       }
       if (tid == 0) sc[SC_M] = nExp;
@@ -367,7 +430,7 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
       OCT_PHASE_BEGIN
       for (int i = tid; i < nExp; i += OCT_NT) {
         const uint32_t a = w.nodeOfRank[i];
-        const uint32_t* c = &w.ccnt[4 * a];
+        const uint32_t* c = &H[4 * a];
         const int add = (int)((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0)) - 1;
         if (size + (int)w.baseOfRank[i] + add >= N) OCT_ATOMIC_MIN(&sc[SC_M], i + 1);
       }
@@ -380,15 +443,13 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
     // ---- creation rank of every child: exclusive scan of non-empty-child counts in processing order ----
     OCT_PHASE_BEGIN
     for (int i = tid; i < nProc; i += OCT_NT) {
-      const uint32_t* c = &w.ccnt[4 * w.nodeOfRank[i]];
+      const uint32_t* c = &H[4 * w.nodeOfRank[i]];
       w.baseOfRank[i] = (uint32_t)((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0));
     }
+    if (tid == 0) sc[SC_NTOEXP] = 0;
     OCT_PHASE_END
     const int T = (int)block_scan_excl(w.baseOfRank, nProc, w.part, sc);
     // ---- build the new generation B in list order: position = T-1-creation rank ----
-    OCT_PHASE_BEGIN
-    if (tid == 0) sc[SC_NTOEXP] = 0;
-    OCT_PHASE_END
     OCT_PHASE_BEGIN
     for (int i = tid; i < nProc; i += OCT_NT) {
       const uint32_t a = w.nodeOfRank[i];
@@ -397,7 +458,7 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
       uint32_t rank = w.baseOfRank[i];
       int nmulti = 0;
       for (int d = 0; d < 4; ++d) {
-        const uint32_t c = w.ccnt[4 * a + d];
+        const uint32_t c = H[4 * a + d];
         if (c == 0) continue;
         const int pos = T - 1 - (int)rank;
         Box nb;
@@ -413,32 +474,43 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
       if (nmulti) OCT_ATOMIC_ADD(&sc[SC_NTOEXP], nmulti);
     }
     OCT_PHASE_END
-    // ---- move points to their child node; freeze single-point children ----
+    // ---- move points to their child node; freeze single-point children; points that stay live get their child digit
+    //      inside the new node straight away (histogram of the next generation) ----
     const int newgen = gen + 1;
     OCT_PHASE_BEGIN
-    for (int p = tid; p < P; p += OCT_NT) {
-      const uint32_t st = pstate[p];
-      if (st == ST_FROZEN) continue;
+    // two sweeps so that the table look-ups of all of a thread's candidates can be in flight together: first the new node
+    // position of every live point (reads only), then the freeze / next-digit step (atomics)
+    OCT_POINTS_BEGIN
+    const uint32_t st = PT_ST();
+    if (st != ST_FROZEN) {
       const uint32_t a = st & 0xffffu;
       const int d = (int)(st >> 16);
       const int r = w.procRank[a];
       if (r < 0) {
-        pstate[p] = ST_UNPROC | a;  // parent not reached by a truncated careful round
-        continue;
+        PT_SET(ST_UNPROC | a);  // parent not reached by a truncated careful round (always the last round)
+      } else {
+        const uint32_t* c = &H[4 * a];
+        const int lower = (int)((d > 0 && c[0] > 0) + (d > 1 && c[1] > 0) + (d > 2 && c[2] > 0));
+        PT_SET((uint32_t)(T - 1 - ((int)w.baseOfRank[r] + lower)));
       }
-      const uint32_t* c = &w.ccnt[4 * a];
-      int lower = 0;
-      for (int dd = 0; dd < d; ++dd) lower += c[dd] > 0;
-      const int pos = T - 1 - ((int)w.baseOfRank[r] + lower);
+    }
+    OCT_POINTS_END
+    OCT_POINTS_BEGIN
+    const uint32_t st = PT_ST();
+    if (st != ST_FROZEN && !(st & ST_UNPROC)) {
+      const int pos = (int)st;
       if (cB[pos] == 1) {
         const int slot = OCT_ATOMIC_ADD(&sc[SC_NOUT], 1);
         w.outKey[slot] = ((uint32_t)(GEN_MAX - newgen) << 16) | (uint32_t)pos;
         w.outPt[slot] = (uint32_t)p;
-        pstate[p] = ST_FROZEN;
+        PT_SET(ST_FROZEN);
       } else {
-        pstate[p] = (uint32_t)pos;
+        const uint32_t nd = child_digit(B[pos], PT_XY());
+        OCT_ATOMIC_ADD(&Hn[4 * pos + nd], 1u);
+        PT_SET((uint32_t)pos | (nd << 16));
       }
     }
+    OCT_POINTS_END
     OCT_PHASE_END
     const int nToExpand = oct_bcast(&sc[SC_NTOEXP]);
     size = prev_size - nProc + T;
@@ -453,6 +525,9 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
       uint32_t* tc = cA;
       cA = cB;
       cB = tc;
+      uint32_t* th = H;
+      H = Hn;
+      Hn = th;
     }
     if (size >= N || size == prev_size) break;  // :1136-1139 / :1201-1202
     if (!careful && size + 3 * nToExpand > N) careful = true;  // :1140
@@ -464,45 +539,49 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
   OCT_PHASE_BEGIN
   for (int i = tid; i < nslots; i += OCT_NT) best[i] = 0;
   OCT_PHASE_END
-  auto point_key = [&](int p) -> uint64_t {
-    const int x = (int)(cand_xy[p] & 0xffff), y = (int)(cand_xy[p] >> 16);
+  // candidate order of the reference (cell-major, raster inside a cell), inverted so that "first" is the larger word; it is
+  // unique per candidate, so the winner of a slot is recognised by this word alone
+  auto point_ord = [&](uint32_t xy) -> uint32_t {
+    const int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
     int j = (x - 3) / pr.wCell, i = (y - 3) / pr.hCell;
     j = j > pr.nCols - 1 ? pr.nCols - 1 : j;
     i = i > pr.nRows - 1 ? pr.nRows - 1 : i;
     const uint32_t ord = ((uint32_t)(i * pr.nCols + j) * 128u + (uint32_t)(y - i * pr.hCell)) * 128u + (uint32_t)(x - j * pr.wCell);
-    return ((uint64_t)cand_score[p] << 32) | (uint64_t)(0xFFFFFFFFu - ord);
+    return 0xFFFFFFFFu - ord;
   };
   OCT_PHASE_BEGIN
-  for (int p = tid; p < P; p += OCT_NT) {
-    const uint32_t st = pstate[p];
-    if (st == ST_FROZEN) continue;
-    const int slot = (st & ST_UNPROC) ? na + (int)(st & 0xffffu) : (int)st;
-    OCT_ATOMIC_MAX64(&best[slot], point_key(p));
+  OCT_POINTS_BEGIN
+  const uint32_t st = PT_ST();
+  if (st != ST_FROZEN) {
+    const int slot = (st & ST_UNPROC) ? na + (int)(st & 0xffffu) : (int)(st & 0xffffu);
+    OCT_ATOMIC_MAX64(&best[slot], ((uint64_t)cand_score[p] << 32) | (uint64_t)point_ord(PT_XY()));
   }
+  OCT_POINTS_END
   OCT_PHASE_END
   OCT_PHASE_BEGIN
-  for (int p = tid; p < P; p += OCT_NT) {
-    const uint32_t st = pstate[p];
-    if (st == ST_FROZEN) continue;
+  OCT_POINTS_BEGIN
+  const uint32_t st = PT_ST();
+  if (st != ST_FROZEN) {
     const bool un = (st & ST_UNPROC) != 0;
-    const int slot = un ? na + (int)(st & 0xffffu) : (int)st;
-    if (best[slot] == point_key(p)) {
+    const int slot = un ? na + (int)(st & 0xffffu) : (int)(st & 0xffffu);
+    if ((uint32_t)best[slot] == point_ord(PT_XY())) {
       const int o = OCT_ATOMIC_ADD(&sc[SC_NOUT], 1);
       w.outKey[o] = ((uint32_t)(GEN_MAX - (un ? gen - 1 : gen)) << 16) | (st & 0xffffu);
       w.outPt[o] = (uint32_t)p;
     }
   }
+  OCT_POINTS_END
   OCT_PHASE_END
 
   // ---- list order = (generation desc, position asc) ----
   const int nOut = oct_bcast(&sc[SC_NOUT]);
-  uint64_t* srt = reinterpret_cast<uint64_t*>(w.ccnt);
+  uint64_t* srt = reinterpret_cast<uint64_t*>(w.ccnt2);
   int n2 = 1;
   while (n2 < nOut) n2 <<= 1;
   OCT_PHASE_BEGIN
   for (int i = tid; i < n2; i += OCT_NT) srt[i] = i < nOut ? (((uint64_t)w.outKey[i] << 32) | w.outPt[i]) : ~0ull;
   OCT_PHASE_END
-  block_sort(srt, nOut, n2, reinterpret_cast<uint64_t*>(B));  // both box buffers are dead by now
+  block_sort(srt, nOut, n2, reinterpret_cast<uint64_t*>(w.ccnt));  // both histograms are dead by now
   OCT_PHASE_BEGIN
   for (int i = tid; i < nOut && i < sel_cap; i += OCT_NT) {
     const uint32_t p = (uint32_t)(srt[i] & 0xffffffffu);
@@ -512,6 +591,13 @@ OCT_FN int run(const Params& pr, const Work& w, const uint32_t* cand_xy, const u
   OCT_PHASE_END
   return nOut;
 }
+
+#undef OCT_POINTS_BEGIN
+#undef OCT_POINTS_END
+#undef PT_XY
+#undef PT_ST
+#undef PT_SET
+#undef OCT_PR
 
 }  // namespace oct
 }  // namespace uvo
