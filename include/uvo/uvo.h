@@ -205,6 +205,142 @@ int uvo_search_by_projection(uvo_matcher* m, const uvo_keypoint* kp, int n, cons
                              const float* view_cos, const uint8_t* in_view, const uint8_t* mp_desc, const float* scale_factors,
                              int nlevels, float th, float nnratio, int* n_matches);
 
+/* ------------------------------------------------------------------------------------------------
+ * The other search loops of ORBmatcher.  They all share one shape -- queries visited in a fixed order, a candidate
+ * list per query, Hamming distance to every candidate, an acceptance rule, and (except Fuse) targets taken by an
+ * earlier query skipped by later ones -- so two generic entry points carry them (candidates from grid windows, or
+ * given by the caller), and the reference-named entry points below are thin marshalling layers over those.
+ * The order-dependent loops are reproduced exactly (see csrc/match_engine.hip).  Host buffers throughout.
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+  UVO_RULE_BEST_RATIO_SAME_LEVEL = 0, /* SearchByProjection(F, vpMapPoints, th): src/ORBmatcher.cc:96-123 */
+  UVO_RULE_BEST_ONLY = 1,             /* SearchByProjection(F, pKF, ...) :1681-1701; Fuse :1084-1119: d <= max_dist */
+  UVO_RULE_BEST_RATIO_LE = 2,         /* SearchByBoW(pKF, F, ...) :194-218: d <= max_dist && d < nnratio * second */
+  UVO_RULE_BEST_RATIO_LT = 3,         /* SearchByBoW(pKF1, pKF2, ...) :762-788: d < max_dist && d < nnratio * second */
+  UVO_RULE_TRIANGULATION = 4          /* SearchForTriangulation :893-935: d <= max_dist, sorted, d <= 2*best, epipolar */
+};
+typedef struct uvo_match_rule {
+  int32_t rule;              /* UVO_RULE_* */
+  int32_t max_dist;          /* TH_HIGH (100), TH_LOW (50) or the caller's ORBdist */
+  float nn_ratio;            /* mfNNratio */
+  int32_t exclusive;         /* 1: a target accepted by an earlier query is skipped by later ones */
+  int32_t check_orientation; /* mbCheckOrientation: rotation histogram + ComputeThreeMaxima (:1748-1789) */
+} uvo_match_rule;
+/* ORBmatcher::CheckDistEpipolarLine (:136-153): l = x1' F12; dsqr = (l . x2)^2 / (a^2+b^2) < 3.84 * sigma2[octave2] */
+typedef struct uvo_epipolar {
+  float f12[9];         /* row-major 3x3 */
+  const float* q_x;     /* query keypoint coordinates (kp1.pt) */
+  const float* q_y;
+  const float* t_x;     /* target keypoint coordinates (kp2.pt) */
+  const float* t_y;
+  const float* sigma2;  /* pKF2->GetSigma2(level), nlevels entries */
+  int32_t nlevels;
+} uvo_epipolar;
+
+/*
+ * Candidates from grid windows: FrameKTL::GetFeaturesInArea (src/FrameKTL.cc:359-424) / KeyFrame::GetFeaturesInArea
+ * (src/KeyFrame.cc:952-992) over the 64 x 48 grid of the target keypoints kp[n].
+ *   blocked[n]  : may be NULL; non-zero = target unavailable from the start (e.g. F.mvpMapPoints[i] != NULL)
+ *   query i     : window centre (qx, qy), radius qr, level filter [qmin_level, qmax_level] with the reference's meaning
+ *                 (-1,-1 = no filter; equal = that level only), qvalid (0 = query skipped), qdesc, qangle (read only
+ *                 when rule->check_orientation; the target angle is kp[].angle)
+ *   match[nq]   : target index or -1;  dist[nq] : its distance or -1;  *n_matches : number of matches
+ */
+int uvo_match_windows(uvo_matcher* m, const uvo_keypoint* kp, int n, const uint8_t* desc, const uint8_t* blocked, int min_x, int min_y,
+                      int max_x, int max_y, int nq, const float* qx, const float* qy, const float* qr, const int32_t* qmin_level,
+                      const int32_t* qmax_level, const uint8_t* qvalid, const uint8_t* qdesc, const float* qangle, const uvo_match_rule* rule,
+                      int32_t* match, int32_t* dist, int* n_matches);
+/*
+ * Candidates given by the caller: query i owns cand_idx[cand_start[i] .. cand_start[i+1]) (target indices, in the order
+ * the reference would visit them).  tlevel / tangle / qangle / tblocked / epi may be NULL when the rule does not read them.
+ */
+int uvo_match_groups(uvo_matcher* m, int nq, const uint8_t* qdesc, const float* qangle, int nt, const uint8_t* tdesc, const float* tangle,
+                     const int32_t* tlevel, const uint8_t* tblocked, const int32_t* cand_start, const int32_t* cand_idx,
+                     const uvo_epipolar* epi, const uvo_match_rule* rule, int32_t* match, int32_t* dist, int* n_matches);
+
+/*
+ * ORBmatcher::SearchByProjection(FrameKTL& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist): :1622-1746.
+ * Per key-frame map point i the caller passes what :1647-1672 computes (uvo_project_points() does it on the device):
+ * valid[i] (non-null, !isBad, not already found, projection inside the image), u, v, predicted level; kf_angle[i] =
+ * pKF->GetKeyPointUn(i).angle.  Window radius th * scale_factors[level], levels [level-1, level+1], best distance
+ * <= orb_dist, first-come exclusivity over the frame keypoints, rotation histogram when check_orientation.
+ *   assigned[n] : in/out, index of the map point held by frame keypoint k or -1 (F.mvpMapPoints[k])
+ */
+int uvo_search_by_projection_kf(uvo_matcher* m, const uvo_keypoint* kp, int n, const uint8_t* desc, int min_x, int min_y, int max_x, int max_y,
+                                int32_t* assigned, int nmp, const float* u, const float* v, const int32_t* level, const uint8_t* valid,
+                                const uint8_t* mp_desc, const float* kf_angle, const float* scale_factors, int nlevels, float th, int orb_dist,
+                                int check_orientation, int* n_matches);
+
+/*
+ * A DBoW2::FeatureVector (std::map<NodeId, vector<unsigned>>) in flat form: node ids ascending, features of node j =
+ * feat[start[j] .. start[j+1]).
+ */
+typedef struct uvo_feature_vector {
+  const uint32_t* node;
+  const int32_t* start;
+  const int32_t* feat;
+  int32_t n_nodes;
+} uvo_feature_vector;
+
+/*
+ * ORBmatcher::SearchByBoW(KeyFrame* pKF, FrameKTL& F, vpMapPointMatches) :155-284 (kf_kf = 0) and
+ * SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12) :715-850 (kf_kf = 1).
+ *   side 1 (queries): n1 keypoints, desc1, angle1, usable1[n1] = pMP1 != NULL && !isBad
+ *   side 2 (targets): n2 keypoints, desc2, angle2, usable2[n2] = kf_kf ? (pMP2 != NULL && !isBad) : 1 (NULL = all usable)
+ *   match12[n1] : target index or -1 (the reference stores the map point: vpMapPoints...[that index])
+ */
+int uvo_search_by_bow(uvo_matcher* m, int kf_kf, const uvo_feature_vector* fv1, int n1, const uint8_t* desc1, const float* angle1,
+                      const uint8_t* usable1, const uvo_feature_vector* fv2, int n2, const uint8_t* desc2, const float* angle2,
+                      const uint8_t* usable2, float nnratio, int check_orientation, int32_t* match12, int* n_matches);
+
+/*
+ * ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, ...) :852-1014.  kp1 / kp2 = undistorted keypoints (x, y, octave,
+ * angle are read), has_mp1 / has_mp2 = "keypoint already has a map point", f12 row-major, sigma2 = pKF2 level sigmas.
+ *   match12[n1] : index into kp2 or -1 (vMatchedPairs = the pairs with match12[i] >= 0, ascending i)
+ */
+int uvo_search_for_triangulation(uvo_matcher* m, const uvo_feature_vector* fv1, const uvo_keypoint* kp1, int n1, const uint8_t* desc1,
+                                 const uint8_t* has_mp1, const uvo_feature_vector* fv2, const uvo_keypoint* kp2, int n2, const uint8_t* desc2,
+                                 const uint8_t* has_mp2, const float* f12, const float* sigma2, int nlevels, int check_orientation,
+                                 int32_t* match12, int* n_matches);
+
+/*
+ * Search core of ORBmatcher::Fuse(pKF, vpMapPoints, th) :1016-1134 and Fuse(pKF, Scw, ...) :1136-1265: per candidate map
+ * point i (valid[i] = passed the projection tests :1037-1076, see uvo_project_points) the best key-frame keypoint in the
+ * window of radius th * scale_factors[level] on levels [level-1, level] with distance <= TH_LOW; no exclusivity.
+ *   best_idx[nmp] / best_dist[nmp] : keypoint index and distance, or -1.  The map mutation (:1104-1118) stays with the caller.
+ */
+int uvo_fuse(uvo_matcher* m, const uvo_keypoint* kp, int n, const uint8_t* desc, int min_x, int min_y, int max_x, int max_y, int nmp,
+             const float* u, const float* v, const int32_t* level, const uint8_t* valid, const uint8_t* mp_desc, const float* scale_factors,
+             int nlevels, float th, int32_t* best_idx, int32_t* best_dist);
+
+/*
+ * Projection prologues of the search loops: what the reference computes per map point before it queries the grid.
+ *   UVO_PROJECT_FRUSTUM  : FrameKTL::isInFrustum (src/FrameKTL.cc:299-357) + MapPoint::PredictScale (src/MapPoint.cc:373-388)
+ *                          -> valid (mbTrackInView), u, v (mTrackProjX/Y), level (mnTrackScaleLevel), view_cos (mTrackViewCos):
+ *                          the inputs of uvo_search_by_projection
+ *   UVO_PROJECT_KF_RELOC : SearchByProjection(CurrentFrame, pKF, ...) src/ORBmatcher.cc:1647-1670 -> the inputs of
+ *                          uvo_search_by_projection_kf (camera centre derived as -Rcw^T tcw like :1628; `ow` is ignored)
+ *   UVO_PROJECT_FUSE     : Fuse src/ORBmatcher.cc:1037-1075 -> the inputs of uvo_fuse
+ * Arithmetic follows the reference expression by expression (fp32 products, the double intermediates of `1.0/z`,
+ * cv::norm and cv::Mat::dot, libm logf); OpenCV's 3x3 * 3x1 product is taken as its small-matrix path (fp32 row sums, the
+ * `+ t` in double) -- an unpinned assumption, stated in DESIGN.md.  log(scaleFactor) is the intended constant
+ * (the reference reads it before it is initialised).
+ *   usable[i]      : 0 = skip (NULL / isBad / already found / already in the key frame ...), may be NULL
+ *   min_distance / max_distance : the raw mfMinDistance / mfMaxDistance members (the 0.8f / 1.2f factors of
+ *                    GetMin/MaxDistanceInvariance are applied here); normal: GetNormal(), modes FRUSTUM and FUSE
+ */
+enum { UVO_PROJECT_FRUSTUM = 0, UVO_PROJECT_KF_RELOC = 1, UVO_PROJECT_FUSE = 2 };
+typedef struct uvo_camera_pose {
+  float rcw[9]; /* row-major world -> camera rotation */
+  float tcw[3];
+  float ow[3];  /* camera centre in the world (mOw / GetCameraCenter()) */
+  float fx, fy, cx, cy;
+  float min_x, max_x, min_y, max_y; /* mnMinX, mnMaxX, mnMinY, mnMaxY */
+} uvo_camera_pose;
+int uvo_project_points(uvo_matcher* m, int mode, const uvo_camera_pose* cam, int npts, const float* xyz, const float* normal,
+                       const float* min_distance, const float* max_distance, const uint8_t* usable, const float* scale_factors, int nlevels,
+                       float scale_factor, float viewing_cos_limit, uint8_t* valid, float* u, float* v, int32_t* level, float* view_cos);
+
 /*
  * Device-side ordering between the two handles' streams (no host synchronisation): work enqueued on the
  * matcher after uvo_matcher_wait_extractor() starts only when everything enqueued on the extractor so far

@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <utility>
+#include <vector>
 
 #include "orb_oracle.hpp"
 
@@ -167,6 +169,331 @@ int search_by_projection(const FrameGrid& g, const uint8_t* fdesc, int32_t* assi
     }
   }
   return nmatches;
+}
+
+
+static const int TH_LOW = 50, HISTO_LENGTH = 30;  // src/ORBmatcher.cc:41-42
+
+// ORBmatcher::ComputeThreeMaxima: src/ORBmatcher.cc:1748-1789
+void compute_three_maxima(const int* sizes, int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = sizes[i];
+    if (s > max1) {
+      max3 = max2;
+      max2 = max1;
+      max1 = s;
+      ind3 = ind2;
+      ind2 = ind1;
+      ind1 = i;
+    } else if (s > max2) {
+      max3 = max2;
+      max2 = s;
+      ind3 = ind2;
+      ind2 = i;
+    } else if (s > max3) {
+      max3 = s;
+      ind3 = i;
+    }
+  }
+  if (max2 < 0.1f * (float)max1) {
+    ind2 = -1;
+    ind3 = -1;
+  } else if (max3 < 0.1f * (float)max1) {
+    ind3 = -1;
+  }
+}
+
+// rotation-bin idiom shared by the search loops, e.g. :1709-1716
+static int rot_bin(float a1, float a2) {
+  const float factor = 1.0f / HISTO_LENGTH;
+  float rot = a1 - a2;
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)roundf(rot * factor);
+  if (bin == HISTO_LENGTH) bin = 0;
+  return bin;
+}
+// the tail every loop ends with, e.g. :1724-1743: entries of all but the three fullest bins are removed
+template <class Remove>
+static int apply_rot_hist(std::vector<int>* rotHist, Remove remove) {
+  int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH], removed = 0;
+  for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+  compute_three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+  for (int i = 0; i < HISTO_LENGTH; i++) {
+    if (i == ind1 || i == ind2 || i == ind3) continue;
+    for (size_t j = 0; j < rotHist[i].size(); j++) {
+      remove(rotHist[i][j]);
+      removed++;
+    }
+  }
+  return removed;
+}
+
+// ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist): src/ORBmatcher.cc:1672-1745
+int search_by_projection_kf(const FrameGrid& g, const uint8_t* fdesc, int32_t* assigned, int nmp, const float* u, const float* v,
+                            const int32_t* level, const uint8_t* valid, const uint8_t* mpdesc, const float* kf_angle,
+                            const float* scaleFactors, float th, int ORBdist, bool checkOri) {
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (int i = 0; i < nmp; i++) {
+    if (!valid[i]) continue;
+    const int nPredictedLevel = level[i];
+    float radius = th * scaleFactors[nPredictedLevel];
+    std::vector<int> vIndices2 = g.GetFeaturesInArea(u[i], v[i], radius, nPredictedLevel - 1, nPredictedLevel + 1);
+    if (vIndices2.empty()) continue;
+    const uint8_t* dMP = mpdesc + (size_t)i * 32;
+    int bestDist = 0x7fffffff, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      if (assigned[i2] >= 0) continue;
+      int dist = descriptor_distance(dMP, fdesc + (size_t)i2 * 32);
+      if (dist < bestDist) {
+        bestDist = dist;
+        bestIdx2 = i2;
+      }
+    }
+    if (bestDist <= ORBdist) {
+      assigned[bestIdx2] = i;
+      nmatches++;
+      if (checkOri) rotHist[rot_bin(kf_angle[i], g.kps[bestIdx2].angle)].push_back(bestIdx2);
+    }
+  }
+  if (checkOri) nmatches -= apply_rot_hist(rotHist, [&](int idx2) { assigned[idx2] = -1; });
+  return nmatches;
+}
+
+// merge walk of :178-249 / :741-819 / :876-965 (std::map iteration; lower_bound jumps == sorted merge)
+template <class F>
+static void walk_shared_nodes(const FeatureVector& a, const FeatureVector& b, F f) {
+  int i = 0, j = 0;
+  while (i < a.n_nodes && j < b.n_nodes) {
+    if (a.node[i] == b.node[j]) {
+      f(i, j);
+      i++, j++;
+    } else if (a.node[i] < b.node[j]) {
+      while (i < a.n_nodes && a.node[i] < b.node[j]) i++;  // lower_bound
+    } else {
+      while (j < b.n_nodes && b.node[j] < a.node[i]) j++;
+    }
+  }
+}
+
+int search_by_bow(bool kf_kf, const FeatureVector& fv1, int n1, const uint8_t* desc1, const float* angle1, const uint8_t* usable1,
+                  const FeatureVector& fv2, int n2, const uint8_t* desc2, const float* angle2, const uint8_t* usable2, float nnratio,
+                  bool checkOri, int32_t* match12) {
+  for (int i = 0; i < n1; i++) match12[i] = -1;
+  std::vector<char> taken2(n2, 0);  // vpMapPointMatches[realIdxF] != NULL (:199)  /  vbMatched2 (:766)
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int nmatches = 0;
+  walk_shared_nodes(fv1, fv2, [&](int a, int b) {
+    for (int e1 = fv1.start[a]; e1 < fv1.start[a + 1]; e1++) {
+      const int idx1 = fv1.feat[e1];
+      if (!usable1[idx1]) continue;  // :188-194 / :751-757
+      const uint8_t* d1 = desc1 + (size_t)idx1 * 32;
+      int bestDist1 = 0x7fffffff, bestIdx2 = -1, bestDist2 = 0x7fffffff;
+      for (int e2 = fv2.start[b]; e2 < fv2.start[b + 1]; e2++) {
+        const int idx2 = fv2.feat[e2];
+        if (taken2[idx2]) continue;
+        if (kf_kf && usable2 && !usable2[idx2]) continue;  // :768-772
+        const int dist = descriptor_distance(d1, desc2 + (size_t)idx2 * 32);
+        if (dist < bestDist1) {
+          bestDist2 = bestDist1;
+          bestDist1 = dist;
+          bestIdx2 = idx2;
+        } else if (dist < bestDist2) {
+          bestDist2 = dist;
+        }
+      }
+      const bool under = kf_kf ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW;  // :786 vs :216
+      if (under && (float)bestDist1 < nnratio * (float)bestDist2) {
+        match12[idx1] = bestIdx2;
+        taken2[bestIdx2] = 1;
+        if (checkOri) rotHist[rot_bin(angle1[idx1], angle2[bestIdx2])].push_back(idx1);
+        nmatches++;
+      }
+    }
+  });
+  if (checkOri) nmatches -= apply_rot_hist(rotHist, [&](int idx1) { match12[idx1] = -1; });
+  return nmatches;
+}
+
+// ORBmatcher::CheckDistEpipolarLine: src/ORBmatcher.cc:136-153
+static bool check_dist_epipolar_line(const KeyPoint& kp1, const KeyPoint& kp2, const float* F12, const float* sigma2) {
+  const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+  const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+  const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+  const float num = a * kp2.x + b * kp2.y + c;
+  const float den = a * a + b * b;
+  if (den == 0) return false;
+  const float dsqr = num * num / den;
+  return dsqr < 3.84 * sigma2[kp2.octave];
+}
+
+int search_for_triangulation(const FeatureVector& fv1, const KeyPoint* kp1, int n1, const uint8_t* desc1, const uint8_t* has_mp1,
+                             const FeatureVector& fv2, const KeyPoint* kp2, int n2, const uint8_t* desc2, const uint8_t* has_mp2,
+                             const float* F12, const float* sigma2, bool checkOri, int32_t* match12) {
+  int nmatches = 0;
+  std::vector<char> vbMatched2(n2, 0);
+  for (int i = 0; i < n1; i++) match12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  walk_shared_nodes(fv1, fv2, [&](int a, int b) {
+    for (int e1 = fv1.start[a]; e1 < fv1.start[a + 1]; e1++) {
+      const int idx1 = fv1.feat[e1];
+      if (has_mp1[idx1]) continue;
+      const uint8_t* d1 = desc1 + (size_t)idx1 * 32;
+      std::vector<std::pair<int, size_t>> vDistIndex;
+      for (int e2 = fv2.start[b]; e2 < fv2.start[b + 1]; e2++) {
+        const int idx2 = fv2.feat[e2];
+        if (vbMatched2[idx2] || has_mp2[idx2]) continue;
+        const int dist = descriptor_distance(d1, desc2 + (size_t)idx2 * 32);
+        if (dist > TH_LOW) continue;
+        vDistIndex.push_back(std::make_pair(dist, (size_t)idx2));
+      }
+      if (vDistIndex.empty()) continue;
+      std::sort(vDistIndex.begin(), vDistIndex.end());
+      int BestDist = vDistIndex.front().first;
+      int DistTh = (int)round(2 * BestDist);
+      for (size_t id = 0; id < vDistIndex.size(); id++) {
+        if (vDistIndex[id].first > DistTh) break;
+        int currentIdx2 = (int)vDistIndex[id].second;
+        if (check_dist_epipolar_line(kp1[idx1], kp2[currentIdx2], F12, sigma2)) {
+          vbMatched2[currentIdx2] = 1;
+          match12[idx1] = currentIdx2;
+          nmatches++;
+          if (checkOri) rotHist[rot_bin(kp1[idx1].angle, kp2[currentIdx2].angle)].push_back(idx1);
+          break;
+        }
+      }
+    }
+  });
+  if (checkOri) nmatches -= apply_rot_hist(rotHist, [&](int idx1) { match12[idx1] = -1; });
+  return nmatches;
+}
+
+// Fuse(pKF, vpMapPoints, th): src/ORBmatcher.cc:1077-1101; KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:952-992) has no level
+// filter of its own (expressed here as -1,-1), the level test is :1094
+void fuse_search(const FrameGrid& g, const uint8_t* kfdesc, int nmp, const float* u, const float* v, const int32_t* level, const uint8_t* valid,
+                 const uint8_t* mpdesc, const float* scaleFactors, float th, int32_t* best_idx, int32_t* best_dist) {
+  for (int i = 0; i < nmp; i++) {
+    best_idx[i] = -1, best_dist[i] = -1;
+    if (!valid[i]) continue;
+    const int nPredictedLevel = level[i];
+    const float radius = th * scaleFactors[nPredictedLevel];
+    std::vector<int> vIndices = g.GetFeaturesInArea(u[i], v[i], radius, -1, -1);
+    if (vIndices.empty()) continue;
+    int bestDist = 0x7fffffff, bestIdx = -1;
+    for (int idx : vIndices) {
+      const int kpLevel = g.kps[idx].octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      const int dist = descriptor_distance(mpdesc + (size_t)i * 32, kfdesc + (size_t)idx * 32);
+      if (dist < bestDist) {
+        bestDist = dist;
+        bestIdx = idx;
+      }
+    }
+    if (bestDist <= TH_LOW) best_idx[i] = bestIdx, best_dist[i] = bestDist;
+  }
+}
+
+// ---- cv::Mat arithmetic used by the projection code, under the assumptions stated in orb_oracle.hpp ----
+static void mat_Rp_plus_t(const float* R, const float* p, const float* t, float* out) {  // cv::gemm small-matrix path
+  for (int i = 0; i < 3; i++) {
+    const float t0 = R[3 * i] * p[0] + R[3 * i + 1] * p[1] + R[3 * i + 2] * p[2];
+    out[i] = (float)(t0 * 1.0 + t[i] * 1.0);
+  }
+}
+static float mat_norm3(const float* a) {  // cv::norm(NORM_L2), CV_32F: double accumulator
+  double s = 0;
+  for (int i = 0; i < 3; i++) {
+    double v = a[i];
+    s += v * v;
+  }
+  return (float)std::sqrt(s);
+}
+static double mat_dot3(const float* a, const float* b) {  // cv::Mat::dot, CV_32F: double accumulator
+  double r = 0;
+  for (int i = 0; i < 3; i++) r += (double)a[i] * b[i];
+  return r;
+}
+
+bool is_in_frustum(const Camera& F, const float* P, const float* Pn, float mfMinDistance, float mfMaxDistance, float viewingCosLimit,
+                   float scaleFactor, int nScaleLevels, float* u_out, float* v_out, int* level, float* viewCos_out) {
+  float Pc[3];
+  mat_Rp_plus_t(F.Rcw, P, F.tcw, Pc);
+  const float PcX = Pc[0], PcY = Pc[1], PcZ = Pc[2];
+  if (PcZ < 0.0) return false;
+  const float invz = 1.0 / PcZ;
+  const float u = F.fx * PcX * invz + F.cx;
+  const float v = F.fy * PcY * invz + F.cy;
+  if (u < F.minX || u > F.maxX) return false;
+  if (v < F.minY || v > F.maxY) return false;
+  const float maxDistance = 1.2f * mfMaxDistance;  // GetMaxDistanceInvariance src/MapPoint.cc:350-354
+  const float minDistance = 0.8f * mfMinDistance;
+  const float PO[3] = {P[0] - F.Ow[0], P[1] - F.Ow[1], P[2] - F.Ow[2]};
+  const float dist = mat_norm3(PO);
+  if (dist < minDistance || dist > maxDistance) return false;
+  float viewCos = mat_dot3(PO, Pn) / dist;
+  if (viewCos < viewingCosLimit) return false;
+  // PredictScale: ratio = mfMaxDistance/currentDist; nScale = ceil(log(ratio)/mfLogScaleFactor) -- float overloads
+  const float ratio = mfMaxDistance / dist;
+  const float mfLogScaleFactor = logf(scaleFactor);
+  int nScale = (int)ceilf(logf(ratio) / mfLogScaleFactor);
+  if (nScale < 0)
+    nScale = 0;
+  else if (nScale >= nScaleLevels)
+    nScale = nScaleLevels - 1;
+  *u_out = u, *v_out = v, *level = nScale, *viewCos_out = viewCos;
+  return true;
+}
+
+bool project_kf_reloc(const Camera& F, const float* x3Dw, float mfMinDistance, const float* scaleFactors, int nScaleLevels, float* u_out,
+                      float* v_out, int* level) {
+  float Ow[3];  // Ow = -Rcw.t()*tcw :1628
+  for (int c = 0; c < 3; c++) {
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += (double)F.Rcw[3 * k + c] * (double)F.tcw[k];
+    Ow[c] = (float)(s * -1.0);
+  }
+  float x3Dc[3];
+  mat_Rp_plus_t(F.Rcw, x3Dw, F.tcw, x3Dc);
+  const float xc = x3Dc[0], yc = x3Dc[1];
+  const float invzc = 1.0 / x3Dc[2];
+  float u = F.fx * xc * invzc + F.cx;
+  float v = F.fy * yc * invzc + F.cy;
+  if (u < F.minX || u > F.maxX) return false;
+  if (v < F.minY || v > F.maxY) return false;
+  float minDistance = 0.8f * mfMinDistance;
+  const float PO[3] = {x3Dw[0] - Ow[0], x3Dw[1] - Ow[1], x3Dw[2] - Ow[2]};
+  float dist3D = mat_norm3(PO);
+  float ratio = dist3D / minDistance;
+  const float* it = std::lower_bound(scaleFactors, scaleFactors + nScaleLevels, ratio);
+  *level = std::min((int)(it - scaleFactors), nScaleLevels - 1);
+  *u_out = u, *v_out = v;
+  return true;
+}
+
+bool project_fuse(const Camera& K, const float* p3Dw, const float* Pn, float mfMinDistance, float mfMaxDistance, const float* scaleFactors,
+                  int nScaleLevels, float* u_out, float* v_out, int* level) {
+  const int nMaxLevel = nScaleLevels - 1;
+  float p3Dc[3];
+  mat_Rp_plus_t(K.Rcw, p3Dw, K.tcw, p3Dc);
+  if (p3Dc[2] < 0.0f) return false;
+  const float invz = 1 / p3Dc[2];
+  const float x = p3Dc[0] * invz;
+  const float y = p3Dc[1] * invz;
+  const float u = K.fx * x + K.cx;
+  const float v = K.fy * y + K.cy;
+  if (!(u >= K.minX && u < K.maxX && v >= K.minY && v < K.maxY)) return false;  // KeyFrame::IsInImage src/KeyFrame.cc:994-997
+  const float maxDistance = 1.2f * mfMaxDistance;
+  const float minDistance = 0.8f * mfMinDistance;
+  const float PO[3] = {p3Dw[0] - K.Ow[0], p3Dw[1] - K.Ow[1], p3Dw[2] - K.Ow[2]};
+  const float dist3D = mat_norm3(PO);
+  if (dist3D < minDistance || dist3D > maxDistance) return false;
+  if (mat_dot3(PO, Pn) < 0.5 * dist3D) return false;
+  const float ratio = dist3D / minDistance;
+  const float* it = std::lower_bound(scaleFactors, scaleFactors + nScaleLevels, ratio);
+  *level = std::min((int)(it - scaleFactors), nMaxLevel);
+  *u_out = u, *v_out = v;
+  return true;
 }
 
 }  // namespace orc

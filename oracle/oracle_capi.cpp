@@ -144,4 +144,66 @@ int orc_search_by_projection(const KeyPoint* kps, int n, const uint8_t* fdesc, i
   return search_by_projection(g, fdesc, assigned, nmp, projx, projy, level, viewcos, inview, mpdesc, scaleFactors, th, nnratio);
 }
 
+int orc_search_by_projection_kf(const KeyPoint* kps, int n, const uint8_t* fdesc, int minX, int minY, int maxX, int maxY, int32_t* assigned,
+                                int nmp, const float* u, const float* v, const int32_t* level, const uint8_t* valid, const uint8_t* mpdesc,
+                                const float* kf_angle, const float* scaleFactors, float th, int orbDist, int checkOri) {
+  FrameGrid g;
+  g.build(kps, n, minX, minY, maxX, maxY);
+  return search_by_projection_kf(g, fdesc, assigned, nmp, u, v, level, valid, mpdesc, kf_angle, scaleFactors, th, orbDist, checkOri != 0);
+}
+
+int orc_search_by_bow(int kf_kf, const uint32_t* node1, const int32_t* start1, const int32_t* feat1, int nn1, int n1, const uint8_t* desc1,
+                      const float* angle1, const uint8_t* usable1, const uint32_t* node2, const int32_t* start2, const int32_t* feat2, int nn2,
+                      int n2, const uint8_t* desc2, const float* angle2, const uint8_t* usable2, float nnratio, int checkOri, int32_t* match12) {
+  FeatureVector a{node1, start1, feat1, nn1}, b{node2, start2, feat2, nn2};
+  return search_by_bow(kf_kf != 0, a, n1, desc1, angle1, usable1, b, n2, desc2, angle2, usable2, nnratio, checkOri != 0, match12);
+}
+
+int orc_search_for_triangulation(const uint32_t* node1, const int32_t* start1, const int32_t* feat1, int nn1, const KeyPoint* kp1, int n1,
+                                 const uint8_t* desc1, const uint8_t* has_mp1, const uint32_t* node2, const int32_t* start2,
+                                 const int32_t* feat2, int nn2, const KeyPoint* kp2, int n2, const uint8_t* desc2, const uint8_t* has_mp2,
+                                 const float* F12, const float* sigma2, int checkOri, int32_t* match12) {
+  FeatureVector a{node1, start1, feat1, nn1}, b{node2, start2, feat2, nn2};
+  return search_for_triangulation(a, kp1, n1, desc1, has_mp1, b, kp2, n2, desc2, has_mp2, F12, sigma2, checkOri != 0, match12);
+}
+
+void orc_fuse_search(const KeyPoint* kps, int n, const uint8_t* kfdesc, int minX, int minY, int maxX, int maxY, int nmp, const float* u,
+                     const float* v, const int32_t* level, const uint8_t* valid, const uint8_t* mpdesc, const float* scaleFactors, float th,
+                     int32_t* best_idx, int32_t* best_dist) {
+  FrameGrid g;
+  g.build(kps, n, minX, minY, maxX, maxY);
+  fuse_search(g, kfdesc, nmp, u, v, level, valid, mpdesc, scaleFactors, th, best_idx, best_dist);
+}
+
+// mode 0 = isInFrustum, 1 = SearchByProjection(F, KF) prologue, 2 = Fuse prologue; cam = 23 floats in Camera order
+void orc_project_points(int mode, const float* cam, int n, const float* xyz, const float* normal, const float* minD, const float* maxD,
+                        const uint8_t* usable, const float* scaleFactors, int nlevels, float scaleFactor, float cosLimit, uint8_t* valid,
+                        float* u, float* v, int32_t* level, float* viewcos) {
+  Camera C;
+  memcpy(&C, cam, sizeof(Camera));
+  for (int i = 0; i < n; ++i) {
+    valid[i] = 0, u[i] = v[i] = 0.f, level[i] = 0;
+    if (viewcos) viewcos[i] = 0.f;
+    if (usable && !usable[i]) continue;
+    float uu = 0, vv = 0, vc = 0;
+    int lv = 0;
+    bool ok;
+    if (mode == 0)
+      ok = is_in_frustum(C, xyz + 3 * i, normal + 3 * i, minD[i], maxD[i], cosLimit, scaleFactor, nlevels, &uu, &vv, &lv, &vc);
+    else if (mode == 1)
+      ok = project_kf_reloc(C, xyz + 3 * i, minD[i], scaleFactors, nlevels, &uu, &vv, &lv);
+    else
+      ok = project_fuse(C, xyz + 3 * i, normal + 3 * i, minD[i], maxD[i], scaleFactors, nlevels, &uu, &vv, &lv);
+    if (!ok) continue;
+    valid[i] = 1, u[i] = uu, v[i] = vv, level[i] = lv;
+    if (viewcos) viewcos[i] = vc;
+  }
+}
+
+void orc_compute_three_maxima(const int* sizes, int L, int* ind) {
+  int a = -1, b = -1, c = -1;
+  compute_three_maxima(sizes, L, a, b, c);
+  ind[0] = a, ind[1] = b, ind[2] = c;
+}
+
 }  // extern "C"

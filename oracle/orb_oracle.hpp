@@ -109,4 +109,51 @@ int search_by_projection(const FrameGrid& g, const uint8_t* fdesc, int32_t* assi
                          int nmp, const float* projx, const float* projy, const int32_t* level, const float* viewcos,
                          const uint8_t* inview, const uint8_t* mpdesc, const float* scaleFactors, float th, float nnratio);
 
+
+// ---- the other search loops, restated on flat inputs (one array per member the reference reads) ----
+// ComputeThreeMaxima: src/ORBmatcher.cc:1748-1789 (sizes of the 30 rotation bins in, three bin indices out)
+void compute_three_maxima(const int* sizes, int L, int& ind1, int& ind2, int& ind3);
+
+// SearchByProjection(FrameKTL& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist): :1622-1746, from the point where
+// u, v and nPredictedLevel are known (:1672); valid[i] = the map point reaches that line.  assigned in/out as above.
+int search_by_projection_kf(const FrameGrid& g, const uint8_t* fdesc, int32_t* assigned, int nmp, const float* u, const float* v,
+                            const int32_t* level, const uint8_t* valid, const uint8_t* mpdesc, const float* kf_angle,
+                            const float* scaleFactors, float th, int ORBdist, bool checkOri);
+
+struct FeatureVector {  // DBoW2::FeatureVector flattened: node ids ascending, features of node j = feat[start[j]..start[j+1])
+  const uint32_t* node;
+  const int32_t* start;
+  const int32_t* feat;
+  int n_nodes;
+};
+// SearchByBoW(KeyFrame*, FrameKTL&, ...) :155-284 (kf_kf false) / SearchByBoW(KeyFrame*, KeyFrame*, ...) :715-850 (true)
+int search_by_bow(bool kf_kf, const FeatureVector& fv1, int n1, const uint8_t* desc1, const float* angle1, const uint8_t* usable1,
+                  const FeatureVector& fv2, int n2, const uint8_t* desc2, const float* angle2, const uint8_t* usable2, float nnratio,
+                  bool checkOri, int32_t* match12);
+// SearchForTriangulation :852-1014 with CheckDistEpipolarLine :136-153
+int search_for_triangulation(const FeatureVector& fv1, const KeyPoint* kp1, int n1, const uint8_t* desc1, const uint8_t* has_mp1,
+                             const FeatureVector& fv2, const KeyPoint* kp2, int n2, const uint8_t* desc2, const uint8_t* has_mp2,
+                             const float* F12, const float* sigma2, bool checkOri, int32_t* match12);
+// search core of Fuse(pKF, vpMapPoints, th) :1077-1101 (KeyFrame::GetFeaturesInArea src/KeyFrame.cc:952-992)
+void fuse_search(const FrameGrid& g, const uint8_t* kfdesc, int nmp, const float* u, const float* v, const int32_t* level, const uint8_t* valid,
+                 const uint8_t* mpdesc, const float* scaleFactors, float th, int32_t* best_idx, int32_t* best_dist);
+
+
+// ---- projection prologues.  OpenCV semantics assumed (unpinned, [OCV-RECALL]): `R*P+t` on 3x3 / 3x1 CV_32F takes cv::gemm's
+// small-matrix path (row sum in float, `(float)(t0*alpha + c*beta)` with double alpha = beta = 1); `-R.t()*t` takes the general
+// path (double accumulator, alpha = -1); cv::norm and cv::Mat::dot accumulate in double.
+struct Camera {
+  float Rcw[9], tcw[3], Ow[3];
+  float fx, fy, cx, cy, minX, maxX, minY, maxY;
+};
+// FrameKTL::isInFrustum src/FrameKTL.cc:299-357 + MapPoint::PredictScale src/MapPoint.cc:373-388 (logScale = logf(scaleFactor))
+bool is_in_frustum(const Camera& F, const float* P, const float* Pn, float mfMinDistance, float mfMaxDistance, float viewingCosLimit,
+                   float scaleFactor, int nScaleLevels, float* u, float* v, int* level, float* viewCos);
+// SearchByProjection(CurrentFrame, pKF, ...) src/ORBmatcher.cc:1626-1670
+bool project_kf_reloc(const Camera& F, const float* x3Dw, float mfMinDistance, const float* scaleFactors, int nScaleLevels, float* u, float* v,
+                      int* level);
+// Fuse src/ORBmatcher.cc:1037-1075
+bool project_fuse(const Camera& K, const float* p3Dw, const float* Pn, float mfMinDistance, float mfMaxDistance, const float* scaleFactors,
+                  int nScaleLevels, float* u, float* v, int* level);
+
 }  // namespace orc

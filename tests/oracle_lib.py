@@ -51,6 +51,12 @@ class Oracle:
         L.orc_distinctive_descriptor.argtypes = [vp, ci, vp]
         L.orc_features_in_area.argtypes = [vp, ci, ci, ci, ci, ci, cf, cf, cf, ci, ci, vp, ci]
         L.orc_search_by_projection.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, cf]
+        L.orc_search_by_projection_kf.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci]
+        L.orc_search_by_bow.argtypes = [ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, cf, ci, vp]
+        L.orc_search_for_triangulation.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp]
+        L.orc_fuse_search.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp]
+        L.orc_compute_three_maxima.argtypes = [vp, ci, vp]
+        L.orc_project_points.argtypes = [ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp, vp]
 
     # ---- extractor ----
     def extractor(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, fastTh=20):
@@ -133,6 +139,86 @@ class Oracle:
         assert assigned.dtype == np.int32
         return self.L.orc_search_by_projection(kps.ctypes.data, len(kps), desc.ctypes.data, *[int(b) for b in bounds], assigned.ctypes.data,
                                                len(a[0]), *[v.ctypes.data for v in a], float(th), float(nnratio))
+
+    def search_by_projection_kf(self, kps, desc, bounds, assigned, u, v, level, valid, mp_desc, kf_angle, scale_factors, th, orb_dist, check_ori):
+        kps = np.ascontiguousarray(kps, KP)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        a = [np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32), np.ascontiguousarray(level, np.int32),
+             np.ascontiguousarray(valid, np.uint8), np.ascontiguousarray(mp_desc, np.uint8), np.ascontiguousarray(kf_angle, np.float32),
+             np.ascontiguousarray(scale_factors, np.float32)]
+        assert assigned.dtype == np.int32
+        return self.L.orc_search_by_projection_kf(kps.ctypes.data, len(kps), desc.ctypes.data, *[int(b) for b in bounds], assigned.ctypes.data,
+                                                  len(a[0]), *[x.ctypes.data for x in a], float(th), int(orb_dist), 1 if check_ori else 0)
+
+    @staticmethod
+    def _fv(groups):
+        nodes = sorted(groups)
+        node = np.asarray(nodes, np.uint32)
+        start = np.zeros(len(nodes) + 1, np.int32)
+        feats = []
+        for j, k in enumerate(nodes):
+            feats.extend(int(x) for x in groups[k])
+            start[j + 1] = len(feats)
+        return node, start, np.asarray(feats if feats else [0], np.int32), len(nodes)
+
+    def search_by_bow(self, kf_kf, groups1, desc1, angle1, usable1, groups2, desc2, angle2, usable2, nnratio, check_ori):
+        """groups*: {node id: [feature indices]} (a DBoW2::FeatureVector).  Returns (match12, nmatches)."""
+        f1, f2 = self._fv(groups1), self._fv(groups2)
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        a1, a2 = np.ascontiguousarray(angle1, np.float32), np.ascontiguousarray(angle2, np.float32)
+        u1 = np.ascontiguousarray(usable1, np.uint8)
+        u2 = None if usable2 is None else np.ascontiguousarray(usable2, np.uint8)
+        match = np.full(len(d1), -1, np.int32)
+        n = self.L.orc_search_by_bow(1 if kf_kf else 0, f1[0].ctypes.data, f1[1].ctypes.data, f1[2].ctypes.data, f1[3], len(d1), d1.ctypes.data,
+                                     a1.ctypes.data, u1.ctypes.data, f2[0].ctypes.data, f2[1].ctypes.data, f2[2].ctypes.data, f2[3], len(d2),
+                                     d2.ctypes.data, a2.ctypes.data, None if u2 is None else u2.ctypes.data, float(nnratio), 1 if check_ori else 0,
+                                     match.ctypes.data)
+        return match, n
+
+    def search_for_triangulation(self, groups1, kp1, desc1, has_mp1, groups2, kp2, desc2, has_mp2, F12, sigma2, check_ori):
+        f1, f2 = self._fv(groups1), self._fv(groups2)
+        kp1, kp2 = np.ascontiguousarray(kp1, KP), np.ascontiguousarray(kp2, KP)
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        h1, h2 = np.ascontiguousarray(has_mp1, np.uint8), np.ascontiguousarray(has_mp2, np.uint8)
+        f, s2 = np.ascontiguousarray(F12, np.float32).reshape(9), np.ascontiguousarray(sigma2, np.float32)
+        match = np.full(len(kp1), -1, np.int32)
+        n = self.L.orc_search_for_triangulation(f1[0].ctypes.data, f1[1].ctypes.data, f1[2].ctypes.data, f1[3], kp1.ctypes.data, len(kp1), d1.ctypes.data,
+                                                h1.ctypes.data, f2[0].ctypes.data, f2[1].ctypes.data, f2[2].ctypes.data, f2[3], kp2.ctypes.data, len(kp2),
+                                                d2.ctypes.data, h2.ctypes.data, f.ctypes.data, s2.ctypes.data, 1 if check_ori else 0, match.ctypes.data)
+        return match, n
+
+    def fuse_search(self, kps, desc, bounds, u, v, level, valid, mp_desc, scale_factors, th):
+        kps = np.ascontiguousarray(kps, KP)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        a = [np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32), np.ascontiguousarray(level, np.int32),
+             np.ascontiguousarray(valid, np.uint8), np.ascontiguousarray(mp_desc, np.uint8), np.ascontiguousarray(scale_factors, np.float32)]
+        bi, bd = np.full(len(a[0]), -1, np.int32), np.full(len(a[0]), -1, np.int32)
+        self.L.orc_fuse_search(kps.ctypes.data, len(kps), desc.ctypes.data, *[int(b) for b in bounds], len(a[0]), *[x.ctypes.data for x in a], float(th),
+                               bi.ctypes.data, bd.ctypes.data)
+        return bi, bd
+
+    def project_points(self, mode, cam, xyz, normal, min_distance, max_distance, usable, scale_factors, scale_factor=1.2, cos_limit=0.5):
+        """cam: 23 floats = Rcw[9], tcw[3], Ow[3], fx, fy, cx, cy, minX, maxX, minY, maxY.  Returns (valid, u, v, level, view_cos)."""
+        cam = np.ascontiguousarray(cam, np.float32)
+        assert cam.shape == (23,)
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        n = len(xyz)
+        nrm = np.ascontiguousarray(normal if normal is not None else np.zeros((n, 3)), np.float32).reshape(-1, 3)
+        mn, mx = np.ascontiguousarray(min_distance, np.float32), np.ascontiguousarray(max_distance, np.float32)
+        us = None if usable is None else np.ascontiguousarray(usable, np.uint8)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        valid, u, v = np.zeros(n, np.uint8), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        level, vc = np.zeros(n, np.int32), np.zeros(n, np.float32)
+        self.L.orc_project_points(int(mode), cam.ctypes.data, n, xyz.ctypes.data, nrm.ctypes.data, mn.ctypes.data, mx.ctypes.data,
+                                  None if us is None else us.ctypes.data, sf.ctypes.data, len(sf), float(scale_factor), float(cos_limit),
+                                  valid.ctypes.data, u.ctypes.data, v.ctypes.data, level.ctypes.data, vc.ctypes.data)
+        return valid, u, v, level, vc
+
+    def compute_three_maxima(self, sizes):
+        s = np.ascontiguousarray(sizes, np.int32)
+        out = np.zeros(3, np.int32)
+        self.L.orc_compute_three_maxima(s.ctypes.data, len(s), out.ctypes.data)
+        return [int(x) for x in out]
 
     def grider_fast(self, img, num_features, grid_x, grid_y, threshold, nms=True):
         img = np.ascontiguousarray(img, np.uint8)

@@ -334,3 +334,207 @@ def test_distinctive_descriptors_batch(uvo, oracle):
         ref = oracle.distinctive_descriptor(d) if len(d) else (-1, -1)
         assert (int(idx[p]), int(med[p])) == ref, "point %d (N=%d)" % (p, len(d))
     m.close()
+
+
+# ---- the other ORBmatcher search loops (generic engine) ---------------------------------------------------------------
+def _two_views(uvo, synth, seed, W=752, H=480, fast_th=7):
+    """Two frames of a synthetic sequence (second = warped first) with their keypoints / descriptors."""
+    a = synth.make_frame(seed, W, H)
+    b = synth.warp_frame(a, seed + 1)
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, fast_th, max_width=W, max_height=H)
+    kp1, de1 = ex(a)
+    kp2, de2 = ex(b)
+    sf = ex.mvScaleFactor.copy()
+    ex.close()
+    return kp1, de1, kp2, de2, sf
+
+
+def _noisy_copies(rng, de, src, flip_p=0.06, true_frac=0.5):
+    M = len(src)
+    out = rng.integers(0, 256, (M, 32), dtype=np.uint8)
+    true = rng.random(M) < true_frac
+    noisy = np.packbits(np.unpackbits(de[src], axis=1) ^ (rng.random((M, 256)) < flip_p), axis=1)
+    out[true] = noisy[true]
+    return out
+
+
+def _bow_groups(rng, de, n_nodes=60):
+    """A stand-in vocabulary: node id = a hash of 6 descriptor bits (true matches mostly share a node), ids spread out."""
+    bits = np.unpackbits(de, axis=1)[:, [3, 41, 77, 130, 201, 250]]
+    node = (bits * (1 << np.arange(6))).sum(1) % n_nodes
+    groups = {}
+    for i in rng.permutation(len(de)):          # DBoW2 keeps features of a node in insertion order; any order must work
+        groups.setdefault(int(node[i]) * 7 + 3, []).append(int(i))
+    return groups
+
+
+@pytest.mark.parametrize("check_ori", [False, True])
+def test_search_by_projection_kf(uvo, oracle, synth, check_ori):
+    """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1622-1746)."""
+    rng = np.random.default_rng(21)
+    kp1, de1, kp2, de2, sf = _two_views(uvo, synth, 4100)
+    n, M = len(kp2), 1500
+    src = rng.integers(0, n, M)
+    mp_desc = _noisy_copies(rng, de2, src)
+    u = (kp2["x"][src] + rng.normal(0, 2.0, M)).astype(np.float32)
+    v = (kp2["y"][src] + rng.normal(0, 2.0, M)).astype(np.float32)
+    level = np.clip(kp2["octave"][src] + rng.integers(-1, 2, M), 0, 7).astype(np.int32)
+    valid = (rng.random(M) < 0.85).astype(np.uint8)
+    kf_angle = np.where(rng.random(M) < 0.8, kp2["angle"][src] + rng.normal(0, 4, M), rng.uniform(0, 360, M)).astype(np.float32) % np.float32(360)
+    m = uvo.ORBmatcher(0.9, check_ori, max_query=4096, max_map_points=8192)
+    for th, orbdist in ((10.0, 100), (15.0, 64)):
+        a_g = np.full(n, -1, np.int32)
+        a_g[rng.integers(0, n, 25)] = 999999
+        a_o = a_g.copy()
+        nm_g = m.SearchByProjectionKF(kp2, de2, (0, 0, 752, 480), a_g, u, v, level, valid, mp_desc, kf_angle, sf, th, orbdist)
+        nm_o = oracle.search_by_projection_kf(kp2, de2, (0, 0, 752, 480), a_o, u, v, level, valid, mp_desc, kf_angle, sf, th, orbdist, check_ori)
+        np.testing.assert_array_equal(a_g, a_o)
+        assert nm_g == nm_o and nm_g > 150
+    m.close()
+
+
+@pytest.mark.parametrize("kf_kf", [False, True])
+def test_search_by_bow(uvo, oracle, synth, kf_kf):
+    """SearchByBoW KF-Frame (:155-284) and KF-KF (:715-850) over a stand-in vocabulary."""
+    rng = np.random.default_rng(22)
+    kp1, de1, kp2, de2, sf = _two_views(uvo, synth, 4200)
+    g1, g2 = _bow_groups(rng, de1), _bow_groups(rng, de2)
+    usable1 = (rng.random(len(kp1)) < 0.8).astype(np.uint8)
+    usable2 = (rng.random(len(kp2)) < 0.85).astype(np.uint8) if kf_kf else None
+    for ratio, ori in ((0.75, True), (0.9, False), (0.6, True)):
+        m = uvo.ORBmatcher(ratio, ori)
+        mg, ng = m.SearchByBoW(uvo.FeatureVector(g1), de1, kp1["angle"], usable1, uvo.FeatureVector(g2), de2, kp2["angle"], usable2, kf_kf=kf_kf)
+        mo, no = oracle.search_by_bow(kf_kf, g1, de1, kp1["angle"], usable1, g2, de2, kp2["angle"], usable2, ratio, ori)
+        np.testing.assert_array_equal(mg, mo)
+        assert ng == no == int((mo >= 0).sum())
+        m.close()
+    assert no > 50
+
+
+def test_search_for_triangulation(uvo, oracle, synth):
+    """SearchForTriangulation (:852-1014) with the epipolar test of :136-153."""
+    rng = np.random.default_rng(23)
+    kp1, de1, kp2, de2, sf = _two_views(uvo, synth, 4300)
+    g1, g2 = _bow_groups(rng, de1, 40), _bow_groups(rng, de2, 40)
+    has1 = (rng.random(len(kp1)) < 0.3).astype(np.uint8)
+    has2 = (rng.random(len(kp2)) < 0.3).astype(np.uint8)
+    sigma2 = (sf * sf).astype(np.float32)
+    # a fundamental matrix of a near-pure translation along x (epipolar lines ~ horizontal), slightly perturbed
+    F12 = (np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) + rng.normal(0, 2e-4, (3, 3)).astype(np.float32))
+    tot = 0
+    for ori in (False, True):
+        m = uvo.ORBmatcher(0.6, ori)
+        for scale in (1.0, 400.0):                       # 400: wide acceptance band, many candidates pass
+            s2 = (sigma2 * np.float32(scale)).astype(np.float32)
+            mg, ng = m.SearchForTriangulation(uvo.FeatureVector(g1), kp1, de1, has1, uvo.FeatureVector(g2), kp2, de2, has2, F12, s2)
+            mo, no = oracle.search_for_triangulation(g1, kp1, de1, has1, g2, kp2, de2, has2, F12, s2, ori)
+            np.testing.assert_array_equal(mg, mo)
+            assert ng == no
+            tot += no
+        m.close()
+    assert tot > 40
+
+
+def test_fuse_search_and_generic_windows(uvo, oracle, synth):
+    """Search core of Fuse (:1077-1101) and the window engine used without exclusivity."""
+    rng = np.random.default_rng(24)
+    kp1, de1, kp2, de2, sf = _two_views(uvo, synth, 4400)
+    n, M = len(kp2), 3000
+    src = rng.integers(0, n, M)
+    mp_desc = _noisy_copies(rng, de2, src, 0.04)
+    u = (kp2["x"][src] + rng.normal(0, 1.5, M)).astype(np.float32)
+    v = (kp2["y"][src] + rng.normal(0, 1.5, M)).astype(np.float32)
+    u[:20] = rng.uniform(-50, 800, 20).astype(np.float32)     # some windows partly or wholly outside the grid
+    v[:20] = rng.uniform(-50, 530, 20).astype(np.float32)
+    level = np.clip(kp2["octave"][src] + rng.integers(-1, 2, M), 0, 7).astype(np.int32)
+    valid = (rng.random(M) < 0.9).astype(np.uint8)
+    m = uvo.ORBmatcher(0.6, True)
+    for th in (3.0, 12.0):
+        bi, bd = m.FuseSearch(kp2, de2, (0, 0, 752, 480), u, v, level, valid, mp_desc, sf, th)
+        oi, od = oracle.fuse_search(kp2, de2, (0, 0, 752, 480), u, v, level, valid, mp_desc, sf, th)
+        np.testing.assert_array_equal(bi, oi)
+        np.testing.assert_array_equal(bd, od)
+    assert (oi >= 0).sum() > 500
+    m.close()
+
+
+def _random_pose(rng):
+    a = rng.normal(0, 0.15, 3)
+    th = np.linalg.norm(a)
+    k = a / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = (np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K).astype(np.float32)
+    t = rng.normal(0, 0.5, 3).astype(np.float32)
+    Ow = (-(R.T.astype(np.float64) @ t.astype(np.float64))).astype(np.float32)
+    return R, t, Ow
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_project_points(uvo, oracle, mode):
+    """uvo_project_points against the restated isInFrustum / PredictScale, SearchByProjection(F, pKF) and Fuse prologues."""
+    rng = np.random.default_rng(30 + mode)
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    m = uvo.ORBmatcher(0.8)
+    hits = 0
+    for trial in range(4):
+        R, t, Ow = _random_pose(rng)
+        bounds = (0.0, 0.0, 752.0, 480.0)
+        cam = uvo.CameraPose.make(R, t, Ow, 458.654, 457.296, 367.215, 248.375, bounds)
+        cam_o = np.concatenate([R.reshape(9), t, Ow, np.float32([458.654, 457.296, 367.215, 248.375]), np.float32([0, 752, 0, 480])]).astype(np.float32)
+        n = 20000
+        xyz = (rng.normal(0, 1, (n, 3)) * [4, 3, 4] + [0, 0, 6]).astype(np.float32)
+        nrm = rng.normal(0, 1, (n, 3))
+        nrm[: n // 2] = (xyz[: n // 2] - Ow) + rng.normal(0, 1.0, (n // 2, 3))     # half the normals roughly face the camera
+        nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+        d = np.linalg.norm(xyz - Ow, axis=1)
+        mn = (d * rng.uniform(0.3, 1.4, n)).astype(np.float32)
+        mx = (mn * rng.uniform(1.5, 6.0, n)).astype(np.float32)
+        usable = (rng.random(n) < 0.9).astype(np.uint8)
+        got = m.project_points(mode, cam, xyz, nrm, mn, mx, usable, sf, 1.2, 0.5)
+        ref = oracle.project_points(mode, cam_o, xyz, nrm, mn, mx, usable, sf, 1.2, 0.5)
+        for g, r, name in zip(got, ref, ("valid", "u", "v", "level", "view_cos")):
+            assert g.dtype == r.dtype
+            np.testing.assert_array_equal(g.view(np.uint32) if g.dtype == np.float32 else g, r.view(np.uint32) if r.dtype == np.float32 else r,
+                                          err_msg="mode %d %s" % (mode, name))
+        hits += int(ref[0].sum())
+        assert len(set(ref[3][ref[0] > 0].tolist())) >= 5          # several levels exercised
+    assert hits > 4000
+    m.close()
+
+
+def test_frustum_then_search_by_projection_chain(uvo, oracle, synth):
+    """Config-5 shape: isInFrustum on the device feeds SearchByProjection on the device; same chain through the oracle."""
+    rng = np.random.default_rng(40)
+    img = synth.make_frame(777, 752, 480)
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 7, max_width=752, max_height=480)
+    kp, de = ex(img)
+    sf = ex.mvScaleFactor.copy()
+    ex.close()
+    n, M = len(kp), 5000
+    R, t, Ow = _random_pose(rng)
+    fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375
+    # map points: back-project keypoints at random depths (+ noise), so that they land near their keypoint again
+    src = rng.integers(0, n, M)
+    z = rng.uniform(2, 12, M)
+    pc = np.stack([(kp["x"][src] - cx) / fx * z, (kp["y"][src] - cy) / fy * z, z], 1) + rng.normal(0, 0.01, (M, 3))
+    xyz = ((pc - t) @ R.astype(np.float64)).astype(np.float32)                      # Xw = R^T (Xc - t)
+    nrm = xyz - Ow
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    d = np.linalg.norm(xyz - Ow, axis=1)
+    lvl_true = kp["octave"][src]
+    mxd = (d * sf[lvl_true] * rng.uniform(0.95, 1.05, M)).astype(np.float32)        # PredictScale then lands near the keypoint's octave
+    mnd = (mxd / sf[7]).astype(np.float32)
+    mp_desc = _noisy_copies(rng, de, src, 0.06, 0.6)
+    bounds = (0, 0, 752, 480)
+    cam = uvo.CameraPose.make(R, t, Ow, fx, fy, cx, cy, bounds)
+    cam_o = np.concatenate([R.reshape(9), t, Ow, np.float32([fx, fy, cx, cy]), np.float32([0, 752, 0, 480])]).astype(np.float32)
+    m = uvo.ORBmatcher(0.8, max_query=4096, max_map_points=8192)
+    valid, u, v, level, vc = m.project_points(uvo.PROJECT_FRUSTUM, cam, xyz, nrm, mnd, mxd, None, sf, 1.2, 0.5)
+    a_g = np.full(n, -1, np.int32)
+    nm_g = m.SearchByProjection(kp, de, bounds, a_g, u, v, level, vc, valid, mp_desc, sf, 1.0)
+    ov, ou, ovv, ol, ovc = oracle.project_points(0, cam_o, xyz, nrm, mnd, mxd, None, sf, 1.2, 0.5)
+    a_o = np.full(n, -1, np.int32)
+    nm_o = oracle.search_by_projection(kp, de, bounds, a_o, ou, ovv, ol, ovc, ov, mp_desc, sf, 1.0, 0.8)
+    np.testing.assert_array_equal(a_g, a_o)
+    assert nm_g == nm_o and nm_g > 300 and ov.sum() > 3000
+    m.close()

@@ -159,3 +159,146 @@ def test_distinctive_descriptor_by_hand(oracle):
     # row of bits(50): [0,10,10,50,50] -> median 10; others: bits(40): [0,10,20,40,60] -> 20; bits(60): 20; ends: 50
     assert oracle.distinctive_descriptor(D5) == (2, 10)
     assert oracle.distinctive_descriptor(D[:1]) == (0, 0)
+
+
+# ---- rotation histogram / ComputeThreeMaxima (src/ORBmatcher.cc:1748-1789) ---------------------------------------------
+def test_compute_three_maxima_by_hand(oracle):
+    s = [0] * 30
+    assert oracle.compute_three_maxima(s) == [-1, -1, -1]
+    s[4], s[7], s[9], s[11] = 50, 20, 6, 5
+    assert oracle.compute_three_maxima(s) == [4, 7, 9]
+    s[9] = 4                                 # bin 11 (5) is now third: 5 < 0.1f * 50 is false -> kept
+    assert oracle.compute_three_maxima(s) == [4, 7, 11]
+    s[11] = 3                                # third = 4 < 0.1 * 50 -> dropped
+    assert oracle.compute_three_maxima(s) == [4, 7, -1]
+    s[7] = 4                                 # second < 0.1 * max -> second and third dropped
+    assert oracle.compute_three_maxima(s)[1:] == [-1, -1]
+    t = [0] * 30
+    t[2] = t[5] = t[8] = 10                  # ties: strict '>' keeps the first seen on top
+    assert oracle.compute_three_maxima(t) == [2, 5, 8]
+
+
+def _desc_with_distance(rng, base, d):
+    out = np.unpackbits(base).copy()
+    flip = rng.choice(256, d, replace=False)
+    out[flip] ^= 1
+    return np.packbits(out)
+
+
+def test_search_by_bow_rules_by_hand(oracle):
+    """Thresholds (<= TH_LOW for KF-Frame, < TH_LOW for KF-KF), ratio against the second best of the same node,
+    first-come exclusivity, usable flags."""
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, 32, dtype=np.uint8)
+    far = base ^ np.uint8(255)
+    d1 = np.stack([base, base, base])                                  # three queries, all the same descriptor
+    d2 = np.stack([_desc_with_distance(rng, base, 50), _desc_with_distance(rng, base, 10), far, _desc_with_distance(rng, base, 30)])
+    ang1, ang2 = np.zeros(3, np.float32), np.zeros(4, np.float32)
+    g1 = {7: [0, 1], 9: [2]}
+    g2 = {7: [1, 0], 8: [2], 9: [3]}
+    # KF-Frame, ratio 0.9: q0 -> t1 (10 < 0.9*50); q1: t1 taken, best t0 at 50 <= TH_LOW, second INT_MAX -> t0; q2 (node 9) -> t3
+    m, n = oracle.search_by_bow(False, g1, d1, ang1, [1, 1, 1], g2, d2, ang2, None, 0.9, False)
+    assert m.tolist() == [1, 0, 3] and n == 3
+    # KF-KF: same but '< TH_LOW' rejects the distance-50 match
+    m, n = oracle.search_by_bow(True, g1, d1, ang1, [1, 1, 1], g2, d2, ang2, [1, 1, 1, 1], 0.9, False)
+    assert m.tolist() == [1, -1, 3] and n == 2
+    # unusable query 0 (no map point): query 1 now gets t1; unusable target 3 in KF-KF mode
+    m, n = oracle.search_by_bow(True, g1, d1, ang1, [0, 1, 1], g2, d2, ang2, [1, 1, 1, 0], 0.9, False)
+    assert m.tolist() == [-1, 1, -1] and n == 1
+    # ratio: 10 < 0.15 * 50 fails
+    m, n = oracle.search_by_bow(False, {7: [0]}, d1[:1], ang1[:1], [1], g2, d2, ang2, None, 0.15, False)
+    assert m.tolist() == [-1] and n == 0
+
+
+def test_rotation_bins_reach_only_0_to_12(oracle):
+    """bin = round(rot / 30) with rot in [0, 360): bins 0..12 (upstream quirk); the three fullest survive."""
+    rng = np.random.default_rng(6)
+    n = 40
+    base = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    d1, d2 = base.copy(), base.copy()                                   # query i matches target i exactly
+    groups = {i: [i] for i in range(n)}
+    ang1 = np.zeros(n, np.float32)
+    ang2 = np.zeros(n, np.float32)
+    # rot = ang1 - ang2 (+360): 20 matches at rot 0 (bin 0), 10 at 90 (bin 3), 6 at 180 (bin 6), 4 at 359 (bin 12)
+    ang2[20:30], ang2[30:36], ang2[36:40] = 270, 180, 1
+    m, nm = oracle.search_by_bow(False, groups, d1, ang1, np.ones(n), groups, d2, ang2, None, 0.9, True)
+    assert nm == 36 and (m[:36] == np.arange(36)).all() and (m[36:] == -1).all()
+
+
+def test_search_for_triangulation_by_hand(oracle):
+    """Sorted by (distance, index), cut at 2 * best, first candidate passing the epipolar test wins."""
+    rng = np.random.default_rng(7)
+    base = rng.integers(0, 256, 32, dtype=np.uint8)
+    kp1 = _kps([(100, 100)], [0])
+    kp2 = _kps([(100, 140), (100, 100.5), (300, 100), (100, 99.5)], [0, 0, 0, 0])
+    d1 = base[None]
+    d2 = np.stack([_desc_with_distance(rng, base, 10), _desc_with_distance(rng, base, 15), _desc_with_distance(rng, base, 20),
+                   _desc_with_distance(rng, base, 21)])
+    # F12 such that the epipolar line of (x1, y1) in image 2 is y = y1:  l = x1' F12 = (0, 1, -y1)
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    sig = np.ones(8, np.float32)
+    g = {3: [0]}
+    g2 = {3: [0, 1, 2, 3]}
+    # best = 10 (t0, off the line by 40 px) -> DistTh 20: t1 (15, 0.5 px off: 0.25 < 3.84) is the first to pass
+    m, n = oracle.search_for_triangulation(g, kp1, d1, [0], g2, kp2, d2, [0, 0, 0, 0], F12, sig, False)
+    assert m.tolist() == [1] and n == 1
+    # t1 already has a map point: t2 (20 <= DistTh) lies on the line; t3 (21) would be past the cut
+    m, n = oracle.search_for_triangulation(g, kp1, d1, [0], g2, kp2, d2, [0, 1, 0, 0], F12, sig, False)
+    assert m.tolist() == [2]
+    m, n = oracle.search_for_triangulation(g, kp1, d1, [0], g2, kp2, d2, [0, 1, 1, 0], F12, sig, False)
+    assert m.tolist() == [-1] and n == 0                              # t3 is beyond 2 * best
+    m, n = oracle.search_for_triangulation(g, kp1, d1, [1], g2, kp2, d2, [0, 0, 0, 0], F12, sig, False)
+    assert m.tolist() == [-1]                                          # keypoint 1 already has a map point
+
+
+def test_projection_kf_and_fuse_by_hand(oracle):
+    rng = np.random.default_rng(8)
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    kp = _kps([(100, 100), (103, 100), (100, 104), (180, 100)], [1, 2, 4, 1])
+    base = rng.integers(0, 256, 32, dtype=np.uint8)
+    desc = np.stack([_desc_with_distance(rng, base, 40), _desc_with_distance(rng, base, 20), _desc_with_distance(rng, base, 5),
+                     _desc_with_distance(rng, base, 0)])
+    bounds = (0, 0, 752, 480)
+    u, v = [100.0, 100.0], [100.0, 100.0]
+    mpd = np.stack([base, base])
+    # level 2, th 3 -> radius 4.32 px, levels 1..3: kp0 (40), kp1 (20) are candidates (kp2 is level 4, kp3 far) -> kp1; the
+    # second map point then takes kp0
+    a = np.full(4, -1, np.int32)
+    n = oracle.search_by_projection_kf(kp, desc, bounds, a, u, v, [2, 2], [1, 1], mpd, [0, 0], sf, 3.0, 100, False)
+    assert n == 2 and a.tolist() == [1, 0, -1, -1]
+    a = np.full(4, -1, np.int32)
+    n = oracle.search_by_projection_kf(kp, desc, bounds, a, u, v, [2, 2], [1, 1], mpd, [0, 0], sf, 3.0, 30, False)
+    assert n == 1 and a.tolist() == [-1, 0, -1, -1]                    # ORBdist 30: the distance-40 match is refused
+    # Fuse: levels [l-1, l], TH_LOW, no exclusivity -> both map points get kp1
+    bi, bd = oracle.fuse_search(kp, desc, bounds, u, v, [2, 2], [1, 1], mpd, sf, 3.0)
+    assert bi.tolist() == [1, 1] and bd.tolist() == [20, 20]
+    bi, bd = oracle.fuse_search(kp, desc, bounds, u, v, [5, 2], [1, 0], mpd, sf, 3.0)
+    assert bi.tolist() == [2, -1] and bd.tolist() == [5, -1]          # level 5 -> levels 4..5, radius 7.46
+
+
+def _cam(R=np.eye(3), t=(0, 0, 0), Ow=(0, 0, 0), fx=500.0, fy=500.0, cx=376.0, cy=240.0, bounds=(0, 752, 0, 480)):
+    return np.concatenate([np.asarray(R, np.float32).reshape(9), np.asarray(t, np.float32), np.asarray(Ow, np.float32),
+                           np.asarray([fx, fy, cx, cy], np.float32), np.asarray(bounds, np.float32)])
+
+
+def test_projection_prologues_by_hand(oracle):
+    """isInFrustum / PredictScale, the SearchByProjection(F, pKF) prologue and the Fuse prologue on an identity pose."""
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    cam = _cam()
+    #          on axis       right of axis   behind      outside image   too far        grazing normal
+    P = [[0, 0, 10.0], [1.0, 0, 10.0], [0, 0, -5.0], [20.0, 0, 10.0], [0, 0, 100.0], [0, 0, 10.0]]
+    Pn = [[0, 0, 1.0]] * 5 + [[1.0, 0, 0.2]]
+    mn, mx = np.full(6, 5.0, np.float32), np.full(6, 20.0, np.float32)
+    valid, u, v, lvl, vc = oracle.project_points(0, cam, P, Pn, mn, mx, None, sf)
+    assert valid.tolist() == [1, 1, 0, 0, 0, 0]
+    assert (u[0], v[0], u[1]) == (376.0, 240.0, 426.0) and vc[0] == 1.0
+    # PredictScale: ratio = mfMax / dist = 2 -> ceil(log 2 / log 1.2) = ceil(3.80) = 4
+    assert lvl[0] == 4 and lvl[1] == 4
+    # mode 1 has no depth-sign, distance or normal test; level = lower_bound(dist / (0.8 * mfMin)): 10 / 4 = 2.5 -> 1.2^6 = 2.99 -> 6
+    valid, u, v, lvl, _ = oracle.project_points(1, cam, P, None, mn, mx, None, sf)
+    assert valid.tolist() == [1, 1, 1, 0, 1, 1] and lvl[0] == 6 and lvl[4] == 7 and (u[2], v[2]) == (376.0, 240.0)
+    # mode 2 (Fuse): depth, image, distance window [4, 24], dot(PO, Pn) >= 0.5 * dist
+    valid, u, v, lvl, _ = oracle.project_points(2, cam, P, Pn, mn, mx, [1, 1, 1, 1, 1, 1], sf)
+    assert valid.tolist() == [1, 1, 0, 0, 0, 0] and lvl[0] == 6
+    valid, *_ = oracle.project_points(2, cam, P, Pn, mn, mx, [0, 1, 1, 1, 1, 1], sf)
+    assert valid.tolist() == [0, 1, 0, 0, 0, 0]

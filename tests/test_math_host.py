@@ -26,6 +26,10 @@ def mh():
     L.mh_cv_round.argtypes = [ctypes.c_float]
     L.mh_sincos_mismatches.restype = ctypes.c_long
     L.mh_sincos_mismatches.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+    L.mh_logf.restype = ctypes.c_float
+    L.mh_logf.argtypes = [ctypes.c_float]
+    L.mh_logf_mismatches.restype = ctypes.c_long
+    L.mh_logf_mismatches.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
     return L
 
 
@@ -38,6 +42,16 @@ def test_sincosf_equals_libm_on_every_float_in_0_2pi(mh):
     first = ctypes.c_uint32()
     bad = mh.mh_sincos_mismatches(0, _bits(6.2832), 4, ctypes.byref(first))
     assert bad == 0, "uvo_sincosf differs from libm on %d inputs, first bit pattern 0x%08x" % (bad, first.value)
+
+
+def test_logf_equals_libm(mh):
+    """`log(ratio)` of MapPoint::PredictScale (src/MapPoint.cc:381): every float in [2^-20, 2^20] -- far beyond any ratio
+    of two scene distances -- plus the special cases (zero, subnormals, inf, nan, negatives)."""
+    first = ctypes.c_uint32()
+    bad = mh.mh_logf_mismatches(_bits(2.0 ** -20), _bits(2.0 ** 20), 4, ctypes.byref(first))
+    assert bad == 0, "uvo_logf differs from libm on %d inputs, first bit pattern 0x%08x" % (bad, first.value)
+    for lo, hi in ((0x00000000, 0x00000400), (0x007ffc00, 0x00800400), (0x7f7ffc00, 0x7f800400), (0x80000000, 0x80000400), (0xbf800000, 0xbf800400)):
+        assert mh.mh_logf_mismatches(lo, hi, 1, ctypes.byref(first)) == 0, hex(first.value)
 
 
 def test_fast_atan2_equals_oracle(mh, oracle):

@@ -29,9 +29,67 @@ ABI_SYMBOLS = [
     "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_level_dims",
     "uvo_grider_fast", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
-    "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
+    "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
+    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
     "uvo_matcher_kernel_times", "uvo_last_error", "uvo_device_info",
 ]
+
+
+class MatchRule(ctypes.Structure):
+    """uvo_match_rule (include/uvo/uvo.h)."""
+    _fields_ = [("rule", ctypes.c_int32), ("max_dist", ctypes.c_int32), ("nn_ratio", ctypes.c_float), ("exclusive", ctypes.c_int32),
+                ("check_orientation", ctypes.c_int32)]
+
+
+class FeatureVectorC(ctypes.Structure):
+    """uvo_feature_vector: a DBoW2::FeatureVector in flat form."""
+    _fields_ = [("node", ctypes.c_void_p), ("start", ctypes.c_void_p), ("feat", ctypes.c_void_p), ("n_nodes", ctypes.c_int32)]
+
+
+class Epipolar(ctypes.Structure):
+    """uvo_epipolar."""
+    _fields_ = [("f12", ctypes.c_float * 9), ("q_x", ctypes.c_void_p), ("q_y", ctypes.c_void_p), ("t_x", ctypes.c_void_p), ("t_y", ctypes.c_void_p),
+                ("sigma2", ctypes.c_void_p), ("nlevels", ctypes.c_int32)]
+
+
+class CameraPose(ctypes.Structure):
+    """uvo_camera_pose."""
+    _fields_ = [("rcw", ctypes.c_float * 9), ("tcw", ctypes.c_float * 3), ("ow", ctypes.c_float * 3), ("fx", ctypes.c_float), ("fy", ctypes.c_float),
+                ("cx", ctypes.c_float), ("cy", ctypes.c_float), ("min_x", ctypes.c_float), ("max_x", ctypes.c_float), ("min_y", ctypes.c_float),
+                ("max_y", ctypes.c_float)]
+
+    @classmethod
+    def make(cls, Rcw, tcw, Ow, fx, fy, cx, cy, bounds):
+        """bounds = (mnMinX, mnMinY, mnMaxX, mnMaxY)"""
+        c = cls()
+        c.rcw[:] = [float(x) for x in np.asarray(Rcw, np.float32).reshape(9)]
+        c.tcw[:] = [float(x) for x in np.asarray(tcw, np.float32).reshape(3)]
+        c.ow[:] = [float(x) for x in np.asarray(Ow, np.float32).reshape(3)]
+        c.fx, c.fy, c.cx, c.cy = float(fx), float(fy), float(cx), float(cy)
+        c.min_x, c.min_y, c.max_x, c.max_y = [float(b) for b in bounds]
+        return c
+
+    def as_array(self):
+        return np.frombuffer(bytes(self), np.float32).copy()
+
+
+PROJECT_FRUSTUM, PROJECT_KF_RELOC, PROJECT_FUSE = range(3)
+RULE_BEST_RATIO_SAME_LEVEL, RULE_BEST_ONLY, RULE_BEST_RATIO_LE, RULE_BEST_RATIO_LT, RULE_TRIANGULATION = range(5)
+
+
+class FeatureVector:
+    """DBoW2::FeatureVector stand-in: {node id: [feature indices]} kept as the flat arrays the C ABI takes."""
+
+    def __init__(self, groups):
+        nodes = sorted(groups)
+        self.node = np.asarray(nodes, np.uint32)
+        self.start = np.zeros(len(nodes) + 1, np.int32)
+        feats = []
+        for j, k in enumerate(nodes):
+            feats.extend(int(v) for v in groups[k])
+            self.start[j + 1] = len(feats)
+        self.feat = np.asarray(feats, np.int32)
+        self.c = FeatureVectorC(_ptr(self.node), _ptr(self.start), _ptr(self.feat) if len(feats) else None, len(nodes))
 
 
 class UvoError(RuntimeError):
@@ -85,6 +143,13 @@ def _load():
     lib.uvo_hamming_matrix.argtypes = [vp, vp, ci, vp, ci, vp]
     lib.uvo_distinctive_descriptors.argtypes = [vp, vp, vp, ci, vp, vp]
     lib.uvo_search_by_projection.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp]
+    lib.uvo_match_windows.argtypes = [vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.uvo_match_groups.argtypes = [vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.uvo_search_by_projection_kf.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, ci, ci, vp]
+    lib.uvo_search_by_bow.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, cf, ci, vp, vp]
+    lib.uvo_search_for_triangulation.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp]
+    lib.uvo_project_points.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp, vp]
+    lib.uvo_fuse.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, vp, vp]
     lib.uvo_matcher_wait_extractor.argtypes = [vp, vp]
     lib.uvo_extractor_wait_matcher.argtypes = [vp, vp]
     lib.uvo_matcher_profile.argtypes = [vp, ci]
@@ -381,6 +446,107 @@ class ORBmatcher:
         if rc:
             raise UvoError(rc, "uvo_search_by_projection")
         return nm.value
+
+
+    # ---- the other search loops (generic engine + reference-named entry points) ----
+    def match_windows(self, kp, desc, bounds, qx, qy, qr, qmin_level, qmax_level, qvalid, qdesc, rule, max_dist, *, blocked=None, qangle=None,
+                      exclusive=True, check_orientation=False):
+        """uvo_match_windows: candidates from 64x48 grid windows over kp; returns (match[nq], dist[nq], nmatches)."""
+        kp = np.ascontiguousarray(kp, KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        a = [np.ascontiguousarray(v, np.float32) for v in (qx, qy, qr)]
+        lo, hi = np.ascontiguousarray(qmin_level, np.int32), np.ascontiguousarray(qmax_level, np.int32)
+        qv, qd = np.ascontiguousarray(qvalid, np.uint8), np.ascontiguousarray(qdesc, np.uint8)
+        bl = None if blocked is None else np.ascontiguousarray(blocked, np.uint8)
+        qa = None if qangle is None else np.ascontiguousarray(qangle, np.float32)
+        nq = len(a[0])
+        match, dist, nm = np.full(nq, -1, np.int32), np.full(nq, -1, np.int32), ctypes.c_int()
+        r = MatchRule(rule, max_dist, self.mfNNratio, 1 if exclusive else 0, 1 if check_orientation else 0)
+        rc = lib.uvo_match_windows(self._h, _ptr(kp), len(kp), _ptr(desc), _ptr(bl), int(bounds[0]), int(bounds[1]), int(bounds[2]), int(bounds[3]),
+                                   nq, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(lo), _ptr(hi), _ptr(qv), _ptr(qd), _ptr(qa), ctypes.byref(r),
+                                   _ptr(match), _ptr(dist), ctypes.byref(nm))
+        if rc:
+            raise UvoError(rc, "uvo_match_windows")
+        return match, dist, nm.value
+
+    def SearchByProjectionKF(self, kp, desc, bounds, assigned, u, v, level, valid, mp_desc, kf_angle, scale_factors, th, ORBdist):
+        """SearchByProjection(FrameKTL& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1622-1746),
+        from the projected (u, v, level) of the key frame's map points.  assigned in/out; returns nmatches."""
+        kp = np.ascontiguousarray(kp, KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        uu, vv = np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32)
+        lv, va = np.ascontiguousarray(level, np.int32), np.ascontiguousarray(valid, np.uint8)
+        md, ka = np.ascontiguousarray(mp_desc, np.uint8), np.ascontiguousarray(kf_angle, np.float32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        assert assigned.dtype == np.int32 and assigned.flags.c_contiguous
+        nm = ctypes.c_int()
+        rc = lib.uvo_search_by_projection_kf(self._h, _ptr(kp), len(kp), _ptr(desc), int(bounds[0]), int(bounds[1]), int(bounds[2]), int(bounds[3]),
+                                             _ptr(assigned), len(uu), _ptr(uu), _ptr(vv), _ptr(lv), _ptr(va), _ptr(md), _ptr(ka), _ptr(sf), len(sf),
+                                             float(th), int(ORBdist), 1 if self.mbCheckOrientation else 0, ctypes.byref(nm))
+        if rc:
+            raise UvoError(rc, "uvo_search_by_projection_kf")
+        return nm.value
+
+    def SearchByBoW(self, fv1, desc1, angle1, usable1, fv2, desc2, angle2, usable2=None, kf_kf=False):
+        """SearchByBoW(KeyFrame*, FrameKTL&, ...) (:155-284) / SearchByBoW(KeyFrame*, KeyFrame*, ...) (:715-850, kf_kf=True).
+        Returns (match12[n1], nmatches)."""
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        a1, a2 = np.ascontiguousarray(angle1, np.float32), np.ascontiguousarray(angle2, np.float32)
+        u1 = np.ascontiguousarray(usable1, np.uint8)
+        u2 = None if usable2 is None else np.ascontiguousarray(usable2, np.uint8)
+        match = np.full(len(d1), -1, np.int32)
+        nm = ctypes.c_int()
+        rc = lib.uvo_search_by_bow(self._h, 1 if kf_kf else 0, ctypes.byref(fv1.c), len(d1), _ptr(d1), _ptr(a1), _ptr(u1), ctypes.byref(fv2.c), len(d2),
+                                   _ptr(d2), _ptr(a2), _ptr(u2), self.mfNNratio, 1 if self.mbCheckOrientation else 0, _ptr(match), ctypes.byref(nm))
+        if rc:
+            raise UvoError(rc, "uvo_search_by_bow")
+        return match, nm.value
+
+    def SearchForTriangulation(self, fv1, kp1, desc1, has_mp1, fv2, kp2, desc2, has_mp2, F12, sigma2):
+        """SearchForTriangulation(pKF1, pKF2, F12, ...) (:852-1014).  Returns (match12[n1], nmatches)."""
+        kp1, kp2 = np.ascontiguousarray(kp1, KEYPOINT_DTYPE), np.ascontiguousarray(kp2, KEYPOINT_DTYPE)
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        h1, h2 = np.ascontiguousarray(has_mp1, np.uint8), np.ascontiguousarray(has_mp2, np.uint8)
+        f, s2 = np.ascontiguousarray(F12, np.float32).reshape(9), np.ascontiguousarray(sigma2, np.float32)
+        match = np.full(len(kp1), -1, np.int32)
+        nm = ctypes.c_int()
+        rc = lib.uvo_search_for_triangulation(self._h, ctypes.byref(fv1.c), _ptr(kp1), len(kp1), _ptr(d1), _ptr(h1), ctypes.byref(fv2.c), _ptr(kp2),
+                                              len(kp2), _ptr(d2), _ptr(h2), _ptr(f), _ptr(s2), len(s2), 1 if self.mbCheckOrientation else 0,
+                                              _ptr(match), ctypes.byref(nm))
+        if rc:
+            raise UvoError(rc, "uvo_search_for_triangulation")
+        return match, nm.value
+
+    def project_points(self, mode, cam, xyz, normal, min_distance, max_distance, usable, scale_factors, scale_factor=1.2, viewing_cos_limit=0.5):
+        """uvo_project_points: FrameKTL::isInFrustum (PROJECT_FRUSTUM), the projection prologue of SearchByProjection(F, pKF, ...)
+        (PROJECT_KF_RELOC) or of Fuse (PROJECT_FUSE).  Returns (valid, u, v, level, view_cos)."""
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        nrm = None if normal is None else np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+        mn, mx = np.ascontiguousarray(min_distance, np.float32), np.ascontiguousarray(max_distance, np.float32)
+        us = None if usable is None else np.ascontiguousarray(usable, np.uint8)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        n = len(xyz)
+        valid, u, v = np.zeros(n, np.uint8), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        level, vc = np.zeros(n, np.int32), np.zeros(n, np.float32)
+        rc = lib.uvo_project_points(self._h, int(mode), ctypes.byref(cam), n, _ptr(xyz), _ptr(nrm), _ptr(mn), _ptr(mx), _ptr(us), _ptr(sf), len(sf),
+                                    float(scale_factor), float(viewing_cos_limit), _ptr(valid), _ptr(u), _ptr(v), _ptr(level), _ptr(vc))
+        if rc:
+            raise UvoError(rc, "uvo_project_points")
+        return valid, u, v, level, vc
+
+    def FuseSearch(self, kp, desc, bounds, u, v, level, valid, mp_desc, scale_factors, th=3.0):
+        """Search core of Fuse (:1077-1101): (best_idx[nmp], best_dist[nmp]), -1 where nothing within TH_LOW."""
+        kp = np.ascontiguousarray(kp, KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        uu, vv = np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32)
+        lv, va = np.ascontiguousarray(level, np.int32), np.ascontiguousarray(valid, np.uint8)
+        md, sf = np.ascontiguousarray(mp_desc, np.uint8), np.ascontiguousarray(scale_factors, np.float32)
+        bi, bd = np.full(len(uu), -1, np.int32), np.full(len(uu), -1, np.int32)
+        rc = lib.uvo_fuse(self._h, _ptr(kp), len(kp), _ptr(desc), int(bounds[0]), int(bounds[1]), int(bounds[2]), int(bounds[3]), len(uu), _ptr(uu),
+                          _ptr(vv), _ptr(lv), _ptr(va), _ptr(md), _ptr(sf), len(sf), float(th), _ptr(bi), _ptr(bd))
+        if rc:
+            raise UvoError(rc, "uvo_fuse")
+        return bi, bd
 
 
 def DescriptorDistance(a, b):

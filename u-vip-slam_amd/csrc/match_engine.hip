@@ -1,0 +1,501 @@
+// Generic search engine behind the ORBmatcher Search* / Fuse entry points (src/ORBmatcher.cc).
+//
+// Every one of those loops has the same shape: queries are visited in a fixed order; each query owns a candidate list
+// (keypoints in a grid window, or the keypoints sharing its vocabulary node); the 256-bit Hamming distance to every
+// candidate is taken; an acceptance rule picks at most one target; and (except in Fuse) a target taken by an earlier query
+// is skipped by later ones.  Here:
+//   k_win_cand<FILL> : candidate lists from grid windows -- FrameKTL::GetFeaturesInArea (src/FrameKTL.cc:359-424) /
+//                      KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:952-992), in their (ix, iy, insertion) order
+//   k_group_dist     : distances (and the epipolar predicate of SearchForTriangulation) for caller-given candidate lists
+//   k_match_resolve  : the order-dependent loop solved exactly as a fixed point -- owner[t] = lowest-index query whose
+//                      accepted choice is target t; query i may not use t when owner[t] < i.  Query 0 is final after one
+//                      sweep, query i after at most i+1, so the iteration ends in the sequential result.
+//   k_rot_filter     : rotation-consistency histogram + ComputeThreeMaxima (src/ORBmatcher.cc:1748-1789)
+// packed candidate: target index (16 bits) | distance (9 bits) << 16 | octave (6 bits) << 25 | predicate << 31
+#include "common.hpp"
+#include "uvo_math.hpp"
+
+namespace uvo {
+
+constexpr int GR_COLS = 64, GR_ROWS = 48;  // include/FrameKTL.h:45-46
+constexpr int HISTO_LENGTH = 30;           // src/ORBmatcher.cc:42
+
+struct WinFrame {
+  const uvo_keypoint* kp;
+  const uint8_t* desc;
+  int n;
+  int min_x, min_y;
+  float inv_w, inv_h;
+};
+struct WinQuery {
+  const float *x, *y, *r;
+  const int32_t *min_level, *max_level;
+  const uint8_t* valid;
+  const uint8_t* desc;
+  int n;
+};
+
+__device__ __forceinline__ int ham256(const uint8_t* a, const uint8_t* b) {
+  const uint4* A = reinterpret_cast<const uint4*>(a);
+  const uint4* B = reinterpret_cast<const uint4*>(b);
+  const uint4 a0 = A[0], a1 = A[1], b0 = B[0], b1 = B[1];
+  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) +
+         __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// FILL = false: count candidates per query; FILL = true: write packed candidates at cand_start[i]
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_win_cand(WinFrame F, WinQuery Q, const int32_t* __restrict__ cell_start,
+                                                  const int32_t* __restrict__ cell_items, int32_t* __restrict__ cand_cnt,
+                                                  const int32_t* __restrict__ cand_start, uint32_t* __restrict__ cand) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Q.n) return;
+  int n = 0;
+  if (Q.valid[i]) {
+    const float x = Q.x[i], y = Q.y[i], r = Q.r[i];
+    const int minLevel = Q.min_level[i], maxLevel = Q.max_level[i];
+    // level filter of FrameKTL::GetFeaturesInArea :384-390,:403-413
+    const bool bCheckLevels = !(minLevel == -1 && maxLevel == -1);
+    const bool bSameLevel = bCheckLevels && minLevel == maxLevel;
+    int x0 = (int)floorf((x - (float)F.min_x - r) * F.inv_w);
+    x0 = max(0, x0);
+    int x1 = (int)ceilf((x - (float)F.min_x + r) * F.inv_w);
+    x1 = min(GR_COLS - 1, x1);
+    int y0 = (int)floorf((y - (float)F.min_y - r) * F.inv_h);
+    y0 = max(0, y0);
+    int y1 = (int)ceilf((y - (float)F.min_y + r) * F.inv_h);
+    y1 = min(GR_ROWS - 1, y1);
+    if (x0 < GR_COLS && x1 >= 0 && y0 < GR_ROWS && y1 >= 0) {
+      const int o = FILL ? cand_start[i] : 0;
+      for (int ix = x0; ix <= x1; ++ix)
+        for (int iy = y0; iy <= y1; ++iy) {
+          const int c = ix * GR_ROWS + iy;
+          for (int k = cell_start[c]; k < cell_start[c + 1]; ++k) {
+            const int idx = cell_items[k];
+            const uvo_keypoint kp = F.kp[idx];
+            if (bCheckLevels && !bSameLevel) {
+              if (kp.octave < minLevel || kp.octave > maxLevel) continue;
+            } else if (bSameLevel) {
+              if (kp.octave != minLevel) continue;
+            }
+            if (fabsf(kp.x - x) > r || fabsf(kp.y - y) > r) continue;
+            if (FILL) {
+              const int d = ham256(Q.desc + (int64_t)i * 32, F.desc + (int64_t)idx * 32);
+              cand[o + n] = (uint32_t)idx | ((uint32_t)d << 16) | ((uint32_t)(kp.octave & 63) << 25) | 0x80000000u;
+            }
+            ++n;
+          }
+        }
+    }
+  }
+  if (!FILL) cand_cnt[i] = n;
+}
+
+// Epipolar predicate of ORBmatcher::CheckDistEpipolarLine (src/ORBmatcher.cc:136-153); f12 row-major 3x3, fp32 in the
+// reference's evaluation order, final comparison in double (3.84 is a double literal).
+struct Epipolar {
+  float f[9];
+  const float* q_x;
+  const float* q_y;
+  const float* t_x;
+  const float* t_y;
+  const float* sigma2;  // per octave of the target key frame
+  int enabled;
+};
+
+// one thread per candidate entry; query of an entry found by binary search in cand_start
+__global__ __launch_bounds__(256) void k_group_dist(int nq, const int32_t* __restrict__ cand_start, const int32_t* __restrict__ cand_idx,
+                                                    const uint8_t* __restrict__ qdesc, const uint8_t* __restrict__ tdesc,
+                                                    const int32_t* __restrict__ tlevel, Epipolar E, uint32_t* __restrict__ cand) {
+  const int total = cand_start[nq];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  int lo = 0, hi = nq - 1;  // last query with cand_start[q] <= e
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (cand_start[mid] <= e)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  const int q = lo, t = cand_idx[e];
+  const int d = ham256(qdesc + (int64_t)q * 32, tdesc + (int64_t)t * 32);
+  const int oct = tlevel ? tlevel[t] : 0;
+  uint32_t ok = 1;
+  if (E.enabled) {
+    const float x1 = E.q_x[q], y1 = E.q_y[q], x2 = E.t_x[t], y2 = E.t_y[t];
+    const float a = x1 * E.f[0] + y1 * E.f[3] + E.f[6];
+    const float b = x1 * E.f[1] + y1 * E.f[4] + E.f[7];
+    const float c = x1 * E.f[2] + y1 * E.f[5] + E.f[8];
+    const float num = a * x2 + b * y2 + c;
+    const float den = a * a + b * b;
+    if (den == 0) {
+      ok = 0;
+    } else {
+      const float dsqr = num * num / den;
+      ok = (double)dsqr < 3.84 * (double)E.sigma2[oct] ? 1u : 0u;
+    }
+  }
+  cand[e] = (uint32_t)t | ((uint32_t)d << 16) | ((uint32_t)(oct & 63) << 25) | (ok << 31);
+}
+
+struct MatchRule {
+  int rule, max_dist;
+  float nn_ratio;
+  int exclusive;
+};
+
+// choice of query i given the current ownership; returns target index or -1, best distance through *dist
+__device__ __forceinline__ int rule_choice(const MatchRule& R, int i, const int32_t* cand_start, const uint32_t* cand, const int32_t* owner,
+                                           int* dist) {
+  const int b = cand_start[i], e = cand_start[i + 1];
+  *dist = -1;
+  if (R.rule == UVO_RULE_TRIANGULATION) {
+    // :893-935 -- free candidates with d <= TH_LOW, sorted by (d, idx2); walk while d <= round(2*best); first that passes
+    // the epipolar test
+    int best = 0x7fffffff;
+    for (int c = b; c < e; ++c) {
+      const uint32_t v = cand[c];
+      if (R.exclusive && owner[v & 0xffffu] < i) continue;
+      const int d = (int)((v >> 16) & 0x1ffu);
+      if (d > R.max_dist) continue;
+      best = d < best ? d : best;
+    }
+    if (best == 0x7fffffff) return -1;
+    const int dist_th = 2 * best;
+    uint32_t pick = 0xffffffffu;  // (d << 16 | idx): the sort order of vector<pair<int,size_t>>
+    for (int c = b; c < e; ++c) {
+      const uint32_t v = cand[c];
+      if (!(v >> 31)) continue;
+      if (R.exclusive && owner[v & 0xffffu] < i) continue;
+      const int d = (int)((v >> 16) & 0x1ffu);
+      if (d > R.max_dist || d > dist_th) continue;
+      const uint32_t key = ((uint32_t)d << 16) | (v & 0xffffu);
+      pick = key < pick ? key : pick;
+    }
+    if (pick == 0xffffffffu) return -1;
+    *dist = (int)(pick >> 16);
+    return (int)(pick & 0xffffu);
+  }
+  const int none = R.rule == UVO_RULE_BEST_RATIO_SAME_LEVEL ? 256 : 0x7fffffff;  // :77-81 vs INT_MAX elsewhere
+  int bestDist = none, bestLevel = -1, bestDist2 = none, bestLevel2 = -1, bestIdx = -1;
+  for (int c = b; c < e; ++c) {
+    const uint32_t v = cand[c];
+    const int idx = (int)(v & 0xffffu);
+    if (R.exclusive && owner[idx] < i) continue;  // taken before this query's turn (or blocked from the start)
+    const int d = (int)((v >> 16) & 0x1ffu), oct = (int)((v >> 25) & 63u);
+    if (d < bestDist) {
+      bestDist2 = bestDist;
+      bestDist = d;
+      bestLevel2 = bestLevel;
+      bestLevel = oct;
+      bestIdx = idx;
+    } else if (d < bestDist2) {
+      bestLevel2 = oct;
+      bestDist2 = d;
+    }
+  }
+  bool ok = false;
+  switch (R.rule) {
+    case UVO_RULE_BEST_RATIO_SAME_LEVEL:  // :114-123
+      ok = bestDist <= R.max_dist && !(bestLevel == bestLevel2 && (float)bestDist > R.nn_ratio * (float)bestDist2);
+      break;
+    case UVO_RULE_BEST_ONLY:  // :1701, :1101
+      ok = bestDist <= R.max_dist;
+      break;
+    case UVO_RULE_BEST_RATIO_LE:  // :216-218
+      ok = bestDist <= R.max_dist && (float)bestDist < R.nn_ratio * (float)bestDist2;
+      break;
+    case UVO_RULE_BEST_RATIO_LT:  // :786-788
+      ok = bestDist < R.max_dist && (float)bestDist < R.nn_ratio * (float)bestDist2;
+      break;
+    default:
+      break;
+  }
+  if (!ok || bestIdx < 0) return -1;
+  *dist = bestDist;
+  return bestIdx;
+}
+
+// single workgroup.  blocked[t] != 0: target unavailable from the start.  match[i] = target or -1, mdist[i] = its distance.
+__global__ __launch_bounds__(1024) void k_match_resolve(int nq, int nt, const int32_t* __restrict__ cand_start, const uint32_t* __restrict__ cand,
+                                                        const uint8_t* __restrict__ blocked, MatchRule R, int32_t* __restrict__ owner,
+                                                        int32_t* __restrict__ owner_next, int32_t* __restrict__ match,
+                                                        int32_t* __restrict__ mdist, int32_t* __restrict__ n_matches) {
+  __shared__ int s_changed, s_count;
+  const int INF = 0x7fffffff;
+  for (int k = threadIdx.x; k < nt; k += blockDim.x) owner[k] = (blocked && blocked[k]) ? -1 : INF;
+  for (int i = threadIdx.x; i < nq; i += blockDim.x) match[i] = -2;
+  __syncthreads();
+  for (int iter = 0; iter <= nq; ++iter) {
+    if (threadIdx.x == 0) s_changed = 0;
+    for (int k = threadIdx.x; k < nt; k += blockDim.x) owner_next[k] = owner[k] < 0 ? -1 : INF;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+      int d;
+      const int ch = rule_choice(R, i, cand_start, cand, owner, &d);
+      if (ch != match[i]) {
+        match[i] = ch;
+        s_changed = 1;
+      }
+      mdist[i] = d;
+      if (ch >= 0 && R.exclusive) atomicMin(&owner_next[ch], i);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nt; k += blockDim.x) owner[k] = owner_next[k];
+    const int changed = s_changed;
+    __syncthreads();
+    if (!changed || !R.exclusive) break;
+  }
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  int c = 0;
+  for (int i = threadIdx.x; i < nq; i += blockDim.x) c += match[i] >= 0;
+  if (c) atomicAdd(&s_count, c);
+  __syncthreads();
+  if (threadIdx.x == 0) *n_matches = s_count;
+}
+
+// Rotation consistency: rot = angle(query) - angle(target), +360 if negative, bin = round(rot / 30) (bin 30 -> 0); keep the
+// three most populated bins (ComputeThreeMaxima), drop the matches of every other bin.  Single workgroup.
+__global__ __launch_bounds__(1024) void k_rot_filter(int nq, const float* __restrict__ qangle, const float* __restrict__ tangle,
+                                                     int32_t* __restrict__ match, int32_t* __restrict__ mdist, int32_t* __restrict__ n_matches) {
+  __shared__ int s_hist[HISTO_LENGTH];
+  __shared__ int s_keep[3];
+  __shared__ int s_removed;
+  if (threadIdx.x < HISTO_LENGTH) s_hist[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_removed = 0;
+  __syncthreads();
+  const float factor = 1.0f / HISTO_LENGTH;
+  auto bin_of = [&](int i) -> int {
+    float rot = qangle[i] - tangle[match[i]];
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+  };
+  for (int i = threadIdx.x; i < nq; i += blockDim.x)
+    if (match[i] >= 0) atomicAdd(&s_hist[bin_of(i)], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      const int s = s_hist[i];
+      if (s > max1) {
+        max3 = max2;
+        max2 = max1;
+        max1 = s;
+        ind3 = ind2;
+        ind2 = ind1;
+        ind1 = i;
+      } else if (s > max2) {
+        max3 = max2;
+        max2 = s;
+        ind3 = ind2;
+        ind2 = i;
+      } else if (s > max3) {
+        max3 = s;
+        ind3 = i;
+      }
+    }
+    if (max2 < 0.1f * (float)max1) {
+      ind2 = -1;
+      ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+      ind3 = -1;
+    }
+    s_keep[0] = ind1, s_keep[1] = ind2, s_keep[2] = ind3;
+  }
+  __syncthreads();
+  int removed = 0;
+  for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+    if (match[i] < 0) continue;
+    const int b = bin_of(i);
+    if (b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) {
+      match[i] = -1;
+      mdist[i] = -1;
+      ++removed;
+    }
+  }
+  if (removed) atomicAdd(&s_removed, removed);
+  __syncthreads();
+  if (threadIdx.x == 0) *n_matches -= s_removed;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_counts(const int32_t* __restrict__ in, int32_t* __restrict__ out, int n) {
+  // single-workgroup exclusive scan, out[n] = total
+  __shared__ int s_part[1024];
+  const int per = (n + 1023) / 1024;
+  const int b = threadIdx.x * per, e = min(b + per, n);
+  int s = 0;
+  for (int i = b; i < e; ++i) s += in[i];
+  s_part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
+    __syncthreads();
+    s_part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = threadIdx.x ? s_part[threadIdx.x - 1] : 0;
+  for (int i = b; i < e; ++i) {
+    const int v = in[i];
+    out[i] = run;
+    run += v;
+  }
+  if (threadIdx.x == 1023) out[n] = s_part[1023];
+}
+
+// ---- projection prologues (uvo_project_points) ------------------------------------------------------------------------
+struct ProjCam {
+  float r[9], t[3], ow[3];
+  float fx, fy, cx, cy, min_x, max_x, min_y, max_y;
+};
+// cv::Mat 3x3 * 3x1 + 3x1 in fp32: row sum in float, `+ t` through double (cv::gemm small-matrix path, alpha = beta = 1.0)
+__device__ __forceinline__ float row_affine(const float* r, const float* p, float t) {
+  const float t0 = r[0] * p[0] + r[1] * p[1] + r[2] * p[2];
+  return (float)((double)t0 * 1.0 + (double)t * 1.0);
+}
+__device__ __forceinline__ int lower_bound_level(const float* sf, int n, float ratio) {  // std::lower_bound index
+  int i = 0;
+  while (i < n && sf[i] < ratio) ++i;
+  return i;
+}
+
+__global__ __launch_bounds__(256) void k_project(int mode, ProjCam C, int n, const float* __restrict__ xyz, const float* __restrict__ normal,
+                                                 const float* __restrict__ min_d, const float* __restrict__ max_d,
+                                                 const uint8_t* __restrict__ usable, const float* __restrict__ sf, int nlevels, float log_sf,
+                                                 float cos_limit, uint8_t* __restrict__ valid, float* __restrict__ out_u,
+                                                 float* __restrict__ out_v, int32_t* __restrict__ out_level, float* __restrict__ out_cos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t ok = 0;
+  float u = 0.f, v = 0.f, vc = 0.f;
+  int lvl = 0;
+  do {
+    if (usable && !usable[i]) break;
+    const float P[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    const float X = row_affine(C.r, P, C.t[0]), Y = row_affine(C.r + 3, P, C.t[1]), Z = row_affine(C.r + 6, P, C.t[2]);
+    float ow[3] = {C.ow[0], C.ow[1], C.ow[2]};
+    if (mode == UVO_PROJECT_KF_RELOC) {
+      // Ow = -Rcw.t()*tcw (src/ORBmatcher.cc:1628): general gemm path, double accumulation, alpha = -1
+      for (int c = 0; c < 3; ++c) {
+        double s = 0.0;
+        for (int k = 0; k < 3; ++k) s += (double)C.r[3 * k + c] * (double)C.t[k];
+        ow[c] = (float)(s * -1.0);
+      }
+    }
+    if (mode == UVO_PROJECT_FUSE) {
+      if (Z < 0.0f) break;                 // :1040
+      const float invz = 1 / Z;            // :1043
+      const float x = X * invz, y = Y * invz;
+      u = C.fx * x + C.cx, v = C.fy * y + C.cy;
+      if (!(u >= C.min_x && u < C.max_x && v >= C.min_y && v < C.max_y)) break;  // KeyFrame::IsInImage
+    } else {
+      if (mode == UVO_PROJECT_FRUSTUM && Z < 0.0) break;  // src/FrameKTL.cc:313
+      const float invz = (float)(1.0 / (double)Z);        // :317 / src/ORBmatcher.cc:1652
+      u = C.fx * X * invz + C.cx, v = C.fy * Y * invz + C.cy;
+      if (u < C.min_x || u > C.max_x) break;
+      if (v < C.min_y || v > C.max_y) break;
+    }
+    const float maxDistance = 1.2f * max_d[i], minDistance = 0.8f * min_d[i];  // src/MapPoint.cc:344-354
+    const float PO[3] = {P[0] - ow[0], P[1] - ow[1], P[2] - ow[2]};
+    double s2 = 0.0;
+    for (int k = 0; k < 3; ++k) s2 += (double)PO[k] * (double)PO[k];  // cv::norm: double accumulator
+    const float dist = (float)sqrt(s2);
+    if (mode != UVO_PROJECT_KF_RELOC && (dist < minDistance || dist > maxDistance)) break;
+    if (mode != UVO_PROJECT_KF_RELOC) {
+      double dot = 0.0;
+      for (int k = 0; k < 3; ++k) dot += (double)PO[k] * (double)normal[3 * i + k];  // cv::Mat::dot: double accumulator
+      if (mode == UVO_PROJECT_FUSE) {
+        if (dot < 0.5 * (double)dist) break;  // :1066
+      } else {
+        vc = (float)(dot / (double)dist);  // src/FrameKTL.cc:338
+        if (vc < cos_limit) break;
+      }
+    }
+    if (mode == UVO_PROJECT_FRUSTUM) {
+      const float ratio = max_d[i] / dist;  // MapPoint::PredictScale src/MapPoint.cc:378
+      int nScale = (int)ceilf(uvo_logf(ratio) / log_sf);
+      if (nScale < 0)
+        nScale = 0;
+      else if (nScale >= nlevels)
+        nScale = nlevels - 1;
+      lvl = nScale;
+    } else {
+      const float ratio = dist / minDistance;  // src/ORBmatcher.cc:1664 / :1070
+      lvl = min(lower_bound_level(sf, nlevels, ratio), nlevels - 1);
+    }
+    ok = 1;
+  } while (false);
+  valid[i] = ok;
+  out_u[i] = ok ? u : 0.f;
+  out_v[i] = ok ? v : 0.f;
+  out_level[i] = ok ? lvl : 0;
+  if (out_cos) out_cos[i] = ok ? vc : 0.f;
+}
+
+void launch_project(hipStream_t s, int mode, const uvo_camera_pose& cam, int n, const float* d_xyz, const float* d_normal, const float* d_min,
+                    const float* d_max, const uint8_t* d_usable, const float* d_sf, int nlevels, float log_sf, float cos_limit, uint8_t* d_valid,
+                    float* d_u, float* d_v, int32_t* d_level, float* d_cos) {
+  ProjCam C;
+  for (int i = 0; i < 9; ++i) C.r[i] = cam.rcw[i];
+  for (int i = 0; i < 3; ++i) C.t[i] = cam.tcw[i], C.ow[i] = cam.ow[i];
+  C.fx = cam.fx, C.fy = cam.fy, C.cx = cam.cx, C.cy = cam.cy;
+  C.min_x = cam.min_x, C.max_x = cam.max_x, C.min_y = cam.min_y, C.max_y = cam.max_y;
+  hipLaunchKernelGGL(k_project, dim3((n + 255) / 256), dim3(256), 0, s, mode, C, n, d_xyz, d_normal, d_min, d_max, d_usable, d_sf, nlevels, log_sf,
+                     cos_limit, d_valid, d_u, d_v, d_level, d_cos);
+}
+
+// grid build shared with search.hip
+void launch_grid_build(hipStream_t s, const uvo_keypoint* d_kp, const uint8_t* d_desc, int n, int min_x, int min_y, int max_x, int max_y,
+                       int32_t* d_cell_start, int32_t* d_cell_items, int32_t* d_cell_of_kp);
+
+void launch_win_count(hipStream_t s, const uvo_keypoint* d_kp, const uint8_t* d_desc, int n, int min_x, int min_y, int max_x, int max_y, int nq,
+                      const float* d_qx, const float* d_qy, const float* d_qr, const int32_t* d_qmin, const int32_t* d_qmax,
+                      const uint8_t* d_qvalid, const uint8_t* d_qdesc, int32_t* d_cell_start, int32_t* d_cell_items, int32_t* d_cell_of_kp,
+                      int32_t* d_cand_cnt, int32_t* d_cand_start) {
+  launch_grid_build(s, d_kp, d_desc, n, min_x, min_y, max_x, max_y, d_cell_start, d_cell_items, d_cell_of_kp);
+  WinFrame F{d_kp, d_desc, n, min_x, min_y, (float)GR_COLS / (float)(max_x - min_x), (float)GR_ROWS / (float)(max_y - min_y)};
+  WinQuery Q{d_qx, d_qy, d_qr, d_qmin, d_qmax, d_qvalid, d_qdesc, nq};
+  hipLaunchKernelGGL(k_win_cand<false>, dim3((nq + 255) / 256), dim3(256), 0, s, F, Q, d_cell_start, d_cell_items, d_cand_cnt,
+                     (const int32_t*)nullptr, (uint32_t*)nullptr);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, d_cand_cnt, d_cand_start, nq);
+}
+
+void launch_win_fill(hipStream_t s, const uvo_keypoint* d_kp, const uint8_t* d_desc, int n, int min_x, int min_y, int max_x, int max_y, int nq,
+                     const float* d_qx, const float* d_qy, const float* d_qr, const int32_t* d_qmin, const int32_t* d_qmax,
+                     const uint8_t* d_qvalid, const uint8_t* d_qdesc, const int32_t* d_cell_start, const int32_t* d_cell_items,
+                     const int32_t* d_cand_start, uint32_t* d_cand) {
+  WinFrame F{d_kp, d_desc, n, min_x, min_y, (float)GR_COLS / (float)(max_x - min_x), (float)GR_ROWS / (float)(max_y - min_y)};
+  WinQuery Q{d_qx, d_qy, d_qr, d_qmin, d_qmax, d_qvalid, d_qdesc, nq};
+  hipLaunchKernelGGL(k_win_cand<true>, dim3((nq + 255) / 256), dim3(256), 0, s, F, Q, d_cell_start, d_cell_items, (int32_t*)nullptr,
+                     d_cand_start, d_cand);
+}
+
+void launch_group_dist(hipStream_t s, int nq, int total, const int32_t* d_cand_start, const int32_t* d_cand_idx, const uint8_t* d_qdesc,
+                       const uint8_t* d_tdesc, const int32_t* d_tlevel, const float* f12, const float* d_qx, const float* d_qy,
+                       const float* d_tx, const float* d_ty, const float* d_sigma2, uint32_t* d_cand) {
+  Epipolar E;
+  E.enabled = f12 ? 1 : 0;
+  for (int i = 0; i < 9; ++i) E.f[i] = f12 ? f12[i] : 0.f;
+  E.q_x = d_qx, E.q_y = d_qy, E.t_x = d_tx, E.t_y = d_ty, E.sigma2 = d_sigma2;
+  if (total > 0)
+    hipLaunchKernelGGL(k_group_dist, dim3((total + 255) / 256), dim3(256), 0, s, nq, d_cand_start, d_cand_idx, d_qdesc, d_tdesc, d_tlevel, E,
+                       d_cand);
+}
+
+void launch_match_resolve(hipStream_t s, int nq, int nt, const int32_t* d_cand_start, const uint32_t* d_cand, const uint8_t* d_blocked, int rule,
+                          int max_dist, float nn_ratio, int exclusive, int32_t* d_owner, int32_t* d_owner_next, int32_t* d_match,
+                          int32_t* d_mdist, int32_t* d_n_matches) {
+  MatchRule R{rule, max_dist, nn_ratio, exclusive};
+  hipLaunchKernelGGL(k_match_resolve, dim3(1), dim3(1024), 0, s, nq, nt, d_cand_start, d_cand, d_blocked, R, d_owner, d_owner_next, d_match,
+                     d_mdist, d_n_matches);
+}
+
+void launch_rot_filter(hipStream_t s, int nq, const float* d_qangle, const float* d_tangle, int32_t* d_match, int32_t* d_mdist,
+                       int32_t* d_n_matches) {
+  hipLaunchKernelGGL(k_rot_filter, dim3(1), dim3(1024), 0, s, nq, d_qangle, d_tangle, d_match, d_mdist, d_n_matches);
+}
+
+}  // namespace uvo

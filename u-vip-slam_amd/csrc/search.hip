@@ -219,6 +219,12 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve(int nkp, int nmp, const in
   if (threadIdx.x == 0) *n_matches = s_count;
 }
 
+void launch_grid_build(hipStream_t s, const uvo_keypoint* d_kp, const uint8_t* d_desc, int n, int min_x, int min_y, int max_x, int max_y,
+                       int32_t* d_cell_start, int32_t* d_cell_items, int32_t* d_cell_of_kp) {
+  SbpFrame F{d_kp, d_desc, n, min_x, min_y, (float)GR_COLS / (float)(max_x - min_x), (float)GR_ROWS / (float)(max_y - min_y)};
+  hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, s, F, d_cell_start, d_cell_items, d_cell_of_kp);
+}
+
 void launch_sbp(hipStream_t s, const uvo_keypoint* d_kp, int n, const uint8_t* d_desc, int min_x, int min_y, int max_x, int max_y,
                 int32_t* d_assigned, int nmp, const float* d_px, const float* d_py, const int32_t* d_level, const float* d_vc,
                 const uint8_t* d_inview, const uint8_t* d_mpdesc, const float* d_scale, float th, float nnratio, int32_t* d_cell_start,
