@@ -9,13 +9,23 @@
  * mbTrackInView, isBad(), mnTrackScaleLevel, mTrackViewCos, mTrackProjX/Y, GetDescriptor() on the map point),
  * marshals them into the ABI's SoA arrays, and writes the winners back into F.mvpMapPoints -- the greedy,
  * order-dependent assignment is reproduced exactly by the library.  All map mutation stays on the host.
- * The other Search* / Fuse members keep running the reference's own code; DESIGN.md lists them as next.
+ * The other search loops follow the same pattern (read the members the reference reads, marshal, call, write back):
+ *   SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)   src/ORBmatcher.cc:1622-1746
+ *   SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches)                    :155-284
+ *   SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12)                       :715-850
+ *   SearchForTriangulation(pKF1, pKF2, F12, keys1, keys2, pairs)         :852-1014
+ *   Fuse(KeyFrame*, vpMapPoints, th)                                     :1016-1134 (search on the GPU, map mutation here)
+ * Members that stay on the reference's own code: SearchByProjection(KeyFrame*, Scw, ...), Fuse(KeyFrame*, Scw, ...),
+ * SearchBySim3 -- their search cores are uvo_match_windows() calls (INTEGRATION.md shows the mapping).
  */
 #ifndef UVO_COMPAT_ORBMATCHER_H_
 #define UVO_COMPAT_ORBMATCHER_H_
 
 #include <cstring>
+#include <map>
+#include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../uvo.h"
@@ -94,6 +104,232 @@ class UVO_COMPAT_MATCHER_NAME {
     return nmatches;
   }
 
+  /* int ORBmatcher::SearchByProjection(FrameKTL &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, float th, int ORBdist) */
+  template <class Frame, class KeyFrameT, class MapPointT>
+  int SearchByProjection(Frame& CurrentFrame, KeyFrameT* pKF, const std::set<MapPointT*>& sAlreadyFound, const float th, const int ORBdist) {
+    const std::vector<MapPointT*> vpMPs = pKF->GetMapPointMatches();
+    const int n = (int)CurrentFrame.mvKeysUn.size(), nmp = (int)vpMPs.size();
+    if (n == 0 || nmp == 0) return 0;
+    if (ensure(n, nmp) != UVO_OK) return 0;
+    uvo_camera_pose cam;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) cam.rcw[3 * r + c] = CurrentFrame.mTcw.template at<float>(r, c);  // :1626-1627
+      cam.tcw[r] = CurrentFrame.mTcw.template at<float>(r, 3);
+      cam.ow[r] = 0.f;  // derived by the library as -Rcw^T tcw (:1628)
+    }
+    cam.fx = CurrentFrame.fx, cam.fy = CurrentFrame.fy, cam.cx = CurrentFrame.cx, cam.cy = CurrentFrame.cy;
+    cam.min_x = CurrentFrame.mnMinX, cam.max_x = CurrentFrame.mnMaxX, cam.min_y = CurrentFrame.mnMinY, cam.max_y = CurrentFrame.mnMaxY;
+    std::vector<float> xyz((size_t)nmp * 3, 0.f), mind(nmp, 1.f), kfang(nmp, 0.f), u(nmp), v(nmp);
+    std::vector<uint8_t> usable(nmp, 0), valid(nmp), mdesc((size_t)nmp * 32), fdesc((size_t)n * 32);
+    std::vector<int32_t> level(nmp), assigned(n);
+    for (int i = 0; i < nmp; ++i) {
+      MapPointT* pMP = vpMPs[i];
+      if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;  // :1642-1644
+      usable[i] = 1;
+      auto x3Dw = pMP->GetWorldPos();
+      for (int k = 0; k < 3; ++k) xyz[(size_t)i * 3 + k] = x3Dw.template at<float>(k);
+      mind[i] = pMP->GetMinDistanceInvariance();
+      auto d = pMP->GetDescriptor();
+      std::memcpy(&mdesc[(size_t)i * 32], d.ptr(0), 32);
+      kfang[i] = pKF->GetKeyPointUn(i).angle;
+    }
+    const int nlev = (int)CurrentFrame.mvScaleFactors.size();
+    if (uvo_project_points(m_, UVO_PROJECT_KF_RELOC, &cam, nmp, xyz.data(), nullptr, mind.data(), nullptr, nullptr, usable.data(),
+                           CurrentFrame.mvScaleFactors.data(), nlev, 0.f, 0.f, valid.data(), u.data(), v.data(),
+                           level.data(), nullptr) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    for (int k = 0; k < n; ++k) {
+      std::memcpy(&fdesc[(size_t)k * 32], CurrentFrame.mDescriptors.ptr(k), 32);
+      assigned[k] = CurrentFrame.mvpMapPoints[k] ? 0x7fffffff : -1;  // :1690
+    }
+    int nmatches = 0;
+    if (uvo_search_by_projection_kf(m_, reinterpret_cast<const uvo_keypoint*>(CurrentFrame.mvKeysUn.data()), n, fdesc.data(), (int)CurrentFrame.mnMinX,
+                                    (int)CurrentFrame.mnMinY, (int)CurrentFrame.mnMaxX, (int)CurrentFrame.mnMaxY, assigned.data(), nmp, u.data(),
+                                    v.data(), level.data(), valid.data(), mdesc.data(), kfang.data(), CurrentFrame.mvScaleFactors.data(), nlev, th,
+                                    ORBdist, mbCheckOrientation ? 1 : 0, &nmatches) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    for (int k = 0; k < n; ++k)
+      if (assigned[k] >= 0 && assigned[k] != 0x7fffffff) CurrentFrame.mvpMapPoints[k] = vpMPs[assigned[k]];  // :1703
+    return nmatches;
+  }
+
+  /* int ORBmatcher::SearchByBoW(KeyFrame* pKF, FrameKTL &F, vector<MapPoint*> &vpMapPointMatches) */
+  template <class KeyFrameT, class Frame, class MapPointT>
+  int SearchByBoW(KeyFrameT* pKF, Frame& F, std::vector<MapPointT*>& vpMapPointMatches) {
+    const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
+    vpMapPointMatches = std::vector<MapPointT*>(F.mvpMapPoints.size(), static_cast<MapPointT*>(NULL));
+    const int n1 = (int)vpMapPointsKF.size(), n2 = (int)F.mvpMapPoints.size();
+    if (n1 == 0 || n2 == 0 || ensure(n1 > n2 ? n1 : n2, 1) != UVO_OK) return 0;
+    FlatFeatureVector f1(pKF->GetFeatureVector()), f2(F.mFeatVec);
+    std::vector<uint8_t> d1((size_t)n1 * 32), d2((size_t)n2 * 32), usable1(n1);
+    std::vector<float> a1(n1), a2(n2);
+    for (int i = 0; i < n1; ++i) {
+      MapPointT* pMP = vpMapPointsKF[i];
+      usable1[i] = pMP && !pMP->isBad();  // :188-194
+      auto d = pKF->GetDescriptor(i);
+      std::memcpy(&d1[(size_t)i * 32], d.ptr(0), 32);
+      a1[i] = pKF->GetKeyPointUn(i).angle;
+    }
+    for (int k = 0; k < n2; ++k) {
+      std::memcpy(&d2[(size_t)k * 32], F.mDescriptors.ptr(k), 32);
+      a2[k] = F.mvKeys[k].angle;  // :225
+    }
+    std::vector<int32_t> match(n1, -1);
+    int nmatches = 0;
+    uvo_feature_vector c1 = f1.c(), c2 = f2.c();
+    if (uvo_search_by_bow(m_, 0, &c1, n1, d1.data(), a1.data(), usable1.data(), &c2, n2, d2.data(), a2.data(), nullptr, mfNNratio,
+                          mbCheckOrientation ? 1 : 0, match.data(), &nmatches) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    for (int i = 0; i < n1; ++i)
+      if (match[i] >= 0) vpMapPointMatches[match[i]] = vpMapPointsKF[i];  // :220
+    return nmatches;
+  }
+
+  /* int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &vpMatches12) */
+  template <class KeyFrameT, class MapPointT>
+  int SearchByBoW(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12) {
+    const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+    const int n1 = (int)vpMapPoints1.size(), n2 = (int)vpMapPoints2.size();
+    vpMatches12 = std::vector<MapPointT*>(n1, static_cast<MapPointT*>(NULL));
+    if (n1 == 0 || n2 == 0 || ensure(n1 > n2 ? n1 : n2, 1) != UVO_OK) return 0;
+    FlatFeatureVector f1(pKF1->GetFeatureVector()), f2(pKF2->GetFeatureVector());
+    std::vector<uint8_t> d1((size_t)n1 * 32), d2((size_t)n2 * 32), usable1(n1), usable2(n2);
+    std::vector<float> a1(n1), a2(n2);
+    fill_kf(pKF1, vpMapPoints1, d1, a1, usable1);
+    fill_kf(pKF2, vpMapPoints2, d2, a2, usable2);
+    std::vector<int32_t> match(n1, -1);
+    int nmatches = 0;
+    uvo_feature_vector c1 = f1.c(), c2 = f2.c();
+    if (uvo_search_by_bow(m_, 1, &c1, n1, d1.data(), a1.data(), usable1.data(), &c2, n2, d2.data(), a2.data(), usable2.data(), mfNNratio,
+                          mbCheckOrientation ? 1 : 0, match.data(), &nmatches) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    for (int i = 0; i < n1; ++i)
+      if (match[i] >= 0) vpMatches12[i] = vpMapPoints2[match[i]];  // :790
+    return nmatches;
+  }
+
+  /* int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vMatchedKeys1, vMatchedKeys2, vMatchedPairs) */
+  template <class KeyFrameT, class Mat33, class KeyPointT>
+  int SearchForTriangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, const Mat33& F12, std::vector<KeyPointT>& vMatchedKeys1,
+                             std::vector<KeyPointT>& vMatchedKeys2, std::vector<std::pair<size_t, size_t> >& vMatchedPairs) {
+    static_assert(sizeof(KeyPointT) == sizeof(uvo_keypoint), "keypoint layout must be cv::KeyPoint");
+    const auto vpMapPoints1 = pKF1->GetMapPointMatches();
+    const auto vpMapPoints2 = pKF2->GetMapPointMatches();
+    const std::vector<KeyPointT> vKeysUn1 = pKF1->GetKeyPointsUn(), vKeysUn2 = pKF2->GetKeyPointsUn();
+    const int n1 = (int)vKeysUn1.size(), n2 = (int)vKeysUn2.size();
+    vMatchedKeys1.clear(), vMatchedKeys2.clear(), vMatchedPairs.clear();
+    if (n1 == 0 || n2 == 0 || ensure(n1 > n2 ? n1 : n2, 1) != UVO_OK) return 0;
+    FlatFeatureVector f1(pKF1->GetFeatureVector()), f2(pKF2->GetFeatureVector());
+    std::vector<uint8_t> d1((size_t)n1 * 32), d2((size_t)n2 * 32), has1(n1), has2(n2);
+    for (int i = 0; i < n1; ++i) {
+      auto d = pKF1->GetDescriptor(i);
+      std::memcpy(&d1[(size_t)i * 32], d.ptr(0), 32);
+      has1[i] = vpMapPoints1[i] != NULL;  // :885-889
+    }
+    for (int k = 0; k < n2; ++k) {
+      auto d = pKF2->GetDescriptor(k);
+      std::memcpy(&d2[(size_t)k * 32], d.ptr(0), 32);
+      has2[k] = vpMapPoints2[k] != NULL;  // :903-905
+    }
+    float f12[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) f12[3 * r + c] = F12.template at<float>(r, c);
+    const int nlev = pKF2->GetScaleLevels();
+    std::vector<float> sigma2(nlev);
+    for (int l = 0; l < nlev; ++l) sigma2[l] = pKF2->GetSigma2(l);
+    std::vector<int32_t> match(n1, -1);
+    int nmatches = 0;
+    uvo_feature_vector c1 = f1.c(), c2 = f2.c();
+    if (uvo_search_for_triangulation(m_, &c1, reinterpret_cast<const uvo_keypoint*>(vKeysUn1.data()), n1, d1.data(), has1.data(), &c2,
+                                     reinterpret_cast<const uvo_keypoint*>(vKeysUn2.data()), n2, d2.data(), has2.data(), f12, sigma2.data(), nlev,
+                                     mbCheckOrientation ? 1 : 0, match.data(), &nmatches) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    for (int i = 0; i < n1; ++i) {  // :1000-1009
+      if (match[i] < 0) continue;
+      vMatchedKeys1.push_back(vKeysUn1[i]);
+      vMatchedKeys2.push_back(vKeysUn2[match[i]]);
+      vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)match[i]));
+    }
+    return nmatches;
+  }
+
+  /* int ORBmatcher::Fuse(KeyFrame *pKF, vector<MapPoint *> &vpMapPoints, float th): projection tests and the window search on the
+   * GPU, the order-dependent map mutation (:1104-1118) here.  IsInKeyFrame is evaluated up front, as the reference's loop would see
+   * it for every point that has not been touched by an earlier iteration (a point appears once in vpMapPoints). */
+  template <class KeyFrameT, class MapPointT>
+  int Fuse(KeyFrameT* pKF, std::vector<MapPointT*>& vpMapPoints, const float th = 3.0) {
+    const int nmp = (int)vpMapPoints.size(), n = (int)pKF->N;
+    if (nmp == 0 || n == 0 || ensure(n, nmp) != UVO_OK) return 0;
+    uvo_camera_pose cam;
+    auto Rcw = pKF->GetRotation();
+    auto tcw = pKF->GetTranslation();
+    auto Ow = pKF->GetCameraCenter();
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) cam.rcw[3 * r + c] = Rcw.template at<float>(r, c);
+      cam.tcw[r] = tcw.template at<float>(r);
+      cam.ow[r] = Ow.template at<float>(r);
+    }
+    cam.fx = pKF->fx, cam.fy = pKF->fy, cam.cx = pKF->cx, cam.cy = pKF->cy;
+    cam.min_x = pKF->mnMinX, cam.max_x = pKF->mnMaxX, cam.min_y = pKF->mnMinY, cam.max_y = pKF->mnMaxY;
+    const std::vector<float> vfScaleFactors = pKF->GetScaleFactors();
+    std::vector<float> xyz((size_t)nmp * 3, 0.f), nrm((size_t)nmp * 3, 0.f), mind(nmp, 1.f), maxd(nmp, 1.f), u(nmp), v(nmp);
+    std::vector<uint8_t> usable(nmp, 0), valid(nmp), mdesc((size_t)nmp * 32), kdesc((size_t)n * 32);
+    std::vector<int32_t> level(nmp), best(nmp), bdist(nmp);
+    for (int i = 0; i < nmp; ++i) {
+      MapPointT* pMP = vpMapPoints[i];
+      if (!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;  // :1031-1035
+      usable[i] = 1;
+      auto p = pMP->GetWorldPos();
+      auto pn = pMP->GetNormal();
+      for (int k = 0; k < 3; ++k) xyz[(size_t)i * 3 + k] = p.template at<float>(k), nrm[(size_t)i * 3 + k] = pn.template at<float>(k);
+      mind[i] = pMP->GetMinDistanceInvariance(), maxd[i] = pMP->GetMaxDistanceInvariance();
+      auto d = pMP->GetDescriptor();
+      std::memcpy(&mdesc[(size_t)i * 32], d.ptr(0), 32);
+    }
+    const int nlev = (int)vfScaleFactors.size();
+    if (uvo_project_points(m_, UVO_PROJECT_FUSE, &cam, nmp, xyz.data(), nrm.data(), mind.data(), maxd.data(), nullptr, usable.data(),
+                           vfScaleFactors.data(), nlev, 0.f, 0.f, valid.data(), u.data(), v.data(), level.data(), nullptr) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    std::vector<uvo_keypoint> kps(n);
+    for (int k = 0; k < n; ++k) {
+      auto d = pKF->GetDescriptor(k);
+      std::memcpy(&kdesc[(size_t)k * 32], d.ptr(0), 32);
+      const auto kp = pKF->GetKeyPointUn(k);
+      std::memcpy(&kps[k], &kp, sizeof(uvo_keypoint));
+    }
+    if (uvo_fuse(m_, kps.data(), n, kdesc.data(), (int)pKF->mnMinX, (int)pKF->mnMinY, (int)pKF->mnMaxX, (int)pKF->mnMaxY, nmp, u.data(), v.data(),
+                 level.data(), valid.data(), mdesc.data(), vfScaleFactors.data(), nlev, th, best.data(), bdist.data()) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    int nFused = 0;
+    for (int i = 0; i < nmp; ++i) {  // :1101-1119
+      if (best[i] < 0) continue;
+      MapPointT* pMP = vpMapPoints[i];
+      MapPointT* pMPinKF = pKF->GetMapPoint(best[i]);
+      if (pMPinKF) {
+        if (!pMPinKF->isBad()) pMP->Replace(pMPinKF);
+      } else {
+        pMP->AddObservation(pKF, best[i]);
+        pKF->AddMapPoint(pMP, best[i]);
+      }
+      nFused++;
+    }
+    return nFused;
+  }
+
   /* Utils::ratioMatching (include/utils.h:81-111) on raw descriptor rows: accepted (query, train, distance) triples. */
   struct Match {
     int queryIdx, trainIdx;
@@ -124,6 +360,35 @@ class UVO_COMPAT_MATCHER_NAME {
   bool mbCheckOrientation;
 
  private:
+  /* DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned int>>) flattened into the three arrays the ABI takes */
+  struct FlatFeatureVector {
+    std::vector<uint32_t> node;
+    std::vector<int32_t> start, feat;
+    template <class FeatVec>
+    explicit FlatFeatureVector(const FeatVec& fv) {
+      start.push_back(0);
+      for (typename FeatVec::const_iterator it = fv.begin(); it != fv.end(); ++it) {
+        node.push_back((uint32_t)it->first);
+        for (size_t k = 0; k < it->second.size(); ++k) feat.push_back((int32_t)it->second[k]);
+        start.push_back((int32_t)feat.size());
+      }
+    }
+    uvo_feature_vector c() const {
+      uvo_feature_vector v;
+      v.node = node.data(), v.start = start.data(), v.feat = feat.data(), v.n_nodes = (int32_t)node.size();
+      return v;
+    }
+  };
+  template <class KeyFrameT, class MapPointT>
+  static void fill_kf(KeyFrameT* pKF, const std::vector<MapPointT*>& mps, std::vector<uint8_t>& desc, std::vector<float>& angle,
+                      std::vector<uint8_t>& usable) {
+    for (size_t i = 0; i < mps.size(); ++i) {
+      usable[i] = mps[i] && !mps[i]->isBad();
+      auto d = pKF->GetDescriptor((int)i);
+      std::memcpy(&desc[i * 32], d.ptr(0), 32);
+      angle[i] = pKF->GetKeyPointUn((int)i).angle;
+    }
+  }
   int ensure(int n, int nmp) {
     if (m_ && n <= cap_n_ && nmp <= cap_mp_) return UVO_OK;
     uvo_matcher_destroy(m_);

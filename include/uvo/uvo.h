@@ -326,8 +326,9 @@ int uvo_fuse(uvo_matcher* m, const uvo_keypoint* kp, int n, const uint8_t* desc,
  * `+ t` in double) -- an unpinned assumption, stated in DESIGN.md.  log(scaleFactor) is the intended constant
  * (the reference reads it before it is initialised).
  *   usable[i]      : 0 = skip (NULL / isBad / already found / already in the key frame ...), may be NULL
- *   min_distance / max_distance : the raw mfMinDistance / mfMaxDistance members (the 0.8f / 1.2f factors of
- *                    GetMin/MaxDistanceInvariance are applied here); normal: GetNormal(), modes FRUSTUM and FUSE
+ *   min_distance_inv / max_distance_inv : GetMinDistanceInvariance() / GetMaxDistanceInvariance() of every point
+ *                    (max_distance_inv is not read by KF_RELOC); max_distance: the raw mfMaxDistance member that
+ *                    MapPoint::PredictScale divides by (FRUSTUM only); normal: GetNormal(), modes FRUSTUM and FUSE
  */
 enum { UVO_PROJECT_FRUSTUM = 0, UVO_PROJECT_KF_RELOC = 1, UVO_PROJECT_FUSE = 2 };
 typedef struct uvo_camera_pose {
@@ -338,8 +339,9 @@ typedef struct uvo_camera_pose {
   float min_x, max_x, min_y, max_y; /* mnMinX, mnMaxX, mnMinY, mnMaxY */
 } uvo_camera_pose;
 int uvo_project_points(uvo_matcher* m, int mode, const uvo_camera_pose* cam, int npts, const float* xyz, const float* normal,
-                       const float* min_distance, const float* max_distance, const uint8_t* usable, const float* scale_factors, int nlevels,
-                       float scale_factor, float viewing_cos_limit, uint8_t* valid, float* u, float* v, int32_t* level, float* view_cos);
+                       const float* min_distance_inv, const float* max_distance_inv, const float* max_distance, const uint8_t* usable,
+                       const float* scale_factors, int nlevels, float scale_factor, float viewing_cos_limit, uint8_t* valid, float* u, float* v,
+                       int32_t* level, float* view_cos);
 
 /*
  * Device-side ordering between the two handles' streams (no host synchronisation): work enqueued on the

@@ -3,6 +3,9 @@
 // Reads a raw u8 image + map-point table from files written by tests/test_cpp_compat.py and writes the results back.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <set>
 #include <vector>
 
 #include "uvo/compat/ORBextractor.h"
@@ -27,6 +30,135 @@ struct Frame {
   std::vector<float> mvScaleFactors;
   int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;
 };
+
+// ---- stand-ins with the member names the other search loops read (src/ORBmatcher.cc:155-284, :715-1134, :1622-1746) ----
+struct Vec3 {  // cv::Mat 3x1 CV_32F
+  float v[3];
+  template <class T>
+  T at(int i) const { return v[i]; }
+};
+struct Mat44 {  // cv::Mat 4x4 / 3x3 CV_32F
+  float m[4][4];
+  template <class T>
+  T at(int r, int c) const { return m[r][c]; }
+  template <class T>
+  T at(int r) const { return m[r][0]; }
+};
+struct Desc1 {
+  const uint8_t* p;
+  const uint8_t* ptr(int) const { return p; }
+};
+struct KeyFrame;
+struct MP2 {
+  Vec3 pos, normal;
+  float mind = 1.f, maxd = 100.f;
+  std::vector<uint8_t> d;
+  bool bad = false;
+  int replaced = 0, observations = 0;
+  bool isBad() const { return bad; }
+  Vec3 GetWorldPos() const { return pos; }
+  Vec3 GetNormal() const { return normal; }
+  float GetMinDistanceInvariance() const { return 0.8f * mind; }
+  float GetMaxDistanceInvariance() const { return 1.2f * maxd; }
+  Desc1 GetDescriptor() const { return Desc1{d.data()}; }
+  bool IsInKeyFrame(KeyFrame*) const { return false; }
+  void Replace(MP2*) { ++replaced; }
+  void AddObservation(KeyFrame*, int) { ++observations; }
+};
+struct KeyFrame {
+  int N = 0;
+  std::vector<uvo_keypoint> keys;
+  std::vector<uint8_t> desc;
+  std::vector<MP2*> mps;
+  std::map<unsigned, std::vector<unsigned> > featvec;
+  std::vector<float> scale, sigma2;
+  Mat44 R, t3, ow;
+  float fx = 458.f, fy = 457.f, cx = 367.f, cy = 248.f;
+  int mnMinX = 0, mnMinY = 0, mnMaxX = 752, mnMaxY = 480;
+  std::vector<MP2*> GetMapPointMatches() const { return mps; }
+  std::vector<uvo_keypoint> GetKeyPointsUn() const { return keys; }
+  uvo_keypoint GetKeyPointUn(int i) const { return keys[i]; }
+  Desc1 GetDescriptor(int i) const { return Desc1{&desc[(size_t)i * 32]}; }
+  const std::map<unsigned, std::vector<unsigned> >& GetFeatureVector() const { return featvec; }
+  int GetScaleLevels() const { return (int)scale.size(); }
+  float GetSigma2(int l) const { return sigma2[l]; }
+  std::vector<float> GetScaleFactors() const { return scale; }
+  Mat44 GetRotation() const { return R; }
+  Mat44 GetTranslation() const { return t3; }
+  Mat44 GetCameraCenter() const { return ow; }
+  MP2* GetMapPoint(int i) const { return mps[i]; }
+  void AddMapPoint(MP2* p, int i) { mps[i] = p; }
+};
+struct Frame2 {
+  std::vector<uvo_keypoint> mvKeysUn, mvKeys;
+  DescRows mDescriptors;
+  std::vector<MP2*> mvpMapPoints;
+  std::vector<float> mvScaleFactors;
+  std::map<unsigned, std::vector<unsigned> > mFeatVec;
+  Mat44 mTcw;
+  float fx = 458.f, fy = 457.f, cx = 367.f, cy = 248.f;
+  float mnMinX = 0, mnMinY = 0, mnMaxX = 752, mnMaxY = 480;
+};
+
+// exercises the remaining adaptor members on data derived from one extraction (identity pose, every keypoint a map point
+// back-projected at depth 5); returns non-zero on an implausible outcome
+static int exercise_other_members(const std::vector<uvo_keypoint>& kps, const std::vector<uint8_t>& desc, float sf) {
+  const int n = (int)kps.size();
+  KeyFrame kf1, kf2;
+  std::vector<MP2> pts(n);
+  for (KeyFrame* k : {&kf1, &kf2}) {
+    k->N = n, k->keys = kps, k->desc = desc;
+    k->scale.assign(8, 1.f), k->sigma2.assign(8, 1.f);
+    for (int l = 1; l < 8; ++l) k->scale[l] = k->scale[l - 1] * sf, k->sigma2[l] = k->scale[l] * k->scale[l];
+    memset(&k->R, 0, sizeof(Mat44)), memset(&k->t3, 0, sizeof(Mat44)), memset(&k->ow, 0, sizeof(Mat44));
+    for (int i = 0; i < 3; ++i) k->R.m[i][i] = 1.f;
+    for (int i = 0; i < n; ++i) k->featvec[desc[(size_t)i * 32] & 15u].push_back((unsigned)i);
+  }
+  for (int i = 0; i < n; ++i) {
+    const float z = 5.f;
+    pts[i].pos = Vec3{{(kps[i].x - 367.f) / 458.f * z, (kps[i].y - 248.f) / 457.f * z, z}};
+    pts[i].normal = Vec3{{0.f, 0.f, 1.f}};
+    pts[i].mind = 5.f / kf1.scale[kps[i].octave] / 0.8f * 0.999f;  // dist / (0.8 * mind) just above scale[octave - 1]
+    pts[i].maxd = 50.f;
+    pts[i].d.assign(desc.begin() + (size_t)i * 32, desc.begin() + (size_t)i * 32 + 32);
+  }
+  kf1.mps.assign(n, nullptr), kf2.mps.assign(n, nullptr);
+  for (int i = 0; i < n; ++i) kf1.mps[i] = &pts[i], kf2.mps[i] = &pts[i];
+  USLAM::ORBmatcher m(0.9f, true);
+  std::vector<MP2*> v12;
+  const int nb = m.SearchByBoW(&kf1, &kf2, v12);  // identical key frames: every descriptor finds itself
+  if (nb < n * 9 / 10) return 10;
+  Frame2 F;
+  F.mvKeysUn = kps, F.mvKeys = kps, F.mDescriptors.d = desc, F.mvpMapPoints.assign(n, nullptr), F.mvScaleFactors = kf1.scale;
+  F.mFeatVec = kf1.featvec;
+  memset(&F.mTcw, 0, sizeof(Mat44));
+  for (int i = 0; i < 4; ++i) F.mTcw.m[i][i] = 1.f;
+  std::vector<MP2*> vF;
+  const int nbf = m.SearchByBoW(&kf1, F, vF);
+  if (nbf < n * 9 / 10) return 11;
+  std::set<MP2*> found;
+  const int np = m.SearchByProjection(F, &kf1, found, 10.f, 100);
+  if (np < n * 8 / 10) return 12;
+  // triangulation between two key frames without map points; F12 of a pure x translation: epipolar lines y = const
+  KeyFrame ka = kf1, kb = kf2;
+  ka.mps.assign(n, nullptr), kb.mps.assign(n, nullptr);
+  Mat44 F12;
+  memset(&F12, 0, sizeof(F12));
+  F12.m[1][2] = -1.f, F12.m[2][1] = 1.f;
+  std::vector<uvo_keypoint> k1, k2;
+  std::vector<std::pair<size_t, size_t> > pairs;
+  const int nt = m.SearchForTriangulation(&ka, &kb, F12, k1, k2, pairs);
+  if (nt < n * 8 / 10 || (int)pairs.size() != nt) return 13;
+  // Fuse the same map points into a key frame that holds none: every usable point adds an observation
+  KeyFrame kc = kf1;
+  kc.mps.assign(n, nullptr);
+  std::vector<MP2*> vp2(n);
+  for (int i = 0; i < n; ++i) vp2[i] = &pts[i];
+  const int nf = m.Fuse(&kc, vp2, 3.f);
+  if (nf < n * 8 / 10) return 14;
+  printf("other members: bow_kk=%d bow_kf=%d proj_kf=%d triang=%d fuse=%d of %d\n", nb, nbf, np, nt, nf, n);
+  return 0;
+}
 
 static std::vector<uint8_t> slurp(const char* p) {
   FILE* f = fopen(p, "rb");
@@ -97,5 +229,5 @@ int main(int argc, char** argv) {
   }
   fclose(o);
   printf("ok %d keypoints %d matches dd=%d\n", n, nmatches, USLAM::ORBmatcher::DescriptorDistance(desc.data(), desc.data() + 32));
-  return 0;
+  return exercise_other_members(kps, desc, ex.GetScaleFactor());
 }

@@ -148,7 +148,7 @@ def _load():
     lib.uvo_search_by_projection_kf.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, ci, ci, vp]
     lib.uvo_search_by_bow.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, cf, ci, vp, vp]
     lib.uvo_search_for_triangulation.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp]
-    lib.uvo_project_points.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp, vp]
+    lib.uvo_project_points.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp, vp]
     lib.uvo_fuse.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, vp, vp]
     lib.uvo_matcher_wait_extractor.argtypes = [vp, vp]
     lib.uvo_extractor_wait_matcher.argtypes = [vp, vp]
@@ -519,16 +519,20 @@ class ORBmatcher:
 
     def project_points(self, mode, cam, xyz, normal, min_distance, max_distance, usable, scale_factors, scale_factor=1.2, viewing_cos_limit=0.5):
         """uvo_project_points: FrameKTL::isInFrustum (PROJECT_FRUSTUM), the projection prologue of SearchByProjection(F, pKF, ...)
-        (PROJECT_KF_RELOC) or of Fuse (PROJECT_FUSE).  Returns (valid, u, v, level, view_cos)."""
+        (PROJECT_KF_RELOC) or of Fuse (PROJECT_FUSE).  min_distance / max_distance are the map points' mfMinDistance / mfMaxDistance
+        members; the invariance bounds (x 0.8f, x 1.2f: MapPoint::GetMin/MaxDistanceInvariance) are formed here in fp32.
+        Returns (valid, u, v, level, view_cos)."""
         xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
         nrm = None if normal is None else np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
-        mn, mx = np.ascontiguousarray(min_distance, np.float32), np.ascontiguousarray(max_distance, np.float32)
+        mx = np.ascontiguousarray(max_distance, np.float32)
+        mn_inv = (np.float32(0.8) * np.ascontiguousarray(min_distance, np.float32)).astype(np.float32)
+        mx_inv = (np.float32(1.2) * mx).astype(np.float32)
         us = None if usable is None else np.ascontiguousarray(usable, np.uint8)
         sf = np.ascontiguousarray(scale_factors, np.float32)
         n = len(xyz)
         valid, u, v = np.zeros(n, np.uint8), np.zeros(n, np.float32), np.zeros(n, np.float32)
         level, vc = np.zeros(n, np.int32), np.zeros(n, np.float32)
-        rc = lib.uvo_project_points(self._h, int(mode), ctypes.byref(cam), n, _ptr(xyz), _ptr(nrm), _ptr(mn), _ptr(mx), _ptr(us), _ptr(sf), len(sf),
+        rc = lib.uvo_project_points(self._h, int(mode), ctypes.byref(cam), n, _ptr(xyz), _ptr(nrm), _ptr(mn_inv), _ptr(mx_inv), _ptr(mx), _ptr(us), _ptr(sf), len(sf),
                                     float(scale_factor), float(viewing_cos_limit), _ptr(valid), _ptr(u), _ptr(v), _ptr(level), _ptr(vc))
         if rc:
             raise UvoError(rc, "uvo_project_points")

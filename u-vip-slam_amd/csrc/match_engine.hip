@@ -364,7 +364,7 @@ __device__ __forceinline__ int lower_bound_level(const float* sf, int n, float r
 
 __global__ __launch_bounds__(256) void k_project(int mode, ProjCam C, int n, const float* __restrict__ xyz, const float* __restrict__ normal,
                                                  const float* __restrict__ min_d, const float* __restrict__ max_d,
-                                                 const uint8_t* __restrict__ usable, const float* __restrict__ sf, int nlevels, float log_sf,
+                                                 const float* __restrict__ max_raw, const uint8_t* __restrict__ usable, const float* __restrict__ sf, int nlevels, float log_sf,
                                                  float cos_limit, uint8_t* __restrict__ valid, float* __restrict__ out_u,
                                                  float* __restrict__ out_v, int32_t* __restrict__ out_level, float* __restrict__ out_cos) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void k_project(int mode, ProjCam C, int n, con
       if (u < C.min_x || u > C.max_x) break;
       if (v < C.min_y || v > C.max_y) break;
     }
-    const float maxDistance = 1.2f * max_d[i], minDistance = 0.8f * min_d[i];  // src/MapPoint.cc:344-354
+    const float maxDistance = max_d[i], minDistance = min_d[i];  // GetMax/MinDistanceInvariance(), src/MapPoint.cc:344-354
     const float PO[3] = {P[0] - ow[0], P[1] - ow[1], P[2] - ow[2]};
     double s2 = 0.0;
     for (int k = 0; k < 3; ++k) s2 += (double)PO[k] * (double)PO[k];  // cv::norm: double accumulator
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void k_project(int mode, ProjCam C, int n, con
       }
     }
     if (mode == UVO_PROJECT_FRUSTUM) {
-      const float ratio = max_d[i] / dist;  // MapPoint::PredictScale src/MapPoint.cc:378
+      const float ratio = max_raw[i] / dist;  // MapPoint::PredictScale src/MapPoint.cc:378 (the raw mfMaxDistance)
       int nScale = (int)ceilf(uvo_logf(ratio) / log_sf);
       if (nScale < 0)
         nScale = 0;
@@ -436,14 +436,14 @@ __global__ __launch_bounds__(256) void k_project(int mode, ProjCam C, int n, con
 }
 
 void launch_project(hipStream_t s, int mode, const uvo_camera_pose& cam, int n, const float* d_xyz, const float* d_normal, const float* d_min,
-                    const float* d_max, const uint8_t* d_usable, const float* d_sf, int nlevels, float log_sf, float cos_limit, uint8_t* d_valid,
+                    const float* d_max, const float* d_max_raw, const uint8_t* d_usable, const float* d_sf, int nlevels, float log_sf, float cos_limit, uint8_t* d_valid,
                     float* d_u, float* d_v, int32_t* d_level, float* d_cos) {
   ProjCam C;
   for (int i = 0; i < 9; ++i) C.r[i] = cam.rcw[i];
   for (int i = 0; i < 3; ++i) C.t[i] = cam.tcw[i], C.ow[i] = cam.ow[i];
   C.fx = cam.fx, C.fy = cam.fy, C.cx = cam.cx, C.cy = cam.cy;
   C.min_x = cam.min_x, C.max_x = cam.max_x, C.min_y = cam.min_y, C.max_y = cam.max_y;
-  hipLaunchKernelGGL(k_project, dim3((n + 255) / 256), dim3(256), 0, s, mode, C, n, d_xyz, d_normal, d_min, d_max, d_usable, d_sf, nlevels, log_sf,
+  hipLaunchKernelGGL(k_project, dim3((n + 255) / 256), dim3(256), 0, s, mode, C, n, d_xyz, d_normal, d_min, d_max, d_max_raw, d_usable, d_sf, nlevels, log_sf,
                      cos_limit, d_valid, d_u, d_v, d_level, d_cos);
 }
 

@@ -26,7 +26,7 @@ void launch_match_resolve(hipStream_t s, int nq, int nt, const int32_t* d_cand_s
 void launch_rot_filter(hipStream_t s, int nq, const float* d_qangle, const float* d_tangle, int32_t* d_match, int32_t* d_mdist,
                        int32_t* d_n_matches);
 void launch_project(hipStream_t s, int mode, const uvo_camera_pose& cam, int n, const float* d_xyz, const float* d_normal, const float* d_min,
-                    const float* d_max, const uint8_t* d_usable, const float* d_sf, int nlevels, float log_sf, float cos_limit, uint8_t* d_valid,
+                    const float* d_max, const float* d_max_raw, const uint8_t* d_usable, const float* d_sf, int nlevels, float log_sf, float cos_limit, uint8_t* d_valid,
                     float* d_u, float* d_v, int32_t* d_level, float* d_cos);
 }  // namespace uvo
 
@@ -405,23 +405,27 @@ int uvo_search_for_triangulation(uvo_matcher* m, const uvo_feature_vector* fv1, 
 }
 
 int uvo_project_points(uvo_matcher* m, int mode, const uvo_camera_pose* cam, int npts, const float* xyz, const float* normal,
-                       const float* min_distance, const float* max_distance, const uint8_t* usable, const float* scale_factors, int nlevels,
-                       float scale_factor, float viewing_cos_limit, uint8_t* valid, float* u, float* v, int32_t* level, float* view_cos) {
+                       const float* min_distance_inv, const float* max_distance_inv, const float* max_distance, const uint8_t* usable,
+                       const float* scale_factors, int nlevels, float scale_factor, float viewing_cos_limit, uint8_t* valid, float* u, float* v,
+                       int32_t* level, float* view_cos) {
   if (!m || !cam) return matcher_fail(UVO_E_BADARG, "null pointer");
   if (mode < UVO_PROJECT_FRUSTUM || mode > UVO_PROJECT_FUSE) return matcher_fail(UVO_E_BADARG, "unknown projection mode");
   if (npts < 0 || nlevels < 1 || nlevels > 64) return matcher_fail(UVO_E_BADARG, "bad sizes");
   if (npts == 0) return UVO_OK;
-  if (!xyz || !min_distance || !max_distance || !scale_factors || !valid || !u || !v || !level) return matcher_fail(UVO_E_BADARG, "null pointer");
+  if (!xyz || !min_distance_inv || !scale_factors || !valid || !u || !v || !level) return matcher_fail(UVO_E_BADARG, "null pointer");
+  if (mode != UVO_PROJECT_KF_RELOC && !max_distance_inv) return matcher_fail(UVO_E_BADARG, "this mode needs the maximum invariance distance");
+  if (mode == UVO_PROJECT_FRUSTUM && !max_distance) return matcher_fail(UVO_E_BADARG, "PredictScale needs the raw mfMaxDistance");
   if (mode != UVO_PROJECT_KF_RELOC && !normal) return matcher_fail(UVO_E_BADARG, "this mode needs the point normals");
   if (mode == UVO_PROJECT_FRUSTUM && !(scale_factor > 1.0f)) return matcher_fail(UVO_E_BADARG, "scale_factor must be > 1");
   UVO_HIP_CHECK(hipSetDevice(m->device));
   hipStream_t s = m->stream;
-  float *d_xyz, *d_normal = nullptr, *d_min, *d_max, *d_sf, *d_u;
+  float *d_xyz, *d_normal = nullptr, *d_min, *d_max = nullptr, *d_max_raw = nullptr, *d_sf, *d_u;
   uint8_t *d_usable = nullptr, *d_valid;
   RC(upload(m, S_QX, xyz, (size_t)npts * 3, &d_xyz));
   if (normal) RC(upload(m, S_QY, normal, (size_t)npts * 3, &d_normal));
-  RC(upload(m, S_QR, min_distance, (size_t)npts, &d_min));
-  RC(upload(m, S_QANGLE, max_distance, (size_t)npts, &d_max));
+  RC(upload(m, S_QR, min_distance_inv, (size_t)npts, &d_min));
+  if (max_distance_inv) RC(upload(m, S_QANGLE, max_distance_inv, (size_t)npts, &d_max));
+  if (max_distance) RC(upload(m, S_MISC, max_distance, (size_t)npts, &d_max_raw));
   if (usable) RC(upload(m, S_QVALID, usable, (size_t)npts, &d_usable));
   RC(upload(m, S_TANGLE, scale_factors, (size_t)nlevels, &d_sf));
   RC(reserve(m, S_MATCH, (size_t)npts * 4, &d_u));  // u, v, level, view_cos
@@ -430,7 +434,7 @@ int uvo_project_points(uvo_matcher* m, int mode, const uvo_camera_pose* cam, int
   int32_t* d_level = reinterpret_cast<int32_t*>(d_u + 2 * (size_t)npts);
   float* d_cos = d_u + 3 * (size_t)npts;
   const float log_sf = uvo_logf(scale_factor);  // mfLogScaleFactor = log(mfScaleFactor), src/FrameKTL.cc:97 (as intended)
-  launch_project(s, mode, *cam, npts, d_xyz, d_normal, d_min, d_max, d_usable, d_sf, nlevels, log_sf, viewing_cos_limit, d_valid, d_u, d_v, d_level,
+  launch_project(s, mode, *cam, npts, d_xyz, d_normal, d_min, d_max, d_max_raw, d_usable, d_sf, nlevels, log_sf, viewing_cos_limit, d_valid, d_u, d_v, d_level,
                  d_cos);
   UVO_HIP_CHECK(hipGetLastError());
   UVO_HIP_CHECK(hipMemcpyAsync(valid, d_valid, (size_t)npts, hipMemcpyDeviceToHost, s));
