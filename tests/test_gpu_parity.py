@@ -78,6 +78,21 @@ def test_other_resolutions(uvo, oracle, synth, shape, nfeat, th):
     ex.close()
 
 
+@pytest.mark.parametrize("scale,nlev", [(1.1, 6), (1.3, 5), (1.5, 4), (2.0, 3)])
+def test_other_scale_factors(uvo, oracle, synth, scale, nlev):
+    """Pyramid scale factors on both sides of the 12-byte-window limit of k_resize_level (byte-gather path above ~1.33)."""
+    w, h = 640, 512
+    img = synth.make_frame(91, w, h)
+    ex = uvo.ORBextractor(800, scale, nlev, 0, 15, max_width=w, max_height=h)
+    oe = oracle.extractor(800, scale, nlev, 15)
+    kp_g, de_g = ex(img)
+    kp_o, de_o = oe(img)
+    for l in range(nlev):
+        np.testing.assert_array_equal(ex.read_plane(l), oe.level_plane(l), err_msg="scale %.2f level %d" % (scale, l))
+    _assert_same_features(kp_g, de_g, kp_o, de_o, "scale %.2f" % scale)
+    ex.close()
+
+
 def test_degenerate_images(uvo, oracle):
     ex = uvo.ORBextractor(500, 1.2, 8, 0, 20, max_width=640, max_height=512)
     oe = oracle.extractor(500, 1.2, 8, 20)

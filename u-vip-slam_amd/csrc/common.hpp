@@ -63,8 +63,8 @@ struct Geom {
 // score word = FAST score (cornerScore), 1..254.
 
 // resize coefficient tables, indexed by padded output coordinates (border reflection folded in)
-struct ResizeCol {  // 8 B
-  int16_t sx, a0, a1, pad;
+struct ResizeCol {  // 8 B: left tap column, the two 11-bit weights scaled by 16 (a << 4 <= 32768)
+  uint16_t sx, a0, a1, pad;
 };
 struct ResizeRow {  // 8 B
   int16_t sy0, sy1, b0, b1;

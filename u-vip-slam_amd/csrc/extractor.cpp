@@ -78,6 +78,7 @@ struct uvo_extractor {
   LevelGeom* d_lv = nullptr;
   CellDesc* d_cells = nullptr;
   ResizeCol* d_ctab = nullptr;
+  int resize_fast[kMaxLevels] = {0};  // per level: the 12-byte-window path of k_resize_level applies
   ResizeRow* d_rtab = nullptr;
   int8_t* d_pattern = nullptr;
   uint16_t* d_patch = nullptr;  // 768 packed (u,v) offsets of the orientation patch
@@ -218,7 +219,9 @@ static inline int reflect101_host(int p, int len) {
   while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
   return p;
 }
-static void build_resize_tables(const Geom& g, std::vector<ResizeCol>& ctab, std::vector<ResizeRow>& rtab) {
+// fast_ok[l]: every output dword of level l finds its eight taps inside one 12-byte aligned source window (true for scale
+// factors up to ~1.33); otherwise the level takes the byte-gather path.
+static void build_resize_tables(const Geom& g, std::vector<ResizeCol>& ctab, std::vector<ResizeRow>& rtab, int* fast_ok) {
   ctab.clear(), rtab.clear();
   for (int l = 1; l < g.nlevels; ++l) {
     const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h, dw = g.lv[l].w, dh = g.lv[l].h;
@@ -231,7 +234,7 @@ static void build_resize_tables(const Geom& g, std::vector<ResizeCol>& ctab, std
       fx -= sx;
       if (sx < 0) fx = 0, sx = 0;
       if (sx >= sw - 1) fx = 0, sx = sw - 1;
-      col[dx] = ResizeCol{(int16_t)sx, (int16_t)cv_round_host((1.f - fx) * 2048.f), (int16_t)cv_round_host(fx * 2048.f), 0};
+      col[dx] = ResizeCol{(uint16_t)sx, (uint16_t)(cv_round_host((1.f - fx) * 2048.f) << 4), (uint16_t)(cv_round_host(fx * 2048.f) << 4), 0};
     }
     for (int dy = 0; dy < dh; ++dy) {
       float fy = (float)((dy + 0.5) * scale_y - 0.5);
@@ -240,9 +243,24 @@ static void build_resize_tables(const Geom& g, std::vector<ResizeCol>& ctab, std
       const int sy0 = std::min(std::max(sy, 0), sh - 1), sy1 = std::min(std::max(sy + 1, 0), sh - 1);
       row[dy] = ResizeRow{(int16_t)sy0, (int16_t)sy1, (int16_t)cv_round_host((1.f - fy) * 2048.f), (int16_t)cv_round_host(fy * 2048.f)};
     }
-    for (int px = 0; px < g.lv[l].pitch; ++px) {
-      int x = reflect101_host(px - kPad, dw);  // columns in the pitch slack map to something valid too
-      ctab.push_back(col[x]);
+    fast_ok[l] = 1;
+    for (int px = 0; px < g.lv[l].pitch; px += 4) {
+      ResizeCol e[4];
+      int lo = 1 << 30;
+      for (int i = 0; i < 4; ++i) {
+        e[i] = col[reflect101_host(px + i - kPad, dw)];  // columns in the pitch slack map to something valid too
+        lo = std::min(lo, (int)e[i].sx);
+      }
+      // per dword: window base (multiple of 4) and the v_perm selector = offsets of the four left taps inside the window
+      const int base = lo & ~3;
+      uint32_t sel = 0;
+      for (int i = 0; i < 4; ++i) {
+        const int o = (int)e[i].sx - base;
+        if (o > 7) fast_ok[l] = 0;
+        sel |= (uint32_t)(o & 0xff) << (8 * i);
+      }
+      e[0].pad = (uint16_t)base, e[1].pad = (uint16_t)(sel & 0xffff), e[2].pad = (uint16_t)(sel >> 16), e[3].pad = 0;
+      for (int i = 0; i < 4; ++i) ctab.push_back(e[i]);
     }
     for (int py = 0; py < g.lv[l].ph; ++py) rtab.push_back(row[reflect101_host(py - kPad, dh)]);
   }
@@ -276,7 +294,7 @@ static int set_geometry(uvo_extractor* h, int width, int height) {
   }
   std::vector<ResizeCol> ctab;
   std::vector<ResizeRow> rtab;
-  build_resize_tables(g, ctab, rtab);
+  build_resize_tables(g, ctab, rtab, h->resize_fast);
   if ((int)ctab.size() > h->cap_xtab || (int)rtab.size() > h->cap_ytab) return fail(UVO_E_BADARG, "image larger than the handle was sized for");
   // in-flight work may still read the old tables
   {
@@ -324,7 +342,7 @@ static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, 
   for (int l = 1; l < g.nlevels; ++l) {
     ProfScope p(h, "k_resize_level");
     launch_resize_level(s, h->lane[h->cur].d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_ctab + g.lv[l].xtab_off, h->d_rtab + g.lv[l].ytab_off,
-                        h->cfg.scale_factor <= 2.0f ? 1 : 0, batch);
+                        h->resize_fast[l], batch);
   }
   static const char* const kFastNames[3] = {"k_fast_score", "k_fast_nms", "k_fast_emit"};
   for (int stage = 0; stage < 3; ++stage) {

@@ -55,68 +55,99 @@ __global__ __launch_bounds__(256) void k_pad_level0(const uint8_t* __restrict__ 
 // = 2048) into int, vertical pass ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2.  The coefficient tables are built
 // on the host exactly as resizeGeneric_ builds them (extractor.cpp) and are indexed by *padded* output coordinates,
 // i.e. the REFLECT_101 border is already folded into them: entry px of the column table holds (sx, a0, a1) of the
-// level column reflect(px-16), entry py of the row table (sy0, sy1, b0, b1).
-// One thread = 4 output bytes.  Interior threads fetch each of the two source rows as three aligned dwords (the four
-// taps span <= 12 bytes for scale factors <= 2) and pick bytes with v_alignbyte; pad threads (reflected, decreasing
-// source order) take the scalar byte path.
-__device__ __forceinline__ uint32_t pick2(uint32_t d0, uint32_t d1, uint32_t d2, int o) {
-  // bytes o and o+1 of the 12-byte window, in bits [0,16)
-  const uint32_t lo = o < 4 ? d0 : (o < 8 ? d1 : d2);
-  const uint32_t hi = o < 4 ? d1 : d2;
-  return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(o & 3));
+// level column reflect(px-16) with the weights scaled by 16, entry py of the row table (sy0, sy1, b0, b1).
+// One thread = 4 output bytes x RZ_ROWS rows.  Each of the two source rows is fetched as three aligned dwords (the four tap
+// pairs of a dword lie inside 12 bytes for scale factors up to ~1.33; checked per level when the tables are built); one
+// v_perm_b32 with a per-thread selector gathers the four left taps, a second one on the window shifted by a byte the four
+// right taps.  Levels that do not fit the window gather bytes instead.
+// The column weights are stored scaled by 16 (a0 << 4, a1 << 4), so that a row sum comes out as r << 4 and `(r >> 4) << 8`
+// -- the operand v_mul_hi_u32_u24 needs to give (b * (r >> 4)) >> 16 in one instruction -- is a single AND.
+__device__ __forceinline__ uint32_t mulhi24(uint32_t a, uint32_t b) {  // v_mul_hi_u32_u24: bits [47:32] of the 48-bit product
+  return (uint32_t)(((uint64_t)(a & 0xffffffu) * (uint64_t)(b & 0xffffffu)) >> 32);
 }
+// left / right tap bytes (bits [8i, 8i+8) of L, R) -> ((left*a0 + right*a1) >> 4) << 8
+template <int I>
+__device__ __forceinline__ uint32_t hrow(uint32_t L, uint32_t R, uint32_t a0s, uint32_t a1s) {
+  const uint32_t r16 = __umul24((L >> (8 * I)) & 0xffu, a0s) + __umul24((R >> (8 * I)) & 0xffu, a1s);
+  return r16 & 0xffffff00u;
+}
+__device__ __forceinline__ uint32_t vrow(uint32_t q0, uint32_t q1, uint32_t b0s, uint32_t b1s) {
+  return ((mulhi24(b0s, q0) + mulhi24(b1s, q1) + 2u) >> 2) & 0xffu;  // ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2
+}
+
+constexpr int RZ_ROWS = 4;  // output rows per thread: one column-table fetch, RZ_ROWS x 2 independent row fetches in flight
 
 __global__ __launch_bounds__(256) void k_resize_level(uint8_t* __restrict__ pyr, int64_t pyr_block, int64_t src_off, int src_pitch, int sw,
                                                       int64_t dst_off, int dst_pitch, int dst_ph, int dw, int fast_ok,
-                                                      const ResizeCol* __restrict__ ctab, const ResizeRow* __restrict__ rtab) {
-  const int wx = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int py = blockIdx.y * 4 + wave_in_block();
-  const int f = blockIdx.z;
-  if (wx * 4 >= dst_pitch || py >= dst_ph) return;
-  const ResizeRow rr = rtab[py];
-  const int b0 = rr.b0, b1 = rr.b1;
+                                                      const ResizeCol* __restrict__ ctab, const ResizeRow* __restrict__ rtab,
+                                                      uint32_t nwx_magic) {
+  // flat index -> (row group, dword column): rows are a few dozen to 150 dwords long, so a (64 x rows) tiling would leave up to
+  // a third of the lanes idle on some levels.  gid / nwx by multiply-high with ceil(2^32 / nwx) (exact for gid < 2^20).
+  const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t nwx = (uint32_t)dst_pitch >> 2;
+  const uint32_t rg = __umulhi(gid, nwx_magic);
+  const int wx = (int)(gid - rg * nwx);
+  const int py0 = (int)rg * RZ_ROWS;
+  const int f = blockIdx.y;
+  if (py0 >= dst_ph) return;
   const uint8_t* S = pyr + f * pyr_block + src_off + (int64_t)kPad * src_pitch + kPad;  // ROI origin of the source level
-  const uint8_t* S0 = S + (int64_t)rr.sy0 * src_pitch;
-  const uint8_t* S1 = S + (int64_t)rr.sy1 * src_pitch;
   const uint4 c01 = reinterpret_cast<const uint4*>(ctab)[wx * 2];      // columns 4wx, 4wx+1
   const uint4 c23 = reinterpret_cast<const uint4*>(ctab)[wx * 2 + 1];  // columns 4wx+2, 4wx+3
   const uint32_t cw[8] = {c01.x, c01.y, c01.z, c01.w, c23.x, c23.y, c23.z, c23.w};
-  int sx[4], a0[4], a1[4];
+  uint32_t sx[4], a0[4], a1[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    sx[i] = (int)(int16_t)(cw[2 * i] & 0xffff);
-    a0[i] = (int)(int16_t)(cw[2 * i] >> 16);
-    a1[i] = (int)(int16_t)(cw[2 * i + 1] & 0xffff);
+    sx[i] = cw[2 * i] & 0xffffu;
+    a0[i] = cw[2 * i] >> 16;
+    a1[i] = cw[2 * i + 1] & 0xffffu;
   }
-  uint32_t v = 0;
-  const bool interior = fast_ok && wx * 4 >= kPad && wx * 4 + 3 < kPad + dw;  // monotone source columns
-  if (interior) {
-    const int base = sx[0] & ~3;
-    const uint32_t* p0 = reinterpret_cast<const uint32_t*>(S0 + base);
-    const uint32_t* p1 = reinterpret_cast<const uint32_t*>(S1 + base);
-    const uint32_t u0 = p0[0], u1 = p0[1], u2 = p0[2];
-    const uint32_t w0 = p1[0], w1 = p1[1], w2 = p1[2];
+  // window base and tap selector come ready-made from the table (pad fields of the four column entries); they cover the reflected
+  // pad columns too (taps in decreasing order), so every thread of a level takes the same path
+  const bool interior = fast_ok != 0;
+  const uint32_t base = cw[1] >> 16;
+  const uint32_t sel = (cw[3] >> 16) | (cw[5] & 0xffff0000u);
+  ResizeRow rr[RZ_ROWS];
+  uint32_t u[RZ_ROWS][3], w[RZ_ROWS][3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int o = sx[i] - base;
-      const uint32_t t0 = pick2(u0, u1, u2, o), t1 = pick2(w0, w1, w2, o);
-      const int r0 = __mul24((int)(t0 & 0xff), a0[i]) + __mul24((int)((t0 >> 8) & 0xff), a1[i]);
-      const int r1 = __mul24((int)(t1 & 0xff), a0[i]) + __mul24((int)((t1 >> 8) & 0xff), a1[i]);
-      const int o8 = ((__mul24(b0, r0 >> 4) >> 16) + (__mul24(b1, r1 >> 4) >> 16) + 2) >> 2;  // all operands < 2^24
-      v |= (uint32_t)(o8 & 0xff) << (8 * i);
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int sx1 = sx[i] + 1 < sw ? sx[i] + 1 : sw - 1;
-      const int r0 = __mul24((int)S0[sx[i]], a0[i]) + __mul24((int)S0[sx1], a1[i]);
-      const int r1 = __mul24((int)S1[sx[i]], a0[i]) + __mul24((int)S1[sx1], a1[i]);
-      const int o8 = ((__mul24(b0, r0 >> 4) >> 16) + (__mul24(b1, r1 >> 4) >> 16) + 2) >> 2;
-      v |= (uint32_t)(o8 & 0xff) << (8 * i);
+  for (int j = 0; j < RZ_ROWS; ++j) {
+    const int py = py0 + j < dst_ph ? py0 + j : dst_ph - 1;  // rows past the plane repeat the last one and are not stored
+    rr[j] = rtab[py];
+    if (interior) {
+      const uint32_t* p0 = reinterpret_cast<const uint32_t*>(S + (int64_t)rr[j].sy0 * src_pitch + base);
+      const uint32_t* p1 = reinterpret_cast<const uint32_t*>(S + (int64_t)rr[j].sy1 * src_pitch + base);
+      u[j][0] = p0[0], u[j][1] = p0[1], u[j][2] = p0[2];
+      w[j][0] = p1[0], w[j][1] = p1[1], w[j][2] = p1[2];
     }
   }
-  uint8_t* dst = pyr + f * pyr_block + dst_off + (int64_t)py * dst_pitch;
-  *reinterpret_cast<uint32_t*>(dst + wx * 4) = v;
+#pragma unroll
+  for (int j = 0; j < RZ_ROWS; ++j) {
+    uint32_t L0, R0, L1, R1;  // left / right taps of the four columns in the two source rows
+    if (interior) {
+      L0 = __builtin_amdgcn_perm(u[j][1], u[j][0], sel);
+      R0 = __builtin_amdgcn_perm(__builtin_amdgcn_alignbyte(u[j][2], u[j][1], 1), __builtin_amdgcn_alignbyte(u[j][1], u[j][0], 1), sel);
+      L1 = __builtin_amdgcn_perm(w[j][1], w[j][0], sel);
+      R1 = __builtin_amdgcn_perm(__builtin_amdgcn_alignbyte(w[j][2], w[j][1], 1), __builtin_amdgcn_alignbyte(w[j][1], w[j][0], 1), sel);
+    } else {
+      const uint8_t* S0 = S + (int64_t)rr[j].sy0 * src_pitch;
+      const uint8_t* S1 = S + (int64_t)rr[j].sy1 * src_pitch;
+      L0 = R0 = L1 = R1 = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t sx1 = sx[i] + 1 < (uint32_t)sw ? sx[i] + 1 : (uint32_t)sw - 1;
+        L0 |= (uint32_t)S0[sx[i]] << (8 * i), R0 |= (uint32_t)S0[sx1] << (8 * i);
+        L1 |= (uint32_t)S1[sx[i]] << (8 * i), R1 |= (uint32_t)S1[sx1] << (8 * i);
+      }
+    }
+    const uint32_t b0s = (uint32_t)rr[j].b0 << 8, b1s = (uint32_t)rr[j].b1 << 8;
+    uint32_t v = vrow(hrow<0>(L0, R0, a0[0], a1[0]), hrow<0>(L1, R1, a0[0], a1[0]), b0s, b1s);
+    v |= vrow(hrow<1>(L0, R0, a0[1], a1[1]), hrow<1>(L1, R1, a0[1], a1[1]), b0s, b1s) << 8;
+    v |= vrow(hrow<2>(L0, R0, a0[2], a1[2]), hrow<2>(L1, R1, a0[2], a1[2]), b0s, b1s) << 16;
+    v |= vrow(hrow<3>(L0, R0, a0[3], a1[3]), hrow<3>(L1, R1, a0[3], a1[3]), b0s, b1s) << 24;
+    if (py0 + j < dst_ph) {
+      uint8_t* dst = pyr + f * pyr_block + dst_off + (int64_t)(py0 + j) * dst_pitch;
+      *reinterpret_cast<uint32_t*>(dst + wx * 4) = v;
+    }
+  }
 }
 
 void launch_pad_level0(hipStream_t s, const uint8_t* d_img, int w, int h, int64_t stride, int64_t frame_stride, uint8_t* d_pyr,
@@ -131,9 +162,11 @@ void launch_pad_level0(hipStream_t s, const uint8_t* d_img, int w, int h, int64_
 void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const LevelGeom& src, const LevelGeom& dst, const ResizeCol* d_ctab,
                          const ResizeRow* d_rtab, int fast_ok, int batch) {
   dim3 block(256);
-  dim3 grid((dst.pitch / 4 + 63) / 64, (dst.ph + 3) / 4, batch);
+  const uint32_t nwx = (uint32_t)dst.pitch / 4, groups = ((uint32_t)dst.ph + RZ_ROWS - 1) / RZ_ROWS;
+  const uint32_t magic = (uint32_t)((0x100000000ull + nwx - 1) / nwx);
+  dim3 grid((nwx * groups + 255) / 256, batch);
   hipLaunchKernelGGL(k_resize_level, grid, block, 0, s, d_pyr, pyr_block, src.plane_off, src.pitch, src.w, dst.plane_off, dst.pitch, dst.ph,
-                     dst.w, fast_ok, d_ctab, d_rtab);
+                     dst.w, fast_ok, d_ctab, d_rtab, magic);
 }
 
 }  // namespace uvo
