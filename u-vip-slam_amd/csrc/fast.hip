@@ -30,14 +30,19 @@ namespace uvo {
 constexpr int FS_COLS = 248;  // useful columns per wavefront strip (lanes 1..62)
 constexpr int FQ_CAP = 320;   // queue entries per wavefront: < 64 left over + <= 256 pushed per row
 
-// max over the 16 arcs of 9 contiguous ring pixels of min(d): a 9-window minimum is the min3 of three 3-window minima
-// (v_min3_i32), the 16 results are folded with v_max3_i32 -- 40 instructions per polarity, branch free.
+// max over the 16 arcs of 9 contiguous ring pixels of min(d).  A 9-window always straddles the two 8-pixel halves of the
+// ring, so with running minima towards the end of each half (S) and from the start of each half (P) every arc minimum is
+// one more min: arc(k) = min(S[k], P[(k + 8) & 15]).  28 + 16 two-operand minima, then a max3 fold -- branch free.
 __device__ __forceinline__ int arc9_maxmin(const int* d) {
-  int m3[16], m9[16];
+  int S[16], P[16];
+  S[7] = d[7], S[15] = d[15], P[0] = d[0], P[8] = d[8];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) m3[k] = min(d[k], min(d[(k + 1) & 15], d[(k + 2) & 15]));
+  for (int k = 6; k >= 0; --k) S[k] = min(d[k], S[k + 1]), S[k + 8] = min(d[k + 8], S[k + 9]);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) m9[k] = min(m3[k], min(m3[(k + 3) & 15], m3[(k + 6) & 15]));
+  for (int k = 1; k < 8; ++k) P[k] = min(d[k], P[k - 1]), P[k + 8] = min(d[k + 8], P[k + 7]);
+  int m9[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m9[k] = min(S[k], P[(k + 8) & 15]);
   int r[6];
 #pragma unroll
   for (int k = 0; k < 5; ++k) r[k] = max(m9[3 * k], max(m9[3 * k + 1], m9[3 * k + 2]));
@@ -47,23 +52,20 @@ __device__ __forceinline__ int arc9_maxmin(const int* d) {
 
 // min over the 16 arcs of max(d): the darker polarity without negating d (max over arcs of min(-d) = -this)
 __device__ __forceinline__ int arc9_minmax(const int* d) {
-  int m3[16], m9[16];
+  int S[16], P[16];
+  S[7] = d[7], S[15] = d[15], P[0] = d[0], P[8] = d[8];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) m3[k] = max(d[k], max(d[(k + 1) & 15], d[(k + 2) & 15]));
+  for (int k = 6; k >= 0; --k) S[k] = max(d[k], S[k + 1]), S[k + 8] = max(d[k + 8], S[k + 9]);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) m9[k] = max(m3[k], max(m3[(k + 3) & 15], m3[(k + 6) & 15]));
+  for (int k = 1; k < 8; ++k) P[k] = max(d[k], P[k - 1]), P[k + 8] = max(d[k + 8], P[k + 7]);
+  int m9[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m9[k] = max(S[k], P[(k + 8) & 15]);
   int r[6];
 #pragma unroll
   for (int k = 0; k < 5; ++k) r[k] = min(m9[3 * k], min(m9[3 * k + 1], m9[3 * k + 2]));
   r[5] = m9[15];
   return min(min(r[0], min(r[1], r[2])), min(r[3], min(r[4], r[5])));
-}
-
-// byte I (0..11, compile time) of the 12-byte window [L C R]
-template <int I>
-__device__ __forceinline__ uint32_t win(uint32_t L, uint32_t C, uint32_t R) {
-  static_assert(I >= 0 && I < 12, "window index");
-  return ((I < 4 ? L : (I < 8 ? C : R)) >> (8 * (I & 3))) & 0xffu;
 }
 
 // Screening of two pixels packed as 16-bit halves (see k_fast_score): non-zero half <=> that pixel may be a corner.
