@@ -148,6 +148,16 @@ def test_hamming_knn2_and_matrix(uvo, oracle):
         np.testing.assert_array_equal(idx0, o[0])
         np.testing.assert_array_equal(idx1, o[2])
         np.testing.assert_array_equal(d0.astype(np.int32), np.where(o[0] < 0, 0xFFFF, o[1]))
+        if nq and nt:
+            # low-entropy descriptors: almost every best / second-best is a tie that the lower train index must win
+            ql = rng.choice(np.array([0, 1, 128, 255], np.uint8), (nq, 32), p=[0.7, 0.1, 0.1, 0.1])
+            tl = rng.choice(np.array([0, 1, 128, 255], np.uint8), (nt, 32), p=[0.7, 0.1, 0.1, 0.1])
+            gi0, gd0, gi1, gd1 = m.knn2(ql, tl)
+            ol = oracle.knn2(ql, tl)
+            np.testing.assert_array_equal(gi0, ol[0])
+            np.testing.assert_array_equal(gi1, ol[2])
+            np.testing.assert_array_equal(gd0.astype(np.int32), np.where(ol[0] < 0, 0xFFFF, ol[1]))
+            np.testing.assert_array_equal(gd1.astype(np.int32), np.where(ol[2] < 0, 0xFFFF, ol[3]))
         np.testing.assert_array_equal(d1.astype(np.int32), np.where(o[2] < 0, 0xFFFF, o[3]))
         if nq and nt:
             dm = m.distance_matrix(q, t)

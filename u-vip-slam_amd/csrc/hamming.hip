@@ -3,9 +3,13 @@
 //              Utils::ratioMatching (include/utils.h:81-111); distance = ORBmatcher::DescriptorDistance
 //              (src/ORBmatcher.cc:1794-1810: popcount of the XOR over 8 x 32 bits).
 //   k_matrix : full distance matrix (MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:236-247).
-// Integer VALU work (v_xor_b32 + v_bcnt_u32_b32), no MFMA: nothing here is a dense contraction.
-// One lane owns one query descriptor in 8 VGPRs; train descriptors are staged through LDS in tiles of 128 and
-// read back as wave-uniform broadcasts (every lane reads the same 16 bytes: conflict free).
+// Two forms of the all-pairs distance:
+//   * k_knn2_mfma (no mask): the all-pairs Hamming distance IS a dense contraction over the 256 bit positions --
+//     d(q, t) = pop(q) + pop(t) - 2 * <q, t> with the descriptors taken as 0/1 vectors -- so the inner products run on the
+//     matrix cores: v_mfma_i32_32x32x32_i8 on descriptors expanded to one byte per bit (the train tile expanded once per
+//     workgroup into LDS, the query fragments once per wavefront into registers).  Exact in int32.
+//   * k_knn2 / k_matrix / k_medoid: integer VALU (v_xor_b32 + v_bcnt_u32_b32); one lane owns one query descriptor in
+//     8 VGPRs, train descriptors are staged through LDS in tiles of 128 and read back as wave-uniform broadcasts.
 #include "common.hpp"
 
 namespace uvo {
@@ -72,6 +76,95 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
   }
 }
 
+// ---- matrix-core form ------------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int KM_ROW = 272;  // bytes per expanded train row in LDS: 256 + 16 so that the 16-byte fragment reads of 16 rows hit 64 banks
+
+// 4 bits -> 4 bytes of 0/1 (bit i -> byte i): (t * (1 + 2^7 + 2^14 + 2^21)) & 0x01010101
+__device__ __forceinline__ uint32_t spread4(uint32_t t) { return (__umul24(t & 0xfu, 0x00204081u)) & 0x01010101u; }
+__device__ __forceinline__ v4i spread16(uint32_t x) {  // 16 bits -> 16 bytes
+  v4i r;
+  r.x = (int)spread4(x), r.y = (int)spread4(x >> 4), r.z = (int)spread4(x >> 8), r.w = (int)spread4(x >> 12);
+  return r;
+}
+
+// grid: (ceil(max_query/128), pairs); 4 wavefronts, each owns 32 queries (MFMA columns); train descriptors = MFMA rows.
+// C/D layout of the 32x32 shapes: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// A / B fragments of k-step s: lane (r = lane & 31, h = lane >> 5) supplies bits 32s + 16h .. +15 of train row r / query column r
+// (any k order is fine as long as A and B use the same one: both come from spread16 of the same 16-bit field).
+__global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t* __restrict__ q, const int32_t* __restrict__ nq_arr, int nq_fixed, int q_stride,
+                                                   const uint8_t* __restrict__ t, const int32_t* __restrict__ nt_arr, int nt_fixed, int t_stride,
+                                                   int out_stride, int32_t* __restrict__ idx0, uint16_t* __restrict__ d0,
+                                                   int32_t* __restrict__ idx1, uint16_t* __restrict__ d1) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_exp[32 * KM_ROW];
+  __shared__ __attribute__((aligned(16))) int32_t s_key[32];
+  const int pair = blockIdx.y;
+  const int nq = nq_arr ? nq_arr[pair] : nq_fixed;
+  const int nt = nt_arr ? nt_arr[pair] : nt_fixed;
+  if (blockIdx.x * 128 >= nq) return;
+  const int lane = threadIdx.x & 63, wv = wave_in_block();
+  const int r = lane & 31, h = lane >> 5;
+  const int qi = blockIdx.x * 128 + wv * 32 + r;
+  const uint32_t* Q = reinterpret_cast<const uint32_t*>(q + (int64_t)pair * q_stride * 32);
+  const uint32_t* T = reinterpret_cast<const uint32_t*>(t + (int64_t)pair * t_stride * 32);
+  // query fragments, held for the whole train loop (8 k-steps x 4 VGPRs) + pop(q)
+  v4i bq[8];
+  int popq = 0;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const uint32_t w = qi < nq ? Q[(int64_t)qi * 8 + s] : 0u;
+    popq += __popc(w);
+    bq[s] = spread16(w >> (16 * h));
+  }
+  int k0 = 0x7fffffff, k1 = 0x7fffffff;  // two smallest keys ((pop(t) - 2 dot) << 16 | train index), signed
+  const int erow = threadIdx.x >> 3, ec = threadIdx.x & 7;  // expansion: thread -> (train row of the tile, 32-bit chunk)
+  for (int base = 0; base < nt; base += 32) {
+    __syncthreads();
+    {
+      const int tr = base + erow;
+      const uint32_t w = tr < nt ? T[(int64_t)tr * 8 + ec] : 0u;
+      v4i* dst = reinterpret_cast<v4i*>(s_exp + erow * KM_ROW + ec * 32);
+      dst[0] = spread16(w), dst[1] = spread16(w >> 16);
+      int pc = __popc(w);  // pop(t) of the row: sum over its 8 chunk threads (adjacent lanes)
+      pc += __shfl_xor(pc, 1, 64);
+      pc += __shfl_xor(pc, 2, 64);
+      pc += __shfl_xor(pc, 4, 64);
+      if (ec == 0) s_key[erow] = tr < nt ? ((pc << 16) | tr) : 0x7fff0000;
+    }
+    __syncthreads();
+    v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint8_t* arow = s_exp + r * KM_ROW + 16 * h;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const v4i a = *reinterpret_cast<const v4i*>(arow + 32 * s);
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const v4i kb = *reinterpret_cast<const v4i*>(&s_key[8 * g + 4 * h]);  // rows 8g + 4h + (0..3)
+      const int kbv[4] = {kb.x, kb.y, kb.z, kb.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = kbv[e] - (acc[4 * g + e] << 17);
+        k1 = min(k1, max(k0, key));
+        k0 = min(k0, key);
+      }
+    }
+  }
+  // the two lane halves saw different train rows of the same query: merge
+  const int o0 = __shfl_xor(k0, 32, 64), o1 = __shfl_xor(k1, 32, 64);
+  const int m0 = min(k0, o0), m1 = min(max(k0, o0), min(k1, o1));
+  if (h == 0 && qi < nq) {
+    const int64_t o = (int64_t)pair * out_stride + qi;
+    const bool v0 = m0 < 0x7fff0000, v1 = m1 < 0x7fff0000;
+    idx0[o] = v0 ? (m0 & 0xffff) : -1;
+    d0[o] = v0 ? (uint16_t)((m0 >> 16) + popq) : (uint16_t)0xFFFF;
+    idx1[o] = v1 ? (m1 & 0xffff) : -1;
+    d1[o] = v1 ? (uint16_t)((m1 >> 16) + popq) : (uint16_t)0xFFFF;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_matrix(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
                                                 uint16_t* __restrict__ dist) {
   __shared__ uint4 s_t[HM_TILE * 2];
@@ -135,6 +228,11 @@ void launch_medoid(hipStream_t s, const uint8_t* d_desc, const int32_t* d_offset
 void launch_knn2(hipStream_t s, int pairs, int max_q, const uint8_t* d_q, const int32_t* d_nq, int nq_fixed, int q_stride, const uint8_t* d_t,
                  const int32_t* d_nt, int nt_fixed, int t_stride, const uint8_t* d_mask, int out_stride, int32_t* d_idx0, uint16_t* d_d0,
                  int32_t* d_idx1, uint16_t* d_d1) {
+  if (!d_mask) {
+    hipLaunchKernelGGL(k_knn2_mfma, dim3((max_q + 127) / 128, pairs), dim3(256), 0, s, d_q, d_nq, nq_fixed, q_stride, d_t, d_nt, nt_fixed, t_stride,
+                       out_stride, d_idx0, d_d0, d_idx1, d_d1);
+    return;
+  }
   hipLaunchKernelGGL(k_knn2, dim3((max_q + 255) / 256, pairs), dim3(256), 0, s, d_q, d_nq, nq_fixed, q_stride, d_t, d_nt, nt_fixed, t_stride,
                      d_mask, out_stride, d_idx0, d_d0, d_idx1, d_d1);
 }
