@@ -123,7 +123,7 @@ void launch_knn2(hipStream_t s, int pairs, int max_q, const uint8_t* d_q, const 
 void launch_medoid(hipStream_t s, const uint8_t* d_desc, const int32_t* d_offsets, int npoints, int32_t* d_idx, int32_t* d_med);
 void launch_matrix(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, uint16_t* d_dist);
 void launch_describe(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, const uint8_t* d_blur, int64_t pyr_block,
-                     const FinalSlot* d_flist, const int32_t* d_n_final, const uvo_keypoint* d_in_kp, int in_cap, const int8_t* d_pattern,
-                     const uint16_t* d_patch, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch);
+                     const FinalSlot* d_flist, const int32_t* d_n_final, const uvo_keypoint* d_in_kp, int in_cap, const float* d_pattern,
+                     const uint32_t* d_patch, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch);
 
 }  // namespace uvo

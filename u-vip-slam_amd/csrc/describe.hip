@@ -100,87 +100,199 @@ __device__ __forceinline__ int wave_sum(int v) {
   return v;
 }
 
-// 4 wavefronts per workgroup, one final slot per wavefront.
+// 4 wavefronts per workgroup, DK_PER_WAVE consecutive final slots per wavefront.  The stages of a keypoint are a chain of
+// dependent gathers (slot -> level geometry -> patch pixels -> angle -> steered sample points -> blurred pixels), so a
+// wavefront keeps several keypoints in flight: all patch loads are issued before the first reduction, all blurred-pixel
+// loads before the first ballot, and the pattern table is read once for the group.
+constexpr int DK_PER_WAVE = 4;
+constexpr int DW_ROWS = 37, DW_ROW_DWORDS = 10, DW_DWORDS = DW_ROWS * DW_ROW_DWORDS;  // steered sample points reach +-18 px
+
 __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blur, int64_t pyr_block,
                                                   const FinalSlot* __restrict__ flist, int flist_cap, const int32_t* __restrict__ n_final,
-                                                  const uvo_keypoint* __restrict__ in_kp, int in_cap, const int8_t* __restrict__ pattern,
-                                                  const uint16_t* __restrict__ patch, uvo_keypoint* __restrict__ out_kp,
+                                                  const uvo_keypoint* __restrict__ in_kp, int in_cap, const float* __restrict__ pattern,
+                                                  const uint32_t* __restrict__ patch, uvo_keypoint* __restrict__ out_kp,
                                                   uint8_t* __restrict__ out_desc, int cap, int32_t* __restrict__ n_out) {
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int slot = blockIdx.x * 4 + wave_in_block();
+  const int slot0 = (blockIdx.x * 4 + wave_in_block()) * DK_PER_WAVE;
   int n = n_final[f];
   if (blockIdx.x == 0 && threadIdx.x == 0) n_out[f] = n;
   n = n > flist_cap ? flist_cap : n;
-  if (slot >= n || slot >= cap) return;
-  const FinalSlot fs = flist[(int64_t)f * flist_cap + slot];
-  const bool is_input = fs.level < 0;
-  uvo_keypoint kp;
-  int level;
-  if (is_input) {
-    kp = in_kp[(int64_t)f * in_cap + fs.aux];
-    level = 0;
-  } else {
-    level = fs.level;
-    kp.x = fs.x, kp.y = fs.y;
-    kp.size = lv[level].patch_size;
-    kp.response = (float)fs.aux;
-    kp.octave = level;
-    kp.class_id = -1;
-  }
-  const LevelGeom& g = lv[level];
-  const int cx = cv_round(kp.x), cy = cv_round(kp.y);
-  const int64_t center_off = f * pyr_block + g.plane_off + (int64_t)(cy + kPad) * g.pitch + (cx + kPad);
+  n = n > cap ? cap : n;
+  if (slot0 >= n) return;
 
-  // ---- IC_Angle: the 749 (u, v) offsets of the circular patch (rows v in [-15,15], |u| <= umax[|v|]) come from a
-  // table padded to 768 entries with (0,0) (contributes nothing); 12 independent byte loads per lane ----
-  {
-    const uint8_t* center = pyr + center_off;
+  // blurred 37-row x 40-byte windows (u in [-18, 21], v in [-18, 18]) of the group's keypoints, wavefront-private
+  __shared__ uint32_t s_win[4][DK_PER_WAVE][DW_DWORDS];
+  uint32_t(*win)[DW_DWORDS] = s_win[wave_in_block()];
+  uvo_keypoint kp[DK_PER_WAVE];
+  int64_t center_off[DK_PER_WAVE];
+  int pitch[DK_PER_WAVE];
+  float scale[DK_PER_WAVE];
+  bool rescale[DK_PER_WAVE], live[DK_PER_WAVE];
+  uint32_t px[DK_PER_WAVE][4];
+  uint32_t wv[DK_PER_WAVE][6];
+  // window dwords of this lane: index = row * 10 + column dword (6 x 64 >= 370)
+  int wrow[6], wcol[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int idx = lane + 64 * i;
+    const int row = (idx * 6554) >> 16;  // idx / 10 for idx < 16384
+    wrow[i] = (row < DW_ROWS ? row : DW_ROWS - 1) - 18;
+    wcol[i] = -18 + 4 * (idx - row * 10);
+  }
+  // orientation-patch slots of this lane (same for every keypoint): row * 8 + chunk, see below
+  int vv[4], u0[4];
+  uint32_t pmask[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int slot = lane + 64 * i;
+    vv[i] = (slot >> 3) - 15;
+    u0[i] = -16 + 4 * (slot & 7);
+    pmask[i] = patch[slot];
+  }
+  // ---- stage A: slot -> keypoint, issue the patch loads ----
+#pragma unroll
+  for (int k = 0; k < DK_PER_WAVE; ++k) {
+    live[k] = slot0 + k < n;
+    const int slot = live[k] ? slot0 + k : slot0;  // dead entries repeat the first slot and are never stored
+    const FinalSlot fs = flist[(int64_t)f * flist_cap + slot];
+    const bool is_input = fs.level < 0;
+    int level;
+    if (is_input) {
+      kp[k] = in_kp[(int64_t)f * in_cap + fs.aux];
+      level = 0;
+    } else {
+      level = fs.level;
+      kp[k].x = fs.x, kp[k].y = fs.y;
+      kp[k].size = lv[level].patch_size;
+      kp[k].response = (float)fs.aux;
+      kp[k].octave = level;
+      kp[k].class_id = -1;
+    }
+    const LevelGeom& g = lv[level];
+    pitch[k] = g.pitch;
+    scale[k] = g.scale;
+    rescale[k] = !is_input && level != 0;
+    const int cx = cv_round(kp[k].x), cy = cv_round(kp[k].y);
+    center_off[k] = f * pyr_block + g.plane_off + (int64_t)(cy + kPad) * g.pitch + (cx + kPad);
+    // IC_Angle: the circular patch (rows v in [-15,15], |u| <= umax[|v|]) is read as 31 rows x 8 dwords starting at u = -16;
+    // a table masks the bytes outside the circle (slots 248..255 = "row 31" are masked out entirely)
+    const uint8_t* center = pyr + center_off[k];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vr = vv[i] <= 15 ? vv[i] : 15;  // keep the (masked) load of row 31 inside the plane
+      uint32_t d;
+      __builtin_memcpy(&d, center + (int64_t)vr * pitch[k] + u0[i], 4);
+      px[k][i] = d & pmask[i];
+    }
+    // blurred window: coalesced row segments (6 rows per load instruction) instead of 512 scattered byte gathers
+    const uint8_t* bcen = blur + center_off[k];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      uint32_t d;
+      __builtin_memcpy(&d, bcen + (int64_t)wrow[i] * pitch[k] + wcol[i], 4);
+      wv[k][i] = d;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DK_PER_WAVE; ++k)
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (lane + 64 * i < DW_DWORDS) win[k][lane + 64 * i] = wv[k][i];
+  // pattern: lane l evaluates pairs l, l+64, l+128, l+192
+  float4 pq[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pq[j] = reinterpret_cast<const float4*>(pattern)[j * 64 + lane];  // (x0, y0, x1, y1)
+
+  // ---- stage B: moments -> angle -> steering.  Per dword sum(I) and sum(k*I) by v_dot4_u32_u8, then
+  // m10 += u0*sum(I) + sum(k*I), m01 += v*sum(I): exact int32 moments.  The 8 partial sums of the group (m10, m01 of 4
+  // keypoints) are reduced together: every exchange step halves the number of values a lane carries (xor 32: 8 -> 4, xor 16:
+  // 4 -> 2, xor 8: 2 -> 1, then xor 4/2/1 on the last one), 10 exchanges instead of 48, and value j ends up in lanes 8j..8j+7.
+  // The angle and its sine / cosine are then computed once, on the lanes that own the keypoint, and broadcast. ----
+  static_assert(DK_PER_WAVE == 4, "the grouped reduction below is written for 4 keypoints (8 moments)");
+  int mv[8];
+#pragma unroll
+  for (int k = 0; k < DK_PER_WAVE; ++k) {
     int m01 = 0, m10 = 0;
-    int pix[12], uu[12], vv[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const int uv = patch[lane + 64 * i];  // u in the low byte, v in the high byte (both int8)
-      uu[i] = (int)(int8_t)(uv & 0xff);
-      vv[i] = (int)(int8_t)(uv >> 8);
-      pix[i] = center[(int64_t)vv[i] * g.pitch + uu[i]];
+    for (int i = 0; i < 4; ++i) {
+      const int sum = (int)__builtin_amdgcn_udot4(px[k][i], 0x01010101u, 0u, false);
+      const int wsum = (int)__builtin_amdgcn_udot4(px[k][i], 0x03020100u, 0u, false);
+      m10 += u0[i] * sum + wsum;
+      m01 += vv[i] * sum;
     }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      m10 += uu[i] * pix[i];
-      m01 += vv[i] * pix[i];
-    }
-    m01 = wave_sum(m01);
-    m10 = wave_sum(m10);
-    kp.angle = uvo_fast_atan2((float)m01, (float)m10);
+    mv[2 * k] = m10, mv[2 * k + 1] = m01;
   }
-
-  // ---- steered rBRIEF on the blurred level: lane l evaluates pairs l, l+64, l+128, l+192 ----
+  int r4[4], r2[2], r1;
+  {
+    const bool hi = (lane & 32) != 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int keep = hi ? mv[4 + j] : mv[j], send = hi ? mv[j] : mv[4 + j];
+      r4[j] = keep + __shfl_xor(send, 32, 64);
+    }
+  }
+  {
+    const bool hi = (lane & 16) != 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int keep = hi ? r4[2 + j] : r4[j], send = hi ? r4[j] : r4[2 + j];
+      r2[j] = keep + __shfl_xor(send, 16, 64);
+    }
+  }
+  {
+    const bool hi = (lane & 8) != 0;
+    const int keep = hi ? r2[1] : r2[0], send = hi ? r2[0] : r2[1];
+    r1 = keep + __shfl_xor(send, 8, 64);
+  }
+  r1 += __shfl_xor(r1, 4, 64);
+  r1 += __shfl_xor(r1, 2, 64);
+  r1 += __shfl_xor(r1, 1, 64);
+  // lanes 16k..16k+7 hold m10 of keypoint k, lanes 16k+8..16k+15 its m01
+  const int other = __shfl_xor(r1, 8, 64);
+  const float my_m10 = (float)((lane & 8) ? other : r1), my_m01 = (float)((lane & 8) ? r1 : other);
+  const float my_angle = uvo_fast_atan2(my_m01, my_m10);
   const float factorPI = (float)(3.14159265358979323846 / 180.f);
-  const float angle = kp.angle * factorPI;
-  float a, b;
-  uvo_sincosf(angle, &b, &a);  // a = cos, b = sin
-  const uint8_t* bc = blur + center_off;
-  uint64_t words[4];
+  float my_sin, my_cos;
+  uvo_sincosf(my_angle * factorPI, &my_sin, &my_cos);
+  float ca[DK_PER_WAVE], sa[DK_PER_WAVE];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint32_t pq = reinterpret_cast<const uint32_t*>(pattern)[j * 64 + lane];  // (x0, y0, x1, y1) int8
-    const float x0 = (float)(int8_t)(pq & 0xff), y0 = (float)(int8_t)((pq >> 8) & 0xff), x1 = (float)(int8_t)((pq >> 16) & 0xff),
-                y1 = (float)(int8_t)(pq >> 24);
-    const int t0 = bc[(int64_t)cv_round(x0 * b + y0 * a) * g.pitch + cv_round(x0 * a - y0 * b)];
-    const int t1 = bc[(int64_t)cv_round(x1 * b + y1 * a) * g.pitch + cv_round(x1 * a - y1 * b)];
-    words[j] = __ballot(t0 < t1);
+  for (int k = 0; k < DK_PER_WAVE; ++k) {
+    kp[k].angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_angle), 16 * k));
+    ca[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_cos), 16 * k));  // a = cos
+    sa[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sin), 16 * k));  // b = sin
   }
-  uint64_t* dd = reinterpret_cast<uint64_t*>(out_desc + ((int64_t)f * cap + slot) * 32);
-  if (lane < 4) dd[lane] = words[lane];
-
-  if (lane == 0) {
-    if (!is_input && level != 0) {
-      kp.x = kp.x * g.scale;
-      kp.y = kp.y * g.scale;
+  // ---- stage C: steered rBRIEF on the blurred level, sample points read from the LDS windows ----
+  uint8_t t0[DK_PER_WAVE][4], t1[DK_PER_WAVE][4];
+#pragma unroll
+  for (int k = 0; k < DK_PER_WAVE; ++k) {
+    const uint8_t* wb = reinterpret_cast<const uint8_t*>(win[k]) + 18 * (DW_ROW_DWORDS * 4) + 18;  // byte of (u, v) = (0, 0)
+    const float a = ca[k], b = sa[k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x0 = pq[j].x, y0 = pq[j].y, x1 = pq[j].z, y1 = pq[j].w;
+      t0[k][j] = wb[cv_round(x0 * b + y0 * a) * (DW_ROW_DWORDS * 4) + cv_round(x0 * a - y0 * b)];
+      t1[k][j] = wb[cv_round(x1 * b + y1 * a) * (DW_ROW_DWORDS * 4) + cv_round(x1 * a - y1 * b)];
     }
-    out_kp[(int64_t)f * cap + slot] = kp;
+  }
+#pragma unroll
+  for (int k = 0; k < DK_PER_WAVE; ++k) {
+    uint64_t words[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) words[j] = __ballot(t0[k][j] < t1[k][j]);
+    if (!live[k]) continue;
+    const int slot = slot0 + k;
+    uint64_t* dd = reinterpret_cast<uint64_t*>(out_desc + ((int64_t)f * cap + slot) * 32);
+    if (lane < 4) dd[lane] = words[lane];
+    if (lane == 0) {
+      uvo_keypoint o = kp[k];
+      if (rescale[k]) {
+        o.x = o.x * scale[k];
+        o.y = o.y * scale[k];
+      }
+      out_kp[(int64_t)f * cap + slot] = o;
+    }
   }
 }
 
@@ -194,10 +306,10 @@ void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const 
 }
 
 void launch_describe(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, const uint8_t* d_blur, int64_t pyr_block,
-                     const FinalSlot* d_flist, const int32_t* d_n_final, const uvo_keypoint* d_in_kp, int in_cap, const int8_t* d_pattern,
-                     const uint16_t* d_patch, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch) {
+                     const FinalSlot* d_flist, const int32_t* d_n_final, const uvo_keypoint* d_in_kp, int in_cap, const float* d_pattern,
+                     const uint32_t* d_patch, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch) {
   const int slots = g.flist_cap < cap ? g.flist_cap : cap;
-  hipLaunchKernelGGL(k_describe, dim3((slots + 3) / 4, batch), dim3(256), 0, s, d_lv, g.nlevels, d_pyr, d_blur, pyr_block, d_flist,
+  hipLaunchKernelGGL(k_describe, dim3((slots + 4 * DK_PER_WAVE - 1) / (4 * DK_PER_WAVE), batch), dim3(256), 0, s, d_lv, g.nlevels, d_pyr, d_blur, pyr_block, d_flist,
                      g.flist_cap, d_n_final, d_in_kp, in_cap, d_pattern, d_patch, d_out_kp, d_out_desc, cap, d_n_out);
 }
 

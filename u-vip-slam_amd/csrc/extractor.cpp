@@ -80,8 +80,8 @@ struct uvo_extractor {
   ResizeCol* d_ctab = nullptr;
   int resize_fast[kMaxLevels] = {0};  // per level: the 12-byte-window path of k_resize_level applies
   ResizeRow* d_rtab = nullptr;
-  int8_t* d_pattern = nullptr;
-  uint16_t* d_patch = nullptr;  // 768 packed (u,v) offsets of the orientation patch
+  float* d_pattern = nullptr;   // 256 point pairs (x0, y0, x1, y1) of the rBRIEF pattern as floats
+  uint32_t* d_patch = nullptr;  // 256 byte masks: which of the 4 pixels of an orientation-patch dword lie inside the circle
   // staging for the host-buffer entry points
   uint8_t* d_imgs = nullptr;
   uvo_keypoint *d_out_kp = nullptr, *d_in_kp = nullptr;
@@ -390,7 +390,7 @@ static int alloc_lane(uvo_extractor* h, int li) {
 #define AL(call) \
   if ((rc = (call)) != UVO_OK) return rc;
   AL(dev_alloc(&L.d_pyr, B * h->cap_pyr_block));
-  AL(dev_alloc(&L.d_blur, B * h->cap_pyr_block));
+  AL(dev_alloc(&L.d_blur, B * h->cap_pyr_block + 256));  // + slack: k_describe reads whole dwords up to 3 bytes past a row end
   AL(dev_alloc(&L.d_score, B * h->cap_pyr_block));
   AL(dev_alloc(&L.d_cand_xy, B * h->cap_cand_block));
   AL(dev_alloc(&L.d_cand_sc, B * h->cap_cand_block));
@@ -495,7 +495,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   A(dev_alloc(&h->d_ctab, (size_t)h->cap_xtab));
   A(dev_alloc(&h->d_rtab, (size_t)h->cap_ytab));
   A(dev_alloc(&h->d_pattern, (size_t)1024));
-  A(dev_alloc(&h->d_patch, (size_t)768));
+  A(dev_alloc(&h->d_patch, (size_t)256));
   // staging for host-buffer calls
   A(dev_alloc(&h->d_imgs, B * (size_t)cfg->max_width * cfg->max_height));
   A(dev_alloc(&h->d_out_kp, B * h->cap_flist));
@@ -505,13 +505,21 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   A(dev_alloc(&h->d_n_in, B));
   A(dev_alloc(&h->d_nfn, B));
 #undef A
-  // circular orientation patch (IC_Angle, src/ORBextractor.cc:125-152): rows v in [-15,15], |u| <= umax[|v|] -> 749 offsets
-  std::vector<uint16_t> patch;
-  for (int v = -15; v <= 15; ++v)
-    for (int u = -h->umax[v < 0 ? -v : v]; u <= h->umax[v < 0 ? -v : v]; ++u) patch.push_back((uint16_t)((uint8_t)(int8_t)u | ((uint8_t)(int8_t)v << 8)));
-  patch.resize(768, 0);
-  if (hipMemcpy(h->d_pattern, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(h->d_patch, patch.data(), 768 * 2, hipMemcpyHostToDevice) != hipSuccess) {
+  // circular orientation patch (IC_Angle, src/ORBextractor.cc:125-152): rows v in [-15,15], |u| <= umax[|v|] (749 pixels).
+  // k_describe reads it as 31 rows x 8 dwords (u = -16 + 4*chunk + byte); entry row*8 + chunk masks the bytes inside the circle.
+  std::vector<uint32_t> patch(256, 0u);
+  for (int row = 0; row < 31; ++row) {
+    const int v = row - 15, um = h->umax[v < 0 ? -v : v];
+    for (int c = 0; c < 8; ++c)
+      for (int k = 0; k < 4; ++k) {
+        const int u = -16 + 4 * c + k;
+        if (u >= -um && u <= um) patch[row * 8 + c] |= 0xffu << (8 * k);
+      }
+  }
+  std::vector<float> patf(1024);
+  for (int i = 0; i < 1024; ++i) patf[i] = (float)kPattern[i];
+  if (hipMemcpy(h->d_pattern, patf.data(), 4096, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(h->d_patch, patch.data(), 1024, hipMemcpyHostToDevice) != hipSuccess) {
     uvo_extractor_destroy(h);
     return fail(UVO_E_HIP, "table upload failed");
   }
