@@ -229,6 +229,18 @@ def main():
         bytes_per_launch = alg.get(dom, 0) * B / launches_per_step
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         total_alg = sum(v for kname, v in alg.items() if kname != "k_pad_level0")
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command (separate --pmc runs,
+        # profiles/r01_d_pmc.json; FETCH_SIZE under-reports reads by 2x on gfx950): bytes per launch, or null if not recorded
+        traffic, traffic_src = None, None
+        try:
+            pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_pmc.json")
+            with open(pmc_path) as fh:
+                e = json.load(fh)["kernels"].get(dom)
+            if e and "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+                traffic = int((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024)
+                traffic_src = "profiles/r01_d_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH + WRITE)"
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "frames/sec ORB extract+match, 640x512 @1000 kp",
             "value": round(value, 1),
@@ -248,12 +260,12 @@ def main():
                        "batch_per_gpu": B, "sharding": "frames, no collective", "pipeline_depth": DEPTH, "mean_keypoints_per_frame": round(k_mean, 1),
                        "knn2_second_neighbours_found": matches},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": round(avg_launch_s * 1e3, 5), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "whole_path_GBps": round(total_alg * value / world / 1e9, 2),
                          "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(ktimes.items())},
                          "kernel_ms_per_step_unoverlapped": {k: round(v[0] / 3, 4) for k, v in sorted(serial.items())},
-                         "note": "k_fast_score (FAST segment test) is integer-VALU bound, not HBM bound (~60 lane-ops per pixel, see "
+                         "note": "k_fast_score (FAST segment test) is integer-VALU bound, not HBM bound (PMC: ~77 lane-ops per pixel, see "
                                  "DESIGN.md section 7); the HBM fraction is reported because the contract asks for it"},
         }
         if not args.no_cpu_baseline:
