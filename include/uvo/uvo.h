@@ -343,6 +343,39 @@ int uvo_project_points(uvo_matcher* m, int mode, const uvo_camera_pose* cam, int
                        const float* scale_factors, int nlevels, float scale_factor, float viewing_cos_limit, uint8_t* valid, float* u, float* v,
                        int32_t* level, float* view_cos);
 
+/* ------------------------------------------------------------------------------------------------
+ * Bag-of-words transform: DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>::transform(features, BowVector&, FeatureVector&,
+ * levelsup) (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1125-1188, per-feature descent :1207-1258), as called by
+ * FrameKTL::ComputeBoW (src/FrameKTL.cc:439-446) and KeyFrame::ComputeBoW (src/KeyFrame.cc:203-210) with levelsup = 4.
+ * The tree descent (Hamming distance to every child, first minimum wins) runs on the device; the two std::map containers are
+ * assembled on the host in the reference's insertion order.  The feature vector comes out in the flat form
+ * uvo_search_by_bow / uvo_search_for_triangulation take.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct uvo_vocabulary uvo_vocabulary;
+typedef struct uvo_vocabulary_desc {
+  int32_t n_nodes;            /* m_nodes.size(); node 0 is the root */
+  const int32_t* child_start; /* [n_nodes + 1]: children of node i = children[child_start[i] .. child_start[i+1]), in m_nodes[i].children order */
+  const int32_t* children;
+  const uint8_t* descriptor;  /* [n_nodes][32]: m_nodes[i].descriptor (row 0 unused) */
+  const int32_t* word_id;     /* [n_nodes]: m_nodes[i].word_id (read for leaves) */
+  const double* weight;       /* [n_nodes]: m_nodes[i].weight */
+  int32_t L;                  /* m_L */
+  int32_t weighting;          /* DBoW2::WeightingType: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY */
+  int32_t normalize;          /* GeneralScoring::mustNormalize: 0 = no (DotProduct), 1 = L1, 2 = L2 */
+  int32_t device;
+} uvo_vocabulary_desc;
+int uvo_vocabulary_create(const uvo_vocabulary_desc* desc, uvo_vocabulary** out);
+void uvo_vocabulary_destroy(uvo_vocabulary* voc);
+/*
+ * desc[n][32] -> per feature: word_id, word_weight, node_id (node reached at level L - levelsup; 0 when that level is <= 0;
+ * the leaf itself when the descent ends above that level -- the reference leaves it uninitialised there);
+ * BowVector as (bow_id ascending, bow_value), *n_bow entries; FeatureVector as fv_node ascending, fv_start[*n_fv + 1],
+ * fv_feat (feature indices, ascending inside a node).  Per-feature arrays may be NULL.  Host buffers.
+ */
+int uvo_bow_transform(uvo_vocabulary* voc, const uint8_t* desc, int n, int levelsup, int32_t* word_id, double* word_weight, int32_t* node_id,
+                      uint32_t* bow_id, double* bow_value, int bow_cap, int* n_bow, uint32_t* fv_node, int32_t* fv_start, int32_t* fv_feat,
+                      int fv_cap, int* n_fv);
+
 /*
  * Device-side ordering between the two handles' streams (no host synchronisation): work enqueued on the
  * matcher after uvo_matcher_wait_extractor() starts only when everything enqueued on the extractor so far

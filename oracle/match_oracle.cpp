@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <utility>
 #include <vector>
 
@@ -494,6 +495,85 @@ bool project_fuse(const Camera& K, const float* p3Dw, const float* Pn, float mfM
   *level = std::min((int)(it - scaleFactors), nMaxLevel);
   *u_out = u, *v_out = v;
   return true;
+}
+
+// ---- DBoW2 ----
+void bow_transform_one(const Vocabulary& voc, const uint8_t* feature, int levelsup, int* word_id, double* weight, int* nid_out) {
+  const int nid_level = voc.L - levelsup;
+  int nid = -1;
+  if (nid_level <= 0) nid = 0;  // root
+  int final_id = 0;             // root
+  int current_level = 0;
+  while (voc.child_start[final_id] != voc.child_start[final_id + 1]) {  // do { ... } while(!isLeaf) on a tree whose root has children
+    ++current_level;
+    const int32_t* nodes = voc.children + voc.child_start[final_id];
+    const int nn = voc.child_start[final_id + 1] - voc.child_start[final_id];
+    final_id = nodes[0];
+    double best_d = descriptor_distance(feature, voc.descriptor + (size_t)final_id * 32);  // FORB::distance == DescriptorDistance
+    for (int c = 1; c < nn; ++c) {
+      const int id = nodes[c];
+      double d = descriptor_distance(feature, voc.descriptor + (size_t)id * 32);
+      if (d < best_d) {
+        best_d = d;
+        final_id = id;
+      }
+    }
+    if (current_level == nid_level) nid = final_id;
+  }
+  if (nid < 0) nid = final_id;
+  *word_id = voc.word_id[final_id];
+  *weight = voc.weight[final_id];
+  *nid_out = nid;
+}
+
+void bow_transform(const Vocabulary& voc, const uint8_t* features, int n, int levelsup, std::vector<std::pair<uint32_t, double>>& bow_out,
+                   std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& fv_out) {
+  std::map<uint32_t, double> v;
+  std::map<uint32_t, std::vector<uint32_t>> fv;
+  const bool must = voc.normalize != 0;
+  if (voc.weighting == 0 || voc.weighting == 1) {
+    for (int i = 0; i < n; ++i) {
+      int id, nid;
+      double w;
+      bow_transform_one(voc, features + (size_t)i * 32, levelsup, &id, &w, &nid);
+      if (w > 0) {
+        auto it = v.lower_bound((uint32_t)id);  // BowVector::addWeight
+        if (it != v.end() && !(v.key_comp()((uint32_t)id, it->first)))
+          it->second += w;
+        else
+          v.insert(it, std::make_pair((uint32_t)id, w));
+        fv[(uint32_t)nid].push_back((uint32_t)i);
+      }
+    }
+    if (!v.empty() && !must) {
+      const double nd = v.size();
+      for (auto& kv : v) kv.second /= nd;
+    }
+  } else {
+    for (int i = 0; i < n; ++i) {
+      int id, nid;
+      double w;
+      bow_transform_one(voc, features + (size_t)i * 32, levelsup, &id, &w, &nid);
+      if (w > 0) {
+        auto it = v.lower_bound((uint32_t)id);  // addIfNotExist
+        if (it == v.end() || v.key_comp()((uint32_t)id, it->first)) v.insert(it, std::make_pair((uint32_t)id, w));
+        fv[(uint32_t)nid].push_back((uint32_t)i);
+      }
+    }
+  }
+  if (must) {
+    double norm = 0.0;
+    if (voc.normalize == 1) {
+      for (auto& kv : v) norm += fabs(kv.second);
+    } else {
+      for (auto& kv : v) norm += kv.second * kv.second;
+      norm = sqrt(norm);
+    }
+    if (norm > 0.0)
+      for (auto& kv : v) kv.second /= norm;
+  }
+  bow_out.assign(v.begin(), v.end());
+  fv_out.assign(fv.begin(), fv.end());
 }
 
 }  // namespace orc

@@ -200,6 +200,33 @@ void orc_project_points(int mode, const float* cam, int n, const float* xyz, con
   }
 }
 
+int orc_bow_transform(int n_nodes, const int32_t* child_start, const int32_t* children, const uint8_t* descriptor, const int32_t* word_id,
+                      const double* weight, int L, int weighting, int normalize, const uint8_t* features, int n, int levelsup,
+                      int32_t* out_word, double* out_weight, int32_t* out_node, uint32_t* bow_id, double* bow_value, int* n_bow,
+                      uint32_t* fv_node, int32_t* fv_start, int32_t* fv_feat, int* n_fv) {
+  Vocabulary V{n_nodes, child_start, children, descriptor, word_id, weight, L, weighting, normalize};
+  for (int i = 0; i < n; ++i) {
+    int id, nid;
+    double w;
+    bow_transform_one(V, features + (size_t)i * 32, levelsup, &id, &w, &nid);
+    out_word[i] = id, out_weight[i] = w, out_node[i] = nid;
+  }
+  std::vector<std::pair<uint32_t, double>> bow;
+  std::vector<std::pair<uint32_t, std::vector<uint32_t>>> fv;
+  bow_transform(V, features, n, levelsup, bow, fv);
+  for (size_t k = 0; k < bow.size(); ++k) bow_id[k] = bow[k].first, bow_value[k] = bow[k].second;
+  *n_bow = (int)bow.size();
+  int off = 0;
+  for (size_t j = 0; j < fv.size(); ++j) {
+    fv_node[j] = fv[j].first;
+    fv_start[j] = off;
+    for (uint32_t f : fv[j].second) fv_feat[off++] = (int32_t)f;
+  }
+  fv_start[fv.size()] = off;
+  *n_fv = (int)fv.size();
+  return 0;
+}
+
 void orc_compute_three_maxima(const int* sizes, int L, int* ind) {
   int a = -1, b = -1, c = -1;
   compute_three_maxima(sizes, L, a, b, c);

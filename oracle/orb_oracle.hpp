@@ -17,6 +17,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 namespace orc {
@@ -155,5 +156,23 @@ bool project_kf_reloc(const Camera& F, const float* x3Dw, float mfMinDistance, c
 // Fuse src/ORBmatcher.cc:1037-1075
 bool project_fuse(const Camera& K, const float* p3Dw, const float* Pn, float mfMinDistance, float mfMaxDistance, const float* scaleFactors,
                   int nScaleLevels, float* u, float* v, int* level);
+
+
+// ---- DBoW2 bag-of-words transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1125-1258, BowVector.cpp, FeatureVector.cpp) ----
+struct Vocabulary {  // m_nodes flattened: children of node i = children[child_start[i] .. child_start[i+1])
+  int n_nodes;
+  const int32_t* child_start;
+  const int32_t* children;
+  const uint8_t* descriptor;
+  const int32_t* word_id;
+  const double* weight;
+  int L, weighting /* 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY */, normalize /* 0 none, 1 L1, 2 L2 */;
+};
+// transform(feature, word_id, weight, nid, levelsup) :1207-1258.  nid is left unset by the reference when the descent ends above
+// level L - levelsup; declared here: the leaf.
+void bow_transform_one(const Vocabulary& voc, const uint8_t* feature, int levelsup, int* word_id, double* weight, int* nid);
+// transform(features, v, fv, levelsup) :1125-1188; outputs flattened in map order
+void bow_transform(const Vocabulary& voc, const uint8_t* features, int n, int levelsup, std::vector<std::pair<uint32_t, double>>& bow,
+                   std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& fv);
 
 }  // namespace orc

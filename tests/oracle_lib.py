@@ -56,6 +56,7 @@ class Oracle:
         L.orc_search_for_triangulation.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp]
         L.orc_fuse_search.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp]
         L.orc_compute_three_maxima.argtypes = [vp, ci, vp]
+        L.orc_bow_transform.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_project_points.argtypes = [ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp, vp]
 
     # ---- extractor ----
@@ -213,6 +214,25 @@ class Oracle:
                                   None if us is None else us.ctypes.data, sf.ctypes.data, len(sf), float(scale_factor), float(cos_limit),
                                   valid.ctypes.data, u.ctypes.data, v.ctypes.data, level.ctypes.data, vc.ctypes.data)
         return valid, u, v, level, vc
+
+    def bow_transform(self, voc, desc, levelsup=4):
+        """voc = dict(child_start, children, descriptor, word_id, weight, L, weighting, normalize).
+        Returns (word_id, weight, node_id, (bow ids, bow values), {node: [features]})."""
+        cs, ch = np.ascontiguousarray(voc["child_start"], np.int32), np.ascontiguousarray(voc["children"], np.int32)
+        de, wi = np.ascontiguousarray(voc["descriptor"], np.uint8), np.ascontiguousarray(voc["word_id"], np.int32)
+        we = np.ascontiguousarray(voc["weight"], np.float64)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        wid, nid, ww = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.float64)
+        bid, bval = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.float64)
+        fnode, fstart, ffeat = np.zeros(max(n, 1), np.uint32), np.zeros(n + 2, np.int32), np.zeros(max(n, 1), np.int32)
+        nb, nf = ctypes.c_int(), ctypes.c_int()
+        self.L.orc_bow_transform(len(cs) - 1, cs.ctypes.data, ch.ctypes.data, de.ctypes.data, wi.ctypes.data, we.ctypes.data, int(voc["L"]),
+                                 int(voc["weighting"]), int(voc["normalize"]), desc.ctypes.data, n, int(levelsup), wid.ctypes.data, ww.ctypes.data,
+                                 nid.ctypes.data, bid.ctypes.data, bval.ctypes.data, ctypes.byref(nb), fnode.ctypes.data, fstart.ctypes.data,
+                                 ffeat.ctypes.data, ctypes.byref(nf))
+        groups = {int(fnode[j]): [int(x) for x in ffeat[fstart[j]:fstart[j + 1]]] for j in range(nf.value)}
+        return wid, ww, nid, (bid[:nb.value].copy(), bval[:nb.value].copy()), groups
 
     def compute_three_maxima(self, sizes):
         s = np.ascontiguousarray(sizes, np.int32)

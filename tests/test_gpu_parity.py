@@ -563,3 +563,71 @@ def test_frustum_then_search_by_projection_chain(uvo, oracle, synth):
     np.testing.assert_array_equal(a_g, a_o)
     assert nm_g == nm_o and nm_g > 300 and ov.sum() > 3000
     m.close()
+
+
+def _random_vocabulary(rng, k=10, L=4, weighting=0, normalize=1):
+    """A k-ary tree of depth <= L whose node descriptors are noisy copies of their parent's (so the descent is meaningful);
+    ~5 % of the inner candidates stop early as leaves, ~5 % of the words are stop words (weight 0)."""
+    desc, children, level = [np.zeros(32, np.uint8)], [[]], [0]
+    frontier = [0]
+    for lvl in range(1, L + 1):
+        nxt = []
+        for p in frontier:
+            base = rng.integers(0, 256, 32, dtype=np.uint8) if p == 0 else desc[p]
+            for _ in range(k):
+                flips = rng.random(256) < (0.25 if lvl == 1 else 0.08)
+                d = np.packbits(np.unpackbits(base) ^ flips)
+                if lvl > 1 and rng.random() < 0.02:
+                    d = desc[children[p][-1]].copy() if children[p] else d        # duplicate sibling: a tie the first child must win
+                desc.append(d), children.append([]), level.append(lvl)
+                children[p].append(len(desc) - 1)
+                if lvl < L and rng.random() > 0.05:
+                    nxt.append(len(desc) - 1)
+        frontier = nxt
+    n = len(desc)
+    child_start = np.zeros(n + 1, np.int32)
+    flat = []
+    for i in range(n):
+        flat.extend(children[i])
+        child_start[i + 1] = len(flat)
+    word_id = np.full(n, -1, np.int32)
+    leaves = [i for i in range(n) if not children[i]]
+    word_id[leaves] = np.arange(len(leaves))
+    weight = np.zeros(n)
+    weight[leaves] = np.where(rng.random(len(leaves)) < 0.05, 0.0, rng.uniform(0.5, 9.0, len(leaves)))
+    return dict(child_start=child_start, children=np.asarray(flat, np.int32), descriptor=np.stack(desc), word_id=word_id, weight=weight, L=L,
+                weighting=weighting, normalize=normalize)
+
+
+@pytest.mark.parametrize("weighting,normalize", [(0, 1), (0, 2), (1, 0), (2, 1), (3, 0)])
+def test_bow_transform(uvo, oracle, synth, weighting, normalize):
+    """DBoW2 TemplatedVocabulary::transform on the device against its restatement; then both feature vectors through SearchByBoW."""
+    rng = np.random.default_rng(50 + weighting)
+    voc = _random_vocabulary(rng, 10, 4, weighting, normalize)
+    kp1, de1, kp2, de2, sf = _two_views(uvo, synth, 4500)
+    # descriptors that resemble vocabulary nodes (so that the descent is not a coin toss) mixed with the real ones
+    leaf_desc = voc["descriptor"][voc["word_id"] >= 0]
+    near = np.packbits(np.unpackbits(leaf_desc[rng.integers(0, len(leaf_desc), 500)], axis=1) ^ (rng.random((500, 256)) < 0.05), axis=1)
+    V = uvo.ORBVocabulary(voc["child_start"], voc["children"], voc["descriptor"], voc["word_id"], voc["weight"], voc["L"], weighting, normalize)
+    for feats in (np.concatenate([de1, near]), de2[:1], de2[:0]):
+        for levelsup in (0, 2, 4, 6):
+            g = V.transform(feats, levelsup)
+            o = oracle.bow_transform(voc, feats, levelsup)
+            np.testing.assert_array_equal(g[0], o[0])
+            np.testing.assert_array_equal(g[2], o[2])
+            np.testing.assert_array_equal(g[1].view(np.uint64), o[1].view(np.uint64))
+            np.testing.assert_array_equal(g[3][0], o[3][0])
+            np.testing.assert_array_equal(g[3][1].view(np.uint64), o[3][1].view(np.uint64))     # BowVector values bit for bit
+            fvg = {int(g[4].node[j]): [int(x) for x in g[4].feat[g[4].start[j]:g[4].start[j + 1]]] for j in range(len(g[4].node))}
+            assert fvg == o[4]
+    # the chain the reference runs: ComputeBoW on both sides, then SearchByBoW
+    f1, f2 = V.transform(de1, 2), V.transform(de2, 2)
+    o1, o2 = oracle.bow_transform(voc, de1, 2), oracle.bow_transform(voc, de2, 2)
+    m = uvo.ORBmatcher(0.8, True)
+    usable1 = np.ones(len(de1), np.uint8)
+    mg, ng = m.SearchByBoW(f1[4], de1, kp1["angle"], usable1, f2[4], de2, kp2["angle"])
+    mo, no = oracle.search_by_bow(False, o1[4], de1, kp1["angle"], usable1, o2[4], de2, kp2["angle"], None, 0.8, True)
+    np.testing.assert_array_equal(mg, mo)
+    assert ng == no
+    m.close()
+    V.close()

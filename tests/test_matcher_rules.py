@@ -302,3 +302,45 @@ def test_projection_prologues_by_hand(oracle):
     assert valid.tolist() == [1, 1, 0, 0, 0, 0] and lvl[0] == 6
     valid, *_ = oracle.project_points(2, cam, P, Pn, mn, mx, [0, 1, 1, 1, 1, 1], sf)
     assert valid.tolist() == [0, 1, 0, 0, 0, 0]
+
+
+# ---- DBoW2 transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1125-1258) ---------------------------------------------
+def _toy_vocabulary(weighting=0, normalize=1):
+    """Root 0 -> {1, 2}; 1 -> leaves {3, 4}; 2 -> leaf {5} and inner 6 -> leaves {7, 8}.  Descriptors: byte 0 carries the value."""
+    d = np.zeros((9, 32), np.uint8)
+    d[1, 0], d[2, 0] = 0x00, 0xFF
+    d[3, 0], d[4, 0] = 0x00, 0x0F
+    d[5, 0], d[6, 0] = 0xFF, 0xF0
+    d[7, 0], d[8, 0] = 0xF0, 0xF1
+    return dict(child_start=[0, 2, 4, 6, 6, 6, 6, 8, 8, 8], children=[1, 2, 3, 4, 5, 6, 7, 8], descriptor=d,
+                word_id=[-1, -1, -1, 0, 1, 2, -1, 3, 4], weight=[0, 0, 0, 1.0, 2.0, 0.0, 0, 0.5, 4.0], L=3, weighting=weighting,
+                normalize=normalize)
+
+
+def test_bow_transform_by_hand(oracle):
+    voc = _toy_vocabulary()
+    f = np.zeros((5, 32), np.uint8)
+    f[:, 0] = [0x01, 0x0E, 0xFF, 0xF1, 0x0F]
+    # f0 = 0x01: level 1 -> node 1 (d 1 vs 7); level 2: node 3 (d 1) vs node 4 (0x0F: d 3) -> word 0
+    # f1 = 0x0E: node 1 (3 vs 5); node 3 (d 3) vs node 4 (d 1) -> word 1
+    # f2 = 0xFF: node 2; node 5 (d 0) vs node 6 (d 4) -> word 2, weight 0: stopped, enters neither container
+    # f3 = 0xF1: node 2 (d 3 vs 5 for node 1); node 5 (0xFF: d 3) vs node 6 (0xF0: d 1) -> 6; node 7 (d 1) vs node 8 (d 0) -> word 4
+    # f4 = 0x0F: node 1 (d 4) vs node 2 (d 4): tie -> first child, node 1; node 3 (d 4) vs node 4 (d 0) -> word 1
+    wid, ww, nid, (bid, bval), fv = oracle.bow_transform(voc, f, levelsup=2)     # nid level = L - 2 = 1
+    assert wid.tolist() == [0, 1, 2, 4, 1] and ww.tolist() == [1.0, 2.0, 0.0, 4.0, 2.0]
+    assert nid.tolist() == [1, 1, 2, 2, 1]
+    assert bid.tolist() == [0, 1, 4]
+    np.testing.assert_array_equal(bval, np.array([1.0, 4.0, 4.0]) / 9.0)            # TF-IDF accumulates, then L1
+    assert fv == {1: [0, 1, 4], 2: [3]}
+    # levelsup = 1 -> nid level 2: f2 / f3 differ (5 is a leaf at level 2, 6 an inner node)
+    _, _, nid, _, fv = oracle.bow_transform(voc, f, levelsup=1)
+    assert nid.tolist() == [3, 4, 5, 6, 4] and fv == {3: [0], 4: [1, 4], 6: [3]}
+    # levelsup >= L -> root for everybody
+    _, _, nid, _, fv = oracle.bow_transform(voc, f, levelsup=3)
+    assert nid.tolist() == [0, 0, 0, 0, 0] and fv == {0: [0, 1, 3, 4]}
+    # BINARY weighting without normalisation: first occurrence only
+    _, _, _, (bid, bval), _ = oracle.bow_transform(_toy_vocabulary(3, 0), f, levelsup=2)
+    assert bid.tolist() == [0, 1, 4] and bval.tolist() == [1.0, 2.0, 4.0]
+    # TF without normalisation divides by the number of distinct words
+    _, _, _, (bid, bval), _ = oracle.bow_transform(_toy_vocabulary(1, 0), f, levelsup=2)
+    np.testing.assert_array_equal(bval, np.array([1.0, 4.0, 4.0]) / 3.0)

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "uvo_grider_fast", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
-    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
+    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
     "uvo_matcher_kernel_times", "uvo_last_error", "uvo_device_info",
 ]
 
@@ -149,6 +149,10 @@ def _load():
     lib.uvo_search_by_bow.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, cf, ci, vp, vp]
     lib.uvo_search_for_triangulation.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp]
     lib.uvo_project_points.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp, vp]
+    lib.uvo_vocabulary_create.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.uvo_vocabulary_destroy.argtypes = [vp]
+    lib.uvo_vocabulary_destroy.restype = None
+    lib.uvo_bow_transform.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp]
     lib.uvo_fuse.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, vp, vp]
     lib.uvo_matcher_wait_extractor.argtypes = [vp, vp]
     lib.uvo_extractor_wait_matcher.argtypes = [vp, vp]
@@ -551,6 +555,56 @@ class ORBmatcher:
         if rc:
             raise UvoError(rc, "uvo_fuse")
         return bi, bd
+
+
+class VocabularyDesc(ctypes.Structure):
+    """uvo_vocabulary_desc."""
+    _fields_ = [("n_nodes", ctypes.c_int32), ("child_start", ctypes.c_void_p), ("children", ctypes.c_void_p), ("descriptor", ctypes.c_void_p),
+                ("word_id", ctypes.c_void_p), ("weight", ctypes.c_void_p), ("L", ctypes.c_int32), ("weighting", ctypes.c_int32),
+                ("normalize", ctypes.c_int32), ("device", ctypes.c_int32)]
+
+
+class ORBVocabulary:
+    """DBoW2 ORBVocabulary stand-in holding the tree on the device: transform() = TemplatedVocabulary::transform
+    (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1125-1258).  Tree given flat: children of node i =
+    children[child_start[i]:child_start[i+1]] (node 0 = root), descriptor[n_nodes][32], word_id[n_nodes], weight[n_nodes]."""
+    TF_IDF, TF, IDF, BINARY = range(4)
+
+    def __init__(self, child_start, children, descriptor, word_id, weight, L, weighting=0, normalize=1, device=0):
+        self._k = [np.ascontiguousarray(child_start, np.int32), np.ascontiguousarray(children, np.int32), np.ascontiguousarray(descriptor, np.uint8),
+                   np.ascontiguousarray(word_id, np.int32), np.ascontiguousarray(weight, np.float64)]
+        d = VocabularyDesc(len(self._k[0]) - 1, _ptr(self._k[0]), _ptr(self._k[1]), _ptr(self._k[2]), _ptr(self._k[3]), _ptr(self._k[4]), int(L),
+                           int(weighting), int(normalize), int(device))
+        self._h = ctypes.c_void_p()
+        rc = lib.uvo_vocabulary_create(ctypes.byref(d), ctypes.byref(self._h))
+        if rc:
+            raise UvoError(rc, "uvo_vocabulary_create")
+
+    def close(self):
+        if self._h:
+            lib.uvo_vocabulary_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def transform(self, desc, levelsup=4):
+        """Returns (word_id[n], weight[n], node_id[n], BowVector as (ids, values), FeatureVector)."""
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        wid, nid, ww = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.float64)
+        bid, bval = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.float64)
+        fnode, fstart, ffeat = np.zeros(max(n, 1), np.uint32), np.zeros(n + 2, np.int32), np.zeros(max(n, 1), np.int32)
+        nb, nf = ctypes.c_int(), ctypes.c_int()
+        rc = lib.uvo_bow_transform(self._h, _ptr(desc), n, int(levelsup), _ptr(wid), _ptr(ww), _ptr(nid), _ptr(bid), _ptr(bval), len(bid), ctypes.byref(nb),
+                                   _ptr(fnode), _ptr(fstart), _ptr(ffeat), len(fnode), ctypes.byref(nf))
+        if rc:
+            raise UvoError(rc, "uvo_bow_transform")
+        groups = {int(fnode[j]): [int(x) for x in ffeat[fstart[j]:fstart[j + 1]]] for j in range(nf.value)}
+        return wid, ww, nid, (bid[:nb.value].copy(), bval[:nb.value].copy()), FeatureVector(groups)
 
 
 def DescriptorDistance(a, b):
