@@ -128,6 +128,18 @@ int uvo_extractor_set_pipeline(uvo_extractor* h, int depth);
 int uvo_grider_fast(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdiff_t stride, int num_features, int grid_x, int grid_y,
                     int threshold, int nonmax_suppression, uvo_keypoint* out_kp, int cap, int* n_out);
 
+/*
+ * cv::CLAHE::apply (8-bit), the pre-processing of Tracking::GrabImage when Enhance = 1 (src/Tracking.cc:425-431: clip limit 4,
+ * 12 x 12 tiles): per-tile clipped histogram LUTs on the image extended by REFLECT_101 to a multiple of the tile grid, then the
+ * bilinear blend of the four neighbouring LUTs per pixel.  In place is allowed (dst == src, same strides).
+ * uvo_clahe: host buffers, one frame.  uvo_clahe_batch_device: HBM-resident, enqueued on the stream the next
+ * uvo_extract_batch_device() call of this handle will use, so that enhance -> extract needs no synchronisation in between.
+ */
+int uvo_clahe(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdiff_t stride, double clip_limit, int tiles_x, int tiles_y,
+              uint8_t* dst, ptrdiff_t dst_stride);
+int uvo_clahe_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
+                           double clip_limit, int tiles_x, int tiles_y, uint8_t* d_dst, ptrdiff_t dst_stride, ptrdiff_t dst_frame_stride);
+
 /* Stage taps for the parity tests (valid after a completed extract call; host destination buffers). */
 int uvo_extractor_level_dims(const uvo_extractor* h, int level, int* width, int* height);
 /* padded plane (width+32) x (height+32), tight rows; which: 0 = pyramid level, 1 = blurred level */

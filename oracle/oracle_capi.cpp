@@ -227,6 +227,10 @@ int orc_bow_transform(int n_nodes, const int32_t* child_start, const int32_t* ch
   return 0;
 }
 
+void orc_clahe(const uint8_t* img, int w, int h, long stride, double clip, int tx, int ty, uint8_t* dst, long dstep) {
+  clahe_apply(View{const_cast<uint8_t*>(img), w, h, (ptrdiff_t)stride}, clip, tx, ty, dst, (ptrdiff_t)dstep);
+}
+
 void orc_compute_three_maxima(const int* sizes, int L, int* ind) {
   int a = -1, b = -1, c = -1;
   compute_three_maxima(sizes, L, a, b, c);

@@ -689,4 +689,100 @@ void grider_fast(const View& img, std::vector<KeyPoint>& pts, int num_features, 
   }
 }
 
+// ---- cv::CLAHE (8-bit) ----
+void clahe_apply(const View& src, double clipLimit_, int tilesX_, int tilesY_, uint8_t* dst, ptrdiff_t dstep) {
+  const int histSize = 256;
+  // CLAHE_Impl::apply: extend to a multiple of the tile grid when needed
+  std::vector<uint8_t> ext;
+  View srcForLut = src;
+  int tileW, tileH;
+  if (src.w % tilesX_ == 0 && src.h % tilesY_ == 0) {
+    tileW = src.w / tilesX_, tileH = src.h / tilesY_;
+  } else {
+    const int bottom = tilesY_ - (src.h % tilesY_), right = tilesX_ - (src.w % tilesX_);
+    const int ew = src.w + right, eh = src.h + bottom;
+    ext.resize((size_t)ew * eh);
+    copy_make_border_reflect101(src, ext.data(), ew, 0, bottom, 0, right);
+    srcForLut = View{ext.data(), ew, eh, ew};
+    tileW = ew / tilesX_, tileH = eh / tilesY_;
+  }
+  const int tileSizeTotal = tileW * tileH;
+  const float lutScale = static_cast<float>(histSize - 1) / tileSizeTotal;
+  int clipLimit = 0;
+  if (clipLimit_ > 0.0) {
+    clipLimit = static_cast<int>(clipLimit_ * tileSizeTotal / histSize);
+    clipLimit = std::max(clipLimit, 1);
+  }
+  std::vector<uint8_t> lut((size_t)tilesX_ * tilesY_ * histSize);
+  // CLAHE_CalcLut_Body
+  for (int k = 0; k < tilesX_ * tilesY_; ++k) {
+    const int ty = k / tilesX_, tx = k % tilesX_;
+    uint8_t* tileLut = &lut[(size_t)k * histSize];
+    int tileHist[256] = {0};
+    for (int y = 0; y < tileH; ++y) {
+      const uint8_t* ptr = srcForLut.row(ty * tileH + y) + tx * tileW;
+      for (int x = 0; x < tileW; ++x) tileHist[ptr[x]]++;
+    }
+    if (clipLimit > 0) {
+      int clipped = 0;
+      for (int i = 0; i < histSize; ++i) {
+        if (tileHist[i] > clipLimit) {
+          clipped += tileHist[i] - clipLimit;
+          tileHist[i] = clipLimit;
+        }
+      }
+      int redistBatch = clipped / histSize;
+      int residual = clipped - redistBatch * histSize;
+      for (int i = 0; i < histSize; ++i) tileHist[i] += redistBatch;
+      if (residual != 0) {
+        int residualStep = std::max(histSize / residual, 1);
+        for (int i = 0; i < histSize && residual > 0; i += residualStep, residual--) tileHist[i]++;
+      }
+    }
+    int sum = 0;
+    for (int i = 0; i < histSize; ++i) {
+      sum += tileHist[i];
+      int v = cv_round_f(sum * lutScale);  // saturate_cast<uchar>(float)
+      tileLut[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+  }
+  // CLAHE_Interpolation_Body
+  std::vector<int> ind1_p(src.w), ind2_p(src.w);
+  std::vector<float> xa_p(src.w), xa1_p(src.w);
+  const int lut_step = histSize;
+  float inv_tw = 1.0f / tileW;
+  for (int x = 0; x < src.w; ++x) {
+    float txf = x * inv_tw - 0.5f;
+    int tx1 = (int)floorf(txf);
+    int tx2 = tx1 + 1;
+    xa_p[x] = txf - tx1;
+    xa1_p[x] = 1.0f - xa_p[x];
+    tx1 = std::max(tx1, 0);
+    tx2 = std::min(tx2, tilesX_ - 1);
+    ind1_p[x] = tx1 * lut_step;
+    ind2_p[x] = tx2 * lut_step;
+  }
+  float inv_th = 1.0f / tileH;
+  for (int y = 0; y < src.h; ++y) {
+    const uint8_t* srcRow = src.row(y);
+    uint8_t* dstRow = dst + (ptrdiff_t)y * dstep;
+    float tyf = y * inv_th - 0.5f;
+    int ty1 = (int)floorf(tyf);
+    int ty2 = ty1 + 1;
+    float ya = tyf - ty1, ya1 = 1.0f - ya;
+    ty1 = std::max(ty1, 0);
+    ty2 = std::min(ty2, tilesY_ - 1);
+    const uint8_t* lutPlane1 = &lut[(size_t)ty1 * tilesX_ * histSize];
+    const uint8_t* lutPlane2 = &lut[(size_t)ty2 * tilesX_ * histSize];
+    for (int x = 0; x < src.w; ++x) {
+      int srcVal = srcRow[x];
+      int ind1 = ind1_p[x] + srcVal;
+      int ind2 = ind2_p[x] + srcVal;
+      float res = (lutPlane1[ind1] * xa1_p[x] + lutPlane1[ind2] * xa_p[x]) * ya1 + (lutPlane2[ind1] * xa1_p[x] + lutPlane2[ind2] * xa_p[x]) * ya;
+      int v = cv_round_f(res);
+      dstRow[x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+  }
+}
+
 }  // namespace orc

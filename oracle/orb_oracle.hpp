@@ -44,6 +44,9 @@ int cv_round_f(float v);   // cvRound(float): round half to even
 int cv_round_d(double v);  // cvRound(double)
 
 // ---- OpenCV primitives (restated, [OCV-RECALL]) ----
+// cv::CLAHE::apply for CV_8UC1 (OpenCV 3.4 imgproc/src/clahe.cpp: CLAHE_Impl::apply, CLAHE_CalcLut_Body, CLAHE_Interpolation_Body)
+// [OCV-RECALL]; call site src/Tracking.cc:425-431 (clip limit 4, 12 x 12 tiles).  dst may alias src.
+void clahe_apply(const View& src, double clipLimit, int tilesX, int tilesY, uint8_t* dst, ptrdiff_t dstep);
 void copy_make_border_reflect101(const View& src, uint8_t* dst, ptrdiff_t dstep, int top, int bottom, int left, int right);
 void resize_linear_u8(const View& src, const View& dst);
 void fast9_16(const View& img, int threshold, bool nms, std::vector<KeyPoint>& out);

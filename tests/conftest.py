@@ -23,6 +23,15 @@ def oracle():
 @pytest.fixture(scope="session")
 def uvo():
     """The product package (ctypes over libuvo.so).  GPU tests fail loudly if the HIP library is missing."""
+    # Some tests hand torch device buffers to the library.  torch ships its own copy of the HIP runtime; when the system runtime
+    # (libuvo's) has already opened the GPU, torch's copy can come up with "No HIP GPUs are available" -- so let torch
+    # initialise first, as bench.py does.  CPU-only runs skip this (is_available() is False there).
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except ImportError:
+        pass
     return importlib.import_module("u-vip-slam_amd")
 
 

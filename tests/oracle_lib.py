@@ -56,6 +56,7 @@ class Oracle:
         L.orc_search_for_triangulation.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp]
         L.orc_fuse_search.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp]
         L.orc_compute_three_maxima.argtypes = [vp, ci, vp]
+        L.orc_clahe.argtypes = [vp, ci, ci, cl, ctypes.c_double, ci, ci, vp, cl]
         L.orc_bow_transform.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_project_points.argtypes = [ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp, vp]
 
@@ -76,6 +77,13 @@ class Oracle:
         h, w = img.shape
         out = np.zeros((dh, dw), np.uint8)
         self.L.orc_resize_linear(img.ctypes.data, w, h, img.strides[0], out.ctypes.data, dw, dh)
+        return out
+
+    def clahe(self, img, clip_limit=4.0, tiles=(12, 12)):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.empty_like(img)
+        self.L.orc_clahe(img.ctypes.data, w, h, img.strides[0], float(clip_limit), int(tiles[0]), int(tiles[1]), out.ctypes.data, out.strides[0])
         return out
 
     def fast(self, img, threshold, nms=True, bruteforce=False):

@@ -631,3 +631,38 @@ def test_bow_transform(uvo, oracle, synth, weighting, normalize):
     assert ng == no
     m.close()
     V.close()
+
+
+def test_clahe(uvo, oracle, synth):
+    """cv::CLAHE::apply (src/Tracking.cc:425-431) on the device: host entry, in-place HBM-resident batch, then extraction."""
+    import torch
+    rng = np.random.default_rng(60)
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=768, max_height=512, max_batch=3)
+    for (w, h), tiles, clip in (((640, 512), (12, 12), 4.0), ((752, 480), (8, 8), 4.0), ((637, 509), (12, 12), 2.0), ((320, 256), (4, 7), 0.0),
+                                ((768, 512), (16, 16), 40.0)):
+        img = synth.make_frame(900 + w, w, h)
+        img = (img.astype(np.float32) * rng.uniform(0.2, 0.5) + 20).astype(np.uint8)          # dim, low contrast: the underwater case
+        np.testing.assert_array_equal(ex.clahe(img, clip, tiles), oracle.clahe(img, clip, tiles), err_msg=str((w, h, tiles, clip)))
+    flat = np.full((512, 640), 10, np.uint8)
+    np.testing.assert_array_equal(ex.clahe(flat), oracle.clahe(flat))
+    # enhance -> extract without leaving the device, in place, 3 frames
+    B, W, H = 3, 640, 512
+    frames = np.stack([(synth.make_frame(1200 + i, W, H).astype(np.float32) * 0.3 + 30).astype(np.uint8) for i in range(B)])
+    d = torch.from_numpy(frames).cuda()
+    ex.clahe_batch_device(d.data_ptr(), B, W, H, d.data_ptr())
+    cap = ex.cap
+    kp = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    de = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d.data_ptr(), B, W, H, kp.data_ptr(), de.data_ptr(), n.data_ptr(), cap)
+    ex.synchronize()
+    enhanced = d.cpu().numpy()
+    oe = oracle.extractor(1000, 1.2, 8, 20)
+    for b in range(B):
+        ref = oracle.clahe(frames[b])
+        np.testing.assert_array_equal(enhanced[b], ref)
+        kp_o, de_o = oe(ref)
+        nb = int(n[b])
+        assert nb == len(kp_o)
+        np.testing.assert_array_equal(de[b, :nb].cpu().numpy(), de_o)
+    ex.close()

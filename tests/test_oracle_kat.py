@@ -430,3 +430,59 @@ def test_grider_fast(oracle, synth):
     for c in range(40):  # inside a cell: response descending
         r = pts["response"][(cy * 8 + cx) == c]
         assert (np.diff(r) <= 0).all()
+
+
+# ---- CLAHE (cv::CLAHE::apply, src/Tracking.cc:425-431) ------------------------------------------------------------------
+def _clahe_numpy(img, clip_limit, tiles):
+    """Independent numpy statement of OpenCV 3.4's 8-bit CLAHE (vectorised differently from the oracle's loops)."""
+    tx, ty = tiles
+    h, w = img.shape
+    if w % tx == 0 and h % ty == 0:
+        ext = img
+    else:
+        ext = np.pad(img, ((0, ty - h % ty), (0, tx - w % tx)), mode="reflect")
+    tw, th = ext.shape[1] // tx, ext.shape[0] // ty
+    total = tw * th
+    scale = np.float32(255) / np.float32(total)
+    clip = max(int(clip_limit * total / 256), 1) if clip_limit > 0 else 0
+    luts = np.zeros((ty, tx, 256), np.float32)
+    for j in range(ty):
+        for i in range(tx):
+            hist = np.bincount(ext[j * th:(j + 1) * th, i * tw:(i + 1) * tw].ravel(), minlength=256).astype(np.int64)
+            if clip > 0:
+                clipped = int(np.maximum(hist - clip, 0).sum())
+                hist = np.minimum(hist, clip) + clipped // 256
+                residual = clipped % 256
+                if residual:
+                    step = max(256 // residual, 1)
+                    idx = np.arange(0, 256, step)[:residual]
+                    hist[idx] += 1
+            luts[j, i] = np.clip(np.rint(np.cumsum(hist).astype(np.float32) * scale), 0, 255)
+    xs, ys = np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32)
+    txf = xs * (np.float32(1) / np.float32(tw)) - np.float32(0.5)
+    tyf = ys * (np.float32(1) / np.float32(th)) - np.float32(0.5)
+    tx1, ty1 = np.floor(txf).astype(int), np.floor(tyf).astype(int)
+    xa, ya = (txf - tx1.astype(np.float32)).astype(np.float32), (tyf - ty1.astype(np.float32)).astype(np.float32)
+    xa1, ya1 = np.float32(1) - xa, np.float32(1) - ya
+    tx2, ty2 = np.minimum(tx1 + 1, tx - 1), np.minimum(ty1 + 1, ty - 1)
+    tx1, ty1 = np.maximum(tx1, 0), np.maximum(ty1, 0)
+    v = img.astype(int)
+    p11, p12 = luts[ty1[:, None], tx1[None, :], v], luts[ty1[:, None], tx2[None, :], v]
+    p21, p22 = luts[ty2[:, None], tx1[None, :], v], luts[ty2[:, None], tx2[None, :], v]
+    res = (p11 * xa1[None, :] + p12 * xa[None, :]) * ya1[:, None] + (p21 * xa1[None, :] + p22 * xa[None, :]) * ya[:, None]
+    return np.clip(np.rint(res.astype(np.float32)), 0, 255).astype(np.uint8)
+
+
+def test_clahe_by_hand_and_against_numpy(oracle, synth):
+    flat = np.full((8, 8), 10, np.uint8)
+    # 2 x 2 tiles of 16 px, no clipping: lut = 0 below 10, 255 from 10 on
+    assert (oracle.clahe(flat, 0.0, (2, 2)) == 255).all()
+    # clip limit 40 -> int(40 * 16 / 256) = 2: 14 px clipped, residual 14 spread over bins 0, 18, ..., 234 -> lut[10] = round(3 * 255 / 16) = 48
+    assert (oracle.clahe(flat, 40.0, (2, 2)) == 48).all()
+    rng = np.random.default_rng(17)
+    for shape, tiles, clip in (((64, 96), (4, 4), 4.0), ((61, 93), (4, 4), 4.0), ((96, 120), (12, 12), 4.0), ((50, 70), (3, 5), 2.0),
+                               ((48, 48), (6, 6), 0.0), ((40, 64), (8, 8), 40.0)):
+        img = (rng.integers(0, 256, shape) * rng.random(shape) ** 2).astype(np.uint8)      # skewed histogram: clipping matters
+        np.testing.assert_array_equal(oracle.clahe(img, clip, tiles), _clahe_numpy(img, clip, tiles), err_msg=str((shape, tiles, clip)))
+    img = synth.make_frame(5, 640, 512)
+    np.testing.assert_array_equal(oracle.clahe(img, 4.0, (12, 12)), _clahe_numpy(img, 4.0, (12, 12)))

@@ -27,7 +27,7 @@ UVO_OK, UVO_E_BADARG, UVO_E_NODEVICE, UVO_E_HIP, UVO_E_CAPACITY, UVO_E_UNSUPPORT
 ABI_SYMBOLS = [
     "uvo_extractor_create", "uvo_extractor_destroy", "uvo_extractor_levels", "uvo_extractor_scale_factor", "uvo_extractor_tables",
     "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_level_dims",
-    "uvo_grider_fast", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
+    "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
     "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
@@ -129,6 +129,8 @@ def _load():
     lib.uvo_extractor_synchronize.argtypes = [vp]
     lib.uvo_extractor_set_pipeline.argtypes = [vp, ci]
     lib.uvo_extractor_level_dims.argtypes = [vp, ci, vp, vp]
+    lib.uvo_clahe.argtypes = [vp, vp, ci, ci, cl, ctypes.c_double, ci, ci, vp, cl]
+    lib.uvo_clahe_batch_device.argtypes = [vp, ci, vp, ci, ci, cl, cl, ctypes.c_double, ci, ci, vp, cl, cl]
     lib.uvo_grider_fast.argtypes = [vp, vp, ci, ci, cl, ci, ci, ci, ci, ci, vp, ci, vp]
     lib.uvo_extractor_read_plane.argtypes = [vp, ci, ci, ci, vp]
     lib.uvo_extractor_read_candidates.argtypes = [vp, ci, ci, vp, ci, vp]
@@ -296,6 +298,22 @@ class ORBextractor:
         if rc:
             raise UvoError(rc, "uvo_extractor_level_dims")
         return w.value, h.value
+
+    def clahe(self, img, clip_limit=4.0, tiles=(12, 12)):
+        """cv::CLAHE::apply as set up at src/Tracking.cc:425-431 (clip limit 4, 12 x 12 tiles); returns the enhanced image."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.empty_like(img)
+        rc = lib.uvo_clahe(self._h, _ptr(img), w, h, img.strides[0], float(clip_limit), int(tiles[0]), int(tiles[1]), _ptr(out), out.strides[0])
+        if rc:
+            raise UvoError(rc, "uvo_clahe")
+        return out
+
+    def clahe_batch_device(self, d_src, batch, w, h, d_dst, clip_limit=4.0, tiles=(12, 12)):
+        """HBM-resident form on tight [batch][h][w] buffers (device pointers); enqueued ahead of the next extract_batch_device."""
+        rc = lib.uvo_clahe_batch_device(self._h, batch, d_src, w, h, w, w * h, float(clip_limit), int(tiles[0]), int(tiles[1]), d_dst, w, w * h)
+        if rc:
+            raise UvoError(rc, "uvo_clahe_batch_device")
 
     def read_plane(self, level, blurred=False, frame=0):
         w, h = self.level_dims(level)

@@ -126,4 +126,8 @@ void launch_describe(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const 
                      const FinalSlot* d_flist, const int32_t* d_n_final, const uvo_keypoint* d_in_kp, int in_cap, const float* d_pattern,
                      const uint32_t* d_patch, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch);
 
+void launch_clahe(hipStream_t s, const uint8_t* d_src, int w, int h, int64_t stride, int64_t frame_stride, int batch, int tiles_x, int tiles_y,
+                  int tile_w, int tile_h, int clip_limit, float lut_scale, uint8_t* d_lut, uint8_t* d_dst, int64_t dst_stride,
+                  int64_t dst_frame_stride);
+
 }  // namespace uvo

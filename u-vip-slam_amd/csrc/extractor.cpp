@@ -78,6 +78,9 @@ struct uvo_extractor {
   LevelGeom* d_lv = nullptr;
   CellDesc* d_cells = nullptr;
   ResizeCol* d_ctab = nullptr;
+  uint8_t* d_clahe_lut = nullptr;  // [max_batch][tiles][256], grown on demand
+  size_t clahe_lut_bytes = 0;
+  uint8_t* d_clahe_out = nullptr;  // staging of the host entry point's result
   int resize_fast[kMaxLevels] = {0};  // per level: the 12-byte-window path of k_resize_level applies
   ResizeRow* d_rtab = nullptr;
   float* d_pattern = nullptr;   // 256 point pairs (x0, y0, x1, y1) of the rBRIEF pattern as floats
@@ -540,7 +543,7 @@ void uvo_extractor_destroy(uvo_extractor* h) {
       if (p) (void)hipFree(p);
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
-  void* ptrs[] = {h->d_lv, h->d_cells, h->d_ctab, h->d_rtab, h->d_pattern, h->d_patch, h->d_imgs, h->d_out_kp,
+  void* ptrs[] = {h->d_clahe_lut, h->d_clahe_out, h->d_lv, h->d_cells, h->d_ctab, h->d_rtab, h->d_pattern, h->d_patch, h->d_imgs, h->d_out_kp,
                   h->d_out_desc, h->d_n_out, h->d_in_kp, h->d_n_in, h->d_nfn, h->d_grid};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -569,6 +572,78 @@ int uvo_extract_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs,
   if (!h) return fail(UVO_E_BADARG, "null handle");
   return run_batch_device(h, batch, d_imgs, width, height, stride, frame_stride, d_in_kp, d_n_in, d_grid2d, grid_rows, grid_cols, min_px_dist,
                           full_detect, d_num_feats_needed, d_out_kp, d_out_desc, cap, d_n_out);
+}
+
+// cv::CLAHE::apply parameters (OpenCV 3.4 clahe.cpp): tile size on the extended image, clip limit in pixels, LUT scale
+static int clahe_setup(uvo_extractor* h, int batch, int width, int height, double clip_limit, int tiles_x, int tiles_y, int* tile_w, int* tile_h,
+                       int* clip, float* lut_scale) {
+  if (batch < 1 || batch > h->cfg.max_batch) return fail(UVO_E_BADARG, "batch outside 1..max_batch");
+  if (width < 1 || height < 1 || tiles_x < 1 || tiles_y < 1 || tiles_x > width || tiles_y > height) return fail(UVO_E_BADARG, "bad image / tile grid size");
+  int ew = width, eh = height;
+  if (!(width % tiles_x == 0 && height % tiles_y == 0)) {  // copyMakeBorder(..., 0, tilesY - rows % tilesY, 0, tilesX - cols % tilesX, REFLECT_101)
+    ew = width + (tiles_x - width % tiles_x);
+    eh = height + (tiles_y - height % tiles_y);
+  }
+  if (ew - width >= width || eh - height >= height) return fail(UVO_E_BADARG, "tile grid too coarse for REFLECT_101 extension");
+  *tile_w = ew / tiles_x, *tile_h = eh / tiles_y;
+  const int tileSizeTotal = *tile_w * *tile_h;
+  *lut_scale = static_cast<float>(256 - 1) / tileSizeTotal;
+  *clip = 0;
+  if (clip_limit > 0.0) {
+    *clip = static_cast<int>(clip_limit * tileSizeTotal / 256);
+    *clip = std::max(*clip, 1);
+  }
+  const size_t need = (size_t)h->cfg.max_batch * tiles_x * tiles_y * 256;
+  if (need > h->clahe_lut_bytes) {
+    int rc = sync_all_lanes(h);
+    if (rc) return rc;
+    if (h->d_clahe_lut) hipFree(h->d_clahe_lut);
+    h->d_clahe_lut = nullptr, h->clahe_lut_bytes = 0;
+    rc = dev_alloc(&h->d_clahe_lut, need);
+    if (rc) return rc;
+    h->clahe_lut_bytes = need;
+  }
+  return UVO_OK;
+}
+
+int uvo_clahe_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
+                           double clip_limit, int tiles_x, int tiles_y, uint8_t* d_dst, ptrdiff_t dst_stride, ptrdiff_t dst_frame_stride) {
+  if (!h || !d_imgs || !d_dst) return fail(UVO_E_BADARG, "null pointer");
+  if (stride < width || dst_stride < width) return fail(UVO_E_BADARG, "stride smaller than the row");
+  UVO_HIP_CHECK(hipSetDevice(h->device));
+  int tw, th, clip;
+  float scale;
+  int rc = clahe_setup(h, batch, width, height, clip_limit, tiles_x, tiles_y, &tw, &th, &clip, &scale);
+  if (rc) return rc;
+  Lane& L = h->lane[h->cur];
+  {
+    Profiler::Scope ps(&L.prof, "k_clahe", L.stream);
+    launch_clahe(L.stream, d_imgs, width, height, stride, frame_stride, batch, tiles_x, tiles_y, tw, th, clip, scale, h->d_clahe_lut, d_dst, dst_stride,
+                 dst_frame_stride);
+  }
+  UVO_HIP_CHECK(hipGetLastError());
+  return UVO_OK;
+}
+
+int uvo_clahe(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdiff_t stride, double clip_limit, int tiles_x, int tiles_y,
+              uint8_t* dst, ptrdiff_t dst_stride) {
+  if (!h || !img || !dst) return fail(UVO_E_BADARG, "null pointer");
+  if (width < 1 || height < 1 || width > h->cfg.max_width || height > h->cfg.max_height || stride < width || dst_stride < width)
+    return fail(UVO_E_BADARG, "image size outside what the handle was sized for");
+  if ((int64_t)width * height > (int64_t)h->cfg.max_width * h->cfg.max_height) return fail(UVO_E_BADARG, "image too large");
+  UVO_HIP_CHECK(hipSetDevice(h->device));
+  if (!h->d_clahe_out) {
+    int rc = dev_alloc(&h->d_clahe_out, (size_t)h->cfg.max_width * h->cfg.max_height);
+    if (rc) return rc;
+  }
+  hipStream_t s = h->lane[h->cur].stream;
+  UVO_HIP_CHECK(hipMemcpy2DAsync(h->d_imgs, width, img, stride, width, (size_t)height, hipMemcpyHostToDevice, s));
+  int rc = uvo_clahe_batch_device(h, 1, h->d_imgs, width, height, width, (ptrdiff_t)width * height, clip_limit, tiles_x, tiles_y, h->d_clahe_out, width,
+                                  (ptrdiff_t)width * height);
+  if (rc) return rc;
+  UVO_HIP_CHECK(hipMemcpy2DAsync(dst, dst_stride, h->d_clahe_out, width, width, (size_t)height, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipStreamSynchronize(s));
+  return UVO_OK;
 }
 
 int uvo_extractor_synchronize(uvo_extractor* h) {
