@@ -209,7 +209,7 @@ class ORBextractor:
         self.cap = int(quota.sum()) + 4 * nlevels + max_input_keypoints
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # `lib` is already gone when the interpreter tears the module down
             lib.uvo_extractor_destroy(self._h)
             self._h = None
 
@@ -361,7 +361,7 @@ class ORBmatcher:
             raise UvoError(rc, "uvo_matcher_create")
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib.uvo_matcher_destroy(self._h)
             self._h = None
 

@@ -27,11 +27,15 @@ struct SbpFrame {
 
 __global__ __launch_bounds__(256) void k_grid_build(SbpFrame F, int32_t* __restrict__ cell_start, int32_t* __restrict__ cell_items,
                                                     int32_t* __restrict__ cell_of_kp) {
-  // phase 1: cell of every keypoint
-  __shared__ int s_cnt[GR_COLS * GR_ROWS];
-  for (int c = threadIdx.x; c < GR_COLS * GR_ROWS; c += blockDim.x) s_cnt[c] = 0;
+  constexpr int NC = GR_COLS * GR_ROWS, PER = NC / 256;  // 3072 cells, 12 per thread
+  __shared__ int s_cnt[NC];
+  __shared__ int s_cur[NC];
+  __shared__ int s_wave[4];
+  const int tid = threadIdx.x;
+  // phase 1: cell of every keypoint, cell populations
+  for (int c = tid; c < NC; c += 256) s_cnt[c] = 0, s_cur[c] = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < F.n; i += blockDim.x) {
+  for (int i = tid; i < F.n; i += 256) {
     const int px = (int)roundf((F.kp[i].x - (float)F.min_x) * F.inv_w);
     const int py = (int)roundf((F.kp[i].y - (float)F.min_y) * F.inv_h);
     int c = -1;
@@ -42,22 +46,48 @@ __global__ __launch_bounds__(256) void k_grid_build(SbpFrame F, int32_t* __restr
     cell_of_kp[i] = c;
   }
   __syncthreads();
-  // phase 2: exclusive scan of the 3072 counts (single thread: 3072 adds, once per frame)
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int c = 0; c < GR_COLS * GR_ROWS; ++c) {
-      cell_start[c] = run;
-      run += s_cnt[c];
-    }
-    cell_start[GR_COLS * GR_ROWS] = run;
+  // phase 2: exclusive scan of the 3072 populations (12 consecutive cells per thread, wavefront scan, 4 partials)
+  int local = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) local += s_cnt[tid * PER + k];
+  int incl = local;
+  const int lane = tid & 63;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) s_wave[tid >> 6] = incl;
+  __syncthreads();
+  int run = incl - local;
+  for (int q = 0; q < (tid >> 6); ++q) run += s_wave[q];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    cell_start[tid * PER + k] = run;
+    run += s_cnt[tid * PER + k];
+  }
+  if (tid == 255) cell_start[NC] = run;
+  __syncthreads();
+  // phase 3: scatter (arbitrary order inside a cell), phase 4: every cell's short list sorted ascending = push_back order
+  for (int i = tid; i < F.n; i += 256) {
+    const int c = cell_of_kp[i];
+    if (c >= 0) cell_items[cell_start[c] + atomicAdd(&s_cur[c], 1)] = i;
   }
   __syncthreads();
-  // phase 3: stable fill -- every cell collects its keypoints in index order
-  for (int c = threadIdx.x; c < GR_COLS * GR_ROWS; c += blockDim.x) {
-    if (s_cnt[c] == 0) continue;
-    int o = cell_start[c];
-    for (int i = 0; i < F.n; ++i)
-      if (cell_of_kp[i] == c) cell_items[o++] = i;
+#pragma unroll 1
+  for (int k = 0; k < PER; ++k) {
+    const int c = tid * PER + k, n = s_cnt[c];
+    if (n < 2) continue;
+    int32_t* a = cell_items + cell_start[c];
+    for (int i = 1; i < n; ++i) {
+      const int v = a[i];
+      int j = i - 1;
+      while (j >= 0 && a[j] > v) {
+        a[j + 1] = a[j];
+        --j;
+      }
+      a[j + 1] = v;
+    }
   }
 }
 
