@@ -389,6 +389,14 @@ int uvo_bow_transform(uvo_vocabulary* voc, const uint8_t* desc, int n, int level
                       int fv_cap, int* n_fv);
 
 /*
+ * haloc::Hash::getHash (src/hash.cpp:57-85; KeyFrame::ComputeHaloc src/KeyFrame.cc:318-329): for every projection vector r_i and
+ * descriptor column c, hash[i*32 + c] = (sum over rows m of r_i[m] * (float)desc[m][c]) / (float)n, accumulated in fp32 in row
+ * order (one thread per output walks the rows, so the rounding sequence is the reference's).  proj: [num_proj][proj_stride]
+ * floats (the reference builds them from time(NULL), so they are an input here), proj_stride >= n.  Host buffers.
+ */
+int uvo_haloc_hash(uvo_matcher* m, const float* proj, int num_proj, int proj_stride, const uint8_t* desc, int n, float* hash);
+
+/*
  * Device-side ordering between the two handles' streams (no host synchronisation): work enqueued on the
  * matcher after uvo_matcher_wait_extractor() starts only when everything enqueued on the extractor so far
  * has finished, and vice versa.  Used when descriptors produced by uvo_extract_batch_device() feed

@@ -576,4 +576,18 @@ void bow_transform(const Vocabulary& voc, const uint8_t* features, int n, int le
   fv_out.assign(fv.begin(), fv.end());
 }
 
+void haloc_hash(const float* r_, int num_proj, int r_stride, const uint8_t* desc, int rows, float* hash) {
+  for (int k = 0; k < num_proj * 32; ++k) hash[k] = 0.0f;
+  if (rows == 0) return;
+  unsigned k = 0;
+  for (int i = 0; i < num_proj; i++) {
+    for (int n = 0; n < 32; n++) {
+      float desc_sum = 0.0;
+      for (int m = 0; m < rows; m++) desc_sum += r_[(size_t)i * r_stride + m] * (float)desc[(size_t)m * 32 + n];
+      hash[k] = desc_sum / (float)rows;
+      k++;
+    }
+  }
+}
+
 }  // namespace orc

@@ -231,6 +231,8 @@ void orc_clahe(const uint8_t* img, int w, int h, long stride, double clip, int t
   clahe_apply(View{const_cast<uint8_t*>(img), w, h, (ptrdiff_t)stride}, clip, tx, ty, dst, (ptrdiff_t)dstep);
 }
 
+void orc_haloc_hash(const float* r, int num_proj, int r_stride, const uint8_t* desc, int n, float* hash) { haloc_hash(r, num_proj, r_stride, desc, n, hash); }
+
 void orc_compute_three_maxima(const int* sizes, int L, int* ind) {
   int a = -1, b = -1, c = -1;
   compute_three_maxima(sizes, L, a, b, c);

@@ -178,4 +178,7 @@ void bow_transform_one(const Vocabulary& voc, const uint8_t* feature, int levels
 void bow_transform(const Vocabulary& voc, const uint8_t* features, int n, int levelsup, std::vector<std::pair<uint32_t, double>>& bow,
                    std::vector<std::pair<uint32_t, std::vector<uint32_t>>>& fv);
 
+// haloc::Hash::getHash: src/hash.cpp:57-85 (r = the projection vectors, each at least n long)
+void haloc_hash(const float* r, int num_proj, int r_stride, const uint8_t* desc, int n, float* hash);
+
 }  // namespace orc

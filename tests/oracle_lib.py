@@ -56,6 +56,7 @@ class Oracle:
         L.orc_search_for_triangulation.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp]
         L.orc_fuse_search.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp]
         L.orc_compute_three_maxima.argtypes = [vp, ci, vp]
+        L.orc_haloc_hash.argtypes = [vp, ci, ci, vp, ci, vp]
         L.orc_clahe.argtypes = [vp, ci, ci, cl, ctypes.c_double, ci, ci, vp, cl]
         L.orc_bow_transform.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_project_points.argtypes = [ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp, vp]
@@ -241,6 +242,12 @@ class Oracle:
                                  ffeat.ctypes.data, ctypes.byref(nf))
         groups = {int(fnode[j]): [int(x) for x in ffeat[fstart[j]:fstart[j + 1]]] for j in range(nf.value)}
         return wid, ww, nid, (bid[:nb.value].copy(), bval[:nb.value].copy()), groups
+
+    def haloc_hash(self, proj, desc):
+        proj, desc = np.ascontiguousarray(proj, np.float32), np.ascontiguousarray(desc, np.uint8)
+        out = np.zeros(proj.shape[0] * 32, np.float32)
+        self.L.orc_haloc_hash(proj.ctypes.data, proj.shape[0], proj.shape[1], desc.ctypes.data, len(desc), out.ctypes.data)
+        return out
 
     def compute_three_maxima(self, sizes):
         s = np.ascontiguousarray(sizes, np.int32)

@@ -666,3 +666,15 @@ def test_clahe(uvo, oracle, synth):
         assert nb == len(kp_o)
         np.testing.assert_array_equal(de[b, :nb].cpu().numpy(), de_o)
     ex.close()
+
+
+def test_haloc_hash(uvo, oracle, synth):
+    """haloc::Hash::getHash bit for bit (the accumulation order is part of the result)."""
+    rng = np.random.default_rng(70)
+    kp1, de1, kp2, de2, sf = _two_views(uvo, synth, 4600)
+    m = uvo.ORBmatcher(0.8)
+    for de in (de1, de2[:1], de2[:0], rng.integers(0, 256, (3000, 32), dtype=np.uint8)):
+        proj = rng.normal(0, 1, (3, 6000)).astype(np.float32)
+        proj /= np.linalg.norm(proj, axis=1, keepdims=True).astype(np.float32)
+        np.testing.assert_array_equal(m.haloc_hash(proj, de).view(np.uint32), oracle.haloc_hash(proj, de).view(np.uint32))
+    m.close()

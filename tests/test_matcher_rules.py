@@ -344,3 +344,15 @@ def test_bow_transform_by_hand(oracle):
     # TF without normalisation divides by the number of distinct words
     _, _, _, (bid, bval), _ = oracle.bow_transform(_toy_vocabulary(1, 0), f, levelsup=2)
     np.testing.assert_array_equal(bval, np.array([1.0, 4.0, 4.0]) / 3.0)
+
+
+def test_haloc_hash_by_hand(oracle):
+    """hash[i*32 + c] = sum_m r_i[m] * desc[m][c] / rows (src/hash.cpp:70-82), fp32 accumulation in row order."""
+    desc = np.zeros((3, 32), np.uint8)
+    desc[:, 0], desc[:, 5] = [10, 20, 30], [1, 0, 255]
+    proj = np.array([[1.0, 0.5, -1.0, 99.0], [0.0, 2.0, 0.0, 99.0]], np.float32)       # 4th entry unused: 3 rows only
+    h = oracle.haloc_hash(proj, desc)
+    assert h.shape == (64,)
+    assert h[0] == np.float32(np.float32(10 + 10 - 30) / np.float32(3)) and h[5] == np.float32(np.float32(1 - 255) / np.float32(3))
+    assert h[32] == np.float32(np.float32(40) / np.float32(3)) and h[32 + 5] == 0 and h[1] == 0
+    assert (oracle.haloc_hash(proj, desc[:0]) == 0).all()

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
-    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
+    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_haloc_hash", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
     "uvo_matcher_kernel_times", "uvo_last_error", "uvo_device_info",
 ]
 
@@ -155,6 +155,7 @@ def _load():
     lib.uvo_vocabulary_destroy.argtypes = [vp]
     lib.uvo_vocabulary_destroy.restype = None
     lib.uvo_bow_transform.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp]
+    lib.uvo_haloc_hash.argtypes = [vp, vp, ci, ci, vp, ci, vp]
     lib.uvo_fuse.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, vp, vp]
     lib.uvo_matcher_wait_extractor.argtypes = [vp, vp]
     lib.uvo_extractor_wait_matcher.argtypes = [vp, vp]
@@ -559,6 +560,16 @@ class ORBmatcher:
         if rc:
             raise UvoError(rc, "uvo_project_points")
         return valid, u, v, level, vc
+
+    def haloc_hash(self, proj, desc):
+        """haloc::Hash::getHash (src/hash.cpp:57-85): proj [num_proj][>= n] float32, desc [n][32] -> hash [num_proj * 32]."""
+        proj = np.ascontiguousarray(proj, np.float32)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        out = np.zeros(proj.shape[0] * 32, np.float32)
+        rc = lib.uvo_haloc_hash(self._h, _ptr(proj), proj.shape[0], proj.shape[1], _ptr(desc), len(desc), _ptr(out))
+        if rc:
+            raise UvoError(rc, "uvo_haloc_hash")
+        return out
 
     def FuseSearch(self, kp, desc, bounds, u, v, level, valid, mp_desc, scale_factors, th=3.0):
         """Search core of Fuse (:1077-1101): (best_idx[nmp], best_dist[nmp]), -1 where nothing within TH_LOW."""

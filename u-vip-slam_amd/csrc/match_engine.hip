@@ -447,6 +447,21 @@ void launch_project(hipStream_t s, int mode, const uvo_camera_pose& cam, int n, 
                      cos_limit, d_valid, d_u, d_v, d_level, d_cos);
 }
 
+// haloc::Hash::getHash (src/hash.cpp:57-85): thread = one (projection, descriptor column) output, sequential fp32 accumulation
+__global__ __launch_bounds__(64) void k_haloc(const float* __restrict__ proj, int num_proj, int proj_stride, const uint8_t* __restrict__ desc, int n,
+                                              float* __restrict__ hash) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= num_proj * 32) return;
+  const int i = k >> 5, c = k & 31;
+  const float* r = proj + (int64_t)i * proj_stride;
+  float desc_sum = 0.0f;
+  for (int m = 0; m < n; ++m) desc_sum += r[m] * (float)desc[(int64_t)m * 32 + c];
+  hash[k] = desc_sum / (float)n;
+}
+void launch_haloc(hipStream_t s, const float* d_proj, int num_proj, int proj_stride, const uint8_t* d_desc, int n, float* d_hash) {
+  hipLaunchKernelGGL(k_haloc, dim3((num_proj * 32 + 63) / 64), dim3(64), 0, s, d_proj, num_proj, proj_stride, d_desc, n, d_hash);
+}
+
 // grid build shared with search.hip
 void launch_grid_build(hipStream_t s, const uvo_keypoint* d_kp, const uint8_t* d_desc, int n, int min_x, int min_y, int max_x, int max_y,
                        int32_t* d_cell_start, int32_t* d_cell_items, int32_t* d_cell_of_kp);

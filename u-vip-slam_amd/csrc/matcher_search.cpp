@@ -28,6 +28,7 @@ void launch_rot_filter(hipStream_t s, int nq, const float* d_qangle, const float
 void launch_project(hipStream_t s, int mode, const uvo_camera_pose& cam, int n, const float* d_xyz, const float* d_normal, const float* d_min,
                     const float* d_max, const float* d_max_raw, const uint8_t* d_usable, const float* d_sf, int nlevels, float log_sf, float cos_limit, uint8_t* d_valid,
                     float* d_u, float* d_v, int32_t* d_level, float* d_cos);
+void launch_haloc(hipStream_t s, const float* d_proj, int num_proj, int proj_stride, const uint8_t* d_desc, int n, float* d_hash);
 }  // namespace uvo
 
 using namespace uvo;
@@ -442,6 +443,28 @@ int uvo_project_points(uvo_matcher* m, int mode, const uvo_camera_pose* cam, int
   UVO_HIP_CHECK(hipMemcpyAsync(v, d_v, (size_t)npts * 4, hipMemcpyDeviceToHost, s));
   UVO_HIP_CHECK(hipMemcpyAsync(level, d_level, (size_t)npts * 4, hipMemcpyDeviceToHost, s));
   if (view_cos) UVO_HIP_CHECK(hipMemcpyAsync(view_cos, d_cos, (size_t)npts * 4, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipStreamSynchronize(s));
+  return UVO_OK;
+}
+
+int uvo_haloc_hash(uvo_matcher* m, const float* proj, int num_proj, int proj_stride, const uint8_t* desc, int n, float* hash) {
+  if (!m || !hash) return matcher_fail(UVO_E_BADARG, "null pointer");
+  if (num_proj < 1 || n < 0 || proj_stride < n) return matcher_fail(UVO_E_BADARG, "bad sizes (proj_stride must cover the descriptor rows)");
+  if (n == 0) {  // :66 the zero-initialised histogram
+    for (int k = 0; k < num_proj * 32; ++k) hash[k] = 0.0f;
+    return UVO_OK;
+  }
+  if (!proj || !desc) return matcher_fail(UVO_E_BADARG, "null pointer");
+  UVO_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  float *d_proj, *d_hash;
+  uint8_t* d_desc;
+  RC(upload(m, S_QX, proj, (size_t)num_proj * proj_stride, &d_proj));
+  RC(upload(m, S_QDESC, desc, (size_t)n * 32, &d_desc));
+  RC(reserve(m, S_QY, (size_t)num_proj * 32, &d_hash));
+  launch_haloc(s, d_proj, num_proj, proj_stride, d_desc, n, d_hash);
+  UVO_HIP_CHECK(hipGetLastError());
+  UVO_HIP_CHECK(hipMemcpyAsync(hash, d_hash, (size_t)num_proj * 32 * 4, hipMemcpyDeviceToHost, s));
   UVO_HIP_CHECK(hipStreamSynchronize(s));
   return UVO_OK;
 }
