@@ -347,8 +347,8 @@ static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, 
     launch_resize_level(s, h->lane[h->cur].d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_ctab + g.lv[l].xtab_off, h->d_rtab + g.lv[l].ytab_off,
                         h->resize_fast[l], batch);
   }
-  static const char* const kFastNames[3] = {"k_fast_score", "k_fast_nms", "k_fast_emit"};
-  for (int stage = 0; stage < 3; ++stage) {
+  static const char* const kFastNames[3] = {"k_fast_score", "", "k_fast_emit"};
+  for (int stage = 0; stage < 3; stage += 2) {
     ProfScope p(h, kFastNames[stage]);
     launch_fast_stage(s, stage, h->lane[h->cur].d_pyr, h->lane[h->cur].d_score, g.pyr_block, h->d_lv, g, h->cfg.fast_th, h->lane[h->cur].d_cor,
                       h->lane[h->cur].d_cor_n, h->lane[h->cur].d_cell_hi, h->lane[h->cur].d_cand_xy, h->lane[h->cur].d_cand_sc, g.cand_block,

@@ -6,20 +6,19 @@
 // 3-px-inset interior or that are not corners count as 0.)
 //
 // The cells' interiors tile the detection window [16, w-16) x [16, h-16) exactly once and the corner score does not
-// depend on the threshold, so the work is split in three:
-//   k_fast_score  : a streaming pass over each level that writes the score plane (0 = not a corner at
-//                   t_min = min(fastTh, 7)).  One wavefront owns a strip of 64 lanes x 4 pixels and walks down the
-//                   rows with the last 7 row dwords in a register ring (one aligned dword load per lane per row, also
-//                   kept in a 16-row wavefront-private LDS ring) -- no workgroup barriers.  Every pixel is screened
-//                   with four opposite ring pairs (any 9-arc contains one pixel of every opposite pair, of one
-//                   polarity): min/max only.  The ~11 % that pass are compacted into a wavefront-private LDS queue and
-//                   the exact test runs on full 64-lane batches of it: max over the 16 arcs of the arc minimum
-//                   (v_min3 / v_max3, branch free) is both the corner test (> t) and cornerScore + 1.
-//                   Corners (3-4 % of the pixels) are also appended to a list private to the wavefront's
-//                   (strip, segment) region -- no atomics, the count lives in a scalar register.
-//   k_fast_nms    : sparse: one lane per listed corner checks its 8 neighbours in the score plane (neighbours outside
-//                   the corner's own cell interior count as 0), compacts the survivors in place and marks cells that
-//                   own a survivor >= fastTh.
+// depend on the threshold, so the work is split in two:
+//   k_fast_score  : a streaming pass over each level.  One wavefront owns a (strip, segment) region of 248 x 24 pixels plus a
+//                   one-pixel halo ring and walks down the rows with the last 7 row dwords in a register ring (one aligned
+//                   dword load per lane per row, also kept in a 16-row wavefront-private LDS ring) -- no workgroup
+//                   barriers.  Every pixel is screened with four opposite ring pairs (any 9-arc contains one pixel of
+//                   every opposite pair, of one polarity) in packed 16-bit min/max arithmetic.  The ~20 % that pass are
+//                   compacted into a wavefront-private LDS queue and the exact test runs on full 64-lane batches of it:
+//                   max over the 16 arcs of the arc minimum (branch free) is both the corner test (> t_min = min(fastTh, 7))
+//                   and cornerScore + 1.  Corners (3-4 % of the pixels) are appended to a list private to the region -- no
+//                   atomics, the count lives in a scalar register.  At the end of the segment the wavefront does the
+//                   in-cell 3x3 NMS itself on a byte tile laid over its LDS (neighbours outside the corner's own cell
+//                   interior count as 0), compacts the survivors in place and marks cells that own a survivor >= fastTh.
+//                   HBM traffic: the level once in, a few hundred survivor records out.
 //   k_fast_emit   : per survivor, the cell's vote picks fastTh or the literal-7 fallback; kept points are appended to
 //                   the (frame, level) candidate list (one wave-aggregated atomic per 64).  Candidate order in HBM is
 //                   arbitrary: the quad-tree orders by coordinates.
@@ -27,8 +26,10 @@
 
 namespace uvo {
 
-constexpr int FS_COLS = 248;  // useful columns per wavefront strip (lanes 1..62)
-constexpr int FQ_CAP = 320;   // queue entries per wavefront: < 64 left over + <= 256 pushed per row
+constexpr int FS_COLS = 248;      // useful columns per wavefront strip (lanes 1..62)
+constexpr int FS_ROWS_MAX = 24;   // rows per (strip, segment) region; bounded by the NMS tile that must fit the wavefront's LDS
+constexpr int FS_REGION_ENTRIES = (FS_COLS + 2) * (FS_ROWS_MAX + 2);  // corner list capacity: the region plus its halo ring
+constexpr int FQ_CAP = 320;       // queue entries per wavefront: < 64 left over + <= 256 pushed per row
 
 // max over the 16 arcs of 9 contiguous ring pixels of min(d).  A 9-window always straddles the two 8-pixel halves of the
 // ring, so with running minima towards the end of each half (S) and from the start of each half (P) every arc minimum is
@@ -86,19 +87,22 @@ constexpr int FR_ROWS = 16;         // LDS row ring depth per wavefront
 constexpr int FR_MIRROR = 6;        // ring slots 0..5 are mirrored into slots 16..21 (see fast_score_chunk)
 constexpr int FR_PITCH = 66;        // row pitch in dwords: 64 + 2 so that the same column of consecutive rows hits different banks
 constexpr int FR_MAXAGE = FR_ROWS - 8;  // a queued pixel needs rows -3..+3 around it: drain before they are overwritten
+constexpr int FW_RING_DW = (FR_ROWS + FR_MIRROR) * FR_PITCH;  // row ring, then the queue: one LDS block per wavefront
+constexpr int FW_DWORDS = FW_RING_DW + FQ_CAP;
+constexpr int FT_PITCH = 256, FT_ROWS = FS_ROWS_MAX + 2;      // NMS score tile, laid over ring + queue at the end of the segment
+static_assert(FT_PITCH * FT_ROWS <= FW_DWORDS * 4, "NMS tile must fit the wavefront's LDS block");
 
 // Full segment test + cornerScore of the queued pixels [first, first+count), one per lane.  The 16 ring pixels are read
 // back from the wavefront's LDS row ring: the queue entry carries the byte address of the pixel in the ring (rows 0..5 are
 // mirrored into slots 16..21, so the seven rows around any centre are consecutive slots and every read is base + immediate).
-// entry = ring byte address | xl << 13 | (row - py0) << 21
+// entry = ring byte address | xl << 13 | (row - py0 + 1) << 21.  Corners go to the wavefront's list as xl | row' << 8 | score << 16.
 __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_t* rows, int first, int count, int lane, int t_min,
-                                                 uint8_t* __restrict__ splane, int pitch, int X0, int py0, uint32_t* __restrict__ region,
-                                                 int& ncorner) {
+                                                 uint32_t* __restrict__ region, int& ncorner) {
   bool corner = false;
   uint32_t packed = 0;
   if (lane < count) {
     const uint32_t meta = q[first + lane];
-    const int xl = (int)((meta >> 13) & 0xff), rr = (int)(meta >> 21);
+    const int xl = (int)((meta >> 13) & 0xff), rrp = (int)(meta >> 21);
     constexpr int RB = FR_PITCH * 4;
     const uint8_t* r0 = rows + (meta & 0x1fffu) - 3;  // 3 bytes left of the pixel
     const uint8_t *rp1 = r0 + RB, *rp2 = r0 + 2 * RB, *rp3 = r0 + 3 * RB, *rm1 = r0 - RB, *rm2 = r0 - 2 * RB, *rm3 = r0 - 3 * RB;
@@ -113,9 +117,8 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
     const int best = max(arc9_maxmin(d), -arc9_minmax(d));
     if (best > t_min) {
       const int sc = best - 1;
-      splane[(int64_t)(py0 + rr) * pitch + X0 + xl] = (uint8_t)sc;
-      corner = sc > 0;  // a score of 0 (only possible at t_min = 0) can never survive NMS
-      packed = (uint32_t)xl | ((uint32_t)rr << 8) | ((uint32_t)sc << 16);
+      corner = sc > 0;  // a score of 0 (only possible at t_min = 0) can never survive NMS nor suppress anything
+      packed = (uint32_t)xl | ((uint32_t)rrp << 8) | ((uint32_t)sc << 16);
     }
   }
   const uint64_t m = __ballot(corner);
@@ -125,127 +128,6 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
   }
 }
 
-__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score, int64_t pyr_block,
-                                                    const LevelGeom* __restrict__ lv, int nlevels, int t_min, int rows_per_seg,
-                                                    uint32_t* __restrict__ cor, int32_t* __restrict__ cor_n, int items_per_frame) {
-  __shared__ uint32_t s_q[4][FQ_CAP];
-  __shared__ uint32_t s_rows[4][(FR_ROWS + FR_MIRROR) * FR_PITCH];
-  const int wv = wave_in_block(), lane = threadIdx.x & 63;
-  uint32_t* q = s_q[wv];
-  uint32_t* rows32 = s_rows[wv];
-  const uint8_t* rows8 = reinterpret_cast<const uint8_t*>(rows32);
-  // work item (one per wavefront) -> (level, strip, segment); window = padded cols [32, w) x rows [32, h)
-  int item = blockIdx.x * 4 + wv;
-  const int64_t region_id = (int64_t)blockIdx.y * items_per_frame + item;
-  uint32_t* region = cor + region_id * ((int64_t)FS_COLS * rows_per_seg);
-  int ncorner = 0;
-  int level = 0, nstrip = 0, nseg = 0;
-  for (;; ++level) {
-    nstrip = (lv[level].w - 32 + FS_COLS - 1) / FS_COLS;
-    nseg = (lv[level].h - 32 + rows_per_seg - 1) / rows_per_seg;
-    if (item < nstrip * nseg) break;
-    item -= nstrip * nseg;
-    if (level == nlevels - 1) return;
-  }
-  const LevelGeom g = lv[level];
-  const int f = blockIdx.y;
-  const int strip = item % nstrip, seg = item / nstrip;
-  const uint8_t* src = pyr + f * pyr_block + g.plane_off;
-  uint8_t* sp = score + f * pyr_block + g.plane_off;
-  const int X0 = 28 + strip * FS_COLS;  // padded column of lane 0 (halo lane)
-  const int X = X0 + lane * 4;
-  const int Xc = X > g.pitch - 4 ? g.pitch - 4 : X;
-  const bool lane_ok = lane >= 1 && lane <= 62 && X < g.w;
-  const int py0 = 32 + seg * rows_per_seg;
-  const int py1 = min(py0 + rows_per_seg, g.h);
-  const int nsrc = py1 - py0 + 6;  // source rows py0-3 .. py1+2
-  int qn = 0;                      // wavefront-uniform queue length
-  int qoldest = 0;                 // centre row of the oldest queued pixel (valid while qn > 0)
-  const int lm = lane > 0 ? lane - 1 : 0, lp = lane < 63 ? lane + 1 : 63;
-  const bool ok0 = lane_ok && X + 0 < g.w, ok1 = lane_ok && X + 1 < g.w, ok2 = lane_ok && X + 2 < g.w, ok3 = lane_ok && X + 3 < g.w;
-  const uint32_t t_even = (uint32_t)t_min * 0x00010001u, t_odd = t_even << 8;
-
-  // Row loads run one unrolled block (7 rows) ahead of their use so that a wavefront never waits on the row it needs next.
-  auto load_row = [&](int j) -> uint32_t { return *reinterpret_cast<const uint32_t*>(src + (int64_t)(py0 - 3 + j) * g.pitch + Xc); };
-  const uint32_t lane_entry = (uint32_t)(lane * 4) * ((1u << 13) + 1u);
-  uint32_t Cr[7], nxt[7];
-#pragma unroll
-  for (int u = 0; u < 7; ++u) nxt[u] = u < nsrc ? load_row(u) : 0u;
-  for (int base = 0; base < nsrc; base += 7) {
-    uint32_t cur[7];
-#pragma unroll
-    for (int u = 0; u < 7; ++u) cur[u] = nxt[u];
-#pragma unroll
-    for (int u = 0; u < 7; ++u) nxt[u] = base + 7 + u < nsrc ? load_row(base + 7 + u) : 0u;
-#pragma unroll
-    for (int u = 0; u < 7; ++u) {
-      const int j = base + u;
-      if (j < nsrc) {
-        const int prow = py0 - 3 + j;
-        const uint32_t C = cur[u];
-        Cr[u] = C;
-        const int slot = prow & (FR_ROWS - 1);
-        rows32[slot * FR_PITCH + lane] = C;
-        if (slot < FR_MIRROR) rows32[(slot + FR_ROWS) * FR_PITCH + lane] = C;
-        if (j >= 6) {
-          const int pc = prow - 3;  // centre row; rows pc-3 .. pc+3 sit in register slots (u+1)%7 .. u
-          const int sm3 = (u + 1) % 7, sm2 = (u + 2) % 7, s0 = (u + 4) % 7, sp2 = (u + 6) % 7, sp3 = u;
-          if (lane_ok) *reinterpret_cast<uint32_t*>(sp + (int64_t)pc * g.pitch + X) = 0u;
-          const uint32_t Cc = Cr[s0], Cu = Cr[sm3], Cd = Cr[sp3], C2 = Cr[sp2], Cm2 = Cr[sm2];
-          // neighbour dwords of rows pc, pc+2, pc-2 from the LDS row ring (written by this wavefront, in order)
-          const uint32_t* rc = rows32 + (pc & (FR_ROWS - 1)) * FR_PITCH;
-          const uint32_t* r2 = rows32 + ((pc + 2) & (FR_ROWS - 1)) * FR_PITCH;
-          const uint32_t* rm = rows32 + ((pc - 2) & (FR_ROWS - 1)) * FR_PITCH;
-          const uint32_t Lc = rc[lm], Rc = rc[lp], L2 = r2[lm], R2 = r2[lp], Lm2 = rm[lm], Rm2 = rm[lp];
-          const int cslot = (pc & (FR_ROWS - 1)) < 3 ? (pc & (FR_ROWS - 1)) + FR_ROWS : (pc & (FR_ROWS - 1));
-          const uint32_t row_entry = (uint32_t)(cslot * (FR_PITCH * 4)) | ((uint32_t)(pc - py0) << 21);
-          // ---- screen the lane's 4 pixels with four opposite ring pairs, queue the ones that pass ----
-          // Packed 16-bit arithmetic, two pixels per instruction: the even bytes of a pixel dword sit in the two 16-bit
-          // halves as they are (x & 0x00ff00ff), the odd bytes scaled by 256 (x & 0xff00ff00); all compares are unsigned.
-          // bright <=> min over the pairs of max(pair) > v + t ; dark <=> max over the pairs of min(pair) < v - t
-          // (saturating add / sub keep v +- t in range; a saturated bound can never be crossed by a pixel value).
-          const uint32_t P4 = __builtin_amdgcn_alignbyte(Rc, Cc, 3), P12 = __builtin_amdgcn_alignbyte(Cc, Lc, 1);
-          const uint32_t P2 = __builtin_amdgcn_alignbyte(R2, C2, 2), P14 = __builtin_amdgcn_alignbyte(C2, L2, 2);
-          const uint32_t P6 = __builtin_amdgcn_alignbyte(Rm2, Cm2, 2), P10 = __builtin_amdgcn_alignbyte(Cm2, Lm2, 2);
-          const uint32_t re = screen2(Cc & kEven, Cd & kEven, Cu & kEven, P4 & kEven, P12 & kEven, P2 & kEven, P10 & kEven, P6 & kEven,
-                                      P14 & kEven, t_even);
-          const uint32_t ro = screen2(Cc & kOdd, Cd & kOdd, Cu & kOdd, P4 & kOdd, P12 & kOdd, P2 & kOdd, P10 & kOdd, P6 & kOdd, P14 & kOdd,
-                                      t_odd);
-#define UVO_FAST_PUSH(K, COND)                                                                                    \
-  {                                                                                                               \
-    const bool pass = (COND) & ok##K;                                                                             \
-    const uint64_t m = __ballot(pass);                                                                            \
-    if (m) {                                                                                                      \
-      if (qn == 0) qoldest = pc;                                                                                  \
-      if (pass)                                                                                                   \
-        q[qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = \
-            lane_entry + (row_entry + (uint32_t)K * ((1u << 13) + 1u));                                           \
-      qn += __popcll(m);                                                                                          \
-    }                                                                                                             \
-  }
-          UVO_FAST_PUSH(0, (re & 0xffffu) != 0u)
-          UVO_FAST_PUSH(1, (ro & 0xffffu) != 0u)
-          UVO_FAST_PUSH(2, re > 0xffffu)
-          UVO_FAST_PUSH(3, ro > 0xffffu)
-#undef UVO_FAST_PUSH
-          // ---- drain full batches (newest first); a stale remainder is flushed before its rows leave the ring ----
-          while (qn >= 64) {
-            qn -= 64;
-            fast_score_chunk(q, rows8, qn, 64, lane, t_min, sp, g.pitch, X0, py0, region, ncorner);
-          }
-          if (qn > 0 && pc - qoldest >= FR_MAXAGE) {
-            fast_score_chunk(q, rows8, 0, qn, lane, t_min, sp, g.pitch, X0, py0, region, ncorner);
-            qn = 0;
-          }
-        }
-      }
-    }
-  }
-  if (qn > 0) fast_score_chunk(q, rows8, 0, qn, lane, t_min, sp, g.pitch, X0, py0, region, ncorner);
-  if (lane == 0) cor_n[region_id] = ncorner;
-}
-
-// ---------------------------------------------------------------------------------------------------------
 struct FastLevel {  // per-level values of the sparse stages, passed in the kernel argument block (scalar loads)
   int64_t plane_off, cand_off;
   int pitch, cand_cap;
@@ -253,6 +135,7 @@ struct FastLevel {  // per-level values of the sparse stages, passed in the kern
   int nCols, nRows, wCell, hCell;
   int flag_base;  // first entry of this level in the per-frame cell-flag array (full nRows x nCols grid)
   int pad;
+  uint32_t inv_wcell, inv_hcell;  // ceil(2^32 / wCell), ceil(2^32 / hCell): n / cell = umulhi(n, inv) for the coordinate range
 };
 struct FastLevels {
   FastLevel l[kMaxLevels];
@@ -274,71 +157,188 @@ __device__ __forceinline__ bool fast_region(const FastLevels& L, int item, int& 
   return false;
 }
 
-// One wavefront per (strip, segment) region of k_fast_score; one lane per listed corner.
-__global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ score, int64_t pyr_block, FastLevels L, int fast_th,
-                                                  uint32_t* __restrict__ cor, int32_t* __restrict__ cor_n, uint8_t* __restrict__ cell_hi) {
+// One wavefront per (strip, segment) region: 248 x rows_per_seg pixels of the detection window plus a one-pixel halo ring whose
+// scores are computed redundantly (the ring radius is 3 and the strip's halo lanes are 4 px wide, so no extra loads), so that the
+// in-cell 3x3 non-max suppression can be done by the wavefront itself at the end of the segment: the corner scores are scattered
+// into a dense byte tile that reuses the LDS of the row ring + queue, the eight neighbours of every corner are read from it
+// (neighbours outside the corner's own FAST cell count as 0), survivors are compacted in place and mark their cell when they
+// reach fastTh.  No score plane in HBM, no zero fill, no second gather pass.
+__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ pyr, int64_t pyr_block, FastLevels L, int t_min, int fast_th,
+                                                    uint32_t* __restrict__ cor, int32_t* __restrict__ cor_n, uint8_t* __restrict__ cell_hi) {
+  __shared__ uint32_t s_mem[4][FW_DWORDS];
   const int wv = wave_in_block(), lane = threadIdx.x & 63;
+  uint32_t* rows32 = s_mem[wv];
+  uint32_t* q = rows32 + FW_RING_DW;
+  const uint8_t* rows8 = reinterpret_cast<const uint8_t*>(rows32);
+  // work item (one per wavefront) -> (level, strip, segment); window = padded cols [32, w) x rows [32, h)
   const int item = blockIdx.x * 4 + wv;
   int level, X0, py0;
   if (!fast_region(L, item, level, X0, py0)) return;
   const FastLevel g = L.l[level];
   const int f = blockIdx.y;
   const int64_t region_id = (int64_t)f * L.items_per_frame + item;
-  uint32_t* region = cor + region_id * ((int64_t)FS_COLS * L.rows_per_seg);
-  const int n = cor_n[region_id];
-  const uint8_t* sp = score + f * pyr_block + g.plane_off;
+  uint32_t* region = cor + region_id * (int64_t)FS_REGION_ENTRIES;
+  int ncorner = 0;
+  const uint8_t* src = pyr + f * pyr_block + g.plane_off;
+  const int X = X0 + lane * 4;  // padded column of the lane's first pixel; lanes 0 and 63 are the strip halo
+  const int Xc = X > g.pitch - 4 ? g.pitch - 4 : X;
+  const int py1 = min(py0 + L.rows_per_seg, g.h);
+  const int nrows = py1 - py0;
+  const int nsrc = nrows + 8;  // centre rows py0-1 .. py1 need source rows py0-4 .. py1+3
+  int qn = 0;                  // wavefront-uniform queue length
+  int qoldest = 0;             // centre row of the oldest queued pixel (valid while qn > 0)
+  const int lm = lane > 0 ? lane - 1 : 0, lp = lane < 63 ? lane + 1 : 63;
+  // pixel K of the lane is screened when it lies in the region or its one-pixel halo (xl in [3, 252]) and in the detection window
+  bool okv[4];
+#pragma unroll
+  for (int K = 0; K < 4; ++K) {
+    const int xl = lane * 4 + K;
+    okv[K] = xl >= 3 && xl <= FS_COLS + 4 && X + K >= 32 && X + K < g.w;
+  }
+  const bool ok0 = okv[0], ok1 = okv[1], ok2 = okv[2], ok3 = okv[3];
+  const uint32_t t_even = (uint32_t)t_min * 0x00010001u, t_odd = t_even << 8;
+
+  // Row loads run one unrolled block (7 rows) ahead of their use so that a wavefront never waits on the row it needs next.
+  auto load_row = [&](int j) -> uint32_t { return *reinterpret_cast<const uint32_t*>(src + (int64_t)(py0 - 4 + j) * g.pitch + Xc); };
+  const uint32_t lane_entry = (uint32_t)(lane * 4) * ((1u << 13) + 1u);
+  uint32_t Cr[7], nxt[7];
+#pragma unroll
+  for (int u = 0; u < 7; ++u) nxt[u] = u < nsrc ? load_row(u) : 0u;
+  for (int base = 0; base < nsrc; base += 7) {
+    uint32_t cur[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) cur[u] = nxt[u];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) nxt[u] = base + 7 + u < nsrc ? load_row(base + 7 + u) : 0u;
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int j = base + u;
+      if (j < nsrc) {
+        const int prow = py0 - 4 + j;
+        const uint32_t C = cur[u];
+        Cr[u] = C;
+        const int slot = prow & (FR_ROWS - 1);
+        rows32[slot * FR_PITCH + lane] = C;
+        if (slot < FR_MIRROR) rows32[(slot + FR_ROWS) * FR_PITCH + lane] = C;
+        if (j >= 6) {
+          const int pc = prow - 3;  // centre row; rows pc-3 .. pc+3 sit in register slots (u+1)%7 .. u
+          if (pc >= 32 && pc < g.h) {
+            const int sm3 = (u + 1) % 7, sm2 = (u + 2) % 7, s0 = (u + 4) % 7, sp2 = (u + 6) % 7, sp3 = u;
+            const uint32_t Cc = Cr[s0], Cu = Cr[sm3], Cd = Cr[sp3], C2 = Cr[sp2], Cm2 = Cr[sm2];
+            // neighbour dwords of rows pc, pc+2, pc-2 from the LDS row ring (written by this wavefront, in order)
+            const uint32_t* rc = rows32 + (pc & (FR_ROWS - 1)) * FR_PITCH;
+            const uint32_t* r2 = rows32 + ((pc + 2) & (FR_ROWS - 1)) * FR_PITCH;
+            const uint32_t* rm = rows32 + ((pc - 2) & (FR_ROWS - 1)) * FR_PITCH;
+            const uint32_t Lc = rc[lm], Rc = rc[lp], L2 = r2[lm], R2 = r2[lp], Lm2 = rm[lm], Rm2 = rm[lp];
+            const int cslot = (pc & (FR_ROWS - 1)) < 3 ? (pc & (FR_ROWS - 1)) + FR_ROWS : (pc & (FR_ROWS - 1));
+            const uint32_t row_entry = (uint32_t)(cslot * (FR_PITCH * 4)) | ((uint32_t)(pc - py0 + 1) << 21);
+            // ---- screen the lane's 4 pixels with four opposite ring pairs, queue the ones that pass ----
+            // Packed 16-bit arithmetic, two pixels per instruction: the even bytes of a pixel dword sit in the two 16-bit
+            // halves as they are (x & 0x00ff00ff), the odd bytes scaled by 256 (x & 0xff00ff00); all compares are unsigned.
+            // bright <=> min over the pairs of max(pair) > v + t ; dark <=> max over the pairs of min(pair) < v - t
+            // (saturating add / sub keep v +- t in range; a saturated bound can never be crossed by a pixel value).
+            const uint32_t P4 = __builtin_amdgcn_alignbyte(Rc, Cc, 3), P12 = __builtin_amdgcn_alignbyte(Cc, Lc, 1);
+            const uint32_t P2 = __builtin_amdgcn_alignbyte(R2, C2, 2), P14 = __builtin_amdgcn_alignbyte(C2, L2, 2);
+            const uint32_t P6 = __builtin_amdgcn_alignbyte(Rm2, Cm2, 2), P10 = __builtin_amdgcn_alignbyte(Cm2, Lm2, 2);
+            const uint32_t re = screen2(Cc & kEven, Cd & kEven, Cu & kEven, P4 & kEven, P12 & kEven, P2 & kEven, P10 & kEven, P6 & kEven,
+                                        P14 & kEven, t_even);
+            const uint32_t ro = screen2(Cc & kOdd, Cd & kOdd, Cu & kOdd, P4 & kOdd, P12 & kOdd, P2 & kOdd, P10 & kOdd, P6 & kOdd, P14 & kOdd,
+                                        t_odd);
+#define UVO_FAST_PUSH(K, COND)                                                                                    \
+  {                                                                                                               \
+    const bool pass = (COND) & ok##K;                                                                             \
+    const uint64_t m = __ballot(pass);                                                                            \
+    if (m) {                                                                                                      \
+      if (qn == 0) qoldest = pc;                                                                                  \
+      if (pass)                                                                                                   \
+        q[qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = \
+            lane_entry + (row_entry + (uint32_t)K * ((1u << 13) + 1u));                                           \
+      qn += __popcll(m);                                                                                          \
+    }                                                                                                             \
+  }
+            UVO_FAST_PUSH(0, (re & 0xffffu) != 0u)
+            UVO_FAST_PUSH(1, (ro & 0xffffu) != 0u)
+            UVO_FAST_PUSH(2, re > 0xffffu)
+            UVO_FAST_PUSH(3, ro > 0xffffu)
+#undef UVO_FAST_PUSH
+          }
+          // ---- drain full batches (newest first); a stale remainder is flushed before its rows leave the ring ----
+          while (qn >= 64) {
+            qn -= 64;
+            fast_score_chunk(q, rows8, qn, 64, lane, t_min, region, ncorner);
+          }
+          if (qn > 0 && pc - qoldest >= FR_MAXAGE) {
+            fast_score_chunk(q, rows8, 0, qn, lane, t_min, region, ncorner);
+            qn = 0;
+          }
+        }
+      }
+    }
+  }
+  if (qn > 0) fast_score_chunk(q, rows8, 0, qn, lane, t_min, region, ncorner);
+
+  // ---- in-cell 3x3 non-max suppression of the region's corners (cv::FAST with nonmaxSuppression on the cell ROI) ----
+  uint8_t* tile = reinterpret_cast<uint8_t*>(rows32);  // [row' = row - py0 + 1][xl], FT_PITCH bytes per row; ring and queue are dead
+  for (int i = lane; i < FT_ROWS * FT_PITCH / 4; i += 64) rows32[i] = 0u;
+  __threadfence_block();  // the corner list below was written by this wavefront's own global stores
   uint8_t* hi = cell_hi + (int64_t)f * L.flags_per_frame + g.flag_base;
   int nkeep = 0;
-  constexpr int U = 4;  // corners per lane per iteration: 4 independent load chains hide the two memory round trips
-  for (int base = 0; base < n; base += 64 * U) {
-    uint32_t e[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) e[u] = base + u * 64 + lane < n ? region[base + u * 64 + lane] : 0u;
-    int nb[U][8], ss[U], xr_[U], yr_[U], cell_[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int px = X0 + (int)(e[u] & 0xff), py = py0 + (int)((e[u] >> 8) & 0xff);
-      ss[u] = (int)(e[u] >> 16);
+  auto nms_one = [&](uint32_t e, bool valid) {
+    bool keep = false;
+    uint32_t out = 0;
+    const int xl = (int)(e & 0xff), rrp = (int)((e >> 8) & 0xff), ss = (int)(e >> 16);
+    const bool owned = valid && xl >= 4 && xl < FS_COLS + 4 && rrp >= 1 && rrp <= nrows;  // not a halo-ring corner
+    if (owned) {
       // coordinates relative to (minBorder, minBorder), as the candidate list wants them
-      const int xr = px - kPad - kMinBorder, yr = py - kPad - kMinBorder;
-      int cj = (xr - 3) / g.wCell, ci = (yr - 3) / g.hCell;
+      const int xr = X0 + xl - kPad - kMinBorder, yr = py0 + rrp - 1 - kPad - kMinBorder;
+      int cj = (int)__umulhi((uint32_t)(xr - 3), g.inv_wcell), ci = (int)__umulhi((uint32_t)(yr - 3), g.inv_hcell);  // (xr-3)/wCell, (yr-3)/hCell
       cj = cj > g.nCols - 1 ? g.nCols - 1 : cj;
       ci = ci > g.nRows - 1 ? g.nRows - 1 : ci;
       // interior of the owning cell: [j*wCell + 3, min(j*wCell + wCell + 6, bw) - 3) and the same in y
       const int cx0 = cj * g.wCell + 3, cx1 = min(cj * g.wCell + g.wCell + 6, g.bw) - 3;
       const int cy0 = ci * g.hCell + 3, cy1 = min(ci * g.hCell + g.hCell + 6, g.bh) - 3;
-      const uint8_t* c = sp + (int64_t)py * g.pitch + px;
-      xr_[u] = xr, yr_[u] = yr, cell_[u] = ci * g.nCols + cj;
-      // three unaligned dword loads fetch the 3x3 neighbourhood (bytes x-1 .. x+2 of rows y-1, y, y+1)
-      typedef uint32_t u32_any __attribute__((aligned(1)));
-      uint32_t rw[3];
-#pragma unroll
-      for (int dy = -1; dy <= 1; ++dy) rw[dy + 1] = ss[u] > 0 ? *reinterpret_cast<const u32_any*>(c + (int64_t)dy * g.pitch - 1) : 0u;
-      int q = 0;
+      const uint8_t* c = tile + rrp * FT_PITCH + xl;
+      keep = true;
 #pragma unroll
       for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
           if (dx == 0 && dy == 0) continue;
           const bool inside = xr + dx >= cx0 && xr + dx < cx1 && yr + dy >= cy0 && yr + dy < cy1;
-          nb[u][q++] = inside ? (int)((rw[dy + 1] >> (8 * (dx + 1))) & 0xff) : 0;
+          const int nb = inside ? (int)c[dy * FT_PITCH + dx] : 0;
+          keep = keep && ss > nb;
         }
+      if (keep && ss >= fast_th) hi[ci * g.nCols + cj] = 1;  // idempotent plain store: every writer stores the same value
+      out = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)ss << 24);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      bool keep = ss[u] > 0;  // padding entries (beyond n) carry score 0
-#pragma unroll
-      for (int q = 0; q < 8; ++q) keep = keep && ss[u] > nb[u][q];
-      if (keep && ss[u] >= fast_th) hi[cell_[u]] = 1;  // idempotent plain store: every writer stores the same value
-      // in-place compaction: survivors land at or before the start of the batch that was just read
-      const uint64_t m = __ballot(keep);
-      if (m) {
-        if (keep)
-          region[nkeep + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
-              (uint32_t)xr_[u] | ((uint32_t)yr_[u] << 12) | ((uint32_t)ss[u] << 24);
-        nkeep += (int)__popcll(m);
-      }
+    // in-place compaction: survivors land at or before the start of the batch that was just read
+    const uint64_t m = __ballot(keep);
+    if (m) {
+      if (keep) region[nkeep + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = out;
+      nkeep += (int)__popcll(m);
     }
+  };
+  // the first 512 corners (the usual case: all of them) are fetched with one batch of independent loads and kept in registers for
+  // both sweeps; longer lists continue from memory
+  constexpr int NR = 8;
+  uint32_t ev[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) ev[k] = lane + 64 * k < ncorner ? region[lane + 64 * k] : 0u;
+#pragma unroll
+  for (int k = 0; k < NR; ++k)
+    if (lane + 64 * k < ncorner) tile[((ev[k] >> 8) & 0xff) * FT_PITCH + (ev[k] & 0xff)] = (uint8_t)(ev[k] >> 16);
+  for (int base = 64 * NR; base < ncorner; base += 64) {
+    if (base + lane < ncorner) {
+      const uint32_t e = region[base + lane];
+      tile[((e >> 8) & 0xff) * FT_PITCH + (e & 0xff)] = (uint8_t)(e >> 16);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NR; ++k)
+    if (64 * k < ncorner) nms_one(ev[k], lane + 64 * k < ncorner);
+  for (int base = 64 * NR; base < ncorner; base += 64) {
+    const bool valid = base + lane < ncorner;
+    nms_one(valid ? region[base + lane] : 0u, valid);
   }
   if (lane == 0) cor_n[region_id] = nkeep;
 }
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_fast_emit(FastLevels L, int fast_th, co
   const FastLevel g = L.l[level];
   const int f = blockIdx.y;
   const int64_t region_id = (int64_t)f * L.items_per_frame + item;
-  const uint32_t* region = cor + region_id * ((int64_t)FS_COLS * L.rows_per_seg);
+  const uint32_t* region = cor + region_id * (int64_t)FS_REGION_ENTRIES;
   const int n = cor_n[region_id];
   const uint8_t* hi = cell_hi + (int64_t)f * L.flags_per_frame + g.flag_base;
   uint32_t* out_xy = cand_xy + f * cand_block + g.cand_off;
@@ -388,14 +388,20 @@ __global__ __launch_bounds__(256) void k_fast_emit(FastLevels L, int fast_th, co
 }
 
 // Rows per (strip, segment) work item.  A wavefront lives for the whole item, so long segments leave a long under-filled
-// tail at the end of the launch: 32 rows measured best for full batches (96: +20 % kernel time), 24 for small ones.
-int fast_rows_per_seg(int batch) { return batch >= 16 ? 32 : 24; }
+// tail at the end of the launch (96 rows: +20 % kernel time over 24..32), and the NMS tile of a region has to fit its LDS.
+int fast_rows_per_seg(int batch) {
+  (void)batch;
+  return FS_ROWS_MAX;
+}
 int fast_items_per_frame(const Geom& g, int rows_per_seg) {
   int items = 0;
   for (int l = 0; l < g.nlevels; ++l) items += ((g.lv[l].w - 32 + FS_COLS - 1) / FS_COLS) * ((g.lv[l].h - 32 + rows_per_seg - 1) / rows_per_seg);
   return items;
 }
-int64_t fast_region_entries(int rows_per_seg) { return (int64_t)FS_COLS * rows_per_seg; }
+int64_t fast_region_entries(int rows_per_seg) {
+  (void)rows_per_seg;
+  return FS_REGION_ENTRIES;
+}
 int fast_flags_per_frame(const Geom& g) {
   int n = 0;
   for (int l = 0; l < g.nlevels; ++l) n += g.lv[l].nRows * g.lv[l].nCols;
@@ -416,6 +422,7 @@ static FastLevels fast_levels(const Geom& g, int batch) {
       F.plane_off = G.plane_off, F.cand_off = G.cand_off, F.pitch = G.pitch, F.cand_cap = G.cand_cap;
       F.w = G.w, F.h = G.h, F.bw = G.bw, F.bh = G.bh, F.nCols = G.nCols, F.nRows = G.nRows, F.wCell = G.wCell, F.hCell = G.hCell;
       F.flag_base = fb;
+      F.inv_wcell = (uint32_t)((0x100000000ull + G.wCell - 1) / G.wCell), F.inv_hcell = (uint32_t)((0x100000000ull + G.hCell - 1) / G.hCell);
       fb += G.nRows * G.nCols;
     } else {
       F = FastLevel{};
@@ -426,7 +433,7 @@ static FastLevels fast_levels(const Geom& g, int batch) {
   return L;
 }
 
-// stage 0: score plane + corner regions, 1: sparse NMS, 2: vote + emit (timed separately by the caller)
+// stage 0: scores + in-cell NMS per region, 2: threshold vote + emit (timed separately by the caller); d_score / d_lv unused
 void launch_fast_stage(hipStream_t s, int stage, const uint8_t* d_pyr, uint8_t* d_score, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g,
                        int fast_th, uint32_t* d_cor, int32_t* d_cor_n, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc,
                        int64_t cand_block, int32_t* d_cand_count, int batch) {
@@ -435,10 +442,9 @@ void launch_fast_stage(hipStream_t s, int stage, const uint8_t* d_pyr, uint8_t* 
   const dim3 grid((L.items_per_frame + 3) / 4, batch);
   if (stage == 0) {
     (void)hipMemsetAsync(d_cell_hi, 0, (size_t)batch * L.flags_per_frame, s);
-    hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, s, d_pyr, d_score, pyr_block, d_lv, g.nlevels, t_min, L.rows_per_seg, d_cor, d_cor_n,
-                       L.items_per_frame);
+    hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, s, d_pyr, pyr_block, L, t_min, fast_th, d_cor, d_cor_n, d_cell_hi);
   } else if (stage == 1) {
-    hipLaunchKernelGGL(k_fast_nms, grid, dim3(256), 0, s, d_score, pyr_block, L, fast_th, d_cor, d_cor_n, d_cell_hi);
+    // (the sparse NMS pass is part of stage 0 now)
   } else {
     hipLaunchKernelGGL(k_fast_emit, grid, dim3(256), 0, s, L, fast_th, d_cor, d_cor_n, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count);
   }
