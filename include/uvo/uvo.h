@@ -408,6 +408,32 @@ int uvo_extractor_wait_matcher(uvo_extractor* h, uvo_matcher* m);
 int uvo_matcher_profile(uvo_matcher* m, int enable);
 int uvo_matcher_kernel_times(uvo_matcher* m, char* names, int names_cap, float* ms, int32_t* launches, int cap, int* n);
 
+/* ------------------------------------------------------------------------------------------------
+ * KLT step in front of the extractor: cv::buildOpticalFlowPyramid (src/FrameKTL.cc:76) and cv::calcOpticalFlowPyrLK with
+ * OPTFLOW_USE_INITIAL_FLOW + OPTFLOW_LK_GET_MIN_EIGENVALS (src/Tracking.cc:1046-1047).  Pyramids (image levels with a
+ * winSize REFLECT_101 border + Scharr derivatives) stay on the device in numbered slots, so a frame's pyramid is built once
+ * and tracked against twice (as previous, then as next).  Integer stages are exact; the tracker's float sums are reduced
+ * across a wavefront, i.e. associated differently from a raster-order CPU loop (positions agree to float rounding).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct uvo_klt uvo_klt;
+typedef struct uvo_klt_cfg {
+  int32_t max_width, max_height;
+  int32_t max_level;              /* mPyr_Levels: levels 0..max_level (fewer when a level would not exceed the window) */
+  int32_t win_width, win_height;  /* mWin_Size, e.g. 21 x 21; at most 1024 pixels */
+  int32_t max_points;
+  int32_t slots;                  /* pyramids kept on the device (>= 2) */
+  int32_t device;
+} uvo_klt_cfg;
+int uvo_klt_create(const uvo_klt_cfg* cfg, uvo_klt** out);
+void uvo_klt_destroy(uvo_klt* k);
+int uvo_klt_build_pyramid(uvo_klt* k, int slot, const uint8_t* img, int width, int height, ptrdiff_t stride, int* levels_built);
+/* test tap: level without its border; img [h][w] u8, deriv [h][w][2] int16 (either may be NULL) */
+int uvo_klt_read_level(uvo_klt* k, int slot, int level, uint8_t* img, int16_t* deriv, int* width, int* height);
+/* prev_pts / next_pts: n x (x, y) float32; next_pts in = initial flow, out = tracked positions; status[n], err[n] (min eigenvalue).
+ * max_count / epsilon: the TermCriteria (30, 0.01 at the call site); min_eig_threshold: 1e-4 (OpenCV default). */
+int uvo_klt_track(uvo_klt* k, int prev_slot, int next_slot, const float* prev_pts, float* next_pts, int n, int max_level, int max_count,
+                  double epsilon, double min_eig_threshold, uint8_t* status, float* err);
+
 /* last HIP / argument error text for the calling thread's most recent failing call (never NULL) */
 const char* uvo_last_error(void);
 /* library + device description, e.g. "uvo 0.1 gfx950 AMD Instinct MI355X" */

@@ -233,6 +233,33 @@ void orc_clahe(const uint8_t* img, int w, int h, long stride, double clip, int t
 
 void orc_haloc_hash(const float* r, int num_proj, int r_stride, const uint8_t* desc, int n, float* hash) { haloc_hash(r, num_proj, r_stride, desc, n, hash); }
 
+// KLT: pyramids are opaque handles
+void* orc_klt_pyramid(const uint8_t* img, int w, int h, long stride, int win_w, int win_h, int maxLevel) {
+  KltPyramid* p = new KltPyramid();
+  p->build(img, w, h, (ptrdiff_t)stride, win_w, win_h, maxLevel);
+  return p;
+}
+void orc_klt_pyramid_free(void* p) { delete static_cast<KltPyramid*>(p); }
+int orc_klt_levels(void* p) { return (int)static_cast<KltPyramid*>(p)->levels.size(); }
+void orc_klt_level_dims(void* p, int l, int* w, int* h) {
+  KltPyramid* P = static_cast<KltPyramid*>(p);
+  *w = P->levels[l].w, *h = P->levels[l].h;
+}
+// copies level l without its border: image (w x h u8) and derivatives (w x h x 2 int16)
+void orc_klt_level(void* p, int l, uint8_t* img, int16_t* deriv) {
+  KltPyramid* P = static_cast<KltPyramid*>(p);
+  const KltPyramid::Level& L = P->levels[l];
+  for (int y = 0; y < L.h; ++y) {
+    memcpy(img + (size_t)y * L.w, L.img.data() + (size_t)(y + P->by) * L.istep + P->bx, L.w);
+    memcpy(deriv + (size_t)y * L.w * 2, L.deriv.data() + (size_t)(y + P->by) * L.dstep + 2 * P->bx, (size_t)L.w * 4);
+  }
+}
+void orc_klt_track(void* p0, void* p1, const float* prevPts, float* nextPts, int n, int win_w, int win_h, int maxLevel, int maxCount, double eps,
+                   double minEig, uint8_t* status, float* err) {
+  klt_track(*static_cast<KltPyramid*>(p0), *static_cast<KltPyramid*>(p1), prevPts, nextPts, n, win_w, win_h, maxLevel, maxCount, eps, minEig, status,
+            err);
+}
+
 void orc_compute_three_maxima(const int* sizes, int L, int* ind) {
   int a = -1, b = -1, c = -1;
   compute_three_maxima(sizes, L, a, b, c);

@@ -181,4 +181,19 @@ void bow_transform(const Vocabulary& voc, const uint8_t* features, int n, int le
 // haloc::Hash::getHash: src/hash.cpp:57-85 (r = the projection vectors, each at least n long)
 void haloc_hash(const float* r, int num_proj, int r_stride, const uint8_t* desc, int n, float* hash);
 
+// ---- KLT front-end step (klt_oracle.cpp): cv::buildOpticalFlowPyramid + cv::calcOpticalFlowPyrLK ----
+struct KltPyramid {
+  struct Level {
+    int w, h;
+    ptrdiff_t istep, dstep;        // image bytes per row / derivative shorts per row, both incl. the window border
+    std::vector<uint8_t> img;      // (w + 2bx) x (h + 2by), REFLECT_101 border
+    std::vector<int16_t> deriv;    // interleaved (dx, dy), zero border
+  };
+  int bx = 0, by = 0;
+  std::vector<Level> levels;
+  void build(const uint8_t* img, int w, int h, ptrdiff_t stride, int win_w, int win_h, int maxLevel);
+};
+void klt_track(const KltPyramid& P0, const KltPyramid& P1, const float* prevPts, float* nextPts, int npts, int win_w, int win_h, int maxLevel,
+               int maxCount, double epsilon, double minEigThreshold, uint8_t* status, float* err);
+
 }  // namespace orc

@@ -56,6 +56,13 @@ class Oracle:
         L.orc_search_for_triangulation.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp]
         L.orc_fuse_search.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp]
         L.orc_compute_three_maxima.argtypes = [vp, ci, vp]
+        L.orc_klt_pyramid.restype = vp
+        L.orc_klt_pyramid.argtypes = [vp, ci, ci, cl, ci, ci, ci]
+        L.orc_klt_pyramid_free.argtypes = [vp]
+        L.orc_klt_levels.argtypes = [vp]
+        L.orc_klt_level_dims.argtypes = [vp, ci, vp, vp]
+        L.orc_klt_level.argtypes = [vp, ci, vp, vp]
+        L.orc_klt_track.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_double, ctypes.c_double, vp, vp]
         L.orc_haloc_hash.argtypes = [vp, ci, ci, vp, ci, vp]
         L.orc_clahe.argtypes = [vp, ci, ci, cl, ctypes.c_double, ci, ci, vp, cl]
         L.orc_bow_transform.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -249,6 +256,17 @@ class Oracle:
         self.L.orc_haloc_hash(proj.ctypes.data, proj.shape[0], proj.shape[1], desc.ctypes.data, len(desc), out.ctypes.data)
         return out
 
+    def klt_pyramid(self, img, win=(21, 21), max_level=5):
+        return OracleKltPyramid(self, img, win, max_level)
+
+    def klt_track(self, p0, p1, prev_pts, next_pts0=None, win=(21, 21), max_level=5, max_count=30, epsilon=0.01, min_eig=1e-4):
+        a = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+        b = a.copy() if next_pts0 is None else np.ascontiguousarray(next_pts0, np.float32).reshape(-1, 2).copy()
+        st, er = np.zeros(len(a), np.uint8), np.zeros(len(a), np.float32)
+        self.L.orc_klt_track(p0.h, p1.h, a.ctypes.data, b.ctypes.data, len(a), win[0], win[1], max_level, max_count, float(epsilon), float(min_eig),
+                             st.ctypes.data, er.ctypes.data)
+        return b, st, er
+
     def compute_three_maxima(self, sizes):
         s = np.ascontiguousarray(sizes, np.int32)
         out = np.zeros(3, np.int32)
@@ -262,6 +280,27 @@ class Oracle:
         n = self.L.orc_grider_fast(img.ctypes.data, w, h, img.strides[0], num_features, grid_x, grid_y, threshold, 1 if nms else 0,
                                    out.ctypes.data, len(out))
         return out[:n].copy()
+
+
+class OracleKltPyramid:
+    def __init__(self, o, img, win, max_level):
+        self.L = o.L
+        img = np.ascontiguousarray(img, np.uint8)
+        self.h = self.L.orc_klt_pyramid(img.ctypes.data, img.shape[1], img.shape[0], img.strides[0], win[0], win[1], max_level)
+        self.levels = self.L.orc_klt_levels(self.h)
+
+    def level(self, l):
+        w, h = ctypes.c_int(), ctypes.c_int()
+        self.L.orc_klt_level_dims(self.h, l, ctypes.byref(w), ctypes.byref(h))
+        img, der = np.zeros((h.value, w.value), np.uint8), np.zeros((h.value, w.value, 2), np.int16)
+        self.L.orc_klt_level(self.h, l, img.ctypes.data, der.ctypes.data)
+        return img, der
+
+    def __del__(self):
+        try:
+            self.L.orc_klt_pyramid_free(self.h)
+        except Exception:
+            pass
 
 
 class OracleExtractor:

@@ -678,3 +678,39 @@ def test_haloc_hash(uvo, oracle, synth):
         proj /= np.linalg.norm(proj, axis=1, keepdims=True).astype(np.float32)
         np.testing.assert_array_equal(m.haloc_hash(proj, de).view(np.uint32), oracle.haloc_hash(proj, de).view(np.uint32))
     m.close()
+
+
+def test_klt_pyramid_and_tracking(uvo, oracle, synth):
+    """cv::buildOpticalFlowPyramid + cv::calcOpticalFlowPyrLK: pyramid levels and derivatives bit-exact; tracked positions to float
+    rounding (the wavefront reduction associates the float sums differently from the raster-order CPU loop; an iteration that
+    lands exactly on a termination threshold may stop one step apart)."""
+    rng = np.random.default_rng(80)
+    for (w, h), win, ml in (((640, 512), (21, 21), 5), ((752, 480), (15, 15), 3), ((331, 257), (21, 21), 5)):
+        a = synth.make_frame(6000 + w, w, h)
+        b = synth.warp_frame(a, 6001 + w)
+        k = uvo.KLT(w, h, win, ml, max_points=4096, slots=2)
+        na, nb = k.build_pyramid(0, a), k.build_pyramid(1, b)
+        pa, pb = oracle.klt_pyramid(a, win, ml), oracle.klt_pyramid(b, win, ml)
+        assert na == nb == pa.levels
+        for l in range(na):
+            gi, gd = k.read_level(0, l)
+            oi, od = pa.level(l)
+            np.testing.assert_array_equal(gi, oi, err_msg="image level %d" % l)
+            np.testing.assert_array_equal(gd, od, err_msg="derivative level %d" % l)
+        n = 2000
+        pts = np.stack([rng.uniform(-5, w + 5, n), rng.uniform(-5, h + 5, n)], 1).astype(np.float32)   # some outside / at the border
+        init = (pts + rng.normal(0, 1.0, (n, 2))).astype(np.float32)                                   # OPTFLOW_USE_INITIAL_FLOW
+        g_next, g_st, g_err = k.track(0, 1, pts, init)
+        o_next, o_st, o_err = oracle.klt_track(pa, pb, pts, init, win, ml)
+        assert (g_st == o_st).mean() > 0.995
+        both = (g_st > 0) & (o_st > 0)
+        assert both.sum() > 0.6 * n
+        d = np.abs(g_next[both] - o_next[both]).max(axis=1)
+        assert np.median(d) < 1e-3 and (d < 0.05).mean() > 0.99, (np.median(d), (d < 0.05).mean())
+        same = g_st == o_st
+        np.testing.assert_allclose(g_err[same], o_err[same], rtol=1e-4, atol=1e-6)
+        # second use of a pyramid in the other role (frame t becomes "previous"), slots swapped
+        g2, s2, _ = k.track(1, 0, pts)
+        o2, so2, _ = oracle.klt_track(pb, pa, pts, None, win, ml)
+        assert (s2 == so2).mean() > 0.995
+        k.close()

@@ -486,3 +486,43 @@ def test_clahe_by_hand_and_against_numpy(oracle, synth):
         np.testing.assert_array_equal(oracle.clahe(img, clip, tiles), _clahe_numpy(img, clip, tiles), err_msg=str((shape, tiles, clip)))
     img = synth.make_frame(5, 640, 512)
     np.testing.assert_array_equal(oracle.clahe(img, 4.0, (12, 12)), _clahe_numpy(img, 4.0, (12, 12)))
+
+
+# ---- KLT step (cv::buildOpticalFlowPyramid + cv::calcOpticalFlowPyrLK, src/FrameKTL.cc:76, src/Tracking.cc:1046-1047) -------
+def test_klt_pyramid_and_tracker_known_answers(oracle, synth):
+    # pyrDown of a constant image is the constant; Scharr derivatives of a horizontal ramp: dx = 32 * slope, dy = 0
+    flat = np.full((64, 96), 77, np.uint8)
+    p = oracle.klt_pyramid(flat, (5, 5), 3)
+    assert p.levels == 4
+    for l in range(4):
+        img, der = p.level(l)
+        assert img.shape == ((64 >> l), (96 >> l)) and (img == 77).all() and (der == 0).all()
+    ramp = np.tile((np.arange(96) * 2).astype(np.uint8), (64, 1))
+    img, der = oracle.klt_pyramid(ramp, (5, 5), 0).level(0)
+    assert (der[:, 1:-1, 0] == 2 * 2 * 16).all() and (der[..., 1] == 0).all() and (der[:, 0, 0] == 0).all()   # (3+10+3) * (I[x+1]-I[x-1]); reflect at the edge
+    # pyrDown against an independent numpy statement (separable 1-4-6-4-1, reflect-101, (sum + 128) >> 8)
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, (45, 71), dtype=np.uint8)
+    lvl1, _ = oracle.klt_pyramid(a, (5, 5), 1).level(1)
+    pad = np.pad(a.astype(np.int64), 2, mode="reflect")
+    k = np.array([1, 4, 6, 4, 1])
+    hor = sum(k[i] * pad[:, i:i + a.shape[1]] for i in range(5))
+    full = sum(k[j] * hor[j:j + a.shape[0], :] for j in range(5))
+    np.testing.assert_array_equal(lvl1, ((full[::2, ::2] + 128) >> 8).astype(np.uint8))
+    # tracker: a frame shifted by whole pixels is found again; points too close to nothing trackable fail the eigenvalue test
+    base = synth.make_frame(21, 400, 320)
+    shifted = np.roll(np.roll(base, 3, axis=1), -2, axis=0)
+    p0, p1 = oracle.klt_pyramid(base), oracle.klt_pyramid(shifted)
+    ys, xs = np.mgrid[60:260:25, 60:340:25]
+    pts = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.float32)
+    nxt, st, er = oracle.klt_track(p0, p1, pts)
+    good = st > 0
+    assert good.mean() > 0.9
+    d = nxt[good] - pts[good]
+    assert np.abs(np.median(d, axis=0) - [3, -2]).max() < 0.05 and (np.abs(d - [3, -2]).max(axis=1) < 0.5).mean() > 0.95
+    flat_p = oracle.klt_pyramid(np.full((320, 400), 90, np.uint8))
+    _, st, er = oracle.klt_track(flat_p, flat_p, pts)
+    assert (st == 0).all() and (er == 0).all()                          # minEig = 0 < 1e-4
+    # a point outside the image by more than the window is rejected at level 0 with err = 0
+    _, st, er = oracle.klt_track(p0, p1, np.array([[-40.0, 50.0], [100.0, 100.0]], np.float32))
+    assert st[0] == 0 and er[0] == 0 and st[1] == 1

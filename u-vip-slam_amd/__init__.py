@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
-    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_haloc_hash", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
+    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_haloc_hash", "uvo_klt_create", "uvo_klt_destroy", "uvo_klt_build_pyramid", "uvo_klt_read_level", "uvo_klt_track", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
     "uvo_matcher_kernel_times", "uvo_last_error", "uvo_device_info",
 ]
 
@@ -156,6 +156,12 @@ def _load():
     lib.uvo_vocabulary_destroy.restype = None
     lib.uvo_bow_transform.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp]
     lib.uvo_haloc_hash.argtypes = [vp, vp, ci, ci, vp, ci, vp]
+    lib.uvo_klt_create.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.uvo_klt_destroy.argtypes = [vp]
+    lib.uvo_klt_destroy.restype = None
+    lib.uvo_klt_build_pyramid.argtypes = [vp, ci, vp, ci, ci, cl, vp]
+    lib.uvo_klt_read_level.argtypes = [vp, ci, ci, vp, vp, vp, vp]
+    lib.uvo_klt_track.argtypes = [vp, ci, ci, vp, vp, ci, ci, ci, ctypes.c_double, ctypes.c_double, vp, vp]
     lib.uvo_fuse.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, vp, vp]
     lib.uvo_matcher_wait_extractor.argtypes = [vp, vp]
     lib.uvo_extractor_wait_matcher.argtypes = [vp, vp]
@@ -634,6 +640,62 @@ class ORBVocabulary:
             raise UvoError(rc, "uvo_bow_transform")
         groups = {int(fnode[j]): [int(x) for x in ffeat[fstart[j]:fstart[j + 1]]] for j in range(nf.value)}
         return wid, ww, nid, (bid[:nb.value].copy(), bval[:nb.value].copy()), FeatureVector(groups)
+
+
+class KltCfg(ctypes.Structure):
+    """uvo_klt_cfg."""
+    _fields_ = [("max_width", ctypes.c_int32), ("max_height", ctypes.c_int32), ("max_level", ctypes.c_int32), ("win_width", ctypes.c_int32),
+                ("win_height", ctypes.c_int32), ("max_points", ctypes.c_int32), ("slots", ctypes.c_int32), ("device", ctypes.c_int32)]
+
+
+class KLT:
+    """cv::buildOpticalFlowPyramid (src/FrameKTL.cc:76) + cv::calcOpticalFlowPyrLK as called at src/Tracking.cc:1046-1047
+    (USE_INITIAL_FLOW + LK_GET_MIN_EIGENVALS, 30 iterations / eps 0.01)."""
+
+    def __init__(self, max_width, max_height, win=(21, 21), max_level=5, max_points=4096, slots=2, device=0):
+        cfg = KltCfg(max_width, max_height, max_level, win[0], win[1], max_points, slots, device)
+        self._h = ctypes.c_void_p()
+        self.max_level = max_level
+        rc = lib.uvo_klt_create(ctypes.byref(cfg), ctypes.byref(self._h))
+        if rc:
+            raise UvoError(rc, "uvo_klt_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib.uvo_klt_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def build_pyramid(self, slot, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        n = ctypes.c_int()
+        rc = lib.uvo_klt_build_pyramid(self._h, slot, _ptr(img), img.shape[1], img.shape[0], img.strides[0], ctypes.byref(n))
+        if rc:
+            raise UvoError(rc, "uvo_klt_build_pyramid")
+        return n.value
+
+    def read_level(self, slot, level):
+        w, h = ctypes.c_int(), ctypes.c_int()
+        rc = lib.uvo_klt_read_level(self._h, slot, level, None, None, ctypes.byref(w), ctypes.byref(h))
+        if rc:
+            raise UvoError(rc, "uvo_klt_read_level")
+        img, der = np.zeros((h.value, w.value), np.uint8), np.zeros((h.value, w.value, 2), np.int16)
+        rc = lib.uvo_klt_read_level(self._h, slot, level, _ptr(img), _ptr(der), ctypes.byref(w), ctypes.byref(h))
+        if rc:
+            raise UvoError(rc, "uvo_klt_read_level")
+        return img, der
+
+    def track(self, prev_slot, next_slot, prev_pts, next_pts0=None, max_count=30, epsilon=0.01, min_eig_threshold=1e-4):
+        """Returns (next_pts, status, err)."""
+        p0 = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+        p1 = p0.copy() if next_pts0 is None else np.ascontiguousarray(next_pts0, np.float32).reshape(-1, 2).copy()
+        st, er = np.zeros(len(p0), np.uint8), np.zeros(len(p0), np.float32)
+        rc = lib.uvo_klt_track(self._h, prev_slot, next_slot, _ptr(p0), _ptr(p1), len(p0), self.max_level, int(max_count), float(epsilon),
+                               float(min_eig_threshold), _ptr(st), _ptr(er))
+        if rc:
+            raise UvoError(rc, "uvo_klt_track")
+        return p1, st, er
 
 
 def DescriptorDistance(a, b):
