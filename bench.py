@@ -229,16 +229,17 @@ def main():
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         total_alg = sum(v for kname, v in alg.items() if kname != "k_pad_level0")
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command (separate --pmc runs,
-        # profiles/r01_d_pmc.json; FETCH_SIZE under-reports reads by 2x on gfx950): bytes per launch, or null if not recorded
+        # the newest profiles/r*_pmc.json; FETCH_SIZE under-reports reads by 2x on gfx950): bytes per launch, or null if not recorded
         traffic, traffic_src = None, None
         try:
-            pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_pmc.json")
+            import glob
+            pmc_path = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc.json")))[-1]
             with open(pmc_path) as fh:
                 e = json.load(fh)["kernels"].get(dom)
             if e and "FETCH_SIZE" in e and "WRITE_SIZE" in e:
                 traffic = int((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024)
-                traffic_src = "profiles/r01_d_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH + WRITE)"
-        except (OSError, ValueError, KeyError):
+                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH + WRITE)" % os.path.basename(pmc_path)
+        except (OSError, ValueError, KeyError, IndexError):
             pass
         out = {
             "metric": "frames/sec ORB extract+match, 640x512 @1000 kp",
