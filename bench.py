@@ -49,7 +49,6 @@ def algorithmic_bytes_per_frame(w, h, k):
         "k_pad_level0": 2 * s[0],                       # not in the survey's model (a design that reads the input in place needs none)
         "k_resize_level": sum(s[:-1]) + sum(s[1:]),     # reads S0..S6, writes S1..S7 (all 7 launches)
         "k_fast_score": tot,                            # reads every level once (the score plane it writes is scratch)
-        "k_fast_emit": 0,
         "k_gauss7": 2 * tot,
         "k_octree": 0,
         "k_assemble": 0,

@@ -347,9 +347,9 @@ static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, 
     launch_resize_level(s, h->lane[h->cur].d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_ctab + g.lv[l].xtab_off, h->d_rtab + g.lv[l].ytab_off,
                         h->resize_fast[l], batch);
   }
-  static const char* const kFastNames[3] = {"k_fast_score", "", "k_fast_emit"};
-  for (int stage = 0; stage < 3; stage += 2) {
-    ProfScope p(h, kFastNames[stage]);
+  {  // the per-cell threshold vote + candidate emit run inside k_octree
+    const int stage = 0;
+    ProfScope p(h, "k_fast_score");
     launch_fast_stage(s, stage, h->lane[h->cur].d_pyr, h->lane[h->cur].d_score, g.pyr_block, h->d_lv, g, h->cfg.fast_th, h->lane[h->cur].d_cor,
                       h->lane[h->cur].d_cor_n, h->lane[h->cur].d_cell_hi, h->lane[h->cur].d_cand_xy, h->lane[h->cur].d_cand_sc, g.cand_block,
                       h->lane[h->cur].d_cand_count, batch);
@@ -360,7 +360,7 @@ static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, 
   }
   {
     ProfScope p(h, "k_octree");
-    launch_octree(s, h->d_lv, g, h->lane[h->cur].d_cand_xy, h->lane[h->cur].d_cand_sc, g.cand_block, h->lane[h->cur].d_cand_count, h->lane[h->cur].d_pstate, h->lane[h->cur].d_sel_xy, h->lane[h->cur].d_sel_sc,
+    launch_octree(s, h->d_lv, g, h->cfg.fast_th, h->lane[h->cur].d_cor, h->lane[h->cur].d_cor_n, h->lane[h->cur].d_cell_hi, h->lane[h->cur].d_cand_xy, h->lane[h->cur].d_cand_sc, g.cand_block, h->lane[h->cur].d_cand_count, h->lane[h->cur].d_pstate, h->lane[h->cur].d_sel_xy, h->lane[h->cur].d_sel_sc,
                   h->lane[h->cur].d_sel_count, batch);
   }
   {

@@ -19,16 +19,14 @@
 //                   in-cell 3x3 NMS itself on a byte tile laid over its LDS (neighbours outside the corner's own cell
 //                   interior count as 0), compacts the survivors in place and marks cells that own a survivor >= fastTh.
 //                   HBM traffic: the level once in, a few hundred survivor records out.
-//   k_fast_emit   : per survivor, the cell's vote picks fastTh or the literal-7 fallback; kept points are appended to
-//                   the (frame, level) candidate list (one wave-aggregated atomic per 64).  Candidate order in HBM is
-//                   arbitrary: the quad-tree orders by coordinates.
+//   the per-cell vote (survivors >= fastTh if the cell has any, else the literal-7 fallback) needs every region of a cell to
+//   be finished, so it is taken by the quad-tree kernel when it gathers a level's candidates (octree.hip).  Candidate order
+//   in HBM is arbitrary: the quad-tree orders by coordinates.
 #include "common.hpp"
+#include "fast_geom.hpp"
 
 namespace uvo {
 
-constexpr int FS_COLS = 248;      // useful columns per wavefront strip (lanes 1..62)
-constexpr int FS_ROWS_MAX = 24;   // rows per (strip, segment) region; bounded by the NMS tile that must fit the wavefront's LDS
-constexpr int FS_REGION_ENTRIES = (FS_COLS + 2) * (FS_ROWS_MAX + 2);  // corner list capacity: the region plus its halo ring
 constexpr int FQ_CAP = 320;       // queue entries per wavefront: < 64 left over + <= 256 pushed per row
 
 // max over the 16 arcs of 9 contiguous ring pixels of min(d).  A 9-window always straddles the two 8-pixel halves of the
@@ -126,35 +124,6 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
     if (corner) region[ncorner + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = packed;
     ncorner += (int)__popcll(m);
   }
-}
-
-struct FastLevel {  // per-level values of the sparse stages, passed in the kernel argument block (scalar loads)
-  int64_t plane_off, cand_off;
-  int pitch, cand_cap;
-  int w, h, bw, bh;
-  int nCols, nRows, wCell, hCell;
-  int flag_base;  // first entry of this level in the per-frame cell-flag array (full nRows x nCols grid)
-  int pad;
-  uint32_t inv_wcell, inv_hcell;  // ceil(2^32 / wCell), ceil(2^32 / hCell): n / cell = umulhi(n, inv) for the coordinate range
-};
-struct FastLevels {
-  FastLevel l[kMaxLevels];
-  int nlevels, rows_per_seg, items_per_frame, flags_per_frame;
-};
-
-// region id -> (level, strip, segment); false when the wavefront has no region
-__device__ __forceinline__ bool fast_region(const FastLevels& L, int item, int& level, int& X0, int& py0) {
-  for (level = 0; level < L.nlevels; ++level) {
-    const int nstrip = (L.l[level].w - 32 + FS_COLS - 1) / FS_COLS;
-    const int nseg = (L.l[level].h - 32 + L.rows_per_seg - 1) / L.rows_per_seg;
-    if (item < nstrip * nseg) {
-      X0 = 28 + (item % nstrip) * FS_COLS;
-      py0 = 32 + (item / nstrip) * L.rows_per_seg;
-      return true;
-    }
-    item -= nstrip * nseg;
-  }
-  return false;
 }
 
 // One wavefront per (strip, segment) region: 248 x rows_per_seg pixels of the detection window plus a one-pixel halo ring whose
@@ -343,50 +312,6 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
   if (lane == 0) cor_n[region_id] = nkeep;
 }
 
-__global__ __launch_bounds__(256) void k_fast_emit(FastLevels L, int fast_th, const uint32_t* __restrict__ cor, const int32_t* __restrict__ cor_n,
-                                                   const uint8_t* __restrict__ cell_hi, uint32_t* __restrict__ cand_xy,
-                                                   uint32_t* __restrict__ cand_sc, int64_t cand_block, int32_t* __restrict__ cand_count) {
-  const int wv = wave_in_block(), lane = threadIdx.x & 63;
-  const int item = blockIdx.x * 4 + wv;
-  int level, X0, py0;
-  if (!fast_region(L, item, level, X0, py0)) return;
-  const FastLevel g = L.l[level];
-  const int f = blockIdx.y;
-  const int64_t region_id = (int64_t)f * L.items_per_frame + item;
-  const uint32_t* region = cor + region_id * (int64_t)FS_REGION_ENTRIES;
-  const int n = cor_n[region_id];
-  const uint8_t* hi = cell_hi + (int64_t)f * L.flags_per_frame + g.flag_base;
-  uint32_t* out_xy = cand_xy + f * cand_block + g.cand_off;
-  uint32_t* out_sc = cand_sc + f * cand_block + g.cand_off;
-  int32_t* cnt = cand_count + f * L.nlevels + level;
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    bool emit = false;
-    int xr = 0, yr = 0, s = 0;
-    if (i < n) {
-      const uint32_t e = region[i];
-      xr = (int)(e & 0xfff), yr = (int)((e >> 12) & 0xfff), s = (int)(e >> 24);
-      int cj = (xr - 3) / g.wCell, ci = (yr - 3) / g.hCell;
-      cj = cj > g.nCols - 1 ? g.nCols - 1 : cj;
-      ci = ci > g.nRows - 1 ? g.nRows - 1 : ci;
-      const int th = hi[ci * g.nCols + cj] ? fast_th : 7;  // FAST(cell, fastTh) empty -> FAST(cell, 7)  (:792-799)
-      emit = s >= th;
-    }
-    const uint64_t m = __ballot(emit);
-    if (m == 0) continue;
-    int gbase = 0;
-    if (lane == 0) gbase = atomicAdd(cnt, (int)__popcll(m));
-    gbase = __shfl(gbase, 0, 64);
-    if (emit) {
-      const int pos = gbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      if (pos < g.cand_cap) {
-        out_xy[pos] = (uint32_t)xr | ((uint32_t)yr << 16);
-        out_sc[pos] = (uint32_t)s;
-      }
-    }
-  }
-}
-
 // Rows per (strip, segment) work item.  A wavefront lives for the whole item, so long segments leave a long under-filled
 // tail at the end of the launch (96 rows: +20 % kernel time over 24..32), and the NMS tile of a region has to fit its LDS.
 int fast_rows_per_seg(int batch) {
@@ -408,7 +333,7 @@ int fast_flags_per_frame(const Geom& g) {
   return n;
 }
 
-static FastLevels fast_levels(const Geom& g, int batch) {
+FastLevels fast_levels(const Geom& g, int batch) {
   FastLevels L;
   L.nlevels = g.nlevels;
   L.rows_per_seg = fast_rows_per_seg(batch);
@@ -433,21 +358,17 @@ static FastLevels fast_levels(const Geom& g, int batch) {
   return L;
 }
 
-// stage 0: scores + in-cell NMS per region, 2: threshold vote + emit (timed separately by the caller); d_score / d_lv unused
+// scores + in-cell NMS per region; d_score / d_lv and the candidate arrays are not touched here any more (see octree.hip)
 void launch_fast_stage(hipStream_t s, int stage, const uint8_t* d_pyr, uint8_t* d_score, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g,
                        int fast_th, uint32_t* d_cor, int32_t* d_cor_n, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc,
                        int64_t cand_block, int32_t* d_cand_count, int batch) {
+  (void)d_score, (void)d_lv, (void)d_cand_xy, (void)d_cand_sc, (void)cand_block, (void)d_cand_count;
+  if (stage != 0) return;
   const int t_min = fast_th < 7 ? fast_th : 7;
   const FastLevels L = fast_levels(g, batch);
   const dim3 grid((L.items_per_frame + 3) / 4, batch);
-  if (stage == 0) {
-    (void)hipMemsetAsync(d_cell_hi, 0, (size_t)batch * L.flags_per_frame, s);
-    hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, s, d_pyr, pyr_block, L, t_min, fast_th, d_cor, d_cor_n, d_cell_hi);
-  } else if (stage == 1) {
-    // (the sparse NMS pass is part of stage 0 now)
-  } else {
-    hipLaunchKernelGGL(k_fast_emit, grid, dim3(256), 0, s, L, fast_th, d_cor, d_cor_n, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count);
-  }
+  (void)hipMemsetAsync(d_cell_hi, 0, (size_t)batch * L.flags_per_frame, s);
+  hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, s, d_pyr, pyr_block, L, t_min, fast_th, d_cor, d_cor_n, d_cell_hi);
 }
 
 }  // namespace uvo

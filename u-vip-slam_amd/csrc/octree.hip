@@ -2,6 +2,7 @@
 // node state carved out of dynamic LDS, candidate state words in HBM scratch.
 #include <cstdio>
 #include "common.hpp"
+#include "fast_geom.hpp"
 #include "octree_core.hpp"
 
 namespace uvo {
@@ -27,8 +28,10 @@ static inline size_t oct_lds_bytes(int M, int Mp2) {
 }
 
 __global__ __launch_bounds__(OCT_THREADS, 4) void k_octree(const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max,
-                                                        const uint32_t* __restrict__ cand_xy, const uint32_t* __restrict__ cand_sc,
-                                                        int64_t cand_block, const int32_t* __restrict__ cand_count,
+                                                        FastLevels FL, int fast_th, const uint32_t* __restrict__ cor,
+                                                        const int32_t* __restrict__ cor_n, const uint8_t* __restrict__ cell_hi,
+                                                        uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc,
+                                                        int64_t cand_block, int32_t* __restrict__ cand_count,
                                                         uint32_t* __restrict__ pstate, uint32_t* __restrict__ sel_xy,
                                                         uint32_t* __restrict__ sel_sc, int sel_block, int32_t* __restrict__ sel_count) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -44,7 +47,70 @@ __global__ __launch_bounds__(OCT_THREADS, 4) void k_octree(const LevelGeom* __re
   } stamp{t_begin, (int)(blockIdx.x * gridDim.y + blockIdx.y)};
 #endif
   const LevelGeom& g = lv[level];
-  int P = cand_count[f * nlevels + level];
+  const int64_t co = f * cand_block + g.cand_off;
+  // ---- candidates of this (frame, level): the NMS survivors of the level's FAST regions that pass the per-cell threshold
+  // (FAST(cell, fastTh); if empty FAST(cell, 7): src/ORBextractor.cc:792-799), gathered by the workgroup itself ----
+  __shared__ int s_pcount;
+  {
+    int first = 0;
+    for (int l = 0; l < level; ++l)
+      first += ((FL.l[l].w - 32 + FS_COLS - 1) / FS_COLS) * ((FL.l[l].h - 32 + FL.rows_per_seg - 1) / FL.rows_per_seg);
+    const FastLevel fg = FL.l[level];
+    const int n_items = ((fg.w - 32 + FS_COLS - 1) / FS_COLS) * ((fg.h - 32 + FL.rows_per_seg - 1) / FL.rows_per_seg);
+    if (threadIdx.x == 0) s_pcount = 0;
+    __syncthreads();
+    const uint8_t* hi = cell_hi + (int64_t)f * FL.flags_per_frame + fg.flag_base;
+    // a wavefront takes four regions at a time so that the three dependent loads (count -> entries -> cell flag) are each issued
+    // for all four before the first result is needed; one LDS atomic per wavefront and batch reserves the output slots
+    const int64_t region0 = (int64_t)f * FL.items_per_frame + first;
+    const int wv = wave_in_block(), lane = threadIdx.x & 63;
+    constexpr int GU = 4, NW = OCT_THREADS / 64;
+    for (int r0 = wv; r0 < n_items; r0 += NW * GU) {
+      int n[GU], nmax = 0;
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const int r = r0 + NW * u;
+        n[u] = r < n_items ? cor_n[region0 + r] : 0;
+        nmax = n[u] > nmax ? n[u] : nmax;
+      }
+      for (int base = 0; base < nmax; base += 64) {
+        uint32_t e[GU];
+        bool emit[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+          e[u] = base + lane < n[u] ? cor[(region0 + r0 + NW * u) * (int64_t)FS_REGION_ENTRIES + base + lane] : 0u;
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+          emit[u] = false;
+          if (base + lane < n[u]) {
+            const int xr = (int)(e[u] & 0xfff), yr = (int)((e[u] >> 12) & 0xfff), sc = (int)(e[u] >> 24);
+            int cj = (int)__umulhi((uint32_t)(xr - 3), fg.inv_wcell), ci = (int)__umulhi((uint32_t)(yr - 3), fg.inv_hcell);
+            cj = cj > fg.nCols - 1 ? fg.nCols - 1 : cj;
+            ci = ci > fg.nRows - 1 ? fg.nRows - 1 : ci;
+            emit[u] = sc >= (hi[ci * fg.nCols + cj] ? fast_th : 7);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+          const uint64_t m = __ballot(emit[u]);
+          if (m == 0) continue;
+          int slot = 0;
+          if (lane == 0) slot = atomicAdd(&s_pcount, (int)__popcll(m));
+          slot = __shfl(slot, 0, 64);
+          if (emit[u]) {
+            const int pos = slot + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (pos < g.cand_cap) {
+              cand_xy[co + pos] = (e[u] & 0xfffu) | (((e[u] >> 12) & 0xfffu) << 16);
+              cand_sc[co + pos] = e[u] >> 24;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  int P = s_pcount;
+  if (threadIdx.x == 0) cand_count[f * nlevels + level] = P;
   P = P > g.cand_cap ? g.cand_cap : P;
   int32_t* out_n = sel_count + f * nlevels + level;
   if (P == 0) {
@@ -78,7 +144,6 @@ __global__ __launch_bounds__(OCT_THREADS, 4) void k_octree(const LevelGeom* __re
   w.part = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * 2 * OCT_THREADS;
   w.sc = reinterpret_cast<int*>(p), p += (size_t)4 * 16;
 
-  const int64_t co = f * cand_block + g.cand_off;
   const int64_t so = (int64_t)f * sel_block + g.sel_off;
   // candidate state in registers when the list fits 8 / 32 candidates per thread, else in the HBM scratch words
   int n;
@@ -91,8 +156,8 @@ __global__ __launch_bounds__(OCT_THREADS, 4) void k_octree(const LevelGeom* __re
   if (threadIdx.x == 0) *out_n = n;
 }
 
-void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_xy, const uint32_t* d_cand_sc,
-                   int64_t cand_block, const int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
+void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, int fast_th, const uint32_t* d_cor, const int32_t* d_cor_n,
+                   const uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
                    int32_t* d_sel_count, int batch) {
   int M = 0;
   for (int l = 0; l < g.nlevels; ++l) {
@@ -122,7 +187,8 @@ void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const ui
     }
   }
 #endif
-  hipLaunchKernelGGL(k_octree, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, d_cand_xy, d_cand_sc, cand_block,
+  hipLaunchKernelGGL(k_octree, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, fast_levels(g, batch), fast_th, d_cor, d_cor_n,
+                     d_cell_hi, d_cand_xy, d_cand_sc, cand_block,
                      d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count);
 }
 
