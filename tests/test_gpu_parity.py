@@ -714,3 +714,40 @@ def test_klt_pyramid_and_tracking(uvo, oracle, synth):
         o2, so2, _ = oracle.klt_track(pb, pa, pts, None, win, ml)
         assert (s2 == so2).mean() > 0.995
         k.close()
+
+
+def test_new_entry_points_reject_bad_arguments(uvo):
+    """Error behaviour of the search / BoW / KLT / CLAHE entry points: bad input -> UvoError with a message, never a crash."""
+    m = uvo.ORBmatcher(0.8)
+    kp = np.zeros(4, uvo.KEYPOINT_DTYPE)
+    kp["x"], kp["y"] = [10, 20, 30, 40], [10, 20, 30, 40]
+    de = np.zeros((4, 32), np.uint8)
+    one = np.ones(1, np.float32)
+    with pytest.raises(uvo.UvoError):                       # unknown rule
+        m.match_windows(kp, de, (0, 0, 64, 48), one, one, one, [0], [0], [1], de[:1], 9, 50)
+    with pytest.raises(uvo.UvoError):                       # empty bounds
+        m.match_windows(kp, de, (0, 0, 0, 48), one, one, one, [0], [0], [1], de[:1], uvo.RULE_BEST_ONLY, 50)
+    with pytest.raises(uvo.UvoError):                       # feature index outside the keypoint range
+        m.SearchByBoW(uvo.FeatureVector({1: [0, 7]}), de, np.zeros(4), np.ones(4), uvo.FeatureVector({1: [0]}), de, np.zeros(4))
+    with pytest.raises(uvo.UvoError):                       # map point level outside the scale table
+        m.FuseSearch(kp, de, (0, 0, 64, 48), one, one, [9], [1], de[:1], np.ones(8, np.float32))
+    # degenerate but legal: no queries, no targets
+    mt, dist, n = m.match_windows(kp[:0], de[:0], (0, 0, 64, 48), one, one, one, [0], [0], [1], de[:1], uvo.RULE_BEST_ONLY, 50)
+    assert n == 0 and mt.tolist() == [-1]
+    mm, n = m.SearchByBoW(uvo.FeatureVector({}), de, np.zeros(4), np.ones(4), uvo.FeatureVector({1: [0]}), de, np.zeros(4))
+    assert n == 0 and (mm == -1).all()
+    m.close()
+    with pytest.raises(uvo.UvoError):                       # child id pointing at the root
+        uvo.ORBVocabulary([0, 1, 1], [0], np.zeros((2, 32), np.uint8), [-1, 0], [0.0, 1.0], 1)
+    with pytest.raises(uvo.UvoError):                       # window larger than 1024 pixels
+        uvo.KLT(640, 480, (40, 40), 3)
+    k = uvo.KLT(640, 480, (21, 21), 3)
+    with pytest.raises(uvo.UvoError):                       # tracking before any pyramid was built
+        k.track(0, 1, np.zeros((1, 2), np.float32))
+    with pytest.raises(uvo.UvoError):                       # image larger than the handle
+        k.build_pyramid(0, np.zeros((500, 700), np.uint8))
+    k.close()
+    ex = uvo.ORBextractor(500, 1.2, 4, 0, 20, max_width=320, max_height=240)
+    with pytest.raises(uvo.UvoError):                       # more tiles than pixels
+        ex.clahe(np.zeros((240, 320), np.uint8), 4.0, (400, 12))
+    ex.close()
