@@ -211,8 +211,9 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
             const uint32_t P6 = __builtin_amdgcn_alignbyte(Rm2, Cm2, 2), P10 = __builtin_amdgcn_alignbyte(Cm2, Lm2, 2);
             const uint32_t re = screen2(Cc & kEven, Cd & kEven, Cu & kEven, P4 & kEven, P12 & kEven, P2 & kEven, P10 & kEven, P6 & kEven,
                                         P14 & kEven, t_even);
-            const uint32_t ro = screen2(Cc & kOdd, Cd & kOdd, Cu & kOdd, P4 & kOdd, P12 & kOdd, P2 & kOdd, P10 & kOdd, P6 & kOdd, P14 & kOdd,
-                                        t_odd);
+            // odd pixels: unmasked words.  The even byte below the odd one only acts as a tie-breaker between equal odd bytes, which
+            // can let a few more pixels through the screen (harmless: the exact test follows) but never drops one.
+            const uint32_t ro = screen2(Cc, Cd, Cu, P4, P12, P2, P10, P6, P14, t_odd);
 #define UVO_FAST_PUSH(K, COND)                                                                                    \
   {                                                                                                               \
     const bool pass = (COND) & ok##K;                                                                             \
