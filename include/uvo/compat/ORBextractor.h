@@ -110,11 +110,8 @@ class ORBextractor {
     c.max_width = max_w_, c.max_height = max_h_, c.max_batch = 1, c.max_input_keypoints = max_in_, c.device = device_;
     int rc = uvo_extractor_create(&c, &h_);
     if (rc != UVO_OK) return rc;
-    std::vector<int32_t> quota(nlevels_);
-    uvo_extractor_tables(h_, nullptr, nullptr, quota.data(), nullptr);
-    cap_ = max_in_;
-    for (int q : quota) cap_ += q + 4;
-    return UVO_OK;
+    cap_ = uvo_extractor_max_keypoints(h_);  // can never overflow: sum over levels of max(quota, 4 * nIni) + 4, plus the pass-through points
+    return cap_ < 0 ? cap_ : UVO_OK;
   }
 
   int nfeatures_;

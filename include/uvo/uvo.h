@@ -66,6 +66,9 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out);
 void uvo_extractor_destroy(uvo_extractor* h);
 
 /* ORBextractor::GetLevels / GetScaleFactor: include/ORBextractor.h:60-64 */
+/* Largest number of keypoints one frame can return with this handle (sum over levels of max(quota, 4 * nIni) + 4, plus
+ * max_input_keypoints): the output capacity that can never overflow.  Negative = error code. */
+int uvo_extractor_max_keypoints(const uvo_extractor* h);
 int uvo_extractor_levels(const uvo_extractor* h);
 float uvo_extractor_scale_factor(const uvo_extractor* h);
 /* constructor tables (mvScaleFactor, mvInvScaleFactor, mnFeaturesPerLevel, umax[16]): src/ORBextractor.cc:463-511 */

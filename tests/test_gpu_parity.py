@@ -1,10 +1,13 @@
 """GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
 Bit-exact bar: pyramid / blurred planes, FAST candidates (as sets), keypoints (x, y, size, angle, response, octave,
 class_id as raw bytes) and 256-bit descriptors."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _kp_bytes(kp):
@@ -751,3 +754,26 @@ def test_new_entry_points_reject_bad_arguments(uvo):
     with pytest.raises(uvo.UvoError):                       # more tiles than pixels
         ex.clahe(np.zeros((240, 320), np.uint8), 4.0, (400, 12))
     ex.close()
+
+
+def test_wide_image_with_few_features(uvo, oracle, synth):
+    """A wide image makes DistributeOctTree start from several root nodes; their first, unconditional split can return more
+    keypoints than quota + 3 on a level (4 * nIni nodes).  Found by tools/soak_parity.py."""
+    for (w, h), nfeat, nlev, th in (((572, 164), 58, 6, 12), ((900, 200), 40, 4, 20), ((640, 130), 300, 5, 7)):
+        img = synth.make_frame(1234 + w, w, h, n_shapes=max(20, w * h // 900))
+        ex = uvo.ORBextractor(nfeat, 1.2, nlev, 0, th, max_width=w, max_height=h)
+        oe = oracle.extractor(nfeat, 1.2, nlev, th)
+        kp_g, de_g = ex(img)
+        kp_o, de_o = oe(img)
+        assert len(kp_o) > nfeat                                   # the case in point: more than nfeatures come back
+        _assert_same_features(kp_g, de_g, kp_o, de_o, "%dx%d nfeat %d" % (w, h, nfeat))
+        assert len(kp_g) <= ex.cap
+        ex.close()
+
+
+def test_randomised_extraction_soak(uvo, oracle, synth):
+    """A short run of tools/soak_parity.py (random sizes, level counts, scale factors, thresholds, content)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_parity.py"), "40", "7"], capture_output=True, text=True)
+    assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Developer soak: extraction parity GPU vs oracle over random image sizes, feature counts, thresholds, level counts and content
+(natural-ish synthetic frames, noise, low contrast).  Usage: soak_parity.py [n_trials] [seed]"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    n_trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    torch.zeros(1, device="cuda")
+    uvo = importlib.import_module("u-vip-slam_amd")
+    synth = importlib.import_module("u-vip-slam_amd.synth")
+    import oracle_lib
+    o = oracle_lib.Oracle()
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for t in range(n_trials):
+        w, h = int(rng.integers(120, 900)), int(rng.integers(120, 700))
+        nlev = int(rng.integers(1, 9))
+        scale = float(rng.choice([1.1, 1.2, 1.2, 1.2, 1.25, 1.4]))
+        while nlev > 1 and min(w, h) / scale ** (nlev - 1) < 60:
+            nlev -= 1
+        nfeat = int(rng.integers(50, 2500))
+        th = int(rng.choice([3, 7, 12, 20, 20, 35]))
+        kind = t % 5
+        if kind == 3:
+            img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        elif kind == 4:
+            img = (rng.integers(0, 30, (h, w)) + 100).astype(np.uint8)
+        else:
+            img = synth.make_frame(int(rng.integers(1 << 30)), w, h, n_shapes=max(20, w * h // 900))
+        try:
+            ex = uvo.ORBextractor(nfeat, scale, nlev, 0, th, max_width=w, max_height=h)
+        except uvo.UvoError as e:
+            print("skip (unsupported geometry):", w, h, nlev, scale, str(e)[:60])
+            continue
+        oe = o.extractor(nfeat, scale, nlev, th)
+        kg, dg = ex(img)
+        ko, do = oe(img)
+        ok = len(kg) == len(ko) and kg.tobytes() == ko.tobytes() and np.array_equal(dg, do)
+        if not ok:
+            bad += 1
+            print("MISMATCH trial", t, dict(w=w, h=h, nlev=nlev, scale=scale, nfeat=nfeat, th=th, kind=kind, n_gpu=len(kg), n_oracle=len(ko)))
+        ex.close()
+    print("trials", n_trials, "mismatches", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -25,7 +25,7 @@ UVO_OK, UVO_E_BADARG, UVO_E_NODEVICE, UVO_E_HIP, UVO_E_CAPACITY, UVO_E_UNSUPPORT
 
 # every symbol include/uvo/uvo.h declares
 ABI_SYMBOLS = [
-    "uvo_extractor_create", "uvo_extractor_destroy", "uvo_extractor_levels", "uvo_extractor_scale_factor", "uvo_extractor_tables",
+    "uvo_extractor_create", "uvo_extractor_destroy", "uvo_extractor_levels", "uvo_extractor_max_keypoints", "uvo_extractor_scale_factor", "uvo_extractor_tables",
     "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_level_dims",
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
@@ -120,6 +120,7 @@ def _load():
     lib.uvo_extractor_destroy.argtypes = [vp]
     lib.uvo_extractor_destroy.restype = None
     lib.uvo_extractor_levels.argtypes = [vp]
+    lib.uvo_extractor_max_keypoints.argtypes = [vp]
     lib.uvo_extractor_scale_factor.argtypes = [vp]
     lib.uvo_extractor_scale_factor.restype = cf
     lib.uvo_extractor_tables.argtypes = [vp, vp, vp, vp, vp]
@@ -213,7 +214,9 @@ class ORBextractor:
         lib.uvo_extractor_tables(self._h, _ptr(scale), _ptr(inv), _ptr(quota), _ptr(umax))
         self.mvScaleFactor, self.mvInvScaleFactor, self.mnFeaturesPerLevel, self.umax = scale, inv, quota, umax
         # upper bound of keypoints per frame: sum(quota + 4) + pass-through keypoints
-        self.cap = int(quota.sum()) + 4 * nlevels + max_input_keypoints
+        self.cap = lib.uvo_extractor_max_keypoints(self._h)
+        if self.cap < 0:
+            raise UvoError(self.cap, "uvo_extractor_max_keypoints")
 
     def close(self):
         if getattr(self, "_h", None) and lib is not None:  # `lib` is already gone when the interpreter tears the module down

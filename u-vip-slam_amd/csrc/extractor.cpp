@@ -195,11 +195,13 @@ static int build_geom(const uvo_extractor* h, int width, int height, Geom& g, st
     L.cand_cap = cap;
     L.cand_off = coff;
     coff += (cap + 63) / 64 * 64;
-    L.sel_cap = L.quota + 4;
-    L.sel_off = soff;
-    soff += L.sel_cap;
     L.nIni = (int)roundf((float)L.bw / (float)L.bh);
     if (L.nIni < 1 || L.nIni > 64) return fail(UVO_E_UNSUPPORTED, "image aspect ratio outside the quad-tree's range");
+    // DistributeOctTree returns at most quota + 3 nodes once it is in its careful phase, but the first pass splits all nIni
+    // roots unconditionally: up to 4 * nIni nodes whatever the quota (wide images with few features)
+    L.sel_cap = std::max(L.quota, 4 * L.nIni) + 4;
+    L.sel_off = soff;
+    soff += L.sel_cap;
     L.hX = (float)L.bw / (float)L.nIni;
     L.scale = h->scale[l];
     L.patch_size = (float)(int)(31 * h->scale[l]);
@@ -286,7 +288,8 @@ static int set_geometry(uvo_extractor* h, int width, int height) {
   std::vector<CellDesc> cells;
   int rc = build_geom(h, width, height, g, cells);
   if (rc) return rc;
-  if (g.pyr_block > h->cap_pyr_block || g.cand_block > h->cap_cand_block || g.total_cells > h->cap_cells || g.sel_block > h->cap_sel_block)
+  if (g.pyr_block > h->cap_pyr_block || g.cand_block > h->cap_cand_block || g.total_cells > h->cap_cells || g.sel_block > h->cap_sel_block ||
+      g.flist_cap > h->cap_flist)
     return fail(UVO_E_BADARG, "image larger than the handle was sized for");
   for (int b : {1, std::min(h->cfg.max_batch, 15), h->cfg.max_batch}) {
     const int rps = fast_rows_per_seg(b);
@@ -644,6 +647,11 @@ int uvo_clahe(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdi
   UVO_HIP_CHECK(hipMemcpy2DAsync(dst, dst_stride, h->d_clahe_out, width, width, (size_t)height, hipMemcpyDeviceToHost, s));
   UVO_HIP_CHECK(hipStreamSynchronize(s));
   return UVO_OK;
+}
+
+int uvo_extractor_max_keypoints(const uvo_extractor* h) {
+  if (!h) return fail(UVO_E_BADARG, "null handle");
+  return h->cap_flist;
 }
 
 int uvo_extractor_synchronize(uvo_extractor* h) {
