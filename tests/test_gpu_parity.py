@@ -777,3 +777,11 @@ def test_randomised_extraction_soak(uvo, oracle, synth):
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_parity.py"), "40", "7"], capture_output=True, text=True)
     assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_randomised_matcher_soak(uvo, oracle):
+    """A short run of tools/soak_matcher.py (every search entry point on random sizes, ratios, thresholds, empty sets)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_matcher.py"), "25", "11"], capture_output=True, text=True)
+    assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
