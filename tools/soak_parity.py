@@ -44,12 +44,44 @@ def main():
             print("skip (unsupported geometry):", w, h, nlev, scale, str(e)[:60])
             continue
         oe = o.extractor(nfeat, scale, nlev, th)
-        kg, dg = ex(img)
-        ko, do = oe(img)
-        ok = len(kg) == len(ko) and kg.tobytes() == ko.tobytes() and np.array_equal(dg, do)
+        mode = "full"
+        if t % 3 == 1:
+            # top-up mode (src/ORBextractor.cc:861-913): caller keypoints pass through level 0, the occupancy grid filters the rest
+            mode = "topup"
+            n_in, need, min_px = int(rng.integers(0, 400)), int(rng.integers(1, 1200)), int(rng.choice([10, 20, 35]))
+            kin = np.zeros(n_in, uvo.KEYPOINT_DTYPE)
+            kin["x"] = rng.uniform(20, w - 21, n_in).astype(np.float32)
+            kin["y"] = rng.uniform(20, h - 21, n_in).astype(np.float32)
+            kin["size"], kin["angle"], kin["response"], kin["class_id"] = 31, -1, rng.uniform(0, 99, n_in), np.arange(n_in)
+            grid = np.zeros((h // min_px + 2, w // min_px + 2), np.int32, order="F")
+            for k in kin:
+                grid[int(k["y"] / min_px), int(k["x"] / min_px)] += 1
+            gg, go = grid.copy(order="F"), grid.copy(order="F")
+            ex.close()
+            ex = uvo.ORBextractor(nfeat, scale, nlev, 0, th, max_width=w, max_height=h, max_input_keypoints=max(n_in, 1))
+            kg, dg = ex(img, kin.copy(), gg, min_px, False, need)
+            ko, do = oe(img, kin.copy(), go, min_px, False, need)
+            ok = len(kg) == len(ko) and kg.tobytes() == ko.tobytes() and np.array_equal(dg, do) and np.array_equal(gg, go)
+        elif t % 4 == 2:
+            # a batch through the multi-frame entry point (frames of different content)
+            mode = "batch"
+            B = int(rng.choice([2, 5, 17]))
+            ex.close()
+            ex = uvo.ORBextractor(nfeat, scale, nlev, 0, th, max_width=w, max_height=h, max_batch=B)
+            frames = np.stack([img] + [synth.make_frame(int(rng.integers(1 << 30)), w, h, n_shapes=max(20, w * h // 1500)) for _ in range(B - 1)])
+            res = ex.extract_batch(frames)
+            ok = True
+            for b in range(B):
+                kob, dob = oe(frames[b])
+                ok = ok and len(res[b][0]) == len(kob) and res[b][0].tobytes() == kob.tobytes() and np.array_equal(res[b][1], dob)
+            kg, ko = res[0][0], oe(frames[0])[0]
+        else:
+            kg, dg = ex(img)
+            ko, do = oe(img)
+            ok = len(kg) == len(ko) and kg.tobytes() == ko.tobytes() and np.array_equal(dg, do)
         if not ok:
             bad += 1
-            print("MISMATCH trial", t, dict(w=w, h=h, nlev=nlev, scale=scale, nfeat=nfeat, th=th, kind=kind, n_gpu=len(kg), n_oracle=len(ko)))
+            print("MISMATCH trial", t, mode, dict(w=w, h=h, nlev=nlev, scale=scale, nfeat=nfeat, th=th, kind=kind, n_gpu=len(kg), n_oracle=len(ko)))
         ex.close()
     print("trials", n_trials, "mismatches", bad)
     return 1 if bad else 0
