@@ -54,43 +54,139 @@ __global__ __launch_bounds__(256) void k_assemble(const LevelGeom* __restrict__ 
     s.aux = i;
     if (i < flist_cap) out[i] = s;
   }
-  if (threadIdx.x != 0) return;
-  int32_t* G = grid + (int64_t)f * grid_rows * grid_cols;
-  const int need = nfn[f];
-  int pos = nin;
-  int Total_counter = 0, KP_counter = 0;
-  bool break_key = false;
-  for (int l = 0; l < nlevels && !break_key; ++l) {
-    int n = cnt[l];
-    n = n > lv[l].sel_cap ? lv[l].sel_cap : n;
-    if (n == 0) continue;
-    const int numofpoint = need * (8 - l) / 30;
-    const float scale = lv[l].scale;
-    for (int i = 0; i < n; ++i) {
-      const uint32_t xy = sxy[lv[l].sel_off + i];
-      const float px = (float)((int)(xy & 0xffff) + kMinBorder), py = (float)((int)(xy >> 16) + kMinBorder);
-      const float tx = px * scale, ty = py * scale;
-      const int r = (int)(ty / (float)min_px_dist), c = (int)(tx / (float)min_px_dist);
-      int32_t* cell = &G[(int64_t)c * grid_rows + r];  // Eigen column-major
-      if (*cell > 0) continue;
-      FinalSlot s;
-      s.x = px, s.y = py, s.level = l, s.aux = (int32_t)ssc[lv[l].sel_off + i];
-      if (pos < flist_cap) out[pos] = s;
-      ++pos;
-      *cell += 1;
-      ++KP_counter;
-      ++Total_counter;
-      if (KP_counter == numofpoint) {
-        KP_counter = 0;
-        break;
-      }
-      if (Total_counter == need) {
-        break_key = true;
-        break;
+  // The walk is sequential (a point's fate depends on the cells taken by the points before it), so its memory has to be close:
+  // the survivor lists and the occupancy grid are staged in LDS by the whole workgroup, one thread walks them there, and the
+  // grid goes back in parallel.  Frames whose lists or grid exceed the staging arrays walk in HBM.
+  constexpr int AS_PTS = 2560, AS_GRID = 6144;
+  __shared__ uint32_t s_xy[AS_PTS];
+  __shared__ int s_lbase[kMaxLevels + 1];
+  int32_t* Gm = grid + (int64_t)f * grid_rows * grid_cols;
+  const int gsize = grid_rows * grid_cols;
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int l = 0; l < nlevels; ++l) {
+      s_lbase[l] = run;
+      int n = cnt[l];
+      run += n > lv[l].sel_cap ? lv[l].sel_cap : n;
+    }
+    s_lbase[nlevels] = run;
+  }
+  __syncthreads();
+  const bool staged = s_lbase[nlevels] <= AS_PTS && gsize <= AS_GRID;
+  if (staged) {
+    for (int l = 0; l < nlevels; ++l) {
+      const int n = s_lbase[l + 1] - s_lbase[l];
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        s_xy[s_lbase[l] + i] = sxy[lv[l].sel_off + i];
       }
     }
   }
-  n_final[f] = pos;
+  const int need = nfn[f];
+  if (staged) {
+    // Level by level (the levels are truly sequential), inside a level in parallel: a point is accepted iff its cell is free
+    // and it is the first point of the level in that cell -- and it lies before the point at which the reference's loop leaves
+    // the level, which has a closed form: the k-th accepted point has KP_counter = carry + k and Total_counter = total + k, the
+    // loop breaks at the first k with carry + k == numofpoint (level cap, counter reset; checked first) or total + k == need
+    // (global cap, break_key).
+    // s_first[cell]: -1 = occupied, else the lowest index of a point of the current level that falls into the (free) cell
+    __shared__ int s_first[AS_GRID];
+    __shared__ int s_cell[AS_PTS];
+    __shared__ int s_wcnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_in_block();
+    for (int i = tid; i < gsize; i += blockDim.x) s_first[i] = Gm[i] > 0 ? -1 : 0x7fffffff;
+    __syncthreads();
+    int pos = nin, Total_counter = 0, KP_counter = 0;
+    bool break_key = false;
+    for (int l = 0; l < nlevels && !break_key; ++l) {
+      const int n = s_lbase[l + 1] - s_lbase[l], lb = s_lbase[l];
+      if (n == 0) continue;
+      const int numofpoint = need * (8 - l) / 30;
+      const float scale = lv[l].scale;
+      for (int i = tid; i < n; i += blockDim.x) {
+        const uint32_t xy = s_xy[lb + i];
+        const float px = (float)((int)(xy & 0xffff) + kMinBorder), py = (float)((int)(xy >> 16) + kMinBorder);
+        const float tx = px * scale, ty = py * scale;
+        const int r = (int)(ty / (float)min_px_dist), c = (int)(tx / (float)min_px_dist);
+        const int cell = c * grid_rows + r;  // Eigen column-major
+        s_cell[i] = cell;
+        atomicMin(&s_first[cell], i);  // stays -1 for an occupied cell
+      }
+      __syncthreads();
+      const int kcap1 = numofpoint - KP_counter >= 1 ? numofpoint - KP_counter : 0x7fffffff;
+      const int kcap2 = need - Total_counter >= 1 ? need - Total_counter : 0x7fffffff;
+      const int kcap = kcap1 < kcap2 ? kcap1 : kcap2;
+      int nfirst = 0;  // would-be accepted points seen so far (uniform)
+      for (int i0 = 0; i0 < n && nfirst < kcap; i0 += blockDim.x) {
+        const int i = i0 + tid;
+        const bool first = i < n && s_first[s_cell[i]] == i;
+        const uint64_t m = __ballot(first);
+        if (lane == 0) s_wcnt[wv] = (int)__popcll(m);
+        __syncthreads();
+        int rank = nfirst + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        for (int q = 0; q < wv; ++q) rank += s_wcnt[q];
+        const int round_total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        if (first && rank < kcap) {
+          const uint32_t xy = s_xy[lb + i];
+          FinalSlot fs;
+          fs.x = (float)((int)(xy & 0xffff) + kMinBorder), fs.y = (float)((int)(xy >> 16) + kMinBorder), fs.level = l;
+          fs.aux = (int32_t)ssc[lv[l].sel_off + i];
+          if (pos + rank < flist_cap) out[pos + rank] = fs;
+          Gm[s_cell[i]] += 1;       // grid_2d(r, c)++ : one writer per cell (the accepted points of a level lie in distinct cells)
+          s_first[s_cell[i]] = -1;  // occupied from now on (no other point compares equal to -1)
+        }
+        nfirst += round_total;
+        __syncthreads();
+      }
+      const int take = nfirst < kcap ? nfirst : kcap;
+      pos += take;
+      Total_counter += take;
+      if (take == kcap1) {
+        KP_counter = 0;  // level cap reached: `break` out of the level, the global cap is not looked at for this point
+      } else if (take == kcap2) {
+        break_key = true;
+      } else {
+        KP_counter += take;
+      }
+      for (int i = tid; i < n; i += blockDim.x)
+        if (s_first[s_cell[i]] != -1) s_first[s_cell[i]] = 0x7fffffff;  // cells that stayed free (or lost their point to the cap)
+      __syncthreads();
+    }
+    if (tid == 0) n_final[f] = pos;
+  } else if (threadIdx.x == 0) {
+    int pos = nin;
+    int Total_counter = 0, KP_counter = 0;
+    bool break_key = false;
+    for (int l = 0; l < nlevels && !break_key; ++l) {
+      const int n = s_lbase[l + 1] - s_lbase[l];
+      if (n == 0) continue;
+      const int numofpoint = need * (8 - l) / 30;
+      const float scale = lv[l].scale;
+      for (int i = 0; i < n; ++i) {
+        const uint32_t xy = sxy[lv[l].sel_off + i];
+        const float px = (float)((int)(xy & 0xffff) + kMinBorder), py = (float)((int)(xy >> 16) + kMinBorder);
+        const float tx = px * scale, ty = py * scale;
+        const int r = (int)(ty / (float)min_px_dist), c = (int)(tx / (float)min_px_dist);
+        int32_t* cell = &Gm[(int64_t)c * grid_rows + r];  // Eigen column-major
+        if (*cell > 0) continue;
+        FinalSlot fs;
+        fs.x = px, fs.y = py, fs.level = l, fs.aux = (int32_t)ssc[lv[l].sel_off + i];
+        if (pos < flist_cap) out[pos] = fs;
+        ++pos;
+        *cell += 1;
+        ++KP_counter;
+        ++Total_counter;
+        if (KP_counter == numofpoint) {
+          KP_counter = 0;
+          break;
+        }
+        if (Total_counter == need) {
+          break_key = true;
+          break;
+        }
+      }
+    }
+    n_final[f] = pos;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
