@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -91,6 +92,10 @@ struct uvo_extractor {
   uint8_t* d_out_desc = nullptr;
   int32_t *d_n_out = nullptr, *d_n_in = nullptr, *d_nfn = nullptr, *d_grid = nullptr;
   size_t grid_bytes = 0;
+  // pinned host staging of the host-buffer entry points' small inputs / outputs (copies to and from pageable caller
+  // memory stall the stream once per call; a pinned bounce keeps them asynchronous behind one wait)
+  uint8_t* h_pin = nullptr;
+  size_t pin_bytes = 0;
 };
 
 namespace uvo {
@@ -336,10 +341,10 @@ static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, 
   UVO_HIP_CHECK(hipSetDevice(h->device));
   int rc = set_geometry(h, width, height);
   if (rc) return rc;
-  const Geom& g = h->geom;
   if (h->nlanes > 1) h->cur = (h->cur + 1) % h->nlanes;  // pipeline depth 2: alternate lanes
   hipStream_t s = h->lane[h->cur].stream;
   h->last_batch = batch;
+  const Geom& g = h->geom;
   UVO_HIP_CHECK(hipMemsetAsync(h->lane[h->cur].d_cand_count, 0, sizeof(int32_t) * batch * g.nlevels, s));
   {
     ProfScope p(h, "k_pad_level0");
@@ -550,6 +555,7 @@ void uvo_extractor_destroy(uvo_extractor* h) {
                   h->d_out_desc, h->d_n_out, h->d_in_kp, h->d_n_in, h->d_nfn, h->d_grid};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (h->h_pin) (void)hipHostFree(h->h_pin);
   delete h;
 }
 
@@ -698,15 +704,20 @@ int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int widt
     }
   }
   // stage inputs (tight rows on the device)
-  UVO_HIP_CHECK(hipMemcpy2DAsync(h->d_imgs, width, imgs, stride, width, (size_t)height, hipMemcpyHostToDevice, s));
-  for (int b = 1; b < batch; ++b)
-    UVO_HIP_CHECK(hipMemcpy2DAsync(h->d_imgs + (size_t)b * width * height, width, imgs + (size_t)b * frame_stride, stride, width, (size_t)height,
-                                   hipMemcpyHostToDevice, s));
+  if (stride == width && (batch == 1 || frame_stride == (ptrdiff_t)width * height)) {
+    UVO_HIP_CHECK(hipMemcpyAsync(h->d_imgs, imgs, (size_t)batch * width * height, hipMemcpyHostToDevice, s));
+  } else {
+    for (int b = 0; b < batch; ++b)
+      UVO_HIP_CHECK(hipMemcpy2DAsync(h->d_imgs + (size_t)b * width * height, width, imgs + (size_t)b * frame_stride, stride, width, (size_t)height,
+                                     hipMemcpyHostToDevice, s));
+  }
   const bool topup = !full_detect;
   const bool have_in = topup && in_kp && n_in && in_cap > 0;
+  const int dcap = h->cap_flist;  // device staging capacity per frame
+  size_t gb = 0;
   if (topup) {
     if (!grid2d || !num_feats_needed) return fail(UVO_E_BADARG, "top-up mode needs grid2d and num_feats_needed");
-    const size_t gb = (size_t)batch * grid_rows * grid_cols * sizeof(int32_t);
+    gb = (size_t)batch * grid_rows * grid_cols * sizeof(int32_t);
     if (gb > h->grid_bytes) {
       UVO_HIP_CHECK(hipStreamSynchronize(s));
       if (h->d_grid) hipFree(h->d_grid);
@@ -715,34 +726,104 @@ int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int widt
       if (rc) return rc;
       h->grid_bytes = gb;
     }
-    UVO_HIP_CHECK(hipMemcpyAsync(h->d_grid, grid2d, gb, hipMemcpyHostToDevice, s));
-    UVO_HIP_CHECK(hipMemcpyAsync(h->d_nfn, num_feats_needed, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
-    if (have_in) {
-      UVO_HIP_CHECK(hipMemcpyAsync(h->d_in_kp, in_kp, sizeof(uvo_keypoint) * (size_t)batch * in_cap, hipMemcpyHostToDevice, s));
-      UVO_HIP_CHECK(hipMemcpyAsync(h->d_n_in, n_in, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+  }
+  // pinned bounce buffer: [n_out | nfn | n_in : 3*batch ints][grid][keypoints in, later keypoints + descriptors out]
+  const size_t kSmallBatch = 16;  // above this the caller-side copies are a small part of the call
+  const bool bounce = (size_t)batch <= kSmallBatch;
+  size_t off_grid = 0, off_kp = 0;
+  if (bounce) {
+    size_t in_total = 0;
+    if (have_in)
+      for (int b = 0; b < batch; ++b) in_total += (size_t)n_in[b];
+    off_grid = (((size_t)3 * batch * sizeof(int32_t)) + 63) & ~(size_t)63;
+    off_kp = (off_grid + gb + 63) & ~(size_t)63;
+    const size_t want = off_kp + std::max(in_total * sizeof(uvo_keypoint), (size_t)batch * dcap * (sizeof(uvo_keypoint) + 32));
+    if (want > h->pin_bytes) {
+      UVO_HIP_CHECK(hipStreamSynchronize(s));
+      if (h->h_pin) (void)hipHostFree(h->h_pin);
+      h->h_pin = nullptr, h->pin_bytes = 0;
+      void* p = nullptr;
+      if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return fail(UVO_E_NOMEM, "pinned staging allocation failed");
+      h->h_pin = (uint8_t*)p, h->pin_bytes = want;
     }
   }
-  const int dcap = h->cap_flist;  // device staging capacity per frame
+  int32_t* pin_i = (int32_t*)h->h_pin;
+  if (topup) {
+    if (bounce) {
+      std::memcpy(pin_i + batch, num_feats_needed, sizeof(int32_t) * batch);
+      std::memcpy(h->h_pin + off_grid, grid2d, gb);
+      UVO_HIP_CHECK(hipMemcpyAsync(h->d_nfn, pin_i + batch, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+      UVO_HIP_CHECK(hipMemcpyAsync(h->d_grid, h->h_pin + off_grid, gb, hipMemcpyHostToDevice, s));
+    } else {
+      UVO_HIP_CHECK(hipMemcpyAsync(h->d_grid, grid2d, gb, hipMemcpyHostToDevice, s));
+      UVO_HIP_CHECK(hipMemcpyAsync(h->d_nfn, num_feats_needed, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+    }
+    if (have_in) {
+      // only the first n_in[b] entries of a frame's slice are ever read on the device
+      if (bounce) {
+        std::memcpy(pin_i + 2 * batch, n_in, sizeof(int32_t) * batch);
+        UVO_HIP_CHECK(hipMemcpyAsync(h->d_n_in, pin_i + 2 * batch, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+        uvo_keypoint* pk = (uvo_keypoint*)(h->h_pin + off_kp);
+        for (int b = 0; b < batch; ++b) {
+          if (n_in[b] <= 0) continue;
+          std::memcpy(pk, in_kp + (size_t)b * in_cap, sizeof(uvo_keypoint) * n_in[b]);
+          UVO_HIP_CHECK(hipMemcpyAsync(h->d_in_kp + (size_t)b * in_cap, pk, sizeof(uvo_keypoint) * n_in[b], hipMemcpyHostToDevice, s));
+          pk += n_in[b];
+        }
+      } else {
+        UVO_HIP_CHECK(hipMemcpyAsync(h->d_n_in, n_in, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+        for (int b = 0; b < batch; ++b)
+          if (n_in[b] > 0)
+            UVO_HIP_CHECK(hipMemcpyAsync(h->d_in_kp + (size_t)b * in_cap, in_kp + (size_t)b * in_cap, sizeof(uvo_keypoint) * n_in[b],
+                                         hipMemcpyHostToDevice, s));
+      }
+    }
+  }
   int rc = run_batch_device(h, batch, h->d_imgs, width, height, width, (ptrdiff_t)width * height, have_in ? h->d_in_kp : nullptr,
                             have_in ? h->d_n_in : nullptr, topup ? h->d_grid : nullptr, grid_rows, grid_cols, min_px_dist, full_detect,
                             topup ? h->d_nfn : nullptr, h->d_out_kp, h->d_out_desc, dcap, h->d_n_out);
   if (rc) return rc;
-  UVO_HIP_CHECK(hipMemcpyAsync(n_out, h->d_n_out, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
-  UVO_HIP_CHECK(hipStreamSynchronize(s));
+  if (bounce) {
+    // the stream is in order: the keypoint uploads above were consumed before the outputs land in the same pinned region
+    UVO_HIP_CHECK(hipMemcpyAsync(pin_i, h->d_n_out, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+    if (topup) UVO_HIP_CHECK(hipMemcpyAsync(h->h_pin + off_grid, h->d_grid, gb, hipMemcpyDeviceToHost, s));
+    UVO_HIP_CHECK(hipStreamSynchronize(s));
+    std::memcpy(n_out, pin_i, sizeof(int32_t) * batch);
+    if (topup) std::memcpy(grid2d, h->h_pin + off_grid, gb);
+  } else {
+    UVO_HIP_CHECK(hipMemcpyAsync(n_out, h->d_n_out, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+    UVO_HIP_CHECK(hipStreamSynchronize(s));
+  }
   int status = UVO_OK;
+  uint8_t* pout = h->h_pin + off_kp;
   for (int b = 0; b < batch; ++b) {
     int n = n_out[b];
     if (n > cap) {
       status = fail(UVO_E_CAPACITY, "output capacity too small; n_out holds the required size");
       n = cap;
     }
-    if (n > 0) {
+    if (n <= 0) continue;
+    if (bounce) {
+      UVO_HIP_CHECK(hipMemcpyAsync(pout, h->d_out_kp + (size_t)b * dcap, sizeof(uvo_keypoint) * n, hipMemcpyDeviceToHost, s));
+      UVO_HIP_CHECK(hipMemcpyAsync(pout + sizeof(uvo_keypoint) * n, h->d_out_desc + (size_t)b * dcap * 32, (size_t)32 * n, hipMemcpyDeviceToHost, s));
+      pout += (sizeof(uvo_keypoint) + 32) * (size_t)n;
+    } else {
       UVO_HIP_CHECK(hipMemcpyAsync(out_kp + (size_t)b * cap, h->d_out_kp + (size_t)b * dcap, sizeof(uvo_keypoint) * n, hipMemcpyDeviceToHost, s));
       UVO_HIP_CHECK(hipMemcpyAsync(out_desc + (size_t)b * cap * 32, h->d_out_desc + (size_t)b * dcap * 32, (size_t)32 * n, hipMemcpyDeviceToHost, s));
     }
   }
-  if (topup) UVO_HIP_CHECK(hipMemcpyAsync(grid2d, h->d_grid, (size_t)batch * grid_rows * grid_cols * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (!bounce && topup) UVO_HIP_CHECK(hipMemcpyAsync(grid2d, h->d_grid, gb, hipMemcpyDeviceToHost, s));
   UVO_HIP_CHECK(hipStreamSynchronize(s));
+  if (bounce) {
+    pout = h->h_pin + off_kp;
+    for (int b = 0; b < batch; ++b) {
+      const int n = std::min(n_out[b], cap);
+      if (n <= 0) continue;
+      std::memcpy(out_kp + (size_t)b * cap, pout, sizeof(uvo_keypoint) * n);
+      std::memcpy(out_desc + (size_t)b * cap * 32, pout + sizeof(uvo_keypoint) * n, (size_t)32 * n);
+      pout += (sizeof(uvo_keypoint) + 32) * (size_t)n;
+    }
+  }
   return status;
 }
 
@@ -752,13 +833,7 @@ int uvo_extract(uvo_extractor* h, const uint8_t* img, int width, int height, ptr
   if (!h || !n_out) return fail(UVO_E_BADARG, "null pointer");
   if (n_in < 0 || n_in > h->cfg.max_input_keypoints) return fail(UVO_E_BADARG, "n_in outside 0..max_input_keypoints");
   int32_t nin = n_in, nfn = num_feats_needed, nout = 0;
-  std::vector<uvo_keypoint> padded;
   const uvo_keypoint* ik = in_kp;
-  if (!full_detect && n_in > 0 && in_kp) {
-    padded.assign(std::max(h->cfg.max_input_keypoints, 1), uvo_keypoint{});
-    std::copy(in_kp, in_kp + n_in, padded.begin());
-    ik = padded.data();
-  }
   int rc = uvo_extract_batch(h, 1, img, width, height, stride, (ptrdiff_t)stride * height, ik, &nin, grid2d, grid_rows, grid_cols, min_px_dist,
                              full_detect, &nfn, out_kp, out_desc, cap, &nout);
   *n_out = nout;

@@ -1,6 +1,10 @@
-// Kernel wrapper of the quad-tree selection (octree_core.hpp): one 256-thread workgroup per (frame, level),
-// node state carved out of dynamic LDS, candidate state words in HBM scratch.
+// Kernel wrapper of the quad-tree selection (octree_core.hpp): one workgroup per (frame, level), node state carved out of
+// dynamic LDS, candidate state in registers (HBM scratch words for very long lists).  Two instantiations: 256 threads, four
+// workgroups per CU (throughput: large batches fill the chip with problems), and 1024 threads, one per CU (latency: a
+// small batch leaves CUs idle, so each problem takes four times the lanes and keeps lists of up to 32 K candidates in
+// registers).
 #include <cstdio>
+#include <cstdlib>
 #include "common.hpp"
 #include "fast_geom.hpp"
 #include "octree_core.hpp"
@@ -11,6 +15,15 @@ static inline int oct_capacity(int N, int nIni) {
   int m = N > 4 * nIni ? N : 4 * nIni;
   return m + 8;
 }
+// at most this many (frame, level) problems run as 1024-thread workgroups (one per CU: beyond 256 problems the chip is full
+// either way, and four independent 256-thread problems per CU use it better).  Measured, 640x512 / 8 levels, kernel span:
+// 60 vs 81 us at batch 1, 75 vs 125 us at batch 32; at batch 128 wide still has the shorter span (240 vs 290 us) but the
+// pipelined throughput of configs[3] drops 5 %, and at batch 256 it is 10 % down.  UVO_OCT_WIDE_MAX overrides for experiments.
+static int oct_wide_max_problems() {
+  const char* e = getenv("UVO_OCT_WIDE_MAX");
+  return e ? atoi(e) : 256;
+}
+static const int kOctWideMaxProblems = oct_wide_max_problems();
 static inline int pow2_ge(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -27,7 +40,8 @@ static inline size_t oct_lds_bytes(int M, int Mp2) {
   return b;
 }
 
-__global__ __launch_bounds__(OCT_THREADS, 4) void k_octree(const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max,
+template <int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max,
                                                         FastLevels FL, int fast_th, const uint32_t* __restrict__ cor,
                                                         const int32_t* __restrict__ cor_n, const uint8_t* __restrict__ cell_hi,
                                                         uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc,
@@ -64,7 +78,7 @@ __global__ __launch_bounds__(OCT_THREADS, 4) void k_octree(const LevelGeom* __re
     // for all four before the first result is needed; one LDS atomic per wavefront and batch reserves the output slots
     const int64_t region0 = (int64_t)f * FL.items_per_frame + first;
     const int wv = wave_in_block(), lane = threadIdx.x & 63;
-    constexpr int GU = 4, NW = OCT_THREADS / 64;
+    constexpr int GU = 4, NW = NT / 64;
     for (int r0 = wv; r0 < n_items; r0 += NW * GU) {
       int n[GU], nmax = 0;
 #pragma unroll
@@ -147,9 +161,9 @@ __global__ __launch_bounds__(OCT_THREADS, 4) void k_octree(const LevelGeom* __re
   const int64_t so = (int64_t)f * sel_block + g.sel_off;
   // candidate state in registers when the list fits 8 / 32 candidates per thread, else in the HBM scratch words
   int n;
-  if (P <= 8 * OCT_THREADS)
+  if (P <= 8 * NT)
     n = oct::run<8>(pr, w, cand_xy + co, cand_sc + co, pstate + co, sel_xy + so, sel_sc + so, g.sel_cap);
-  else if (P <= 32 * OCT_THREADS)
+  else if (P <= 32 * NT)
     n = oct::run<32>(pr, w, cand_xy + co, cand_sc + co, pstate + co, sel_xy + so, sel_sc + so, g.sel_cap);
   else
     n = oct::run<0>(pr, w, cand_xy + co, cand_sc + co, pstate + co, sel_xy + so, sel_sc + so, g.sel_cap);
@@ -167,11 +181,13 @@ void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, int fast
   const int Mp2 = pow2_ge(M);
   // The kernel is latency bound (a few dozen dependent phases per problem): the per-candidate state lives in registers,
   // the node tables in LDS, and the grid is level-major so that the long level-0 problems are dispatched first.
-  const int threads = OCT_THREADS;
+  const bool wide = batch * g.nlevels <= kOctWideMaxProblems;
+  const int threads = wide ? 1024 : OCT_THREADS;
   const size_t lds = oct_lds_bytes(M, Mp2);
   static size_t configured = 0;
   if (lds > 64 * 1024 && lds > configured) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<OCT_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = lds;
   }
 #ifdef UVO_OCT_TRACE
@@ -180,16 +196,20 @@ void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, int fast
     if (!once) {
       once = true;
       int nb = -1;
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_octree), threads, lds);
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_octree<OCT_THREADS>), OCT_THREADS, lds);
       hipFuncAttributes fa;
-      hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_octree));
+      hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_octree<OCT_THREADS>));
       fprintf(stderr, "[oct] M=%d Mp2=%d lds=%zu occupancy blocks/CU=%d regs=%d static_lds=%zu\n", M, Mp2, lds, nb, fa.numRegs, fa.sharedSizeBytes);
     }
   }
 #endif
-  hipLaunchKernelGGL(k_octree, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, fast_levels(g, batch), fast_th, d_cor, d_cor_n,
-                     d_cell_hi, d_cand_xy, d_cand_sc, cand_block,
-                     d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count);
+  if (wide)
+    hipLaunchKernelGGL(k_octree<1024>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, fast_levels(g, batch), fast_th, d_cor,
+                       d_cor_n, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count);
+  else
+    hipLaunchKernelGGL(k_octree<OCT_THREADS>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, fast_levels(g, batch), fast_th,
+                       d_cor, d_cor_n, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block,
+                       d_sel_count);
 }
 
 }  // namespace uvo
