@@ -15,8 +15,9 @@
  *   SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12)                       :715-850
  *   SearchForTriangulation(pKF1, pKF2, F12, keys1, keys2, pairs)         :852-1014
  *   Fuse(KeyFrame*, vpMapPoints, th)                                     :1016-1134 (search on the GPU, map mutation here)
- * Members that stay on the reference's own code: SearchByProjection(KeyFrame*, Scw, ...), Fuse(KeyFrame*, Scw, ...),
- * SearchBySim3 -- their search cores are uvo_match_windows() calls (INTEGRATION.md shows the mapping).
+ *   SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th)          :286-407   (loop closing)
+ *   Fuse(KeyFrame*, Scw, vpPoints, th)                                   :1136-1265 (loop closing; map mutation here)
+ *   SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)             :1267-1505
  */
 #ifndef UVO_COMPAT_ORBMATCHER_H_
 #define UVO_COMPAT_ORBMATCHER_H_
@@ -330,6 +331,145 @@ class UVO_COMPAT_MATCHER_NAME {
     return nFused;
   }
 
+  /* int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th) */
+  template <class KeyFrameT, class MatT, class MapPointT>
+  int SearchByProjection(KeyFrameT* pKF, const MatT& Scw, const std::vector<MapPointT*>& vpPoints, std::vector<MapPointT*>& vpMatched, int th) {
+    const int nmp = (int)vpPoints.size(), n = (int)pKF->N;
+    if (nmp == 0 || n == 0 || ensure(n, nmp) != UVO_OK) return 0;
+    std::set<MapPointT*> spAlreadyFound(vpMatched.begin(), vpMatched.end());  // :306-307
+    spAlreadyFound.erase(static_cast<MapPointT*>(nullptr));
+    Sim3Candidates<MapPointT> c;
+    if (!project_with_scw(pKF, Scw, vpPoints, spAlreadyFound, c)) return 0;
+    std::vector<uvo_keypoint> kps;
+    std::vector<uint8_t> kdesc;
+    marshal_keyframe(pKF, kps, kdesc);
+    std::vector<int32_t> matched(n);
+    for (int k = 0; k < n; ++k) matched[k] = vpMatched[k] ? 0x7fffffff : -1;  // :372
+    int nmatches = 0;
+    if (uvo_search_by_projection_sim3(m_, kps.data(), n, kdesc.data(), (int)pKF->mnMinX, (int)pKF->mnMinY, (int)pKF->mnMaxX, (int)pKF->mnMaxY,
+                                      matched.data(), nmp, c.u.data(), c.v.data(), c.level.data(), c.valid.data(), c.mdesc.data(),
+                                      c.scale.data(), (int)c.scale.size(), th, &nmatches) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    for (int k = 0; k < n; ++k)
+      if (matched[k] >= 0 && matched[k] != 0x7fffffff) vpMatched[k] = vpPoints[matched[k]];  // :394
+    return nmatches;
+  }
+
+  /* int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoints, float th) */
+  template <class KeyFrameT, class MatT, class MapPointT>
+  int Fuse(KeyFrameT* pKF, const MatT& Scw, const std::vector<MapPointT*>& vpPoints, float th) {
+    const int nmp = (int)vpPoints.size(), n = (int)pKF->N;
+    if (nmp == 0 || n == 0 || ensure(n, nmp) != UVO_OK) return 0;
+    const std::set<MapPointT*> spAlreadyFound = pKF->GetMapPoints();  // :1152
+    Sim3Candidates<MapPointT> c;
+    if (!project_with_scw(pKF, Scw, vpPoints, spAlreadyFound, c)) return 0;
+    std::vector<uvo_keypoint> kps;
+    std::vector<uint8_t> kdesc;
+    marshal_keyframe(pKF, kps, kdesc);
+    std::vector<int32_t> best(nmp), bdist(nmp);
+    if (uvo_fuse(m_, kps.data(), n, kdesc.data(), (int)pKF->mnMinX, (int)pKF->mnMinY, (int)pKF->mnMaxX, (int)pKF->mnMaxY, nmp, c.u.data(), c.v.data(),
+                 c.level.data(), c.valid.data(), c.mdesc.data(), c.scale.data(), (int)c.scale.size(), th, best.data(), bdist.data()) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    int nFused = 0;
+    for (int i = 0; i < nmp; ++i) {  // :1241-1258
+      if (best[i] < 0) continue;
+      MapPointT* pMP = vpPoints[i];
+      MapPointT* pMPinKF = pKF->GetMapPoint(best[i]);
+      if (pMPinKF) {
+        if (!pMPinKF->isBad()) pMPinKF->Replace(pMP);
+      } else {
+        pMP->AddObservation(pKF, best[i]);
+        pKF->AddMapPoint(pMP, best[i]);
+      }
+      nFused++;
+    }
+    return nFused;
+  }
+
+  /* int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12,
+   *                              const cv::Mat &t12, float th) */
+  template <class KeyFrameT, class MapPointT, class MatT>
+  int SearchBySim3(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12, const float& s12, const MatT& R12, const MatT& t12,
+                   float th) {
+    const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+    const int N1 = (int)vpMapPoints1.size(), N2 = (int)vpMapPoints2.size();
+    if (N1 == 0 || N2 == 0 || ensure(N1 > N2 ? N1 : N2, N1 > N2 ? N1 : N2) != UVO_OK) return 0;
+    float r12[9], t12v[3], sR12[9], sR21[9], t21[3], R1w[9], t1w[3], R2w[9], t2w[3];
+    auto R1 = pKF1->GetRotation(), R2 = pKF2->GetRotation();
+    auto T1 = pKF1->GetTranslation(), T2 = pKF2->GetTranslation();
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c)
+        r12[3 * r + c] = R12.template at<float>(r, c), R1w[3 * r + c] = R1.template at<float>(r, c), R2w[3 * r + c] = R2.template at<float>(r, c);
+      t12v[r] = t12.template at<float>(r), t1w[r] = T1.template at<float>(r), t2w[r] = T2.template at<float>(r);
+    }
+    if (uvo_sim3_relative(s12, r12, t12v, sR12, sR21, t21) != UVO_OK) {  // :1284-1287
+      err_ = uvo_last_error();
+      return 0;
+    }
+    std::vector<uint8_t> already1(N1, 0), already2(N2, 0);  // :1302-1314
+    for (int i = 0; i < N1; ++i) {
+      MapPointT* pMP = vpMatches12[i];
+      if (!pMP) continue;
+      already1[i] = 1;
+      const int idx2 = pMP->GetIndexInKeyFrame(pKF2);
+      if (idx2 >= 0 && idx2 < N2) already2[idx2] = 1;
+    }
+    struct Side {
+      std::vector<float> xyz, mind, maxd, u, v;
+      std::vector<uint8_t> usable, valid, mdesc;
+      std::vector<int32_t> level;
+    } a, b;
+    auto gather = [](const std::vector<MapPointT*>& pts, const std::vector<uint8_t>& already, Side& s) {
+      const int n = (int)pts.size();
+      s.xyz.assign((size_t)n * 3, 0.f), s.mind.assign(n, 1.f), s.maxd.assign(n, 1.f), s.u.resize(n), s.v.resize(n);
+      s.usable.assign(n, 0), s.valid.resize(n), s.mdesc.assign((size_t)n * 32, 0), s.level.resize(n);
+      for (int i = 0; i < n; ++i) {
+        MapPointT* pMP = pts[i];
+        if (!pMP || already[i] || pMP->isBad()) continue;  // :1324-1328
+        s.usable[i] = 1;
+        auto p = pMP->GetWorldPos();
+        for (int k = 0; k < 3; ++k) s.xyz[(size_t)i * 3 + k] = p.template at<float>(k);
+        s.mind[i] = pMP->GetMinDistanceInvariance(), s.maxd[i] = pMP->GetMaxDistanceInvariance();
+        auto d = pMP->GetDescriptor();
+        std::memcpy(&s.mdesc[(size_t)i * 32], d.ptr(0), 32);
+      }
+    };
+    gather(vpMapPoints1, already1, a);
+    gather(vpMapPoints2, already2, b);
+    const std::vector<float> sf1 = pKF1->GetScaleFactors(), sf2 = pKF2->GetScaleFactors();
+    uvo_camera_pose cam1 = intrinsics_of(pKF1), cam2 = intrinsics_of(pKF2);
+    // the reference projects with pKF1's fx, fy, cx, cy in both directions (:1270-1273) and tests the bounds of the target key frame
+    cam2.fx = cam1.fx, cam2.fy = cam1.fy, cam2.cx = cam1.cx, cam2.cy = cam1.cy;
+    if (uvo_project_sim3(m_, R1w, t1w, sR21, t21, &cam2, N1, a.xyz.data(), a.mind.data(), a.maxd.data(), a.usable.data(), sf2.data(), (int)sf2.size(),
+                         a.valid.data(), a.u.data(), a.v.data(), a.level.data()) != UVO_OK ||
+        uvo_project_sim3(m_, R2w, t2w, sR12, t12v, &cam1, N2, b.xyz.data(), b.mind.data(), b.maxd.data(), b.usable.data(), sf1.data(), (int)sf1.size(),
+                         b.valid.data(), b.u.data(), b.v.data(), b.level.data()) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    std::vector<uvo_keypoint> kps1, kps2;
+    std::vector<uint8_t> kdesc1, kdesc2;
+    marshal_keyframe(pKF1, kps1, kdesc1);
+    marshal_keyframe(pKF2, kps2, kdesc2);
+    const int32_t b1[4] = {(int32_t)pKF1->mnMinX, (int32_t)pKF1->mnMinY, (int32_t)pKF1->mnMaxX, (int32_t)pKF1->mnMaxY};
+    const int32_t b2[4] = {(int32_t)pKF2->mnMinX, (int32_t)pKF2->mnMinY, (int32_t)pKF2->mnMaxX, (int32_t)pKF2->mnMaxY};
+    std::vector<int32_t> match12(N1, -1);
+    int nFound = 0;
+    if (uvo_search_by_sim3(m_, kps1.data(), N1, kdesc1.data(), b1, kps2.data(), N2, kdesc2.data(), b2, a.u.data(), a.v.data(), a.level.data(),
+                           a.valid.data(), a.mdesc.data(), b.u.data(), b.v.data(), b.level.data(), b.valid.data(), b.mdesc.data(), sf1.data(),
+                           (int)sf1.size(), sf2.data(), (int)sf2.size(), th, match12.data(), &nFound) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    for (int i1 = 0; i1 < N1; ++i1)
+      if (match12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[match12[i1]];  // :1489
+    return nFound;
+  }
+
   /* Utils::ratioMatching (include/utils.h:81-111) on raw descriptor rows: accepted (query, train, distance) triples. */
   struct Match {
     int queryIdx, trainIdx;
@@ -360,6 +500,68 @@ class UVO_COMPAT_MATCHER_NAME {
   bool mbCheckOrientation;
 
  private:
+  template <class KeyFrameT>
+  static void marshal_keyframe(KeyFrameT* pKF, std::vector<uvo_keypoint>& kps, std::vector<uint8_t>& kdesc) {
+    const int n = (int)pKF->N;
+    kps.resize(n), kdesc.resize((size_t)n * 32);
+    for (int k = 0; k < n; ++k) {
+      auto d = pKF->GetDescriptor(k);
+      std::memcpy(&kdesc[(size_t)k * 32], d.ptr(0), 32);
+      const auto kp = pKF->GetKeyPointUn(k);
+      static_assert(sizeof(kp) == sizeof(uvo_keypoint), "keypoint layout must be cv::KeyPoint");
+      std::memcpy(&kps[k], &kp, sizeof(uvo_keypoint));
+    }
+  }
+  template <class KeyFrameT>
+  static uvo_camera_pose intrinsics_of(KeyFrameT* pKF) {
+    uvo_camera_pose cam;
+    std::memset(&cam, 0, sizeof(cam));
+    cam.fx = pKF->fx, cam.fy = pKF->fy, cam.cx = pKF->cx, cam.cy = pKF->cy;
+    cam.min_x = pKF->mnMinX, cam.max_x = pKF->mnMaxX, cam.min_y = pKF->mnMinY, cam.max_y = pKF->mnMaxY;
+    return cam;
+  }
+  /* the candidates of the two Scw members after :299-361 / :1145-1207: decomposition of Scw, then the Fuse-form projection tests */
+  template <class MapPointT>
+  struct Sim3Candidates {
+    std::vector<float> u, v, scale;
+    std::vector<int32_t> level;
+    std::vector<uint8_t> valid, mdesc;
+  };
+  template <class KeyFrameT, class MatT, class MapPointT>
+  bool project_with_scw(KeyFrameT* pKF, const MatT& Scw, const std::vector<MapPointT*>& vpPoints, const std::set<MapPointT*>& spAlreadyFound,
+                        Sim3Candidates<MapPointT>& c) {
+    const int nmp = (int)vpPoints.size();
+    float scw[12];
+    for (int r = 0; r < 3; ++r)
+      for (int k = 0; k < 4; ++k) scw[4 * r + k] = Scw.template at<float>(r, k);
+    uvo_camera_pose cam = intrinsics_of(pKF);
+    if (uvo_sim3_decompose(scw, 4, &cam) != UVO_OK) {
+      err_ = uvo_last_error();
+      return false;
+    }
+    c.scale = pKF->GetScaleFactors();
+    std::vector<float> xyz((size_t)nmp * 3, 0.f), nrm((size_t)nmp * 3, 0.f), mind(nmp, 1.f), maxd(nmp, 1.f);
+    std::vector<uint8_t> usable(nmp, 0);
+    c.u.resize(nmp), c.v.resize(nmp), c.level.resize(nmp), c.valid.resize(nmp), c.mdesc.assign((size_t)nmp * 32, 0);
+    for (int i = 0; i < nmp; ++i) {
+      MapPointT* pMP = vpPoints[i];
+      if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;  // :315-317 / :1167-1168
+      usable[i] = 1;
+      auto p = pMP->GetWorldPos();
+      auto pn = pMP->GetNormal();
+      for (int k = 0; k < 3; ++k) xyz[(size_t)i * 3 + k] = p.template at<float>(k), nrm[(size_t)i * 3 + k] = pn.template at<float>(k);
+      mind[i] = pMP->GetMinDistanceInvariance(), maxd[i] = pMP->GetMaxDistanceInvariance();
+      auto d = pMP->GetDescriptor();
+      std::memcpy(&c.mdesc[(size_t)i * 32], d.ptr(0), 32);
+    }
+    if (uvo_project_points(m_, UVO_PROJECT_FUSE, &cam, nmp, xyz.data(), nrm.data(), mind.data(), maxd.data(), nullptr, usable.data(), c.scale.data(),
+                           (int)c.scale.size(), 0.f, 0.f, c.valid.data(), c.u.data(), c.v.data(), c.level.data(), nullptr) != UVO_OK) {
+      err_ = uvo_last_error();
+      return false;
+    }
+    return true;
+  }
+
   /* DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned int>>) flattened into the three arrays the ABI takes */
   struct FlatFeatureVector {
     std::vector<uint32_t> node;

@@ -358,6 +358,42 @@ int uvo_project_points(uvo_matcher* m, int mode, const uvo_camera_pose* cam, int
                        const float* scale_factors, int nlevels, float scale_factor, float viewing_cos_limit, uint8_t* valid, float* u, float* v,
                        int32_t* level, float* view_cos);
 
+/*
+ * Loop-closing (Sim3) forms of the search loops.
+ *
+ * uvo_sim3_decompose: the head of SearchByProjection(pKF, Scw, ...) src/ORBmatcher.cc:299-303 and Fuse(pKF, Scw, ...) :1145-1149:
+ *   scw = |row 0 of sR|, Rcw = sR / scw, tcw = s t / scw, Ow = -Rcw^T tcw, written to cam->rcw / tcw / ow (the other members are
+ *   left alone).  scw_mat: 3 rows of row_stride floats (a 4x4 or 3x4 row-major Scw).  Host arithmetic, evaluated the way OpenCV
+ *   evaluates those cv::Mat expressions (double dot product, multiplication by the float reciprocal, double-accumulating gemm).
+ *   With the result, uvo_project_points(UVO_PROJECT_FUSE) is the per-point prologue of both members (:315-361 / :1161-1207 are
+ *   the same tests as :1037-1075).
+ * uvo_sim3_relative: SearchBySim3 :1284-1287: s_r12 = s12 R12, s_r21 = (1/s12) R12^T, t21 = -s_r21 t12 (3x3 row-major, 3-vectors).
+ * uvo_project_sim3: the per-point prologue of either direction of SearchBySim3 (:1323-1359 / :1403-1441): world -> the owning
+ *   key frame's camera (r_own, t_own) -> the other camera (s_r, t) -> pixel (cam_other: fx, fy, cx, cy and the image bounds are
+ *   read), positive depth, KeyFrame::IsInImage, distance inside [min_distance_inv, max_distance_inv], level by lower_bound over
+ *   scale_factors.  usable[i] = point exists, not already matched, not bad (may be NULL).
+ * uvo_search_by_projection_sim3: :357-398 on the projected candidates: best unmatched key point within th * scale_factors[level]
+ *   on levels [level-1, level], accepted at <= TH_LOW, first come first served in candidate order.
+ *   matched[n]: in: >= 0 where vpMatched[idx] is set; out: newly matched key points hold the candidate's index.
+ * uvo_search_by_sim3: :1361-1504: both directions (best key point of the other frame on levels [level-1, level], <= TH_HIGH,
+ *   no exclusivity) and the agreement check.  *12 arrays have n1 entries (KF1's map points, projected into KF2, with their
+ *   representative descriptors mp_desc1), *21 arrays n2 entries.  bounds = {mnMinX, mnMinY, mnMaxX, mnMaxY} of each key frame.
+ *   match12[n1]: index into KF2 or -1.
+ */
+int uvo_sim3_decompose(const float* scw_mat, int row_stride, uvo_camera_pose* cam);
+int uvo_sim3_relative(float s12, const float* r12, const float* t12, float* s_r12, float* s_r21, float* t21);
+int uvo_project_sim3(uvo_matcher* m, const float* r_own, const float* t_own, const float* s_r, const float* t, const uvo_camera_pose* cam_other,
+                     int npts, const float* xyz, const float* min_distance_inv, const float* max_distance_inv, const uint8_t* usable,
+                     const float* scale_factors, int nlevels, uint8_t* valid, float* u, float* v, int32_t* level);
+int uvo_search_by_projection_sim3(uvo_matcher* m, const uvo_keypoint* kp, int n, const uint8_t* desc, int min_x, int min_y, int max_x, int max_y,
+                                  int32_t* matched, int nmp, const float* u, const float* v, const int32_t* level, const uint8_t* valid,
+                                  const uint8_t* mp_desc, const float* scale_factors, int nlevels, int th, int* n_matches);
+int uvo_search_by_sim3(uvo_matcher* m, const uvo_keypoint* kp1, int n1, const uint8_t* desc1, const int32_t* bounds1, const uvo_keypoint* kp2,
+                       int n2, const uint8_t* desc2, const int32_t* bounds2, const float* u12, const float* v12, const int32_t* level12,
+                       const uint8_t* valid12, const uint8_t* mp_desc1, const float* u21, const float* v21, const int32_t* level21,
+                       const uint8_t* valid21, const uint8_t* mp_desc2, const float* scale_factors1, int nlevels1, const float* scale_factors2,
+                       int nlevels2, float th, int32_t* match12, int* n_found);
+
 /* ------------------------------------------------------------------------------------------------
  * Bag-of-words transform: DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>::transform(features, BowVector&, FeatureVector&,
  * levelsup) (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1125-1188, per-feature descent :1207-1258), as called by

@@ -497,6 +497,144 @@ bool project_fuse(const Camera& K, const float* p3Dw, const float* Pn, float mfM
   return true;
 }
 
+// ---- Sim3 forms (loop closing) ----
+// Decomposition of Scw at the head of SearchByProjection(pKF, Scw, ...) and Fuse(pKF, Scw, ...): src/ORBmatcher.cc:299-303 / :1145-1149.
+// cv::Mat expressions, as OpenCV 3.4 evaluates them (unpinned, orb_oracle.hpp): Mat::dot accumulates in double; `M / s` is
+// convertTo(alpha = 1./s) whose 32F kernel multiplies by (float)alpha; `-A.t() * b` is gemm(GEMM_1_T, alpha = -1) on the general
+// path (double accumulation).  Scw: 3 rows of row_stride floats (a 4x4 or 3x4 row-major matrix).
+void sim3_decompose(const float* Scw, int row_stride, float* Rcw, float* tcw, float* Ow) {
+  double dot = 0;
+  for (int k = 0; k < 3; k++) dot += (double)Scw[k] * Scw[k];
+  const float scw = sqrt(dot);
+  const float inv = (float)(1. / scw);
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) Rcw[3 * i + j] = Scw[i * row_stride + j] * inv;
+    tcw[i] = Scw[i * row_stride + 3] * inv;
+  }
+  for (int c = 0; c < 3; c++) {
+    double acc = 0;
+    for (int k = 0; k < 3; k++) acc += (double)Rcw[3 * k + c] * (double)tcw[k];
+    Ow[c] = (float)(acc * -1.0);
+  }
+}
+
+// SearchBySim3 :1284-1287: sR12 = s12*R12 (convertTo, float product); sR21 = (1.0/s12)*R12.t() (transpose, then convertTo with
+// (float)(1.0/s12)); t21 = -sR21*t12 (gemm small-matrix path: fp32 row sum, times alpha = -1 in double)
+void sim3_relative(float s12, const float* R12, const float* t12, float* sR12, float* sR21, float* t21) {
+  for (int i = 0; i < 9; i++) sR12[i] = R12[i] * s12;
+  const float inv = (float)(1.0 / s12);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) sR21[3 * i + j] = R12[3 * j + i] * inv;
+  for (int i = 0; i < 3; i++) {
+    const float t0 = sR21[3 * i] * t12[0] + sR21[3 * i + 1] * t12[1] + sR21[3 * i + 2] * t12[2];
+    t21[i] = (float)(t0 * -1.0 + 0.f * 0.0);
+  }
+}
+
+// SearchBySim3, the per-point prologue of either direction (:1323-1359 / :1403-1441): world -> own camera (Ra, ta) -> other
+// camera (sR, t) -> pixel of the other key frame K (intrinsics + image bounds are the only members of K that are read)
+bool project_sim3(const float* Ra, const float* ta, const float* sR, const float* t, const Camera& K, const float* p3Dw, float minDistance,
+                  float maxDistance, const float* scaleFactors, int nScaleLevels, float* u_out, float* v_out, int* level) {
+  float p3Dc1[3], p3Dc2[3];
+  mat_Rp_plus_t(Ra, p3Dw, ta, p3Dc1);
+  mat_Rp_plus_t(sR, p3Dc1, t, p3Dc2);
+  if (p3Dc2[2] < 0.0) return false;
+  float invz = 1.0 / p3Dc2[2];
+  float x = p3Dc2[0] * invz;
+  float y = p3Dc2[1] * invz;
+  float u = K.fx * x + K.cx;
+  float v = K.fy * y + K.cy;
+  if (!(u >= K.minX && u < K.maxX && v >= K.minY && v < K.maxY)) return false;  // KeyFrame::IsInImage src/KeyFrame.cc:994-997
+  float dist3D = mat_norm3(p3Dc2);
+  if (dist3D < minDistance || dist3D > maxDistance) return false;
+  float ratio = dist3D / minDistance;
+  const float* it = std::lower_bound(scaleFactors, scaleFactors + nScaleLevels, ratio);
+  *level = std::min((int)(it - scaleFactors), nScaleLevels - 1);
+  *u_out = u, *v_out = v;
+  return true;
+}
+
+// SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) :357-398 after the projection tests: matched[idx] >= 0 stands for
+// vpMatched[idx] != NULL; a new match stores the candidate's index
+int search_by_projection_sim3(const FrameGrid& g, const uint8_t* kfdesc, int32_t* matched, int nmp, const float* u, const float* v,
+                              const int32_t* level, const uint8_t* valid, const uint8_t* mpdesc, const float* scaleFactors, int th) {
+  int nmatches = 0;
+  for (int iMP = 0; iMP < nmp; iMP++) {
+    if (!valid[iMP]) continue;
+    const int nPredictedLevel = level[iMP];
+    const float radius = th * scaleFactors[nPredictedLevel];
+    std::vector<int> vIndices = g.GetFeaturesInArea(u[iMP], v[iMP], radius, -1, -1);
+    if (vIndices.empty()) continue;
+    const uint8_t* dMP = mpdesc + (size_t)iMP * 32;
+    int bestDist = 0x7fffffff, bestIdx = -1;
+    for (int idx : vIndices) {
+      if (matched[idx] >= 0) continue;
+      const int kpLevel = g.kps[idx].octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      const int dist = descriptor_distance(dMP, kfdesc + (size_t)idx * 32);
+      if (dist < bestDist) {
+        bestDist = dist;
+        bestIdx = idx;
+      }
+    }
+    if (bestDist <= TH_LOW) {
+      matched[bestIdx] = iMP;
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
+// one direction of SearchBySim3 (:1361-1394 / :1443-1476): best key point of the other frame on levels [l-1, l], <= TH_HIGH
+static void sim3_direction(const FrameGrid& g, const uint8_t* kfdesc, int n, const float* u, const float* v, const int32_t* level,
+                           const uint8_t* valid, const uint8_t* mpdesc, const float* scaleFactors, float th, std::vector<int>& vnMatch) {
+  const int TH_HIGH = 100;  // :40
+  vnMatch.assign(n, -1);
+  for (int i = 0; i < n; i++) {
+    if (!valid[i]) continue;
+    const int nPredictedLevel = level[i];
+    float radius = th * scaleFactors[nPredictedLevel];
+    std::vector<int> vIndices = g.GetFeaturesInArea(u[i], v[i], radius, -1, -1);
+    if (vIndices.empty()) continue;
+    int bestDist = 0x7fffffff, bestIdx = -1;
+    for (int idx : vIndices) {
+      const int octave = g.kps[idx].octave;
+      if (octave < nPredictedLevel - 1 || octave > nPredictedLevel) continue;
+      int dist = descriptor_distance(mpdesc + (size_t)i * 32, kfdesc + (size_t)idx * 32);
+      if (dist < bestDist) {
+        bestDist = dist;
+        bestIdx = idx;
+      }
+    }
+    if (bestDist <= TH_HIGH) vnMatch[i] = bestIdx;
+  }
+}
+
+// SearchBySim3 :1361-1504.  valid12[i1] = point i1 of KF1 exists, is not already matched, is not bad and passed the projection into
+// KF2 (u12, v12, level12); likewise valid21 for KF2's points projected into KF1.  match12[i1] = index in KF2 or -1 (the reference
+// stores vpMapPoints2[that index]).
+int search_by_sim3(const FrameGrid& g1, const uint8_t* desc1, int n1, const FrameGrid& g2, const uint8_t* desc2, int n2, const float* u12,
+                   const float* v12, const int32_t* level12, const uint8_t* valid12, const uint8_t* mpdesc1, const float* u21, const float* v21,
+                   const int32_t* level21, const uint8_t* valid21, const uint8_t* mpdesc2, const float* scaleFactors1,
+                   const float* scaleFactors2, float th, int32_t* match12) {
+  std::vector<int> vnMatch1, vnMatch2;
+  sim3_direction(g2, desc2, n1, u12, v12, level12, valid12, mpdesc1, scaleFactors2, th, vnMatch1);
+  sim3_direction(g1, desc1, n2, u21, v21, level21, valid21, mpdesc2, scaleFactors1, th, vnMatch2);
+  int nFound = 0;
+  for (int i1 = 0; i1 < n1; i1++) {
+    match12[i1] = -1;
+    int idx2 = vnMatch1[i1];
+    if (idx2 >= 0) {
+      int idx1 = vnMatch2[idx2];
+      if (idx1 == i1) {
+        match12[i1] = idx2;
+        nFound++;
+      }
+    }
+  }
+  return nFound;
+}
+
 // ---- DBoW2 ----
 void bow_transform_one(const Vocabulary& voc, const uint8_t* feature, int levelsup, int* word_id, double* weight, int* nid_out) {
   const int nid_level = voc.L - levelsup;

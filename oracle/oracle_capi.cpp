@@ -200,6 +200,43 @@ void orc_project_points(int mode, const float* cam, int n, const float* xyz, con
   }
 }
 
+void orc_sim3_decompose(const float* Scw, int row_stride, float* Rcw, float* tcw, float* Ow) { sim3_decompose(Scw, row_stride, Rcw, tcw, Ow); }
+void orc_sim3_relative(float s12, const float* R12, const float* t12, float* sR12, float* sR21, float* t21) {
+  sim3_relative(s12, R12, t12, sR12, sR21, t21);
+}
+// cam = 23 floats in Camera order (only the intrinsics and bounds are read)
+void orc_project_sim3(const float* Ra, const float* ta, const float* sR, const float* t, const float* cam, int n, const float* xyz,
+                      const float* minD, const float* maxD, const uint8_t* usable, const float* scaleFactors, int nlevels, uint8_t* valid,
+                      float* u, float* v, int32_t* level) {
+  Camera C;
+  memcpy(&C, cam, sizeof(Camera));
+  for (int i = 0; i < n; ++i) {
+    valid[i] = 0, u[i] = v[i] = 0.f, level[i] = 0;
+    if (usable && !usable[i]) continue;
+    float uu, vv;
+    int lv;
+    if (!project_sim3(Ra, ta, sR, t, C, xyz + 3 * i, minD[i], maxD[i], scaleFactors, nlevels, &uu, &vv, &lv)) continue;
+    valid[i] = 1, u[i] = uu, v[i] = vv, level[i] = lv;
+  }
+}
+int orc_search_by_projection_sim3(const KeyPoint* kps, int n, const uint8_t* kfdesc, int minX, int minY, int maxX, int maxY, int32_t* matched,
+                                  int nmp, const float* u, const float* v, const int32_t* level, const uint8_t* valid, const uint8_t* mpdesc,
+                                  const float* scaleFactors, int th) {
+  FrameGrid g;
+  g.build(kps, n, minX, minY, maxX, maxY);
+  return search_by_projection_sim3(g, kfdesc, matched, nmp, u, v, level, valid, mpdesc, scaleFactors, th);
+}
+int orc_search_by_sim3(const KeyPoint* kp1, int n1, const uint8_t* desc1, const int32_t* bounds1, const KeyPoint* kp2, int n2,
+                       const uint8_t* desc2, const int32_t* bounds2, const float* u12, const float* v12, const int32_t* level12,
+                       const uint8_t* valid12, const uint8_t* mpdesc1, const float* u21, const float* v21, const int32_t* level21,
+                       const uint8_t* valid21, const uint8_t* mpdesc2, const float* sf1, const float* sf2, float th, int32_t* match12) {
+  FrameGrid g1, g2;
+  g1.build(kp1, n1, bounds1[0], bounds1[1], bounds1[2], bounds1[3]);
+  g2.build(kp2, n2, bounds2[0], bounds2[1], bounds2[2], bounds2[3]);
+  return search_by_sim3(g1, desc1, n1, g2, desc2, n2, u12, v12, level12, valid12, mpdesc1, u21, v21, level21, valid21, mpdesc2, sf1, sf2, th,
+                        match12);
+}
+
 int orc_bow_transform(int n_nodes, const int32_t* child_start, const int32_t* children, const uint8_t* descriptor, const int32_t* word_id,
                       const double* weight, int L, int weighting, int normalize, const uint8_t* features, int n, int levelsup,
                       int32_t* out_word, double* out_weight, int32_t* out_node, uint32_t* bow_id, double* bow_value, int* n_bow,

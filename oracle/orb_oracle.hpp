@@ -159,6 +159,17 @@ bool project_kf_reloc(const Camera& F, const float* x3Dw, float mfMinDistance, c
 // Fuse src/ORBmatcher.cc:1037-1075
 bool project_fuse(const Camera& K, const float* p3Dw, const float* Pn, float mfMinDistance, float mfMaxDistance, const float* scaleFactors,
                   int nScaleLevels, float* u, float* v, int* level);
+// Sim3 forms: src/ORBmatcher.cc:299-303 (= :1145-1149), :1284-1287, :1323-1359 (= :1403-1441), :357-398, :1361-1504
+void sim3_decompose(const float* Scw, int row_stride, float* Rcw, float* tcw, float* Ow);
+void sim3_relative(float s12, const float* R12, const float* t12, float* sR12, float* sR21, float* t21);
+bool project_sim3(const float* Ra, const float* ta, const float* sR, const float* t, const Camera& K, const float* p3Dw, float minDistance,
+                  float maxDistance, const float* scaleFactors, int nScaleLevels, float* u, float* v, int* level);
+int search_by_projection_sim3(const FrameGrid& g, const uint8_t* kfdesc, int32_t* matched, int nmp, const float* u, const float* v,
+                              const int32_t* level, const uint8_t* valid, const uint8_t* mpdesc, const float* scaleFactors, int th);
+int search_by_sim3(const FrameGrid& g1, const uint8_t* desc1, int n1, const FrameGrid& g2, const uint8_t* desc2, int n2, const float* u12,
+                   const float* v12, const int32_t* level12, const uint8_t* valid12, const uint8_t* mpdesc1, const float* u21, const float* v21,
+                   const int32_t* level21, const uint8_t* valid21, const uint8_t* mpdesc2, const float* scaleFactors1,
+                   const float* scaleFactors2, float th, int32_t* match12);
 
 
 // ---- DBoW2 bag-of-words transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1125-1258, BowVector.cpp, FeatureVector.cpp) ----

@@ -62,6 +62,8 @@ struct MP2 {
   float GetMaxDistanceInvariance() const { return 1.2f * maxd; }
   Desc1 GetDescriptor() const { return Desc1{d.data()}; }
   bool IsInKeyFrame(KeyFrame*) const { return false; }
+  int index_in_kf = -1;
+  int GetIndexInKeyFrame(KeyFrame*) const { return index_in_kf; }
   void Replace(MP2*) { ++replaced; }
   void AddObservation(KeyFrame*, int) { ++observations; }
 };
@@ -87,6 +89,11 @@ struct KeyFrame {
   Mat44 GetTranslation() const { return t3; }
   Mat44 GetCameraCenter() const { return ow; }
   MP2* GetMapPoint(int i) const { return mps[i]; }
+  std::set<MP2*> GetMapPoints() const {
+    std::set<MP2*> s(mps.begin(), mps.end());
+    s.erase(nullptr);
+    return s;
+  }
   void AddMapPoint(MP2* p, int i) { mps[i] = p; }
 };
 struct Frame2 {
@@ -156,7 +163,31 @@ static int exercise_other_members(const std::vector<uvo_keypoint>& kps, const st
   for (int i = 0; i < n; ++i) vp2[i] = &pts[i];
   const int nf = m.Fuse(&kc, vp2, 3.f);
   if (nf < n * 8 / 10) return 14;
-  printf("other members: bow_kk=%d bow_kf=%d proj_kf=%d triang=%d fuse=%d of %d\n", nb, nbf, np, nt, nf, n);
+  // loop-closing forms with Scw = [2 I | 0]: scale 2 drops out of Rcw / tcw, so every point projects onto its own key point
+  Mat44 Scw;
+  memset(&Scw, 0, sizeof(Scw));
+  for (int i = 0; i < 3; ++i) Scw.m[i][i] = 2.f;
+  Scw.m[3][3] = 1.f;
+  KeyFrame kd = kf1;
+  kd.mps.assign(n, nullptr);
+  std::vector<MP2*> vpMatched(n, nullptr);
+  const int ns = m.SearchByProjection(&kd, Scw, vp2, vpMatched, 10);
+  int placed = 0;
+  for (int i = 0; i < n; ++i) placed += vpMatched[i] != nullptr;
+  if (ns < n * 8 / 10 || placed != ns) return 15;
+  const int nfs = m.Fuse(&kd, Scw, vp2, 4.f);
+  if (nfs < n * 8 / 10) return 16;
+  // SearchBySim3 between two identical key frames under the identity Sim3: mutual matches for (nearly) every point
+  Mat44 I3;
+  memset(&I3, 0, sizeof(I3));
+  for (int i = 0; i < 3; ++i) I3.m[i][i] = 1.f;
+  Mat44 zero;
+  memset(&zero, 0, sizeof(zero));
+  std::vector<MP2*> vm12(n, nullptr);
+  const float s12 = 1.f;
+  const int n3 = m.SearchBySim3(&kf1, &kf2, vm12, s12, I3, zero, 7.5f);
+  if (n3 < n * 8 / 10) return 17;
+  printf("other members: bow_kk=%d bow_kf=%d proj_kf=%d triang=%d fuse=%d proj_scw=%d fuse_scw=%d sim3=%d of %d\n", nb, nbf, np, nt, nf, ns, nfs, n3, n);
   return 0;
 }
 

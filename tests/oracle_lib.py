@@ -67,6 +67,11 @@ class Oracle:
         L.orc_clahe.argtypes = [vp, ci, ci, cl, ctypes.c_double, ci, ci, vp, cl]
         L.orc_bow_transform.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_project_points.argtypes = [ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp, vp, vp, vp]
+        L.orc_sim3_decompose.argtypes = [vp, ci, vp, vp, vp]
+        L.orc_sim3_relative.argtypes = [cf, vp, vp, vp, vp, vp]
+        L.orc_project_sim3.argtypes = [vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]
+        L.orc_search_by_projection_sim3.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci]
+        L.orc_search_by_sim3.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, cf, vp]
 
     # ---- extractor ----
     def extractor(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, fastTh=20):
@@ -230,6 +235,61 @@ class Oracle:
                                   None if us is None else us.ctypes.data, sf.ctypes.data, len(sf), float(scale_factor), float(cos_limit),
                                   valid.ctypes.data, u.ctypes.data, v.ctypes.data, level.ctypes.data, vc.ctypes.data)
         return valid, u, v, level, vc
+
+    def sim3_decompose(self, scw):
+        scw = np.ascontiguousarray(scw, np.float32)
+        r, t, o = np.zeros(9, np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)
+        self.L.orc_sim3_decompose(scw.ctypes.data, 4, r.ctypes.data, t.ctypes.data, o.ctypes.data)
+        return r, t, o
+
+    def sim3_relative(self, s12, r12, t12):
+        r12, t12 = np.ascontiguousarray(r12, np.float32).reshape(9), np.ascontiguousarray(t12, np.float32).reshape(3)
+        a, b, c = np.zeros((3, 3), np.float32), np.zeros((3, 3), np.float32), np.zeros(3, np.float32)
+        self.L.orc_sim3_relative(ctypes.c_float(s12), r12.ctypes.data, t12.ctypes.data, a.ctypes.data, b.ctypes.data, c.ctypes.data)
+        return a, b, c
+
+    def project_sim3(self, r_own, t_own, s_r, t, cam, xyz, min_distance, max_distance, usable, scale_factors):
+        """min_distance / max_distance = mfMinDistance / mfMaxDistance; returns (valid, u, v, level)."""
+        ro, to = np.ascontiguousarray(r_own, np.float32).reshape(9), np.ascontiguousarray(t_own, np.float32).reshape(3)
+        sr, tt = np.ascontiguousarray(s_r, np.float32).reshape(9), np.ascontiguousarray(t, np.float32).reshape(3)
+        cam = np.ascontiguousarray(cam, np.float32)
+        assert cam.shape == (23,)
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        n = len(xyz)
+        mn = (np.float32(0.8) * np.ascontiguousarray(min_distance, np.float32)).astype(np.float32)   # MapPoint::GetMinDistanceInvariance
+        mx = (np.float32(1.2) * np.ascontiguousarray(max_distance, np.float32)).astype(np.float32)
+        us = None if usable is None else np.ascontiguousarray(usable, np.uint8)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        valid, u, v, level = np.zeros(n, np.uint8), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+        self.L.orc_project_sim3(ro.ctypes.data, to.ctypes.data, sr.ctypes.data, tt.ctypes.data, cam.ctypes.data, n, xyz.ctypes.data, mn.ctypes.data,
+                                mx.ctypes.data, None if us is None else us.ctypes.data, sf.ctypes.data, len(sf), valid.ctypes.data, u.ctypes.data,
+                                v.ctypes.data, level.ctypes.data)
+        return valid, u, v, level
+
+    def search_by_projection_sim3(self, kps, desc, bounds, matched, u, v, level, valid, mp_desc, scale_factors, th):
+        kps, desc = np.ascontiguousarray(kps, KP), np.ascontiguousarray(desc, np.uint8)
+        assert matched.dtype == np.int32
+        a = [np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32), np.ascontiguousarray(level, np.int32),
+             np.ascontiguousarray(valid, np.uint8), np.ascontiguousarray(mp_desc, np.uint8), np.ascontiguousarray(scale_factors, np.float32)]
+        return self.L.orc_search_by_projection_sim3(kps.ctypes.data, len(kps), desc.ctypes.data, *[int(b) for b in bounds], matched.ctypes.data,
+                                                    len(a[0]), *[x.ctypes.data for x in a], int(th))
+
+    def search_by_sim3(self, kp1, desc1, bounds1, kp2, desc2, bounds2, proj12, mp_desc1, proj21, mp_desc2, sf1, sf2, th):
+        kp1, kp2 = np.ascontiguousarray(kp1, KP), np.ascontiguousarray(kp2, KP)
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        b1, b2 = np.ascontiguousarray(bounds1, np.int32), np.ascontiguousarray(bounds2, np.int32)
+
+        def unpack(p):
+            return [np.ascontiguousarray(p[1], np.float32), np.ascontiguousarray(p[2], np.float32), np.ascontiguousarray(p[3], np.int32),
+                    np.ascontiguousarray(p[0], np.uint8)]
+        a12, a21 = unpack(proj12), unpack(proj21)
+        m1, m2 = np.ascontiguousarray(mp_desc1, np.uint8), np.ascontiguousarray(mp_desc2, np.uint8)
+        s1, s2 = np.ascontiguousarray(sf1, np.float32), np.ascontiguousarray(sf2, np.float32)
+        match12 = np.full(len(kp1), -1, np.int32)
+        n = self.L.orc_search_by_sim3(kp1.ctypes.data, len(kp1), d1.ctypes.data, b1.ctypes.data, kp2.ctypes.data, len(kp2), d2.ctypes.data,
+                                      b2.ctypes.data, *[x.ctypes.data for x in a12], m1.ctypes.data, *[x.ctypes.data for x in a21], m2.ctypes.data,
+                                      s1.ctypes.data, s2.ctypes.data, ctypes.c_float(th), match12.ctypes.data)
+        return match12, n
 
     def bow_transform(self, voc, desc, levelsup=4):
         """voc = dict(child_start, children, descriptor, word_id, weight, L, weighting, normalize).

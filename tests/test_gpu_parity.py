@@ -530,6 +530,111 @@ def test_project_points(uvo, oracle, mode):
     m.close()
 
 
+def _bits(a):
+    a = np.asarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def test_sim3_decompose_and_relative(uvo, oracle):
+    """uvo_sim3_decompose / uvo_sim3_relative (host arithmetic behind the C ABI) against the restated cv::Mat expressions."""
+    rng = np.random.default_rng(50)
+    for trial in range(300):
+        R, t, _ = _random_pose(rng)
+        s = np.float32(rng.uniform(0.2, 5.0))
+        Scw = np.eye(4, dtype=np.float32)
+        Scw[:3, :3], Scw[:3, 3] = s * R, s * t
+        cam = uvo.CameraPose.make(np.zeros(9), np.zeros(3), np.zeros(3), 1, 1, 0, 0, (0, 0, 1, 1))
+        uvo.ORBmatcher.sim3_decompose(Scw, cam)
+        r, tt, o = oracle.sim3_decompose(Scw)
+        np.testing.assert_array_equal(_bits(np.float32(cam.rcw[:])), _bits(r))
+        np.testing.assert_array_equal(_bits(np.float32(cam.tcw[:])), _bits(tt))
+        np.testing.assert_array_equal(_bits(np.float32(cam.ow[:])), _bits(o))
+        got = uvo.ORBmatcher.sim3_relative(s, R, t)
+        ref = oracle.sim3_relative(s, R, t)
+        for g, e in zip(got, ref):
+            np.testing.assert_array_equal(_bits(g), _bits(e))
+
+
+def test_project_sim3(uvo, oracle):
+    """Per-point prologue of SearchBySim3 (:1323-1359): world -> own camera -> other camera -> pixel, distance window, level."""
+    rng = np.random.default_rng(51)
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    m = uvo.ORBmatcher(0.8)
+    hits = 0
+    for trial in range(4):
+        R1, t1, _ = _random_pose(rng)
+        R12, t12, _ = _random_pose(rng)
+        s12 = np.float32(rng.uniform(0.5, 2.0))
+        sR12, sR21, t21 = uvo.ORBmatcher.sim3_relative(s12, R12, t12)
+        bounds = (0.0, 0.0, 752.0, 480.0)
+        cam = uvo.CameraPose.make(np.eye(3), np.zeros(3), np.zeros(3), 458.654, 457.296, 367.215, 248.375, bounds)
+        n = 20000
+        xyz = (rng.normal(0, 1, (n, 3)) * [4, 3, 4] + [0, 0, 6]).astype(np.float32)
+        d = np.linalg.norm(xyz, axis=1) / s12
+        mn = (d * rng.uniform(0.3, 1.4, n)).astype(np.float32)
+        mx = (mn * rng.uniform(1.5, 6.0, n)).astype(np.float32)
+        usable = (rng.random(n) < 0.9).astype(np.uint8)
+        for sr, tt in ((sR21, t21), (sR12, t12)):
+            got = m.project_sim3(R1, t1, sr, tt, cam, xyz, mn, mx, usable, sf)
+            ref = oracle.project_sim3(R1, t1, sr, tt, cam.as_array(), xyz, mn, mx, usable, sf)
+            for g, r, name in zip(got, ref, ("valid", "u", "v", "level")):
+                assert g.dtype == r.dtype
+                np.testing.assert_array_equal(_bits(g), _bits(r), err_msg=name)
+            hits += int(ref[0].sum())
+            assert len(set(ref[3][ref[0] > 0].tolist())) >= 4
+    assert hits > 4000
+    m.close()
+
+
+def test_search_by_projection_sim3_and_search_by_sim3(uvo, oracle, synth):
+    """SearchByProjection(pKF, Scw, ...) search core (:357-398) and SearchBySim3 (:1361-1504) on two real views."""
+    rng = np.random.default_rng(52)
+    kp1, de1, kp2, de2, sf = _two_views(uvo, synth, 4500)
+    n1, n2 = len(kp1), len(kp2)
+    bounds = (0, 0, 752, 480)
+    m = uvo.ORBmatcher(0.75, True)
+    # --- exclusive projection search into key frame 2 ---
+    M = 3000
+    src = rng.integers(0, n2, M)
+    mp_desc = _noisy_copies(rng, de2, src, 0.04)
+    u = (kp2["x"][src] + rng.normal(0, 1.5, M)).astype(np.float32)
+    v = (kp2["y"][src] + rng.normal(0, 1.5, M)).astype(np.float32)
+    level = np.clip(kp2["octave"][src] + rng.integers(0, 2, M), 0, 7).astype(np.int32)
+    valid = (rng.random(M) < 0.9).astype(np.uint8)
+    for th in (10, 3):
+        mg = np.where(rng.random(n2) < 0.2, 5000 + np.arange(n2), -1).astype(np.int32)      # some key points already hold a point
+        mo = mg.copy()
+        ng = m.SearchByProjectionSim3(kp2, de2, bounds, mg, u, v, level, valid, mp_desc, sf, th)
+        no = oracle.search_by_projection_sim3(kp2, de2, bounds, mo, u, v, level, valid, mp_desc, sf, th)
+        assert ng == no
+        np.testing.assert_array_equal(mg, mo)
+    assert no > 200
+    # --- SearchBySim3: every key point of either frame owns a map point; its projection into the other frame = the position of a
+    #     true correspondent (nearest key point of the other frame after the known warp is not available here, so positions of
+    #     descriptor-nearest neighbours stand in) plus noise ---
+    i0, d0, _, _ = oracle.knn2(de1, de2)
+    j0, e0, _, _ = oracle.knn2(de2, de1)
+
+    def projection(kp_to, nn, n):
+        uu = (kp_to["x"][nn] + rng.normal(0, 2.0, n)).astype(np.float32)
+        vv = (kp_to["y"][nn] + rng.normal(0, 2.0, n)).astype(np.float32)
+        lv = np.clip(kp_to["octave"][nn] + rng.integers(0, 2, n), 0, 7).astype(np.int32)
+        va = (rng.random(n) < 0.85).astype(np.uint8)
+        return va, uu, vv, lv
+    p12, p21 = projection(kp2, i0, n1), projection(kp1, j0, n2)
+    md1 = _noisy_copies(rng, de1, np.arange(n1), 0.03, 0.9)
+    md2 = _noisy_copies(rng, de2, np.arange(n2), 0.03, 0.9)
+    tot = 0
+    for th in (7.5, 20.0):
+        g12, gf = m.SearchBySim3(kp1, de1, bounds, kp2, de2, bounds, p12, md1, p21, md2, sf, sf, th)
+        o12, of = oracle.search_by_sim3(kp1, de1, bounds, kp2, de2, bounds, p12, md1, p21, md2, sf, sf, th)
+        assert gf == of
+        np.testing.assert_array_equal(g12, o12)
+        tot += of
+    assert tot > 100
+    m.close()
+
+
 def test_frustum_then_search_by_projection_chain(uvo, oracle, synth):
     """Config-5 shape: isInFrustum on the device feeds SearchByProjection on the device; same chain through the oracle."""
     rng = np.random.default_rng(40)

@@ -304,6 +304,59 @@ def test_projection_prologues_by_hand(oracle):
     assert valid.tolist() == [0, 1, 0, 0, 0, 0]
 
 
+def test_sim3_forms_by_hand(oracle):
+    """Loop-closing forms: the Scw decomposition (:299-303), the relative transforms of SearchBySim3 (:1284-1287), its per-point
+    prologue, the exclusive search of SearchByProjection(pKF, Scw, ...) and the mutual-agreement rule."""
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    # Scw = [2 R | 2 t] with R = rotation by 90 deg about z, t = (1, 2, 3): scale 2 comes out, Ow = -R^T t
+    R = np.float32([[0, -1, 0], [1, 0, 0], [0, 0, 1]])
+    Scw = np.eye(4, dtype=np.float32)
+    Scw[:3, :3], Scw[:3, 3] = 2 * R, [2, 4, 6]
+    r, t, o = oracle.sim3_decompose(Scw)
+    np.testing.assert_array_equal(r.reshape(3, 3), R)
+    assert t.tolist() == [1.0, 2.0, 3.0] and o.tolist() == [-2.0, 1.0, -3.0]
+    # relative transforms: s12 = 2, R12 = R, t12 = (1, 0, 0): sR21 = R^T / 2, t21 = -(R^T / 2) t12 = (0, 0.5, 0)
+    a, b, c = oracle.sim3_relative(2.0, R, [1, 0, 0])
+    np.testing.assert_array_equal(a, 2 * R)
+    np.testing.assert_array_equal(b, R.T / 2)
+    assert c.tolist() == [0.0, 0.5, 0.0]
+    # prologue with identity transforms: like the Fuse prologue without the normal test, distance = norm of the camera-frame point
+    I, z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    P = [[0, 0, 10.0], [1.0, 0, 10.0], [0, 0, -5.0], [20.0, 0, 10.0], [0, 0, 100.0]]
+    mn, mx = np.full(5, 5.0, np.float32), np.full(5, 20.0, np.float32)
+    valid, u, v, lvl = oracle.project_sim3(I, z, I, z, _cam(), P, mn, mx, None, sf)
+    assert valid.tolist() == [1, 1, 0, 0, 0] and (u[0], v[0], u[1]) == (376.0, 240.0, 426.0) and lvl[0] == 6
+    # the chain really is other <- own <- world: own = translate by (0, 0, 5), other = scale by 2 -> depth 30, u = 376 + 500 * 2 / 30
+    valid, u, v, lvl = oracle.project_sim3(I, [0, 0, 5.0], 2 * I, z, _cam(), [[1.0, 0, 10.0]], [10.0], [40.0], None, sf)
+    assert valid.tolist() == [1] and u[0] == np.float32(376.0) + np.float32(500.0) * (np.float32(2.0) * np.float32(np.float32(1.0) / np.float32(30.0)))
+    # exclusive search: key points 0 (d 40), 1 (d 20) at level 1/2, both map points prefer kp1; the second must settle for kp0
+    rng = np.random.default_rng(9)
+    kp = _kps([(100, 100), (103, 100), (100, 104), (180, 100)], [1, 2, 4, 1])
+    base = rng.integers(0, 256, 32, dtype=np.uint8)
+    desc = np.stack([_desc_with_distance(rng, base, 40), _desc_with_distance(rng, base, 20), _desc_with_distance(rng, base, 5),
+                     _desc_with_distance(rng, base, 0)])
+    bounds = (0, 0, 752, 480)
+    mpd = np.stack([base, base])
+    matched = np.full(4, -1, np.int32)
+    n = oracle.search_by_projection_sim3(kp, desc, bounds, matched, [100.0, 100.0], [100.0, 100.0], [2, 2], [1, 1], mpd, sf, 3)
+    assert n == 2 and matched.tolist() == [1, 0, -1, -1]
+    matched = np.int32([-1, 7, -1, -1])                                   # kp1 already holds a point: both candidates see only kp0
+    n = oracle.search_by_projection_sim3(kp, desc, bounds, matched, [100.0, 100.0], [100.0, 100.0], [2, 2], [1, 1], mpd, sf, 3)
+    assert n == 1 and matched.tolist() == [0, 7, -1, -1]
+    # SearchBySim3: two key frames with the same two key points; direction 1->2 maps point 0 -> kp 0 and point 1 -> kp 0 (TH_HIGH,
+    # no exclusivity), direction 2->1 maps kp 0's point -> 0: only the mutual pair (0, 0) survives
+    kpA = _kps([(100, 100), (300, 100)], [1, 1])
+    dA = np.stack([base, _desc_with_distance(rng, base, 90)])
+    proj12 = ([1, 1], [100.0, 100.0], [100.0, 100.0], [1, 1])
+    proj21 = ([1, 0], [100.0, 0.0], [100.0, 0.0], [1, 0])
+    m12, nf = oracle.search_by_sim3(kpA, dA, bounds, kpA, dA, bounds, proj12, np.stack([base, base]), proj21, np.stack([base, base]), sf, sf, 7.5)
+    assert nf == 1 and m12.tolist() == [0, -1]
+    # beyond TH_HIGH nothing is kept
+    far = np.stack([_desc_with_distance(rng, base, 101), _desc_with_distance(rng, base, 120)])
+    m12, nf = oracle.search_by_sim3(kpA, dA, bounds, kpA, dA, bounds, proj12, far, proj21, far, sf, sf, 7.5)
+    assert nf == 0 and m12.tolist() == [-1, -1]
+
+
 # ---- DBoW2 transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1125-1258) ---------------------------------------------
 def _toy_vocabulary(weighting=0, normalize=1):
     """Root 0 -> {1, 2}; 1 -> leaves {3, 4}; 2 -> leaf {5} and inner 6 -> leaves {7, 8}.  Descriptors: byte 0 carries the value."""

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
-    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_haloc_hash", "uvo_klt_create", "uvo_klt_destroy", "uvo_klt_build_pyramid", "uvo_klt_read_level", "uvo_klt_track", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
+    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_sim3_decompose", "uvo_sim3_relative", "uvo_project_sim3", "uvo_search_by_projection_sim3", "uvo_search_by_sim3", "uvo_haloc_hash", "uvo_klt_create", "uvo_klt_destroy", "uvo_klt_build_pyramid", "uvo_klt_read_level", "uvo_klt_track", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
     "uvo_matcher_kernel_times", "uvo_last_error", "uvo_device_info",
 ]
 
@@ -164,6 +164,11 @@ def _load():
     lib.uvo_klt_read_level.argtypes = [vp, ci, ci, vp, vp, vp, vp]
     lib.uvo_klt_track.argtypes = [vp, ci, ci, vp, vp, ci, ci, ci, ctypes.c_double, ctypes.c_double, vp, vp]
     lib.uvo_fuse.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, vp, vp]
+    lib.uvo_sim3_decompose.argtypes = [vp, ci, vp]
+    lib.uvo_sim3_relative.argtypes = [cf, vp, vp, vp, vp, vp]
+    lib.uvo_project_sim3.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]
+    lib.uvo_search_by_projection_sim3.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, vp]
+    lib.uvo_search_by_sim3.argtypes = [vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci, cf, vp, vp]
     lib.uvo_matcher_wait_extractor.argtypes = [vp, vp]
     lib.uvo_extractor_wait_matcher.argtypes = [vp, vp]
     lib.uvo_matcher_profile.argtypes = [vp, ci]
@@ -579,6 +584,82 @@ class ORBmatcher:
         if rc:
             raise UvoError(rc, "uvo_haloc_hash")
         return out
+
+    @staticmethod
+    def sim3_decompose(scw, cam):
+        """Head of SearchByProjection(pKF, Scw, ...) / Fuse(pKF, Scw, ...) (:299-303): fills cam.rcw / tcw / ow from a 4x4 (or 3x4) Scw."""
+        scw = np.ascontiguousarray(scw, np.float32)
+        assert scw.ndim == 2 and scw.shape[0] >= 3 and scw.shape[1] == 4
+        rc = lib.uvo_sim3_decompose(_ptr(scw), 4, ctypes.addressof(cam))
+        if rc:
+            raise UvoError(rc, "uvo_sim3_decompose")
+        return cam
+
+    @staticmethod
+    def sim3_relative(s12, r12, t12):
+        """SearchBySim3 :1284-1287: returns (sR12, sR21, t21)."""
+        r12, t12 = np.ascontiguousarray(r12, np.float32).reshape(3, 3), np.ascontiguousarray(t12, np.float32).reshape(3)
+        a, b, c = np.zeros((3, 3), np.float32), np.zeros((3, 3), np.float32), np.zeros(3, np.float32)
+        rc = lib.uvo_sim3_relative(float(s12), _ptr(r12), _ptr(t12), _ptr(a), _ptr(b), _ptr(c))
+        if rc:
+            raise UvoError(rc, "uvo_sim3_relative")
+        return a, b, c
+
+    def project_sim3(self, r_own, t_own, s_r, t, cam_other, xyz, min_distance, max_distance, usable, scale_factors):
+        """Per-point prologue of one direction of SearchBySim3 (:1323-1359).  min_distance / max_distance = mfMinDistance / mfMaxDistance
+        (the invariance bounds x 0.8f / x 1.2f are formed here).  Returns (valid, u, v, level)."""
+        ro, to = np.ascontiguousarray(r_own, np.float32).reshape(9), np.ascontiguousarray(t_own, np.float32).reshape(3)
+        sr, tt = np.ascontiguousarray(s_r, np.float32).reshape(9), np.ascontiguousarray(t, np.float32).reshape(3)
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        mn_inv = (np.float32(0.8) * np.ascontiguousarray(min_distance, np.float32)).astype(np.float32)
+        mx_inv = (np.float32(1.2) * np.ascontiguousarray(max_distance, np.float32)).astype(np.float32)
+        us = None if usable is None else np.ascontiguousarray(usable, np.uint8)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        n = len(xyz)
+        valid, u, v, level = np.zeros(n, np.uint8), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+        rc = lib.uvo_project_sim3(self._h, _ptr(ro), _ptr(to), _ptr(sr), _ptr(tt), ctypes.addressof(cam_other), n, _ptr(xyz), _ptr(mn_inv), _ptr(mx_inv),
+                                  _ptr(us), _ptr(sf), len(sf), _ptr(valid), _ptr(u), _ptr(v), _ptr(level))
+        if rc:
+            raise UvoError(rc, "uvo_project_sim3")
+        return valid, u, v, level
+
+    def SearchByProjectionSim3(self, kp, desc, bounds, matched, u, v, level, valid, mp_desc, scale_factors, th):
+        """Search core of SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (:357-398).  matched (int32[n], >= 0 = taken) is
+        updated in place; returns the number of new matches."""
+        kp = np.ascontiguousarray(kp, KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        assert matched.dtype == np.int32 and matched.flags.c_contiguous and len(matched) == len(kp)
+        uu, vv = np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32)
+        lv, va = np.ascontiguousarray(level, np.int32), np.ascontiguousarray(valid, np.uint8)
+        md, sf = np.ascontiguousarray(mp_desc, np.uint8), np.ascontiguousarray(scale_factors, np.float32)
+        nm = ctypes.c_int()
+        rc = lib.uvo_search_by_projection_sim3(self._h, _ptr(kp), len(kp), _ptr(desc), int(bounds[0]), int(bounds[1]), int(bounds[2]), int(bounds[3]),
+                                               _ptr(matched), len(uu), _ptr(uu), _ptr(vv), _ptr(lv), _ptr(va), _ptr(md), _ptr(sf), len(sf), int(th),
+                                               ctypes.byref(nm))
+        if rc:
+            raise UvoError(rc, "uvo_search_by_projection_sim3")
+        return nm.value
+
+    def SearchBySim3(self, kp1, desc1, bounds1, kp2, desc2, bounds2, proj12, mp_desc1, proj21, mp_desc2, scale_factors1, scale_factors2, th):
+        """SearchBySim3 (:1361-1504) after the projections: proj12 = (valid, u, v, level) of KF1's points in KF2, proj21 the reverse.
+        Returns (match12[n1], n_found)."""
+        kp1, kp2 = np.ascontiguousarray(kp1, KEYPOINT_DTYPE), np.ascontiguousarray(kp2, KEYPOINT_DTYPE)
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        b1, b2 = np.ascontiguousarray(bounds1, np.int32), np.ascontiguousarray(bounds2, np.int32)
+        va12, u12, v12, l12 = (np.ascontiguousarray(proj12[0], np.uint8), np.ascontiguousarray(proj12[1], np.float32),
+                               np.ascontiguousarray(proj12[2], np.float32), np.ascontiguousarray(proj12[3], np.int32))
+        va21, u21, v21, l21 = (np.ascontiguousarray(proj21[0], np.uint8), np.ascontiguousarray(proj21[1], np.float32),
+                               np.ascontiguousarray(proj21[2], np.float32), np.ascontiguousarray(proj21[3], np.int32))
+        m1, m2 = np.ascontiguousarray(mp_desc1, np.uint8), np.ascontiguousarray(mp_desc2, np.uint8)
+        s1, s2 = np.ascontiguousarray(scale_factors1, np.float32), np.ascontiguousarray(scale_factors2, np.float32)
+        match12 = np.full(len(kp1), -1, np.int32)
+        nf = ctypes.c_int()
+        rc = lib.uvo_search_by_sim3(self._h, _ptr(kp1), len(kp1), _ptr(d1), _ptr(b1), _ptr(kp2), len(kp2), _ptr(d2), _ptr(b2), _ptr(u12), _ptr(v12),
+                                    _ptr(l12), _ptr(va12), _ptr(m1), _ptr(u21), _ptr(v21), _ptr(l21), _ptr(va21), _ptr(m2), _ptr(s1), len(s1), _ptr(s2),
+                                    len(s2), float(th), _ptr(match12), ctypes.byref(nf))
+        if rc:
+            raise UvoError(rc, "uvo_search_by_sim3")
+        return match12, nf.value
 
     def FuseSearch(self, kp, desc, bounds, u, v, level, valid, mp_desc, scale_factors, th=3.0):
         """Search core of Fuse (:1077-1101): (best_idx[nmp], best_dist[nmp]), -1 where nothing within TH_LOW."""

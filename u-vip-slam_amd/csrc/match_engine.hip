@@ -447,6 +447,54 @@ void launch_project(hipStream_t s, int mode, const uvo_camera_pose& cam, int n, 
                      cos_limit, d_valid, d_u, d_v, d_level, d_cos);
 }
 
+// SearchBySim3 per-point prologue (src/ORBmatcher.cc:1323-1359 / :1403-1441): world -> own camera -> other camera -> pixel
+struct Sim3Chain {
+  float r_own[9], t_own[3], s_r[9], t[3];
+  float fx, fy, cx, cy, min_x, max_x, min_y, max_y;
+};
+__global__ __launch_bounds__(256) void k_project_sim3(Sim3Chain C, int n, const float* __restrict__ xyz, const float* __restrict__ min_d,
+                                                      const float* __restrict__ max_d, const uint8_t* __restrict__ usable,
+                                                      const float* __restrict__ sf, int nlevels, uint8_t* __restrict__ valid,
+                                                      float* __restrict__ out_u, float* __restrict__ out_v, int32_t* __restrict__ out_level) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t ok = 0;
+  float u = 0.f, v = 0.f;
+  int lvl = 0;
+  do {
+    if (usable && !usable[i]) break;
+    const float P[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    const float Q[3] = {row_affine(C.r_own, P, C.t_own[0]), row_affine(C.r_own + 3, P, C.t_own[1]), row_affine(C.r_own + 6, P, C.t_own[2])};
+    const float X = row_affine(C.s_r, Q, C.t[0]), Y = row_affine(C.s_r + 3, Q, C.t[1]), Z = row_affine(C.s_r + 6, Q, C.t[2]);
+    if (Z < 0.0f) break;                           // :1328
+    const float invz = (float)(1.0 / (double)Z);   // :1331
+    const float x = X * invz, y = Y * invz;
+    u = C.fx * x + C.cx, v = C.fy * y + C.cy;
+    if (!(u >= C.min_x && u < C.max_x && v >= C.min_y && v < C.max_y)) break;  // KeyFrame::IsInImage
+    const double s2 = (double)X * (double)X + (double)Y * (double)Y + (double)Z * (double)Z;  // cv::norm(p3Dc2): double accumulator
+    const float dist3D = (float)sqrt(s2);
+    if (dist3D < min_d[i] || dist3D > max_d[i]) break;  // :1346
+    const float ratio = dist3D / min_d[i];
+    lvl = min(lower_bound_level(sf, nlevels, ratio), nlevels - 1);  // :1352-1353
+    ok = 1;
+  } while (false);
+  valid[i] = ok;
+  out_u[i] = ok ? u : 0.f;
+  out_v[i] = ok ? v : 0.f;
+  out_level[i] = ok ? lvl : 0;
+}
+void launch_project_sim3(hipStream_t s, const float* r_own, const float* t_own, const float* s_r, const float* t, const uvo_camera_pose& cam, int n,
+                         const float* d_xyz, const float* d_min, const float* d_max, const uint8_t* d_usable, const float* d_sf, int nlevels,
+                         uint8_t* d_valid, float* d_u, float* d_v, int32_t* d_level) {
+  Sim3Chain C;
+  for (int i = 0; i < 9; ++i) C.r_own[i] = r_own[i], C.s_r[i] = s_r[i];
+  for (int i = 0; i < 3; ++i) C.t_own[i] = t_own[i], C.t[i] = t[i];
+  C.fx = cam.fx, C.fy = cam.fy, C.cx = cam.cx, C.cy = cam.cy;
+  C.min_x = cam.min_x, C.max_x = cam.max_x, C.min_y = cam.min_y, C.max_y = cam.max_y;
+  hipLaunchKernelGGL(k_project_sim3, dim3((n + 255) / 256), dim3(256), 0, s, C, n, d_xyz, d_min, d_max, d_usable, d_sf, nlevels, d_valid, d_u, d_v,
+                     d_level);
+}
+
 // haloc::Hash::getHash (src/hash.cpp:57-85): thread = one (projection, descriptor column) output, sequential fp32 accumulation
 __global__ __launch_bounds__(64) void k_haloc(const float* __restrict__ proj, int num_proj, int proj_stride, const uint8_t* __restrict__ desc, int n,
                                               float* __restrict__ hash) {

@@ -3,6 +3,7 @@
 // is taken on the device.
 #include <algorithm>
 #include <cstring>
+#include <cmath>
 #include <vector>
 
 #include "matcher_priv.hpp"
@@ -25,6 +26,9 @@ void launch_match_resolve(hipStream_t s, int nq, int nt, const int32_t* d_cand_s
                           int32_t* d_mdist, int32_t* d_n_matches);
 void launch_rot_filter(hipStream_t s, int nq, const float* d_qangle, const float* d_tangle, int32_t* d_match, int32_t* d_mdist,
                        int32_t* d_n_matches);
+void launch_project_sim3(hipStream_t s, const float* r_own, const float* t_own, const float* s_r, const float* t, const uvo_camera_pose& cam, int n,
+                         const float* d_xyz, const float* d_min, const float* d_max, const uint8_t* d_usable, const float* d_sf, int nlevels,
+                         uint8_t* d_valid, float* d_u, float* d_v, int32_t* d_level);
 void launch_project(hipStream_t s, int mode, const uvo_camera_pose& cam, int n, const float* d_xyz, const float* d_normal, const float* d_min,
                     const float* d_max, const float* d_max_raw, const uint8_t* d_usable, const float* d_sf, int nlevels, float log_sf, float cos_limit, uint8_t* d_valid,
                     float* d_u, float* d_v, int32_t* d_level, float* d_cos);
@@ -444,6 +448,146 @@ int uvo_project_points(uvo_matcher* m, int mode, const uvo_camera_pose* cam, int
   UVO_HIP_CHECK(hipMemcpyAsync(level, d_level, (size_t)npts * 4, hipMemcpyDeviceToHost, s));
   if (view_cos) UVO_HIP_CHECK(hipMemcpyAsync(view_cos, d_cos, (size_t)npts * 4, hipMemcpyDeviceToHost, s));
   UVO_HIP_CHECK(hipStreamSynchronize(s));
+  return UVO_OK;
+}
+
+// src/ORBmatcher.cc:299-303 (= :1145-1149).  cv::Mat::dot accumulates the three products in double; `sRcw / scw` is
+// convertTo(alpha = 1./scw), whose 32F kernel multiplies by (float)alpha; `-Rcw.t() * tcw` is gemm(GEMM_1_T, alpha = -1): general
+// path, double accumulation.
+int uvo_sim3_decompose(const float* scw_mat, int row_stride, uvo_camera_pose* cam) {
+  if (!scw_mat || !cam || row_stride < 4) return matcher_fail(UVO_E_BADARG, "null pointer / row_stride < 4");
+  double dot = 0.0;
+  for (int k = 0; k < 3; ++k) dot += (double)scw_mat[k] * (double)scw_mat[k];
+  const float scw = (float)std::sqrt(dot);
+  if (!(scw > 0.f)) return matcher_fail(UVO_E_BADARG, "Scw has a zero first row");
+  const float inv = (float)(1.0 / (double)scw);
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) cam->rcw[3 * i + j] = scw_mat[i * row_stride + j] * inv;
+    cam->tcw[i] = scw_mat[i * row_stride + 3] * inv;
+  }
+  for (int c = 0; c < 3; ++c) {
+    double acc = 0.0;
+    for (int k = 0; k < 3; ++k) acc += (double)cam->rcw[3 * k + c] * (double)cam->tcw[k];
+    cam->ow[c] = (float)(acc * -1.0);
+  }
+  return UVO_OK;
+}
+
+// src/ORBmatcher.cc:1284-1287: `s12*R12` and `(1.0/s12)*R12.t()` are convertTo with (float)alpha; `-sR21*t12` is the small-matrix
+// gemm: fp32 row sum, times alpha = -1 in double
+int uvo_sim3_relative(float s12, const float* r12, const float* t12, float* s_r12, float* s_r21, float* t21) {
+  if (!r12 || !t12 || !s_r12 || !s_r21 || !t21) return matcher_fail(UVO_E_BADARG, "null pointer");
+  if (!(s12 > 0.f)) return matcher_fail(UVO_E_BADARG, "s12 must be positive");
+  for (int i = 0; i < 9; ++i) s_r12[i] = r12[i] * s12;
+  const float inv = (float)(1.0 / (double)s12);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) s_r21[3 * i + j] = r12[3 * j + i] * inv;
+  for (int i = 0; i < 3; ++i) {
+    const float t0 = s_r21[3 * i] * t12[0] + s_r21[3 * i + 1] * t12[1] + s_r21[3 * i + 2] * t12[2];
+    t21[i] = (float)((double)t0 * -1.0);
+  }
+  return UVO_OK;
+}
+
+int uvo_project_sim3(uvo_matcher* m, const float* r_own, const float* t_own, const float* s_r, const float* t, const uvo_camera_pose* cam_other,
+                     int npts, const float* xyz, const float* min_distance_inv, const float* max_distance_inv, const uint8_t* usable,
+                     const float* scale_factors, int nlevels, uint8_t* valid, float* u, float* v, int32_t* level) {
+  if (!m || !r_own || !t_own || !s_r || !t || !cam_other) return matcher_fail(UVO_E_BADARG, "null pointer");
+  if (npts < 0 || nlevels < 1 || nlevels > 64) return matcher_fail(UVO_E_BADARG, "bad sizes");
+  if (npts == 0) return UVO_OK;
+  if (!xyz || !min_distance_inv || !max_distance_inv || !scale_factors || !valid || !u || !v || !level)
+    return matcher_fail(UVO_E_BADARG, "null pointer");
+  UVO_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  float *d_xyz, *d_min, *d_max, *d_sf, *d_u;
+  uint8_t *d_usable = nullptr, *d_valid;
+  RC(upload(m, S_QX, xyz, (size_t)npts * 3, &d_xyz));
+  RC(upload(m, S_QR, min_distance_inv, (size_t)npts, &d_min));
+  RC(upload(m, S_QANGLE, max_distance_inv, (size_t)npts, &d_max));
+  if (usable) RC(upload(m, S_QVALID, usable, (size_t)npts, &d_usable));
+  RC(upload(m, S_TANGLE, scale_factors, (size_t)nlevels, &d_sf));
+  RC(reserve(m, S_MATCH, (size_t)npts * 3, &d_u));  // u, v, level
+  RC(reserve(m, S_BLOCKED, (size_t)npts, &d_valid));
+  float* d_v = d_u + npts;
+  int32_t* d_level = reinterpret_cast<int32_t*>(d_u + 2 * (size_t)npts);
+  launch_project_sim3(s, r_own, t_own, s_r, t, *cam_other, npts, d_xyz, d_min, d_max, d_usable, d_sf, nlevels, d_valid, d_u, d_v, d_level);
+  UVO_HIP_CHECK(hipGetLastError());
+  UVO_HIP_CHECK(hipMemcpyAsync(valid, d_valid, (size_t)npts, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(u, d_u, (size_t)npts * 4, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(v, d_v, (size_t)npts * 4, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(level, d_level, (size_t)npts * 4, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipStreamSynchronize(s));
+  return UVO_OK;
+}
+
+int uvo_search_by_projection_sim3(uvo_matcher* m, const uvo_keypoint* kp, int n, const uint8_t* desc, int min_x, int min_y, int max_x, int max_y,
+                                  int32_t* matched, int nmp, const float* u, const float* v, const int32_t* level, const uint8_t* valid,
+                                  const uint8_t* mp_desc, const float* scale_factors, int nlevels, int th, int* n_matches) {
+  if (!m || !n_matches) return matcher_fail(UVO_E_BADARG, "null pointer");
+  *n_matches = 0;
+  if (n < 0 || nmp < 0 || nlevels < 1) return matcher_fail(UVO_E_BADARG, "bad sizes");
+  if (n == 0 || nmp == 0) return UVO_OK;
+  if (!matched || !u || !v || !level || !valid || !mp_desc || !scale_factors) return matcher_fail(UVO_E_BADARG, "null pointer");
+  std::vector<float> r(nmp, 0.f);
+  std::vector<int32_t> lo(nmp, 0), hi(nmp, 0), match(nmp, -1);
+  std::vector<uint8_t> blocked(n);
+  for (int i = 0; i < nmp; ++i) {
+    if (!valid[i]) continue;
+    if (level[i] < 0 || level[i] >= nlevels) return matcher_fail(UVO_E_BADARG, "map point level outside 0..nlevels-1");
+    r[i] = th * scale_factors[level[i]];      // :357 (int th promoted to float)
+    lo[i] = level[i] - 1, hi[i] = level[i];   // :377
+  }
+  for (int k = 0; k < n; ++k) blocked[k] = matched[k] >= 0;  // :372
+  uvo_match_rule rule{UVO_RULE_BEST_ONLY, 50 /* TH_LOW :41 */, 0.f, 1, 0};
+  int rc = uvo_match_windows(m, kp, n, desc, blocked.data(), min_x, min_y, max_x, max_y, nmp, u, v, r.data(), lo.data(), hi.data(), valid, mp_desc,
+                             nullptr, &rule, match.data(), nullptr, n_matches);
+  if (rc) return rc;
+  for (int i = 0; i < nmp; ++i)
+    if (match[i] >= 0) matched[match[i]] = i;
+  return UVO_OK;
+}
+
+int uvo_search_by_sim3(uvo_matcher* m, const uvo_keypoint* kp1, int n1, const uint8_t* desc1, const int32_t* bounds1, const uvo_keypoint* kp2,
+                       int n2, const uint8_t* desc2, const int32_t* bounds2, const float* u12, const float* v12, const int32_t* level12,
+                       const uint8_t* valid12, const uint8_t* mp_desc1, const float* u21, const float* v21, const int32_t* level21,
+                       const uint8_t* valid21, const uint8_t* mp_desc2, const float* scale_factors1, int nlevels1, const float* scale_factors2,
+                       int nlevels2, float th, int32_t* match12, int* n_found) {
+  if (!m || !n_found) return matcher_fail(UVO_E_BADARG, "null pointer");
+  *n_found = 0;
+  if (n1 < 0 || n2 < 0 || nlevels1 < 1 || nlevels2 < 1) return matcher_fail(UVO_E_BADARG, "bad sizes");
+  if (n1 == 0) return UVO_OK;
+  if (!match12) return matcher_fail(UVO_E_BADARG, "null pointer");
+  for (int i = 0; i < n1; ++i) match12[i] = -1;
+  if (n2 == 0) return UVO_OK;
+  if (!bounds1 || !bounds2 || !u12 || !v12 || !level12 || !valid12 || !mp_desc1 || !u21 || !v21 || !level21 || !valid21 || !mp_desc2 ||
+      !scale_factors1 || !scale_factors2)
+    return matcher_fail(UVO_E_BADARG, "null pointer");
+  // one direction: queries = the projected map points, targets = the other key frame's key points (:1361-1394 / :1443-1476)
+  auto direction = [&](const uvo_keypoint* kp, int n, const uint8_t* desc, const int32_t* b, int nq, const float* u, const float* v,
+                       const int32_t* level, const uint8_t* valid, const uint8_t* qdesc, const float* sf, int nl, std::vector<int32_t>& out) -> int {
+    std::vector<float> r(nq, 0.f);
+    std::vector<int32_t> lo(nq, 0), hi(nq, 0);
+    for (int i = 0; i < nq; ++i) {
+      if (!valid[i]) continue;
+      if (level[i] < 0 || level[i] >= nl) return matcher_fail(UVO_E_BADARG, "map point level outside 0..nlevels-1");
+      r[i] = th * sf[level[i]];
+      lo[i] = level[i] - 1, hi[i] = level[i];
+    }
+    out.assign(nq, -1);
+    uvo_match_rule rule{UVO_RULE_BEST_ONLY, 100 /* TH_HIGH :40 */, 0.f, 0, 0};
+    int nm = 0;
+    return uvo_match_windows(m, kp, n, desc, nullptr, b[0], b[1], b[2], b[3], nq, u, v, r.data(), lo.data(), hi.data(), valid, qdesc, nullptr, &rule,
+                             out.data(), nullptr, &nm);
+  };
+  std::vector<int32_t> vnMatch1, vnMatch2;
+  RC(direction(kp2, n2, desc2, bounds2, n1, u12, v12, level12, valid12, mp_desc1, scale_factors2, nlevels2, vnMatch1));
+  RC(direction(kp1, n1, desc1, bounds1, n2, u21, v21, level21, valid21, mp_desc2, scale_factors1, nlevels1, vnMatch2));
+  int found = 0;
+  for (int i1 = 0; i1 < n1; ++i1) {  // :1479-1494
+    const int idx2 = vnMatch1[i1];
+    if (idx2 >= 0 && vnMatch2[idx2] == i1) match12[i1] = idx2, ++found;
+  }
+  *n_found = found;
   return UVO_OK;
 }
 
