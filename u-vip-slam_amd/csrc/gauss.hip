@@ -18,6 +18,8 @@
 namespace uvo {
 
 constexpr int GS_COLS = 248;  // useful columns per wavefront strip
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 pk(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
 
 // Row pass for the lane's 4 pixels with the packed-byte dot product (v_dot4_u32_u8): pixel k needs window bytes
 // k+1 .. k+7 of [L C R]; they are fetched as two byte-aligned dwords (v_alignbyte) and multiplied with the taps packed as
@@ -63,6 +65,9 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
   const int X = 8 + strip * GS_COLS + lane * 4;
   const int Xc = X > g.pitch - 4 ? g.pitch - 4 : X;  // clamp loads into the row (only halo / out-of-region lanes)
   const bool lane_out = lane >= 1 && lane <= 62 && X >= 12 && X < g.w + 20;
+  uint32_t inmask = 0;  // bytes of the lane's dword that lie inside the image columns
+#pragma unroll
+  for (int k = 0; k < 4; ++k) inmask |= (X + k >= kPad && X + k < g.w + kPad) ? 0xffu << (8 * k) : 0u;
   // padded-plane rows: region rows [12, h+20); segment rows [py0, py1)
   const int py0 = 12 + seg * rows_per_seg;
   const int py1 = min(py0 + rows_per_seg, g.h + 20);
@@ -105,17 +110,20 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
           const int* r6 = hring[u];
           const uint32_t centre = cring[(u + 4) % 7];
           const bool row_in = py >= kPad && py < g.h + kPad;
-          uint32_t out = 0;
+          // column pass; (s + 2^15) >> 16 is the upper half of the sum, so two pixels' results are picked into one dword with a
+          // byte permute, clamped to 255 as a 16-bit pair, and the four bytes gathered with a second permute
+          uint32_t sum[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int s = __mul24(taps.x, r0[k] + r6[k]) + __mul24(taps.y, r1[k] + r5[k]) + __mul24(taps.z, r2[k] + r4[k]) + __mul24(taps.w, r3[k]);
-            int v = (s + (1 << 15)) >> 16;
-            v = v > 255 ? 255 : v;
-            const int px = X + k;
-            const bool inside = row_in && px >= kPad && px < g.w + kPad;
-            v = inside ? v : (int)((centre >> (8 * k)) & 0xff);  // pad ring: un-blurred copy
-            out |= (uint32_t)v << (8 * k);
-          }
+          for (int k = 0; k < 4; ++k)
+            sum[k] = (uint32_t)(__mul24(taps.x, r0[k] + r6[k]) + __mul24(taps.y, r1[k] + r5[k]) + __mul24(taps.z, r2[k] + r4[k]) +
+                                __mul24(taps.w, r3[k]) + (1 << 15));
+          const u16x2 lim = {255, 255};
+          const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(pk(__builtin_amdgcn_perm(sum[1], sum[0], 0x07060302u)), lim));
+          const uint32_t p23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(pk(__builtin_amdgcn_perm(sum[3], sum[2], 0x07060302u)), lim));
+          const uint32_t blurred = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
+          // pad ring and anything outside the image: the un-blurred centre pixel (byte mask per lane, rows uniform)
+          const uint32_t m = row_in ? inmask : 0u;
+          const uint32_t out = (blurred & m) | (centre & ~m);
           if (lane_out) *reinterpret_cast<uint32_t*>(dst + (int64_t)py * g.pitch + X) = out;
         }
       }
