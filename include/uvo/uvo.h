@@ -359,6 +359,22 @@ int uvo_project_points(uvo_matcher* m, int mode, const uvo_camera_pose* cam, int
                        int32_t* level, float* view_cos);
 
 /*
+ * Tracking::SearchReferencePointsInFrustum (src/Tracking.cc:2176-2230) as one call: FrameKTL::isInFrustum(pMP, viewing_cos_limit) on
+ * every local map point (UVO_PROJECT_FRUSTUM above), then SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th) (:49-125) on the
+ * points in view -- same results as uvo_project_points followed by uvo_search_by_projection, but the inputs travel as one block,
+ * the projections stay on the device and the host waits once.  Frame side: kp / desc / assigned as in uvo_search_by_projection; the
+ * grid bounds are cam->min_x .. max_y.  Map side: as in uvo_project_points, plus the representative descriptors mp_desc[npts][32].
+ *   usable[i]  : 0 for points the caller's loop skips (:2207-2210: seen in this frame already, or bad); NULL = all usable
+ *   in_view, proj_x, proj_y, level, view_cos : optional outputs = mbTrackInView, mTrackProjX/Y, mnTrackScaleLevel, mTrackViewCos
+ *   *n_to_match = number of points in view (nToMatch; the reference skips the search when it is 0 -- so does this call, in effect)
+ */
+int uvo_search_points_in_frustum(uvo_matcher* m, const uvo_keypoint* kp, int n, const uint8_t* desc, int32_t* assigned, const uvo_camera_pose* cam,
+                                 int npts, const float* xyz, const float* normal, const float* min_distance_inv, const float* max_distance_inv,
+                                 const float* max_distance, const uint8_t* usable, const uint8_t* mp_desc, const float* scale_factors, int nlevels,
+                                 float scale_factor, float viewing_cos_limit, float th, float nnratio, uint8_t* in_view, float* proj_x,
+                                 float* proj_y, int32_t* level, float* view_cos, int* n_to_match, int* n_matches);
+
+/*
  * Loop-closing (Sim3) forms of the search loops.
  *
  * uvo_sim3_decompose: the head of SearchByProjection(pKF, Scw, ...) src/ORBmatcher.cc:299-303 and Fuse(pKF, Scw, ...) :1145-1149:

@@ -670,6 +670,30 @@ def test_frustum_then_search_by_projection_chain(uvo, oracle, synth):
     nm_o = oracle.search_by_projection(kp, de, bounds, a_o, ou, ovv, ol, ovc, ov, mp_desc, sf, 1.0, 0.8)
     np.testing.assert_array_equal(a_g, a_o)
     assert nm_g == nm_o and nm_g > 300 and ov.sum() > 3000
+    # the same as one call (uvo_search_points_in_frustum): projections stay on the device
+    for th in (1.0, 5.0):
+        usable = None if th == 1.0 else (rng.random(M) < 0.8).astype(np.uint8)
+        a_f = np.where(rng.random(n) < 0.1, 9000, -1).astype(np.int32) if th == 5.0 else np.full(n, -1, np.int32)
+        a_r = a_f.copy()
+        nm_f, iv, fu, fv, fl, fc = m.SearchPointsInFrustum(kp, de, a_f, cam, xyz, nrm, mnd, mxd, usable, mp_desc, sf, 1.2, 0.5, th, want_projections=True)
+        ov, ou, ovv, ol, ovc = oracle.project_points(0, cam_o, xyz, nrm, mnd, mxd, usable, sf, 1.2, 0.5)
+        nm_r = oracle.search_by_projection(kp, de, bounds, a_r, ou, ovv, ol, ovc, ov, mp_desc, sf, th, 0.8)
+        np.testing.assert_array_equal(iv, ov)
+        for g, r in ((fu, ou), (fv, ovv), (fc, ovc)):
+            np.testing.assert_array_equal(g.view(np.uint32), r.view(np.uint32))
+        np.testing.assert_array_equal(fl, ol)
+        np.testing.assert_array_equal(a_f, a_r)
+        assert nm_f == nm_r
+    # a matcher that has never sized its candidate buffer, dense windows (th = 40): the truncated first run must be repeated
+    m2 = uvo.ORBmatcher(0.8, max_query=4096, max_map_points=8192)
+    a_f = np.full(n, -1, np.int32)
+    a_r = a_f.copy()
+    nm_f, iv = m2.SearchPointsInFrustum(kp, de, a_f, cam, xyz, nrm, mnd, mxd, None, mp_desc, sf, 1.2, 0.5, 40.0)
+    ov, ou, ovv, ol, ovc = oracle.project_points(0, cam_o, xyz, nrm, mnd, mxd, None, sf, 1.2, 0.5)
+    nm_r = oracle.search_by_projection(kp, de, bounds, a_r, ou, ovv, ol, ovc, ov, mp_desc, sf, 40.0, 0.8)
+    np.testing.assert_array_equal(a_f, a_r)
+    assert nm_f == nm_r
+    m2.close()
     m.close()
 
 

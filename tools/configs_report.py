@@ -68,21 +68,31 @@ def main():
     flip = rng.random((M, 256)) < 0.06
     mp_desc = np.packbits(np.unpackbits(mp_desc, axis=1) ^ flip, axis=1)
     cam = uvo.CameraPose.make(R, t, Ow, fx, fy, cx, cy, (0, 0, W, H))
-    def frame():
+    def frame_two_calls():
         k, d_ = ex(img)
         valid, u, v, level, vc = m.project_points(uvo.PROJECT_FRUSTUM, cam, xyz, nrm, mnd, mxd, None, sf, 1.2, 0.5)
         a = np.full(len(k), -1, np.int32)
         return m.SearchByProjection(k, d_, (0, 0, W, H), a, u, v, level, vc, valid, mp_desc, sf, 1.0)
-    for _ in range(5):
-        nm = frame()
-    ts = []
-    for _ in range(50):
-        t0 = time.perf_counter()
-        nm = frame()
-        ts.append(time.perf_counter() - t0)
-    ts = np.array(ts) * 1e3
-    out["configs[4]: 752x480 extract + isInFrustum + SearchByProjection vs 5000 map points (host buffers in/out)"] = {
-        "ms_per_frame_median": round(float(np.median(ts)), 3), "ms_p95": round(float(np.percentile(ts, 95)), 3), "matches": int(nm), "keypoints": int(n)}
+
+    def frame_fused():
+        k, d_ = ex(img)
+        a = np.full(len(k), -1, np.int32)
+        return m.SearchPointsInFrustum(k, d_, a, cam, xyz, nrm, mnd, mxd, None, mp_desc, sf, 1.2, 0.5, 1.0)[0]
+    res = {}
+    for name, frame in (("two_calls", frame_two_calls), ("fused", frame_fused)):
+        for _ in range(5):
+            nm = frame()
+        ts = []
+        for _ in range(50):
+            t0 = time.perf_counter()
+            nm = frame()
+            ts.append(time.perf_counter() - t0)
+        ts = np.array(ts) * 1e3
+        res[name] = {"ms_per_frame_median": round(float(np.median(ts)), 3), "ms_p95": round(float(np.percentile(ts, 95)), 3), "matches": int(nm)}
+    assert res["two_calls"]["matches"] == res["fused"]["matches"]
+    res["keypoints"] = int(n)
+    res["note"] = "fused = uvo_search_points_in_frustum (Tracking::SearchReferencePointsInFrustum as one call); two_calls = uvo_project_points + uvo_search_by_projection"
+    out["configs[4]: 752x480 extract + isInFrustum + SearchByProjection vs 5000 map points (host buffers in/out)"] = res
     print(json.dumps(out, indent=1))
 
 

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
-    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_sim3_decompose", "uvo_sim3_relative", "uvo_project_sim3", "uvo_search_by_projection_sim3", "uvo_search_by_sim3", "uvo_haloc_hash", "uvo_klt_create", "uvo_klt_destroy", "uvo_klt_build_pyramid", "uvo_klt_read_level", "uvo_klt_track", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
+    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_search_points_in_frustum", "uvo_sim3_decompose", "uvo_sim3_relative", "uvo_project_sim3", "uvo_search_by_projection_sim3", "uvo_search_by_sim3", "uvo_haloc_hash", "uvo_klt_create", "uvo_klt_destroy", "uvo_klt_build_pyramid", "uvo_klt_read_level", "uvo_klt_track", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
     "uvo_matcher_kernel_times", "uvo_last_error", "uvo_device_info",
 ]
 
@@ -164,6 +164,7 @@ def _load():
     lib.uvo_klt_read_level.argtypes = [vp, ci, ci, vp, vp, vp, vp]
     lib.uvo_klt_track.argtypes = [vp, ci, ci, vp, vp, ci, ci, ci, ctypes.c_double, ctypes.c_double, vp, vp]
     lib.uvo_fuse.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, vp, vp]
+    lib.uvo_search_points_in_frustum.argtypes = [vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, cf, vp, vp, vp, vp, vp, vp, vp]
     lib.uvo_sim3_decompose.argtypes = [vp, ci, vp]
     lib.uvo_sim3_relative.argtypes = [cf, vp, vp, vp, vp, vp]
     lib.uvo_project_sim3.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]
@@ -584,6 +585,36 @@ class ORBmatcher:
         if rc:
             raise UvoError(rc, "uvo_haloc_hash")
         return out
+
+    def SearchPointsInFrustum(self, kp, desc, assigned, cam, xyz, normal, min_distance, max_distance, usable, mp_desc, scale_factors,
+                              scale_factor=1.2, viewing_cos_limit=0.5, th=1.0, want_projections=False):
+        """Tracking::SearchReferencePointsInFrustum (src/Tracking.cc:2176-2230) in one call: isInFrustum on every map point, then
+        SearchByProjection on the ones in view.  assigned (int32[n], -1 = free) is updated in place.  Returns (n_matches, in_view) or
+        (n_matches, in_view, u, v, level, view_cos)."""
+        kp = np.ascontiguousarray(kp, KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        assert assigned.dtype == np.int32 and assigned.flags.c_contiguous and len(assigned) == len(kp)
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        nrm = np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+        mx = np.ascontiguousarray(max_distance, np.float32)
+        mn_inv = (np.float32(0.8) * np.ascontiguousarray(min_distance, np.float32)).astype(np.float32)
+        mx_inv = (np.float32(1.2) * mx).astype(np.float32)
+        us = None if usable is None else np.ascontiguousarray(usable, np.uint8)
+        md, sf = np.ascontiguousarray(mp_desc, np.uint8), np.ascontiguousarray(scale_factors, np.float32)
+        n = len(xyz)
+        in_view = np.zeros(n, np.uint8)
+        u = v = lv = vc = None
+        if want_projections:
+            u, v, lv, vc = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros(n, np.float32)
+        ntm, nm = ctypes.c_int(), ctypes.c_int()
+        rc = lib.uvo_search_points_in_frustum(self._h, _ptr(kp), len(kp), _ptr(desc), _ptr(assigned), ctypes.addressof(cam), n, _ptr(xyz), _ptr(nrm),
+                                              _ptr(mn_inv), _ptr(mx_inv), _ptr(mx), _ptr(us), _ptr(md), _ptr(sf), len(sf), float(scale_factor),
+                                              float(viewing_cos_limit), float(th), self.mfNNratio, _ptr(in_view), _ptr(u), _ptr(v), _ptr(lv),
+                                              _ptr(vc), ctypes.byref(ntm), ctypes.byref(nm))
+        if rc:
+            raise UvoError(rc, "uvo_search_points_in_frustum")
+        assert ntm.value == int(in_view.sum())
+        return (nm.value, in_view, u, v, lv, vc) if want_projections else (nm.value, in_view)
 
     @staticmethod
     def sim3_decompose(scw, cam):

@@ -6,13 +6,17 @@
 #include <vector>
 
 #include "matcher_priv.hpp"
+#include "uvo_math.hpp"
 
 namespace uvo {
 void launch_sbp(hipStream_t s, const uvo_keypoint* d_kp, int n, const uint8_t* d_desc, int min_x, int min_y, int max_x, int max_y,
                 int32_t* d_assigned, int nmp, const float* d_px, const float* d_py, const int32_t* d_level, const float* d_vc,
                 const uint8_t* d_inview, const uint8_t* d_mpdesc, const float* d_scale, float th, float nnratio, int32_t* d_cell_start,
                 int32_t* d_cell_items, int32_t* d_cell_of_kp, int32_t* d_cand_cnt, int32_t* d_cand_start, uint32_t* d_cand, int32_t* d_owner,
-                int32_t* d_owner_next, int32_t* d_choice, int32_t* d_n_matches, int stage);
+                int32_t* d_owner_next, int32_t* d_choice, int32_t* d_n_matches, int stage, int64_t cand_cap);
+void launch_project(hipStream_t s, int mode, const uvo_camera_pose& cam, int n, const float* d_xyz, const float* d_normal, const float* d_min,
+                    const float* d_max, const float* d_max_raw, const uint8_t* d_usable, const float* d_sf, int nlevels, float log_sf, float cos_limit,
+                    uint8_t* d_valid, float* d_u, float* d_v, int32_t* d_level, float* d_cos);
 int matcher_fail(int code, const char* msg);
 }  // namespace uvo
 extern "C" hipStream_t uvo_extractor_stream_internal(uvo_extractor* h);
@@ -94,6 +98,8 @@ void uvo_matcher_destroy(uvo_matcher* m) {
     if (p) hipFree(p);
   for (DevBuf& b : m->scratch)
     if (b.p) hipFree(b.p);
+  if (m->d_arena) hipFree(m->d_arena);
+  if (m->h_arena) (void)hipHostFree(m->h_arena);
   m->prof.clear();
   if (m->ev) (void)hipEventDestroy(m->ev);
   if (m->stream) hipStreamDestroy(m->stream);
@@ -241,7 +247,7 @@ int uvo_search_by_projection(uvo_matcher* m, const uvo_keypoint* kp, int n, cons
   auto go = [&](int stage) {
     launch_sbp(s, m->d_kp, n, m->d_q, min_x, min_y, max_x, max_y, m->d_assigned, nmp, m->d_px, m->d_py, m->d_level, m->d_vc, m->d_inview,
                m->d_mpdesc, m->d_scale, th, nnratio, m->d_cell_start, m->d_cell_items, m->d_cell_of_kp, m->d_cand_cnt, m->d_cand_start,
-               m->d_cand, m->d_owner, m->d_owner_next, m->d_choice, m->d_nm, stage);
+               m->d_cand, m->d_owner, m->d_owner_next, m->d_choice, m->d_nm, stage, (int64_t)m->cand_elems);
   };
   go(0);
   UVO_HIP_CHECK(hipGetLastError());
@@ -262,6 +268,144 @@ int uvo_search_by_projection(uvo_matcher* m, const uvo_keypoint* kp, int n, cons
   UVO_HIP_CHECK(hipMemcpyAsync(assigned, m->d_assigned, (size_t)n * 4, hipMemcpyDeviceToHost, s));
   UVO_HIP_CHECK(hipMemcpyAsync(&nm, m->d_nm, 4, hipMemcpyDeviceToHost, s));
   UVO_HIP_CHECK(hipStreamSynchronize(s));
+  *n_matches = nm;
+  return UVO_OK;
+}
+
+// Tracking::SearchReferencePointsInFrustum (src/Tracking.cc:2176-2230) as one call: FrameKTL::isInFrustum on every local map
+// point, then SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th) on the ones in view.  All inputs travel as one packed block
+// through a pinned mirror, the projection results never leave the device, and the host waits once.
+int uvo_search_points_in_frustum(uvo_matcher* m, const uvo_keypoint* kp, int n, const uint8_t* desc, int32_t* assigned, const uvo_camera_pose* cam,
+                                 int npts, const float* xyz, const float* normal, const float* min_distance_inv, const float* max_distance_inv,
+                                 const float* max_distance, const uint8_t* usable, const uint8_t* mp_desc, const float* scale_factors, int nlevels,
+                                 float scale_factor, float viewing_cos_limit, float th, float nnratio, uint8_t* in_view, float* proj_x,
+                                 float* proj_y, int32_t* level, float* view_cos, int* n_to_match, int* n_matches) {
+  if (!m || !n_matches || !cam) return matcher_fail(UVO_E_BADARG, "null pointer");
+  *n_matches = 0;
+  if (n_to_match) *n_to_match = 0;
+  const int min_x = (int)cam->min_x, min_y = (int)cam->min_y, max_x = (int)cam->max_x, max_y = (int)cam->max_y;
+  if (n < 0 || npts < 0 || n > m->cfg.max_query || npts > m->cfg.max_map_points || nlevels < 1 || nlevels > kMaxLevels * 4 || max_x <= min_x ||
+      max_y <= min_y)
+    return matcher_fail(UVO_E_BADARG, "sizes outside handle capacity");
+  if (npts == 0) return UVO_OK;
+  if (!xyz || !normal || !min_distance_inv || !max_distance_inv || !max_distance || !mp_desc || !scale_factors)
+    return matcher_fail(UVO_E_BADARG, "null pointer");
+  if (n > 0 && (!kp || !desc || !assigned)) return matcher_fail(UVO_E_BADARG, "null pointer");
+  if (!(scale_factor > 1.0f)) return matcher_fail(UVO_E_BADARG, "scale_factor must be > 1");
+  UVO_HIP_CHECK(hipSetDevice(m->device));
+  hipStream_t s = m->stream;
+  // ---- packed layout (offsets in bytes, every array 16-byte aligned) ----
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off = (off + bytes + 15) & ~(size_t)15;
+    return o;
+  };
+  const size_t N = (size_t)n, P = (size_t)npts;
+  const size_t o_kp = take(N * sizeof(uvo_keypoint)), o_desc = take(N * 32), o_asg = take(N * 4), o_xyz = take(P * 12), o_nrm = take(P * 12);
+  const size_t o_min = take(P * 4), o_max = take(P * 4), o_raw = take(P * 4), o_use = take(P), o_mpd = take(P * 32), o_sf = take((size_t)nlevels * 4);
+  const size_t in_bytes = off;
+  const size_t o_valid = take(P), o_u = take(P * 4), o_v = take(P * 4), o_lvl = take(P * 4), o_vc = take(P * 4), o_tail = take(16);
+  const size_t total_bytes = off;
+  if (total_bytes > m->arena_bytes) {
+    UVO_HIP_CHECK(hipStreamSynchronize(s));
+    if (m->d_arena) hipFree(m->d_arena);
+    if (m->h_arena) (void)hipHostFree(m->h_arena);
+    m->d_arena = nullptr, m->h_arena = nullptr, m->arena_bytes = 0;
+    const size_t want = total_bytes + total_bytes / 4;
+    int rc = m_alloc(&m->d_arena, want);
+    if (rc) return rc;
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, want, hipHostMallocDefault) != hipSuccess) return matcher_fail(UVO_E_NOMEM, "pinned staging allocation failed");
+    m->h_arena = (uint8_t*)hp, m->arena_bytes = want;
+  }
+  uint8_t *H = m->h_arena, *D = m->d_arena;
+  if (n > 0) {
+    std::memcpy(H + o_kp, kp, N * sizeof(uvo_keypoint));
+    std::memcpy(H + o_desc, desc, N * 32);
+    std::memcpy(H + o_asg, assigned, N * 4);
+  }
+  std::memcpy(H + o_xyz, xyz, P * 12);
+  std::memcpy(H + o_nrm, normal, P * 12);
+  std::memcpy(H + o_min, min_distance_inv, P * 4);
+  std::memcpy(H + o_max, max_distance_inv, P * 4);
+  std::memcpy(H + o_raw, max_distance, P * 4);
+  if (usable)
+    std::memcpy(H + o_use, usable, P);
+  else
+    std::memset(H + o_use, 1, P);
+  std::memcpy(H + o_mpd, mp_desc, P * 32);
+  std::memcpy(H + o_sf, scale_factors, (size_t)nlevels * 4);
+  UVO_HIP_CHECK(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, s));
+  uint8_t* d_valid = D + o_valid;
+  float *d_u = (float*)(D + o_u), *d_v = (float*)(D + o_v), *d_vc = (float*)(D + o_vc);
+  int32_t *d_lvl = (int32_t*)(D + o_lvl), *d_asg = (int32_t*)(D + o_asg), *d_tail = (int32_t*)(D + o_tail);
+  const float* d_sf = (const float*)(D + o_sf);
+  {
+    Profiler::Scope ps(&m->prof, "k_project", s);
+    launch_project(s, UVO_PROJECT_FRUSTUM, *cam, npts, (const float*)(D + o_xyz), (const float*)(D + o_nrm), (const float*)(D + o_min),
+                   (const float*)(D + o_max), (const float*)(D + o_raw), D + o_use, d_sf, nlevels, uvo_logf(scale_factor), viewing_cos_limit, d_valid,
+                   d_u, d_v, d_lvl, d_vc);
+  }
+  int32_t total = 0, nm = 0;
+  UVO_HIP_CHECK(hipGetLastError());
+  if (n > 0) {
+    // candidate lists: sized for 8 per map point up front; a denser frame is detected from the returned total and the match
+    // stage is repeated once with a larger buffer (the kernels never write or read past the capacity they are given)
+    if (m->cand_elems < P * 8) {
+      UVO_HIP_CHECK(hipStreamSynchronize(s));
+      if (m->d_cand) hipFree(m->d_cand);
+      m->d_cand = nullptr, m->cand_elems = 0;
+      int rc = m_alloc(&m->d_cand, P * 8);
+      if (rc) return rc;
+      m->cand_elems = P * 8;
+    }
+    auto go = [&](int stage) {
+      Profiler::Scope ps(&m->prof, stage ? "k_sbp_match" : "k_sbp_count", s);
+      launch_sbp(s, (const uvo_keypoint*)(D + o_kp), n, D + o_desc, min_x, min_y, max_x, max_y, d_asg, npts, d_u, d_v, d_lvl, d_vc, d_valid, D + o_mpd,
+                 d_sf, th, nnratio, m->d_cell_start, m->d_cell_items, m->d_cell_of_kp, m->d_cand_cnt, m->d_cand_start, m->d_cand, m->d_owner,
+                 m->d_owner_next, m->d_choice, m->d_nm, stage, (int64_t)m->cand_elems);
+    };
+    auto fetch = [&]() -> int {
+      UVO_HIP_CHECK(hipGetLastError());
+      UVO_HIP_CHECK(hipMemcpyAsync(H + o_asg, d_asg, N * 4, hipMemcpyDeviceToHost, s));
+      UVO_HIP_CHECK(hipMemcpyAsync(H + o_tail, m->d_cand_start + npts, 4, hipMemcpyDeviceToHost, s));
+      UVO_HIP_CHECK(hipMemcpyAsync(H + o_tail + 4, m->d_nm, 4, hipMemcpyDeviceToHost, s));
+      UVO_HIP_CHECK(hipMemcpyAsync(H + o_valid, d_valid, o_tail - o_valid, hipMemcpyDeviceToHost, s));
+      UVO_HIP_CHECK(hipStreamSynchronize(s));
+      return UVO_OK;
+    };
+    go(0);
+    go(1);
+    int rc = fetch();
+    if (rc) return rc;
+    std::memcpy(&total, H + o_tail, 4);
+    if ((size_t)total > m->cand_elems) {
+      hipFree(m->d_cand);
+      m->d_cand = nullptr, m->cand_elems = 0;
+      const size_t want = (size_t)total + total / 2 + 1024;
+      rc = m_alloc(&m->d_cand, want);
+      if (rc) return rc;
+      m->cand_elems = want;
+      UVO_HIP_CHECK(hipMemcpyAsync(d_asg, assigned, N * 4, hipMemcpyHostToDevice, s));  // undo the truncated run's assignments
+      go(1);
+      rc = fetch();
+      if (rc) return rc;
+    }
+    std::memcpy(&nm, H + o_tail + 4, 4);
+    std::memcpy(assigned, H + o_asg, N * 4);
+  } else {
+    UVO_HIP_CHECK(hipMemcpyAsync(H + o_valid, d_valid, o_tail - o_valid, hipMemcpyDeviceToHost, s));
+    UVO_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  int to_match = 0;
+  for (size_t i = 0; i < P; ++i) to_match += H[o_valid + i] != 0;
+  if (n_to_match) *n_to_match = to_match;
+  if (in_view) std::memcpy(in_view, H + o_valid, P);
+  if (proj_x) std::memcpy(proj_x, H + o_u, P * 4);
+  if (proj_y) std::memcpy(proj_y, H + o_v, P * 4);
+  if (level) std::memcpy(level, H + o_lvl, P * 4);
+  if (view_cos) std::memcpy(view_cos, H + o_vc, P * 4);
   *n_matches = nm;
   return UVO_OK;
 }

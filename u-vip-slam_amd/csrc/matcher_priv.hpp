@@ -34,6 +34,9 @@ struct uvo_matcher {
   size_t md_rows = 0, md_points = 0;
   hipEvent_t ev = nullptr;
   DevBuf scratch[24];  // matcher_search.cpp staging, see the slot enum there
+  // uvo_search_points_in_frustum: one packed input block (pinned host mirror -> device arena, one copy each way)
+  uint8_t *d_arena = nullptr, *h_arena = nullptr;
+  size_t arena_bytes = 0;
   uvo::Profiler prof;
 };
 

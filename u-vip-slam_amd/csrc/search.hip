@@ -132,7 +132,7 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void k_sbp_cand(SbpFrame F, SbpMap M, const int32_t* __restrict__ cell_start,
                                                   const int32_t* __restrict__ cell_items, const float* __restrict__ scale_factors, float th,
                                                   int32_t* __restrict__ cand_cnt, const int32_t* __restrict__ cand_start,
-                                                  uint32_t* __restrict__ cand) {
+                                                  uint32_t* __restrict__ cand, int64_t cand_cap) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M.n) return;
   int n = 0;
@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void k_sbp_cand(SbpFrame F, SbpMap M, const in
             if (fabsf(kp.x - x) > r || fabsf(kp.y - y) > r) continue;
             if (FILL) {
               const int d = hamming256(M.desc + (int64_t)i * 32, F.desc + (int64_t)idx * 32);
-              cand[o + n] = (uint32_t)idx | ((uint32_t)d << 16) | ((uint32_t)(kp.octave & 63) << 25);
+              // a list that outgrows the buffer is dropped here and the host repeats the stage with a larger one
+              if ((int64_t)o + n < cand_cap) cand[o + n] = (uint32_t)idx | ((uint32_t)d << 16) | ((uint32_t)(kp.octave & 63) << 25);
             }
             ++n;
           }
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(1024) void k_scan_i32(const int32_t* __restrict__ i
 }
 
 __global__ __launch_bounds__(1024) void k_sbp_resolve(int nkp, int nmp, const int32_t* __restrict__ cand_start, const uint32_t* __restrict__ cand,
-                                                      float nnratio, int32_t* __restrict__ assigned, int32_t* __restrict__ owner,
+                                                      int64_t cand_cap, float nnratio, int32_t* __restrict__ assigned, int32_t* __restrict__ owner,
                                                       int32_t* __restrict__ owner_next, int32_t* __restrict__ choice,
                                                       int32_t* __restrict__ n_matches) {
   __shared__ int s_changed, s_count;
@@ -206,7 +207,8 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve(int nkp, int nmp, const in
     __syncthreads();
     for (int i = threadIdx.x; i < nmp; i += blockDim.x) {
       int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-      for (int c = cand_start[i]; c < cand_start[i + 1]; ++c) {
+      const int c_end = (int)min((int64_t)cand_start[i + 1], cand_cap);
+      for (int c = cand_start[i]; c < c_end; ++c) {
         const uint32_t v = cand[c];
         const int idx = (int)(v & 0xffffu);
         if (owner[idx] < i) continue;  // taken before this map point's turn
@@ -259,20 +261,20 @@ void launch_sbp(hipStream_t s, const uvo_keypoint* d_kp, int n, const uint8_t* d
                 int32_t* d_assigned, int nmp, const float* d_px, const float* d_py, const int32_t* d_level, const float* d_vc,
                 const uint8_t* d_inview, const uint8_t* d_mpdesc, const float* d_scale, float th, float nnratio, int32_t* d_cell_start,
                 int32_t* d_cell_items, int32_t* d_cell_of_kp, int32_t* d_cand_cnt, int32_t* d_cand_start, uint32_t* d_cand, int32_t* d_owner,
-                int32_t* d_owner_next, int32_t* d_choice, int32_t* d_n_matches, int stage) {
+                int32_t* d_owner_next, int32_t* d_choice, int32_t* d_n_matches, int stage, int64_t cand_cap) {
   SbpFrame F{d_kp, d_desc, n, min_x, min_y, (float)GR_COLS / (float)(max_x - min_x), (float)GR_ROWS / (float)(max_y - min_y)};
   SbpMap M{d_px, d_py, d_level, d_vc, d_inview, d_mpdesc, nmp};
   const int blocks = (nmp + 255) / 256;
   if (stage == 0) {
     hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, s, F, d_cell_start, d_cell_items, d_cell_of_kp);
     hipLaunchKernelGGL(k_sbp_cand<false>, dim3(blocks), dim3(256), 0, s, F, M, d_cell_start, d_cell_items, d_scale, th, d_cand_cnt,
-                       (const int32_t*)nullptr, (uint32_t*)nullptr);
+                       (const int32_t*)nullptr, (uint32_t*)nullptr, (int64_t)0);
     hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, s, d_cand_cnt, d_cand_start, nmp);
   } else {
     hipLaunchKernelGGL(k_sbp_cand<true>, dim3(blocks), dim3(256), 0, s, F, M, d_cell_start, d_cell_items, d_scale, th, d_cand_cnt, d_cand_start,
-                       d_cand);
-    hipLaunchKernelGGL(k_sbp_resolve, dim3(1), dim3(1024), 0, s, n, nmp, d_cand_start, d_cand, nnratio, d_assigned, d_owner, d_owner_next,
-                       d_choice, d_n_matches);
+                       d_cand, cand_cap);
+    hipLaunchKernelGGL(k_sbp_resolve, dim3(1), dim3(1024), 0, s, n, nmp, d_cand_start, d_cand, cand_cap, nnratio, d_assigned, d_owner,
+                       d_owner_next, d_choice, d_n_matches);
   }
 }
 
