@@ -141,34 +141,44 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
   const uint8_t* rows8 = reinterpret_cast<const uint8_t*>(rows32);
   // work item (one per wavefront) -> (level, strip, segment); window = padded cols [32, w) x rows [32, h)
   const int item = blockIdx.x * 4 + wv;
-  int level, X0, py0;
-  if (!fast_region(L, item, level, X0, py0)) return;
+  int level, X0, py0, nsub;
+  if (!fast_region(L, item, level, X0, py0, nsub)) return;
   const FastLevel g = L.l[level];
   const int f = blockIdx.y;
   const int64_t region_id = (int64_t)f * L.items_per_frame + item;
   uint32_t* region = cor + region_id * (int64_t)FS_REGION_ENTRIES;
   int ncorner = 0;
   const uint8_t* src = pyr + f * pyr_block + g.plane_off;
-  const int X = X0 + lane * 4;  // padded column of the lane's first pixel; lanes 0 and 63 are the strip halo
+  // nsub sub-strips side by side (1: the whole wavefront; 2 / 4: 32 / 16 lanes each, consecutive row segments of one narrow strip).
+  // Everything that depends on the row is kept relative to the sub-strip's own first row, so the loop below stays uniform.
+  const int lps = 64 / nsub;                 // lanes per sub-strip
+  const int sub = (lane * nsub) >> 6, ls = lane - sub * lps;
+  const int sub_px = 4 * lps;                // pixels a sub-strip spans, halo lanes included
+  const int py0l = py0 + sub * L.rows_per_seg;
+  const int nrows_l = max(min(py0l + L.rows_per_seg, g.h) - py0l, 0);  // 0: this sub-strip lies below the level
+  const int X = X0 + ls * 4;  // padded column of the lane's first pixel; the first and last lane of a sub-strip are its halo
   const int Xc = X > g.pitch - 4 ? g.pitch - 4 : X;
-  const int py1 = min(py0 + L.rows_per_seg, g.h);
-  const int nrows = py1 - py0;
+  const int nrows = min(py0 + L.rows_per_seg, g.h) - py0;  // sub-strip 0 has the most rows
   const int nsrc = nrows + 8;  // centre rows py0-1 .. py1 need source rows py0-4 .. py1+3
   int qn = 0;                  // wavefront-uniform queue length
-  int qoldest = 0;             // centre row of the oldest queued pixel (valid while qn > 0)
-  const int lm = lane > 0 ? lane - 1 : 0, lp = lane < 63 ? lane + 1 : 63;
-  // pixel K of the lane is screened when it lies in the region or its one-pixel halo (xl in [3, 252]) and in the detection window
+  int qoldest = 0;             // loop index of the oldest queued pixel's row (valid while qn > 0)
+  const int lm = ls > 0 ? lane - 1 : lane, lp = ls < lps - 1 ? lane + 1 : lane;
+  // pixel K of the lane is screened when it lies in the sub-strip or its one-pixel halo and in the detection window
   bool okv[4];
 #pragma unroll
   for (int K = 0; K < 4; ++K) {
-    const int xl = lane * 4 + K;
-    okv[K] = xl >= 3 && xl <= FS_COLS + 4 && X + K >= 32 && X + K < g.w;
+    const int xs = ls * 4 + K;
+    okv[K] = nrows_l > 0 && xs >= 3 && xs <= sub_px - 4 && X + K >= 32 && X + K < g.w;
   }
   const bool ok0 = okv[0], ok1 = okv[1], ok2 = okv[2], ok3 = okv[3];
   const uint32_t t_even = (uint32_t)t_min * 0x00010001u, t_odd = t_even << 8;
 
   // Row loads run one unrolled block (7 rows) ahead of their use so that a wavefront never waits on the row it needs next.
-  auto load_row = [&](int j) -> uint32_t { return *reinterpret_cast<const uint32_t*>(src + (int64_t)(py0 - 4 + j) * g.pitch + Xc); };
+  const int last_row = g.h + 15;  // last row of the padded plane
+  auto load_row = [&](int j) -> uint32_t {
+    const int r = min(py0l - 4 + j, last_row);  // rows past the plane belong to a sub-strip below the level: never used
+    return *reinterpret_cast<const uint32_t*>(src + (int64_t)r * g.pitch + Xc);
+  };
   const uint32_t lane_entry = (uint32_t)(lane * 4) * ((1u << 13) + 1u);
   uint32_t Cr[7], nxt[7];
 #pragma unroll
@@ -183,24 +193,26 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
     for (int u = 0; u < 7; ++u) {
       const int j = base + u;
       if (j < nsrc) {
-        const int prow = py0 - 4 + j;
         const uint32_t C = cur[u];
         Cr[u] = C;
-        const int slot = prow & (FR_ROWS - 1);
+        const int slot = j & (FR_ROWS - 1);  // ring slots follow the loop index: the same for every sub-strip
         rows32[slot * FR_PITCH + lane] = C;
         if (slot < FR_MIRROR) rows32[(slot + FR_ROWS) * FR_PITCH + lane] = C;
         if (j >= 6) {
-          const int pc = prow - 3;  // centre row; rows pc-3 .. pc+3 sit in register slots (u+1)%7 .. u
-          if (pc >= 32 && pc < g.h) {
+          const int jc = j - 3;           // loop index of the centre row; rows jc-3 .. jc+3 sit in register slots (u+1)%7 .. u
+          const int rrp = j - 6;          // centre row relative to the sub-strip: 0 = halo row above, nrows + 1 = halo row below
+          const int pcl = py0l - 1 + rrp;  // the lane's centre row in the padded plane
+          const bool row_ok = pcl >= 32 && pcl < g.h && rrp <= nrows_l + 1;
+          {
             const int sm3 = (u + 1) % 7, sm2 = (u + 2) % 7, s0 = (u + 4) % 7, sp2 = (u + 6) % 7, sp3 = u;
             const uint32_t Cc = Cr[s0], Cu = Cr[sm3], Cd = Cr[sp3], C2 = Cr[sp2], Cm2 = Cr[sm2];
-            // neighbour dwords of rows pc, pc+2, pc-2 from the LDS row ring (written by this wavefront, in order)
-            const uint32_t* rc = rows32 + (pc & (FR_ROWS - 1)) * FR_PITCH;
-            const uint32_t* r2 = rows32 + ((pc + 2) & (FR_ROWS - 1)) * FR_PITCH;
-            const uint32_t* rm = rows32 + ((pc - 2) & (FR_ROWS - 1)) * FR_PITCH;
+            // neighbour dwords of the centre row and of the rows two above / below it from the LDS row ring (written by this wavefront, in order)
+            const uint32_t* rc = rows32 + (jc & (FR_ROWS - 1)) * FR_PITCH;
+            const uint32_t* r2 = rows32 + ((jc + 2) & (FR_ROWS - 1)) * FR_PITCH;
+            const uint32_t* rm = rows32 + ((jc - 2) & (FR_ROWS - 1)) * FR_PITCH;
             const uint32_t Lc = rc[lm], Rc = rc[lp], L2 = r2[lm], R2 = r2[lp], Lm2 = rm[lm], Rm2 = rm[lp];
-            const int cslot = (pc & (FR_ROWS - 1)) < 3 ? (pc & (FR_ROWS - 1)) + FR_ROWS : (pc & (FR_ROWS - 1));
-            const uint32_t row_entry = (uint32_t)(cslot * (FR_PITCH * 4)) | ((uint32_t)(pc - py0 + 1) << 21);
+            const int cslot = (jc & (FR_ROWS - 1)) < 3 ? (jc & (FR_ROWS - 1)) + FR_ROWS : (jc & (FR_ROWS - 1));
+            const uint32_t row_entry = (uint32_t)(cslot * (FR_PITCH * 4)) | ((uint32_t)rrp << 21);
             // ---- screen the lane's 4 pixels with four opposite ring pairs, queue the ones that pass ----
             // Packed 16-bit arithmetic, two pixels per instruction: the even bytes of a pixel dword sit in the two 16-bit
             // halves as they are (x & 0x00ff00ff), the odd bytes scaled by 256 (x & 0xff00ff00); all compares are unsigned.
@@ -216,10 +228,10 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
             const uint32_t ro = screen2(Cc, Cd, Cu, P4, P12, P2, P10, P6, P14, t_odd);
 #define UVO_FAST_PUSH(K, COND)                                                                                    \
   {                                                                                                               \
-    const bool pass = (COND) & ok##K;                                                                             \
+    const bool pass = (COND) & ok##K & row_ok;                                                                    \
     const uint64_t m = __ballot(pass);                                                                            \
     if (m) {                                                                                                      \
-      if (qn == 0) qoldest = pc;                                                                                  \
+      if (qn == 0) qoldest = jc;                                                                                  \
       if (pass)                                                                                                   \
         q[qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = \
             lane_entry + (row_entry + (uint32_t)K * ((1u << 13) + 1u));                                           \
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
             qn -= 64;
             fast_score_chunk(q, rows8, qn, 64, lane, t_min, region, ncorner);
           }
-          if (qn > 0 && pc - qoldest >= FR_MAXAGE) {
+          if (qn > 0 && jc - qoldest >= FR_MAXAGE) {
             fast_score_chunk(q, rows8, 0, qn, lane, t_min, region, ncorner);
             qn = 0;
           }
@@ -257,10 +269,14 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
     bool keep = false;
     uint32_t out = 0;
     const int xl = (int)(e & 0xff), rrp = (int)((e >> 8) & 0xff), ss = (int)(e >> 16);
-    const bool owned = valid && xl >= 4 && xl < FS_COLS + 4 && rrp >= 1 && rrp <= nrows;  // not a halo-ring corner
+    // the sub-strip the corner belongs to: columns [es * sub_px, (es + 1) * sub_px) of the tile, rows of segment es
+    const int es = (xl * nsub) >> 8;
+    const int xs = xl - es * sub_px, py0e = py0 + es * L.rows_per_seg;
+    const int nrows_e = min(py0e + L.rows_per_seg, g.h) - py0e;
+    const bool owned = valid && xs >= 4 && xs < sub_px - 4 && rrp >= 1 && rrp <= nrows_e;  // not a halo-ring corner
     if (owned) {
       // coordinates relative to (minBorder, minBorder), as the candidate list wants them
-      const int xr = X0 + xl - kPad - kMinBorder, yr = py0 + rrp - 1 - kPad - kMinBorder;
+      const int xr = X0 + xs - kPad - kMinBorder, yr = py0e + rrp - 1 - kPad - kMinBorder;
       int cj = (int)__umulhi((uint32_t)(xr - 3), g.inv_wcell), ci = (int)__umulhi((uint32_t)(yr - 3), g.inv_hcell);  // (xr-3)/wCell, (yr-3)/hCell
       cj = cj > g.nCols - 1 ? g.nCols - 1 : cj;
       ci = ci > g.nRows - 1 ? g.nRows - 1 : ci;
@@ -321,7 +337,11 @@ int fast_rows_per_seg(int batch) {
 }
 int fast_items_per_frame(const Geom& g, int rows_per_seg) {
   int items = 0;
-  for (int l = 0; l < g.nlevels; ++l) items += ((g.lv[l].w - 32 + FS_COLS - 1) / FS_COLS) * ((g.lv[l].h - 32 + rows_per_seg - 1) / rows_per_seg);
+  for (int l = 0; l < g.nlevels; ++l) {
+    FastLevel F;
+    fast_strip_plan(g.lv[l].w - 32, g.lv[l].h - 32, rows_per_seg, F);
+    items += F.items;
+  }
   return items;
 }
 int64_t fast_region_entries(int rows_per_seg) {
@@ -340,7 +360,7 @@ FastLevels fast_levels(const Geom& g, int batch) {
   L.rows_per_seg = fast_rows_per_seg(batch);
   L.items_per_frame = fast_items_per_frame(g, L.rows_per_seg);
   L.flags_per_frame = fast_flags_per_frame(g);
-  int fb = 0;
+  int fb = 0, first = 0;
   for (int l = 0; l < kMaxLevels; ++l) {
     FastLevel& F = L.l[l];
     if (l < g.nlevels) {
@@ -350,6 +370,9 @@ FastLevels fast_levels(const Geom& g, int batch) {
       F.flag_base = fb;
       F.inv_wcell = (uint32_t)((0x100000000ull + G.wCell - 1) / G.wCell), F.inv_hcell = (uint32_t)((0x100000000ull + G.hCell - 1) / G.hCell);
       fb += G.nRows * G.nCols;
+      fast_strip_plan(G.w - 32, G.h - 32, L.rows_per_seg, F);
+      F.first_item = first;
+      first += F.items;
     } else {
       F = FastLevel{};
       F.w = F.h = 32;

@@ -17,24 +17,62 @@ struct FastLevel {  // per-level values of the sparse stages, passed in the kern
   int flag_base;  // first entry of this level in the per-frame cell-flag array (full nRows x nCols grid)
   int pad;
   uint32_t inv_wcell, inv_hcell;  // ceil(2^32 / wCell), ceil(2^32 / hCell): n / cell = umulhi(n, inv) for the coordinate range
+  // strips of the detection window (see fast_strip_plan): nfull wavefront-wide strips of FS_COLS columns, then up to two narrow ones
+  // in which a wavefront walks `sub[k]` row segments side by side (32 or 16 lanes each)
+  int nfull, nseg, items, first_item;
+  int sub[2], x0[2];
 };
 struct FastLevels {
   FastLevel l[kMaxLevels];
   int nlevels, rows_per_seg, items_per_frame, flags_per_frame;
 };
 
-// region id -> (level, strip, segment); false when the wavefront has no region
+// Strip plan of one level.  A wavefront is 64 lanes x 4 pixels wide; a level's window is rarely a multiple of the 248 useful
+// columns, and a wavefront that owns a 5-pixel remainder costs as much as a full one.  So the remainder is cut into narrow strips
+// of at most 120 (two segments side by side, 32 lanes each) or 56 columns (four segments, 16 lanes each); a remainder wider than
+// 176 columns stays one ordinary strip.  Columns owned by a sub-strip of L lanes: 4 L - 8 (its first and last lane are halo).
+inline __host__ __device__ int fast_sub_cols(int sub) { return 256 / sub - 8; }
+inline __host__ __device__ void fast_strip_plan(int window_w, int window_h, int rows_per_seg, FastLevel& F) {
+  F.nseg = (window_h + rows_per_seg - 1) / rows_per_seg;
+  F.nfull = window_w / FS_COLS;
+  int rem = window_w - F.nfull * FS_COLS, x = F.nfull * FS_COLS;
+  F.sub[0] = F.sub[1] = 0, F.x0[0] = F.x0[1] = 0;
+  if (rem > fast_sub_cols(2) + fast_sub_cols(4)) {
+    F.nfull += 1;
+    rem = 0;
+  }
+  for (int k = 0; k < 2 && rem > 0; ++k) {
+    F.sub[k] = rem > fast_sub_cols(4) ? 2 : 4;
+    F.x0[k] = x;
+    x += fast_sub_cols(F.sub[k]);
+    rem -= fast_sub_cols(F.sub[k]);
+  }
+  F.items = F.nfull * F.nseg;
+  for (int k = 0; k < 2; ++k)
+    if (F.sub[k]) F.items += (F.nseg + F.sub[k] - 1) / F.sub[k];
+}
+
+// region id -> (level, first padded column, first padded row of sub-strip 0, sub-strips); false when the wavefront has no region
 #ifdef __HIPCC__
-__device__ __forceinline__ bool fast_region(const FastLevels& L, int item, int& level, int& X0, int& py0) {
+__device__ __forceinline__ bool fast_region(const FastLevels& L, int item, int& level, int& X0, int& py0, int& sub) {
   for (level = 0; level < L.nlevels; ++level) {
-    const int nstrip = (L.l[level].w - 32 + FS_COLS - 1) / FS_COLS;
-    const int nseg = (L.l[level].h - 32 + L.rows_per_seg - 1) / L.rows_per_seg;
-    if (item < nstrip * nseg) {
-      X0 = 28 + (item % nstrip) * FS_COLS;
-      py0 = 32 + (item / nstrip) * L.rows_per_seg;
+    const FastLevel& F = L.l[level];
+    if (item < F.items) {
+      int strip_x, seg;
+      if (item < F.nfull * F.nseg) {
+        strip_x = (item % F.nfull) * FS_COLS, seg = item / F.nfull, sub = 1;
+      } else {
+        item -= F.nfull * F.nseg;
+        const int n0 = F.sub[0] ? (F.nseg + F.sub[0] - 1) / F.sub[0] : 0;
+        const int k = item < n0 ? 0 : 1;
+        if (k) item -= n0;
+        sub = F.sub[k], strip_x = F.x0[k], seg = item * sub;
+      }
+      X0 = 28 + strip_x;
+      py0 = 32 + seg * L.rows_per_seg;
       return true;
     }
-    item -= nstrip * nseg;
+    item -= F.items;
   }
   return false;
 }

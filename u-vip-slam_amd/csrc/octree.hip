@@ -66,11 +66,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
   // (FAST(cell, fastTh); if empty FAST(cell, 7): src/ORBextractor.cc:792-799), gathered by the workgroup itself ----
   __shared__ int s_pcount;
   {
-    int first = 0;
-    for (int l = 0; l < level; ++l)
-      first += ((FL.l[l].w - 32 + FS_COLS - 1) / FS_COLS) * ((FL.l[l].h - 32 + FL.rows_per_seg - 1) / FL.rows_per_seg);
     const FastLevel fg = FL.l[level];
-    const int n_items = ((fg.w - 32 + FS_COLS - 1) / FS_COLS) * ((fg.h - 32 + FL.rows_per_seg - 1) / FL.rows_per_seg);
+    const int first = fg.first_item, n_items = fg.items;
     if (threadIdx.x == 0) s_pcount = 0;
     __syncthreads();
     const uint8_t* hi = cell_hi + (int64_t)f * FL.flags_per_frame + fg.flag_base;
