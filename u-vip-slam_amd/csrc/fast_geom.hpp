@@ -32,7 +32,8 @@ struct FastLevels {
 // of at most 120 (two segments side by side, 32 lanes each) or 56 columns (four segments, 16 lanes each); a remainder wider than
 // 176 columns stays one ordinary strip.  Columns owned by a sub-strip of L lanes: 4 L - 8 (its first and last lane are halo).
 inline __host__ __device__ int fast_sub_cols(int sub) { return 256 / sub - 8; }
-inline __host__ __device__ void fast_strip_plan(int window_w, int window_h, int rows_per_seg, FastLevel& F) {
+template <class PlanT>
+inline __host__ __device__ void fast_strip_plan(int window_w, int window_h, int rows_per_seg, PlanT& F) {
   F.nseg = (window_h + rows_per_seg - 1) / rows_per_seg;
   F.nfull = window_w / FS_COLS;
   int rem = window_w - F.nfull * FS_COLS, x = F.nfull * FS_COLS;
@@ -52,6 +53,24 @@ inline __host__ __device__ void fast_strip_plan(int window_w, int window_h, int 
     if (F.sub[k]) F.items += (F.nseg + F.sub[k] - 1) / F.sub[k];
 }
 
+// item of a planned level -> (first window column of the strip, first segment, sub-strips)
+template <class PlanT>
+inline __host__ __device__ void fast_strip_item(const PlanT& F, int item, int& strip_x, int& seg, int& sub) {
+  if (item < F.nfull * F.nseg) {
+    strip_x = (item % F.nfull) * FS_COLS, seg = item / F.nfull, sub = 1;
+  } else {
+    item -= F.nfull * F.nseg;
+    const int n0 = F.sub[0] ? (F.nseg + F.sub[0] - 1) / F.sub[0] : 0;
+    const int k = item < n0 ? 0 : 1;
+    if (k) item -= n0;
+    sub = F.sub[k], strip_x = F.x0[k], seg = item * sub;
+  }
+}
+struct StripPlan {
+  int nfull, nseg, items;
+  int sub[2], x0[2];
+};
+
 // region id -> (level, first padded column, first padded row of sub-strip 0, sub-strips); false when the wavefront has no region
 #ifdef __HIPCC__
 __device__ __forceinline__ bool fast_region(const FastLevels& L, int item, int& level, int& X0, int& py0, int& sub) {
@@ -59,15 +78,7 @@ __device__ __forceinline__ bool fast_region(const FastLevels& L, int item, int& 
     const FastLevel& F = L.l[level];
     if (item < F.items) {
       int strip_x, seg;
-      if (item < F.nfull * F.nseg) {
-        strip_x = (item % F.nfull) * FS_COLS, seg = item / F.nfull, sub = 1;
-      } else {
-        item -= F.nfull * F.nseg;
-        const int n0 = F.sub[0] ? (F.nseg + F.sub[0] - 1) / F.sub[0] : 0;
-        const int k = item < n0 ? 0 : 1;
-        if (k) item -= n0;
-        sub = F.sub[k], strip_x = F.x0[k], seg = item * sub;
-      }
+      fast_strip_item(F, item, strip_x, seg, sub);
       X0 = 28 + strip_x;
       py0 = 32 + seg * L.rows_per_seg;
       return true;

@@ -14,10 +14,11 @@
 // a register ring (the loop is unrolled by 7 so ring slots are compile-time); the column pass then emits one dword.
 // Every byte of a level is loaded once per strip segment (+6 halo rows per GS_ROWS) and written once.
 #include "common.hpp"
+#include "fast_geom.hpp"
 
 namespace uvo {
 
-constexpr int GS_COLS = 248;  // useful columns per wavefront strip
+constexpr int GS_COLS = FS_COLS;  // useful columns per wavefront strip (the strip plan of fast_geom.hpp is shared)
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 pk(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
 
@@ -44,34 +45,38 @@ __device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t 
 
 __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int64_t pyr_block,
                                                 const LevelGeom* __restrict__ lv, int nlevels, int4 taps, int rows_per_seg) {
-  // work item (one per wavefront) -> (level, strip, segment)
+  // work item (one per wavefront) -> (level, strip, segment group); narrow remainder strips hold 2 or 4 row segments side by side
+  // (fast_strip_plan), so a level costs about as many wavefront-rows as its width needs
   int item = blockIdx.x * 4 + wave_in_block();
   const int lane = threadIdx.x & 63;
-  int level = 0, nstrip = 0, nseg = 0;
+  int level = 0;
+  StripPlan plan;
   for (;; ++level) {
-    nstrip = (lv[level].w + 8 + GS_COLS - 1) / GS_COLS;
-    nseg = (lv[level].h + 8 + rows_per_seg - 1) / rows_per_seg;
-    if (item < nstrip * nseg) break;
-    item -= nstrip * nseg;
+    fast_strip_plan(lv[level].w + 8, lv[level].h + 8, rows_per_seg, plan);
+    if (item < plan.items) break;
+    item -= plan.items;
     if (level == nlevels - 1) return;
   }
   const LevelGeom g = lv[level];
   const int f = blockIdx.y;
-  const int strip = item % nstrip, seg = item / nstrip;
+  int strip_x, seg, nsub;
+  fast_strip_item(plan, item, strip_x, seg, nsub);
   const uint8_t* src = pyr + f * pyr_block + g.plane_off;
   uint8_t* dst = blur + f * pyr_block + g.plane_off;
 
-  // padded-plane column of this lane's dword; lane 0 is the left halo of the strip.  Region = padded cols [12, w+20).
-  const int X = 8 + strip * GS_COLS + lane * 4;
+  const int lps = 64 / nsub, sub = (lane * nsub) >> 6, ls = lane - sub * lps;
+  // padded-plane column of this lane's dword; the first lane of a sub-strip is its left halo.  Region = padded cols [12, w+20).
+  const int X = 8 + strip_x + ls * 4;
   const int Xc = X > g.pitch - 4 ? g.pitch - 4 : X;  // clamp loads into the row (only halo / out-of-region lanes)
-  const bool lane_out = lane >= 1 && lane <= 62 && X >= 12 && X < g.w + 20;
+  // padded-plane rows: region rows [12, h+20); the lane's segment rows [py0l, py1l)
+  const int py0 = 12 + seg * rows_per_seg;
+  const int py0l = py0 + sub * rows_per_seg;
+  const int py1l = min(py0l + rows_per_seg, g.h + 20);
+  const bool lane_out = ls >= 1 && ls <= lps - 2 && X >= 12 && X < g.w + 20 && py1l > py0l;
   uint32_t inmask = 0;  // bytes of the lane's dword that lie inside the image columns
 #pragma unroll
   for (int k = 0; k < 4; ++k) inmask |= (X + k >= kPad && X + k < g.w + kPad) ? 0xffu << (8 * k) : 0u;
-  // padded-plane rows: region rows [12, h+20); segment rows [py0, py1)
-  const int py0 = 12 + seg * rows_per_seg;
-  const int py1 = min(py0 + rows_per_seg, g.h + 20);
-  const int nsrc = py1 - py0 + 6;  // source rows py0-3 .. py1+2
+  const int nsrc = min(py0 + rows_per_seg, g.h + 20) - py0 + 6;  // source rows py0-3 .. py1+2 of sub-strip 0 (the longest)
 
   const uint32_t T1 = (uint32_t)taps.x | ((uint32_t)taps.y << 8) | ((uint32_t)taps.z << 16) | ((uint32_t)taps.w << 24);
   const uint32_t T2 = (uint32_t)taps.z | ((uint32_t)taps.y << 8) | ((uint32_t)taps.x << 16);
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
   // Row loads are issued one unrolled block (7 rows) ahead of their use: a wavefront walks ~70 rows one after another, so
   // without the prefetch every row would expose a full memory round trip.
   auto load_row = [&](int j) -> uint32_t {
-    int prow = py0 - 3 + j;
+    int prow = py0l - 3 + j;
     prow = prow > g.ph - 1 ? g.ph - 1 : prow;  // rows past the plane are never used by a valid output
     return *reinterpret_cast<const uint32_t*>(src + (int64_t)prow * g.pitch + Xc);
   };
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
         gauss_row_pass(L, C, R, T1, T2, hring[u]);
         cring[u] = C;
         if (j >= 6) {
-          const int py = py0 + j - 6;  // output row; its 7 source rows sit in ring slots (u+1)%7 .. (u+7)%7
+          const int py = py0l + j - 6;  // output row; its 7 source rows sit in ring slots (u+1)%7 .. (u+7)%7
           const int* r0 = hring[(u + 1) % 7];
           const int* r1 = hring[(u + 2) % 7];
           const int* r2 = hring[(u + 3) % 7];
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
           // pad ring and anything outside the image: the un-blurred centre pixel (byte mask per lane, rows uniform)
           const uint32_t m = row_in ? inmask : 0u;
           const uint32_t out = (blurred & m) | (centre & ~m);
-          if (lane_out) *reinterpret_cast<uint32_t*>(dst + (int64_t)py * g.pitch + X) = out;
+          if (lane_out && py < py1l) *reinterpret_cast<uint32_t*>(dst + (int64_t)py * g.pitch + X) = out;
         }
       }
     }
@@ -138,7 +143,11 @@ void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t
   // fewer, longer segments when the batch already fills the chip (6 halo rows are re-read per segment)
   const int rows_per_seg = batch >= 16 ? 64 : 16;
   int items = 0;
-  for (int l = 0; l < g.nlevels; ++l) items += ((g.lv[l].w + 8 + GS_COLS - 1) / GS_COLS) * ((g.lv[l].h + 8 + rows_per_seg - 1) / rows_per_seg);
+  for (int l = 0; l < g.nlevels; ++l) {
+    StripPlan plan;
+    fast_strip_plan(g.lv[l].w + 8, g.lv[l].h + 8, rows_per_seg, plan);
+    items += plan.items;
+  }
   hipLaunchKernelGGL(k_gauss7, dim3((items + 3) / 4, batch), dim3(256), 0, s, d_pyr, d_blur, pyr_block, d_lv, g.nlevels, taps, rows_per_seg);
 }
 
