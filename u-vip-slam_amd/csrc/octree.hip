@@ -36,7 +36,7 @@ static inline size_t oct_lds_bytes(int M, int Mp2) {
   b += (size_t)8 * M * 2;                   // boxA, boxB
   b += (size_t)4 * M * 7;                   // cntA, cntB, procRank, nodeOfRank, baseOfRank, outKey, outPt
   b += (size_t)4 * Mp2;                     // sortbuf
-  b += (size_t)4 * (2 * OCT_THREADS + 16);  // part, sc
+  b += (size_t)4 * (32 + 16);               // part (one partial per wavefront on the device), sc
   return b;
 }
 
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
   w.outKey = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mmax;
   w.outPt = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mmax;
   w.sortbuf = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mp2max;
-  w.part = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * 2 * OCT_THREADS;
+  w.part = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * 32;
   w.sc = reinterpret_cast<int*>(p), p += (size_t)4 * 16;
 
   const int64_t so = (int64_t)f * sel_block + g.sel_off;
