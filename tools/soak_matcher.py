@@ -81,6 +81,38 @@ def main():
         fa, fb = m.FuseSearch(kp, de, bounds, u, v, lvl, valid, mpd, sf, th), o.fuse_search(kp, de, bounds, u, v, lvl, valid, mpd, sf, th)
         if not (np.array_equal(fa[0], fb[0]) and np.array_equal(fa[1], fb[1])):
             what.append("fuse")
+        # loop-closing forms: exclusive projection search, and (further down, with the second set) SearchBySim3
+        a, b = pre.copy(), pre.copy()
+        thi = int(rng.choice([3, 10]))
+        na, nb = m.SearchByProjectionSim3(kp, de, bounds, a, u, v, lvl, valid, mpd, sf, thi), o.search_by_projection_sim3(kp, de, bounds, b, u, v, lvl, valid, mpd, sf, thi)
+        if na != nb or not np.array_equal(a, b):
+            what.append("sbp_sim3")
+        # SearchReferencePointsInFrustum as one call: random pose, points scattered in front of the camera
+        if M:
+            ax = rng.normal(0, 0.1, 3)
+            ang_ = np.linalg.norm(ax)
+            kx = ax / ang_
+            K_ = np.array([[0, -kx[2], kx[1]], [kx[2], 0, -kx[0]], [-kx[1], kx[0], 0]])
+            R = (np.eye(3) + np.sin(ang_) * K_ + (1 - np.cos(ang_)) * K_ @ K_).astype(np.float32)
+            tt = rng.normal(0, 0.3, 3).astype(np.float32)
+            Ow = (-(R.T.astype(np.float64) @ tt.astype(np.float64))).astype(np.float32)
+            fx, fy, cx, cy = 0.6 * w, 0.6 * w, w / 2, h / 2
+            cam = uvo.CameraPose.make(R, tt, Ow, fx, fy, cx, cy, bounds)
+            z = rng.uniform(1, 10, M)
+            pc = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], 1)
+            xyz = ((pc - tt) @ R.astype(np.float64)).astype(np.float32)
+            nrm = xyz - Ow + rng.normal(0, 2.0, (M, 3))
+            nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+            dd = np.linalg.norm(xyz - Ow, axis=1)
+            mxd = (dd * rng.uniform(0.6, 4.0, M)).astype(np.float32)
+            mnd = (mxd / np.float32(rng.uniform(2.0, 5.0))).astype(np.float32)
+            us = None if rng.random() < 0.5 else (rng.random(M) < 0.8).astype(np.uint8)
+            a, b = pre.copy(), pre.copy()
+            nm_a, iv = m.SearchPointsInFrustum(kp, de, a, cam, xyz, nrm, mnd, mxd, us, mpd, sf, 1.2, 0.5, th)
+            pv, pu, pvv, pl, pvc = o.project_points(0, cam.as_array(), xyz, nrm, mnd, mxd, us, sf, 1.2, 0.5)
+            nm_b = o.search_by_projection(kp, de, bounds, b, pu, pvv, pl, pvc, pv, mpd, sf, th, ratio)
+            if nm_a != nm_b or not np.array_equal(a, b) or not np.array_equal(iv, pv):
+                what.append("frustum_fused")
         # BoW searches + triangulation on a second random set
         n2 = int(rng.integers(0, 2000))
         kp2 = rand_kps(rng, n2, w, h, uvo)
@@ -100,6 +132,20 @@ def main():
         tb = o.search_for_triangulation(g1, kp, de, 1 - us1, g2, kp2, de2, 1 - us2, F12, s2, ori)
         if ta[1] != tb[1] or not np.array_equal(ta[0], tb[0]):
             what.append("triang")
+        # SearchBySim3: projections of set 1 into frame 2 and back (random targets near key points of the other frame)
+        if n and n2:
+            def proj(kp_to, cnt):
+                nn_ = rng.integers(0, len(kp_to), cnt)
+                return ((rng.random(cnt) < 0.85).astype(np.uint8), (kp_to["x"][nn_] + rng.normal(0, 3, cnt)).astype(np.float32),
+                        (kp_to["y"][nn_] + rng.normal(0, 3, cnt)).astype(np.float32), rng.integers(0, 8, cnt).astype(np.int32)), nn_
+            p12, i12 = proj(kp2, n)
+            p21, i21 = proj(kp, n2)
+            md1, md2 = noisy(rng, de2[i12], 0.08), noisy(rng, de[i21], 0.08)
+            th3 = float(rng.choice([7.5, 15.0]))
+            sa = m.SearchBySim3(kp, de, bounds, kp2, de2, bounds, p12, md1, p21, md2, sf, sf, th3)
+            sb = o.search_by_sim3(kp, de, bounds, kp2, de2, bounds, p12, md1, p21, md2, sf, sf, th3)
+            if sa[1] != sb[1] or not np.array_equal(sa[0], sb[0]):
+                what.append("sim3")
         # knn-2 and the medoid pick
         if n and n2:
             ka, kb = m.knn2(de[:2000], de2), o.knn2(de[:2000], de2)
