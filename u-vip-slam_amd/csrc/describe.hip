@@ -209,11 +209,14 @@ __global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ 
                                                   const uvo_keypoint* __restrict__ in_kp, int in_cap, const float* __restrict__ pattern,
                                                   const uint32_t* __restrict__ patch, uvo_keypoint* __restrict__ out_kp,
                                                   uint8_t* __restrict__ out_desc, int cap, int32_t* __restrict__ n_out) {
-  const int f = blockIdx.y;
+  // a frame's keypoints stay on one XCD: their 37-row windows overlap heavily (1000 windows cover a level about once), and with
+  // round-robin placement every XCD's L2 would fetch the same lines
+  const int vb = xcd_contiguous((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  const int bx = vb % (int)gridDim.x, f = vb / (int)gridDim.x;
   const int lane = threadIdx.x & 63;
-  const int slot0 = (blockIdx.x * 4 + wave_in_block()) * DK_PER_WAVE;
+  const int slot0 = (bx * 4 + wave_in_block()) * DK_PER_WAVE;
   int n = n_final[f];
-  if (blockIdx.x == 0 && threadIdx.x == 0) n_out[f] = n;
+  if (bx == 0 && threadIdx.x == 0) n_out[f] = n;
   n = n > flist_cap ? flist_cap : n;
   n = n > cap ? cap : n;
   if (slot0 >= n) return;

@@ -140,11 +140,11 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
   uint32_t* q = rows32 + FW_RING_DW;
   const uint8_t* rows8 = reinterpret_cast<const uint8_t*>(rows32);
   // work item (one per wavefront) -> (level, strip, segment); window = padded cols [32, w) x rows [32, h)
-  const int item = blockIdx.x * 4 + wv;
+  const int vb = xcd_contiguous((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  const int item = (vb % (int)gridDim.x) * 4 + wv, f = vb / (int)gridDim.x;  // an XCD walks whole frames, region after region
   int level, X0, py0, nsub;
   if (!fast_region(L, item, level, X0, py0, nsub)) return;
   const FastLevel g = L.l[level];
-  const int f = blockIdx.y;
   const int64_t region_id = (int64_t)f * L.items_per_frame + item;
   uint32_t* region = cor + region_id * (int64_t)FS_REGION_ENTRIES;
   int ncorner = 0;

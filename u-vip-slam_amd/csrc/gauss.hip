@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
                                                 const LevelGeom* __restrict__ lv, int nlevels, int4 taps, int rows_per_seg) {
   // work item (one per wavefront) -> (level, strip, segment group); narrow remainder strips hold 2 or 4 row segments side by side
   // (fast_strip_plan), so a level costs about as many wavefront-rows as its width needs
-  int item = blockIdx.x * 4 + wave_in_block();
+  const int vb = xcd_contiguous((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  const int vbx = vb % (int)gridDim.x, f = vb / (int)gridDim.x;  // an XCD walks whole frames, item after item
+  int item = vbx * 4 + wave_in_block();
   const int lane = threadIdx.x & 63;
   int level = 0;
   StripPlan plan;
@@ -58,7 +60,6 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
     if (level == nlevels - 1) return;
   }
   const LevelGeom g = lv[level];
-  const int f = blockIdx.y;
   int strip_x, seg, nsub;
   fast_strip_item(plan, item, strip_x, seg, nsub);
   const uint8_t* src = pyr + f * pyr_block + g.plane_off;
