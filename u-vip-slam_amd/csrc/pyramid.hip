@@ -30,8 +30,20 @@ __global__ __launch_bounds__(256) void k_pad_level0(const uint8_t* __restrict__ 
   const uint8_t* src = img + f * frame_stride + (int64_t)y * stride;
   const int x0 = qx * 16 - kPad;  // image column of byte 0
   uint4 v;
+  // 16 columns that lie wholly in the left or right pad are a reversed run of 16 image columns (REFLECT_101): four
+  // unaligned dword loads and a byte swap each, instead of sixteen reflected byte gathers that stall the whole wavefront
+  const int r0 = x0 + 16 <= 0 ? -(x0 + 15) : 2 * (w - 1) - x0 - 15;  // first image column of that run
   if (vec_ok && x0 >= 0 && x0 + 16 <= w) {
     v = *reinterpret_cast<const uint4*>(src + x0);
+  } else if ((x0 + 16 <= 0 || x0 >= w) && r0 >= 0 && r0 + 16 <= w) {
+    uint32_t d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t t;
+      __builtin_memcpy(&t, src + r0 + 4 * j, 4);
+      d[3 - j] = __builtin_bswap32(t);
+    }
+    v = make_uint4(d[0], d[1], d[2], d[3]);
   } else {
     uint32_t d[4];
 #pragma unroll
