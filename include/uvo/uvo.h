@@ -159,6 +159,8 @@ int uvo_extractor_read_candidates(uvo_extractor* h, int frame, int level, int32_
  * launches[i]: number of launches.
  */
 int uvo_extractor_profile(uvo_extractor* h, int enable);
+/* restricts the timing to launches of one kernel (name as reported by uvo_extractor_kernel_times; NULL or "" = all kernels) */
+int uvo_extractor_profile_only(uvo_extractor* h, const char* kernel_name);
 int uvo_extractor_kernel_times(uvo_extractor* h, char* names, int names_cap, float* ms, int32_t* launches, int cap, int* n);
 
 /* ------------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ UVO_OK, UVO_E_BADARG, UVO_E_NODEVICE, UVO_E_HIP, UVO_E_CAPACITY, UVO_E_UNSUPPORT
 ABI_SYMBOLS = [
     "uvo_extractor_create", "uvo_extractor_destroy", "uvo_extractor_levels", "uvo_extractor_max_keypoints", "uvo_extractor_scale_factor", "uvo_extractor_tables",
     "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_level_dims",
-    "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_kernel_times",
+    "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_profile_only", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
     "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_search_points_in_frustum", "uvo_sim3_decompose", "uvo_sim3_relative", "uvo_project_sim3", "uvo_search_by_projection_sim3", "uvo_search_by_sim3", "uvo_haloc_hash", "uvo_klt_create", "uvo_klt_destroy", "uvo_klt_build_pyramid", "uvo_klt_read_level", "uvo_klt_track", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
@@ -136,6 +136,7 @@ def _load():
     lib.uvo_extractor_read_plane.argtypes = [vp, ci, ci, ci, vp]
     lib.uvo_extractor_read_candidates.argtypes = [vp, ci, ci, vp, ci, vp]
     lib.uvo_extractor_profile.argtypes = [vp, ci]
+    lib.uvo_extractor_profile_only.argtypes = [vp, ctypes.c_char_p]
     lib.uvo_extractor_kernel_times.argtypes = [vp, ctypes.c_char_p, ci, vp, vp, ci, vp]
     lib.uvo_matcher_create.argtypes = [ctypes.POINTER(MatcherCfg), ctypes.POINTER(vp)]
     lib.uvo_matcher_destroy.argtypes = [vp]
@@ -347,7 +348,9 @@ class ORBextractor:
             raise UvoError(rc, "uvo_extractor_read_candidates")
         return buf[:min(n.value, cap)].copy()
 
-    def profile(self, enable=True):
+    def profile(self, enable=True, only=None):
+        """Per-kernel HIP-event timing; only = a kernel name restricts it to that kernel (two event records per launch cost ~3 %)."""
+        lib.uvo_extractor_profile_only(self._h, only.encode() if only else None)
         lib.uvo_extractor_profile(self._h, 1 if enable else 0)
 
     def kernel_times(self):

@@ -932,6 +932,12 @@ int uvo_extractor_profile(uvo_extractor* h, int enable) {
   return UVO_OK;
 }
 
+int uvo_extractor_profile_only(uvo_extractor* h, const char* kernel_name) {
+  if (!h) return fail(UVO_E_BADARG, "null handle");
+  for (int i = 0; i < kMaxLanes; ++i) h->lane[i].prof.only = kernel_name ? kernel_name : "";
+  return UVO_OK;
+}
+
 int uvo_extractor_kernel_times(uvo_extractor* h, char* names, int names_cap, float* ms, int32_t* launches, int cap, int* n) {
   if (!h || !names || !ms || !launches || !n) return fail(UVO_E_BADARG, "null pointer");
   UVO_HIP_CHECK(hipSetDevice(h->device));

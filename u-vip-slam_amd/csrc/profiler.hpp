@@ -14,7 +14,9 @@ struct Profiler {
     hipEvent_t a, b;
   };
   bool on = false;
+  std::string only;  // when not empty: time launches of this kernel only (two event records per launch are not free)
   std::vector<Rec> recs;
+  bool wants(const char* name) const { return on && (only.empty() || only == name); }
 
   void clear() {
     for (auto& r : recs) {
@@ -27,17 +29,18 @@ struct Profiler {
     Profiler* p;
     hipStream_t s;
     Rec r;
-    Scope(Profiler* p_, const char* name, hipStream_t s_) : p(p_), s(s_) {
+    bool active;
+    Scope(Profiler* p_, const char* name, hipStream_t s_) : p(p_), s(s_), active(p_->wants(name)) {
       r.name = name;
       r.a = r.b = nullptr;
-      if (p->on) {
+      if (active) {
         (void)hipEventCreate(&r.a);
         (void)hipEventCreate(&r.b);
         (void)hipEventRecord(r.a, s);
       }
     }
     ~Scope() {
-      if (p->on) {
+      if (active) {
         (void)hipEventRecord(r.b, s);
         p->recs.push_back(r);
       }
