@@ -119,7 +119,7 @@ int fast_items_per_frame(const Geom& g, int rows_per_seg);
 int64_t fast_region_entries(int rows_per_seg);
 int fast_flags_per_frame(const Geom& g);
 void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, int fast_th, const uint32_t* d_cor, const int32_t* d_cor_n,
-                   const uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate,
+                   uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate,
                    uint32_t* d_sel_xy, uint32_t* d_sel_sc, int32_t* d_sel_count, int batch);
 void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_sel_xy, const uint32_t* d_sel_sc,
                      const int32_t* d_sel_count,

@@ -345,7 +345,6 @@ static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, 
   hipStream_t s = h->lane[h->cur].stream;
   h->last_batch = batch;
   const Geom& g = h->geom;
-  UVO_HIP_CHECK(hipMemsetAsync(h->lane[h->cur].d_cand_count, 0, sizeof(int32_t) * batch * g.nlevels, s));
   {
     ProfScope p(h, "k_pad_level0");
     launch_pad_level0(s, d_imgs, width, height, stride, frame_stride, h->lane[h->cur].d_pyr, g.pyr_block, g.lv[0], batch);
@@ -415,6 +414,8 @@ static int alloc_lane(uvo_extractor* h, int li) {
   AL(dev_alloc(&L.d_cor, h->cap_cor));
   AL(dev_alloc(&L.d_cor_n, h->cap_cor_n));
   AL(dev_alloc(&L.d_cell_hi, h->cap_flags));
+  // the cell flags are zero between calls: k_fast_score sets them, k_octree clears the ones it has consumed
+  if (hipMemset(L.d_cell_hi, 0, h->cap_flags) != hipSuccess) return fail(UVO_E_HIP, "hipMemset failed");
 #undef AL
   return UVO_OK;
 }

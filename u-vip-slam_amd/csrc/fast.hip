@@ -391,7 +391,6 @@ void launch_fast_stage(hipStream_t s, int stage, const uint8_t* d_pyr, uint8_t* 
   const int t_min = fast_th < 7 ? fast_th : 7;
   const FastLevels L = fast_levels(g, batch);
   const dim3 grid((L.items_per_frame + 3) / 4, batch);
-  (void)hipMemsetAsync(d_cell_hi, 0, (size_t)batch * L.flags_per_frame, s);
   hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, s, d_pyr, pyr_block, L, t_min, fast_th, d_cor, d_cor_n, d_cell_hi);
 }
 

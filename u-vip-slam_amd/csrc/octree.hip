@@ -43,7 +43,7 @@ static inline size_t oct_lds_bytes(int M, int Mp2) {
 template <int NT>
 __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max,
                                                         FastLevels FL, int fast_th, const uint32_t* __restrict__ cor,
-                                                        const int32_t* __restrict__ cor_n, const uint8_t* __restrict__ cell_hi,
+                                                        const int32_t* __restrict__ cor_n, uint8_t* cell_hi,
                                                         uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc,
                                                         int64_t cand_block, int32_t* __restrict__ cand_count,
                                                         uint32_t* __restrict__ pstate, uint32_t* __restrict__ sel_xy,
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
     const int first = fg.first_item, n_items = fg.items;
     if (threadIdx.x == 0) s_pcount = 0;
     __syncthreads();
-    const uint8_t* hi = cell_hi + (int64_t)f * FL.flags_per_frame + fg.flag_base;
+    uint8_t* hi = cell_hi + (int64_t)f * FL.flags_per_frame + fg.flag_base;
     // a wavefront takes four regions at a time so that the three dependent loads (count -> entries -> cell flag) are each issued
     // for all four before the first result is needed; one LDS atomic per wavefront and batch reserves the output slots
     const int64_t region0 = (int64_t)f * FL.items_per_frame + first;
@@ -119,6 +119,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
       }
     }
     __syncthreads();
+    // the flags of this (frame, level) have been consumed: leave them zero for the next batch (k_fast_score only ever sets them)
+    for (int i = threadIdx.x; i < fg.nRows * fg.nCols; i += NT) hi[i] = 0;
   }
   int P = s_pcount;
   if (threadIdx.x == 0) cand_count[f * nlevels + level] = P;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
 }
 
 void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, int fast_th, const uint32_t* d_cor, const int32_t* d_cor_n,
-                   const uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
+                   uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
                    int32_t* d_sel_count, int batch) {
   int M = 0;
   for (int l = 0; l < g.nlevels; ++l) {
