@@ -104,6 +104,21 @@ int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int widt
                       int32_t* n_out);
 
 /*
+ * Asynchronous host-buffer form (FullDetect): uvo_extract_batch_submit() enqueues the upload of the frames, the extraction and
+ * the download of the results on the next pipeline lane and returns at once with a ticket (the lane); uvo_extract_batch_wait()
+ * blocks until that lane has finished.  With uvo_extractor_set_pipeline(h, 2) and page-locked buffers (uvo_host_alloc) the
+ * PCIe transfers of one batch overlap the kernels of the other: submit(k+1), wait(k), consume k, ...
+ *   imgs, out_kp, out_desc, n_out must stay valid and untouched until the matching wait returns; a lane must be waited for
+ *   before it is submitted to again (with depth d: at most d batches in flight).
+ *   out_kp / out_desc: [B][cap] / [B][cap][32]; records past n_out[b] are unspecified.  cap must be >= uvo_extractor_max_keypoints().
+ */
+int uvo_host_alloc(void** ptr, size_t bytes);
+int uvo_host_free(void* ptr);
+int uvo_extract_batch_submit(uvo_extractor* h, int batch, const uint8_t* imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
+                             uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int* ticket);
+int uvo_extract_batch_wait(uvo_extractor* h, int ticket);
+
+/*
  * HBM-resident form: every pointer is a device pointer on the handle's GPU and the call only enqueues work
  * on the handle's stream (uvo_extractor_synchronize() waits for it).  Same argument meaning as above.
  * d_n_out[b] may exceed `cap`; only the first `cap` records of a frame are written in that case.

@@ -530,6 +530,38 @@ def test_project_points(uvo, oracle, mode):
     m.close()
 
 
+def test_async_host_form_matches_the_synchronous_one(uvo, synth):
+    """uvo_extract_batch_submit / _wait with two batches in flight (pipeline depth 2, page-locked buffers) against uvo_extract_batch."""
+    W, H, B = 320, 256, 6
+    frames = [np.stack([synth.make_frame(9100 + 10 * k + i, W, H) for i in range(B)]) for k in range(3)]
+    ex = uvo.ORBextractor(500, 1.2, 8, 0, 20, max_width=W, max_height=H, max_batch=B)
+    ref = [ex.extract_batch(f) for f in frames]
+    ex.set_pipeline(2)
+    cap = ex.cap
+    bufs = []
+    for k in range(3):
+        img = uvo.pinned_empty((B, H, W), np.uint8)
+        img[:] = frames[k]
+        bufs.append((img, uvo.pinned_empty((B, cap), uvo.KEYPOINT_DTYPE), uvo.pinned_empty((B, cap, 32), np.uint8), uvo.pinned_empty((B,), np.int32)))
+    t0 = ex.submit(*bufs[0])
+    t1 = ex.submit(*bufs[1])
+    assert t0 != t1
+    with pytest.raises(uvo.UvoError):
+        ex.submit(*bufs[2])                      # both lanes busy
+    ex.wait(t0)
+    t2 = ex.submit(*bufs[2])
+    ex.wait(t1)
+    ex.wait(t2)
+    for k in range(3):
+        _, kp, de, n = bufs[k]
+        for b in range(B):
+            rk, rd = ref[k][b]
+            assert n[b] == len(rk)
+            assert kp[b, :n[b]].tobytes() == rk.tobytes()
+            np.testing.assert_array_equal(de[b, :n[b]], rd)
+    ex.close()
+
+
 def _bits(a):
     a = np.asarray(a)
     return a.view(np.uint32) if a.dtype == np.float32 else a

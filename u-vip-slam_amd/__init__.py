@@ -26,7 +26,7 @@ UVO_OK, UVO_E_BADARG, UVO_E_NODEVICE, UVO_E_HIP, UVO_E_CAPACITY, UVO_E_UNSUPPORT
 # every symbol include/uvo/uvo.h declares
 ABI_SYMBOLS = [
     "uvo_extractor_create", "uvo_extractor_destroy", "uvo_extractor_levels", "uvo_extractor_max_keypoints", "uvo_extractor_scale_factor", "uvo_extractor_tables",
-    "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_level_dims",
+    "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_host_alloc", "uvo_host_free", "uvo_extract_batch_submit", "uvo_extract_batch_wait", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_level_dims",
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_profile_only", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
@@ -127,6 +127,10 @@ def _load():
     lib.uvo_extract.argtypes = [vp, vp, ci, ci, cl, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp]
     lib.uvo_extract_batch.argtypes = [vp, ci, vp, ci, ci, cl, cl, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
     lib.uvo_extract_batch_device.argtypes = [vp, ci, vp, ci, ci, cl, cl, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
+    lib.uvo_host_alloc.argtypes = [vp, ctypes.c_size_t]
+    lib.uvo_host_free.argtypes = [vp]
+    lib.uvo_extract_batch_submit.argtypes = [vp, ci, vp, ci, ci, cl, cl, vp, vp, ci, vp, vp]
+    lib.uvo_extract_batch_wait.argtypes = [vp, ci]
     lib.uvo_extractor_synchronize.argtypes = [vp]
     lib.uvo_extractor_set_pipeline.argtypes = [vp, ci]
     lib.uvo_extractor_level_dims.argtypes = [vp, ci, vp, vp]
@@ -195,6 +199,21 @@ def device_info(device=0):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data
+
+
+def pinned_empty(shape, dtype):
+    """numpy array in page-locked host memory (uvo_host_alloc), for the asynchronous host-buffer form; freed with the array."""
+    import weakref
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    p = ctypes.c_void_p()
+    rc = lib.uvo_host_alloc(ctypes.byref(p), max(n, 1))
+    if rc:
+        raise UvoError(rc, "uvo_host_alloc")
+    buf = (ctypes.c_uint8 * max(n, 1)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+    weakref.finalize(buf, lib.uvo_host_free, p.value)
+    return arr
 
 
 class ORBextractor:
@@ -277,6 +296,27 @@ class ORBextractor:
         if rc:
             raise UvoError(rc, "uvo_extract_batch")
         return [(out_kp[i, :n_out[i]].copy(), out_desc[i, :n_out[i]].copy()) for i in range(b)]
+
+    def submit(self, images, out_kp, out_desc, n_out):
+        """Asynchronous FullDetect extraction of a (B, H, W) uint8 stack into caller arrays out_kp (B, cap) KEYPOINT_DTYPE,
+        out_desc (B, cap, 32) uint8, n_out (B,) int32 -- ideally all from pinned_empty(); returns the ticket for wait()."""
+        assert images.dtype == np.uint8 and images.flags.c_contiguous and images.ndim == 3
+        b, h, w = images.shape
+        cap = out_kp.shape[1]
+        assert out_kp.dtype == KEYPOINT_DTYPE and out_kp.flags.c_contiguous and out_kp.shape[0] >= b
+        assert out_desc.dtype == np.uint8 and out_desc.flags.c_contiguous and out_desc.shape[1:] == (cap, 32)
+        assert n_out.dtype == np.int32 and len(n_out) >= b
+        t = ctypes.c_int()
+        rc = lib.uvo_extract_batch_submit(self._h, b, images.ctypes.data, w, h, w, w * h, out_kp.ctypes.data, out_desc.ctypes.data, cap,
+                                          n_out.ctypes.data, ctypes.byref(t))
+        if rc:
+            raise UvoError(rc, "uvo_extract_batch_submit")
+        return t.value
+
+    def wait(self, ticket):
+        rc = lib.uvo_extract_batch_wait(self._h, int(ticket))
+        if rc:
+            raise UvoError(rc, "uvo_extract_batch_wait")
 
     def extract_batch_device(self, d_imgs, batch, width, height, d_out_kp, d_out_desc, d_n_out, cap=None):
         """HBM-resident FullDetect extraction; all arguments are integer device addresses.  Asynchronous."""

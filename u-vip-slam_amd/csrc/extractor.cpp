@@ -54,6 +54,13 @@ struct Lane {
   uint8_t* d_cell_hi = nullptr;  // per cell: owns an NMS survivor >= fastTh
   FinalSlot* d_flist = nullptr;
   Profiler prof;
+  // staging of the asynchronous host-buffer form (allocated on first use): a lane's frames and results must not be touched by the
+  // other lane's batch
+  uint8_t* a_imgs = nullptr;
+  uvo_keypoint* a_kp = nullptr;
+  uint8_t* a_desc = nullptr;
+  int32_t* a_n = nullptr;
+  int a_batch = 0;  // frames of the batch in flight on this lane (0 = none)
 };
 
 struct uvo_extractor {
@@ -547,7 +554,7 @@ void uvo_extractor_destroy(uvo_extractor* h) {
     if (L.stream) (void)hipStreamSynchronize(L.stream);
     L.prof.clear();
     void* lp[] = {L.d_pyr,   L.d_blur,   L.d_score,      L.d_cand_xy,   L.d_cand_sc, L.d_pstate, L.d_sel_xy, L.d_sel_sc,
-                  L.d_cand_count, L.d_sel_count, L.d_n_final, L.d_cor_n, L.d_cor, L.d_cell_hi, L.d_flist};
+                  L.d_cand_count, L.d_sel_count, L.d_n_final, L.d_cor_n, L.d_cor, L.d_cell_hi, L.d_flist, L.a_imgs, L.a_kp, L.a_desc, L.a_n};
     for (void* p : lp)
       if (p) (void)hipFree(p);
     if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -826,6 +833,70 @@ int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int widt
     }
   }
   return status;
+}
+
+int uvo_host_alloc(void** ptr, size_t bytes) {
+  if (!ptr || bytes == 0) return fail(UVO_E_BADARG, "null pointer / zero size");
+  if (hipHostMalloc(ptr, bytes, hipHostMallocPortable) != hipSuccess) return fail(UVO_E_NOMEM, "page-locked allocation failed");
+  return UVO_OK;
+}
+int uvo_host_free(void* ptr) {
+  if (ptr && hipHostFree(ptr) != hipSuccess) return fail(UVO_E_HIP, "hipHostFree failed");
+  return UVO_OK;
+}
+
+int uvo_extract_batch_submit(uvo_extractor* h, int batch, const uint8_t* imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
+                             uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int* ticket) {
+  if (!h || !imgs || !out_kp || !out_desc || !n_out || !ticket) return fail(UVO_E_BADARG, "null pointer");
+  *ticket = -1;
+  if (batch < 1 || batch > h->cfg.max_batch) return fail(UVO_E_BADARG, "batch outside 1..max_batch");
+  if (width < 1 || height < 1 || width > h->cfg.max_width || height > h->cfg.max_height || stride < width ||
+      (int64_t)width * height > (int64_t)h->cfg.max_width * h->cfg.max_height)
+    return fail(UVO_E_BADARG, "image size outside what the handle was sized for");
+  const int dcap = h->cap_flist;
+  if (cap < dcap) return fail(UVO_E_CAPACITY, "cap must be at least uvo_extractor_max_keypoints()");
+  UVO_HIP_CHECK(hipSetDevice(h->device));
+  int rc = set_geometry(h, width, height);  // before the lane is chosen: a geometry change waits for every lane
+  if (rc) return rc;
+  const int li = h->nlanes > 1 ? (h->cur + 1) % h->nlanes : h->cur;  // the lane run_batch_device() is about to use
+  Lane& L = h->lane[li];
+  if (L.a_batch) return fail(UVO_E_BADARG, "the next lane still has a batch in flight: wait for it first");
+  if (!L.a_imgs) {
+    const size_t B = (size_t)h->cfg.max_batch;
+    if ((rc = dev_alloc(&L.a_imgs, B * (size_t)h->cfg.max_width * h->cfg.max_height)) || (rc = dev_alloc(&L.a_kp, B * dcap)) ||
+        (rc = dev_alloc(&L.a_desc, B * dcap * 32)) || (rc = dev_alloc(&L.a_n, B)))
+      return rc;
+  }
+  hipStream_t s = L.stream;
+  if (stride == width && (batch == 1 || frame_stride == (ptrdiff_t)width * height)) {
+    UVO_HIP_CHECK(hipMemcpyAsync(L.a_imgs, imgs, (size_t)batch * width * height, hipMemcpyHostToDevice, s));
+  } else {
+    for (int b = 0; b < batch; ++b)
+      UVO_HIP_CHECK(hipMemcpy2DAsync(L.a_imgs + (size_t)b * width * height, width, imgs + (size_t)b * frame_stride, stride, width, (size_t)height,
+                                     hipMemcpyHostToDevice, s));
+  }
+  rc = run_batch_device(h, batch, L.a_imgs, width, height, width, (ptrdiff_t)width * height, nullptr, nullptr, nullptr, 0, 0, 0, 1, nullptr, L.a_kp,
+                        L.a_desc, dcap, L.a_n);
+  if (rc) return rc;
+  if (h->cur != li) return fail(UVO_E_HIP, "internal: lane bookkeeping out of step");
+  // results: whole per-frame slices (a frame holds at most dcap records), frame b lands at b * cap of the caller's arrays
+  UVO_HIP_CHECK(hipMemcpyAsync(n_out, L.a_n, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipMemcpy2DAsync(out_kp, (size_t)cap * sizeof(uvo_keypoint), L.a_kp, (size_t)dcap * sizeof(uvo_keypoint),
+                                 (size_t)dcap * sizeof(uvo_keypoint), (size_t)batch, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipMemcpy2DAsync(out_desc, (size_t)cap * 32, L.a_desc, (size_t)dcap * 32, (size_t)dcap * 32, (size_t)batch, hipMemcpyDeviceToHost, s));
+  L.a_batch = batch;
+  *ticket = li;
+  return UVO_OK;
+}
+
+int uvo_extract_batch_wait(uvo_extractor* h, int ticket) {
+  if (!h || ticket < 0 || ticket >= kMaxLanes || !h->lane[ticket].stream) return fail(UVO_E_BADARG, "bad ticket");
+  Lane& L = h->lane[ticket];
+  if (!L.a_batch) return fail(UVO_E_BADARG, "no batch in flight on this lane");
+  UVO_HIP_CHECK(hipSetDevice(h->device));
+  UVO_HIP_CHECK(hipStreamSynchronize(L.stream));
+  L.a_batch = 0;
+  return UVO_OK;
 }
 
 int uvo_extract(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdiff_t stride, const uvo_keypoint* in_kp, int n_in,
