@@ -27,7 +27,8 @@
 
 namespace uvo {
 
-constexpr int FQ_CAP = 320;       // queue entries per wavefront: < 64 left over + <= 256 pushed per row
+constexpr int FQ_CAP = 212;       // queue entries per wavefront: < 64 left over + <= 128 pushed per half row (drained in between); sized so
+                                  // that ring + queue = the NMS tile = 6656 B per wavefront, six workgroups per CU
 
 // max over the 16 arcs of 9 contiguous ring pixels of min(d).  A 9-window always straddles the two 8-pixel halves of the
 // ring, so with running minima towards the end of each half (S) and from the start of each half (P) every arc minimum is
@@ -240,6 +241,10 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
   }
             UVO_FAST_PUSH(0, (re & 0xffffu) != 0u)
             UVO_FAST_PUSH(1, (ro & 0xffffu) != 0u)
+            while (qn >= 64) {  // keeps the queue within FQ_CAP
+              qn -= 64;
+              fast_score_chunk(q, rows8, qn, 64, lane, t_min, region, ncorner);
+            }
             UVO_FAST_PUSH(2, re > 0xffffu)
             UVO_FAST_PUSH(3, ro > 0xffffu)
 #undef UVO_FAST_PUSH
