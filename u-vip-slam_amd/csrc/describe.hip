@@ -15,6 +15,8 @@ namespace uvo {
 //             a point is skipped when its min_px_dist cell of grid_2d is occupied, else accepted and the cell
 //             incremented; per-level cap num_featsneeded*(8-level)/30 with a counter that carries across levels
 //             (:878,:892-897), global cap num_featsneeded (:898-901).  Order dependent -> one thread walks it.
+// TOPUP = false is the FullDetect concatenation alone: no LDS, so its workgroups find room next to the other lane's kernels
+template <bool TOPUP>
 __global__ __launch_bounds__(256) void k_assemble(const LevelGeom* __restrict__ lv, int nlevels, const uint32_t* __restrict__ sel_xy,
                                                   const uint32_t* __restrict__ sel_sc, int sel_block,
                                                   const int32_t* __restrict__ sel_count, const int32_t* __restrict__ n_in, int in_cap,
@@ -26,7 +28,7 @@ __global__ __launch_bounds__(256) void k_assemble(const LevelGeom* __restrict__ 
   const uint32_t* ssc = sel_sc + (int64_t)f * sel_block;
   const int32_t* cnt = sel_count + f * nlevels;
   FinalSlot* out = flist + (int64_t)f * flist_cap;
-  if (full_detect) {
+  if (!TOPUP || full_detect) {
     int base = 0;
     for (int l = 0; l < nlevels; ++l) {
       int n = cnt[l];
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(256) void k_assemble(const LevelGeom* __restrict__ 
     if (threadIdx.x == 0) n_final[f] = base;
     return;
   }
+  if constexpr (TOPUP) {
   // top-up mode
   const int nin = n_in ? min(n_in[f], in_cap) : 0;
   for (int i = threadIdx.x; i < nin; i += blockDim.x) {
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(256) void k_assemble(const LevelGeom* __restrict__ 
     }
     n_final[f] = pos;
   }
+  }  // TOPUP
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -400,8 +404,12 @@ void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const 
                      int grid_cols, int min_px_dist, int full_detect, const int32_t* d_nfn, FinalSlot* d_flist, int32_t* d_n_final,
                      int batch) {
   (void)d_in_kp;
-  hipLaunchKernelGGL(k_assemble, dim3(batch), dim3(256), 0, s, d_lv, g.nlevels, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count, d_n_in, in_cap,
-                     d_grid, grid_rows, grid_cols, min_px_dist, full_detect, d_nfn, d_flist, g.flist_cap, d_n_final);
+  if (full_detect)
+    hipLaunchKernelGGL(k_assemble<false>, dim3(batch), dim3(256), 0, s, d_lv, g.nlevels, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count, d_n_in, in_cap,
+                       d_grid, grid_rows, grid_cols, min_px_dist, full_detect, d_nfn, d_flist, g.flist_cap, d_n_final);
+  else
+    hipLaunchKernelGGL(k_assemble<true>, dim3(batch), dim3(256), 0, s, d_lv, g.nlevels, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count, d_n_in, in_cap,
+                       d_grid, grid_rows, grid_cols, min_px_dist, full_detect, d_nfn, d_flist, g.flist_cap, d_n_final);
 }
 
 void launch_describe(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, const uint8_t* d_blur, int64_t pyr_block,
