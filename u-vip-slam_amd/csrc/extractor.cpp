@@ -303,12 +303,13 @@ static int set_geometry(uvo_extractor* h, int width, int height) {
   if (g.pyr_block > h->cap_pyr_block || g.cand_block > h->cap_cand_block || g.total_cells > h->cap_cells || g.sel_block > h->cap_sel_block ||
       g.flist_cap > h->cap_flist)
     return fail(UVO_E_BADARG, "image larger than the handle was sized for");
-  for (int b : {1, std::min(h->cfg.max_batch, 15), h->cfg.max_batch}) {
+  for (int b = 1; b <= h->cfg.max_batch; b = b < 16 ? b + 1 : h->cfg.max_batch) {
     const int rps = fast_rows_per_seg(b);
     const size_t it = (size_t)fast_items_per_frame(g, rps);
     if ((size_t)b * it * (size_t)fast_region_entries(rps) > h->cap_cor || (size_t)b * it > h->cap_cor_n ||
         (size_t)h->cfg.max_batch * fast_flags_per_frame(g) > h->cap_flags)
       return fail(UVO_E_BADARG, "image larger than the handle was sized for");
+    if (b == h->cfg.max_batch) break;
   }
   std::vector<ResizeCol> ctab;
   std::vector<ResizeRow> rtab;
@@ -490,20 +491,13 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   {
     // corner-list regions: sized for both segment heights the launcher may pick, at the maximum resolution
     size_t ce = 0, cn = 0;
-    for (int b : {1, (int)B}) {
-      if (b > (int)B) continue;
+    // the segment height depends on the batch size (fast_rows_per_seg): size for the worst batch
+    for (int b = 1; b <= (int)B; b = b < 16 ? b + 1 : (int)B) {
       const int rps = fast_rows_per_seg(b);
       const size_t it = (size_t)fast_items_per_frame(g, rps) + 8;
       ce = std::max(ce, (size_t)b * it * (size_t)fast_region_entries(rps));
       cn = std::max(cn, (size_t)b * it);
-    }
-    // the small-batch segment height may be used up to batch 15
-    {
-      const int b = (int)std::min<size_t>(B, 15);
-      const int rps = fast_rows_per_seg(b);
-      const size_t it = (size_t)fast_items_per_frame(g, rps) + 8;
-      ce = std::max(ce, (size_t)b * it * (size_t)fast_region_entries(rps));
-      cn = std::max(cn, (size_t)b * it);
+      if (b == (int)B) break;
     }
     h->cap_cor = ce + ce / 8, h->cap_cor_n = cn + cn / 8 + 64;
     h->cap_flags = (size_t)B * ((size_t)fast_flags_per_frame(g) + fast_flags_per_frame(g) / 8 + 64);

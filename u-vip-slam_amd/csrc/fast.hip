@@ -22,6 +22,7 @@
 //   the per-cell vote (survivors >= fastTh if the cell has any, else the literal-7 fallback) needs every region of a cell to
 //   be finished, so it is taken by the quad-tree kernel when it gathers a level's candidates (octree.hip).  Candidate order
 //   in HBM is arbitrary: the quad-tree orders by coordinates.
+#include <cstdlib>
 #include "common.hpp"
 #include "fast_geom.hpp"
 
@@ -336,9 +337,11 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
 
 // Rows per (strip, segment) work item.  A wavefront lives for the whole item, so long segments leave a long under-filled
 // tail at the end of the launch (96 rows: +20 % kernel time over 24..32), and the NMS tile of a region has to fit its LDS.
+// A single frame has only ~160 items of 24 rows for 1024 SIMDs: short segments (8 rows of work under 8 halo rows) spread it over
+// three times as many wavefronts and halve the time of the launch (UVO_FAST_ROWS_SMALL overrides, for experiments).
 int fast_rows_per_seg(int batch) {
-  (void)batch;
-  return FS_ROWS_MAX;
+  static const int small = getenv("UVO_FAST_ROWS_SMALL") ? atoi(getenv("UVO_FAST_ROWS_SMALL")) : 8;
+  return batch <= 2 ? (small < FS_ROWS_MAX ? small : FS_ROWS_MAX) : FS_ROWS_MAX;
 }
 int fast_items_per_frame(const Geom& g, int rows_per_seg) {
   int items = 0;
