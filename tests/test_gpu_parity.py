@@ -914,7 +914,31 @@ def test_new_entry_points_reject_bad_arguments(uvo):
     ex = uvo.ORBextractor(500, 1.2, 4, 0, 20, max_width=320, max_height=240)
     with pytest.raises(uvo.UvoError):                       # more tiles than pixels
         ex.clahe(np.zeros((240, 320), np.uint8), 4.0, (400, 12))
+    # asynchronous host form: output rows shorter than a frame can need, waiting for nothing
+    img = np.zeros((1, 240, 320), np.uint8)
+    with pytest.raises(uvo.UvoError):
+        ex.submit(img, np.zeros((1, 8), uvo.KEYPOINT_DTYPE), np.zeros((1, 8, 32), np.uint8), np.zeros(1, np.int32))
+    with pytest.raises(uvo.UvoError):
+        ex.wait(0)
+    with pytest.raises(uvo.UvoError):
+        ex.wait(17)
     ex.close()
+    # loop-closing forms and the fused frustum search
+    m = uvo.ORBmatcher(0.8, max_query=64, max_map_points=64)
+    cam = uvo.CameraPose.make(np.eye(3), np.zeros(3), np.zeros(3), 500, 500, 320, 240, (0, 0, 640, 480))
+    with pytest.raises(uvo.UvoError):                       # Scw with a zero rotation block
+        uvo.ORBmatcher.sim3_decompose(np.zeros((4, 4), np.float32), cam)
+    with pytest.raises(uvo.UvoError):                       # non-positive scale
+        uvo.ORBmatcher.sim3_relative(0.0, np.eye(3), np.zeros(3))
+    with pytest.raises(uvo.UvoError):                       # level outside the scale table
+        m.SearchByProjectionSim3(kp, de, (0, 0, 64, 48), np.full(4, -1, np.int32), one, one, [9], [1], de[:1], np.ones(8, np.float32), 3)
+    with pytest.raises(uvo.UvoError):                       # more map points than the handle was sized for
+        m.SearchPointsInFrustum(kp, de, np.full(4, -1, np.int32), cam, np.zeros((100, 3)), np.zeros((100, 3)), np.ones(100), np.ones(100), None,
+                                np.zeros((100, 32), np.uint8), np.ones(8, np.float32))
+    nm, iv = m.SearchPointsInFrustum(kp[:0], de[:0], np.zeros(0, np.int32), cam, [[0, 0, 5.0]], [[0, 0, 1.0]], [2.0], [10.0], None,
+                                     np.zeros((1, 32), np.uint8), (np.float32(1.2) ** np.arange(8)).astype(np.float32))
+    assert nm == 0 and iv.tolist() == [1]                   # no keypoints: the projection still reports the point in view
+    m.close()
 
 
 def test_wide_image_with_few_features(uvo, oracle, synth):
