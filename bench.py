@@ -278,7 +278,7 @@ def main():
                          "note": "k_fast_score (FAST segment test) is integer-VALU bound, not HBM bound (PMC: ~77 lane-ops per pixel, see "
                                  "DESIGN.md section 7); the HBM fraction is reported because the contract asks for it"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(frames)
         print(json.dumps(out))
     if dist is not None:
