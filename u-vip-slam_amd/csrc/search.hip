@@ -146,22 +146,52 @@ __global__ __launch_bounds__(256) void k_sbp_cand(SbpFrame F, SbpMap M, const in
     int x0, x1, y0, y1;
     if (sbp_window(F, x, y, r, x0, x1, y0, y1)) {
       const int o = FILL ? cand_start[i] : 0;
-      for (int ix = x0; ix <= x1; ++ix)
-        for (int iy = y0; iy <= y1; ++iy) {
-          const int c = ix * GR_ROWS + iy;
-          for (int k = cell_start[c]; k < cell_start[c + 1]; ++k) {
-            const int idx = cell_items[k];
-            const uvo_keypoint kp = F.kp[idx];
-            if (kp.octave < minLevel || kp.octave > maxLevel) continue;  // minLevel != maxLevel always here
-            if (fabsf(kp.x - x) > r || fabsf(kp.y - y) > r) continue;
-            if (FILL) {
-              const int d = hamming256(M.desc + (int64_t)i * 32, F.desc + (int64_t)idx * 32);
-              // a list that outgrows the buffer is dropped here and the host repeats the stage with a larger one
-              if ((int64_t)o + n < cand_cap) cand[o + n] = (uint32_t)idx | ((uint32_t)d << 16) | ((uint32_t)(kp.octave & 63) << 25);
+      uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+      if (FILL) {
+        const uint4* Q = reinterpret_cast<const uint4*>(M.desc + (int64_t)i * 32);
+        q0 = Q[0], q1 = Q[1];
+      }
+      // the cells (ix, y0..y1) of one grid column are consecutive in the CSR arrays, so a column is one contiguous run of items in
+      // GetFeaturesInArea's own (ix, iy, insertion) order; the run is walked eight items at a time with the index, key point and
+      // descriptor loads of a batch issued together
+      for (int ix = x0; ix <= x1; ++ix) {
+        const int k_end = cell_start[ix * GR_ROWS + y1 + 1];
+        for (int k0 = cell_start[ix * GR_ROWS + y0]; k0 < k_end; k0 += 8) {
+          int idx[8], oct[8];
+          float kx[8], ky[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) idx[u] = k0 + u < k_end ? cell_items[k0 + u] : -1;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const uvo_keypoint* p = F.kp + (idx[u] >= 0 ? idx[u] : 0);
+            kx[u] = p->x, ky[u] = p->y, oct[u] = p->octave;
+          }
+          bool take[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            take[u] = idx[u] >= 0 && !(oct[u] < minLevel || oct[u] > maxLevel) && !(fabsf(kx[u] - x) > r || fabsf(ky[u] - y) > r);
+          if (FILL) {
+            uint4 d0[8], d1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const uint4* D = reinterpret_cast<const uint4*>(F.desc + (int64_t)(take[u] ? idx[u] : 0) * 32);
+              d0[u] = D[0], d1[u] = D[1];
             }
-            ++n;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              if (!take[u]) continue;
+              const int d = __popc(q0.x ^ d0[u].x) + __popc(q0.y ^ d0[u].y) + __popc(q0.z ^ d0[u].z) + __popc(q0.w ^ d0[u].w) +
+                            __popc(q1.x ^ d1[u].x) + __popc(q1.y ^ d1[u].y) + __popc(q1.z ^ d1[u].z) + __popc(q1.w ^ d1[u].w);
+              // a list that outgrows the buffer is dropped here and the host repeats the stage with a larger one
+              if ((int64_t)o + n < cand_cap) cand[o + n] = (uint32_t)idx[u] | ((uint32_t)d << 16) | ((uint32_t)(oct[u] & 63) << 25);
+              ++n;
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) n += take[u] ? 1 : 0;
           }
         }
+      }
     }
   }
   if (!FILL) cand_cnt[i] = n;
@@ -208,20 +238,32 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve(int nkp, int nmp, const in
     for (int i = threadIdx.x; i < nmp; i += blockDim.x) {
       int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
       const int c_end = (int)min((int64_t)cand_start[i + 1], cand_cap);
-      for (int c = cand_start[i]; c < c_end; ++c) {
-        const uint32_t v = cand[c];
-        const int idx = (int)(v & 0xffffu);
-        if (owner[idx] < i) continue;  // taken before this map point's turn
-        const int dist = (int)((v >> 16) & 0x1ffu), oct = (int)(v >> 25);
-        if (dist < bestDist) {
-          bestDist2 = bestDist;
-          bestDist = dist;
-          bestLevel2 = bestLevel;
-          bestLevel = oct;
-          bestIdx = idx;
-        } else if (dist < bestDist2) {
-          bestLevel2 = oct;
-          bestDist2 = dist;
+      // eight candidates at a time: their words, then their owners, are fetched as independent loads before the (ordered) walk,
+      // instead of two dependent memory round trips per candidate
+      for (int c0 = cand_start[i]; c0 < c_end; c0 += 8) {
+        uint32_t vv[8];
+        int ow[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) vv[k] = c0 + k < c_end ? cand[c0 + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ow[k] = c0 + k < c_end ? owner[vv[k] & 0xffffu] : -1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (c0 + k >= c_end) break;
+          const uint32_t v = vv[k];
+          const int idx = (int)(v & 0xffffu);
+          if (ow[k] < i) continue;  // taken before this map point's turn
+          const int dist = (int)((v >> 16) & 0x1ffu), oct = (int)(v >> 25);
+          if (dist < bestDist) {
+            bestDist2 = bestDist;
+            bestDist = dist;
+            bestLevel2 = bestLevel;
+            bestLevel = oct;
+            bestIdx = idx;
+          } else if (dist < bestDist2) {
+            bestLevel2 = oct;
+            bestDist2 = dist;
+          }
         }
       }
       int ch = -1;
