@@ -67,25 +67,56 @@ __global__ __launch_bounds__(256) void k_win_cand(WinFrame F, WinQuery Q, const 
     y1 = min(GR_ROWS - 1, y1);
     if (x0 < GR_COLS && x1 >= 0 && y0 < GR_ROWS && y1 >= 0) {
       const int o = FILL ? cand_start[i] : 0;
-      for (int ix = x0; ix <= x1; ++ix)
-        for (int iy = y0; iy <= y1; ++iy) {
-          const int c = ix * GR_ROWS + iy;
-          for (int k = cell_start[c]; k < cell_start[c + 1]; ++k) {
-            const int idx = cell_items[k];
-            const uvo_keypoint kp = F.kp[idx];
-            if (bCheckLevels && !bSameLevel) {
-              if (kp.octave < minLevel || kp.octave > maxLevel) continue;
-            } else if (bSameLevel) {
-              if (kp.octave != minLevel) continue;
+      uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+      if (FILL) {
+        const uint4* QD = reinterpret_cast<const uint4*>(Q.desc + (int64_t)i * 32);
+        q0 = QD[0], q1 = QD[1];
+      }
+      // a grid column's cells are consecutive CSR runs: walk the run of (ix, y0..y1) eight items at a time, index / key point /
+      // descriptor loads of a batch issued together (same (ix, iy, insertion) order as the nested loops of GetFeaturesInArea)
+      for (int ix = x0; ix <= x1; ++ix) {
+        const int k_end = cell_start[ix * GR_ROWS + y1 + 1];
+        for (int k0 = cell_start[ix * GR_ROWS + y0]; k0 < k_end; k0 += 8) {
+          int idx[8], oct[8];
+          float kx[8], ky[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) idx[u] = k0 + u < k_end ? cell_items[k0 + u] : -1;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const uvo_keypoint* p = F.kp + (idx[u] >= 0 ? idx[u] : 0);
+            kx[u] = p->x, ky[u] = p->y, oct[u] = p->octave;
+          }
+          bool take[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            bool t = idx[u] >= 0;
+            if (bCheckLevels && !bSameLevel)
+              t = t && !(oct[u] < minLevel || oct[u] > maxLevel);
+            else if (bSameLevel)
+              t = t && oct[u] == minLevel;
+            take[u] = t && !(fabsf(kx[u] - x) > r || fabsf(ky[u] - y) > r);
+          }
+          if (FILL) {
+            uint4 d0[8], d1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const uint4* D = reinterpret_cast<const uint4*>(F.desc + (int64_t)(take[u] ? idx[u] : 0) * 32);
+              d0[u] = D[0], d1[u] = D[1];
             }
-            if (fabsf(kp.x - x) > r || fabsf(kp.y - y) > r) continue;
-            if (FILL) {
-              const int d = ham256(Q.desc + (int64_t)i * 32, F.desc + (int64_t)idx * 32);
-              cand[o + n] = (uint32_t)idx | ((uint32_t)d << 16) | ((uint32_t)(kp.octave & 63) << 25) | 0x80000000u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              if (!take[u]) continue;
+              const int d = __popc(q0.x ^ d0[u].x) + __popc(q0.y ^ d0[u].y) + __popc(q0.z ^ d0[u].z) + __popc(q0.w ^ d0[u].w) +
+                            __popc(q1.x ^ d1[u].x) + __popc(q1.y ^ d1[u].y) + __popc(q1.z ^ d1[u].z) + __popc(q1.w ^ d1[u].w);
+              cand[o + n] = (uint32_t)idx[u] | ((uint32_t)d << 16) | ((uint32_t)(oct[u] & 63) << 25) | 0x80000000u;
+              ++n;
             }
-            ++n;
+          } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) n += take[u] ? 1 : 0;
           }
         }
+      }
     }
   }
   if (!FILL) cand_cnt[i] = n;
@@ -179,20 +210,31 @@ __device__ __forceinline__ int rule_choice(const MatchRule& R, int i, const int3
   }
   const int none = R.rule == UVO_RULE_BEST_RATIO_SAME_LEVEL ? 256 : 0x7fffffff;  // :77-81 vs INT_MAX elsewhere
   int bestDist = none, bestLevel = -1, bestDist2 = none, bestLevel2 = -1, bestIdx = -1;
-  for (int c = b; c < e; ++c) {
-    const uint32_t v = cand[c];
-    const int idx = (int)(v & 0xffffu);
-    if (R.exclusive && owner[idx] < i) continue;  // taken before this query's turn (or blocked from the start)
-    const int d = (int)((v >> 16) & 0x1ffu), oct = (int)((v >> 25) & 63u);
-    if (d < bestDist) {
-      bestDist2 = bestDist;
-      bestDist = d;
-      bestLevel2 = bestLevel;
-      bestLevel = oct;
-      bestIdx = idx;
-    } else if (d < bestDist2) {
-      bestLevel2 = oct;
-      bestDist2 = d;
+  // eight candidates at a time: their words, then their owners, as independent loads in front of the ordered walk
+  for (int c0 = b; c0 < e; c0 += 8) {
+    uint32_t vv[8];
+    int ow[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) vv[k] = c0 + k < e ? cand[c0 + k] : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ow[k] = (R.exclusive && c0 + k < e) ? owner[vv[k] & 0xffffu] : 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (c0 + k >= e) break;
+      const uint32_t v = vv[k];
+      const int idx = (int)(v & 0xffffu);
+      if (R.exclusive && ow[k] < i) continue;  // taken before this query's turn (or blocked from the start)
+      const int d = (int)((v >> 16) & 0x1ffu), oct = (int)((v >> 25) & 63u);
+      if (d < bestDist) {
+        bestDist2 = bestDist;
+        bestDist = d;
+        bestLevel2 = bestLevel;
+        bestLevel = oct;
+        bestIdx = idx;
+      } else if (d < bestDist2) {
+        bestLevel2 = oct;
+        bestDist2 = d;
+      }
     }
   }
   bool ok = false;
