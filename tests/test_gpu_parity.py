@@ -486,6 +486,34 @@ def test_fuse_search_and_generic_windows(uvo, oracle, synth):
     m.close()
 
 
+def test_window_search_on_a_frame_larger_than_the_lds_grid_build(uvo, oracle):
+    """More key points than k_grid_build keeps in LDS (4096): the global-memory phases of the same kernel."""
+    rng = np.random.default_rng(77)
+    n, M = 6000, 3000
+    kp = np.zeros(n, uvo.KEYPOINT_DTYPE)
+    kp["x"], kp["y"], kp["octave"] = rng.uniform(-3, 755, n), rng.uniform(-3, 483, n), rng.integers(0, 8, n)
+    de = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    src = rng.integers(0, n, M)
+    mpd = _noisy_copies(rng, de, src, 0.05)
+    u = (kp["x"][src] + rng.normal(0, 2, M)).astype(np.float32)
+    v = (kp["y"][src] + rng.normal(0, 2, M)).astype(np.float32)
+    lvl = np.clip(kp["octave"][src] + rng.integers(0, 2, M), 0, 7).astype(np.int32)
+    valid = (rng.random(M) < 0.9).astype(np.uint8)
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    m = uvo.ORBmatcher(0.8, max_query=8192, max_map_points=8192)
+    bi, bd = m.FuseSearch(kp, de, (0, 0, 752, 480), u, v, lvl, valid, mpd, sf, 6.0)
+    oi, od = oracle.fuse_search(kp, de, (0, 0, 752, 480), u, v, lvl, valid, mpd, sf, 6.0)
+    np.testing.assert_array_equal(bi, oi)
+    np.testing.assert_array_equal(bd, od)
+    a, b = np.full(n, -1, np.int32), np.full(n, -1, np.int32)
+    vc = np.full(M, 0.9, np.float32)
+    na = m.SearchByProjection(kp, de, (0, 0, 752, 480), a, u, v, lvl, vc, valid, mpd, sf, 2.0)
+    nb = oracle.search_by_projection(kp, de, (0, 0, 752, 480), b, u, v, lvl, vc, valid, mpd, sf, 2.0, 0.8)
+    assert na == nb and na > 500
+    np.testing.assert_array_equal(a, b)
+    m.close()
+
+
 def _random_pose(rng):
     a = rng.normal(0, 0.15, 3)
     th = np.linalg.norm(a)

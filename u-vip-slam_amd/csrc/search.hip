@@ -25,17 +25,24 @@ struct SbpFrame {
   float inv_w, inv_h;
 };
 
-__global__ __launch_bounds__(256) void k_grid_build(SbpFrame F, int32_t* __restrict__ cell_start, int32_t* __restrict__ cell_items,
-                                                    int32_t* __restrict__ cell_of_kp) {
-  constexpr int NC = GR_COLS * GR_ROWS, PER = NC / 256;  // 3072 cells, 12 per thread
+// One workgroup of 1024 threads.  Frames of up to GB_ITEMS key points keep the item list and the cell of every key point in LDS,
+// so the scatter and the per-cell insertion sorts never wait on HBM; larger frames run the same phases on the output arrays.
+constexpr int GB_THREADS = 1024, GB_ITEMS = 4096;
+__global__ __launch_bounds__(GB_THREADS) void k_grid_build(SbpFrame F, int32_t* __restrict__ cell_start, int32_t* __restrict__ cell_items,
+                                                           int32_t* __restrict__ cell_of_kp) {
+  constexpr int NC = GR_COLS * GR_ROWS, PER = NC / GB_THREADS;  // 3072 cells, 3 per thread
+  static_assert(NC % GB_THREADS == 0, "cells must divide evenly over the threads");
   __shared__ int s_cnt[NC];
   __shared__ int s_cur[NC];
-  __shared__ int s_wave[4];
+  __shared__ int s_wave[GB_THREADS / 64];
+  __shared__ int32_t s_items[GB_ITEMS];
+  __shared__ int16_t s_cell[GB_ITEMS];
   const int tid = threadIdx.x;
+  const bool in_lds = F.n <= GB_ITEMS;
   // phase 1: cell of every keypoint, cell populations
-  for (int c = tid; c < NC; c += 256) s_cnt[c] = 0, s_cur[c] = 0;
+  for (int c = tid; c < NC; c += GB_THREADS) s_cnt[c] = 0, s_cur[c] = 0;
   __syncthreads();
-  for (int i = tid; i < F.n; i += 256) {
+  for (int i = tid; i < F.n; i += GB_THREADS) {
     const int px = (int)roundf((F.kp[i].x - (float)F.min_x) * F.inv_w);
     const int py = (int)roundf((F.kp[i].y - (float)F.min_y) * F.inv_h);
     int c = -1;
@@ -44,9 +51,10 @@ __global__ __launch_bounds__(256) void k_grid_build(SbpFrame F, int32_t* __restr
       atomicAdd(&s_cnt[c], 1);
     }
     cell_of_kp[i] = c;
+    if (in_lds) s_cell[i] = (int16_t)c;
   }
   __syncthreads();
-  // phase 2: exclusive scan of the 3072 populations (12 consecutive cells per thread, wavefront scan, 4 partials)
+  // phase 2: exclusive scan of the 3072 populations (3 consecutive cells per thread, wavefront scan, 16 partials)
   int local = 0;
 #pragma unroll
   for (int k = 0; k < PER; ++k) local += s_cnt[tid * PER + k];
@@ -61,24 +69,30 @@ __global__ __launch_bounds__(256) void k_grid_build(SbpFrame F, int32_t* __restr
   __syncthreads();
   int run = incl - local;
   for (int q = 0; q < (tid >> 6); ++q) run += s_wave[q];
+  int first[PER];
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
+    first[k] = run;
     cell_start[tid * PER + k] = run;
     run += s_cnt[tid * PER + k];
   }
-  if (tid == 255) cell_start[NC] = run;
+  if (tid == GB_THREADS - 1) cell_start[NC] = run;
+  // s_cur doubles as the cells' first slots for the scatter of other threads
+#pragma unroll
+  for (int k = 0; k < PER; ++k) s_cur[tid * PER + k] = first[k];
   __syncthreads();
   // phase 3: scatter (arbitrary order inside a cell), phase 4: every cell's short list sorted ascending = push_back order
-  for (int i = tid; i < F.n; i += 256) {
-    const int c = cell_of_kp[i];
-    if (c >= 0) cell_items[cell_start[c] + atomicAdd(&s_cur[c], 1)] = i;
+  int32_t* items = in_lds ? s_items : cell_items;
+  for (int i = tid; i < F.n; i += GB_THREADS) {
+    const int c = in_lds ? (int)s_cell[i] : cell_of_kp[i];
+    if (c >= 0) items[atomicAdd(&s_cur[c], 1)] = i;
   }
   __syncthreads();
 #pragma unroll 1
   for (int k = 0; k < PER; ++k) {
-    const int c = tid * PER + k, n = s_cnt[c];
+    const int n = s_cnt[tid * PER + k];
     if (n < 2) continue;
-    int32_t* a = cell_items + cell_start[c];
+    int32_t* a = items + first[k];
     for (int i = 1; i < n; ++i) {
       const int v = a[i];
       int j = i - 1;
@@ -88,6 +102,10 @@ __global__ __launch_bounds__(256) void k_grid_build(SbpFrame F, int32_t* __restr
       }
       a[j + 1] = v;
     }
+  }
+  if (in_lds) {
+    __syncthreads();
+    for (int i = tid; i < F.n; i += GB_THREADS) cell_items[i] = s_items[i];  // key points outside the grid leave the tail unused
   }
 }
 
@@ -296,7 +314,7 @@ __global__ __launch_bounds__(1024) void k_sbp_resolve(int nkp, int nmp, const in
 void launch_grid_build(hipStream_t s, const uvo_keypoint* d_kp, const uint8_t* d_desc, int n, int min_x, int min_y, int max_x, int max_y,
                        int32_t* d_cell_start, int32_t* d_cell_items, int32_t* d_cell_of_kp) {
   SbpFrame F{d_kp, d_desc, n, min_x, min_y, (float)GR_COLS / (float)(max_x - min_x), (float)GR_ROWS / (float)(max_y - min_y)};
-  hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, s, F, d_cell_start, d_cell_items, d_cell_of_kp);
+  hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(GB_THREADS), 0, s, F, d_cell_start, d_cell_items, d_cell_of_kp);
 }
 
 void launch_sbp(hipStream_t s, const uvo_keypoint* d_kp, int n, const uint8_t* d_desc, int min_x, int min_y, int max_x, int max_y,
@@ -308,7 +326,7 @@ void launch_sbp(hipStream_t s, const uvo_keypoint* d_kp, int n, const uint8_t* d
   SbpMap M{d_px, d_py, d_level, d_vc, d_inview, d_mpdesc, nmp};
   const int blocks = (nmp + 255) / 256;
   if (stage == 0) {
-    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, s, F, d_cell_start, d_cell_items, d_cell_of_kp);
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(GB_THREADS), 0, s, F, d_cell_start, d_cell_items, d_cell_of_kp);
     hipLaunchKernelGGL(k_sbp_cand<false>, dim3(blocks), dim3(256), 0, s, F, M, d_cell_start, d_cell_items, d_scale, th, d_cand_cnt,
                        (const int32_t*)nullptr, (uint32_t*)nullptr, (int64_t)0);
     hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, s, d_cand_cnt, d_cand_start, nmp);
