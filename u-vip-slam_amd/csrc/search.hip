@@ -240,10 +240,13 @@ __global__ __launch_bounds__(1024) void k_scan_i32(const int32_t* __restrict__ i
 }
 
 __global__ __launch_bounds__(1024) void k_sbp_resolve(int nkp, int nmp, const int32_t* __restrict__ cand_start, const uint32_t* __restrict__ cand,
-                                                      int64_t cand_cap, float nnratio, int32_t* __restrict__ assigned, int32_t* __restrict__ owner,
-                                                      int32_t* __restrict__ owner_next, int32_t* __restrict__ choice,
+                                                      int64_t cand_cap, float nnratio, int32_t* __restrict__ assigned, int32_t* owner,
+                                                      int32_t* owner_next, int32_t* __restrict__ choice,
                                                       int32_t* __restrict__ n_matches) {
   __shared__ int s_changed, s_count;
+  // ownership tables in LDS for frames of up to 4096 key points (the atomics and the dependent reads of the walk stay on chip)
+  __shared__ int32_t s_owner[4096], s_owner_next[4096];
+  if (nkp <= 4096) owner = s_owner, owner_next = s_owner_next;
   const int INF = 0x7fffffff;
   // owner: -1 = held before the call (F.mvpMapPoints[idx] already set), INF = free
   for (int k = threadIdx.x; k < nkp; k += blockDim.x) owner[k] = assigned[k] >= 0 ? -1 : INF;
