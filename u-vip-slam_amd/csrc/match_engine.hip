@@ -261,10 +261,13 @@ __device__ __forceinline__ int rule_choice(const MatchRule& R, int i, const int3
 
 // single workgroup.  blocked[t] != 0: target unavailable from the start.  match[i] = target or -1, mdist[i] = its distance.
 __global__ __launch_bounds__(1024) void k_match_resolve(int nq, int nt, const int32_t* __restrict__ cand_start, const uint32_t* __restrict__ cand,
-                                                        const uint8_t* __restrict__ blocked, MatchRule R, int32_t* __restrict__ owner,
-                                                        int32_t* __restrict__ owner_next, int32_t* __restrict__ match,
+                                                        const uint8_t* __restrict__ blocked, MatchRule R, int32_t* owner,
+                                                        int32_t* owner_next, int32_t* __restrict__ match,
                                                         int32_t* __restrict__ mdist, int32_t* __restrict__ n_matches) {
   __shared__ int s_changed, s_count;
+  // ownership tables in LDS for up to 4096 targets (the atomics and the dependent reads of the walk stay on chip)
+  __shared__ int32_t s_owner[4096], s_owner_next[4096];
+  if (nt <= 4096) owner = s_owner, owner_next = s_owner_next;
   const int INF = 0x7fffffff;
   for (int k = threadIdx.x; k < nt; k += blockDim.x) owner[k] = (blocked && blocked[k]) ? -1 : INF;
   for (int i = threadIdx.x; i < nq; i += blockDim.x) match[i] = -2;
