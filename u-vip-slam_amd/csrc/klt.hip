@@ -13,6 +13,7 @@
 //       differently from a raster-order CPU loop, so positions agree with the CPU statement to float rounding (tolerance in
 //       the parity test), as they do between OpenCV's own scalar and SIMD builds.
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "common.hpp"
@@ -223,6 +224,8 @@ struct uvo_klt {
   uint8_t* d_img = nullptr;    // [slots][img_block]
   int16_t* d_der = nullptr;    // [slots][der_block]
   uint8_t* d_in = nullptr;     // staging of the caller image
+  // point arrays of one track call, one device block [prev | next | err | status] with a page-locked mirror: one copy each way
+  uint8_t *d_pts = nullptr, *h_pts = nullptr;
   float *d_prev = nullptr, *d_next = nullptr, *d_err = nullptr;
   uint8_t* d_status = nullptr;
   std::vector<int> slot_w, slot_h, slot_levels;
@@ -254,9 +257,10 @@ void uvo_klt_destroy(uvo_klt* k) {
   if (!k) return;
   hipSetDevice(k->cfg.device);
   if (k->stream) hipStreamSynchronize(k->stream);
-  void* ptrs[] = {k->d_img, k->d_der, k->d_in, k->d_prev, k->d_next, k->d_err, k->d_status};
+  void* ptrs[] = {k->d_img, k->d_der, k->d_in, k->d_pts};
   for (void* p : ptrs)
     if (p) hipFree(p);
+  if (k->h_pts) (void)hipHostFree(k->h_pts);
   if (k->stream) hipStreamDestroy(k->stream);
   delete k;
 }
@@ -280,9 +284,8 @@ int uvo_klt_create(const uvo_klt_cfg* cfg, uvo_klt** out) {
   k->slot_w.assign(cfg->slots, 0), k->slot_h.assign(cfg->slots, 0), k->slot_levels.assign(cfg->slots, 0);
   const size_t S = (size_t)cfg->slots, N = (size_t)cfg->max_points;
   if (hipMalloc((void**)&k->d_img, S * k->img_block) != hipSuccess || hipMalloc((void**)&k->d_der, S * k->der_block * 2) != hipSuccess ||
-      hipMalloc((void**)&k->d_in, (size_t)cfg->max_width * cfg->max_height) != hipSuccess || hipMalloc((void**)&k->d_prev, N * 8) != hipSuccess ||
-      hipMalloc((void**)&k->d_next, N * 8) != hipSuccess || hipMalloc((void**)&k->d_err, N * 4) != hipSuccess ||
-      hipMalloc((void**)&k->d_status, N) != hipSuccess) {
+      hipMalloc((void**)&k->d_in, (size_t)cfg->max_width * cfg->max_height) != hipSuccess || hipMalloc((void**)&k->d_pts, N * 21 + 64) != hipSuccess ||
+      hipHostMalloc((void**)&k->h_pts, N * 21 + 64, hipHostMallocDefault) != hipSuccess) {
     uvo_klt_destroy(k);
     return fail(UVO_E_NOMEM, "KLT scratch allocation failed");
   }
@@ -362,8 +365,13 @@ int uvo_klt_track(uvo_klt* k, int prev_slot, int next_slot, const float* prev_pt
   max_count = std::min(std::max(max_count, 0), 100);                   // criteria.maxCount clamp
   epsilon = std::min(std::max(epsilon, 0.), 10.);
   epsilon *= epsilon;
-  UVO_HIP_CHECK(hipMemcpyAsync(k->d_prev, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, s));
-  UVO_HIP_CHECK(hipMemcpyAsync(k->d_next, next_pts, (size_t)n * 8, hipMemcpyHostToDevice, s));
+  // layout of the block for this call: prev [n][2] f32 | next [n][2] f32 | err [n] f32 | status [n] u8
+  const size_t N = (size_t)n, o_next = N * 8, o_err = N * 16, o_status = N * 20;
+  k->d_prev = reinterpret_cast<float*>(k->d_pts), k->d_next = reinterpret_cast<float*>(k->d_pts + o_next);
+  k->d_err = reinterpret_cast<float*>(k->d_pts + o_err), k->d_status = k->d_pts + o_status;
+  std::memcpy(k->h_pts, prev_pts, N * 8);
+  std::memcpy(k->h_pts + o_next, next_pts, N * 8);
+  UVO_HIP_CHECK(hipMemcpyAsync(k->d_pts, k->h_pts, N * 16, hipMemcpyHostToDevice, s));
   const uint8_t* I0 = k->d_img + (int64_t)prev_slot * k->img_block;
   const int16_t* D0 = k->d_der + (int64_t)prev_slot * k->der_block;
   const uint8_t* I1 = k->d_img + (int64_t)next_slot * k->img_block;
@@ -376,10 +384,11 @@ int uvo_klt_track(uvo_klt* k, int prev_slot, int next_slot, const float* prev_pt
     hipLaunchKernelGGL(k_klt_track<16>, grid, dim3(256), 0, s, G, I0, D0, I1, k->d_prev, k->d_next, n, k->cfg.win_width, k->cfg.win_height, max_level,
                        max_count, (float)epsilon, (float)min_eig_threshold, k->d_status, k->d_err);
   UVO_HIP_CHECK(hipGetLastError());
-  UVO_HIP_CHECK(hipMemcpyAsync(next_pts, k->d_next, (size_t)n * 8, hipMemcpyDeviceToHost, s));
-  UVO_HIP_CHECK(hipMemcpyAsync(status, k->d_status, (size_t)n, hipMemcpyDeviceToHost, s));
-  UVO_HIP_CHECK(hipMemcpyAsync(err, k->d_err, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipMemcpyAsync(k->h_pts + o_next, k->d_pts + o_next, N * 13, hipMemcpyDeviceToHost, s));  // next, err, status
   UVO_HIP_CHECK(hipStreamSynchronize(s));
+  std::memcpy(next_pts, k->h_pts + o_next, N * 8);
+  std::memcpy(err, k->h_pts + o_err, N * 4);
+  std::memcpy(status, k->h_pts + o_status, N);
   return UVO_OK;
 }
 
