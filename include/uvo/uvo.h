@@ -150,7 +150,10 @@ int uvo_grider_fast(uvo_extractor* h, const uint8_t* img, int width, int height,
  * cv::CLAHE::apply (8-bit), the pre-processing of Tracking::GrabImage when Enhance = 1 (src/Tracking.cc:425-431: clip limit 4,
  * 12 x 12 tiles): per-tile clipped histogram LUTs on the image extended by REFLECT_101 to a multiple of the tile grid, then the
  * bilinear blend of the four neighbouring LUTs per pixel.  In place is allowed (dst == src, same strides).
- * uvo_clahe: host buffers, one frame.  uvo_clahe_batch_device: HBM-resident, enqueued on the stream the next
+ * uvo_clahe: host buffers, one frame; the enhanced frame also stays in the handle's HBM, so that the calls that follow in
+ * Tracking::GrabImage need no second upload: uvo_extract(img = NULL, same width / height) extracts from it and
+ * uvo_klt_build_pyramid_from_extractor() builds the optical-flow pyramid from it; dst = NULL skips the download altogether.
+ * uvo_clahe_batch_device: HBM-resident, enqueued on the stream the next
  * uvo_extract_batch_device() call of this handle will use, so that enhance -> extract needs no synchronisation in between.
  */
 int uvo_clahe(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdiff_t stride, double clip_limit, int tiles_x, int tiles_y,
@@ -499,6 +502,8 @@ typedef struct uvo_klt_cfg {
 int uvo_klt_create(const uvo_klt_cfg* cfg, uvo_klt** out);
 void uvo_klt_destroy(uvo_klt* k);
 int uvo_klt_build_pyramid(uvo_klt* k, int slot, const uint8_t* img, int width, int height, ptrdiff_t stride, int* levels_built);
+/* HBM-resident chain: the image is the result of the extractor handle's last uvo_clahe() call (see there), no upload */
+int uvo_klt_build_pyramid_from_extractor(uvo_klt* k, int slot, uvo_extractor* h, int* levels_built);
 /* test tap: level without its border; img [h][w] u8, deriv [h][w][2] int16 (either may be NULL) */
 int uvo_klt_read_level(uvo_klt* k, int slot, int level, uint8_t* img, int16_t* deriv, int* width, int* height);
 /* prev_pts / next_pts: n x (x, y) float32; next_pts in = initial flow, out = tracked positions; status[n], err[n] (min eigenvalue).

@@ -860,6 +860,36 @@ def test_clahe(uvo, oracle, synth):
     ex.close()
 
 
+def test_hbm_resident_chain_clahe_pyramid_extract(uvo, synth):
+    """uvo_clahe keeps its result in HBM: extraction with img = NULL and the KLT pyramid built from the extractor's handle must
+    equal the same calls fed with the downloaded image."""
+    W, H = 640, 512
+    raw = (synth.make_frame(515, W, H).astype(np.float32) * 0.45 + 25).astype(np.uint8)
+    ex = uvo.ORBextractor(800, 1.2, 8, 0, 20, max_width=W, max_height=H)
+    klt = uvo.KLT(W, H, (21, 21), 5, max_points=64, slots=2)
+    with pytest.raises(uvo.UvoError):
+        klt.build_pyramid_from(0, ex)                     # no clahe() result yet
+    enh = ex.clahe(raw, 4.0, (12, 12))
+    kp_a, de_a = ex(enh)
+    n_a = klt.build_pyramid(0, enh)
+    assert ex.clahe(raw, 4.0, (12, 12), download=False) is None
+    kp_b, de_b = ex(None)
+    n_b = klt.build_pyramid_from(1, ex)
+    assert kp_a.tobytes() == kp_b.tobytes() and np.array_equal(de_a, de_b) and n_a == n_b
+    for lvl in range(n_a):
+        ia, da = klt.read_level(0, lvl)
+        ib, db = klt.read_level(1, lvl)
+        np.testing.assert_array_equal(ia, ib)
+        np.testing.assert_array_equal(da, db)
+    ex.close()
+    ex2 = uvo.ORBextractor(800, 1.2, 8, 0, 20, max_width=W, max_height=H)
+    ex2._clahe_shape = (H, W)
+    with pytest.raises(uvo.UvoError):
+        ex2(None)                                         # img = NULL without a preceding clahe()
+    ex2.close()
+    klt.close()
+
+
 def test_haloc_hash(uvo, oracle, synth):
     """haloc::Hash::getHash bit for bit (the accumulation order is part of the result)."""
     rng = np.random.default_rng(70)

@@ -39,14 +39,19 @@ def main():
     ntracked = []
     # pass 0: the stages back to back (a busy GPU); pass 1: the oracle's ~25 ms of CPU work between frames, so every stage
     # starts on a GPU that has gone idle, as it does at a 20 Hz camera rate
-    for check in (False, True):
+    for check in (False, True, "chain"):
+        # "chain": the enhanced frame stays in HBM between the three calls (clahe without download, pyramid and extraction from it)
+        chain = check == "chain"
         t = {"clahe": [], "pyramid": [], "track": [], "extract": []}
         prev_pts = None
         for i, raw in enumerate(frames):
             t0 = time.perf_counter()
-            img = ex.clahe(raw, 4.0, (12, 12))
+            img = ex.clahe(raw, 4.0, (12, 12), download=not chain)
             t1 = time.perf_counter()
-            klt.build_pyramid(i & 1, img)
+            if chain:
+                klt.build_pyramid_from(i & 1, ex)
+            else:
+                klt.build_pyramid(i & 1, img)
             t2 = time.perf_counter()
             kin = np.zeros(0, uvo.KEYPOINT_DTYPE)
             if prev_pts is not None and len(prev_pts):
@@ -68,11 +73,11 @@ def main():
             t5 = time.perf_counter()
             if i >= 3:
                 t["clahe"].append(t1 - t0), t["pyramid"].append(t2 - t1), t["track"].append(t3 - t2), t["extract"].append(t5 - t4)
-            if check:
+            if check:   # both the idle-GPU pass and the chained pass are checked against the oracle
                 kp_o, de_o = oe(o.clahe(raw, 4.0, (12, 12)), kin.copy(), g_orc, MINPX, i == 0, need)
                 exact = exact and kp.tobytes() == kp_o.tobytes() and np.array_equal(de, de_o) and np.array_equal(g_gpu, g_orc)
             prev_pts = np.stack([kp["x"], kp["y"]], 1).astype(np.float32)
-        key = "idle_gpu_between_frames" if check else "back_to_back"
+        key = "hbm_chained_idle_gpu_between_frames" if chain else ("idle_gpu_between_frames" if check else "back_to_back")
         res[key] = {k: round(float(np.median(v)) * 1e3, 3) for k, v in t.items()}
         res[key]["total"] = round(float(sum(np.median(v) for v in t.values())) * 1e3, 3)
     out = {"workload": "640x512 sequence of 21 frames, CLAHE(4, 12x12) + KLT(21x21, 5 levels) + top-up ORB (1000 feats, fastTh 20, Px_distance 20)",

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_profile_only", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
-    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_search_points_in_frustum", "uvo_sim3_decompose", "uvo_sim3_relative", "uvo_project_sim3", "uvo_search_by_projection_sim3", "uvo_search_by_sim3", "uvo_haloc_hash", "uvo_klt_create", "uvo_klt_destroy", "uvo_klt_build_pyramid", "uvo_klt_read_level", "uvo_klt_track", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
+    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_search_points_in_frustum", "uvo_sim3_decompose", "uvo_sim3_relative", "uvo_project_sim3", "uvo_search_by_projection_sim3", "uvo_search_by_sim3", "uvo_haloc_hash", "uvo_klt_create", "uvo_klt_destroy", "uvo_klt_build_pyramid", "uvo_klt_build_pyramid_from_extractor", "uvo_klt_read_level", "uvo_klt_track", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
     "uvo_matcher_kernel_times", "uvo_last_error", "uvo_device_info",
 ]
 
@@ -166,6 +166,7 @@ def _load():
     lib.uvo_klt_destroy.argtypes = [vp]
     lib.uvo_klt_destroy.restype = None
     lib.uvo_klt_build_pyramid.argtypes = [vp, ci, vp, ci, ci, cl, vp]
+    lib.uvo_klt_build_pyramid_from_extractor.argtypes = [vp, ci, vp, vp]
     lib.uvo_klt_read_level.argtypes = [vp, ci, ci, vp, vp, vp, vp]
     lib.uvo_klt_track.argtypes = [vp, ci, ci, vp, vp, ci, ci, ci, ctypes.c_double, ctypes.c_double, vp, vp]
     lib.uvo_fuse.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, vp, vp]
@@ -264,8 +265,11 @@ class ORBextractor:
         grid_2d: int32 array of shape (rows, cols) in Fortran (column-major) order, mutated in place like the
         reference's Eigen::MatrixXi&.  Returns (keypoints, descriptors).
         """
-        image = np.ascontiguousarray(image, dtype=np.uint8)
-        h, w = image.shape
+        if image is None:      # the handle's last clahe() result, already in HBM
+            h, w = self._clahe_shape
+        else:
+            image = np.ascontiguousarray(image, dtype=np.uint8)
+            h, w = image.shape
         n_in = 0 if keypoints is None else len(keypoints)
         kin = None if n_in == 0 else np.ascontiguousarray(keypoints, dtype=KEYPOINT_DTYPE)
         rows = cols = 0
@@ -276,7 +280,7 @@ class ORBextractor:
         out_kp = np.zeros(self.cap, KEYPOINT_DTYPE)
         out_desc = np.zeros((self.cap, 32), np.uint8)
         n_out = ctypes.c_int(0)
-        rc = lib.uvo_extract(self._h, image.ctypes.data, w, h, image.strides[0], _ptr(kin), n_in, _ptr(grid_2d), rows, cols, int(min_px_dist),
+        rc = lib.uvo_extract(self._h, _ptr(image), w, h, w if image is None else image.strides[0], _ptr(kin), n_in, _ptr(grid_2d), rows, cols, int(min_px_dist),
                              1 if FullDetect else 0, int(num_featsneeded), out_kp.ctypes.data, out_desc.ctypes.data, self.cap,
                              ctypes.byref(n_out))
         if rc:
@@ -356,12 +360,16 @@ class ORBextractor:
             raise UvoError(rc, "uvo_extractor_level_dims")
         return w.value, h.value
 
-    def clahe(self, img, clip_limit=4.0, tiles=(12, 12)):
-        """cv::CLAHE::apply as set up at src/Tracking.cc:425-431 (clip limit 4, 12 x 12 tiles); returns the enhanced image."""
+    def clahe(self, img, clip_limit=4.0, tiles=(12, 12), download=True):
+        """cv::CLAHE::apply as set up at src/Tracking.cc:425-431 (clip limit 4, 12 x 12 tiles); returns the enhanced image.
+        The result also stays in the handle's HBM: ex(None, ...) extracts from it, KLT.build_pyramid_from(slot, ex) builds the
+        optical-flow pyramid from it; download=False skips the copy back (returns None)."""
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
-        out = np.empty_like(img)
-        rc = lib.uvo_clahe(self._h, _ptr(img), w, h, img.strides[0], float(clip_limit), int(tiles[0]), int(tiles[1]), _ptr(out), out.strides[0])
+        self._clahe_shape = (h, w)
+        out = np.empty_like(img) if download else None
+        rc = lib.uvo_clahe(self._h, _ptr(img), w, h, img.strides[0], float(clip_limit), int(tiles[0]), int(tiles[1]), _ptr(out),
+                           out.strides[0] if download else 0)
         if rc:
             raise UvoError(rc, "uvo_clahe")
         return out
@@ -831,6 +839,14 @@ class KLT:
         rc = lib.uvo_klt_build_pyramid(self._h, slot, _ptr(img), img.shape[1], img.shape[0], img.strides[0], ctypes.byref(n))
         if rc:
             raise UvoError(rc, "uvo_klt_build_pyramid")
+        return n.value
+
+    def build_pyramid_from(self, slot, extractor):
+        """Pyramid of the extractor's last clahe() result, taken from HBM (no upload)."""
+        n = ctypes.c_int()
+        rc = lib.uvo_klt_build_pyramid_from_extractor(self._h, slot, extractor._h, ctypes.byref(n))
+        if rc:
+            raise UvoError(rc, "uvo_klt_build_pyramid_from_extractor")
         return n.value
 
     def read_level(self, slot, level):

@@ -88,7 +88,8 @@ struct uvo_extractor {
   ResizeCol* d_ctab = nullptr;
   uint8_t* d_clahe_lut = nullptr;  // [max_batch][tiles][256], grown on demand
   size_t clahe_lut_bytes = 0;
-  uint8_t* d_clahe_out = nullptr;  // staging of the host entry point's result
+  uint8_t* d_clahe_out = nullptr;  // result of the host entry point (tight rows); stays valid for img == NULL calls
+  int clahe_w = 0, clahe_h = 0;
   int resize_fast[kMaxLevels] = {0};  // per level: the 12-byte-window path of k_resize_level applies
   ResizeRow* d_rtab = nullptr;
   float* d_pattern = nullptr;   // 256 point pairs (x0, y0, x1, y1) of the rBRIEF pattern as floats
@@ -638,8 +639,8 @@ int uvo_clahe_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, i
 
 int uvo_clahe(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdiff_t stride, double clip_limit, int tiles_x, int tiles_y,
               uint8_t* dst, ptrdiff_t dst_stride) {
-  if (!h || !img || !dst) return fail(UVO_E_BADARG, "null pointer");
-  if (width < 1 || height < 1 || width > h->cfg.max_width || height > h->cfg.max_height || stride < width || dst_stride < width)
+  if (!h || !img) return fail(UVO_E_BADARG, "null pointer");
+  if (width < 1 || height < 1 || width > h->cfg.max_width || height > h->cfg.max_height || stride < width || (dst && dst_stride < width))
     return fail(UVO_E_BADARG, "image size outside what the handle was sized for");
   if ((int64_t)width * height > (int64_t)h->cfg.max_width * h->cfg.max_height) return fail(UVO_E_BADARG, "image too large");
   UVO_HIP_CHECK(hipSetDevice(h->device));
@@ -652,8 +653,10 @@ int uvo_clahe(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdi
   int rc = uvo_clahe_batch_device(h, 1, h->d_imgs, width, height, width, (ptrdiff_t)width * height, clip_limit, tiles_x, tiles_y, h->d_clahe_out, width,
                                   (ptrdiff_t)width * height);
   if (rc) return rc;
-  UVO_HIP_CHECK(hipMemcpy2DAsync(dst, dst_stride, h->d_clahe_out, width, width, (size_t)height, hipMemcpyDeviceToHost, s));
-  UVO_HIP_CHECK(hipStreamSynchronize(s));
+  h->clahe_w = width, h->clahe_h = height;
+  // dst == NULL: the enhanced image stays in HBM only, for uvo_extract(img = NULL) / uvo_klt_build_pyramid_from_extractor()
+  if (dst) UVO_HIP_CHECK(hipMemcpy2DAsync(dst, dst_stride, h->d_clahe_out, width, width, (size_t)height, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipStreamSynchronize(s));  // the caller's image may be reused
   return UVO_OK;
 }
 
@@ -685,8 +688,14 @@ int uvo_extractor_set_pipeline(uvo_extractor* h, int depth) {
 int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
                       const uvo_keypoint* in_kp, const int32_t* n_in, int32_t* grid2d, int grid_rows, int grid_cols, int min_px_dist,
                       int full_detect, const int32_t* num_feats_needed, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out) {
-  if (!h || !imgs || !out_kp || !out_desc || !n_out) return fail(UVO_E_BADARG, "null pointer");
+  if (!h || !out_kp || !out_desc || !n_out) return fail(UVO_E_BADARG, "null pointer");
   if (batch < 1 || batch > h->cfg.max_batch) return fail(UVO_E_BADARG, "batch outside 1..max_batch");
+  const bool from_clahe = imgs == nullptr;  // the frame is the result of the last uvo_clahe() call, already in HBM
+  if (from_clahe) {
+    if (batch != 1 || !h->d_clahe_out || h->clahe_w != width || h->clahe_h != height)
+      return fail(UVO_E_BADARG, "img == NULL needs a preceding uvo_clahe() of the same size (single frame)");
+    stride = width;
+  }
   if (width < 1 || height < 1 || width > h->cfg.max_width || height > h->cfg.max_height || stride < width)
     return fail(UVO_E_BADARG, "image size outside what the handle was sized for");
   if ((int64_t)width * height > (int64_t)h->cfg.max_width * h->cfg.max_height) return fail(UVO_E_BADARG, "image too large");
@@ -706,13 +715,16 @@ int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int widt
     }
   }
   // stage inputs (tight rows on the device)
-  if (stride == width && (batch == 1 || frame_stride == (ptrdiff_t)width * height)) {
+  if (from_clahe) {
+    // nothing to upload
+  } else if (stride == width && (batch == 1 || frame_stride == (ptrdiff_t)width * height)) {
     UVO_HIP_CHECK(hipMemcpyAsync(h->d_imgs, imgs, (size_t)batch * width * height, hipMemcpyHostToDevice, s));
   } else {
     for (int b = 0; b < batch; ++b)
       UVO_HIP_CHECK(hipMemcpy2DAsync(h->d_imgs + (size_t)b * width * height, width, imgs + (size_t)b * frame_stride, stride, width, (size_t)height,
                                      hipMemcpyHostToDevice, s));
   }
+  const uint8_t* d_frames = from_clahe ? h->d_clahe_out : h->d_imgs;
   const bool topup = !full_detect;
   const bool have_in = topup && in_kp && n_in && in_cap > 0;
   const int dcap = h->cap_flist;  // device staging capacity per frame
@@ -781,7 +793,7 @@ int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int widt
       }
     }
   }
-  int rc = run_batch_device(h, batch, h->d_imgs, width, height, width, (ptrdiff_t)width * height, have_in ? h->d_in_kp : nullptr,
+  int rc = run_batch_device(h, batch, d_frames, width, height, width, (ptrdiff_t)width * height, have_in ? h->d_in_kp : nullptr,
                             have_in ? h->d_n_in : nullptr, topup ? h->d_grid : nullptr, grid_rows, grid_cols, min_px_dist, full_detect,
                             topup ? h->d_nfn : nullptr, h->d_out_kp, h->d_out_desc, dcap, h->d_n_out);
   if (rc) return rc;
@@ -1020,5 +1032,9 @@ int uvo_extractor_kernel_times(uvo_extractor* h, char* names, int names_cap, flo
 
 hipStream_t uvo_extractor_stream_internal(uvo_extractor* h) { return h->lane[h->cur].stream; }
 int uvo_extractor_device_internal(uvo_extractor* h) { return h->device; }
+const uint8_t* uvo_extractor_clahe_internal(uvo_extractor* h, int* width, int* height) {
+  *width = h->clahe_w, *height = h->clahe_h;
+  return h->d_clahe_out;
+}
 
 }  // extern "C"

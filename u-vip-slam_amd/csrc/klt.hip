@@ -293,13 +293,8 @@ int uvo_klt_create(const uvo_klt_cfg* cfg, uvo_klt** out) {
   return UVO_OK;
 }
 
-int uvo_klt_build_pyramid(uvo_klt* k, int slot, const uint8_t* img, int width, int height, ptrdiff_t stride, int* levels_built) {
-  if (!k || !img) return fail(UVO_E_BADARG, "null pointer");
-  if (slot < 0 || slot >= k->cfg.slots) return fail(UVO_E_BADARG, "slot outside 0..slots-1");
-  if (width < 8 || height < 8 || width > k->cfg.max_width || height > k->cfg.max_height || stride < width ||
-      (int64_t)width * height > (int64_t)k->cfg.max_width * k->cfg.max_height)
-    return fail(UVO_E_BADARG, "image size outside what the handle was sized for");
-  UVO_HIP_CHECK(hipSetDevice(k->cfg.device));
+// d_src: device image (tight or pitched rows) already ordered before the handle's stream
+static int klt_build_from_device(uvo_klt* k, int slot, const uint8_t* d_src, int width, int height, int64_t src_pitch, int* levels_built) {
   hipStream_t s = k->stream;
   KltGeom G;
   int64_t ib, db;
@@ -308,13 +303,12 @@ int uvo_klt_build_pyramid(uvo_klt* k, int slot, const uint8_t* img, int width, i
   uint8_t* I = k->d_img + (int64_t)slot * k->img_block;
   int16_t* D = k->d_der + (int64_t)slot * k->der_block;
   const int bx = G.bx, by = G.by;
-  UVO_HIP_CHECK(hipMemcpy2DAsync(k->d_in, width, img, stride, width, (size_t)height, hipMemcpyHostToDevice, s));
   UVO_HIP_CHECK(hipMemsetAsync(D, 0, (size_t)db * 2, s));  // derivBorder = BORDER_CONSTANT (zeros)
   for (int l = 0; l < G.nlevels; ++l) {
     const KltLevel& L = G.l[l];
     const dim3 gb((L.w + 2 * bx + 255) / 256, L.h + 2 * by), gi((L.w + 255) / 256, L.h);
     if (l == 0) {
-      hipLaunchKernelGGL(k_klt_level0, gb, dim3(256), 0, s, k->d_in, width, height, (int64_t)width, I + L.ioff, L.ipitch, bx, by);
+      hipLaunchKernelGGL(k_klt_level0, gb, dim3(256), 0, s, d_src, width, height, src_pitch, I + L.ioff, L.ipitch, bx, by);
     } else {
       const KltLevel& P = G.l[l - 1];
       hipLaunchKernelGGL(k_klt_pyrdown, gi, dim3(256), 0, s, I + P.ioff, P.ipitch, I + L.ioff, L.w, L.h, L.ipitch, bx, by);
@@ -323,10 +317,45 @@ int uvo_klt_build_pyramid(uvo_klt* k, int slot, const uint8_t* img, int width, i
     hipLaunchKernelGGL(k_klt_scharr, gi, dim3(256), 0, s, I + L.ioff, L.w, L.h, L.ipitch, bx, by, D + L.doff, L.dpitch);
   }
   UVO_HIP_CHECK(hipGetLastError());
-  UVO_HIP_CHECK(hipStreamSynchronize(s));  // the caller's image may be reused
+  UVO_HIP_CHECK(hipStreamSynchronize(s));  // the source image may be reused
   k->slot_w[slot] = width, k->slot_h[slot] = height, k->slot_levels[slot] = G.nlevels;
   if (levels_built) *levels_built = G.nlevels;
   return UVO_OK;
+}
+
+int uvo_klt_build_pyramid(uvo_klt* k, int slot, const uint8_t* img, int width, int height, ptrdiff_t stride, int* levels_built) {
+  if (!k || !img) return fail(UVO_E_BADARG, "null pointer");
+  if (slot < 0 || slot >= k->cfg.slots) return fail(UVO_E_BADARG, "slot outside 0..slots-1");
+  if (width < 8 || height < 8 || width > k->cfg.max_width || height > k->cfg.max_height || stride < width ||
+      (int64_t)width * height > (int64_t)k->cfg.max_width * k->cfg.max_height)
+    return fail(UVO_E_BADARG, "image size outside what the handle was sized for");
+  UVO_HIP_CHECK(hipSetDevice(k->cfg.device));
+  UVO_HIP_CHECK(hipMemcpy2DAsync(k->d_in, width, img, stride, width, (size_t)height, hipMemcpyHostToDevice, k->stream));
+  return klt_build_from_device(k, slot, k->d_in, width, height, (int64_t)width, levels_built);
+}
+
+// The image is the result of the extractor handle's last uvo_clahe() call, still in HBM: no upload.  The extractor's stream is
+// ordered in front of this handle's stream by an event.
+extern "C" const uint8_t* uvo_extractor_clahe_internal(uvo_extractor* h, int* width, int* height);
+extern "C" hipStream_t uvo_extractor_stream_internal(uvo_extractor* h);
+extern "C" int uvo_extractor_device_internal(uvo_extractor* h);
+int uvo_klt_build_pyramid_from_extractor(uvo_klt* k, int slot, uvo_extractor* h, int* levels_built) {
+  if (!k || !h) return fail(UVO_E_BADARG, "null pointer");
+  if (slot < 0 || slot >= k->cfg.slots) return fail(UVO_E_BADARG, "slot outside 0..slots-1");
+  if (uvo_extractor_device_internal(h) != k->cfg.device) return fail(UVO_E_BADARG, "handles live on different devices");
+  int width = 0, height = 0;
+  const uint8_t* d_src = uvo_extractor_clahe_internal(h, &width, &height);
+  if (!d_src || width < 8 || height < 8) return fail(UVO_E_BADARG, "the extractor holds no uvo_clahe() result");
+  if (width > k->cfg.max_width || height > k->cfg.max_height || (int64_t)width * height > (int64_t)k->cfg.max_width * k->cfg.max_height)
+    return fail(UVO_E_BADARG, "image size outside what the handle was sized for");
+  UVO_HIP_CHECK(hipSetDevice(k->cfg.device));
+  hipEvent_t ev;
+  UVO_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e1 = hipEventRecord(ev, uvo_extractor_stream_internal(h));
+  hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(k->stream, ev, 0) : e1;
+  (void)hipEventDestroy(ev);
+  if (e2 != hipSuccess) return fail(UVO_E_HIP, "stream ordering between the extractor and the tracker failed");
+  return klt_build_from_device(k, slot, d_src, width, height, (int64_t)width, levels_built);
 }
 
 int uvo_klt_read_level(uvo_klt* k, int slot, int level, uint8_t* img, int16_t* deriv, int* width, int* height) {
