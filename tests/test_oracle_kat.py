@@ -2,6 +2,7 @@
 so every answer here is hand-derivable from the reference sources, or cross-checked by an independent numpy
 formulation written in this file)."""
 import ctypes
+import subprocess
 import os
 
 import numpy as np
@@ -526,3 +527,36 @@ def test_klt_pyramid_and_tracker_known_answers(oracle, synth):
     # a point outside the image by more than the window is rejected at level 0 with err = 0
     _, st, er = oracle.klt_track(p0, p1, np.array([[-40.0, 50.0], [100.0, 100.0]], np.float32))
     assert st[0] == 0 and er[0] == 0 and st[1] == 1
+
+def test_strip_plan_tiles_every_window_exactly_once():
+    """Host check of the wavefront strip plan shared by k_fast_score and k_gauss7 (csrc/strip_plan.hpp, compiled with a plain C++
+    compiler): every pixel of a window belongs to exactly one (item, sub-strip); the plan never needs more wavefront-rows than
+    one 248-column strip per started 248 columns would."""
+    lib = os.path.join(ROOT, "tests", "emu", "libstrip_plan_emu.so")
+    srcs = [os.path.join(ROOT, "tests", "emu", "strip_plan_emu.cpp"), os.path.join(ROOT, "u-vip-slam_amd", "csrc", "strip_plan.hpp")]
+    if not os.path.exists(lib) or max(os.path.getmtime(p) for p in srcs) > os.path.getmtime(lib):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", lib, srcs[0]])
+    E = ctypes.CDLL(lib)
+    E.emu_strip_plan_check.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2
+    rng = np.random.default_rng(12)
+    widths = list(range(1, 700)) + [int(x) for x in rng.integers(700, 4200, 150)]
+    saved = total = 0
+    for w in widths:
+        for h, rps in ((int(rng.integers(1, 600)), 24), (int(rng.integers(1, 300)), 8), (int(rng.integers(1, 1100)), 64)):
+            items, lane_rows = ctypes.c_int(), ctypes.c_int()
+            rc = E.emu_strip_plan_check(w, h, rps, ctypes.byref(items), ctypes.byref(lane_rows))
+            assert rc == 0, (w, h, rps, rc)
+            nseg = -(-h // rps)
+            plain = -(-w // 248) * nseg * rps        # one full-width wavefront strip per started 248 columns
+            assert lane_rows.value <= plain, (w, h, rps)
+            saved += plain - lane_rows.value
+            total += plain
+    assert saved > 0.05 * total                      # the narrow strips pay off on average (about 10 % over random sizes)
+    # the level widths of the 640 x 512 pyramid (windows = width - 32): 20 % fewer wavefront-rows than full strips only
+    rows = plain = 0
+    for w, h in ((608, 480), (501, 395), (412, 324), (338, 264), (277, 215), (225, 174), (182, 139), (147, 111)):
+        items, lane_rows = ctypes.c_int(), ctypes.c_int()
+        assert E.emu_strip_plan_check(w, h, 24, ctypes.byref(items), ctypes.byref(lane_rows)) == 0
+        rows += lane_rows.value
+        plain += -(-w // 248) * -(-h // 24) * 24
+    assert rows < 0.83 * plain
