@@ -35,3 +35,19 @@ extern "C" int emu_strip_plan_check(int w, int h, int rows_per_seg, int* items_o
   *lane_rows_out = (int)lane_rows;
   return 0;
 }
+
+// xcd_contiguous must be a permutation of [0, total) that keeps the workgroups of one XCD (b % 8) in one contiguous range
+extern "C" int emu_xcd_contiguous_check(int total) {
+  std::vector<int> seen(total, 0);
+  std::vector<int> lo(8, total), hi(8, -1), cnt(8, 0);
+  for (int b = 0; b < total; ++b) {
+    const int v = uvo::xcd_contiguous(b, total);
+    if (v < 0 || v >= total) return 1;
+    if (seen[v]++) return 2;
+    const int x = b & 7;
+    lo[x] = v < lo[x] ? v : lo[x], hi[x] = v > hi[x] ? v : hi[x], ++cnt[x];
+  }
+  for (int x = 0; x < 8; ++x)
+    if (cnt[x] && hi[x] - lo[x] + 1 != cnt[x]) return 3;  // not contiguous
+  return 0;
+}

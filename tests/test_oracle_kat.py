@@ -560,3 +560,7 @@ def test_strip_plan_tiles_every_window_exactly_once():
         rows += lane_rows.value
         plain += -(-w // 248) * -(-h // 24) * 24
     assert rows < 0.83 * plain
+    # the XCD-contiguous work mapping used by the same kernels is a permutation with one contiguous range per XCD
+    E.emu_xcd_contiguous_check.argtypes = [ctypes.c_int]
+    for total in list(range(1, 300)) + [1023, 1024, 1025, 10496, 65537]:
+        assert E.emu_xcd_contiguous_check(total) == 0, total

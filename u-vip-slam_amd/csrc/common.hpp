@@ -8,6 +8,7 @@
 //   sel      : [frame][level][quota_l+4] quad-tree survivors in the reference's list order
 //   flist    : [frame][flist_cap] final (level, x, y, aux) slots in output order
 #pragma once
+#include "strip_plan.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -81,14 +82,6 @@ const char* hip_err_set(hipError_t e, const char* what);
 // index of the calling wavefront inside its workgroup, as a scalar: the compiler cannot prove threadIdx.x >> 6 wave-uniform by
 // itself, and everything derived from it (row counters, queue lengths, addresses) would otherwise live in vector registers.
 __device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
-// Workgroups are dealt round-robin over the 8 XCDs (workgroups b and b + 8 share an XCD and its L2).  This maps the linear
-// workgroup index to a virtual one such that each XCD walks a contiguous range of virtual indices: neighbouring work items
-// (strips / segments that re-read each other's halo rows) then meet in one L2.  Speed only, never correctness.
-__device__ __forceinline__ int xcd_contiguous(int b, int total) {
-  const int per = total >> 3, rem = total & 7;  // the first `rem` XCDs own per + 1 workgroups
-  const int x = b & 7, i = b >> 3;
-  return x < rem ? x * (per + 1) + i : rem * (per + 1) + (x - rem) * per + i;
-}
 #endif
 
 int fail(int code, const char* msg);  // records msg for uvo_last_error() and returns code

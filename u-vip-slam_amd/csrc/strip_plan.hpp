@@ -61,4 +61,14 @@ struct StripPlan {
   int sub[2], x0[2];
 };
 
+
+// Workgroups are dealt round-robin over the 8 XCDs (workgroups b and b + 8 share an XCD and its L2).  This maps the linear
+// workgroup index to a virtual one such that each XCD walks a contiguous range of virtual indices: neighbouring work items
+// (strips / segments that re-read each other's halo rows) then meet in one L2.  Speed only, never correctness.
+UVO_HD inline int xcd_contiguous(int b, int total) {
+  const int per = total >> 3, rem = total & 7;  // the first `rem` XCDs own per + 1 workgroups
+  const int x = b & 7, i = b >> 3;
+  return x < rem ? x * (per + 1) + i : rem * (per + 1) + (x - rem) * per + i;
+}
+
 }  // namespace uvo
