@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_f -o kt -- python3 bench.py --steps 5 --warmup 2 > gpurun_out/prof_f_bench.json 2> gpurun_out/prof_f.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_f -o kt -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_f_bench.json 2> gpurun_out/prof_f.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_a -- python3 bench.py --steps 2 --warmup 1 > /dev/null 2> gpurun_out/pmc_a.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_b -- python3 bench.py --steps 2 --warmup 1 > /dev/null 2> gpurun_out/pmc_b.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/pmc_c -- python3 bench.py --steps 2 --warmup 1 > /dev/null 2> gpurun_out/pmc_c.err
