@@ -135,6 +135,14 @@ int uvo_extractor_synchronize(uvo_extractor* h);
  * buffers.  uvo_matcher_wait_extractor() / uvo_extractor_wait_matcher() refer to the most recently used stream.
  */
 int uvo_extractor_set_pipeline(uvo_extractor* h, int depth);
+/*
+ * Launch-shape knobs of one handle (speed only -- results never depend on them; the parity tests force each shape).
+ *   UVO_TUNE_OCT_WIDE_MAX : batches with at most this many (frame, level) quad-tree problems run DistributeOctTree
+ *                           (src/ORBextractor.cc:1006-1230) as 1024-thread workgroups, larger ones as 256-thread workgroups
+ *                           (default 256; 0 = always the 256-thread form, a large value = always the 1024-thread form).
+ */
+#define UVO_TUNE_OCT_WIDE_MAX 1
+int uvo_extractor_tune(uvo_extractor* h, int knob, int value);
 
 /*
  * Grid-bucketed FAST -- Grider_FAST::perform_griding(img, pts, num_features, grid_x, grid_y, threshold, nonmaxSuppression)
@@ -209,6 +217,8 @@ int uvo_hamming_knn2(uvo_matcher* m, const uint8_t* q, int nq, const uint8_t* t,
 /*
  * Batched, HBM-resident: pair p matches d_q[p*q_stride ...] (d_nq[p] rows) against d_t[p*t_stride ...]
  * (d_nt[p] rows); strides in descriptors; outputs [P][max_query].  Enqueues on the matcher's stream.
+ * q_stride <= max_query, t_stride <= 65535 (UVO_E_BADARG otherwise).  The counts are device values (an extractor's
+ * d_n_out may exceed the slice it could fill): the kernel clamps d_nq[p] to q_stride and d_nt[p] to t_stride.
  */
 int uvo_hamming_knn2_batch_device(uvo_matcher* m, int pairs, const uint8_t* d_q, const int32_t* d_nq, int q_stride, const uint8_t* d_t,
                                   const int32_t* d_nt, int t_stride, int32_t* d_idx0, uint16_t* d_d0, int32_t* d_idx1, uint16_t* d_d1);

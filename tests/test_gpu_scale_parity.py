@@ -1,0 +1,169 @@
+"""The code path bench.py times, under the oracle at the benchmark's own sizes.
+
+BASELINE.json configs[2] (batch 256 @ 640x512, 1000 features: `k_octree<256>`, the XCD-contiguous dealing of 256-frame grids,
+`k_assemble<false>` at scale) and configs[3]'s per-GPU share (batch 128 @ 1920x1080, 2000 features) are run exactly as the bench
+runs them -- HBM-resident, pipeline depth 2, all-pairs knn-2 of consecutive frames on the matcher's stream -- and EVERY frame is
+compared with the CPU oracle byte for byte (keypoints as raw 28-byte records, descriptors, knn-2 rows).  A second group forces each
+launch shape of the quad-tree kernel (DistributeOctTree, src/ORBextractor.cc:1006-1230) on the same input and holds both to the
+oracle, and a third covers the host-buffer entry points after uvo_extractor_set_pipeline(2)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _kp_bytes(kp):
+    return np.ascontiguousarray(kp).view(np.uint8).reshape(len(kp), -1)
+
+
+def _same(kp_g, de_g, kp_o, de_o, what):
+    assert len(kp_g) == len(kp_o), "%s: %d keypoints on the GPU, %d in the oracle" % (what, len(kp_g), len(kp_o))
+    bad = np.nonzero((_kp_bytes(kp_g) != _kp_bytes(kp_o)).any(1))[0]
+    assert len(bad) == 0, "%s: %d keypoints differ, first %d: gpu=%s oracle=%s" % (what, len(bad), bad[0], kp_g[bad[0]], kp_o[bad[0]])
+    assert (de_g == de_o).all(), "%s: descriptors differ" % what
+
+
+def _run_bench_path(uvo, frames, nfeat, fast_th, passes=3, tune=None):
+    """bench.py's step: extract_batch_device on alternating lanes + knn-2 of (frame i, frame i+1), `passes` steps back to back
+    without a host synchronisation; returns the outputs of the LAST step on each lane (so both lanes' scratch sets are checked)."""
+    import torch
+    B, H, W = frames.shape
+    dev = torch.device("cuda", 0)
+    ex = uvo.ORBextractor(nfeat, 1.2, 8, 0, fast_th, max_width=W, max_height=H, max_batch=B)
+    if tune is not None:
+        ex.tune(uvo.UVO_TUNE_OCT_WIDE_MAX, tune)
+    ex.set_pipeline(2)
+    cap = ex.cap
+    mt = uvo.ORBmatcher(0.8, max_query=cap, max_train=cap, max_batch=B)
+    d_img = torch.from_numpy(frames).to(dev)
+
+    class Out:
+        def __init__(self):
+            self.kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+            self.de = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+            self.n = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.i0 = torch.full((B, cap), -7, dtype=torch.int32, device=dev)
+            self.i1 = torch.full((B, cap), -7, dtype=torch.int32, device=dev)
+            self.d0 = torch.zeros((B, cap), dtype=torch.int16, device=dev)
+            self.d1 = torch.zeros((B, cap), dtype=torch.int16, device=dev)
+
+    outs = [Out(), Out()]
+    torch.cuda.synchronize()
+    for k in range(passes):
+        o = outs[k % 2]
+        ex.extract_batch_device(d_img.data_ptr(), B, W, H, o.kp.data_ptr(), o.de.data_ptr(), o.n.data_ptr(), cap)
+        mt.wait_extractor(ex)
+        mt.knn2_batch_device(B - 1, o.de.data_ptr(), o.n.data_ptr(), cap, o.de.data_ptr() + cap * 32, o.n.data_ptr() + 4, cap,
+                             o.i0.data_ptr(), o.d0.data_ptr(), o.i1.data_ptr(), o.d1.data_ptr())
+        mt.release_to_extractor(ex)
+    ex.synchronize()
+    mt.synchronize()
+    res = []
+    for o in outs:
+        res.append(dict(n=o.n.cpu().numpy(), kp=o.kp.cpu().numpy(), de=o.de.cpu().numpy(), i0=o.i0.cpu().numpy(), i1=o.i1.cpu().numpy(),
+                        d0=o.d0.cpu().numpy().astype(np.uint16), d1=o.d1.cpu().numpy().astype(np.uint16)))
+    ex.close()
+    mt.close()
+    return res
+
+
+def _check_against_oracle(uvo, oracle, frames, nfeat, fast_th, res, what, min_kp):
+    oe = oracle.extractor(nfeat, 1.2, 8, fast_th)
+    B = len(frames)
+    ref = [oe(frames[b]) for b in range(B)]
+    assert min(len(r[0]) for r in ref) >= min_kp
+    for li, r in enumerate(res):
+        for b in range(B):
+            n = int(r["n"][b])
+            kp_g = np.ascontiguousarray(r["kp"][b, :n]).view(uvo.KEYPOINT_DTYPE).reshape(-1)
+            _same(kp_g, r["de"][b, :n], ref[b][0], ref[b][1], "%s lane %d frame %d" % (what, li, b))
+        for b in range(B - 1):
+            o = oracle.knn2(ref[b][1], ref[b + 1][1])
+            nq = len(ref[b][1])
+            np.testing.assert_array_equal(r["i0"][b, :nq], o[0], err_msg="%s lane %d pair %d idx0" % (what, li, b))
+            np.testing.assert_array_equal(r["d0"][b, :nq].astype(np.int32), o[1], err_msg="%s lane %d pair %d d0" % (what, li, b))
+            np.testing.assert_array_equal(r["i1"][b, :nq], o[2], err_msg="%s lane %d pair %d idx1" % (what, li, b))
+            np.testing.assert_array_equal(r["d1"][b, :nq].astype(np.int32), o[3], err_msg="%s lane %d pair %d d1" % (what, li, b))
+    return ref
+
+
+@pytest.mark.parametrize("batch", [64, 256])
+def test_configs2_throughput_path_every_frame_vs_oracle(uvo, oracle, synth, batch):
+    """BASELINE.json configs[2] as bench.py runs it (batch 256: 2048 quad-tree problems -> k_octree<256>, four per CU)."""
+    frames = synth.make_sequence(0, batch, 640, 512)
+    res = _run_bench_path(uvo, frames, 1000, 20)
+    _check_against_oracle(uvo, oracle, frames, 1000, 20, res, "configs[2] batch %d" % batch, 1000)
+
+
+def test_configs3_hd_share_of_one_gpu_every_frame_vs_oracle(uvo, oracle, synth):
+    """BASELINE.json configs[3]: 1920x1080 @ 2000 features, 128 frames per GPU (two quad-tree roots per level, 6594 FAST cells)."""
+    frames = synth.make_sequence(0, 128, 1920, 1080, n_shapes=2500)
+    res = _run_bench_path(uvo, frames, 2000, 20, passes=2)
+    _check_against_oracle(uvo, oracle, frames, 2000, 20, res, "configs[3] batch 128", 2000)
+
+
+@pytest.mark.parametrize("shape,nfeat,batch", [((512, 640), 1000, 40), ((1080, 1920), 2000, 6), ((480, 752), 1000, 3)])
+def test_both_quad_tree_launch_shapes_equal_the_oracle(uvo, oracle, synth, shape, nfeat, batch):
+    """The same batch through k_octree<1024> (UVO_TUNE_OCT_WIDE_MAX = huge) and k_octree<256> (= 0): both must be the oracle's
+    DistributeOctTree.  (By default batch 40 x 8 levels = 320 problems takes the 256-thread form, batch <= 32 the 1024-thread one.)"""
+    H, W = shape
+    frames = synth.make_sequence(64, batch, W, H, n_shapes=400 if W < 1000 else 2500)
+    ref = None
+    for tune in (0, 1 << 30):
+        res = _run_bench_path(uvo, frames, nfeat, 20, passes=2, tune=tune)
+        ref = _check_against_oracle(uvo, oracle, frames, nfeat, 20, res, "wide_max=%d" % tune, nfeat)
+    assert ref is not None
+
+
+def test_host_entry_points_after_set_pipeline_2(uvo, oracle, synth):
+    """uvo_extract / uvo_extract_batch / uvo_clahe -> uvo_extract(img = NULL) on a handle with two lanes: uploads, kernels and
+    downloads of a call must share one lane's stream (the synchronous forms alternate lanes like the asynchronous ones)."""
+    W, H, B = 640, 512, 5
+    frames = synth.make_sequence(200, B, W, H)
+    oe = oracle.extractor(1000, 1.2, 8, 20)
+    ref = [oe(f) for f in frames]
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=W, max_height=H, max_batch=B, max_input_keypoints=64)
+    ex.set_pipeline(2)
+    for rep in range(3):                       # consecutive calls land on alternating lanes
+        for b in range(B):
+            kp, de = ex(frames[b])
+            _same(kp, de, ref[b][0], ref[b][1], "uvo_extract rep %d frame %d" % (rep, b))
+        for b, (kp, de) in enumerate(ex.extract_batch(frames)):
+            _same(kp, de, ref[b][0], ref[b][1], "uvo_extract_batch rep %d frame %d" % (rep, b))
+    # top-up mode (uploads of grid / counts / caller keypoints ride the same lane)
+    rng = np.random.default_rng(5)
+    kin = np.zeros(40, uvo.KEYPOINT_DTYPE)
+    kin["x"], kin["y"] = rng.uniform(20, W - 21, 40).astype(np.float32), rng.uniform(20, H - 21, 40).astype(np.float32)
+    kin["size"], kin["angle"], kin["octave"], kin["class_id"] = 31, -1, 0, -1
+    rows, cols = H // 20 + 2, W // 20 + 2
+    for rep in range(3):
+        g1, g2 = np.zeros((rows, cols), np.int32, order="F"), np.zeros((rows, cols), np.int32, order="F")
+        kp_g, de_g = ex(frames[rep], kin.copy(), g1, 20, False, 300)
+        kp_o, de_o = oe(frames[rep], kin.copy(), g2, 20, False, 300)
+        _same(kp_g, de_g, kp_o, de_o, "top-up rep %d" % rep)
+        np.testing.assert_array_equal(g1, g2)
+    # CLAHE result kept in HBM, then extraction from it
+    for rep in range(3):
+        enh = ex.clahe(frames[rep])
+        np.testing.assert_array_equal(enh, oracle.clahe(frames[rep], 4.0, (12, 12)))
+        kp_g, de_g = ex(None)
+        kp_o, de_o = oe(enh)
+        _same(kp_g, de_g, kp_o, de_o, "clahe -> extract(NULL) rep %d" % rep)
+    ex.close()
+
+
+def test_topup_grid_smaller_than_the_image_is_rejected(uvo, synth):
+    """src/ORBextractor.cc:884-891 indexes grid_2d(int(y / d), int(x / d)); the call site sizes it rows / d + 2 (src/Tracking.cc:930-934).
+    A smaller grid is a caller error here (Eigen would assert), never an out-of-bounds write."""
+    W, H = 320, 256
+    img = synth.make_frame(3, W, H, n_shapes=100)
+    ex = uvo.ORBextractor(300, 1.2, 4, 0, 20, max_width=W, max_height=H, max_input_keypoints=8)
+    ok = np.zeros((H // 20 + 2, W // 20 + 2), np.int32, order="F")
+    ex(img, None, ok, 20, False, 100)
+    for shape in [((H - 1) // 20, W // 20 + 2), (H // 20 + 2, (W - 1) // 20), (1, 1)]:
+        with pytest.raises(uvo.UvoError) as ei:
+            ex(img, None, np.zeros(shape, np.int32, order="F"), 20, False, 100)
+        assert ei.value.code == uvo.UVO_E_BADARG
+    exact = np.zeros(((H - 1) // 20 + 1, (W - 1) // 20 + 1), np.int32, order="F")   # the smallest grid every pixel position fits
+    ex(img, None, exact, 20, False, 100)
+    ex.close()

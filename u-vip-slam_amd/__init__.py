@@ -22,11 +22,12 @@ KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle"
 assert KEYPOINT_DTYPE.itemsize == 28
 
 UVO_OK, UVO_E_BADARG, UVO_E_NODEVICE, UVO_E_HIP, UVO_E_CAPACITY, UVO_E_UNSUPPORTED, UVO_E_NOMEM = 0, -1, -2, -3, -4, -5, -6
+UVO_TUNE_OCT_WIDE_MAX = 1
 
 # every symbol include/uvo/uvo.h declares
 ABI_SYMBOLS = [
     "uvo_extractor_create", "uvo_extractor_destroy", "uvo_extractor_levels", "uvo_extractor_max_keypoints", "uvo_extractor_scale_factor", "uvo_extractor_tables",
-    "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_host_alloc", "uvo_host_free", "uvo_extract_batch_submit", "uvo_extract_batch_wait", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_level_dims",
+    "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_host_alloc", "uvo_host_free", "uvo_extract_batch_submit", "uvo_extract_batch_wait", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_tune", "uvo_extractor_level_dims",
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_profile_only", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
@@ -133,6 +134,7 @@ def _load():
     lib.uvo_extract_batch_wait.argtypes = [vp, ci]
     lib.uvo_extractor_synchronize.argtypes = [vp]
     lib.uvo_extractor_set_pipeline.argtypes = [vp, ci]
+    lib.uvo_extractor_tune.argtypes = [vp, ci, ci]
     lib.uvo_extractor_level_dims.argtypes = [vp, ci, vp, vp]
     lib.uvo_clahe.argtypes = [vp, vp, ci, ci, cl, ctypes.c_double, ci, ci, vp, cl]
     lib.uvo_clahe_batch_device.argtypes = [vp, ci, vp, ci, ci, cl, cl, ctypes.c_double, ci, ci, vp, cl, cl]
@@ -351,6 +353,11 @@ class ORBextractor:
         rc = lib.uvo_extractor_set_pipeline(self._h, depth)
         if rc:
             raise UvoError(rc, "uvo_extractor_set_pipeline")
+
+    def tune(self, knob, value):
+        rc = lib.uvo_extractor_tune(self._h, knob, value)
+        if rc:
+            raise UvoError(rc, "uvo_extractor_tune")
 
     # ---- stage taps used by the parity tests ----
     def level_dims(self, level):

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "fast_geom.hpp"
 #include "profiler.hpp"
 #include "uvo_math.hpp"
 
@@ -47,7 +48,7 @@ constexpr int kMaxLanes = 4;
 
 struct Lane {
   hipStream_t stream = nullptr;
-  uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_score = nullptr;
+  uint8_t *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_cand_xy = nullptr, *d_cand_sc = nullptr, *d_pstate = nullptr, *d_sel_xy = nullptr, *d_sel_sc = nullptr;
   int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_n_final = nullptr, *d_cor_n = nullptr;
   uint32_t* d_cor = nullptr;     // FAST corner lists, one region per k_fast_score wavefront
@@ -67,7 +68,9 @@ struct uvo_extractor {
   uvo_extractor_cfg cfg;
   int device = 0;
   Lane lane[kMaxLanes];
-  int nlanes = 1, cur = 0;
+  int nlanes = 1, cur = 0;  // cur = the lane of the most recent batch
+  OctLaunchState oct;       // quad-tree launch shape + what has been configured on this handle's device
+  uint8_t* d_grid_score = nullptr;  // score plane of the Grider_FAST mode (allocated on first use)
   // constructor tables (src/ORBextractor.cc:463-511)
   std::vector<float> scale, inv_scale;
   std::vector<int> quota;
@@ -307,7 +310,7 @@ static int set_geometry(uvo_extractor* h, int width, int height) {
   for (int b = 1; b <= h->cfg.max_batch; b = b < 16 ? b + 1 : h->cfg.max_batch) {
     const int rps = fast_rows_per_seg(b);
     const size_t it = (size_t)fast_items_per_frame(g, rps);
-    if ((size_t)b * it * (size_t)fast_region_entries(rps) > h->cap_cor || (size_t)b * it > h->cap_cor_n ||
+    if ((size_t)b * it * (size_t)FS_REGION_ENTRIES > h->cap_cor || (size_t)b * it > h->cap_cor_n ||
         (size_t)h->cfg.max_batch * fast_flags_per_frame(g) > h->cap_flags)
       return fail(UVO_E_BADARG, "image larger than the handle was sized for");
     if (b == h->cfg.max_batch) break;
@@ -337,8 +340,12 @@ struct ProfScope : Profiler::Scope {
   ProfScope(uvo_extractor* h, const char* name) : Profiler::Scope(&h->lane[h->cur].prof, name, h->lane[h->cur].stream) {}
 };
 
-// The launch sequence of one batch (everything on h->lane[h->cur].stream, nothing synchronous).
-static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
+// The lane the next batch runs on.  With pipeline depth > 1 consecutive batches alternate; whoever stages inputs for a batch
+// (uploads, CLAHE) must enqueue them on this lane's stream, and read results back from it.
+static inline int next_lane(const uvo_extractor* h) { return h->nlanes > 1 ? (h->cur + 1) % h->nlanes : h->cur; }
+
+// The launch sequence of one batch: everything on lane `li`'s stream, nothing synchronous.  Makes `li` the current lane.
+static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* d_imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
                             const uvo_keypoint* d_in_kp, const int32_t* d_n_in, int32_t* d_grid2d, int grid_rows, int grid_cols,
                             int min_px_dist, int full_detect, const int32_t* d_nfn, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap,
                             int32_t* d_n_out) {
@@ -347,47 +354,50 @@ static int run_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, 
   if (width < 1 || height < 1 || stride < width || cap < 1) return fail(UVO_E_BADARG, "bad image size / stride / cap");
   if (!full_detect && (!d_grid2d || !d_nfn || min_px_dist < 1 || grid_rows < 1 || grid_cols < 1))
     return fail(UVO_E_BADARG, "top-up mode needs grid2d, num_feats_needed and min_px_dist >= 1");
+  // the occupancy filter indexes grid_2d(int(y / d), int(x / d)) for every pixel position (src/ORBextractor.cc:884-891; the call
+  // site allocates rows / d + 2 by cols / d + 2, src/Tracking.cc:930-934): a smaller grid would be indexed out of bounds
+  if (!full_detect && (grid_rows <= (height - 1) / min_px_dist || grid_cols <= (width - 1) / min_px_dist))
+    return fail(UVO_E_BADARG, "grid2d smaller than ceil(image / min_px_dist)");
   UVO_HIP_CHECK(hipSetDevice(h->device));
   int rc = set_geometry(h, width, height);
   if (rc) return rc;
-  if (h->nlanes > 1) h->cur = (h->cur + 1) % h->nlanes;  // pipeline depth 2: alternate lanes
-  hipStream_t s = h->lane[h->cur].stream;
+  h->cur = li;
+  Lane& L = h->lane[li];
+  hipStream_t s = L.stream;
   h->last_batch = batch;
   const Geom& g = h->geom;
   {
     ProfScope p(h, "k_pad_level0");
-    launch_pad_level0(s, d_imgs, width, height, stride, frame_stride, h->lane[h->cur].d_pyr, g.pyr_block, g.lv[0], batch);
+    launch_pad_level0(s, d_imgs, width, height, stride, frame_stride, L.d_pyr, g.pyr_block, g.lv[0], batch);
   }
   for (int l = 1; l < g.nlevels; ++l) {
     ProfScope p(h, "k_resize_level");
-    launch_resize_level(s, h->lane[h->cur].d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_ctab + g.lv[l].xtab_off, h->d_rtab + g.lv[l].ytab_off,
-                        h->resize_fast[l], batch);
+    launch_resize_level(s, L.d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_ctab + g.lv[l].xtab_off, h->d_rtab + g.lv[l].ytab_off, h->resize_fast[l],
+                        batch);
   }
   {  // the per-cell threshold vote + candidate emit run inside k_octree
-    const int stage = 0;
     ProfScope p(h, "k_fast_score");
-    launch_fast_stage(s, stage, h->lane[h->cur].d_pyr, h->lane[h->cur].d_score, g.pyr_block, h->d_lv, g, h->cfg.fast_th, h->lane[h->cur].d_cor,
-                      h->lane[h->cur].d_cor_n, h->lane[h->cur].d_cell_hi, h->lane[h->cur].d_cand_xy, h->lane[h->cur].d_cand_sc, g.cand_block,
-                      h->lane[h->cur].d_cand_count, batch);
+    launch_fast_score(s, L.d_pyr, g.pyr_block, g, h->cfg.fast_th, L.d_cor, L.d_cor_n, L.d_cell_hi, batch);
   }
   {
     ProfScope p(h, "k_gauss7");
-    launch_gauss7(s, h->lane[h->cur].d_pyr, h->lane[h->cur].d_blur, g.pyr_block, h->d_lv, g, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), batch);
+    launch_gauss7(s, L.d_pyr, L.d_blur, g.pyr_block, h->d_lv, g, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), batch);
   }
   {
     ProfScope p(h, "k_octree");
-    launch_octree(s, h->d_lv, g, h->cfg.fast_th, h->lane[h->cur].d_cor, h->lane[h->cur].d_cor_n, h->lane[h->cur].d_cell_hi, h->lane[h->cur].d_cand_xy, h->lane[h->cur].d_cand_sc, g.cand_block, h->lane[h->cur].d_cand_count, h->lane[h->cur].d_pstate, h->lane[h->cur].d_sel_xy, h->lane[h->cur].d_sel_sc,
-                  h->lane[h->cur].d_sel_count, batch);
+    rc = launch_octree(s, h->oct, h->d_lv, g, h->cfg.fast_th, L.d_cor, L.d_cor_n, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count,
+                       L.d_pstate, L.d_sel_xy, L.d_sel_sc, L.d_sel_count, batch);
+    if (rc) return rc;
   }
   {
     ProfScope p(h, "k_assemble");
-    launch_assemble(s, h->d_lv, g, h->lane[h->cur].d_sel_xy, h->lane[h->cur].d_sel_sc, h->lane[h->cur].d_sel_count, d_in_kp, d_n_in, h->cfg.max_input_keypoints, d_grid2d, grid_rows,
-                    grid_cols, min_px_dist, full_detect, d_nfn, h->lane[h->cur].d_flist, h->lane[h->cur].d_n_final, batch);
+    launch_assemble(s, h->d_lv, g, L.d_sel_xy, L.d_sel_sc, L.d_sel_count, d_in_kp, d_n_in, h->cfg.max_input_keypoints, d_grid2d, grid_rows, grid_cols,
+                    min_px_dist, full_detect, d_nfn, L.d_flist, L.d_n_final, batch);
   }
   {
     ProfScope p(h, "k_describe");
-    launch_describe(s, h->d_lv, g, h->lane[h->cur].d_pyr, h->lane[h->cur].d_blur, g.pyr_block, h->lane[h->cur].d_flist, h->lane[h->cur].d_n_final, d_in_kp, h->cfg.max_input_keypoints,
-                    h->d_pattern, h->d_patch, d_out_kp, d_out_desc, cap, d_n_out, batch);
+    launch_describe(s, h->d_lv, g, L.d_pyr, L.d_blur, g.pyr_block, L.d_flist, L.d_n_final, d_in_kp, h->cfg.max_input_keypoints, h->d_pattern,
+                    h->d_patch, d_out_kp, d_out_desc, cap, d_n_out, batch);
   }
   UVO_HIP_CHECK(hipGetLastError());
   return UVO_OK;
@@ -410,7 +420,6 @@ static int alloc_lane(uvo_extractor* h, int li) {
   if ((rc = (call)) != UVO_OK) return rc;
   AL(dev_alloc(&L.d_pyr, B * h->cap_pyr_block));
   AL(dev_alloc(&L.d_blur, B * h->cap_pyr_block + 256));  // + slack: k_describe reads whole dwords up to 3 bytes past a row end
-  AL(dev_alloc(&L.d_score, B * h->cap_pyr_block));
   AL(dev_alloc(&L.d_cand_xy, B * h->cap_cand_block));
   AL(dev_alloc(&L.d_cand_sc, B * h->cap_cand_block));
   AL(dev_alloc(&L.d_pstate, B * h->cap_cand_block));
@@ -496,7 +505,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
     for (int b = 1; b <= (int)B; b = b < 16 ? b + 1 : (int)B) {
       const int rps = fast_rows_per_seg(b);
       const size_t it = (size_t)fast_items_per_frame(g, rps) + 8;
-      ce = std::max(ce, (size_t)b * it * (size_t)fast_region_entries(rps));
+      ce = std::max(ce, (size_t)b * it * (size_t)FS_REGION_ENTRIES);
       cn = std::max(cn, (size_t)b * it);
       if (b == (int)B) break;
     }
@@ -548,14 +557,14 @@ void uvo_extractor_destroy(uvo_extractor* h) {
     Lane& L = h->lane[i];
     if (L.stream) (void)hipStreamSynchronize(L.stream);
     L.prof.clear();
-    void* lp[] = {L.d_pyr,   L.d_blur,   L.d_score,      L.d_cand_xy,   L.d_cand_sc, L.d_pstate, L.d_sel_xy, L.d_sel_sc,
+    void* lp[] = {L.d_pyr,   L.d_blur,   L.d_cand_xy,   L.d_cand_sc, L.d_pstate, L.d_sel_xy, L.d_sel_sc,
                   L.d_cand_count, L.d_sel_count, L.d_n_final, L.d_cor_n, L.d_cor, L.d_cell_hi, L.d_flist, L.a_imgs, L.a_kp, L.a_desc, L.a_n};
     for (void* p : lp)
       if (p) (void)hipFree(p);
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
   void* ptrs[] = {h->d_clahe_lut, h->d_clahe_out, h->d_lv, h->d_cells, h->d_ctab, h->d_rtab, h->d_pattern, h->d_patch, h->d_imgs, h->d_out_kp,
-                  h->d_out_desc, h->d_n_out, h->d_in_kp, h->d_n_in, h->d_nfn, h->d_grid};
+                  h->d_out_desc, h->d_n_out, h->d_in_kp, h->d_n_in, h->d_nfn, h->d_grid, h->d_grid_score};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->h_pin) (void)hipHostFree(h->h_pin);
@@ -582,7 +591,7 @@ int uvo_extract_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs,
                              int grid_cols, int min_px_dist, int full_detect, const int32_t* d_num_feats_needed, uvo_keypoint* d_out_kp,
                              uint8_t* d_out_desc, int cap, int32_t* d_n_out) {
   if (!h) return fail(UVO_E_BADARG, "null handle");
-  return run_batch_device(h, batch, d_imgs, width, height, stride, frame_stride, d_in_kp, d_n_in, d_grid2d, grid_rows, grid_cols, min_px_dist,
+  return run_batch_device(h, next_lane(h), batch, d_imgs, width, height, stride, frame_stride, d_in_kp, d_n_in, d_grid2d, grid_rows, grid_cols, min_px_dist,
                           full_detect, d_num_feats_needed, d_out_kp, d_out_desc, cap, d_n_out);
 }
 
@@ -627,7 +636,7 @@ int uvo_clahe_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, i
   float scale;
   int rc = clahe_setup(h, batch, width, height, clip_limit, tiles_x, tiles_y, &tw, &th, &clip, &scale);
   if (rc) return rc;
-  Lane& L = h->lane[h->cur];
+  Lane& L = h->lane[next_lane(h)];  // the lane of the extraction that consumes d_dst (same stream: in order behind this kernel)
   {
     Profiler::Scope ps(&L.prof, "k_clahe", L.stream);
     launch_clahe(L.stream, d_imgs, width, height, stride, frame_stride, batch, tiles_x, tiles_y, tw, th, clip, scale, h->d_clahe_lut, d_dst, dst_stride,
@@ -648,7 +657,7 @@ int uvo_clahe(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdi
     int rc = dev_alloc(&h->d_clahe_out, (size_t)h->cfg.max_width * h->cfg.max_height);
     if (rc) return rc;
   }
-  hipStream_t s = h->lane[h->cur].stream;
+  hipStream_t s = h->lane[next_lane(h)].stream;  // the stream uvo_clahe_batch_device() enqueues on
   UVO_HIP_CHECK(hipMemcpy2DAsync(h->d_imgs, width, img, stride, width, (size_t)height, hipMemcpyHostToDevice, s));
   int rc = uvo_clahe_batch_device(h, 1, h->d_imgs, width, height, width, (ptrdiff_t)width * height, clip_limit, tiles_x, tiles_y, h->d_clahe_out, width,
                                   (ptrdiff_t)width * height);
@@ -669,6 +678,18 @@ int uvo_extractor_synchronize(uvo_extractor* h) {
   if (!h) return fail(UVO_E_BADARG, "null handle");
   UVO_HIP_CHECK(hipSetDevice(h->device));
   return sync_all_lanes(h);
+}
+
+int uvo_extractor_tune(uvo_extractor* h, int knob, int value) {
+  if (!h) return fail(UVO_E_BADARG, "null handle");
+  switch (knob) {
+    case UVO_TUNE_OCT_WIDE_MAX:
+      if (value < 0) return fail(UVO_E_BADARG, "knob value must be >= 0");
+      h->oct.wide_max_problems = value;
+      return UVO_OK;
+    default:
+      return fail(UVO_E_BADARG, "unknown knob");
+  }
 }
 
 int uvo_extractor_set_pipeline(uvo_extractor* h, int depth) {
@@ -700,7 +721,9 @@ int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int widt
     return fail(UVO_E_BADARG, "image size outside what the handle was sized for");
   if ((int64_t)width * height > (int64_t)h->cfg.max_width * h->cfg.max_height) return fail(UVO_E_BADARG, "image too large");
   UVO_HIP_CHECK(hipSetDevice(h->device));
-  hipStream_t s = h->lane[h->cur].stream;
+  // uploads, kernels and downloads of this call share one lane: the one the batch is about to run on
+  const int li = next_lane(h);
+  hipStream_t s = h->lane[li].stream;
   const int in_cap = h->cfg.max_input_keypoints;
   // the reference reads the centre pixel row of a caller keypoint without any bounds check; reject what would
   // leave the padded plane (patch radius 15 + descriptor reach 18 against a 16 px pad)
@@ -793,7 +816,7 @@ int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int widt
       }
     }
   }
-  int rc = run_batch_device(h, batch, d_frames, width, height, width, (ptrdiff_t)width * height, have_in ? h->d_in_kp : nullptr,
+  int rc = run_batch_device(h, li, batch, d_frames, width, height, width, (ptrdiff_t)width * height, have_in ? h->d_in_kp : nullptr,
                             have_in ? h->d_n_in : nullptr, topup ? h->d_grid : nullptr, grid_rows, grid_cols, min_px_dist, full_detect,
                             topup ? h->d_nfn : nullptr, h->d_out_kp, h->d_out_desc, dcap, h->d_n_out);
   if (rc) return rc;
@@ -864,7 +887,7 @@ int uvo_extract_batch_submit(uvo_extractor* h, int batch, const uint8_t* imgs, i
   UVO_HIP_CHECK(hipSetDevice(h->device));
   int rc = set_geometry(h, width, height);  // before the lane is chosen: a geometry change waits for every lane
   if (rc) return rc;
-  const int li = h->nlanes > 1 ? (h->cur + 1) % h->nlanes : h->cur;  // the lane run_batch_device() is about to use
+  const int li = next_lane(h);
   Lane& L = h->lane[li];
   if (L.a_batch) return fail(UVO_E_BADARG, "the next lane still has a batch in flight: wait for it first");
   if (!L.a_imgs) {
@@ -881,10 +904,9 @@ int uvo_extract_batch_submit(uvo_extractor* h, int batch, const uint8_t* imgs, i
       UVO_HIP_CHECK(hipMemcpy2DAsync(L.a_imgs + (size_t)b * width * height, width, imgs + (size_t)b * frame_stride, stride, width, (size_t)height,
                                      hipMemcpyHostToDevice, s));
   }
-  rc = run_batch_device(h, batch, L.a_imgs, width, height, width, (ptrdiff_t)width * height, nullptr, nullptr, nullptr, 0, 0, 0, 1, nullptr, L.a_kp,
+  rc = run_batch_device(h, li, batch, L.a_imgs, width, height, width, (ptrdiff_t)width * height, nullptr, nullptr, nullptr, 0, 0, 0, 1, nullptr, L.a_kp,
                         L.a_desc, dcap, L.a_n);
   if (rc) return rc;
-  if (h->cur != li) return fail(UVO_E_HIP, "internal: lane bookkeeping out of step");
   // results: whole per-frame slices (a frame holds at most dcap records), frame b lands at b * cap of the caller's arrays
   UVO_HIP_CHECK(hipMemcpyAsync(n_out, L.a_n, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
   UVO_HIP_CHECK(hipMemcpy2DAsync(out_kp, (size_t)cap * sizeof(uvo_keypoint), L.a_kp, (size_t)dcap * sizeof(uvo_keypoint),
@@ -930,17 +952,18 @@ int uvo_grider_fast(uvo_extractor* h, const uint8_t* img, int width, int height,
   const int rois = (width / size_x) * (height / size_y);
   const int keep = num_features / (grid_x * grid_y) + 1;
   Lane& L = h->lane[0];
-  if ((size_t)width * height > h->cap_cor || (size_t)rois > h->cap_cor_n || (int64_t)width * height > (int64_t)h->cfg.max_batch * h->cap_pyr_block)
+  if ((size_t)width * height > h->cap_cor || (size_t)rois > h->cap_cor_n)
     return fail(UVO_E_BADARG, "image / grid larger than the handle's scratch");
   const int64_t dcap = (int64_t)h->cfg.max_batch * h->cap_flist;
   if ((int64_t)rois * keep > dcap) return fail(UVO_E_CAPACITY, "num_features + cells exceeds the handle's output staging");
   UVO_HIP_CHECK(hipSetDevice(h->device));
   int rcs = sync_all_lanes(h);
   if (rcs) return rcs;
+  if (!h->d_grid_score && (rcs = dev_alloc(&h->d_grid_score, (size_t)h->cfg.max_width * h->cfg.max_height))) return rcs;
   hipStream_t s = L.stream;
   UVO_HIP_CHECK(hipMemcpy2DAsync(h->d_imgs, width, img, stride, width, (size_t)height, hipMemcpyHostToDevice, s));
   UVO_HIP_CHECK(hipMemsetAsync(h->d_n_out, 0, sizeof(int32_t), s));
-  launch_grider(s, h->d_imgs, width, height, width, num_features, grid_x, grid_y, threshold, nonmax_suppression ? 1 : 0, L.d_score, L.d_cor,
+  launch_grider(s, h->d_imgs, width, height, width, num_features, grid_x, grid_y, threshold, nonmax_suppression ? 1 : 0, h->d_grid_score, L.d_cor,
                 L.d_cor_n, h->d_out_kp, (int)std::min<int64_t>(dcap, 1 << 30), h->d_n_out);
   UVO_HIP_CHECK(hipGetLastError());
   int32_t n = 0;

@@ -338,11 +338,8 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
 // Rows per (strip, segment) work item.  A wavefront lives for the whole item, so long segments leave a long under-filled
 // tail at the end of the launch (96 rows: +20 % kernel time over 24..32), and the NMS tile of a region has to fit its LDS.
 // A single frame has only ~160 items of 24 rows for 1024 SIMDs: short segments (8 rows of work under 8 halo rows) spread it over
-// three times as many wavefronts and halve the time of the launch (UVO_FAST_ROWS_SMALL overrides, for experiments).
-int fast_rows_per_seg(int batch) {
-  static const int small = getenv("UVO_FAST_ROWS_SMALL") ? atoi(getenv("UVO_FAST_ROWS_SMALL")) : 8;
-  return batch <= 2 ? (small < FS_ROWS_MAX ? small : FS_ROWS_MAX) : FS_ROWS_MAX;
-}
+// three times as many wavefronts and halve the time of the launch.
+int fast_rows_per_seg(int batch) { return batch <= 2 ? 8 : FS_ROWS_MAX; }
 int fast_items_per_frame(const Geom& g, int rows_per_seg) {
   int items = 0;
   for (int l = 0; l < g.nlevels; ++l) {
@@ -351,10 +348,6 @@ int fast_items_per_frame(const Geom& g, int rows_per_seg) {
     items += F.items;
   }
   return items;
-}
-int64_t fast_region_entries(int rows_per_seg) {
-  (void)rows_per_seg;
-  return FS_REGION_ENTRIES;
 }
 int fast_flags_per_frame(const Geom& g) {
   int n = 0;
@@ -390,12 +383,9 @@ FastLevels fast_levels(const Geom& g, int batch) {
   return L;
 }
 
-// scores + in-cell NMS per region; d_score / d_lv and the candidate arrays are not touched here any more (see octree.hip)
-void launch_fast_stage(hipStream_t s, int stage, const uint8_t* d_pyr, uint8_t* d_score, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g,
-                       int fast_th, uint32_t* d_cor, int32_t* d_cor_n, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc,
-                       int64_t cand_block, int32_t* d_cand_count, int batch) {
-  (void)d_score, (void)d_lv, (void)d_cand_xy, (void)d_cand_sc, (void)cand_block, (void)d_cand_count;
-  if (stage != 0) return;
+// scores + in-cell NMS per region (the per-cell vote and the candidate emit: octree.hip)
+void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, int fast_th, uint32_t* d_cor, int32_t* d_cor_n,
+                       uint8_t* d_cell_hi, int batch) {
   const int t_min = fast_th < 7 ? fast_th : 7;
   const FastLevels L = fast_levels(g, batch);
   const dim3 grid((L.items_per_frame + 3) / 4, batch);

@@ -28,6 +28,8 @@ __device__ __forceinline__ int popc256(const uint4& qa, const uint4& qb, const u
   return d;
 }
 
+__device__ __forceinline__ int clamp_count(int n, int cap) { return n < 0 ? 0 : (n > cap ? cap : n); }
+
 // grid: (ceil(max_query/256), pairs).  Ties keep the lower train index (strict <, ascending scan).
 __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, const int32_t* __restrict__ nq_arr, int nq_fixed, int q_stride,
                                               const uint8_t* __restrict__ t, const int32_t* __restrict__ nt_arr, int nt_fixed, int t_stride,
@@ -35,8 +37,10 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
                                               uint16_t* __restrict__ d0, int32_t* __restrict__ idx1, uint16_t* __restrict__ d1) {
   __shared__ uint4 s_t[HM_TILE * 2];
   const int pair = blockIdx.y;
-  const int nq = nq_arr ? nq_arr[pair] : nq_fixed;
-  const int nt = nt_arr ? nt_arr[pair] : nt_fixed;
+  // counts come from device arrays (an extractor's n_out may exceed the caller's capacity): never walk past a slice
+  // (fixed counts were validated on the host)
+  const int nq = nq_arr ? clamp_count(nq_arr[pair], q_stride < out_stride ? q_stride : out_stride) : nq_fixed;
+  const int nt = nt_arr ? clamp_count(nt_arr[pair], t_stride < 65535 ? t_stride : 65535) : nt_fixed;  // the key packs the train index in 16 bits
   const int qi = blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x * 256 >= nq) return;
   const uint4* Q = reinterpret_cast<const uint4*>(q + (int64_t)pair * q_stride * 32);
@@ -100,8 +104,10 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t* __restrict__ q
   __shared__ __attribute__((aligned(16))) uint8_t s_exp[32 * KM_ROW];
   __shared__ __attribute__((aligned(16))) int32_t s_key[32];
   const int pair = blockIdx.y;
-  const int nq = nq_arr ? nq_arr[pair] : nq_fixed;
-  const int nt = nt_arr ? nt_arr[pair] : nt_fixed;
+  // counts come from device arrays (an extractor's n_out may exceed the caller's capacity): never walk past a slice
+  // (fixed counts were validated on the host)
+  const int nq = nq_arr ? clamp_count(nq_arr[pair], q_stride < out_stride ? q_stride : out_stride) : nq_fixed;
+  const int nt = nt_arr ? clamp_count(nt_arr[pair], t_stride < 65535 ? t_stride : 65535) : nt_fixed;  // the key packs the train index in 16 bits
   if (blockIdx.x * 128 >= nq) return;
   const int lane = threadIdx.x & 63, wv = wave_in_block();
   const int r = lane & 31, h = lane >> 5;

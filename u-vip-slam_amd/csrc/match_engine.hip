@@ -315,12 +315,18 @@ __global__ __launch_bounds__(1024) void k_rot_filter(int nq, const float* __rest
   auto bin_of = [&](int i) -> int {
     float rot = qangle[i] - tangle[match[i]];
     if (rot < 0.0) rot += 360.0f;
+    // the reference asserts bin >= 0 && bin < HISTO_LENGTH (e.g. src/ORBmatcher.cc:237); angles outside [0, 360) or NaN would
+    // break that: such a match lands in no bin (-2 is never a kept bin) and is dropped below
+    if (!(rot >= 0.0f && rot < 360.0f * 1.05f)) return -2;
     int bin = (int)roundf(rot * factor);
     if (bin == HISTO_LENGTH) bin = 0;
-    return bin;
+    return bin >= 0 && bin < HISTO_LENGTH ? bin : -2;
   };
   for (int i = threadIdx.x; i < nq; i += blockDim.x)
-    if (match[i] >= 0) atomicAdd(&s_hist[bin_of(i)], 1);
+    if (match[i] >= 0) {
+      const int b = bin_of(i);
+      if (b >= 0) atomicAdd(&s_hist[b], 1);
+    }
   __syncthreads();
   if (threadIdx.x == 0) {
     int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;

@@ -151,6 +151,9 @@ int uvo_hamming_knn2_batch_device(uvo_matcher* m, int pairs, const uint8_t* d_q,
                                   const int32_t* d_nt, int t_stride, int32_t* d_idx0, uint16_t* d_d0, int32_t* d_idx1, uint16_t* d_d1) {
   if (!m || !d_q || !d_t || !d_nq || !d_nt || !d_idx0 || !d_d0 || !d_idx1 || !d_d1) return matcher_fail(UVO_E_BADARG, "null pointer");
   if (pairs < 1 || pairs > m->cfg.max_batch || q_stride < 1 || t_stride < 1) return matcher_fail(UVO_E_BADARG, "bad batch / stride");
+  // the launch covers max_query rows per pair and the outputs are [pairs][max_query]: a wider query slice would lose rows silently
+  if (q_stride > m->cfg.max_query) return matcher_fail(UVO_E_BADARG, "q_stride above the handle's max_query");
+  if (t_stride > 65535) return matcher_fail(UVO_E_BADARG, "t_stride above 65535 (train indices are packed in 16 bits)");
   UVO_HIP_CHECK(hipSetDevice(m->device));
   {
     Profiler::Scope ps(&m->prof, "k_knn2", m->stream);

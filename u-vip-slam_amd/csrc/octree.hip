@@ -15,15 +15,10 @@ static inline int oct_capacity(int N, int nIni) {
   int m = N > 4 * nIni ? N : 4 * nIni;
   return m + 8;
 }
-// at most this many (frame, level) problems run as 1024-thread workgroups (one per CU: beyond 256 problems the chip is full
-// either way, and four independent 256-thread problems per CU use it better).  Measured, 640x512 / 8 levels, kernel span:
-// 60 vs 81 us at batch 1, 75 vs 125 us at batch 32; at batch 128 wide still has the shorter span (240 vs 290 us) but the
-// pipelined throughput of configs[3] drops 5 %, and at batch 256 it is 10 % down.  UVO_OCT_WIDE_MAX overrides for experiments.
-static int oct_wide_max_problems() {
-  const char* e = getenv("UVO_OCT_WIDE_MAX");
-  return e ? atoi(e) : 256;
-}
-static const int kOctWideMaxProblems = oct_wide_max_problems();
+// OctLaunchState::wide_max_problems: at most this many (frame, level) problems run as 1024-thread workgroups (one per CU: beyond
+// 256 problems the chip is full either way, and four independent 256-thread problems per CU use it better).  Measured, 640x512 /
+// 8 levels, kernel span: 60 vs 81 us at batch 1, 75 vs 125 us at batch 32; at batch 128 wide still has the shorter span (240 vs
+// 290 us) but the pipelined throughput of configs[3] drops 5 %, and at batch 256 it is 10 % down.
 static inline int pow2_ge(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -169,7 +164,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
   if (threadIdx.x == 0) *out_n = n;
 }
 
-void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, int fast_th, const uint32_t* d_cor, const int32_t* d_cor_n,
+int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, int fast_th, const uint32_t* d_cor, const int32_t* d_cor_n,
                    uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
                    int32_t* d_sel_count, int batch) {
   int M = 0;
@@ -180,14 +175,13 @@ void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, int fast
   const int Mp2 = pow2_ge(M);
   // The kernel is latency bound (a few dozen dependent phases per problem): the per-candidate state lives in registers,
   // the node tables in LDS, and the grid is level-major so that the long level-0 problems are dispatched first.
-  const bool wide = batch * g.nlevels <= kOctWideMaxProblems;
+  const bool wide = batch * g.nlevels <= st.wide_max_problems;
   const int threads = wide ? 1024 : OCT_THREADS;
   const size_t lds = oct_lds_bytes(M, Mp2);
-  static size_t configured = 0;
-  if (lds > 64 * 1024 && lds > configured) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<OCT_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured = lds;
+  if (lds > 64 * 1024 && lds > st.lds_configured) {  // the attribute is per device: every handle raises it for its own
+    UVO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<OCT_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    UVO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    st.lds_configured = lds;
   }
 #ifdef UVO_OCT_TRACE
   {
@@ -209,6 +203,7 @@ void launch_octree(hipStream_t s, const LevelGeom* d_lv, const Geom& g, int fast
     hipLaunchKernelGGL(k_octree<OCT_THREADS>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, fast_levels(g, batch), fast_th,
                        d_cor, d_cor_n, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block,
                        d_sel_count);
+  return UVO_OK;
 }
 
 }  // namespace uvo

@@ -2,9 +2,9 @@
 // Free of HIP headers so that the host-side tests can compile it with a plain C++ compiler (tests/emu/strip_plan_emu.cpp).
 #pragma once
 #if defined(__HIPCC__)
-#define UVO_HD __host__ __device__
+#define UVO_PLAN_HD __host__ __device__
 #else
-#define UVO_HD
+#define UVO_PLAN_HD
 #endif
 
 namespace uvo {
@@ -15,9 +15,9 @@ constexpr int FS_COLS = 248;  // useful columns per wavefront strip (lanes 1..62
 // columns, and a wavefront that owns a 5-pixel remainder costs as much as a full one.  So the remainder is cut into narrow strips
 // of at most 120 (two segments side by side, 32 lanes each) or 56 columns (four segments, 16 lanes each); a remainder wider than
 // 176 columns stays one ordinary strip.  Columns owned by a sub-strip of L lanes: 4 L - 8 (its first and last lane are halo).
-UVO_HD inline int fast_sub_cols(int sub) { return 256 / sub - 8; }
+UVO_PLAN_HD inline int fast_sub_cols(int sub) { return 256 / sub - 8; }
 template <class PlanT>
-UVO_HD inline void fast_strip_plan(int window_w, int window_h, int rows_per_seg, PlanT& F) {
+UVO_PLAN_HD inline void fast_strip_plan(int window_w, int window_h, int rows_per_seg, PlanT& F) {
   F.nseg = (window_h + rows_per_seg - 1) / rows_per_seg;
   F.nfull = window_w / FS_COLS;
   int rem = window_w - F.nfull * FS_COLS, x = F.nfull * FS_COLS;
@@ -45,7 +45,7 @@ UVO_HD inline void fast_strip_plan(int window_w, int window_h, int rows_per_seg,
 
 // item of a planned level -> (first window column of the strip, first segment, sub-strips)
 template <class PlanT>
-UVO_HD inline void fast_strip_item(const PlanT& F, int item, int& strip_x, int& seg, int& sub) {
+UVO_PLAN_HD inline void fast_strip_item(const PlanT& F, int item, int& strip_x, int& seg, int& sub) {
   if (item < F.nfull * F.nseg) {
     strip_x = (item % F.nfull) * FS_COLS, seg = item / F.nfull, sub = 1;
   } else {
@@ -65,7 +65,7 @@ struct StripPlan {
 // Workgroups are dealt round-robin over the 8 XCDs (workgroups b and b + 8 share an XCD and its L2).  This maps the linear
 // workgroup index to a virtual one such that each XCD walks a contiguous range of virtual indices: neighbouring work items
 // (strips / segments that re-read each other's halo rows) then meet in one L2.  Speed only, never correctness.
-UVO_HD inline int xcd_contiguous(int b, int total) {
+UVO_PLAN_HD inline int xcd_contiguous(int b, int total) {
   const int per = total >> 3, rem = total & 7;  // the first `rem` XCDs own per + 1 workgroups
   const int x = b & 7, i = b >> 3;
   return x < rem ? x * (per + 1) + i : rem * (per + 1) + (x - rem) * per + i;

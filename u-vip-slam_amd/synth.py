@@ -78,3 +78,19 @@ def warp_frame(img, seed):
 
 def make_batch(n, w=640, h=512, seed0=1000):
     return np.stack([make_frame(seed0 + i, w, h) for i in range(n)])
+
+
+def make_sequence(first, count, w=640, h=512, chain=32, n_shapes=400, seed_base=1000):
+    """Frames [first, first + count) of the global synthetic sequence bench.py and the sharding tests use: frame g starts a new
+    chain when g % chain == 0 (make_frame, seed seed_base + g), otherwise it is the previous frame warped (seed seed_base + g), so
+    consecutive frames truly correspond.  Any shard of the sequence can be generated on its own (it replays its first chain from
+    the chain's start), which is what lets every rank / device produce its frames and its neighbour's halo frame independently."""
+    out = []
+    g = first - first % chain
+    prev = None
+    while g < first + count:
+        prev = make_frame(seed_base + g, w, h, n_shapes) if g % chain == 0 else warp_frame(prev, seed_base + g)
+        if g >= first:
+            out.append(prev)
+        g += 1
+    return np.stack(out) if out else np.zeros((0, h, w), np.uint8)
