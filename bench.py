@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of ORB extract + match on MI355X (BASELINE.json metric).
 
-A step = one pass of the hot path over one batch of synthetic frames, all inputs already resident in HBM:
-  uvo_extract_batch_device  (pyramid -> per-cell FAST -> quad-tree -> IC angle -> blur -> rBRIEF, B frames)
-  uvo_hamming_knn2_batch_device (frame i vs frame i+1, all-pairs 256-bit Hamming knn-2, B pairs)
-Workload at N=1: BASELINE.json configs[2] -- batch=256 synthetic 640x512 mono frames, 1000 features, 8 levels,
-fastTh 20.  With N GPUs every rank owns its own batch of 256 frames (frame batches shard embarrassingly; weak
-scaling, no data-path collective: torch.distributed/RCCL is used for the timing barrier and the max-over-ranks only).
+A step = one pass of the hot path over one rank's batch of synthetic frames, all inputs already resident in HBM:
+  uvo_extract_batch_device       (pyramid -> per-cell FAST -> quad-tree -> IC angle -> blur -> rBRIEF; B frames + 1 halo frame)
+  uvo_hamming_knn2_batch_device  (frame i vs frame i+1, all-pairs 256-bit Hamming knn-2, B pairs)
+Workloads (--config): 2 = BASELINE.json configs[2], the configuration the metric is quoted on (batch 256 synthetic 640x512 mono
+frames per GPU, 1000 features, 8 levels, fastTh 20; default); 3 = configs[3] (1920x1080 @ 2000 features, 128 frames per GPU).
+With N GPUs (one process per GPU) rank r owns frames [r*B, (r+1)*B) of ONE global synthetic sequence and its matching pair B-1 uses
+the NEIGHBOURING rank's first frame, recomputed locally as a 1-frame halo: weak scaling, no data-path collective
+(torch.distributed / RCCL carries the timing barrier and the max-over-ranks only).
 
-Prints ONE JSON line on rank 0.  `roofline` is for the kernel with the largest share of device time, its duration
-measured live with HIP events on the library's own stream inside the timed region; `cpu_baseline` is the CPU
-oracle (a line-by-line port of the reference path) timed on this host's cores on a bounded sample of the same frames.
+`value` is the HBM-resident rate.  The same line carries: the host-to-host rate through uvo_sharder_run (uploads of page-locked
+frames + the gather of all ranks' results into one page-locked host region, `host_to_host`), sub-records for configs[1] (batch-1
+latency), extract-only and configs[4] (fused frustum search), both roofs of the dominant kernel (`roofline`: HBM bytes and VALU
+issue), a measured device-copy bandwidth next to the 8 TB/s spec, `verified_frames` (outputs of the TIMED buffers compared with
+the CPU oracle after the timed region; a mismatch fails the run) and `cpu_baseline` (the CPU oracle -- a line-by-line port of the
+reference path -- timed on this host's cores on bounded samples).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import importlib
 import json
+import mmap
 import os
+import subprocess
 import sys
 import time
 
@@ -25,12 +32,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-W, H, NFEAT, NLEVELS, FAST_TH = 640, 512, 1000, 8, 20
-BATCH = 256
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy kernel reaches
+NLEVELS, FAST_TH, SCALE = 8, 20, 1.2
+CONFIGS = {
+    2: dict(name="BASELINE.json configs[2]", W=640, H=512, nfeat=1000, batch=256, n_shapes=400, steps=100),
+    3: dict(name="BASELINE.json configs[3]", W=1920, H=1080, nfeat=2000, batch=128, n_shapes=2500, steps=30),
+}
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the measured device-copy rate is reported beside it
+VALU_PEAK_GINSTR = 1228.8        # wave-instructions/s the chip can issue: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 op on a SIMD32
 
 
-def level_sizes(w, h, nlevels=NLEVELS, sf=1.2):
+def level_sizes(w, h, nlevels=NLEVELS, sf=SCALE):
     inv = np.float32(1.0)
     step = np.float32(np.float32(1.0) / np.float64(np.float32(sf)))
     out = []
@@ -48,8 +59,9 @@ def algorithmic_bytes_per_frame(w, h, k):
     return {
         "k_pad_level0": 2 * s[0],                       # not in the survey's model (a design that reads the input in place needs none)
         "k_resize_level": sum(s[:-1]) + sum(s[1:]),     # reads S0..S6, writes S1..S7 (all 7 launches)
-        "k_fast_score": tot,                            # reads every level once (the score plane it writes is scratch)
+        "k_fast_score": tot,                            # reads every level once
         "k_gauss7": 2 * tot,
+        "k_fast_blur": 3 * tot,                         # the fused form: one read serves FAST and the blur, one write
         "k_octree": 0,
         "k_assemble": 0,
         "k_describe": 749 * k + (512 + 32) * k + 20 * k,
@@ -57,21 +69,10 @@ def algorithmic_bytes_per_frame(w, h, k):
     }
 
 
-def gen_frames(synth, n, seed0):
-    """n frames: chains of a base frame followed by small-affine warps, so consecutive frames truly correspond."""
-    chain = 32
-    out = []
-    for i in range(n):
-        if i % chain == 0:
-            out.append(synth.make_frame(seed0 + i, W, H))
-        else:
-            out.append(synth.warp_frame(out[-1], seed0 + i))
-    return np.stack(out)
-
-
-def shard_seed0(rank, batch):
-    """Frames shard embarrassingly: rank r owns frames [r*batch, (r+1)*batch) of the synthetic sequence."""
-    return 1000 + rank * batch
+def shard_frames(rank, world, batch):
+    """Frames shard embarrassingly: rank r owns frames [r*batch, (r+1)*batch) of the global sequence; its halo is the neighbouring
+    rank's first frame (the last rank wraps to frame 0 so that every rank does the same work).  -> (first_frame, halo_frame)"""
+    return rank * batch, ((rank + 1) * batch) % (world * batch)
 
 
 def timed_steps(step, sync, steps, dist=None, device=None):
@@ -94,36 +95,212 @@ def timed_steps(step, sync, steps, dist=None, device=None):
     return dt
 
 
-def cpu_baseline(frames, budget_s=12.0):
-    """The oracle (kind 'port') on one host core: extract the sample frames one after another (cycling through this run's batch),
-    knn-2 match consecutive ones, until about budget_s seconds of CPU work have been timed."""
+# ------------------------------------------------------------------------------------------------ CPU baseline (the checker, timed)
+def _cpu_info():
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return model, len(phys) or (os.cpu_count() or 1), os.cpu_count() or 1
+
+
+def _oracle(native=False):
     import oracle_lib
-    o = oracle_lib.Oracle()
-    oe = o.extractor(NFEAT, 1.2, NLEVELS, FAST_TH)
+    if not native:
+        return oracle_lib.Oracle()
+    # -march=native must be built on the host it runs on
+    subprocess.check_call(["make", "-s", "-C", oracle_lib.ORACLE_DIR, "liborb_oracle_native.so"])
+    return oracle_lib.Oracle(os.path.join(oracle_lib.ORACLE_DIR, "liborb_oracle_native.so"))
+
+
+def _time_extract_match(o, frames, nfeat, budget_s, match=True):
+    oe = o.extractor(nfeat, SCALE, NLEVELS, FAST_TH)
     t0 = time.perf_counter()
-    prev = None
-    n = 0
+    prev, n = None, 0
     while time.perf_counter() - t0 < budget_s:
-        img = frames[n % len(frames)]
-        kp, de = oe(img)
-        if prev is not None and len(prev) and len(de):
+        kp, de = oe(frames[n % len(frames)])
+        if match and prev is not None and len(prev) and len(de):
             o.knn2(prev, de)
         prev = de
         n += 1
+    return n, time.perf_counter() - t0
+
+
+def _time_threads(o, frames, nfeat, budget_s, threads):
+    """One frame per thread (ctypes releases the GIL inside the oracle; every thread owns its extractor)."""
+    from concurrent.futures import ThreadPoolExecutor
+    counts = [0] * threads
+    t0 = time.perf_counter()
+
+    def work(i):
+        oe = o.extractor(nfeat, SCALE, NLEVELS, FAST_TH)
+        prev, n = None, 0
+        while time.perf_counter() - t0 < budget_s:
+            kp, de = oe(frames[(i + n * threads) % len(frames)])
+            if prev is not None and len(prev) and len(de):
+                o.knn2(prev, de)
+            prev = de
+            n += 1
+        counts[i] = n
+
+    with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(work, range(threads)))
+    return sum(counts), time.perf_counter() - t0
+
+
+def cpu_baseline(frames, cfg, c4=None):
+    """The oracle (kind 'port') on this host.  Headline row = BASELINE.md CPU-1 (1 core, -O3 without -march=native, mirroring the
+    reference's CMakeLists.txt:19-22); `rows` holds the other rows of BASELINE.md section 2, each on a bounded sample."""
+    model, phys, logical = _cpu_info()
+    nfeat = cfg["nfeat"]
+    what = "%dx%d, %d feats, %d levels, fastTh %d" % (cfg["W"], cfg["H"], nfeat, NLEVELS, FAST_TH)
+    o = _oracle()
+    n1, dt1 = _time_extract_match(o, frames, nfeat, 8.0)
+    rows = {"CPU-1": {"frames_per_s": round(n1 / dt1, 3), "cores": 1, "flags": "-O3", "what": "extract + knn-2 of consecutive frames, " + what, "frames": n1}}
+    try:
+        on = _oracle(native=True)
+        n, dt = _time_extract_match(on, frames, nfeat, 4.0)
+        rows["CPU-1n"] = {"frames_per_s": round(n / dt, 3), "cores": 1, "flags": "-O3 -march=native", "what": "same", "frames": n}
+        n, dt = _time_threads(on, frames, nfeat, 5.0, phys)
+        rows["CPU-N"] = {"frames_per_s": round(n / dt, 3), "cores": phys, "flags": "-O3 -march=native", "frames": n,
+                         "what": "same, one frame per thread on all physical cores"}
+    except (OSError, subprocess.CalledProcessError) as e:  # no compiler on the box: the rows are simply absent
+        rows["CPU-1n"] = {"error": str(e)[:200]}
+    # CPU-M: the matcher alone (all-pairs knn-2 + ratio test of include/utils.h:81-111 on two consecutive frames' descriptors)
+    oe = o.extractor(nfeat, SCALE, NLEVELS, FAST_TH)
+    d0, d1 = oe(frames[0])[1], oe(frames[1])[1]
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 2.0:
+        i0, dd0, i1, dd1 = o.knn2(d0, d1)
+        (dd0 <= 0.8 * dd1).sum()
+        n += 1
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames drawn in order from this run's 640x512 batch: oracle extract (1000 feats, 8 levels, fastTh 20) + knn-2 match of consecutive "
-                      "frames, 1 thread, g++ -O3 without -march=native" % n}
+    rows["CPU-M"] = {"pairs_per_s": round(n / dt, 2), "cores": 1, "flags": "-O3", "what": "all-pairs knn-2 + ratio 0.8, %d x %d descriptors" % (len(d0), len(d1))}
+    if c4 is not None:  # CPU-P: isInFrustum + SearchByProjection(Frame, MapPoints, th) of configs[4]
+        kp, de, sf, mp, cam_o = c4
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 2.0:
+            ov, ou, ovv, ol, ovc = o.project_points(0, cam_o, mp["xyz"], mp["normal"], mp["min_distance"], mp["max_distance"], None, sf, 1.2, 0.5)
+            a = np.full(len(kp), -1, np.int32)
+            nm = o.search_by_projection(kp, de, (0, 0, 752, 480), a, ou, ovv, ol, ovc, ov, mp["mp_desc"], sf, 1.0, 0.8)
+            n += 1
+        dt = time.perf_counter() - t0
+        rows["CPU-P"] = {"calls_per_s": round(n / dt, 2), "ms_per_call": round(dt / n * 1e3, 3), "cores": 1, "flags": "-O3", "matches": int(nm),
+                         "what": "isInFrustum + SearchByProjection, 752x480 frame (%d kp) vs 5000 map points" % len(kp)}
+    return {"value": rows["CPU-1"]["frames_per_s"], "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames drawn in order from this run's batch: oracle extract (%s) + knn-2 match of consecutive frames, 1 thread, g++ -O3 "
+                      "without -march=native (BASELINE.md row CPU-1)" % (n1, what),
+            "host": {"cpu_model": model, "physical_cores": phys, "logical_cpus": logical}, "rows": rows}
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+class SharedHostRegion:
+    """One host region every rank gathers into.  One rank: page-locked memory from uvo_host_alloc.  Several ranks (processes): one
+    /dev/shm mapping, page-locked in every process with uvo_host_register, so each rank's device-to-host copies land at their final
+    offsets of the SAME physical pages -- the gather of north_star, with no collective."""
+
+    def __init__(self, uvo, nbytes, rank, world, dist):
+        self.uvo, self.nbytes, self.registered, self.mm, self.path = uvo, nbytes, True, None, None
+        if world == 1:
+            self.buf = uvo.pinned_empty((nbytes,), np.uint8)
+            return
+        name = [None]
+        if rank == 0:
+            name[0] = "/dev/shm/uvo_bench_%d_%d" % (os.getpid(), int(time.time() * 1e3) % 100000)
+            with open(name[0], "wb") as fh:
+                fh.truncate(nbytes)
+        dist.broadcast_object_list(name, src=0)
+        self.path = name[0]
+        fd = os.open(self.path, os.O_RDWR)
+        self.mm = mmap.mmap(fd, nbytes)
+        os.close(fd)
+        self.buf = np.frombuffer(self.mm, dtype=np.uint8)
+        try:
+            uvo.host_register(self.buf)
+        except uvo.UvoError:
+            self.registered = False   # still correct: the copies just stop being asynchronous
+
+    def carve(self, offset, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        return self.buf[offset:offset + n].view(dtype).reshape(shape), (offset + n + 255) // 256 * 256
+
+    def close(self, rank, dist):
+        if self.mm is not None:
+            if self.registered:
+                self.uvo.host_unregister(self.buf)
+            if dist is not None:
+                dist.barrier()
+            if rank == 0:
+                os.unlink(self.path)
+
+
+def device_copy_gbps(torch, dev):
+    """Measured device-to-device copy bandwidth (read + write bytes / time) of one 1 GiB buffer: what a pure streaming kernel reaches."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    a.fill_(1)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del a, b
+    return 2.0 * n * 10 / dt / 1e9
+
+
+def load_pmc(config, dom):
+    """Counters of the dominant kernel from the committed rocprofv3 PMC passes of this same command (separate --pmc runs; the newest
+    profiles/r*_pmc.json recorded for this config): HBM bytes per launch (2 * FETCH_SIZE + WRITE_SIZE, in KB as counted: FETCH_SIZE
+    under-reports reads by 2x on gfx950) and VALU wave-instructions per launch."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                j = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if int(j.get("_config", 2)) != config:
+            continue
+        e = j.get("kernels", {}).get(dom)
+        if not e:
+            continue
+        traffic = int((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024) if "FETCH_SIZE" in e and "WRITE_SIZE" in e else None
+        return traffic, e.get("SQ_INSTS_VALU"), "profiles/" + os.path.basename(path)
+    return None, None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)  # 100 x 1.6 ms: long enough that filling and draining the two lanes is noise
+    ap.add_argument("--steps", type=int, default=None)   # default: 100 (config 2) / 30 (config 3) -- long enough that filling the two lanes is noise
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-subrecords", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    W, H, NFEAT = cfg["W"], cfg["H"], cfg["nfeat"]
+    B = args.batch or cfg["batch"]
+    steps = args.steps or cfg["steps"]
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -140,21 +317,26 @@ def main():
 
     uvo = importlib.import_module("u-vip-slam_amd")
     synth = importlib.import_module("u-vip-slam_amd.synth")
-    B = args.batch
+    workloads = importlib.import_module("u-vip-slam_amd.workloads")
     dev = torch.device("cuda", local_rank)
 
-    frames = gen_frames(synth, B, shard_seed0(rank, B))   # every rank its own shard of the sequence
+    # this rank's shard of the global sequence + the neighbour's first frame, in page-locked host memory (the host-to-host leg uploads
+    # from here); slot B of the device copy is the halo
+    first, halo = shard_frames(rank, world, B)
+    frames = uvo.pinned_empty((B + 1, H, W), np.uint8)
+    frames[:B] = synth.make_sequence(first, B, W, H, n_shapes=cfg["n_shapes"])
+    frames[B] = synth.make_sequence(halo, 1, W, H, n_shapes=cfg["n_shapes"])[0]
     d_imgs = torch.from_numpy(frames).to(dev)
 
-    ex = uvo.ORBextractor(NFEAT, 1.2, NLEVELS, 0, FAST_TH, max_width=W, max_height=H, max_batch=B, device=local_rank)
+    ex = uvo.ORBextractor(NFEAT, SCALE, NLEVELS, 0, FAST_TH, max_width=W, max_height=H, max_batch=B + 1, device=local_rank)
     cap = ex.cap
     mt = uvo.ORBmatcher(0.8, max_query=cap, max_train=cap, max_batch=B, device=local_rank)
-    # outputs stay in HBM, double buffered: with pipeline depth 2 the extractor alternates between two scratch sets /
-    # streams, so batch i+1's streaming stages overlap batch i's latency-bound stages and its matching.
-    # One extra descriptor slot per buffer holds a copy of frame 0 so that pair B-1 = (frame B-1, frame 0).
+
+    # outputs stay in HBM, double buffered: with pipeline depth 2 the extractor alternates between two scratch sets / streams, so
+    # batch i+1's streaming stages overlap batch i's latency-bound stages and its matching.
     class Out:
         def __init__(self):
-            self.kp = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+            self.kp = torch.zeros((B + 1, cap, 7), dtype=torch.float32, device=dev)
             self.desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
             self.n = torch.zeros(B + 1, dtype=torch.int32, device=dev)
             self.idx0 = torch.zeros((B, cap), dtype=torch.int32, device=dev)
@@ -168,11 +350,16 @@ def main():
     torch.cuda.synchronize()
     counter = [0]
 
-    def step():
+    def extract_only():
         o = outs[counter[0] % DEPTH]
         counter[0] += 1
-        ex.extract_batch_device(d_imgs.data_ptr(), B, W, H, o.kp.data_ptr(), o.desc.data_ptr(), o.n.data_ptr(), cap)
+        ex.extract_batch_device(d_imgs.data_ptr(), B + 1, W, H, o.kp.data_ptr(), o.desc.data_ptr(), o.n.data_ptr(), cap)
+        return o
+
+    def step():
+        o = extract_only()
         mt.wait_extractor(ex)
+        # pair p = (frame p, frame p + 1), p < B; pair B-1's partner is the halo frame in slot B
         mt.knn2_batch_device(B, o.desc.data_ptr(), o.n.data_ptr(), cap, o.desc.data_ptr() + cap * 32, o.n.data_ptr() + 4, cap,
                              o.idx0.data_ptr(), o.d0.data_ptr(), o.idx1.data_ptr(), o.d1.data_ptr())
         mt.release_to_extractor(ex)
@@ -182,14 +369,7 @@ def main():
         mt.synchronize()
         torch.cuda.synchronize()
 
-    # frame 0's descriptors into slot B of each buffer (halo for the wrap-around pair); they do not change between steps
-    for _ in range(DEPTH):
-        step()
-    sync_all()
-    for o in outs:
-        o.desc[B].copy_(o.desc[0])
-        o.n[B] = o.n[0]
-    for _ in range(args.warmup):
+    for _ in range(args.warmup + DEPTH):
         step()
     sync_all()
 
@@ -216,70 +396,214 @@ def main():
         mt.profile(True)
     else:
         ex.profile(True, only=dom)
-    dt = timed_steps(step, sync_all, args.steps, dist, dev)
+    dt = timed_steps(step, sync_all, steps, dist, dev)
     ktimes = dict(ex.kernel_times())
     ktimes.update(mt.kernel_times())
     ex.profile(False)
     mt.profile(False)
 
-    n_kp = outs[0].n[:B].cpu().numpy()
-    matches = int((outs[0].idx1.cpu().numpy() >= 0).sum())
+    # ---- the timed buffers, on the host (both lanes' last results) ----
+    host = []
+    for o in outs:
+        host.append(dict(n=o.n.cpu().numpy(), kp=o.kp.cpu().numpy().view(np.uint8).reshape(B + 1, cap, 28), de=o.desc.cpu().numpy(), i0=o.idx0.cpu().numpy(),
+                         i1=o.idx1.cpu().numpy(), d0=o.d0.cpu().numpy().astype(np.uint16), d1=o.d1.cpu().numpy().astype(np.uint16)))
+    n_kp = host[0]["n"][:B]
+
+    # ---- verification of the timed outputs against the CPU oracle (rank 0; a mismatch fails the run) ----
+    verified = None
+    if rank == 0 and not args.no_verify:
+        import oracle_lib
+        orc = oracle_lib.Oracle()
+        oe = orc.extractor(NFEAT, SCALE, NLEVELS, FAST_TH)
+        pairs = sorted(set([0, B // 4, B // 2 - 1, B - 2, B - 1]))   # (p, p + 1); B - 1 pairs with the halo frame
+        need = sorted(set(pairs) | set(p + 1 for p in pairs))
+        ref = {f: oe(frames[f]) for f in need}
+        for li, hb in enumerate(host):
+            for f in need:
+                kp_o, de_o = ref[f]
+                n = int(hb["n"][f])
+                if n != len(kp_o) or hb["kp"][f, :n].tobytes() != kp_o.tobytes() or not (hb["de"][f, :n] == de_o).all():
+                    raise SystemExit("bench.py: VERIFICATION FAILED -- lane %d frame %d of the timed buffers differs from the oracle" % (li, f))
+            for p in pairs:
+                r = orc.knn2(ref[p][1], ref[p + 1][1])
+                nq = len(ref[p][1])
+                got = (hb["i0"][p, :nq], hb["d0"][p, :nq].astype(np.int32), hb["i1"][p, :nq], hb["d1"][p, :nq].astype(np.int32))
+                if not all((g == e).all() for g, e in zip(got, r)):
+                    raise SystemExit("bench.py: VERIFICATION FAILED -- lane %d knn-2 rows of pair %d differ from the oracle" % (li, p))
+        verified = {"frames": len(need) * len(host), "distinct_frames": need, "knn2_pairs": pairs, "lanes": len(host), "against": "CPU oracle, byte for byte"}
+
+    # ---- host-to-host leg: the sharder (uploads from page-locked frames, results gathered into ONE host region shared by all ranks) ----
+    sub = {}
+    h2h = None
+    if not args.no_subrecords:
+        total = world * B
+        chunk = max(B // 2, 1)            # two chunks per rank in flight: the upload of one under the kernels of the other
+        devices = [uvo.UVO_SHARD_REMOTE] * world
+        devices[rank] = local_rank
+        sh = uvo.Sharder(NFEAT, SCALE, NLEVELS, FAST_TH, max_width=W, max_height=H, devices=devices, chunk_frames=chunk, match=True)
+        scap = sh.cap
+        assert scap == cap
+        sizes = [((total, scap), uvo.KEYPOINT_DTYPE), ((total, scap, 32), np.uint8), ((total,), np.int32), ((total, scap), np.int32),
+                 ((total, scap), np.uint16), ((total, scap), np.int32), ((total, scap), np.uint16)]
+        nbytes = sum(int(np.prod(s)) * np.dtype(t).itemsize + 256 for s, t in sizes)
+        region = SharedHostRegion(uvo, nbytes, rank, world, dist)
+        arrs, off = [], 0
+        for s, t in sizes:
+            a, off = region.carve(off, s, t)
+            arrs.append(a)
+        g_kp, g_de, g_n, g_i0, g_d0, g_i1, g_d1 = arrs
+
+        def h2h_run():
+            # frames of this rank start at global index `first`; its halo frame sits right behind them in `frames` (for the last
+            # rank the job simply ends there: the wrap-around pair exists only in the HBM-resident leg)
+            sh.run(frames, first, total, g_kp, g_de, g_n, g_i0, g_d0, g_i1, g_d1)
+
+        for _ in range(2):
+            h2h_run()
+        reps = max(4, min(20, steps // 5))
+        dth = timed_steps(h2h_run, lambda: None, reps, dist, dev)
+        # the gathered region must hold exactly what the HBM-resident leg produced (this rank's block; pair B-1 only where the halo
+        # is the true next frame)
+        hb = host[0]
+        ok = (g_n[first:first + B] == hb["n"][:B]).all()
+        for f in range(B):
+            n = int(hb["n"][f])
+            ok = ok and g_kp[first + f, :n].tobytes() == hb["kp"][f, :n].tobytes() and (g_de[first + f, :n] == hb["de"][f, :n]).all()
+        npairs = B if first + B < total else B - 1
+        for p in range(npairs):
+            nq = int(hb["n"][p])
+            ok = ok and (g_i0[first + p, :nq] == hb["i0"][p, :nq]).all() and (g_d0[first + p, :nq] == hb["d0"][p, :nq]).all() and \
+                (g_i1[first + p, :nq] == hb["i1"][p, :nq]).all() and (g_d1[first + p, :nq] == hb["d1"][p, :nq]).all()
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        if dist is not None:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            raise SystemExit("bench.py: VERIFICATION FAILED -- the gathered host region differs from the HBM-resident outputs")
+        if rank == 0 and world > 1:   # rank 0 sees every rank's block in the one region
+            assert (g_n[:total] > 0).all(), "a rank's block is missing from the gathered region"
+        up = B * W * H + (W * H if first + B < total else 0)
+        down = B * scap * (28 + 32) + B * 4 + npairs * scap * 12
+        h2h = {"value": round(total * reps / dth, 1), "unit": "frames/s", "ms_per_job": round(dth / reps * 1e3, 3), "frames_per_job": total,
+               "chunk_frames": chunk, "pcie_bytes_up_per_rank": up, "pcie_bytes_down_per_rank": down, "gather": "device-to-host copies at precomputed "
+               "offsets of one page-locked region shared by all ranks (%s)" % ("uvo_host_alloc" if world == 1 else "/dev/shm mapping + uvo_host_register" +
+                                                                                  ("" if region.registered else " [registration failed: pageable]")),
+               "gathered_equals_hbm_resident": True}
+        sh.close()
+        region.close(rank, dist)
+
+    # ---- sub-records on rank 0 (the other ranks idle at the barrier below) ----
+    c4_cpu = None
+    if rank == 0 and not args.no_subrecords:
+        # extract only
+        for _ in range(DEPTH):
+            extract_only()
+        sync_all()
+        n_eo = max(10, steps // 3)
+        t0 = time.perf_counter()
+        for _ in range(n_eo):
+            extract_only()
+        sync_all()
+        sub["extract_only"] = {"frames_per_s": round(B * n_eo / (time.perf_counter() - t0), 1), "note": "same batch (+1 halo frame extracted, not counted), no matching"}
+        # configs[1]: batch-1 latency
+        ex1 = uvo.ORBextractor(NFEAT, SCALE, NLEVELS, 0, FAST_TH, max_width=W, max_height=H, max_batch=1, device=local_rank)
+        o1 = (torch.zeros((1, ex1.cap, 7), dtype=torch.float32, device=dev), torch.zeros((1, ex1.cap, 32), dtype=torch.uint8, device=dev),
+              torch.zeros(1, dtype=torch.int32, device=dev))
+        lat_dev, lat_host = [], []
+        for i in range(260):
+            t0 = time.perf_counter()
+            ex1.extract_batch_device(d_imgs.data_ptr() + (i % B) * W * H, 1, W, H, o1[0].data_ptr(), o1[1].data_ptr(), o1[2].data_ptr(), ex1.cap)
+            ex1.synchronize()
+            lat_dev.append(time.perf_counter() - t0)
+        for i in range(130):
+            t0 = time.perf_counter()
+            ex1(frames[i % B])
+            lat_host.append(time.perf_counter() - t0)
+        sub["configs[1] batch-1 latency"] = {"ms_hbm_resident_median": round(float(np.median(lat_dev[60:])) * 1e3, 4),
+                                             "ms_host_in_host_out_median": round(float(np.median(lat_host[30:])) * 1e3, 4),
+                                             "ms_host_in_host_out_p95": round(float(np.percentile(lat_host[30:], 95)) * 1e3, 4)}
+        ex1.close()
+        # configs[4]: 752x480 extract + isInFrustum + SearchByProjection vs 5000 map points, as one fused call
+        W4, H4 = workloads.EUROC_W, workloads.EUROC_H
+        img4 = synth.make_frame(31337, W4, H4)
+        ex4 = uvo.ORBextractor(1000, SCALE, NLEVELS, 0, 7, max_width=W4, max_height=H4, device=local_rank)
+        m4 = uvo.ORBmatcher(0.8, max_query=4096, max_map_points=8192, device=local_rank)
+        kp4, de4 = ex4(img4)
+        sf4 = ex4.mvScaleFactor.copy()
+        mp = workloads.config4_local_map(kp4, de4, sf4)
+        cam = uvo.CameraPose.make(mp["R"], mp["t"], mp["Ow"], workloads.EUROC_FX, workloads.EUROC_FY, workloads.EUROC_CX, workloads.EUROC_CY, (0, 0, W4, H4))
+        ts = []
+        for i in range(70):
+            t0 = time.perf_counter()
+            k, d_ = ex4(img4)
+            a = np.full(len(k), -1, np.int32)
+            nm = m4.SearchPointsInFrustum(k, d_, a, cam, mp["xyz"], mp["normal"], mp["min_distance"], mp["max_distance"], None, mp["mp_desc"], sf4, 1.2, 0.5, 1.0)[0]
+            ts.append(time.perf_counter() - t0)
+        sub["configs[4] extract + fused frustum search"] = {"ms_per_frame_median": round(float(np.median(ts[10:])) * 1e3, 4), "matches": int(nm), "keypoints": len(kp4),
+                                                            "map_points": 5000, "note": "752x480, fastTh 7, host buffers in and out"}
+        cam_o = np.concatenate([mp["R"].reshape(9), mp["t"], mp["Ow"], np.float32([workloads.EUROC_FX, workloads.EUROC_FY, workloads.EUROC_CX, workloads.EUROC_CY]),
+                                np.float32([0, W4, 0, H4])]).astype(np.float32)
+        c4_cpu = (kp4, de4, sf4, mp, cam_o)
+        ex4.close()
+        m4.close()
+        sub["device_copy_GBps"] = round(device_copy_gbps(torch, dev), 1)
 
     if rank == 0:
-        frames_total = B * args.steps * world
+        frames_total = B * steps * world
         value = frames_total / dt
         k_mean = float(n_kp.mean())
         alg = algorithmic_bytes_per_frame(W, H, k_mean)
         # dominant kernel by device time (all launches of a name together), its launches inside the timed region
         dom_ms, dom_launches = ktimes[dom]
-        # per launch: k_resize_level is launched once per level, its model is for all 7 together
-        launches_per_step = dom_launches / args.steps
+        launches_per_step = dom_launches / steps          # k_resize_level is launched once per level, its model is for all 7 together
         avg_launch_s = dom_ms * 1e-3 / dom_launches
-        bytes_per_launch = alg.get(dom, 0) * B / launches_per_step
+        bytes_per_launch = alg.get(dom, 0) * (B + 1) / launches_per_step
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        total_alg = sum(v for kname, v in alg.items() if kname != "k_pad_level0")
-        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command (separate --pmc runs,
-        # the newest profiles/r*_pmc.json; FETCH_SIZE under-reports reads by 2x on gfx950): bytes per launch, or null if not recorded
-        traffic, traffic_src = None, None
-        try:
-            import glob
-            pmc_path = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc.json")))[-1]
-            with open(pmc_path) as fh:
-                e = json.load(fh)["kernels"].get(dom)
-            if e and "FETCH_SIZE" in e and "WRITE_SIZE" in e:
-                traffic = int((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024)
-                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH + WRITE)" % os.path.basename(pmc_path)
-        except (OSError, ValueError, KeyError, IndexError):
-            pass
+        total_alg = sum(v for kname, v in alg.items() if kname not in ("k_pad_level0", "k_fast_blur"))
+        traffic, valu_instr, pmc_src = load_pmc(args.config, dom)
+        hbm_frac = achieved / HBM_PEAK_GBS
+        roof_hbm = {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 5),
+                    "algorithmic_bytes_per_launch": int(bytes_per_launch), "measured_device_copy_GBps": sub.get("device_copy_GBps")}
+        roof = dict(roof_hbm)
+        bound = "hbm"
+        roof_valu = None
+        if valu_instr:
+            ginstr = valu_instr / avg_launch_s / 1e9
+            roof_valu = {"achieved": round(ginstr, 2), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": round(ginstr / VALU_PEAK_GINSTR, 5),
+                         "valu_wave_instructions_per_launch": int(valu_instr)}
+            if roof_valu["frac"] > hbm_frac:
+                bound, roof = "valu", dict(roof_valu)
         out = {
-            "metric": "frames/sec ORB extract+match, 640x512 @1000 kp",
+            "metric": "frames/sec ORB extract+match, %dx%d @%d kp" % (W, H, NFEAT),
             "value": round(value, 1),
             "unit": "frames/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "ms_per_step": round(dt / steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: 1xMI355X per rank, batch=%d synthetic %dx%d mono frames, %d feats, %d levels, "
-                                   "fastTh %d, FullDetect extract + all-pairs 256-bit Hamming knn-2 of consecutive frames, HBM-resident I/O"
-                                   % (B, W, H, NFEAT, NLEVELS, FAST_TH),
-                       "batch_per_gpu": B, "sharding": "frames, no collective", "pipeline_depth": DEPTH, "mean_keypoints_per_frame": round(k_mean, 1),
-                       "knn2_second_neighbours_found": matches},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_launch_ms": round(avg_launch_s * 1e3, 5), "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                         "whole_path_GBps": round(total_alg * value / world / 1e9, 2),
-                         "kernel_ms_per_step_in_timed_region": {k: round(v[0] / args.steps, 4) for k, v in sorted(ktimes.items())},
-                         "kernel_ms_per_step_unoverlapped": {k: round(v[0] / 3, 4) for k, v in sorted(serial.items())},
-                         "note": "k_fast_score (FAST segment test) is integer-VALU bound, not HBM bound (PMC: ~77 lane-ops per pixel, see "
-                                 "DESIGN.md section 7); the HBM fraction is reported because the contract asks for it"},
+            "config": {"workload": "%s: 1xMI355X per rank, batch=%d synthetic %dx%d mono frames (+1 halo frame: the neighbouring rank's first), %d feats, "
+                                   "%d levels, fastTh %d, FullDetect extract + all-pairs 256-bit Hamming knn-2 of consecutive frames, HBM-resident I/O"
+                                   % (cfg["name"], B, W, H, NFEAT, NLEVELS, FAST_TH),
+                       "batch_per_gpu": B, "sharding": "contiguous frame blocks of one global sequence, 1-frame halo from the neighbour, no collective",
+                       "pipeline_depth": DEPTH, "mean_keypoints_per_frame": round(k_mean, 1)},
+            "verified_frames": verified["frames"] if verified else 0,
+            "verification": verified,
+            "roofline": dict(roof, bound=bound, kernel=dom, traffic=traffic, traffic_source=pmc_src, avg_launch_ms=round(avg_launch_s * 1e3, 5),
+                             hbm=roof_hbm, valu=roof_valu, whole_path_GBps=round(total_alg * value / world / 1e9, 2),
+                             kernel_ms_per_step_in_timed_region={k: round(v[0] / steps, 4) for k, v in sorted(ktimes.items())},
+                             kernel_ms_per_step_unoverlapped={k: round(v[0] / 3, 4) for k, v in sorted(serial.items())},
+                             note="both roofs of the dominant kernel: HBM = algorithmic bytes / live launch time against 8 TB/s; VALU = SQ_INSTS_VALU per "
+                                  "launch (committed rocprofv3 --pmc pass of this command) / live launch time against the chip's wave-instruction issue "
+                                  "peak; `bound` is the larger fraction"),
+            "host_to_host": h2h,
+            "sub_records": sub,
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
-            out["cpu_baseline"] = cpu_baseline(frames)
+            out["cpu_baseline"] = cpu_baseline(frames[:B], cfg, c4_cpu)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -117,6 +117,54 @@ int uvo_host_free(void* ptr);
 int uvo_extract_batch_submit(uvo_extractor* h, int batch, const uint8_t* imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
                              uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int* ticket);
 int uvo_extract_batch_wait(uvo_extractor* h, int ticket);
+/* Page-lock memory the caller already owns (e.g. a shared mapping that several processes gather into); uvo_host_alloc()'s sibling. */
+int uvo_host_register(void* ptr, size_t bytes);
+int uvo_host_unregister(void* ptr);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sharder -- one job of `total` frames over N GPUs of one node, no collective.
+ * The reference has one extractor call per frame on one thread (src/Tracking.cc:946); an offline
+ * mapping run (BASELINE.json configs[3]) is that call over a whole sequence.  Frames are independent:
+ * shard i owns one contiguous block, runs it on its own device from its own host thread in chunks
+ * (two in flight: the upload of one under the kernels of the other), and every chunk's results are
+ * copied straight to element frame * cap of ONE set of caller arrays -- the gather is those copies.
+ * With match = 1 pair p = (frame p, frame p + 1) is matched (all-pairs knn-2, uvo_hamming_knn2) by the
+ * shard that owns frame p; the last pair of a chunk needs the next frame's descriptors, so a chunk
+ * extracts one halo frame beyond its own (at a shard's end: the neighbouring shard's first frame,
+ * recomputed here, bit-identical to the neighbour's own copy) rather than exchanging descriptors.
+ * ---------------------------------------------------------------------------------------------- */
+#define UVO_SHARD_MAX 64
+#define UVO_SHARD_REMOTE (-1) /* devices[i]: shard i is run by another process (same plan, same offsets) */
+typedef struct uvo_sharder uvo_sharder;
+typedef struct uvo_sharder_cfg {
+  uvo_extractor_cfg extractor;    /* device / max_batch / max_input_keypoints are set per shard by the sharder */
+  int32_t n_shards;
+  int32_t devices[UVO_SHARD_MAX]; /* HIP device ordinal of shard i (ordinals may repeat), or UVO_SHARD_REMOTE */
+  int32_t chunk_frames;           /* frames per chunk (per device launch sequence); device scratch is sized for chunk_frames + 1 */
+  int32_t match;                  /* 1: also the knn-2 rows of consecutive frames */
+} uvo_sharder_cfg;
+/* The block of shard `shard` and what it matches -- pure arithmetic, no device needed. */
+typedef struct uvo_shard_plan {
+  int32_t first_frame, n_frames; /* frames [first_frame, first_frame + n_frames): results at element first_frame * cap of the outputs */
+  int32_t first_pair, n_pairs;   /* pairs p = (p, p + 1), p in [first_pair, first_pair + n_pairs): rows at element p * cap */
+  int32_t halo_frame;            /* the neighbouring shard's first frame, extracted here too for the block's last pair; -1 = none */
+  int32_t n_chunks;
+} uvo_shard_plan;
+int uvo_shard_plan_make(int total_frames, int n_shards, int shard, int chunk_frames, uvo_shard_plan* out);
+int uvo_sharder_create(const uvo_sharder_cfg* cfg, uvo_sharder** out);
+void uvo_sharder_destroy(uvo_sharder* s);
+int uvo_sharder_max_keypoints(const uvo_sharder* s); /* smallest `cap` uvo_sharder_run accepts */
+/*
+ * Run the local shards of a job (blocks until their results are in the output arrays).
+ *   imgs             : host frames, frame g at imgs + (g - imgs_first_frame) * frame_stride (a process that owns only some shards
+ *                      need only hold their frames and each block's halo frame); page-locked memory makes the uploads asynchronous
+ *   out_kp / out_desc / n_out : [total][cap] / [total][cap][32] / [total]   (cap >= uvo_sharder_max_keypoints())
+ *   idx0 / d0 / idx1 / d1     : [total - 1][cap] knn-2 rows of pair p (row q = keypoint q of frame p; as uvo_hamming_knn2), or all NULL
+ * Only the elements of the local shards' frames / pairs are written.
+ */
+int uvo_sharder_run(uvo_sharder* s, const uint8_t* imgs, int imgs_first_frame, int total_frames, int width, int height, ptrdiff_t stride,
+                    ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int32_t* idx0, uint16_t* d0,
+                    int32_t* idx1, uint16_t* d1);
 
 /*
  * HBM-resident form: every pointer is a device pointer on the handle's GPU and the call only enqueues work

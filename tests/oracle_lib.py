@@ -20,8 +20,9 @@ def build_oracle():
 
 
 class Oracle:
-    def __init__(self):
-        self.L = L = ctypes.CDLL(build_oracle())
+    def __init__(self, lib_path=None):
+        """lib_path: another build of the same sources (bench.py's -march=native row); default = liborb_oracle.so, built on demand."""
+        self.L = L = ctypes.CDLL(lib_path or build_oracle())
         vp, ci, cf, cl = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long
         L.orc_extractor_create.restype = vp
         L.orc_extractor_create.argtypes = [ci, cf, ci, ci]

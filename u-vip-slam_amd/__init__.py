@@ -27,7 +27,7 @@ UVO_TUNE_OCT_WIDE_MAX = 1
 # every symbol include/uvo/uvo.h declares
 ABI_SYMBOLS = [
     "uvo_extractor_create", "uvo_extractor_destroy", "uvo_extractor_levels", "uvo_extractor_max_keypoints", "uvo_extractor_scale_factor", "uvo_extractor_tables",
-    "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_host_alloc", "uvo_host_free", "uvo_extract_batch_submit", "uvo_extract_batch_wait", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_tune", "uvo_extractor_level_dims",
+    "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_host_alloc", "uvo_host_free", "uvo_host_register", "uvo_host_unregister", "uvo_shard_plan_make", "uvo_sharder_create", "uvo_sharder_destroy", "uvo_sharder_max_keypoints", "uvo_sharder_run", "uvo_extract_batch_submit", "uvo_extract_batch_wait", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_tune", "uvo_extractor_level_dims",
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_profile_only", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
@@ -105,6 +105,19 @@ class ExtractorCfg(ctypes.Structure):
                 ("max_input_keypoints", ctypes.c_int32), ("device", ctypes.c_int32)]
 
 
+UVO_SHARD_MAX, UVO_SHARD_REMOTE = 64, -1
+
+
+class SharderCfg(ctypes.Structure):
+    _fields_ = [("extractor", ExtractorCfg), ("n_shards", ctypes.c_int32), ("devices", ctypes.c_int32 * UVO_SHARD_MAX), ("chunk_frames", ctypes.c_int32),
+                ("match", ctypes.c_int32)]
+
+
+class ShardPlan(ctypes.Structure):
+    _fields_ = [("first_frame", ctypes.c_int32), ("n_frames", ctypes.c_int32), ("first_pair", ctypes.c_int32), ("n_pairs", ctypes.c_int32),
+                ("halo_frame", ctypes.c_int32), ("n_chunks", ctypes.c_int32)]
+
+
 class MatcherCfg(ctypes.Structure):
     _fields_ = [("max_query", ctypes.c_int32), ("max_train", ctypes.c_int32), ("max_batch", ctypes.c_int32), ("max_map_points", ctypes.c_int32),
                 ("device", ctypes.c_int32)]
@@ -130,6 +143,14 @@ def _load():
     lib.uvo_extract_batch_device.argtypes = [vp, ci, vp, ci, ci, cl, cl, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
     lib.uvo_host_alloc.argtypes = [vp, ctypes.c_size_t]
     lib.uvo_host_free.argtypes = [vp]
+    lib.uvo_host_register.argtypes = [vp, ctypes.c_size_t]
+    lib.uvo_host_unregister.argtypes = [vp]
+    lib.uvo_shard_plan_make.argtypes = [ci, ci, ci, ci, ctypes.POINTER(ShardPlan)]
+    lib.uvo_sharder_create.argtypes = [ctypes.POINTER(SharderCfg), ctypes.POINTER(vp)]
+    lib.uvo_sharder_destroy.argtypes = [vp]
+    lib.uvo_sharder_destroy.restype = None
+    lib.uvo_sharder_max_keypoints.argtypes = [vp]
+    lib.uvo_sharder_run.argtypes = [vp, vp, ci, ci, ci, ci, cl, cl, vp, vp, ci, vp, vp, vp, vp, vp]
     lib.uvo_extract_batch_submit.argtypes = [vp, ci, vp, ci, ci, cl, cl, vp, vp, ci, vp, vp]
     lib.uvo_extract_batch_wait.argtypes = [vp, ci]
     lib.uvo_extractor_synchronize.argtypes = [vp]
@@ -217,6 +238,76 @@ def pinned_empty(shape, dtype):
     arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
     weakref.finalize(buf, lib.uvo_host_free, p.value)
     return arr
+
+
+def shard_plan(total_frames, n_shards, shard, chunk_frames):
+    """uvo_shard_plan_make: the block of one shard (pure arithmetic, works without a GPU)."""
+    p = ShardPlan()
+    rc = lib.uvo_shard_plan_make(total_frames, n_shards, shard, chunk_frames, ctypes.byref(p))
+    if rc:
+        raise UvoError(rc, "uvo_shard_plan_make")
+    return p
+
+
+class Sharder:
+    """uvo_sharder: one job of `total` frames over the GPUs of one node, results gathered by the device-to-host copies themselves
+    (include/uvo/uvo.h "Sharder").  devices[i] = HIP ordinal of shard i, or UVO_SHARD_REMOTE for shards another process runs."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, fastTh=20, *, max_width=640, max_height=512, devices=(0,), chunk_frames=128,
+                 match=True):
+        self.cfg = SharderCfg()
+        self.cfg.extractor = ExtractorCfg(nfeatures, scaleFactor, nlevels, 0, fastTh, max_width, max_height, 1, 0, 0)
+        self.cfg.n_shards = len(devices)
+        for i, d in enumerate(devices):
+            self.cfg.devices[i] = d
+        self.cfg.chunk_frames = chunk_frames
+        self.cfg.match = 1 if match else 0
+        self._h = ctypes.c_void_p()
+        rc = lib.uvo_sharder_create(ctypes.byref(self.cfg), ctypes.byref(self._h))
+        if rc:
+            self._h = None
+            raise UvoError(rc, "uvo_sharder_create")
+        self.cap = lib.uvo_sharder_max_keypoints(self._h)
+        self.n_shards, self.chunk_frames = len(devices), chunk_frames
+
+    def close(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib.uvo_sharder_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def plan(self, total_frames, shard):
+        return shard_plan(total_frames, self.n_shards, shard, self.chunk_frames)
+
+    def run(self, imgs, imgs_first_frame, total_frames, out_kp, out_desc, n_out, idx0=None, d0=None, idx1=None, d1=None):
+        """imgs: (n, H, W) uint8 C-contiguous holding frames imgs_first_frame .. ; outputs as uvo_sharder_run documents them."""
+        assert imgs.dtype == np.uint8 and imgs.ndim == 3 and imgs.flags.c_contiguous
+        _, h, w = imgs.shape
+        cap = out_kp.shape[1]
+        assert out_kp.dtype == KEYPOINT_DTYPE and out_kp.shape[0] >= total_frames and out_kp.flags.c_contiguous
+        assert out_desc.dtype == np.uint8 and out_desc.shape[1:] == (cap, 32) and out_desc.flags.c_contiguous
+        assert n_out.dtype == np.int32 and len(n_out) >= total_frames
+        if idx0 is not None:
+            for a, dt in ((idx0, np.int32), (idx1, np.int32), (d0, np.uint16), (d1, np.uint16)):
+                assert a.dtype == dt and a.shape[1] == cap and a.shape[0] >= total_frames - 1 and a.flags.c_contiguous
+        rc = lib.uvo_sharder_run(self._h, imgs.ctypes.data, imgs_first_frame, total_frames, w, h, w, w * h, out_kp.ctypes.data, out_desc.ctypes.data, cap,
+                                 n_out.ctypes.data, _ptr(idx0), _ptr(d0), _ptr(idx1), _ptr(d1))
+        if rc:
+            raise UvoError(rc, "uvo_sharder_run")
+
+
+def host_register(arr):
+    """Page-lock memory the caller owns (uvo_host_register), e.g. a mapping shared between processes."""
+    rc = lib.uvo_host_register(arr.ctypes.data, arr.nbytes)
+    if rc:
+        raise UvoError(rc, "uvo_host_register")
+
+
+def host_unregister(arr):
+    rc = lib.uvo_host_unregister(arr.ctypes.data)
+    if rc:
+        raise UvoError(rc, "uvo_host_unregister")
 
 
 class ORBextractor:

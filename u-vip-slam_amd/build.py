@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libuvo.so")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["pyramid.hip", "gauss.hip", "fast.hip", "octree.hip", "describe.hip", "hamming.hip", "search.hip", "match_engine.hip", "grider.hip", "extractor.cpp", "matcher.cpp",
+SOURCES = ["pyramid.hip", "gauss.hip", "fast.hip", "octree.hip", "describe.hip", "hamming.hip", "search.hip", "match_engine.hip", "grider.hip", "extractor.cpp", "sharder.cpp", "matcher.cpp",
            "matcher_search.cpp", "bow.hip", "bow.cpp", "clahe.hip", "klt.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",

@@ -873,12 +873,30 @@ int uvo_host_free(void* ptr) {
   if (ptr && hipHostFree(ptr) != hipSuccess) return fail(UVO_E_HIP, "hipHostFree failed");
   return UVO_OK;
 }
+int uvo_host_register(void* ptr, size_t bytes) {
+  if (!ptr || bytes == 0) return fail(UVO_E_BADARG, "null pointer / zero size");
+  hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
+  if (e != hipSuccess) {
+    hip_err_set(e, "hipHostRegister");
+    return UVO_E_HIP;
+  }
+  return UVO_OK;
+}
+int uvo_host_unregister(void* ptr) {
+  if (ptr && hipHostUnregister(ptr) != hipSuccess) return fail(UVO_E_HIP, "hipHostUnregister failed");
+  return UVO_OK;
+}
 
-int uvo_extract_batch_submit(uvo_extractor* h, int batch, const uint8_t* imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
-                             uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int* ticket) {
+// The asynchronous host form with its knobs exposed to the sharder (sharder.cpp): only the first n_download frames' results are
+// copied to the caller's arrays (the rest of the batch is a halo whose owner downloads it), `after_kernels` (optional) is recorded
+// between the kernels and the downloads, and the device-side descriptors / counts of the batch are handed out so that the matcher
+// can read them in HBM (valid until the lane is submitted to again).
+int uvo_extract_batch_submit_internal(uvo_extractor* h, int batch, int n_download, const uint8_t* imgs, int width, int height, ptrdiff_t stride,
+                                      ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int* ticket,
+                                      hipEvent_t after_kernels, const uint8_t** d_desc, const int32_t** d_n) {
   if (!h || !imgs || !out_kp || !out_desc || !n_out || !ticket) return fail(UVO_E_BADARG, "null pointer");
   *ticket = -1;
-  if (batch < 1 || batch > h->cfg.max_batch) return fail(UVO_E_BADARG, "batch outside 1..max_batch");
+  if (batch < 1 || batch > h->cfg.max_batch || n_download < 0 || n_download > batch) return fail(UVO_E_BADARG, "batch outside 1..max_batch");
   if (width < 1 || height < 1 || width > h->cfg.max_width || height > h->cfg.max_height || stride < width ||
       (int64_t)width * height > (int64_t)h->cfg.max_width * h->cfg.max_height)
     return fail(UVO_E_BADARG, "image size outside what the handle was sized for");
@@ -907,14 +925,25 @@ int uvo_extract_batch_submit(uvo_extractor* h, int batch, const uint8_t* imgs, i
   rc = run_batch_device(h, li, batch, L.a_imgs, width, height, width, (ptrdiff_t)width * height, nullptr, nullptr, nullptr, 0, 0, 0, 1, nullptr, L.a_kp,
                         L.a_desc, dcap, L.a_n);
   if (rc) return rc;
+  if (after_kernels) UVO_HIP_CHECK(hipEventRecord(after_kernels, s));
   // results: whole per-frame slices (a frame holds at most dcap records), frame b lands at b * cap of the caller's arrays
-  UVO_HIP_CHECK(hipMemcpyAsync(n_out, L.a_n, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
-  UVO_HIP_CHECK(hipMemcpy2DAsync(out_kp, (size_t)cap * sizeof(uvo_keypoint), L.a_kp, (size_t)dcap * sizeof(uvo_keypoint),
-                                 (size_t)dcap * sizeof(uvo_keypoint), (size_t)batch, hipMemcpyDeviceToHost, s));
-  UVO_HIP_CHECK(hipMemcpy2DAsync(out_desc, (size_t)cap * 32, L.a_desc, (size_t)dcap * 32, (size_t)dcap * 32, (size_t)batch, hipMemcpyDeviceToHost, s));
+  if (n_download > 0) {
+    UVO_HIP_CHECK(hipMemcpyAsync(n_out, L.a_n, sizeof(int32_t) * n_download, hipMemcpyDeviceToHost, s));
+    UVO_HIP_CHECK(hipMemcpy2DAsync(out_kp, (size_t)cap * sizeof(uvo_keypoint), L.a_kp, (size_t)dcap * sizeof(uvo_keypoint),
+                                   (size_t)dcap * sizeof(uvo_keypoint), (size_t)n_download, hipMemcpyDeviceToHost, s));
+    UVO_HIP_CHECK(hipMemcpy2DAsync(out_desc, (size_t)cap * 32, L.a_desc, (size_t)dcap * 32, (size_t)dcap * 32, (size_t)n_download, hipMemcpyDeviceToHost, s));
+  }
   L.a_batch = batch;
   *ticket = li;
+  if (d_desc) *d_desc = L.a_desc;
+  if (d_n) *d_n = L.a_n;
   return UVO_OK;
+}
+
+int uvo_extract_batch_submit(uvo_extractor* h, int batch, const uint8_t* imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
+                             uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int* ticket) {
+  return uvo_extract_batch_submit_internal(h, batch, batch, imgs, width, height, stride, frame_stride, out_kp, out_desc, cap, n_out, ticket, nullptr,
+                                           nullptr, nullptr);
 }
 
 int uvo_extract_batch_wait(uvo_extractor* h, int ticket) {

@@ -413,6 +413,8 @@ int uvo_search_points_in_frustum(uvo_matcher* m, const uvo_keypoint* kp, int n, 
   return UVO_OK;
 }
 
+hipStream_t uvo_matcher_stream_internal(uvo_matcher* m) { return m->stream; }
+
 int uvo_matcher_wait_extractor(uvo_matcher* m, uvo_extractor* h) {
   if (!m || !h) return matcher_fail(UVO_E_BADARG, "null handle");
   if (uvo_extractor_device_internal(h) != m->device) return matcher_fail(UVO_E_BADARG, "handles live on different devices");

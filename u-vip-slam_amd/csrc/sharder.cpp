@@ -1,0 +1,270 @@
+// Multi-GPU form of the extractor + consecutive-frame matcher (the single extractor call site it feeds is
+// src/Tracking.cc:946).  A frame's extraction depends on nothing but its own pixels, so a job of `total` frames is cut into one
+// contiguous block per shard; every shard has its own extractor + matcher handle on its device and one host thread that streams
+// the block through the two pipeline lanes in chunks (upload of chunk k+1 under the kernels of chunk k).  There is no collective:
+// every chunk's results are copied by hipMemcpyAsync straight to their final place -- offset frame * cap of ONE set of page-locked
+// host arrays shared by all shards -- and that is the gather.  Matching pair p = (frame p, frame p+1) needs frame p+1's
+// descriptors: a chunk therefore extracts one frame more than it owns (its halo: the first frame of the next chunk, which at a
+// shard's end belongs to the neighbouring shard) instead of exchanging descriptors between devices; +1/chunk extra work.
+//
+// Shards whose device is UVO_SHARD_REMOTE are owned by another process (one process per GPU under a launcher such as
+// torch.distributed.run): the same plan, the same offsets, each process runs its own shards, and the output arrays are one shared
+// mapping registered with uvo_host_register() in every process.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "common.hpp"
+
+extern "C" int uvo_extract_batch_submit_internal(uvo_extractor* h, int batch, int n_download, const uint8_t* imgs, int width, int height,
+                                                  ptrdiff_t stride, ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap,
+                                                  int32_t* n_out, int* ticket, hipEvent_t after_kernels, const uint8_t** d_desc,
+                                                  const int32_t** d_n);
+extern "C" hipStream_t uvo_matcher_stream_internal(uvo_matcher* m);
+
+using namespace uvo;
+
+namespace {
+
+struct Shard {
+  int device = UVO_SHARD_REMOTE;
+  uvo_extractor* ex = nullptr;
+  uvo_matcher* mt = nullptr;
+  // per pipeline lane: knn-2 rows of the chunk in HBM, and the events that order the two handles' streams
+  int32_t *d_idx0[2] = {nullptr, nullptr}, *d_idx1[2] = {nullptr, nullptr};
+  uint16_t *d_d0[2] = {nullptr, nullptr}, *d_d1[2] = {nullptr, nullptr};
+  hipEvent_t kernels_done[2] = {nullptr, nullptr};  // extractor lane: descriptors of the chunk are final
+  hipEvent_t rows_sent[2] = {nullptr, nullptr};     // matcher stream: the chunk's rows are on their way to the host
+  int rc = UVO_OK;
+  char err[512] = "";
+};
+
+}  // namespace
+
+struct uvo_sharder {
+  uvo_sharder_cfg cfg;
+  std::vector<Shard> shards;
+  int dcap = 0;  // keypoints a frame can return (uvo_extractor_max_keypoints)
+};
+
+extern "C" {
+
+int uvo_shard_plan_make(int total_frames, int n_shards, int shard, int chunk_frames, uvo_shard_plan* out) {
+  if (!out || total_frames < 0 || n_shards < 1 || shard < 0 || shard >= n_shards || chunk_frames < 1) return fail(UVO_E_BADARG, "bad shard plan request");
+  const int base = total_frames / n_shards, rem = total_frames % n_shards;
+  out->first_frame = shard * base + std::min(shard, rem);
+  out->n_frames = base + (shard < rem ? 1 : 0);
+  const int end = out->first_frame + out->n_frames;
+  // pair p = (frame p, frame p + 1), p in [0, total - 1): a shard matches the pairs whose first frame it owns
+  out->first_pair = out->first_frame;
+  out->n_pairs = std::max(std::min(end, total_frames - 1) - out->first_frame, 0);
+  out->halo_frame = (out->n_frames > 0 && end < total_frames) ? end : -1;
+  out->n_chunks = (out->n_frames + chunk_frames - 1) / chunk_frames;
+  return UVO_OK;
+}
+
+void uvo_sharder_destroy(uvo_sharder* s) {
+  if (!s) return;
+  for (Shard& sh : s->shards) {
+    if (sh.device == UVO_SHARD_REMOTE) continue;
+    (void)hipSetDevice(sh.device);
+    if (sh.ex) (void)uvo_extractor_synchronize(sh.ex);
+    if (sh.mt) (void)uvo_matcher_synchronize(sh.mt);
+    for (int l = 0; l < 2; ++l) {
+      void* p[] = {sh.d_idx0[l], sh.d_idx1[l], sh.d_d0[l], sh.d_d1[l]};
+      for (void* q : p)
+        if (q) (void)hipFree(q);
+      if (sh.kernels_done[l]) (void)hipEventDestroy(sh.kernels_done[l]);
+      if (sh.rows_sent[l]) (void)hipEventDestroy(sh.rows_sent[l]);
+    }
+    if (sh.mt) uvo_matcher_destroy(sh.mt);
+    if (sh.ex) uvo_extractor_destroy(sh.ex);
+  }
+  delete s;
+}
+
+int uvo_sharder_create(const uvo_sharder_cfg* cfg, uvo_sharder** out) {
+  if (!cfg || !out) return fail(UVO_E_BADARG, "null pointer");
+  *out = nullptr;
+  if (cfg->n_shards < 1 || cfg->n_shards > UVO_SHARD_MAX || cfg->chunk_frames < 1) return fail(UVO_E_BADARG, "bad sharder configuration");
+  uvo_sharder* s = new uvo_sharder();
+  s->cfg = *cfg;
+  s->shards.resize(cfg->n_shards);
+  int local = 0;
+  for (int i = 0; i < cfg->n_shards; ++i) {
+    Shard& sh = s->shards[i];
+    sh.device = cfg->devices[i];
+    if (sh.device == UVO_SHARD_REMOTE) continue;
+    ++local;
+    uvo_extractor_cfg ec = cfg->extractor;
+    ec.device = sh.device;
+    ec.max_batch = cfg->chunk_frames + 1;  // a chunk + its halo frame
+    ec.max_input_keypoints = 0;
+    int rc = uvo_extractor_create(&ec, &sh.ex);
+    if (!rc) rc = uvo_extractor_set_pipeline(sh.ex, 2);
+    if (rc) {
+      uvo_sharder_destroy(s);
+      return rc;
+    }
+    const int dcap = uvo_extractor_max_keypoints(sh.ex);
+    s->dcap = dcap;
+    if (cfg->match) {
+      if (dcap > 65535) {
+        uvo_sharder_destroy(s);
+        return fail(UVO_E_UNSUPPORTED, "more than 65535 keypoints per frame: the all-pairs matcher packs train indices in 16 bits");
+      }
+      uvo_matcher_cfg mc;
+      memset(&mc, 0, sizeof(mc));
+      mc.max_query = dcap, mc.max_train = dcap, mc.max_batch = cfg->chunk_frames, mc.max_map_points = 0, mc.device = sh.device;
+      rc = uvo_matcher_create(&mc, &sh.mt);
+      if (rc) {
+        uvo_sharder_destroy(s);
+        return rc;
+      }
+      const size_t rows = (size_t)cfg->chunk_frames * dcap;
+      bool ok = true;
+      for (int l = 0; l < 2 && ok; ++l) {
+        ok = hipMalloc((void**)&sh.d_idx0[l], rows * 4) == hipSuccess && hipMalloc((void**)&sh.d_idx1[l], rows * 4) == hipSuccess &&
+             hipMalloc((void**)&sh.d_d0[l], rows * 2) == hipSuccess && hipMalloc((void**)&sh.d_d1[l], rows * 2) == hipSuccess &&
+             hipEventCreateWithFlags(&sh.kernels_done[l], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sh.rows_sent[l], hipEventDisableTiming) == hipSuccess;
+      }
+      if (!ok) {
+        uvo_sharder_destroy(s);
+        return fail(UVO_E_NOMEM, "sharder staging allocation failed");
+      }
+    }
+  }
+  if (local == 0) {
+    uvo_sharder_destroy(s);
+    return fail(UVO_E_BADARG, "no local shard (every device is UVO_SHARD_REMOTE)");
+  }
+  *out = s;
+  return UVO_OK;
+}
+
+int uvo_sharder_max_keypoints(const uvo_sharder* s) { return s ? s->dcap : fail(UVO_E_BADARG, "null handle"); }
+
+}  // extern "C"
+
+namespace {
+
+struct RunArgs {
+  const uint8_t* imgs;
+  int imgs_first_frame, total, width, height;
+  ptrdiff_t stride, frame_stride;
+  uvo_keypoint* out_kp;
+  uint8_t* out_desc;
+  int cap;
+  int32_t* n_out;
+  int32_t *idx0, *idx1;
+  uint16_t *d0, *d1;
+};
+
+#define SH_CHECK(expr)                                                                   \
+  do {                                                                                   \
+    int _rc = (expr);                                                                    \
+    if (_rc != UVO_OK) {                                                                 \
+      sh.rc = _rc;                                                                       \
+      snprintf(sh.err, sizeof(sh.err), "shard %d: %s", shard_index, uvo_last_error());   \
+      return;                                                                            \
+    }                                                                                    \
+  } while (0)
+#define SH_HIP(expr)                                                                                            \
+  do {                                                                                                          \
+    hipError_t _e = (expr);                                                                                     \
+    if (_e != hipSuccess) {                                                                                     \
+      sh.rc = UVO_E_HIP;                                                                                        \
+      snprintf(sh.err, sizeof(sh.err), "shard %d: HIP error %d (%s) in %s", shard_index, (int)_e, hipGetErrorString(_e), #expr); \
+      return;                                                                                                   \
+    }                                                                                                           \
+  } while (0)
+
+// One shard's block, chunk by chunk through the two lanes.  Runs on the shard's own host thread.
+void run_shard(uvo_sharder* s, int shard_index, const RunArgs& a) {
+  Shard& sh = s->shards[shard_index];
+  sh.rc = UVO_OK, sh.err[0] = 0;
+  uvo_shard_plan pl;
+  SH_CHECK(uvo_shard_plan_make(a.total, s->cfg.n_shards, shard_index, s->cfg.chunk_frames, &pl));
+  if (pl.n_frames == 0) return;
+  SH_HIP(hipSetDevice(sh.device));
+  const int C = s->cfg.chunk_frames, dcap = s->dcap;
+  const bool match = s->cfg.match != 0 && a.idx0 != nullptr;
+  hipStream_t ms = match ? uvo_matcher_stream_internal(sh.mt) : nullptr;
+  int inflight[2] = {-1, -1};  // tickets, oldest first
+  int n_inflight = 0;
+  auto retire_oldest = [&]() -> int {
+    const int t = inflight[0];
+    int rc = uvo_extract_batch_wait(sh.ex, t);
+    if (rc) return rc;
+    if (match && hipEventSynchronize(sh.rows_sent[t]) != hipSuccess) return fail(UVO_E_HIP, "hipEventSynchronize failed");
+    inflight[0] = inflight[1], inflight[1] = -1, --n_inflight;
+    return UVO_OK;
+  };
+  const int end = pl.first_frame + pl.n_frames;
+  for (int f0 = pl.first_frame; f0 < end; f0 += C) {
+    const int nb = std::min(C, end - f0);               // frames this chunk owns
+    const int ne = nb + (f0 + nb < a.total ? 1 : 0);    // + the halo frame (the next chunk's / the neighbouring shard's first frame)
+    if (n_inflight == 2) SH_CHECK(retire_oldest());     // the lane about to be reused must have delivered its results
+    int t = -1;
+    const uint8_t* d_desc = nullptr;
+    const int32_t* d_n = nullptr;
+    // both events of a lane are free again: its previous batch was retired above
+    SH_CHECK(uvo_extract_batch_submit_internal(sh.ex, ne, nb, a.imgs + (ptrdiff_t)(f0 - a.imgs_first_frame) * a.frame_stride, a.width, a.height, a.stride,
+                                               a.frame_stride, a.out_kp + (size_t)f0 * a.cap, a.out_desc + (size_t)f0 * a.cap * 32, a.cap, a.n_out + f0,
+                                               &t, nullptr, &d_desc, &d_n));
+    if (match) {
+      const int np = ne - 1;  // pairs (f0 + j, f0 + j + 1)
+      // the matcher reads the lane's descriptors in HBM: order its stream behind the extraction (uvo_matcher_wait_extractor refers to
+      // the lane just submitted to), and the lane's next batch behind the matcher via retire_oldest()
+      SH_CHECK(uvo_matcher_wait_extractor(sh.mt, sh.ex));
+      if (np > 0) {
+        SH_CHECK(uvo_hamming_knn2_batch_device(sh.mt, np, d_desc, d_n, dcap, d_desc + (size_t)dcap * 32, d_n + 1, dcap, sh.d_idx0[t], sh.d_d0[t],
+                                               sh.d_idx1[t], sh.d_d1[t]));
+        const size_t row4 = (size_t)dcap * 4, row2 = (size_t)dcap * 2;
+        SH_HIP(hipMemcpy2DAsync(a.idx0 + (size_t)f0 * a.cap, (size_t)a.cap * 4, sh.d_idx0[t], row4, row4, np, hipMemcpyDeviceToHost, ms));
+        SH_HIP(hipMemcpy2DAsync(a.idx1 + (size_t)f0 * a.cap, (size_t)a.cap * 4, sh.d_idx1[t], row4, row4, np, hipMemcpyDeviceToHost, ms));
+        SH_HIP(hipMemcpy2DAsync(a.d0 + (size_t)f0 * a.cap, (size_t)a.cap * 2, sh.d_d0[t], row2, row2, np, hipMemcpyDeviceToHost, ms));
+        SH_HIP(hipMemcpy2DAsync(a.d1 + (size_t)f0 * a.cap, (size_t)a.cap * 2, sh.d_d1[t], row2, row2, np, hipMemcpyDeviceToHost, ms));
+      }
+      SH_HIP(hipEventRecord(sh.rows_sent[t], ms));
+    }
+    inflight[n_inflight++] = t;
+  }
+  while (n_inflight > 0) SH_CHECK(retire_oldest());
+}
+
+}  // namespace
+
+extern "C" {
+
+int uvo_sharder_run(uvo_sharder* s, const uint8_t* imgs, int imgs_first_frame, int total_frames, int width, int height, ptrdiff_t stride,
+                    ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int32_t* idx0, uint16_t* d0,
+                    int32_t* idx1, uint16_t* d1) {
+  if (!s || !imgs || !out_kp || !out_desc || !n_out) return fail(UVO_E_BADARG, "null pointer");
+  if (total_frames < 1 || imgs_first_frame < 0 || width < 1 || height < 1 || stride < width || frame_stride < (ptrdiff_t)stride * (height - 1) + width)
+    return fail(UVO_E_BADARG, "bad frame count / geometry");
+  if (cap < s->dcap) return fail(UVO_E_CAPACITY, "cap must be at least uvo_sharder_max_keypoints()");
+  const bool any_match_ptr = idx0 || d0 || idx1 || d1, all_match_ptr = idx0 && d0 && idx1 && d1;
+  if (any_match_ptr && (!all_match_ptr || !s->cfg.match)) return fail(UVO_E_BADARG, "match outputs need all four arrays and a sharder created with match = 1");
+  RunArgs a{imgs, imgs_first_frame, total_frames, width, height, stride, frame_stride, out_kp, out_desc, cap, n_out, idx0, idx1, d0, d1};
+  // the local shards' frames (+ halo) must lie inside what `imgs` holds from imgs_first_frame on; the caller guarantees the upper end
+  for (int i = 0; i < s->cfg.n_shards; ++i) {
+    if (s->shards[i].device == UVO_SHARD_REMOTE) continue;
+    uvo_shard_plan pl;
+    int rc = uvo_shard_plan_make(total_frames, s->cfg.n_shards, i, s->cfg.chunk_frames, &pl);
+    if (rc) return rc;
+    if (pl.n_frames > 0 && pl.first_frame < imgs_first_frame) return fail(UVO_E_BADARG, "imgs does not hold a local shard's first frame");
+  }
+  std::vector<std::thread> th;
+  for (int i = 0; i < s->cfg.n_shards; ++i)
+    if (s->shards[i].device != UVO_SHARD_REMOTE) th.emplace_back(run_shard, s, i, std::cref(a));
+  for (std::thread& t : th) t.join();
+  for (const Shard& sh : s->shards)
+    if (sh.device != UVO_SHARD_REMOTE && sh.rc != UVO_OK) return fail(sh.rc, sh.err);
+  return UVO_OK;
+}
+
+}  // extern "C"
