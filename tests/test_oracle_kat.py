@@ -300,40 +300,66 @@ def test_octree_toy_cases(oracle):
     assert e.octree(pts, W, H, 4).tolist() == [[40, 90, 6], [5, 60, 5], [90, 40, 4], [40, 40, 2]]
 
 
-def test_octree_kernel_body_matches_oracle_on_random_sets(oracle):
-    """The HIP kernel's selection logic (csrc/octree_core.hpp), executed on the host through the phase macros."""
+def _octree_emu():
     lib = os.path.join(ROOT, "tests", "emu", "liboctree_emu.so")
-    srcs = [os.path.join(ROOT, "tests", "emu", "octree_emu.cpp"), os.path.join(ROOT, "u-vip-slam_amd", "csrc", "octree_core.hpp")]
+    srcs = [os.path.join(ROOT, "tests", "emu", "octree_emu.cpp"), os.path.join(ROOT, "u-vip-slam_amd", "csrc", "octree_core.hpp"),
+            os.path.join(ROOT, "u-vip-slam_amd", "csrc", "octree_pyramid.hpp")]
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(f) for f in srcs):
         import subprocess
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", lib, srcs[0]])
     E = ctypes.CDLL(lib)
-    E.emu_octree_k.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    E.emu_octree_algo.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 8 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                                                           ctypes.c_int]
+    return E
+
+
+def _octree_case(rng, trial, dense):
+    """-> W, H, grid, candidates in the reference's order, responses, N.  dense: FAST-like inputs (thousands of candidates for a
+    quota of a few hundred: shallow, balanced trees); otherwise anything goes (sparse, clustered, collinear: deep trees)."""
+    W = int(rng.integers(30, 1900 if dense else 900))
+    H = int(rng.integers(max(30, W // 3), min(1100 if dense else 900, 2 * W - 1)))
+    if round(W / H) < 1:
+        return None
+    nCols, nRows = W // 30, H // 30
+    wCell, hCell = -(-W // nCols), -(-H // nRows)
+    mode = trial % 4
+    if dense:
+        N = int(rng.integers(20, 450))
+        P = int(N * rng.uniform(3, 20))
+        mode = 0 if mode != 2 else 2
+    else:
+        P, N = int(rng.integers(0, 2500)), int(rng.integers(1, 450))
+    if mode == 1:
+        cx, cy = rng.integers(3, W - 3), rng.integers(3, H - 3)
+        xs = np.clip(cx + rng.normal(0, 8, P).astype(int), 3, W - 4)
+        ys = np.clip(cy + rng.normal(0, 8, P).astype(int), 3, H - 4)
+    elif mode == 3:
+        xs, ys = rng.integers(3, W - 3, size=P), np.full(P, rng.integers(3, H - 3))
+    else:
+        xs, ys = rng.integers(3, W - 3, size=P), rng.integers(3, H - 3, size=P)
+    pts = np.unique(np.stack([xs, ys], 1), axis=0).reshape(-1, 2)
+    j = np.minimum((pts[:, 0] - 3) // wCell, nCols - 1)
+    i = np.minimum((pts[:, 1] - 3) // hCell, nRows - 1)
+    pts = pts[np.lexsort((pts[:, 0], pts[:, 1], j, i))]   # reference candidate order: cell-major, raster inside a cell
+    resp = rng.integers(1, 4 if mode == 2 else 200, size=len(pts))
+    return W, H, (nCols, nRows, wCell, hCell), pts, resp, N
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_octree_kernel_bodies_match_oracle_on_random_sets(oracle, dense):
+    """The HIP kernel's selection logic, executed on the host through the phase macros: the closed form over the count pyramid
+    (csrc/octree_pyramid.hpp), the pass-per-generation form (csrc/octree_core.hpp) and the kernel's combination of the two, in every
+    candidate-state instantiation, against the literal std::list restatement."""
+    E = _octree_emu()
     e = oracle.extractor(1000, 1.2, 8, 20)
-    rng = np.random.default_rng(123)
-    done = 0
+    rng = np.random.default_rng(123 + dense)
+    done = fast = 0
     for trial in range(160):
-        W = int(rng.integers(30, 900))
-        H = int(rng.integers(max(30, W // 3), min(900, 2 * W - 1)))
-        if round(W / H) < 1:
+        case = _octree_case(rng, trial, dense)
+        if case is None:
             continue
-        nCols, nRows = W // 30, H // 30
-        wCell, hCell = -(-W // nCols), -(-H // nRows)
-        P, N, mode = int(rng.integers(0, 2500)), int(rng.integers(1, 450)), trial % 4
-        if mode == 1:
-            cx, cy = rng.integers(3, W - 3), rng.integers(3, H - 3)
-            xs = np.clip(cx + rng.normal(0, 8, P).astype(int), 3, W - 4)
-            ys = np.clip(cy + rng.normal(0, 8, P).astype(int), 3, H - 4)
-        elif mode == 3:
-            xs, ys = rng.integers(3, W - 3, size=P), np.full(P, rng.integers(3, H - 3))
-        else:
-            xs, ys = rng.integers(3, W - 3, size=P), rng.integers(3, H - 3, size=P)
-        pts = np.unique(np.stack([xs, ys], 1), axis=0).reshape(-1, 2)
-        j = np.minimum((pts[:, 0] - 3) // wCell, nCols - 1)
-        i = np.minimum((pts[:, 1] - 3) // hCell, nRows - 1)
-        pts = pts[np.lexsort((pts[:, 0], pts[:, 1], j, i))]   # reference candidate order: cell-major, raster inside a cell
+        W, H, (nCols, nRows, wCell, hCell), pts, resp, N = case
         P = len(pts)
-        resp = rng.integers(1, 4 if mode == 2 else 200, size=P)
         ref = e.octree(np.concatenate([pts, resp[:, None]], 1), W, H, N).tolist()
         perm = rng.permutation(P)                              # the GPU candidate array is in arbitrary order
         xy = (pts[perm, 0].astype(np.uint32) | (pts[perm, 1].astype(np.uint32) << 16)).astype(np.uint32)
@@ -343,12 +369,21 @@ def test_octree_kernel_body_matches_oracle_on_random_sets(oracle):
         for k_regs in (8, 32, 0):
             if k_regs and P > k_regs * 256:
                 continue
-            m = E.emu_octree_k(xy.ctypes.data, sc.ctypes.data, P, N, W, H, nCols, nRows, wCell, hCell, sxy.ctypes.data, ssc.ctypes.data, len(sxy),
-                               k_regs)
-            got = [[int(v & 0xffff), int(v >> 16), int(s)] for v, s in zip(sxy[:m], ssc[:m])]
-            assert got == ref, "trial %d W=%d H=%d P=%d N=%d k_regs=%d" % (trial, W, H, P, N, k_regs)
+            for algo in (0, 1, 2):   # passes only / pyramid only (-2: tree deeper than the pyramid) / as the kernel
+                sxy[:], ssc[:] = 0, 0
+                m = E.emu_octree_algo(xy.ctypes.data, sc.ctypes.data, P, N, W, H, nCols, nRows, wCell, hCell, sxy.ctypes.data, ssc.ctypes.data,
+                                      len(sxy), k_regs, algo)
+                if algo == 1 and m == -2:
+                    continue
+                got = [[int(v & 0xffff), int(v >> 16), int(s)] for v, s in zip(sxy[:m], ssc[:m])]
+                assert got == ref, "trial %d W=%d H=%d P=%d N=%d k_regs=%d algo=%d" % (trial, W, H, P, N, k_regs, algo)
+                fast += algo == 1 and k_regs == 0 and P > 0
         done += 1
     assert done > 100
+    if dense:
+        assert fast >= 0.95 * done, "FAST-like candidate sets must take the closed form (%d of %d did)" % (fast, done)
+    else:
+        assert 0.2 * done < fast < done, "the mixed set must exercise both paths (%d of %d took the closed form)" % (fast, done)
 
 
 # ---- extractor glue -------------------------------------------------------------------------------------------

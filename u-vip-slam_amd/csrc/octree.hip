@@ -3,11 +3,12 @@
 // workgroups per CU (throughput: large batches fill the chip with problems), and 1024 threads, one per CU (latency: a
 // small batch leaves CUs idle, so each problem takes four times the lanes and keeps lists of up to 32 K candidates in
 // registers).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include "common.hpp"
 #include "fast_geom.hpp"
-#include "octree_core.hpp"
+#include "octree_pyramid.hpp"
 
 namespace uvo {
 
@@ -24,11 +25,16 @@ static inline int pow2_ge(int v) {
   while (p < v) p <<= 1;
   return p;
 }
-// bytes of LDS for node capacity M (layout must match the carve in k_octree)
-static inline size_t oct_lds_bytes(int M, int Mp2) {
+// bytes of LDS for node capacity M and a count pyramid of pyr_words (layout must match the carve in k_octree).  The pyramid (+ its 16
+// statistics words) shares its bytes with the two box tables: the closed form never touches boxes, and the fall-back starts over.
+static inline size_t oct_box_region_bytes(int M, int pyr_words) {
+  const size_t boxes = (size_t)8 * M * 2, pyr = (size_t)4 * (pyr_words + 16);
+  return (boxes > pyr ? boxes : pyr) + 15 & ~(size_t)15;
+}
+static inline size_t oct_lds_bytes(int M, int Mp2, int pyr_words) {
   size_t b = 0;
   b += (size_t)16 * M * 2;                  // ccnt[4M], ccnt2[4M] (aliased at the end by best64[2M] / sort64[Mp2])
-  b += (size_t)8 * M * 2;                   // boxA, boxB
+  b += oct_box_region_bytes(M, pyr_words);  // boxA, boxB | count pyramid
   b += (size_t)4 * M * 7;                   // cntA, cntB, procRank, nodeOfRank, baseOfRank, outKey, outPt
   b += (size_t)4 * Mp2;                     // sortbuf
   b += (size_t)4 * (32 + 16);               // part (one partial per wavefront on the device), sc
@@ -36,7 +42,7 @@ static inline size_t oct_lds_bytes(int M, int Mp2) {
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max,
+__global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max, int pyr_words, int box_region,
                                                         FastLevels FL, int fast_th, const uint32_t* __restrict__ cor,
                                                         const int32_t* __restrict__ cor_n, uint8_t* cell_hi,
                                                         uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc,
@@ -139,8 +145,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
   uint8_t* p = lds;
   w.ccnt = reinterpret_cast<uint32_t*>(p), p += (size_t)16 * Mmax;
   w.ccnt2 = reinterpret_cast<uint32_t*>(p), p += (size_t)16 * Mmax;
-  w.boxA = reinterpret_cast<oct::Box*>(p), p += (size_t)8 * Mmax;
-  w.boxB = reinterpret_cast<oct::Box*>(p), p += (size_t)8 * Mmax;
+  w.boxA = reinterpret_cast<oct::Box*>(p);
+  w.boxB = w.boxA + Mmax;
+  w.pyr = reinterpret_cast<uint32_t*>(p);  // same bytes as the boxes
+  w.stat = reinterpret_cast<int*>(p) + pyr_words;
+  p += box_region;
   w.cntA = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mmax;
   w.cntB = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mmax;
   w.procRank = reinterpret_cast<int32_t*>(p), p += (size_t)4 * Mmax;
@@ -153,14 +162,16 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
   w.sc = reinterpret_cast<int*>(p), p += (size_t)4 * 16;
 
   const int64_t so = (int64_t)f * sel_block + g.sel_off;
-  // candidate state in registers when the list fits 8 / 32 candidates per thread, else in the HBM scratch words
-  int n;
-  if (P <= 8 * NT)
-    n = oct::run<8>(pr, w, cand_xy + co, cand_sc + co, pstate + co, sel_xy + so, sel_sc + so, g.sel_cap);
-  else if (P <= 32 * NT)
-    n = oct::run<32>(pr, w, cand_xy + co, cand_sc + co, pstate + co, sel_xy + so, sel_sc + so, g.sel_cap);
-  else
-    n = oct::run<0>(pr, w, cand_xy + co, cand_sc + co, pstate + co, sel_xy + so, sel_sc + so, g.sel_cap);
+  // First the closed form over the count pyramid (no pass over the candidates per generation, no per-candidate state).  Trees deeper
+  // than the pyramid (sparse or clustered candidate sets: short lists in practice) take the pass-per-generation form, candidate state
+  // in 8 registers per thread or, for long lists, in the HBM scratch words.
+  int n = oct::run_pyramid(pr, w, cand_xy + co, cand_sc + co, sel_xy + so, sel_sc + so, g.sel_cap);
+  if (n < 0) {
+    if (P <= 8 * NT)
+      n = oct::run<8>(pr, w, cand_xy + co, cand_sc + co, pstate + co, sel_xy + so, sel_sc + so, g.sel_cap);
+    else
+      n = oct::run<0>(pr, w, cand_xy + co, cand_sc + co, pstate + co, sel_xy + so, sel_sc + so, g.sel_cap);
+  }
   if (threadIdx.x == 0) *out_n = n;
 }
 
@@ -173,11 +184,13 @@ int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, cons
     M = m > M ? m : M;
   }
   const int Mp2 = pow2_ge(M);
+  int pyr_words = 0;
+  for (int l = 0; l < g.nlevels; ++l) pyr_words = std::max(pyr_words, oct::pyramid_words(g.lv[l].nIni));
   // The kernel is latency bound (a few dozen dependent phases per problem): the per-candidate state lives in registers,
   // the node tables in LDS, and the grid is level-major so that the long level-0 problems are dispatched first.
   const bool wide = batch * g.nlevels <= st.wide_max_problems;
   const int threads = wide ? 1024 : OCT_THREADS;
-  const size_t lds = oct_lds_bytes(M, Mp2);
+  const size_t lds = oct_lds_bytes(M, Mp2, pyr_words);
   if (lds > 64 * 1024 && lds > st.lds_configured) {  // the attribute is per device: every handle raises it for its own
     UVO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<OCT_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     UVO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -197,10 +210,10 @@ int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, cons
   }
 #endif
   if (wide)
-    hipLaunchKernelGGL(k_octree<1024>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, fast_levels(g, batch), fast_th, d_cor,
+    hipLaunchKernelGGL(k_octree<1024>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), fast_levels(g, batch), fast_th, d_cor,
                        d_cor_n, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count);
   else
-    hipLaunchKernelGGL(k_octree<OCT_THREADS>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, fast_levels(g, batch), fast_th,
+    hipLaunchKernelGGL(k_octree<OCT_THREADS>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), fast_levels(g, batch), fast_th,
                        d_cor, d_cor_n, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block,
                        d_sel_count);
   return UVO_OK;

@@ -17,6 +17,9 @@
 // A pass is: per-point child digit + histogram (LDS atomics), a scan over <= N parents, and for careful rounds a
 // bitonic sort of <= N keys.  Point state lives in HBM scratch (L2 resident), node state in LDS.
 //
+// k_octree tries the closed form over a count pyramid first (octree_pyramid.hpp, included by the users of this header: it needs no
+// pass over the points per generation); this formulation handles trees deeper than the pyramid.
+//
 // The body is written against the OCT_* phase macros so that tests/emu/octree_emu.cpp can run the *same* logic on
 // the CPU (threads of a phase executed one after another) against that checker; on the GPU a phase ends in a
 // workgroup barrier.
@@ -119,6 +122,9 @@ struct Work {
   uint32_t* part;        // [OCT_THREADS] scan partials
   // shared scalars
   int* sc;               // [16]
+  // count pyramid of the closed-form path (octree_pyramid.hpp)
+  uint32_t* pyr;         // [pyramid_words(nIni)]
+  int* stat;             // [16]
 };
 
 enum { SC_NA = 0, SC_NOUT, SC_NEXP, SC_NPROC, SC_T, SC_NTOEXP, SC_M, SC_TMP };

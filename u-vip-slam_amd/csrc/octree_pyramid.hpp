@@ -1,0 +1,332 @@
+// Quad-tree keypoint selection in closed form over a count pyramid -- the fast path of k_octree.
+// Replaces ORBextractor::DistributeOctTree + ExtractorNode::DivideNode (src/ORBextractor.cc:1006-1287); same results as the
+// pass-per-generation formulation in octree_core.hpp, which stays as the fall-back for trees deeper than the pyramid.
+//
+// DivideNode halves a box at ceil(size / 2), so a point's whole root-to-leaf path is a pure function of its coordinates and the
+// root box, and the node it sits in at generation g is the length-g prefix of its path.  One pass over the points histograms the
+// depth-G prefixes, sums of four give the counts of every shallower node, and then everything the full passes (:1061-1132) decide
+// is arithmetic on those counts: a node of depth g exists iff it has points and its parent has more than one; the list size after
+// pass g is (#expandable nodes of depth g) + (#single-point nodes of depth <= g); the careful phase starts at the first g with
+// size + 3 * expandable > N (:1140).  No pass over the points and no workgroup barrier per generation.  The careful rounds
+// (:1143-1204) work on the < N expandable nodes of one generation: sort by (size desc, newest first), cut at the first split that
+// reaches N, children by creation rank -- node-level work only, child counts read from the pyramid.  A second pass over the points
+// finds each point's final node by walking its prefixes and takes the per-node maximum response (:1208-1226).
+//
+// List order (tools/octree_pyramid_proto.py is the executable derivation, checked against the std::list restatement): children are
+// pushed to the FRONT in the order n1..n4 while parents are visited front to back, so a generation made by full passes reads: last
+// digit descending, the digits above alternating, the root like digit 1.  With the even digits complemented ("T bin") generation
+// g is ascending in T for even g and descending for odd g: the position of a node in its generation is its bin (or the mirrored
+// bin), and the output order (generation desc, position asc) needs one sort of <= N + 3 keys at the end.
+//
+// Written against the OCT_* phase macros of octree_core.hpp so that tests/emu/ runs the same body on the host.
+#pragma once
+#include "octree_core.hpp"
+
+namespace uvo {
+namespace oct {
+
+constexpr uint32_t PYR_FINAL = 0x80000000u;  // pyramid word of a final node: flag | output slot
+constexpr int PYR_MAX_DEPTH = 5;
+constexpr int PYR_MAX_BINS = 4096;           // deepest level: nIni * 4^G bins; positions inside a generation fit 12 bits
+constexpr int PYR_STAT_E = 0, PYR_STAT_F = 8;  // stat[]: expandable / single-point nodes per depth
+
+OCT_FN int pyramid_depth(int nIni) { return nIni <= 4 ? 5 : (nIni <= 16 ? 4 : (nIni <= 64 ? 3 : 0)); }
+OCT_FN int pyramid_words(int nIni) {
+  const int G = pyramid_depth(nIni);
+  int o = 0, n = nIni;
+  for (int g = 0; g <= G; ++g) o += n, n *= 4;
+  return o;
+}
+
+// T bin of the depth-G prefix of a point's path: root, then per DivideNode level the child digit (n1..n4 = 0..3: right +1, bottom +2),
+// even levels complemented.  The box arithmetic is DivideNode's (:1233-1258): halfX = ceil((UR.x - UL.x) / 2), left iff x < UL.x + halfX.
+OCT_FN uint32_t path_tbin(const Params& pr, int G, uint32_t xy) {
+  const int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
+  const int r = (int)((float)x / pr.hX);
+  int ulx = (int)(pr.hX * (float)r), urx = (int)(pr.hX * (float)(r + 1)), uly = 0, bry = pr.H;
+  uint32_t b = (uint32_t)r;
+#pragma unroll
+  for (int k = 1; k <= PYR_MAX_DEPTH; ++k) {
+    if (k > G) break;
+    const int mx = ulx + half_ceil(urx - ulx), my = uly + half_ceil(bry - uly);
+    const int dx = x >= mx ? 1 : 0, dy = y >= my ? 1 : 0;
+    ulx = dx ? mx : ulx, urx = dx ? urx : mx;
+    uly = dy ? my : uly, bry = dy ? bry : my;
+    uint32_t d = (uint32_t)(dx + 2 * dy);
+    if ((k & 1) == 0) d = 3u - d;
+    b = b * 4u + d;
+  }
+  return b;
+}
+
+// adds a wave's worth of predicate counts to an LDS counter with one atomic per wavefront (host emulation: a plain add)
+OCT_FN void stat_add(int* dst, bool pred) {
+#if OCT_DEVICE
+  const unsigned long long m = __ballot(pred);
+  if (m != 0 && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(dst, (int)__popcll(m));
+#else
+  if (pred) *dst += 1;
+#endif
+}
+
+// returns the number of selected points, or -1 when the tree is deeper than the pyramid (caller falls back to oct::run).
+// No per-candidate state: both passes over the candidates recompute the path from the coordinates (a few dozen integer
+// operations), so the kernel's register budget is set by the node-level phases alone.
+OCT_FN int run_pyramid(const Params& pr, const Work& w, const uint32_t* cand_xy, const uint32_t* cand_score, uint32_t* sel_xy,
+                       uint32_t* sel_score, int sel_cap) {
+  const int P = pr.P, N = pr.N;
+  const int G = pyramid_depth(pr.nIni);
+  if (G == 0) return -1;
+  int base[PYR_MAX_DEPTH + 2], nb[PYR_MAX_DEPTH + 2];
+  {
+    int o = 0, n = pr.nIni;
+    for (int g = 0; g <= PYR_MAX_DEPTH; ++g) {
+      base[g] = o, nb[g] = n;
+      if (g <= G) o += n, n *= 4;
+    }
+    base[PYR_MAX_DEPTH + 1] = o, nb[PYR_MAX_DEPTH + 1] = 0;
+  }
+  const int total = base[G] + nb[G];
+  int* sc = w.sc;
+  uint32_t* pyr = w.pyr;
+  int* stat = w.stat;
+  uint32_t* keys_in = reinterpret_cast<uint32_t*>(w.procRank);  // expandable nodes of the next careful round: (0xFFFFF - count) << 12 | position
+  uint32_t* Acur = w.cntA;   // careful-born generation: bin of the node at a list position
+  uint32_t* Anext = w.cntB;
+
+  // ---- histogram of the depth-G prefixes ----
+  OCT_PHASE_BEGIN
+  for (int i = tid; i < total; i += OCT_NT) pyr[i] = 0;
+  if (tid < 16) stat[tid] = 0;
+  if (tid == 0) sc[SC_NOUT] = 0, sc[SC_NA] = 0;
+  OCT_PHASE_END
+  OCT_PHASE_BEGIN
+#pragma unroll 4
+  for (int p = tid; p < P; p += OCT_NT) OCT_ATOMIC_ADD(&pyr[base[G] + (int)path_tbin(pr, G, cand_xy[p])], 1u);
+  OCT_PHASE_END
+  // ---- counts of the shallower nodes: sums of four, two levels per phase ----
+  for (int g = G; g > 0;) {
+    const bool two = g >= 2;
+    OCT_PHASE_BEGIN
+    if (two) {
+      for (int b = tid; b < nb[g - 2]; b += OCT_NT) {
+        uint32_t s = 0;
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t* q = &pyr[base[g] + 16 * b + 4 * c];
+          const uint32_t s1 = q[0] + q[1] + q[2] + q[3];
+          pyr[base[g - 1] + 4 * b + c] = s1;
+          s += s1;
+        }
+        pyr[base[g - 2] + b] = s;
+      }
+    } else {
+      for (int b = tid; b < nb[g - 1]; b += OCT_NT) {
+        const uint32_t* q = &pyr[base[g] + 4 * b];
+        pyr[base[g - 1] + b] = q[0] + q[1] + q[2] + q[3];
+      }
+    }
+    OCT_PHASE_END
+    g -= two ? 2 : 1;
+  }
+  // ---- per depth: how many nodes exist (parent was split) with more than one point / with exactly one ----
+  OCT_PHASE_BEGIN
+  for (int g = 0; g <= G; ++g) {
+    for (int b0 = 0; b0 < nb[g]; b0 += OCT_NT) {  // whole wavefronts take part in every ballot
+      const int b = b0 + tid;
+      uint32_t c = 0;
+      if (b < nb[g]) {
+        c = pyr[base[g] + b];
+        if (g > 0 && pyr[base[g - 1] + (b >> 2)] <= 1) c = 0;
+      }
+      stat_add(&stat[PYR_STAT_E + g], c > 1);
+      stat_add(&stat[PYR_STAT_F + g], c == 1);
+    }
+  }
+  OCT_PHASE_END
+  // ---- the full passes, on counts alone (every thread walks the same few numbers) ----
+  int g = 0;
+  int size = stat[PYR_STAT_E] + stat[PYR_STAT_F];
+  bool careful = false;
+  for (;;) {
+    const int E = stat[PYR_STAT_E + g];
+    if (E == 0) break;        // nothing to split: the pass changes nothing (:1136-1139)
+    if (g == G) return -1;    // the next generation lies below the pyramid
+    const int prev = size;
+    size = size - E + stat[PYR_STAT_E + g + 1] + stat[PYR_STAT_F + g + 1];
+    ++g;
+    if (size >= N || size == prev) break;
+    if (size + 3 * stat[PYR_STAT_E + g] > N) {  // :1140
+      careful = true;
+      break;
+    }
+  }
+  if (careful && g == G) return -1;  // a careful round reads the children's counts
+  // ---- nodes of the pass-made generations: single-point nodes are final where they were born; the multi-point nodes of generation g
+  //      are final too, or become the first careful round's candidates ----
+  OCT_PHASE_BEGIN
+  for (int k = 0; k <= g; ++k) {
+    for (int b = tid; b < nb[k]; b += OCT_NT) {
+      const uint32_t c = pyr[base[k] + b];
+      if (c == 0 || (k > 0 && pyr[base[k - 1] + (b >> 2)] <= 1)) continue;
+      const uint32_t pos = (uint32_t)((k & 1) ? nb[k] - 1 - b : b);
+      if (c == 1 || (k == g && !careful)) {
+        const int slot = OCT_ATOMIC_ADD(&sc[SC_NOUT], 1);
+        w.outKey[slot] = ((uint32_t)(GEN_MAX - k) << 16) | pos;
+        w.outPt[slot] = ((uint32_t)k << 16) | (uint32_t)b;
+      } else if (k == g) {
+        const int slot = OCT_ATOMIC_ADD(&sc[SC_NA], 1);
+        keys_in[slot] = ((0xFFFFFu - (c > 0xFFFFFu ? 0xFFFFFu : c)) << 12) | pos;
+      }
+    }
+  }
+  OCT_PHASE_END
+  // ---- careful rounds (:1143-1204) ----
+  bool first = true;
+  while (careful) {
+    const int nExp = oct_bcast(&sc[SC_NA]);
+    if (nExp == 0) break;
+    if (g + 1 > G) return -1;
+    const int dch = g + 1;  // depth of the children
+    int n2 = 1;
+    while (n2 < nExp) n2 <<= 1;
+    OCT_PHASE_BEGIN
+    for (int i = tid; i < pr.Mp2; i += OCT_NT) w.sortbuf[i] = i < nExp ? keys_in[i] : 0xFFFFFFFFu;
+    OCT_PHASE_END
+    block_sort(w.sortbuf, nExp, n2, w.baseOfRank);
+    // parents in processing order: their bin, and the net number of nodes each split adds
+    OCT_PHASE_BEGIN
+    for (int i = tid; i < nExp; i += OCT_NT) {
+      const uint32_t pos = w.sortbuf[i] & 0xfffu;
+      const uint32_t bin = first ? (uint32_t)((g & 1) ? nb[g] - 1 - (int)pos : (int)pos) : Acur[pos];
+      w.nodeOfRank[i] = bin;
+      const uint32_t* c = &pyr[base[dch] + 4 * (int)bin];
+      w.baseOfRank[i] = (uint32_t)((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0)) - 1u;
+    }
+    if (tid == 0) sc[SC_M] = nExp;
+    OCT_PHASE_END
+    (void)block_scan_excl(w.baseOfRank, nExp, w.part, sc);
+    OCT_PHASE_BEGIN
+    for (int i = tid; i < nExp; i += OCT_NT) {
+      const uint32_t* c = &pyr[base[dch] + 4 * (int)w.nodeOfRank[i]];
+      const int add = (int)((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0)) - 1;
+      if (size + (int)w.baseOfRank[i] + add >= N) OCT_ATOMIC_MIN(&sc[SC_M], i + 1);  // :1197-1198: stop at the first split reaching N
+    }
+    OCT_PHASE_END
+    const int nProc = oct_bcast(&sc[SC_M]);
+    OCT_PHASE_BEGIN
+    for (int i = tid; i < nProc; i += OCT_NT) {
+      const uint32_t* c = &pyr[base[dch] + 4 * (int)w.nodeOfRank[i]];
+      w.baseOfRank[i] = (uint32_t)((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0));
+    }
+    if (tid == 0) sc[SC_NA] = 0;
+    OCT_PHASE_END
+    const int T = (int)block_scan_excl(w.baseOfRank, nProc, w.part, sc);
+    // children by creation rank (parent processing order, n1..n4), pushed to the front: position = T - 1 - rank
+    OCT_PHASE_BEGIN
+    for (int i = tid; i < nExp; i += OCT_NT) {
+      const uint32_t bin = w.nodeOfRank[i];
+      if (i < nProc) {
+        uint32_t rank = w.baseOfRank[i];
+        for (int d = 0; d < 4; ++d) {
+          const uint32_t cb = 4u * bin + (uint32_t)((dch & 1) == 0 ? 3 - d : d);
+          const uint32_t c = pyr[base[dch] + (int)cb];
+          if (c == 0) continue;
+          const uint32_t pos = (uint32_t)(T - 1) - rank;
+          ++rank;
+          if (c == 1) {
+            const int slot = OCT_ATOMIC_ADD(&sc[SC_NOUT], 1);
+            w.outKey[slot] = ((uint32_t)(GEN_MAX - dch) << 16) | pos;
+            w.outPt[slot] = ((uint32_t)dch << 16) | cb;
+          } else {
+            const int slot = OCT_ATOMIC_ADD(&sc[SC_NA], 1);
+            keys_in[slot] = ((0xFFFFFu - (c > 0xFFFFFu ? 0xFFFFFu : c)) << 12) | pos;
+            Anext[pos] = cb;
+          }
+        }
+      } else {  // not reached by the truncated round: stays where it is in generation g
+        const int slot = OCT_ATOMIC_ADD(&sc[SC_NOUT], 1);
+        w.outKey[slot] = ((uint32_t)(GEN_MAX - g) << 16) | (w.sortbuf[i] & 0xfffu);
+        w.outPt[slot] = ((uint32_t)g << 16) | bin;
+      }
+    }
+    OCT_PHASE_END
+    const int prev = size;
+    size = prev - nProc + T;
+    g = dch;
+    first = false;
+    {
+      uint32_t* t = Acur;
+      Acur = Anext;
+      Anext = t;
+    }
+    if (size >= N || size == prev) break;  // :1201-1202
+  }
+  // the multi-point nodes the last careful round created stay as they are
+  if (careful) {
+    const int nLeft = oct_bcast(&sc[SC_NA]);
+    OCT_PHASE_BEGIN
+    for (int i = tid; i < nLeft; i += OCT_NT) {
+      const uint32_t pos = keys_in[i] & 0xfffu;
+      const int slot = OCT_ATOMIC_ADD(&sc[SC_NOUT], 1);
+      w.outKey[slot] = ((uint32_t)(GEN_MAX - g) << 16) | pos;
+      w.outPt[slot] = ((uint32_t)g << 16) | Acur[pos];
+    }
+    OCT_PHASE_END
+  }
+
+  // ---- list order = (generation desc, position asc): the output slot of every final node ----
+  const int nOut = oct_bcast(&sc[SC_NOUT]);
+  uint64_t* srt = reinterpret_cast<uint64_t*>(w.ccnt2);
+  uint64_t* best = reinterpret_cast<uint64_t*>(w.ccnt);
+  int n2 = 1;
+  while (n2 < nOut) n2 <<= 1;
+  OCT_PHASE_BEGIN
+  for (int i = tid; i < n2; i += OCT_NT) srt[i] = i < nOut ? (((uint64_t)w.outKey[i] << 32) | w.outPt[i]) : ~0ull;
+  OCT_PHASE_END
+  block_sort(srt, nOut, n2, best);
+  OCT_PHASE_BEGIN
+  for (int i = tid; i < nOut; i += OCT_NT) {
+    const uint32_t ref = (uint32_t)(srt[i] & 0xffffffffu);
+    pyr[base[ref >> 16] + (int)(ref & 0xffffu)] = PYR_FINAL | (uint32_t)i;
+    best[i] = 0;
+  }
+  OCT_PHASE_END
+  // ---- per final node the best response, first in candidate order on ties (:1208-1226).  The candidate order of the reference
+  //      (cell-major, raster inside a cell) is unique per candidate and invertible, so the winner's coordinates come back out of the
+  //      word that won: (score << 32) | ~order ----
+  OCT_PHASE_BEGIN
+#pragma unroll 4
+  for (int p = tid; p < P; p += OCT_NT) {
+    const uint32_t xy = cand_xy[p];
+    const uint32_t tb = path_tbin(pr, G, xy);
+    uint32_t slot = 0xFFFFFFFFu;
+#pragma unroll
+    for (int d = PYR_MAX_DEPTH; d >= 0; --d) {  // a path crosses exactly one final node; deepest first so that the shallowest wins
+      if (d > G) continue;
+      const uint32_t v = pyr[base[d] + (int)(tb >> (2 * (G - d)))];
+      if (v & PYR_FINAL) slot = v & 0x7FFFFFFFu;
+    }
+    const int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
+    int j = (x - 3) / pr.wCell, i = (y - 3) / pr.hCell;
+    j = j > pr.nCols - 1 ? pr.nCols - 1 : j;
+    i = i > pr.nRows - 1 ? pr.nRows - 1 : i;
+    const uint32_t ord = ((uint32_t)(i * pr.nCols + j) * 128u + (uint32_t)(y - i * pr.hCell)) * 128u + (uint32_t)(x - j * pr.wCell);
+    if (slot != 0xFFFFFFFFu) OCT_ATOMIC_MAX64(&best[slot], ((uint64_t)cand_score[p] << 32) | (uint64_t)(0xFFFFFFFFu - ord));
+  }
+  OCT_PHASE_END
+  OCT_PHASE_BEGIN
+  for (int o = tid; o < nOut && o < sel_cap; o += OCT_NT) {
+    const uint64_t v = best[o];
+    const uint32_t ord = 0xFFFFFFFFu - (uint32_t)v;
+    const int cell = (int)(ord >> 14), i = cell / pr.nCols, j = cell - i * pr.nCols;
+    const uint32_t x = (ord & 127u) + (uint32_t)(j * pr.wCell), y = ((ord >> 7) & 127u) + (uint32_t)(i * pr.hCell);
+    sel_xy[o] = x | (y << 16);
+    sel_score[o] = (uint32_t)(v >> 32);
+  }
+  OCT_PHASE_END
+  return nOut;
+}
+
+}  // namespace oct
+}  // namespace uvo
+
