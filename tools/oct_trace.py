@@ -17,9 +17,10 @@ import bench  # noqa: E402
 
 def main():
     batch = int(os.environ.get("BATCH", "256"))
+    W, H, NF = (1920, 1080, 2000) if os.environ.get("HD") else (640, 512, 1000)
     synth = importlib.import_module("u-vip-slam_amd.synth")
-    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=640, max_height=512, max_batch=batch)
-    frames = bench.gen_frames(synth, batch, 0)
+    ex = uvo.ORBextractor(NF, 1.2, 8, 0, 20, max_width=W, max_height=H, max_batch=batch)
+    frames = synth.make_sequence(0, batch, W, H, n_shapes=2500 if W > 1000 else 400)
     d_imgs = torch.from_numpy(frames).cuda()
     cap = ex.cap
     kp = torch.zeros((batch, cap, 7), dtype=torch.float32, device="cuda")
@@ -31,13 +32,13 @@ def main():
     buf = np.zeros(2 * 1024, dtype=np.uint64)
     n = 0
     for it in range(3):
-        ex.extract_batch_device(d_imgs.data_ptr(), batch, 640, 512, kp.data_ptr(), desc.data_ptr(), nk.data_ptr(), cap)
+        ex.extract_batch_device(d_imgs.data_ptr(), batch, W, H, kp.data_ptr(), desc.data_ptr(), nk.data_ptr(), cap)
         ex.synchronize()
         n = lib.uvo_debug_oct_trace(buf.ctypes.data, 1024)
     bb = np.zeros(4096, dtype=np.uint64)
     lib.uvo_debug_oct_blocks.argtypes = [ctypes.c_void_p]
     lib.uvo_debug_oct_blocks(bb.ctypes.data)
-    bb = bb.reshape(2048, 2).astype(np.int64)
+    bb = bb.reshape(2048, 2).astype(np.int64)[: min(2048, batch * 8)]
     base = bb[:, 0].min()
     st = (bb[:, 0] - base) / 100.0
     en = (bb[:, 1] - base) / 100.0

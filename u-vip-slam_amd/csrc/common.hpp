@@ -2,8 +2,11 @@
 // wrappers.  Data layout in HBM (see DESIGN.md "Data layout"):
 //   pyramid  : [frame][level] padded u8 planes, row pitch = (w+32) rounded up to 64 B, ROI origin at (16,16)
 //   blurred  : same geometry, 7x7 sigma-2 blurred interior + un-blurred reflected pad ring
-//   corners  : [frame][region][248 x rows_per_seg] packed corner records, one region per k_fast_score wavefront
+//   corners  : [frame][region][250 x 26] packed corner records, one region per k_fast_score wavefront -- overflow storage only: a
+//              wavefront keeps its corner list in LDS and moves it here when a region holds more than 384 corners
 //   cand     : [frame][level][cap_l] FAST candidates, SoA words {x | y<<16} and {score}, count in cand_count[frame][level]
+//   cand_lo  : [frame][level][cap_l] NMS survivors below fastTh (x | y<<12 | score<<24) waiting for the per-cell threshold vote
+//   cursor   : [frame][level][2] fill counts of cand (survivors >= fastTh) and cand_lo; zero between batches
 //   sel      : [frame][level][quota_l+4] quad-tree survivors in the reference's list order
 //   flist    : [frame][flist_cap] final (level, x, y, aux) slots in output order
 #pragma once
@@ -101,8 +104,8 @@ void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const
                          const ResizeRow* d_rtab, int fast_ok, int batch);
 void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g, int4 taps,
                    int batch);
-void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, int fast_th, uint32_t* d_cor, int32_t* d_cor_n,
-                       uint8_t* d_cell_hi, int batch);
+void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, int fast_th, uint32_t* d_cor, uint8_t* d_cell_hi,
+                       uint32_t* d_cand_xy, uint32_t* d_cand_sc, uint32_t* d_cand_lo, int64_t cand_block, int32_t* d_cursor, int batch);
 void launch_grider(hipStream_t s, const uint8_t* d_img, int w, int h, int64_t stride, int num_features, int grid_x, int grid_y, int threshold,
                    int nms, uint8_t* d_score, uint32_t* d_lists, int32_t* d_counts, uvo_keypoint* d_out, int cap, int32_t* d_n_out);
 int fast_rows_per_seg(int batch);
@@ -114,7 +117,7 @@ struct OctLaunchState {
   int wide_max_problems = 256;
   size_t lds_configured = 0;  // dynamic-LDS limit already raised on this handle's device for both instantiations
 };
-int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, int fast_th, const uint32_t* d_cor, const int32_t* d_cor_n,
+int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_lo, int32_t* d_cursor,
                    uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate,
                    uint32_t* d_sel_xy, uint32_t* d_sel_sc, int32_t* d_sel_count, int batch);
 void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_sel_xy, const uint32_t* d_sel_sc,

@@ -49,8 +49,8 @@ constexpr int kMaxLanes = 4;
 struct Lane {
   hipStream_t stream = nullptr;
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
-  uint32_t *d_cand_xy = nullptr, *d_cand_sc = nullptr, *d_pstate = nullptr, *d_sel_xy = nullptr, *d_sel_sc = nullptr;
-  int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_n_final = nullptr, *d_cor_n = nullptr;
+  uint32_t *d_cand_xy = nullptr, *d_cand_sc = nullptr, *d_cand_lo = nullptr, *d_pstate = nullptr, *d_sel_xy = nullptr, *d_sel_sc = nullptr;
+  int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_n_final = nullptr, *d_cor_n = nullptr, *d_cursor = nullptr;
   uint32_t* d_cor = nullptr;     // FAST corner lists, one region per k_fast_score wavefront
   uint8_t* d_cell_hi = nullptr;  // per cell: owns an NMS survivor >= fastTh
   FinalSlot* d_flist = nullptr;
@@ -377,7 +377,8 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   }
   {  // the per-cell threshold vote + candidate emit run inside k_octree
     ProfScope p(h, "k_fast_score");
-    launch_fast_score(s, L.d_pyr, g.pyr_block, g, h->cfg.fast_th, L.d_cor, L.d_cor_n, L.d_cell_hi, batch);
+    launch_fast_score(s, L.d_pyr, g.pyr_block, g, h->cfg.fast_th, L.d_cor, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, L.d_cand_lo, g.cand_block, L.d_cursor,
+                      batch);
   }
   {
     ProfScope p(h, "k_gauss7");
@@ -385,7 +386,7 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   }
   {
     ProfScope p(h, "k_octree");
-    rc = launch_octree(s, h->oct, h->d_lv, g, h->cfg.fast_th, L.d_cor, L.d_cor_n, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count,
+    rc = launch_octree(s, h->oct, h->d_lv, g, L.d_cand_lo, L.d_cursor, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count,
                        L.d_pstate, L.d_sel_xy, L.d_sel_sc, L.d_sel_count, batch);
     if (rc) return rc;
   }
@@ -422,6 +423,8 @@ static int alloc_lane(uvo_extractor* h, int li) {
   AL(dev_alloc(&L.d_blur, B * h->cap_pyr_block + 256));  // + slack: k_describe reads whole dwords up to 3 bytes past a row end
   AL(dev_alloc(&L.d_cand_xy, B * h->cap_cand_block));
   AL(dev_alloc(&L.d_cand_sc, B * h->cap_cand_block));
+  AL(dev_alloc(&L.d_cand_lo, B * h->cap_cand_block));
+  AL(dev_alloc(&L.d_cursor, B * kMaxLevels * 2));
   AL(dev_alloc(&L.d_pstate, B * h->cap_cand_block));
   AL(dev_alloc(&L.d_sel_xy, B * h->cap_sel_block));
   AL(dev_alloc(&L.d_sel_sc, B * h->cap_sel_block));
@@ -432,8 +435,9 @@ static int alloc_lane(uvo_extractor* h, int li) {
   AL(dev_alloc(&L.d_cor, h->cap_cor));
   AL(dev_alloc(&L.d_cor_n, h->cap_cor_n));
   AL(dev_alloc(&L.d_cell_hi, h->cap_flags));
-  // the cell flags are zero between calls: k_fast_score sets them, k_octree clears the ones it has consumed
-  if (hipMemset(L.d_cell_hi, 0, h->cap_flags) != hipSuccess) return fail(UVO_E_HIP, "hipMemset failed");
+  // the cell flags and the fill cursors are zero between calls: k_fast_score sets / advances them, k_octree clears what it has consumed
+  if (hipMemset(L.d_cell_hi, 0, h->cap_flags) != hipSuccess || hipMemset(L.d_cursor, 0, B * kMaxLevels * 2 * sizeof(int32_t)) != hipSuccess)
+    return fail(UVO_E_HIP, "hipMemset failed");
 #undef AL
   return UVO_OK;
 }
@@ -558,7 +562,7 @@ void uvo_extractor_destroy(uvo_extractor* h) {
     if (L.stream) (void)hipStreamSynchronize(L.stream);
     L.prof.clear();
     void* lp[] = {L.d_pyr,   L.d_blur,   L.d_cand_xy,   L.d_cand_sc, L.d_pstate, L.d_sel_xy, L.d_sel_sc,
-                  L.d_cand_count, L.d_sel_count, L.d_n_final, L.d_cor_n, L.d_cor, L.d_cell_hi, L.d_flist, L.a_imgs, L.a_kp, L.a_desc, L.a_n};
+                  L.d_cand_count, L.d_sel_count, L.d_n_final, L.d_cor_n, L.d_cor, L.d_cell_hi, L.d_cand_lo, L.d_cursor, L.d_flist, L.a_imgs, L.a_kp, L.a_desc, L.a_n};
     for (void* p : lp)
       if (p) (void)hipFree(p);
     if (L.stream) (void)hipStreamDestroy(L.stream);

@@ -14,20 +14,26 @@
 //                   every opposite pair, of one polarity) in packed 16-bit min/max arithmetic.  The ~20 % that pass are
 //                   compacted into a wavefront-private LDS queue and the exact test runs on full 64-lane batches of it:
 //                   max over the 16 arcs of the arc minimum (branch free) is both the corner test (> t_min = min(fastTh, 7))
-//                   and cornerScore + 1.  Corners (3-4 % of the pixels) are appended to a list private to the region -- no
-//                   atomics, the count lives in a scalar register.  At the end of the segment the wavefront does the
-//                   in-cell 3x3 NMS itself on a byte tile laid over its LDS (neighbours outside the corner's own cell
-//                   interior count as 0), compacts the survivors in place and marks cells that own a survivor >= fastTh.
-//                   HBM traffic: the level once in, a few hundred survivor records out.
+//                   and cornerScore + 1.  Corners (3-4 % of the pixels) are appended to a list in the wavefront's LDS -- no
+//                   atomics, the count lives in a scalar register (a region with more corners than the list holds flushes it to
+//                   its slice of an HBM list array).  At the end of the segment the wavefront does the in-cell 3x3 NMS itself
+//                   on a byte tile laid over its LDS (neighbours outside the corner's own cell interior count as 0), compacts
+//                   the survivors in place, marks cells that own a survivor >= fastTh and writes the survivors out: those that
+//                   reach fastTh straight into the level's candidate array, the others into the level's low list (one
+//                   atomic per class and wavefront reserves the slots).  HBM traffic: the level once in, the survivors out.
 //   the per-cell vote (survivors >= fastTh if the cell has any, else the literal-7 fallback) needs every region of a cell to
-//   be finished, so it is taken by the quad-tree kernel when it gathers a level's candidates (octree.hip).  Candidate order
-//   in HBM is arbitrary: the quad-tree orders by coordinates.
+//   be finished, so it is taken by the quad-tree kernel, which appends the low survivors of cells without a high one to the
+//   level's candidates (octree.hip).  Candidate order in HBM is arbitrary: the quad-tree orders by coordinates.
 #include <cstdlib>
 #include "common.hpp"
 #include "fast_geom.hpp"
 
 namespace uvo {
 
+#define UVO_FAST_MIN_BLOCKS 5  // workgroups per CU the register allocation is held to; LDS: 31 KB per workgroup -> five fit (at
+                               // exactly 32 KB only four do: measured, 0.87 instead of 0.76 ms per 256-frame launch)
+constexpr int FL_CAP = 320;       // corner records a wavefront keeps in LDS (a 248 x 24 region of these frames holds ~250); a busier region
+                                  // flushes its list to the region's slice of the HBM list array and carries on
 constexpr int FQ_CAP = 212;       // queue entries per wavefront: < 64 left over + <= 128 pushed per half row (drained in between); sized so
                                   // that ring + queue = the NMS tile = 6656 B per wavefront, six workgroups per CU
 
@@ -92,12 +98,17 @@ constexpr int FW_DWORDS = FW_RING_DW + FQ_CAP;
 constexpr int FT_PITCH = 256, FT_ROWS = FS_ROWS_MAX + 2;      // NMS score tile, laid over ring + queue at the end of the segment
 static_assert(FT_PITCH * FT_ROWS <= FW_DWORDS * 4, "NMS tile must fit the wavefront's LDS block");
 
+// out of line on purpose: the streaming loop below inlines the scoring chunk a dozen times, and this runs once in a blue moon
+__device__ __noinline__ void flush_corner_list(const uint32_t* list, uint32_t* dst, int n, int lane) {
+  for (int i = lane; i < n; i += 64) dst[i] = list[i];
+}
+
 // Full segment test + cornerScore of the queued pixels [first, first+count), one per lane.  The 16 ring pixels are read
 // back from the wavefront's LDS row ring: the queue entry carries the byte address of the pixel in the ring (rows 0..5 are
 // mirrored into slots 16..21, so the seven rows around any centre are consecutive slots and every read is base + immediate).
 // entry = ring byte address | xl << 13 | (row - py0 + 1) << 21.  Corners go to the wavefront's list as xl | row' << 8 | score << 16.
 __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_t* rows, int first, int count, int lane, int t_min,
-                                                 uint32_t* __restrict__ region, int& ncorner) {
+                                                 uint32_t* list, uint32_t* __restrict__ region, int& ncorner, int& nflushed) {
   bool corner = false;
   uint32_t packed = 0;
   if (lane < count) {
@@ -123,8 +134,14 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
   }
   const uint64_t m = __ballot(corner);
   if (m) {
-    if (corner) region[ncorner + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = packed;
-    ncorner += (int)__popcll(m);
+    const int add = (int)__popcll(m);
+    if (ncorner + add > FL_CAP) {  // wave-uniform, rare: the LDS list is flushed to the region's slice in memory and starts again
+      flush_corner_list(list, region + nflushed, ncorner, lane);
+      nflushed += ncorner;
+      ncorner = 0;
+    }
+    if (corner) list[ncorner + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = packed;
+    ncorner += add;
   }
 }
 
@@ -134,9 +151,12 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
 // into a dense byte tile that reuses the LDS of the row ring + queue, the eight neighbours of every corner are read from it
 // (neighbours outside the corner's own FAST cell count as 0), survivors are compacted in place and mark their cell when they
 // reach fastTh.  No score plane in HBM, no zero fill, no second gather pass.
-__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ pyr, int64_t pyr_block, FastLevels L, int t_min, int fast_th,
-                                                    uint32_t* __restrict__ cor, int32_t* __restrict__ cor_n, uint8_t* __restrict__ cell_hi) {
+__global__ __launch_bounds__(256, UVO_FAST_MIN_BLOCKS) void k_fast_score(const uint8_t* __restrict__ pyr, int64_t pyr_block, FastLevels L, int t_min, int fast_th,
+                                                    uint32_t* __restrict__ cor, uint8_t* __restrict__ cell_hi, uint32_t* __restrict__ cand_xy,
+                                                    uint32_t* __restrict__ cand_sc, uint32_t* __restrict__ cand_lo, int64_t cand_block,
+                                                    int32_t* __restrict__ cursor) {
   __shared__ uint32_t s_mem[4][FW_DWORDS];
+  __shared__ uint32_t s_list[4][FL_CAP];
   const int wv = wave_in_block(), lane = threadIdx.x & 63;
   uint32_t* rows32 = s_mem[wv];
   uint32_t* q = rows32 + FW_RING_DW;
@@ -148,8 +168,10 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
   if (!fast_region(L, item, level, X0, py0, nsub)) return;
   const FastLevel g = L.l[level];
   const int64_t region_id = (int64_t)f * L.items_per_frame + item;
-  uint32_t* region = cor + region_id * (int64_t)FS_REGION_ENTRIES;
-  int ncorner = 0;
+  uint32_t* region = cor + region_id * (int64_t)FS_REGION_ENTRIES;  // only touched when the LDS list overflows
+  uint32_t* list = s_list[wv];
+  int ncorner = 0;   // corners in the LDS list
+  int nflushed = 0;  // corners already moved to the region's slice in memory
   const uint8_t* src = pyr + f * pyr_block + g.plane_off;
   // nsub sub-strips side by side (1: the whole wavefront; 2 / 4: 32 / 16 lanes each, consecutive row segments of one narrow strip).
   // Everything that depends on the row is kept relative to the sub-strip's own first row, so the loop below stays uniform.
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
             UVO_FAST_PUSH(1, (ro & 0xffffu) != 0u)
             while (qn >= 64) {  // keeps the queue within FQ_CAP
               qn -= 64;
-              fast_score_chunk(q, rows8, qn, 64, lane, t_min, region, ncorner);
+              fast_score_chunk(q, rows8, qn, 64, lane, t_min, list, region, ncorner, nflushed);
             }
             UVO_FAST_PUSH(2, re > 0xffffu)
             UVO_FAST_PUSH(3, ro > 0xffffu)
@@ -253,86 +275,140 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
           // ---- drain full batches (newest first); a stale remainder is flushed before its rows leave the ring ----
           while (qn >= 64) {
             qn -= 64;
-            fast_score_chunk(q, rows8, qn, 64, lane, t_min, region, ncorner);
+            fast_score_chunk(q, rows8, qn, 64, lane, t_min, list, region, ncorner, nflushed);
           }
           if (qn > 0 && jc - qoldest >= FR_MAXAGE) {
-            fast_score_chunk(q, rows8, 0, qn, lane, t_min, region, ncorner);
+            fast_score_chunk(q, rows8, 0, qn, lane, t_min, list, region, ncorner, nflushed);
             qn = 0;
           }
         }
       }
     }
   }
-  if (qn > 0) fast_score_chunk(q, rows8, 0, qn, lane, t_min, region, ncorner);
+  if (qn > 0) fast_score_chunk(q, rows8, 0, qn, lane, t_min, list, region, ncorner, nflushed);
 
   // ---- in-cell 3x3 non-max suppression of the region's corners (cv::FAST with nonmaxSuppression on the cell ROI) ----
   uint8_t* tile = reinterpret_cast<uint8_t*>(rows32);  // [row' = row - py0 + 1][xl], FT_PITCH bytes per row; ring and queue are dead
   for (int i = lane; i < FT_ROWS * FT_PITCH / 4; i += 64) rows32[i] = 0u;
-  __threadfence_block();  // the corner list below was written by this wavefront's own global stores
   uint8_t* hi = cell_hi + (int64_t)f * L.flags_per_frame + g.flag_base;
-  int nkeep = 0;
-  auto nms_one = [&](uint32_t e, bool valid) {
-    bool keep = false;
-    uint32_t out = 0;
-    const int xl = (int)(e & 0xff), rrp = (int)((e >> 8) & 0xff), ss = (int)(e >> 16);
-    // the sub-strip the corner belongs to: columns [es * sub_px, (es + 1) * sub_px) of the tile, rows of segment es
-    const int es = (xl * nsub) >> 8;
-    const int xs = xl - es * sub_px, py0e = py0 + es * L.rows_per_seg;
-    const int nrows_e = min(py0e + L.rows_per_seg, g.h) - py0e;
-    const bool owned = valid && xs >= 4 && xs < sub_px - 4 && rrp >= 1 && rrp <= nrows_e;  // not a halo-ring corner
-    if (owned) {
-      // coordinates relative to (minBorder, minBorder), as the candidate list wants them
-      const int xr = X0 + xs - kPad - kMinBorder, yr = py0e + rrp - 1 - kPad - kMinBorder;
-      int cj = (int)__umulhi((uint32_t)(xr - 3), g.inv_wcell), ci = (int)__umulhi((uint32_t)(yr - 3), g.inv_hcell);  // (xr-3)/wCell, (yr-3)/hCell
-      cj = cj > g.nCols - 1 ? g.nCols - 1 : cj;
-      ci = ci > g.nRows - 1 ? g.nRows - 1 : ci;
-      // interior of the owning cell: [j*wCell + 3, min(j*wCell + wCell + 6, bw) - 3) and the same in y
-      const int cx0 = cj * g.wCell + 3, cx1 = min(cj * g.wCell + g.wCell + 6, g.bw) - 3;
-      const int cy0 = ci * g.hCell + 3, cy1 = min(ci * g.hCell + g.hCell + 6, g.bh) - 3;
-      const uint8_t* c = tile + rrp * FT_PITCH + xl;
-      keep = true;
+  // the corner list (in LDS, or in memory once it has spilled) is compacted in place to the NMS survivors: x | y << 12 | score << 24
+  // relative to (minBorder, minBorder)
+  auto nms_list = [&](uint32_t* C) -> int {
+    __builtin_amdgcn_wave_barrier();
+    constexpr int NB = 4;  // batches of 64 corners handled together: their LDS round trips overlap
+    for (int base = 0; base < ncorner; base += 64 * NB) {
+      uint32_t e[NB];
 #pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
+      for (int u = 0; u < NB; ++u) e[u] = base + 64 * u + lane < ncorner ? C[base + 64 * u + lane] : 0u;
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          if (dx == 0 && dy == 0) continue;
-          const bool inside = xr + dx >= cx0 && xr + dx < cx1 && yr + dy >= cy0 && yr + dy < cy1;
-          const int nb = inside ? (int)c[dy * FT_PITCH + dx] : 0;
-          keep = keep && ss > nb;
-        }
-      if (keep && ss >= fast_th) hi[ci * g.nCols + cj] = 1;  // idempotent plain store: every writer stores the same value
-      out = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)ss << 24);
+      for (int u = 0; u < NB; ++u)
+        if (base + 64 * u + lane < ncorner) tile[((e[u] >> 8) & 0xff) * FT_PITCH + (e[u] & 0xff)] = (uint8_t)(e[u] >> 16);
     }
-    // in-place compaction: survivors land at or before the start of the batch that was just read
-    const uint64_t m = __ballot(keep);
-    if (m) {
-      if (keep) region[nkeep + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = out;
-      nkeep += (int)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    int nkeep = 0;
+    for (int base = 0; base < ncorner; base += 64 * NB) {
+      uint32_t e[NB], out[NB];
+      bool keep[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) e[u] = base + 64 * u + lane < ncorner ? C[base + 64 * u + lane] : 0u;
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const bool valid = base + 64 * u + lane < ncorner;
+        keep[u] = false, out[u] = 0;
+        const int xl = (int)(e[u] & 0xff), rrp = (int)((e[u] >> 8) & 0xff), ss = (int)(e[u] >> 16);
+        // the sub-strip the corner belongs to: columns [es * sub_px, (es + 1) * sub_px) of the tile, rows of segment es
+        const int es = (xl * nsub) >> 8;
+        const int xs = xl - es * sub_px, py0e = py0 + es * L.rows_per_seg;
+        const int nrows_e = min(py0e + L.rows_per_seg, g.h) - py0e;
+        const bool owned = valid && xs >= 4 && xs < sub_px - 4 && rrp >= 1 && rrp <= nrows_e;  // not a halo-ring corner
+        if (owned) {
+          // coordinates relative to (minBorder, minBorder), as the candidate list wants them
+          const int xr = X0 + xs - kPad - kMinBorder, yr = py0e + rrp - 1 - kPad - kMinBorder;
+          int cj = (int)__umulhi((uint32_t)(xr - 3), g.inv_wcell), ci = (int)__umulhi((uint32_t)(yr - 3), g.inv_hcell);  // (xr-3)/wCell, (yr-3)/hCell
+          cj = cj > g.nCols - 1 ? g.nCols - 1 : cj;
+          ci = ci > g.nRows - 1 ? g.nRows - 1 : ci;
+          // interior of the owning cell: [j*wCell + 3, min(j*wCell + wCell + 6, bw) - 3) and the same in y.  The corner lies inside it, so
+          // a neighbour can only fall outside on the side where the corner touches the interior's edge
+          const int cx0 = cj * g.wCell + 3, cx1 = min(cj * g.wCell + g.wCell + 6, g.bw) - 3;
+          const int cy0 = ci * g.hCell + 3, cy1 = min(ci * g.hCell + g.hCell + 6, g.bh) - 3;
+          const bool okx[3] = {xr > cx0, true, xr + 1 < cx1}, oky[3] = {yr > cy0, true, yr + 1 < cy1};
+          const uint8_t* c = tile + rrp * FT_PITCH + xl;
+          bool k = true;
+#pragma unroll
+          for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+              if (dx == 0 && dy == 0) continue;
+              const int nb = (okx[dx + 1] && oky[dy + 1]) ? (int)c[dy * FT_PITCH + dx] : 0;
+              k = k && ss > nb;
+            }
+          keep[u] = k;
+          if (k && ss >= fast_th) hi[ci * g.nCols + cj] = 1;  // idempotent plain store: every writer stores the same value
+          out[u] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)ss << 24);
+        }
+      }
+      // in-place compaction: survivors land at or before the start of the group that was just read
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const uint64_t m = __ballot(keep[u]);
+        if (m) {
+          if (keep[u]) C[nkeep + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = out[u];
+          nkeep += (int)__popcll(m);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return nkeep;
+  };
+  // Survivors leave the wavefront in two classes (the per-cell threshold vote of src/ORBextractor.cc:792-799 needs every region of a
+  // cell to be finished, so it is taken by the quad-tree kernel): those that reach fastTh are candidates whatever the vote says and go
+  // straight to the level's candidate array; the rest (7 <= score < fastTh) wait in the level's "low" list for the vote.  One atomic
+  // per class and wavefront reserves the slots; the order inside the arrays is arbitrary (the quad-tree orders by coordinates).
+  auto emit = [&](uint32_t* C, int nkeep) {
+    int n_hi = 0;
+    for (int base = 0; base < nkeep; base += 64) {
+      const bool valid = base + lane < nkeep;
+      const uint32_t e = valid ? C[base + lane] : 0u;
+      n_hi += (int)__popcll(__ballot(valid && (int)(e >> 24) >= fast_th));
+    }
+    const int n_lo = nkeep - n_hi;
+    int32_t* cur = cursor + 2 * ((int64_t)f * L.nlevels + level);
+    int off_hi = 0, off_lo = 0;
+    if (lane == 0) {
+      if (n_hi) off_hi = atomicAdd(&cur[0], n_hi);
+      if (n_lo) off_lo = atomicAdd(&cur[1], n_lo);
+    }
+    off_hi = __builtin_amdgcn_readfirstlane(off_hi), off_lo = __builtin_amdgcn_readfirstlane(off_lo);
+    const int64_t co = (int64_t)f * cand_block + g.cand_off;
+    for (int base = 0; base < nkeep; base += 64) {
+      const bool valid = base + lane < nkeep;
+      const uint32_t e = valid ? C[base + lane] : 0u;
+      const bool is_hi = valid && (int)(e >> 24) >= fast_th, is_lo = valid && !is_hi;
+      const uint64_t mh = __ballot(is_hi), ml = __ballot(is_lo);
+      if (is_hi) {
+        const int pos = off_hi + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mh, 0u));
+        if (pos < g.cand_cap) {
+          cand_xy[co + pos] = (e & 0xfffu) | (((e >> 12) & 0xfffu) << 16);
+          cand_sc[co + pos] = e >> 24;
+        }
+      } else if (is_lo) {
+        const int pos = off_lo + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u));
+        if (pos < g.cand_cap) cand_lo[co + pos] = e;
+      }
+      off_hi += (int)__popcll(mh), off_lo += (int)__popcll(ml);
     }
   };
-  // the first 512 corners (the usual case: all of them) are fetched with one batch of independent loads and kept in registers for
-  // both sweeps; longer lists continue from memory
-  constexpr int NR = 8;
-  uint32_t ev[NR];
-#pragma unroll
-  for (int k = 0; k < NR; ++k) ev[k] = lane + 64 * k < ncorner ? region[lane + 64 * k] : 0u;
-#pragma unroll
-  for (int k = 0; k < NR; ++k)
-    if (lane + 64 * k < ncorner) tile[((ev[k] >> 8) & 0xff) * FT_PITCH + (ev[k] & 0xff)] = (uint8_t)(ev[k] >> 16);
-  for (int base = 64 * NR; base < ncorner; base += 64) {
-    if (base + lane < ncorner) {
-      const uint32_t e = region[base + lane];
-      tile[((e >> 8) & 0xff) * FT_PITCH + (e & 0xff)] = (uint8_t)(e >> 16);
-    }
+  // (generic pointer from here on: the list is in LDS unless the region overflowed it)
+  uint32_t* C = list;
+  if (nflushed) {
+    for (int i = lane; i < ncorner; i += 64) region[nflushed + i] = list[i];
+    ncorner += nflushed;
+    C = region;
+    __threadfence_block();  // the list in memory was written by this wavefront's own global stores
   }
-#pragma unroll
-  for (int k = 0; k < NR; ++k)
-    if (64 * k < ncorner) nms_one(ev[k], lane + 64 * k < ncorner);
-  for (int base = 64 * NR; base < ncorner; base += 64) {
-    const bool valid = base + lane < ncorner;
-    nms_one(valid ? region[base + lane] : 0u, valid);
-  }
-  if (lane == 0) cor_n[region_id] = nkeep;
+  const int nkeep = nms_list(C);
+  if (nflushed) __threadfence_block();
+  emit(C, nkeep);
 }
 
 // Rows per (strip, segment) work item.  A wavefront lives for the whole item, so long segments leave a long under-filled
@@ -383,13 +459,14 @@ FastLevels fast_levels(const Geom& g, int batch) {
   return L;
 }
 
-// scores + in-cell NMS per region (the per-cell vote and the candidate emit: octree.hip)
-void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, int fast_th, uint32_t* d_cor, int32_t* d_cor_n,
-                       uint8_t* d_cell_hi, int batch) {
+// scores + in-cell NMS per region; survivors to the candidate array / the low list of their (frame, level) (the per-cell vote: octree.hip)
+void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, int fast_th, uint32_t* d_cor, uint8_t* d_cell_hi,
+                       uint32_t* d_cand_xy, uint32_t* d_cand_sc, uint32_t* d_cand_lo, int64_t cand_block, int32_t* d_cursor, int batch) {
   const int t_min = fast_th < 7 ? fast_th : 7;
   const FastLevels L = fast_levels(g, batch);
   const dim3 grid((L.items_per_frame + 3) / 4, batch);
-  hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, s, d_pyr, pyr_block, L, t_min, fast_th, d_cor, d_cor_n, d_cell_hi);
+  hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, s, d_pyr, pyr_block, L, t_min, fast_th, d_cor, d_cell_hi, d_cand_xy, d_cand_sc, d_cand_lo,
+                     cand_block, d_cursor);
 }
 
 }  // namespace uvo

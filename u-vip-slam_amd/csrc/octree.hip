@@ -42,9 +42,9 @@ static inline size_t oct_lds_bytes(int M, int Mp2, int pyr_words) {
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max, int pyr_words, int box_region,
-                                                        FastLevels FL, int fast_th, const uint32_t* __restrict__ cor,
-                                                        const int32_t* __restrict__ cor_n, uint8_t* cell_hi,
+__global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max, int pyr_words, int box_region, int lds_bytes,
+                                                        FastLevels FL, const uint32_t* __restrict__ cand_lo,
+                                                        int32_t* __restrict__ cursor, uint8_t* cell_hi,
                                                         uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc,
                                                         int64_t cand_block, int32_t* __restrict__ cand_count,
                                                         uint32_t* __restrict__ pstate, uint32_t* __restrict__ sel_xy,
@@ -61,68 +61,73 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
     }
   } stamp{t_begin, (int)(blockIdx.x * gridDim.y + blockIdx.y)};
 #endif
+  OCT_TRACE_MARK()  // kernel start
   const LevelGeom& g = lv[level];
   const int64_t co = f * cand_block + g.cand_off;
-  // ---- candidates of this (frame, level): the NMS survivors of the level's FAST regions that pass the per-cell threshold
-  // (FAST(cell, fastTh); if empty FAST(cell, 7): src/ORBextractor.cc:792-799), gathered by the workgroup itself ----
+  // ---- candidates of this (frame, level).  k_fast_score has already put the NMS survivors that reach fastTh into the candidate array
+  // (n_hi of them); the others (7 <= score < fastTh) wait in the level's low list for the per-cell vote, which needs every region of
+  // a cell finished: FAST(cell, fastTh); if empty FAST(cell, 7) (src/ORBextractor.cc:792-799) -- a low survivor is a candidate iff its
+  // cell holds no survivor >= fastTh.  One contiguous read of the low list, appended behind the first n_hi candidates. ----
   __shared__ int s_pcount;
   {
     const FastLevel fg = FL.l[level];
-    const int first = fg.first_item, n_items = fg.items;
-    if (threadIdx.x == 0) s_pcount = 0;
-    __syncthreads();
+    int32_t* cur = cursor + 2 * ((int64_t)f * nlevels + level);
+    const int n_hi = min(cur[0], g.cand_cap), n_lo = min(cur[1], g.cand_cap);
+    if (threadIdx.x == 0) s_pcount = n_hi;
     uint8_t* hi = cell_hi + (int64_t)f * FL.flags_per_frame + fg.flag_base;
-    // a wavefront takes four regions at a time so that the three dependent loads (count -> entries -> cell flag) are each issued
-    // for all four before the first result is needed; one LDS atomic per wavefront and batch reserves the output slots
-    const int64_t region0 = (int64_t)f * FL.items_per_frame + first;
-    const int wv = wave_in_block(), lane = threadIdx.x & 63;
-    constexpr int GU = 4, NW = NT / 64;
-    for (int r0 = wv; r0 < n_items; r0 += NW * GU) {
-      int n[GU], nmax = 0;
+    const int lane = threadIdx.x & 63;
+    // the level's cell flags go to LDS first (the node tables are not live yet: the staging shares their bytes); levels with more
+    // cells than fit read them from memory
+    uint8_t* s_flag = lds;
+    const int n_flags = fg.nRows * fg.nCols;
+    const bool flag_lds = n_flags <= lds_bytes;
+    if (flag_lds)
+      for (int i = threadIdx.x; i < n_flags; i += NT) s_flag[i] = hi[i];
+    __syncthreads();
+    for (int i0 = 0; i0 < n_lo; i0 += 4 * NT) {
+      uint32_t e[4];
+      bool emit[4];
 #pragma unroll
-      for (int u = 0; u < GU; ++u) {
-        const int r = r0 + NW * u;
-        n[u] = r < n_items ? cor_n[region0 + r] : 0;
-        nmax = n[u] > nmax ? n[u] : nmax;
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NT + (int)threadIdx.x;
+        e[u] = i < n_lo ? cand_lo[co + i] : 0u;
       }
-      for (int base = 0; base < nmax; base += 64) {
-        uint32_t e[GU];
-        bool emit[GU];
 #pragma unroll
-        for (int u = 0; u < GU; ++u)
-          e[u] = base + lane < n[u] ? cor[(region0 + r0 + NW * u) * (int64_t)FS_REGION_ENTRIES + base + lane] : 0u;
-#pragma unroll
-        for (int u = 0; u < GU; ++u) {
-          emit[u] = false;
-          if (base + lane < n[u]) {
-            const int xr = (int)(e[u] & 0xfff), yr = (int)((e[u] >> 12) & 0xfff), sc = (int)(e[u] >> 24);
-            int cj = (int)__umulhi((uint32_t)(xr - 3), fg.inv_wcell), ci = (int)__umulhi((uint32_t)(yr - 3), fg.inv_hcell);
-            cj = cj > fg.nCols - 1 ? fg.nCols - 1 : cj;
-            ci = ci > fg.nRows - 1 ? fg.nRows - 1 : ci;
-            emit[u] = sc >= (hi[ci * fg.nCols + cj] ? fast_th : 7);
-          }
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NT + (int)threadIdx.x;
+        emit[u] = false;
+        if (i < n_lo) {
+          const int xr = (int)(e[u] & 0xfff), yr = (int)((e[u] >> 12) & 0xfff), sc = (int)(e[u] >> 24);
+          int cj = (int)__umulhi((uint32_t)(xr - 3), fg.inv_wcell), ci = (int)__umulhi((uint32_t)(yr - 3), fg.inv_hcell);
+          cj = cj > fg.nCols - 1 ? fg.nCols - 1 : cj;
+          ci = ci > fg.nRows - 1 ? fg.nRows - 1 : ci;
+          const uint8_t flag = flag_lds ? s_flag[ci * fg.nCols + cj] : hi[ci * fg.nCols + cj];
+          emit[u] = !flag && sc >= 7;
         }
+      }
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
-          const uint64_t m = __ballot(emit[u]);
-          if (m == 0) continue;
-          int slot = 0;
-          if (lane == 0) slot = atomicAdd(&s_pcount, (int)__popcll(m));
-          slot = __shfl(slot, 0, 64);
-          if (emit[u]) {
-            const int pos = slot + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (pos < g.cand_cap) {
-              cand_xy[co + pos] = (e[u] & 0xfffu) | (((e[u] >> 12) & 0xfffu) << 16);
-              cand_sc[co + pos] = e[u] >> 24;
-            }
+      for (int u = 0; u < 4; ++u) {
+        const uint64_t m = __ballot(emit[u]);
+        if (m == 0) continue;
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&s_pcount, (int)__popcll(m));
+        slot = __shfl(slot, 0, 64);
+        if (emit[u]) {
+          const int pos = slot + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          if (pos < g.cand_cap) {
+            cand_xy[co + pos] = (e[u] & 0xfffu) | (((e[u] >> 12) & 0xfffu) << 16);
+            cand_sc[co + pos] = e[u] >> 24;
           }
         }
       }
     }
     __syncthreads();
-    // the flags of this (frame, level) have been consumed: leave them zero for the next batch (k_fast_score only ever sets them)
-    for (int i = threadIdx.x; i < fg.nRows * fg.nCols; i += NT) hi[i] = 0;
+    // the flags and cursors of this (frame, level) have been consumed: leave them zero for the next batch (k_fast_score only ever
+    // sets / advances them)
+    for (int i = threadIdx.x; i < n_flags; i += NT) hi[i] = 0;
+    if (threadIdx.x == 0) cur[0] = 0, cur[1] = 0;
   }
+  OCT_TRACE_MARK()  // end of the candidate gather
   int P = s_pcount;
   if (threadIdx.x == 0) cand_count[f * nlevels + level] = P;
   P = P > g.cand_cap ? g.cand_cap : P;
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
   if (threadIdx.x == 0) *out_n = n;
 }
 
-int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, int fast_th, const uint32_t* d_cor, const int32_t* d_cor_n,
+int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_lo, int32_t* d_cursor,
                    uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
                    int32_t* d_sel_count, int batch) {
   int M = 0;
@@ -210,11 +215,11 @@ int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, cons
   }
 #endif
   if (wide)
-    hipLaunchKernelGGL(k_octree<1024>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), fast_levels(g, batch), fast_th, d_cor,
-                       d_cor_n, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count);
+    hipLaunchKernelGGL(k_octree<1024>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), (int)lds, fast_levels(g, batch), d_cand_lo,
+                       d_cursor, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count);
   else
-    hipLaunchKernelGGL(k_octree<OCT_THREADS>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), fast_levels(g, batch), fast_th,
-                       d_cor, d_cor_n, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block,
+    hipLaunchKernelGGL(k_octree<OCT_THREADS>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), (int)lds, fast_levels(g, batch),
+                       d_cand_lo, d_cursor, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block,
                        d_sel_count);
   return UVO_OK;
 }

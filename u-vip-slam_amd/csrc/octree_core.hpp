@@ -70,6 +70,7 @@ __device__ unsigned long long g_oct_blocks[4096];
 #endif
 #define OCT_PHASE_BEGIN for (int tid = 0; tid < OCT_THREADS; ++tid) {
 #define OCT_PHASE_END }
+#define OCT_TRACE_MARK()
 template <class T, class U>
 static inline T oct_host_add(T* p, U v) {
   T o = *p;
