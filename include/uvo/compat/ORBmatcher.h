@@ -18,6 +18,11 @@
  *   SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th)          :286-407   (loop closing)
  *   Fuse(KeyFrame*, Scw, vpPoints, th)                                   :1136-1265 (loop closing; map mutation here)
  *   SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)             :1267-1505
+ * and the four members nothing in the reference calls (kept so that the class is complete):
+ *   WindowSearch(F1, F2, windowSize, vpMapPointMatches2, minOctave, maxOctave)   :409-516
+ *   SearchByProjection(F1, F2, windowSize, vpMapPointMatches2)                   :519-594
+ *   SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)      :598-713
+ *   SearchByProjection(CurrentFrame, LastFrame, th)                              :1507-1620
  */
 #ifndef UVO_COMPAT_ORBMATCHER_H_
 #define UVO_COMPAT_ORBMATCHER_H_
@@ -495,6 +500,159 @@ class UVO_COMPAT_MATCHER_NAME {
   const std::string& last_error() const { return err_; }
   void set_device(int device) { device_ = device; }
 
+  /* ---- members without a caller in the reference ---- */
+
+  /* int ORBmatcher::WindowSearch(FrameKTL &F1, FrameKTL &F2, int windowSize, vector<MapPoint*> &vpMapPointMatches2, int minOctave, int maxOctave) */
+  template <class Frame, class MapPointT>
+  int WindowSearch(Frame& F1, Frame& F2, int windowSize, std::vector<MapPointT*>& vpMapPointMatches2, int minScaleLevel = -1,
+                   int maxScaleLevel = 0x7fffffff) {
+    const int n1 = (int)F1.mvpMapPoints.size(), n2 = (int)F2.mvKeysUn.size();
+    vpMapPointMatches2 = std::vector<MapPointT*>(F2.mvpMapPoints.size(), static_cast<MapPointT*>(NULL));  // :412
+    if (n1 == 0 || n2 == 0 || ensure(n1 > n2 ? n1 : n2, n1) != UVO_OK) return 0;
+    static_assert(sizeof(F1.mvKeysUn[0]) == sizeof(uvo_keypoint), "keypoint layout must be cv::KeyPoint");
+    const uvo_keypoint* k1 = reinterpret_cast<const uvo_keypoint*>(F1.mvKeysUn.data());
+    std::vector<float> qx(n1), qy(n1), qr(n1, (float)windowSize), qa(n1);
+    std::vector<int32_t> lv(n1), match(n1, -1);
+    std::vector<uint8_t> valid(n1), d1((size_t)n1 * 32), d2((size_t)n2 * 32);
+    for (int i = 0; i < n1; ++i) {
+      MapPointT* p = F1.mvpMapPoints[i];
+      const int level1 = k1[i].octave;
+      valid[i] = p && !p->isBad() && !(minScaleLevel > 0 && level1 < minScaleLevel) && !(maxScaleLevel < 0x7fffffff && level1 > maxScaleLevel);  // :425-441
+      qx[i] = k1[i].x, qy[i] = k1[i].y, qa[i] = k1[i].angle, lv[i] = level1;
+      std::memcpy(&d1[(size_t)i * 32], F1.mDescriptors.ptr(i), 32);
+    }
+    for (int k = 0; k < n2; ++k) std::memcpy(&d2[(size_t)k * 32], F2.mDescriptors.ptr(k), 32);
+    uvo_match_rule rule = {UVO_RULE_BEST_RATIO_LEQ, TH_HIGH, mfNNratio, 1, mbCheckOrientation ? 1 : 0};
+    int nmatches = 0;
+    if (uvo_match_windows(m_, reinterpret_cast<const uvo_keypoint*>(F2.mvKeysUn.data()), n2, d2.data(), nullptr, (int)F2.mnMinX, (int)F2.mnMinY,
+                          (int)F2.mnMaxX, (int)F2.mnMaxY, n1, qx.data(), qy.data(), qr.data(), lv.data(), lv.data(), valid.data(), d1.data(), qa.data(),
+                          &rule, match.data(), nullptr, &nmatches) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    for (int i = 0; i < n1; ++i)
+      if (match[i] >= 0) vpMapPointMatches2[match[i]] = F1.mvpMapPoints[i];  // :477
+    return nmatches;
+  }
+
+  /* int ORBmatcher::SearchByProjection(FrameKTL &F1, FrameKTL &F2, int windowSize, vector<MapPoint*> &vpMapPointMatches2) */
+  template <class Frame, class MapPointT>
+  int SearchByProjection(Frame& F1, Frame& F2, int windowSize, std::vector<MapPointT*>& vpMapPointMatches2) {
+    vpMapPointMatches2 = F2.mvpMapPoints;  // :521
+    const std::set<MapPointT*> found(vpMapPointMatches2.begin(), vpMapPointMatches2.end());
+    const int n1 = (int)F1.mvpMapPoints.size(), n2 = (int)F2.mvKeysUn.size();
+    if (n1 == 0 || n2 == 0 || ensure(n1 > n2 ? n1 : n2, n1) != UVO_OK) return 0;
+    uvo_camera_pose cam;
+    pose_of(F2, cam);
+    std::vector<float> xyz((size_t)n1 * 3, 0.f), u(n1), v(n1), qr(n1, (float)windowSize), one(1, 1.f);
+    std::vector<uint8_t> usable(n1, 0), valid(n1), blocked(n2), d1((size_t)n1 * 32), d2((size_t)n2 * 32);
+    std::vector<int32_t> lv(n1), dummy(n1), match(n1, -1);
+    for (int i = 0; i < n1; ++i) {
+      MapPointT* p = F1.mvpMapPoints[i];
+      lv[i] = F1.mvKeysUn[i].octave;
+      std::memcpy(&d1[(size_t)i * 32], F1.mDescriptors.ptr(i), 32);
+      if (!p || p->isBad() || found.count(p)) continue;  // :533-537
+      usable[i] = 1;
+      auto x3Dw = p->GetWorldPos();
+      for (int k = 0; k < 3; ++k) xyz[(size_t)i * 3 + k] = x3Dw.template at<float>(k);
+    }
+    for (int k = 0; k < n2; ++k) {
+      std::memcpy(&d2[(size_t)k * 32], F2.mDescriptors.ptr(k), 32);
+      blocked[k] = vpMapPointMatches2[k] ? 1 : 0;  // :566
+    }
+    if (uvo_project_points(m_, UVO_PROJECT_PIXEL, &cam, n1, xyz.data(), nullptr, nullptr, nullptr, nullptr, usable.data(), one.data(), 1, 0.f, 0.f,
+                           valid.data(), u.data(), v.data(), dummy.data(), nullptr) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    uvo_match_rule rule = {UVO_RULE_BEST_RATIO_LEQ, TH_HIGH, mfNNratio, 1, 0};
+    int nmatches = 0;
+    if (uvo_match_windows(m_, reinterpret_cast<const uvo_keypoint*>(F2.mvKeysUn.data()), n2, d2.data(), blocked.data(), (int)F2.mnMinX, (int)F2.mnMinY,
+                          (int)F2.mnMaxX, (int)F2.mnMaxY, n1, u.data(), v.data(), qr.data(), lv.data(), lv.data(), valid.data(), d1.data(), nullptr, &rule,
+                          match.data(), nullptr, &nmatches) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    for (int i = 0; i < n1; ++i)
+      if (match[i] >= 0) vpMapPointMatches2[match[i]] = F1.mvpMapPoints[i];  // :585
+    return nmatches;
+  }
+
+  /* int ORBmatcher::SearchForInitialization(FrameKTL &F1, FrameKTL &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize) */
+  template <class Frame, class Point2fT>
+  int SearchForInitialization(Frame& F1, Frame& F2, std::vector<Point2fT>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10) {
+    const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();
+    vnMatches12 = std::vector<int>(n1, -1);  // :601
+    if (n1 == 0 || n2 == 0 || ensure(n1 > n2 ? n1 : n2, n1) != UVO_OK) return 0;
+    const uvo_keypoint* k1 = reinterpret_cast<const uvo_keypoint*>(F1.mvKeysUn.data());
+    const uvo_keypoint* k2 = reinterpret_cast<const uvo_keypoint*>(F2.mvKeysUn.data());
+    std::vector<float> qx(n1), qy(n1), qr(n1, (float)windowSize), qa(n1);
+    std::vector<int32_t> lv(n1), match(n1, -1);
+    std::vector<uint8_t> valid(n1), d1((size_t)n1 * 32), d2((size_t)n2 * 32);
+    for (int i = 0; i < n1; ++i) {
+      lv[i] = k1[i].octave;
+      valid[i] = lv[i] <= 0;  // :620-622
+      qx[i] = vbPrevMatched[i].x, qy[i] = vbPrevMatched[i].y, qa[i] = k1[i].angle;
+      std::memcpy(&d1[(size_t)i * 32], F1.mDescriptors.ptr(i), 32);
+    }
+    for (int k = 0; k < n2; ++k) std::memcpy(&d2[(size_t)k * 32], F2.mDescriptors.ptr(k), 32);
+    uvo_match_rule rule = {UVO_RULE_INIT_STEAL, TH_LOW, mfNNratio, 0, mbCheckOrientation ? 1 : 0};
+    int nmatches = 0;
+    if (uvo_match_windows(m_, reinterpret_cast<const uvo_keypoint*>(F2.mvKeysUn.data()), n2, d2.data(), nullptr, (int)F2.mnMinX, (int)F2.mnMinY,
+                          (int)F2.mnMaxX, (int)F2.mnMaxY, n1, qx.data(), qy.data(), qr.data(), lv.data(), lv.data(), valid.data(), d1.data(), qa.data(),
+                          &rule, match.data(), nullptr, &nmatches) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    for (int i = 0; i < n1; ++i) {
+      vnMatches12[i] = match[i];
+      if (match[i] >= 0) vbPrevMatched[i].x = k2[match[i]].x, vbPrevMatched[i].y = k2[match[i]].y;  // :705-708
+    }
+    return nmatches;
+  }
+
+  /* int ORBmatcher::SearchByProjection(FrameKTL &CurrentFrame, const FrameKTL &LastFrame, float th) */
+  template <class Frame>
+  int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, float th) {
+    const int n = (int)CurrentFrame.mvKeysUn.size(), nl = (int)LastFrame.mvpMapPoints.size();
+    if (n == 0 || nl == 0 || ensure(n, nl) != UVO_OK) return 0;
+    uvo_camera_pose cam;
+    pose_of(CurrentFrame, cam);
+    std::vector<float> xyz((size_t)nl * 3, 0.f), u(nl), v(nl), ang(nl, 0.f);
+    std::vector<uint8_t> usable(nl, 0), valid(nl), dl((size_t)nl * 32), fdesc((size_t)n * 32);
+    std::vector<int32_t> oct(nl, 0), dummy(nl), assigned(n);
+    for (int i = 0; i < nl; ++i) {
+      auto* pMP = LastFrame.mvpMapPoints[i];
+      std::memcpy(&dl[(size_t)i * 32], LastFrame.mDescriptors.ptr(i), 32);
+      oct[i] = LastFrame.mvKeys[i].octave, ang[i] = LastFrame.mvKeysUn[i].angle;  // :1547, :1592
+      if (!pMP || LastFrame.mvbOutlier[i]) continue;  // :1524-1526
+      usable[i] = 1;
+      auto x3Dw = pMP->GetWorldPos();
+      for (int k = 0; k < 3; ++k) xyz[(size_t)i * 3 + k] = x3Dw.template at<float>(k);
+    }
+    const int nlev = (int)CurrentFrame.mvScaleFactors.size();
+    if (uvo_project_points(m_, UVO_PROJECT_PIXEL_BOUNDED, &cam, nl, xyz.data(), nullptr, nullptr, nullptr, nullptr, usable.data(),
+                           CurrentFrame.mvScaleFactors.data(), nlev, 0.f, 0.f, valid.data(), u.data(), v.data(), dummy.data(), nullptr) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    for (int k = 0; k < n; ++k) {
+      std::memcpy(&fdesc[(size_t)k * 32], CurrentFrame.mDescriptors.ptr(k), 32);
+      assigned[k] = CurrentFrame.mvpMapPoints[k] ? 0x7fffffff : -1;  // :1566
+    }
+    int nmatches = 0;
+    if (uvo_search_by_projection_kf(m_, reinterpret_cast<const uvo_keypoint*>(CurrentFrame.mvKeysUn.data()), n, fdesc.data(), (int)CurrentFrame.mnMinX,
+                                    (int)CurrentFrame.mnMinY, (int)CurrentFrame.mnMaxX, (int)CurrentFrame.mnMaxY, assigned.data(), nl, u.data(), v.data(),
+                                    oct.data(), valid.data(), dl.data(), ang.data(), CurrentFrame.mvScaleFactors.data(), nlev, th, TH_HIGH,
+                                    mbCheckOrientation ? 1 : 0, &nmatches) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    for (int k = 0; k < n; ++k)
+      if (assigned[k] >= 0 && assigned[k] != 0x7fffffff) CurrentFrame.mvpMapPoints[k] = LastFrame.mvpMapPoints[assigned[k]];  // :1585
+    return nmatches;
+  }
+
  protected:
   float mfNNratio;
   bool mbCheckOrientation;
@@ -590,6 +748,17 @@ class UVO_COMPAT_MATCHER_NAME {
       std::memcpy(&desc[i * 32], d.ptr(0), 32);
       angle[i] = pKF->GetKeyPointUn((int)i).angle;
     }
+  }
+  /* Rcw, tcw (mTcw.rowRange(0,3).colRange(0,3) / .col(3)), intrinsics and image bounds of a frame */
+  template <class Frame>
+  static void pose_of(const Frame& F, uvo_camera_pose& cam) {
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) cam.rcw[3 * r + c] = F.mTcw.template at<float>(r, c);
+      cam.tcw[r] = F.mTcw.template at<float>(r, 3);
+      cam.ow[r] = 0.f;
+    }
+    cam.fx = F.fx, cam.fy = F.fy, cam.cx = F.cx, cam.cy = F.cy;
+    cam.min_x = F.mnMinX, cam.max_x = F.mnMaxX, cam.min_y = F.mnMinY, cam.max_y = F.mnMaxY;
   }
   int ensure(int n, int nmp) {
     if (m_ && n <= cap_n_ && nmp <= cap_mp_) return UVO_OK;

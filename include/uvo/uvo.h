@@ -310,7 +310,14 @@ enum {
   UVO_RULE_BEST_ONLY = 1,             /* SearchByProjection(F, pKF, ...) :1681-1701; Fuse :1084-1119: d <= max_dist */
   UVO_RULE_BEST_RATIO_LE = 2,         /* SearchByBoW(pKF, F, ...) :194-218: d <= max_dist && d < nnratio * second */
   UVO_RULE_BEST_RATIO_LT = 3,         /* SearchByBoW(pKF1, pKF2, ...) :762-788: d < max_dist && d < nnratio * second */
-  UVO_RULE_TRIANGULATION = 4          /* SearchForTriangulation :893-935: d <= max_dist, sorted, d <= 2*best, epipolar */
+  UVO_RULE_TRIANGULATION = 4,         /* SearchForTriangulation :893-935: d <= max_dist, sorted, d <= 2*best, epipolar */
+  /* the members of ORBmatcher that have no caller in the reference */
+  UVO_RULE_BEST_RATIO_LEQ = 5,        /* WindowSearch :409-516, SearchByProjection(F1, F2, windowSize) :519-594: d <= nnratio * second
+                                         (second = INT_MAX when there is none) && d <= max_dist; both use exclusive = 1 */
+  UVO_RULE_INIT_STEAL = 6             /* SearchForInitialization :598-713: candidates whose target is currently matched at <= d are
+                                         skipped, d <= max_dist && d < nnratio * second, and a later query with a strictly smaller
+                                         distance takes a target over (`exclusive` is ignored); match[i] >= 0 only for queries that
+                                         still hold their target at the end; the rotation histogram counts every accept (:662-670) */
 };
 typedef struct uvo_match_rule {
   int32_t rule;              /* UVO_RULE_* */
@@ -420,10 +427,17 @@ int uvo_fuse(uvo_matcher* m, const uvo_keypoint* kp, int n, const uint8_t* desc,
  * (the reference reads it before it is initialised).
  *   usable[i]      : 0 = skip (NULL / isBad / already found / already in the key frame ...), may be NULL
  *   min_distance_inv / max_distance_inv : GetMinDistanceInvariance() / GetMaxDistanceInvariance() of every point
- *                    (max_distance_inv is not read by KF_RELOC); max_distance: the raw mfMaxDistance member that
+ *                    (max_distance_inv is not read by KF_RELOC; the PIXEL modes read neither and accept NULL); max_distance: the raw mfMaxDistance member that
  *                    MapPoint::PredictScale divides by (FRUSTUM only); normal: GetNormal(), modes FRUSTUM and FUSE
  */
-enum { UVO_PROJECT_FRUSTUM = 0, UVO_PROJECT_KF_RELOC = 1, UVO_PROJECT_FUSE = 2 };
+enum {
+  UVO_PROJECT_FRUSTUM = 0,
+  UVO_PROJECT_KF_RELOC = 1,
+  UVO_PROJECT_FUSE = 2,
+  /* the two caller-less projection searches: u, v only; the caller supplies the level (the keypoint's octave) */
+  UVO_PROJECT_PIXEL_BOUNDED = 3, /* SearchByProjection(CurrentFrame, LastFrame, th) :1530-1545: valid = inside [min_x, max_x] x [min_y, max_y] */
+  UVO_PROJECT_PIXEL = 4          /* SearchByProjection(F1, F2, windowSize) :541-550: no test (not even the depth's sign) */
+};
 typedef struct uvo_camera_pose {
   float rcw[9]; /* row-major world -> camera rotation */
   float tcw[3];

@@ -173,7 +173,7 @@ int search_by_projection(const FrameGrid& g, const uint8_t* fdesc, int32_t* assi
 }
 
 
-static const int TH_LOW = 50, HISTO_LENGTH = 30;  // src/ORBmatcher.cc:41-42
+static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;  // src/ORBmatcher.cc:40-42
 
 // ORBmatcher::ComputeThreeMaxima: src/ORBmatcher.cc:1748-1789
 void compute_three_maxima(const int* sizes, int L, int& ind1, int& ind2, int& ind3) {
@@ -263,6 +263,194 @@ int search_by_projection_kf(const FrameGrid& g, const uint8_t* fdesc, int32_t* a
 }
 
 // merge walk of :178-249 / :741-819 / :876-965 (std::map iteration; lower_bound jumps == sorted merge)
+// ---- the four ORBmatcher members without a caller in the reference, as literal loops ----
+static void mat_Rp_plus_t(const float* R, const float* p, const float* t, float* out);
+
+// ORBmatcher::WindowSearch(F1, F2, windowSize, vpMapPointMatches2, minScaleLevel, maxScaleLevel): src/ORBmatcher.cc:409-516.
+// has_mp1[i1] = F1.mvpMapPoints[i1] non-null and not bad.  match21[i2] = vnMatches21 (index into F1, or -1) -- vpMapPointMatches2[i2]
+// is F1's map point at that index.
+int window_search(const KeyPoint* kp1, int n1, const uint8_t* desc1, const uint8_t* has_mp1, const FrameGrid& g2, const uint8_t* desc2, int n2,
+                  int windowSize, int minScaleLevel, int maxScaleLevel, float nnratio, bool checkOri, int32_t* match21) {
+  int nmatches = 0;
+  for (int i = 0; i < n2; i++) match21[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const bool bMinLevel = minScaleLevel > 0;
+  const bool bMaxLevel = maxScaleLevel < 0x7fffffff;
+  for (int i1 = 0; i1 < n1; i1++) {
+    if (!has_mp1[i1]) continue;
+    const KeyPoint& k1 = kp1[i1];
+    int level1 = k1.octave;
+    if (bMinLevel)
+      if (level1 < minScaleLevel) continue;
+    if (bMaxLevel)
+      if (level1 > maxScaleLevel) continue;
+    std::vector<int> vIndices2 = g2.GetFeaturesInArea(k1.x, k1.y, windowSize, level1, level1);
+    if (vIndices2.empty()) continue;
+    const uint8_t* d1 = desc1 + (size_t)i1 * 32;
+    int bestDist = 0x7fffffff, bestDist2 = 0x7fffffff, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      if (match21[i2] >= 0) continue;  // vpMapPointMatches2[i2]
+      int dist = descriptor_distance(d1, desc2 + (size_t)i2 * 32);
+      if (dist < bestDist) {
+        bestDist2 = bestDist;
+        bestDist = dist;
+        bestIdx2 = i2;
+      } else if (dist < bestDist2) {
+        bestDist2 = dist;
+      }
+    }
+    if (bestDist <= bestDist2 * nnratio && bestDist <= TH_HIGH) {
+      match21[bestIdx2] = i1;
+      nmatches++;
+      rotHist[rot_bin(k1.angle, g2.kps[bestIdx2].angle)].push_back(bestIdx2);
+    }
+  }
+  if (checkOri) nmatches -= apply_rot_hist(rotHist, [&](int idx2) { match21[idx2] = -1; });
+  return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(F1, F2, windowSize, vpMapPointMatches2): :519-594.  usable1[i1] = map point of F1's keypoint i1
+// exists, is not bad and is not among F2's map points already; assigned2[i2] in/out: >= 0 where vpMapPointMatches2[i2] is set
+// (on return: the F1 index for new matches).  Camera = F2's pose and intrinsics.
+int search_by_projection_frames(const KeyPoint* kp1, int n1, const uint8_t* desc1, const uint8_t* usable1, const float* xyz1, const Camera& F2,
+                                const FrameGrid& g2, const uint8_t* desc2, int32_t* assigned2, int windowSize, float nnratio) {
+  int nmatches = 0;
+  for (int i1 = 0; i1 < n1; i1++) {
+    if (!usable1[i1]) continue;
+    int level1 = kp1[i1].octave;
+    float x3Dc2[3];
+    mat_Rp_plus_t(F2.Rcw, xyz1 + 3 * (size_t)i1, F2.tcw, x3Dc2);
+    const float xc2 = x3Dc2[0], yc2 = x3Dc2[1];
+    const float invzc2 = 1.0 / x3Dc2[2];
+    float u2 = F2.fx * xc2 * invzc2 + F2.cx;
+    float v2 = F2.fy * yc2 * invzc2 + F2.cy;
+    std::vector<int> vIndices2 = g2.GetFeaturesInArea(u2, v2, windowSize, level1, level1);
+    if (vIndices2.empty()) continue;
+    const uint8_t* d1 = desc1 + (size_t)i1 * 32;
+    int bestDist = 0x7fffffff, bestDist2 = 0x7fffffff, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      if (assigned2[i2] >= 0) continue;
+      int dist = descriptor_distance(d1, desc2 + (size_t)i2 * 32);
+      if (dist < bestDist) {
+        bestDist2 = bestDist;
+        bestDist = dist;
+        bestIdx2 = i2;
+      } else if (dist < bestDist2) {
+        bestDist2 = dist;
+      }
+    }
+    if (static_cast<float>(bestDist) <= static_cast<float>(bestDist2) * nnratio && bestDist <= TH_HIGH) {
+      assigned2[bestIdx2] = i1;
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
+// ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize): :598-713.  prev_matched: 2 floats per F1
+// keypoint, updated at the end (:705-708).
+int search_for_initialization(const KeyPoint* kp1, int n1, const uint8_t* desc1, const FrameGrid& g2, const uint8_t* desc2, int n2,
+                              float* prev_matched, int32_t* vnMatches12, int windowSize, float nnratio, bool checkOri) {
+  int nmatches = 0;
+  for (int i = 0; i < n1; i++) vnMatches12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  std::vector<int> vMatchedDistance(n2, 0x7fffffff);
+  std::vector<int> vnMatches21(n2, -1);
+  for (int i1 = 0; i1 < n1; i1++) {
+    const KeyPoint k1 = kp1[i1];
+    int level1 = k1.octave;
+    if (level1 > 0) continue;
+    std::vector<int> vIndices2 = g2.GetFeaturesInArea(prev_matched[2 * i1], prev_matched[2 * i1 + 1], windowSize, level1, level1);
+    if (vIndices2.empty()) continue;
+    const uint8_t* d1 = desc1 + (size_t)i1 * 32;
+    int bestDist = 0x7fffffff, bestDist2 = 0x7fffffff, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      int dist = descriptor_distance(d1, desc2 + (size_t)i2 * 32);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) {
+        bestDist2 = bestDist;
+        bestDist = dist;
+        bestIdx2 = i2;
+      } else if (dist < bestDist2) {
+        bestDist2 = dist;
+      }
+    }
+    if (bestDist <= TH_LOW) {
+      if (bestDist < (float)bestDist2 * nnratio) {
+        if (vnMatches21[bestIdx2] >= 0) {
+          vnMatches12[vnMatches21[bestIdx2]] = -1;
+          nmatches--;
+        }
+        vnMatches12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (checkOri) rotHist[rot_bin(k1.angle, g2.kps[bestIdx2].angle)].push_back(i1);
+      }
+    }
+  }
+  if (checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+    compute_three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+        int idx1 = rotHist[i][j];
+        if (vnMatches12[idx1] >= 0) {
+          vnMatches12[idx1] = -1;
+          nmatches--;
+        }
+      }
+    }
+  }
+  for (int i1 = 0; i1 < n1; i1++)
+    if (vnMatches12[i1] >= 0) prev_matched[2 * i1] = g2.kps[vnMatches12[i1]].x, prev_matched[2 * i1 + 1] = g2.kps[vnMatches12[i1]].y;
+  return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th): :1507-1620.  usable_last[i] = LastFrame.mvpMapPoints[i] non-null and
+// !LastFrame.mvbOutlier[i]; octave_last = LastFrame.mvKeys[i].octave, angle_last = LastFrame.mvKeysUn[i].angle.  assigned in/out:
+// >= 0 where CurrentFrame.mvpMapPoints[i2] is set (new matches hold the LastFrame index).
+int search_by_projection_last(const Camera& Cur, const FrameGrid& g, const uint8_t* fdesc, int32_t* assigned, int nlast, const uint8_t* usable_last,
+                              const float* xyz_last, const int32_t* octave_last, const float* angle_last, const uint8_t* desc_last,
+                              const float* scaleFactors, float th, bool checkOri) {
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (int i = 0; i < nlast; i++) {
+    if (!usable_last[i]) continue;
+    float x3Dc[3];
+    mat_Rp_plus_t(Cur.Rcw, xyz_last + 3 * (size_t)i, Cur.tcw, x3Dc);
+    const float xc = x3Dc[0], yc = x3Dc[1];
+    const float invzc = 1.0 / x3Dc[2];
+    float u = Cur.fx * xc * invzc + Cur.cx;
+    float v = Cur.fy * yc * invzc + Cur.cy;
+    if (u < Cur.minX || u > Cur.maxX) continue;
+    if (v < Cur.minY || v > Cur.maxY) continue;
+    int nPredictedOctave = octave_last[i];
+    float radius = th * scaleFactors[nPredictedOctave];
+    std::vector<int> vIndices2 = g.GetFeaturesInArea(u, v, radius, nPredictedOctave - 1, nPredictedOctave + 1);
+    if (vIndices2.empty()) continue;
+    const uint8_t* dMP = desc_last + (size_t)i * 32;
+    int bestDist = 0x7fffffff, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      if (assigned[i2] >= 0) continue;
+      int dist = descriptor_distance(dMP, fdesc + (size_t)i2 * 32);
+      if (dist < bestDist) {
+        bestDist = dist;
+        bestIdx2 = i2;
+      }
+    }
+    if (bestDist <= TH_HIGH) {
+      assigned[bestIdx2] = i;
+      nmatches++;
+      if (checkOri) rotHist[rot_bin(angle_last[i], g.kps[bestIdx2].angle)].push_back(bestIdx2);
+    }
+  }
+  if (checkOri) nmatches -= apply_rot_hist(rotHist, [&](int idx2) { assigned[idx2] = -1; });
+  return nmatches;
+}
+
 template <class F>
 static void walk_shared_nodes(const FeatureVector& a, const FeatureVector& b, F f) {
   int i = 0, j = 0;

@@ -152,6 +152,44 @@ int orc_search_by_projection_kf(const KeyPoint* kps, int n, const uint8_t* fdesc
   return search_by_projection_kf(g, fdesc, assigned, nmp, u, v, level, valid, mpdesc, kf_angle, scaleFactors, th, orbDist, checkOri != 0);
 }
 
+static Camera make_camera(const float* cam23) {
+  Camera F;
+  memcpy(F.Rcw, cam23, 36), memcpy(F.tcw, cam23 + 9, 12), memcpy(F.Ow, cam23 + 12, 12);
+  F.fx = cam23[15], F.fy = cam23[16], F.cx = cam23[17], F.cy = cam23[18];
+  F.minX = cam23[19], F.maxX = cam23[20], F.minY = cam23[21], F.maxY = cam23[22];
+  return F;
+}
+int orc_window_search(const KeyPoint* kp1, int n1, const uint8_t* desc1, const uint8_t* has_mp1, const KeyPoint* kp2, int n2, const uint8_t* desc2,
+                      int minX, int minY, int maxX, int maxY, int windowSize, int minLevel, int maxLevel, float nnratio, int checkOri,
+                      int32_t* match21) {
+  FrameGrid g;
+  g.build(kp2, n2, minX, minY, maxX, maxY);
+  return window_search(kp1, n1, desc1, has_mp1, g, desc2, n2, windowSize, minLevel, maxLevel, nnratio, checkOri != 0, match21);
+}
+int orc_search_by_projection_frames(const KeyPoint* kp1, int n1, const uint8_t* desc1, const uint8_t* usable1, const float* xyz1, const float* cam23,
+                                    const KeyPoint* kp2, int n2, const uint8_t* desc2, int32_t* assigned2, int windowSize, float nnratio) {
+  const Camera F2 = make_camera(cam23);
+  FrameGrid g;
+  g.build(kp2, n2, (int)F2.minX, (int)F2.minY, (int)F2.maxX, (int)F2.maxY);
+  return search_by_projection_frames(kp1, n1, desc1, usable1, xyz1, F2, g, desc2, assigned2, windowSize, nnratio);
+}
+int orc_search_for_initialization(const KeyPoint* kp1, int n1, const uint8_t* desc1, const KeyPoint* kp2, int n2, const uint8_t* desc2, int minX,
+                                  int minY, int maxX, int maxY, float* prev_matched, int32_t* vnMatches12, int windowSize, float nnratio,
+                                  int checkOri) {
+  FrameGrid g;
+  g.build(kp2, n2, minX, minY, maxX, maxY);
+  return search_for_initialization(kp1, n1, desc1, g, desc2, n2, prev_matched, vnMatches12, windowSize, nnratio, checkOri != 0);
+}
+int orc_search_by_projection_last(const float* cam23, const KeyPoint* kps, int n, const uint8_t* fdesc, int32_t* assigned, int nlast,
+                                  const uint8_t* usable_last, const float* xyz_last, const int32_t* octave_last, const float* angle_last,
+                                  const uint8_t* desc_last, const float* scaleFactors, float th, int checkOri) {
+  const Camera C = make_camera(cam23);
+  FrameGrid g;
+  g.build(kps, n, (int)C.minX, (int)C.minY, (int)C.maxX, (int)C.maxY);
+  return search_by_projection_last(C, g, fdesc, assigned, nlast, usable_last, xyz_last, octave_last, angle_last, desc_last, scaleFactors, th,
+                                   checkOri != 0);
+}
+
 int orc_search_by_bow(int kf_kf, const uint32_t* node1, const int32_t* start1, const int32_t* feat1, int nn1, int n1, const uint8_t* desc1,
                       const float* angle1, const uint8_t* usable1, const uint32_t* node2, const int32_t* start2, const int32_t* feat2, int nn2,
                       int n2, const uint8_t* desc2, const float* angle2, const uint8_t* usable2, float nnratio, int checkOri, int32_t* match12) {

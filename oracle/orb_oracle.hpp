@@ -156,6 +156,17 @@ bool is_in_frustum(const Camera& F, const float* P, const float* Pn, float mfMin
 // SearchByProjection(CurrentFrame, pKF, ...) src/ORBmatcher.cc:1626-1670
 bool project_kf_reloc(const Camera& F, const float* x3Dw, float mfMinDistance, const float* scaleFactors, int nScaleLevels, float* u, float* v,
                       int* level);
+// the four members without a caller in the reference (WindowSearch :409-516, SearchByProjection(F1, F2, windowSize) :519-594,
+// SearchForInitialization :598-713, SearchByProjection(CurrentFrame, LastFrame, th) :1507-1620)
+int window_search(const KeyPoint* kp1, int n1, const uint8_t* desc1, const uint8_t* has_mp1, const FrameGrid& g2, const uint8_t* desc2, int n2,
+                  int windowSize, int minScaleLevel, int maxScaleLevel, float nnratio, bool checkOri, int32_t* match21);
+int search_by_projection_frames(const KeyPoint* kp1, int n1, const uint8_t* desc1, const uint8_t* usable1, const float* xyz1, const Camera& F2,
+                                const FrameGrid& g2, const uint8_t* desc2, int32_t* assigned2, int windowSize, float nnratio);
+int search_for_initialization(const KeyPoint* kp1, int n1, const uint8_t* desc1, const FrameGrid& g2, const uint8_t* desc2, int n2,
+                              float* prev_matched, int32_t* vnMatches12, int windowSize, float nnratio, bool checkOri);
+int search_by_projection_last(const Camera& Cur, const FrameGrid& g, const uint8_t* fdesc, int32_t* assigned, int nlast, const uint8_t* usable_last,
+                              const float* xyz_last, const int32_t* octave_last, const float* angle_last, const uint8_t* desc_last,
+                              const float* scaleFactors, float th, bool checkOri);
 // Fuse src/ORBmatcher.cc:1037-1075
 bool project_fuse(const Camera& K, const float* p3Dw, const float* Pn, float mfMinDistance, float mfMaxDistance, const float* scaleFactors,
                   int nScaleLevels, float* u, float* v, int* level);

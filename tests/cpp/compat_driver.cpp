@@ -100,6 +100,7 @@ struct Frame2 {
   std::vector<uvo_keypoint> mvKeysUn, mvKeys;
   DescRows mDescriptors;
   std::vector<MP2*> mvpMapPoints;
+  std::vector<bool> mvbOutlier;
   std::vector<float> mvScaleFactors;
   std::map<unsigned, std::vector<unsigned> > mFeatVec;
   Mat44 mTcw;
@@ -146,6 +147,33 @@ static int exercise_other_members(const std::vector<uvo_keypoint>& kps, const st
   std::set<MP2*> found;
   const int np = m.SearchByProjection(F, &kf1, found, 10.f, 100);
   if (np < n * 8 / 10) return 12;
+  // the four members nothing in the reference calls, on two identical frames at the identity pose
+  {
+    struct P2 {
+      float x, y;
+    };
+    Frame2 A = F, B = F;
+    A.mvpMapPoints.assign(n, nullptr), B.mvpMapPoints.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) A.mvpMapPoints[i] = &pts[i];
+    A.mvbOutlier.assign(n, false), B.mvbOutlier.assign(n, false);
+    std::vector<MP2*> v2;
+    const int nw = m.WindowSearch(A, B, 10, v2);  // every keypoint finds itself at distance 0
+    if (nw < n * 8 / 10 || (int)v2.size() != n) return 20;
+    const int nq = m.SearchByProjection(A, B, 10, v2);
+    if (nq < n * 8 / 10) return 21;
+    std::vector<P2> prev(n);
+    for (int i = 0; i < n; ++i) prev[i].x = kps[i].x + 1.f, prev[i].y = kps[i].y;
+    std::vector<int> m12;
+    USLAM::ORBmatcher mi(0.9f, true);
+    const int ni = mi.SearchForInitialization(A, B, prev, m12, 10);
+    int lvl0 = 0;
+    for (int i = 0; i < n; ++i) lvl0 += kps[i].octave == 0;
+    if (ni < lvl0 * 8 / 10 || ni > lvl0) return 22;
+    for (int i = 0; i < n; ++i)
+      if (m12[i] >= 0 && (prev[i].x != kps[m12[i]].x || prev[i].y != kps[m12[i]].y)) return 23;
+    const int nl = m.SearchByProjection(B, static_cast<const Frame2&>(A), 7.f);
+    if (nl < n * 8 / 10) return 24;
+  }
   // triangulation between two key frames without map points; F12 of a pure x translation: epipolar lines y = const
   KeyFrame ka = kf1, kb = kf2;
   ka.mps.assign(n, nullptr), kb.mps.assign(n, nullptr);

@@ -52,6 +52,10 @@ class Oracle:
         L.orc_distinctive_descriptor.argtypes = [vp, ci, vp]
         L.orc_features_in_area.argtypes = [vp, ci, ci, ci, ci, ci, cf, cf, cf, ci, ci, vp, ci]
         L.orc_search_by_projection.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, cf]
+        L.orc_window_search.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, cf, ci, vp]
+        L.orc_search_by_projection_frames.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, ci, cf]
+        L.orc_search_for_initialization.argtypes = [vp, ci, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, cf, ci]
+        L.orc_search_by_projection_last.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci]
         L.orc_search_by_projection_kf.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci]
         L.orc_search_by_bow.argtypes = [ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, cf, ci, vp]
         L.orc_search_for_triangulation.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp]
@@ -219,6 +223,43 @@ class Oracle:
         self.L.orc_fuse_search(kps.ctypes.data, len(kps), desc.ctypes.data, *[int(b) for b in bounds], len(a[0]), *[x.ctypes.data for x in a], float(th),
                                bi.ctypes.data, bd.ctypes.data)
         return bi, bd
+
+    # ---- the four ORBmatcher members without a caller in the reference (src/ORBmatcher.cc:409-713, :1507-1620) ----
+    def window_search(self, kp1, desc1, has_mp1, kp2, desc2, bounds2, window, min_level, max_level, nnratio, check_ori):
+        kp1, kp2 = np.ascontiguousarray(kp1, KP), np.ascontiguousarray(kp2, KP)
+        d1, d2, hm = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8), np.ascontiguousarray(has_mp1, np.uint8)
+        m21 = np.full(len(kp2), -1, np.int32)
+        n = self.L.orc_window_search(kp1.ctypes.data, len(kp1), d1.ctypes.data, hm.ctypes.data, kp2.ctypes.data, len(kp2), d2.ctypes.data,
+                                     *[int(b) for b in bounds2], int(window), int(min_level), int(max_level), float(nnratio), 1 if check_ori else 0,
+                                     m21.ctypes.data)
+        return m21, n
+
+    def search_by_projection_frames(self, kp1, desc1, usable1, xyz1, cam, kp2, desc2, assigned2, window, nnratio):
+        kp1, kp2 = np.ascontiguousarray(kp1, KP), np.ascontiguousarray(kp2, KP)
+        d1, d2, us = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8), np.ascontiguousarray(usable1, np.uint8)
+        x, cam = np.ascontiguousarray(xyz1, np.float32), np.ascontiguousarray(cam, np.float32)
+        assert assigned2.dtype == np.int32
+        return self.L.orc_search_by_projection_frames(kp1.ctypes.data, len(kp1), d1.ctypes.data, us.ctypes.data, x.ctypes.data, cam.ctypes.data,
+                                                      kp2.ctypes.data, len(kp2), d2.ctypes.data, assigned2.ctypes.data, int(window), float(nnratio))
+
+    def search_for_initialization(self, kp1, desc1, kp2, desc2, bounds2, prev_matched, window, nnratio, check_ori):
+        kp1, kp2 = np.ascontiguousarray(kp1, KP), np.ascontiguousarray(kp2, KP)
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        assert prev_matched.dtype == np.float32 and prev_matched.shape == (len(kp1), 2) and prev_matched.flags.c_contiguous
+        m12 = np.full(len(kp1), -1, np.int32)
+        n = self.L.orc_search_for_initialization(kp1.ctypes.data, len(kp1), d1.ctypes.data, kp2.ctypes.data, len(kp2), d2.ctypes.data,
+                                                 *[int(b) for b in bounds2], prev_matched.ctypes.data, m12.ctypes.data, int(window), float(nnratio),
+                                                 1 if check_ori else 0)
+        return m12, n
+
+    def search_by_projection_last(self, cam, kps, desc, assigned, usable_last, xyz_last, octave_last, angle_last, desc_last, scale_factors, th, check_ori):
+        kps, cam = np.ascontiguousarray(kps, KP), np.ascontiguousarray(cam, np.float32)
+        a = [np.ascontiguousarray(usable_last, np.uint8), np.ascontiguousarray(xyz_last, np.float32), np.ascontiguousarray(octave_last, np.int32),
+             np.ascontiguousarray(angle_last, np.float32), np.ascontiguousarray(desc_last, np.uint8), np.ascontiguousarray(scale_factors, np.float32)]
+        d = np.ascontiguousarray(desc, np.uint8)
+        assert assigned.dtype == np.int32
+        return self.L.orc_search_by_projection_last(cam.ctypes.data, kps.ctypes.data, len(kps), d.ctypes.data, assigned.ctypes.data, len(a[0]),
+                                                    *[x.ctypes.data for x in a], float(th), 1 if check_ori else 0)
 
     def project_points(self, mode, cam, xyz, normal, min_distance, max_distance, usable, scale_factors, scale_factor=1.2, cos_limit=0.5):
         """cam: 23 floats = Rcw[9], tcw[3], Ow[3], fx, fy, cx, cy, minX, maxX, minY, maxY.  Returns (valid, u, v, level, view_cos)."""

@@ -1028,3 +1028,78 @@ def test_randomised_matcher_soak(uvo, oracle):
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_matcher.py"), "25", "11"], capture_output=True, text=True)
     assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---- the four ORBmatcher members without a caller in the reference ----
+@pytest.mark.parametrize("check_ori", [False, True])
+def test_window_search_and_search_for_initialization(uvo, oracle, synth, check_ori):
+    """WindowSearch (src/ORBmatcher.cc:409-516) and SearchForInitialization (:598-713) on two consecutive views."""
+    rng = np.random.default_rng(77 + check_ori)
+    kp1, de1, kp2, de2, _ = _two_views(uvo, synth, 6100, fast_th=20)
+    bounds = (0, 0, 752, 480)
+    m = uvo.ORBmatcher(0.9, check_ori, max_query=4096, max_map_points=8192)
+    for window, lo, hi, frac in [(15, -1, 0x7fffffff, 0.8), (40, 1, 3, 0.5), (8, -1, 2, 1.0), (100, -1, 0x7fffffff, 0.9)]:
+        has = (rng.random(len(kp1)) < frac).astype(np.uint8)
+        m21_g, n_g = m.WindowSearch(kp1, de1, has, kp2, de2, bounds, window, lo, hi)
+        m21_o, n_o = oracle.window_search(kp1, de1, has, kp2, de2, bounds, window, lo, hi, 0.9, check_ori)
+        np.testing.assert_array_equal(m21_g, m21_o)
+        assert n_g == n_o
+    assert n_o > 200
+    # SearchForInitialization: level-0 keypoints only, targets change hands when a later query is strictly closer
+    for window, jitter in [(10, 2.0), (30, 6.0), (100, 1.0)]:
+        prev = np.stack([kp1["x"], kp1["y"]], 1).astype(np.float32) + rng.normal(0, jitter, (len(kp1), 2)).astype(np.float32)
+        p_g, p_o = prev.copy(), prev.copy()
+        m12_g, n_g = m.SearchForInitialization(kp1, de1, kp2, de2, bounds, p_g, window)
+        m12_o, n_o = oracle.search_for_initialization(kp1, de1, kp2, de2, bounds, p_o, window, 0.9, check_ori)
+        np.testing.assert_array_equal(m12_g, m12_o)
+        np.testing.assert_array_equal(p_g, p_o)
+        assert n_g == n_o
+    assert n_o > 50
+    # a crowd competing for few targets: every level-0 query looks at the same spot with a huge window
+    sel = np.nonzero(kp1["octave"] == 0)[0][:300]
+    prev = np.tile(np.float32([[376, 240]]), (len(kp1), 1))
+    p_g, p_o = prev.copy(), prev.copy()
+    few = slice(0, 40)
+    m12_g, n_g = m.SearchForInitialization(kp1, de1, kp2[few], de2[few], bounds, p_g, 400)
+    m12_o, n_o = oracle.search_for_initialization(kp1, de1, kp2[few], de2[few], bounds, p_o, 400, 0.9, check_ori)
+    np.testing.assert_array_equal(m12_g, m12_o)
+    assert n_g == n_o and len(sel) > 100
+    m.close()
+
+
+@pytest.mark.parametrize("check_ori", [False, True])
+def test_projection_searches_between_frames(uvo, oracle, synth, check_ori):
+    """SearchByProjection(F1, F2, windowSize) (:519-594) and SearchByProjection(CurrentFrame, LastFrame, th) (:1507-1620)."""
+    rng = np.random.default_rng(91 + check_ori)
+    kp1, de1, kp2, de2, sf = _two_views(uvo, synth, 6200, fast_th=20)
+    n1, n2 = len(kp1), len(kp2)
+    R, t, Ow = _random_pose(rng)
+    fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375
+    bounds = (0, 0, 752, 480)
+    cam = uvo.CameraPose.make(R, t, Ow, fx, fy, cx, cy, bounds)
+    cam_o = np.concatenate([R.reshape(9), t, Ow, np.float32([fx, fy, cx, cy]), np.float32([0, 752, 0, 480])]).astype(np.float32)
+    # F1's map points: the back-projection of its own keypoints into frame 2's camera (+ noise), some behind the camera, some far outside
+    z = rng.uniform(2, 12, n1) * np.where(rng.random(n1) < 0.05, -1, 1)
+    pc = np.stack([(kp1["x"] - cx) / fx * z, (kp1["y"] - cy) / fy * z, z], 1) + rng.normal(0, 0.02, (n1, 3))
+    pc[rng.random(n1) < 0.05] *= [30, 1, 1]
+    xyz = ((pc - t) @ R.astype(np.float64)).astype(np.float32)
+    m = uvo.ORBmatcher(0.9, check_ori, max_query=4096, max_map_points=8192)
+    for window in (10, 40):
+        usable = (rng.random(n1) < 0.8).astype(np.uint8)
+        a_g = np.where(rng.random(n2) < 0.15, 5000, -1).astype(np.int32)
+        a_o = a_g.copy()
+        n_g = m.SearchByProjectionFrames(kp1, de1, usable, xyz, cam, kp2, de2, a_g, window)
+        n_o = oracle.search_by_projection_frames(kp1, de1, usable, xyz, cam_o, kp2, de2, a_o, window, 0.9)
+        np.testing.assert_array_equal(a_g, a_o)
+        assert n_g == n_o
+    assert n_o > 200
+    for th in (7.0, 15.0):
+        usable = (rng.random(n1) < 0.8).astype(np.uint8)
+        a_g = np.where(rng.random(n2) < 0.15, 5000, -1).astype(np.int32)
+        a_o = a_g.copy()
+        n_g = m.SearchByProjectionLast(kp2, de2, a_g, cam, usable, xyz, kp1["octave"], kp1["angle"], de1, sf, th)
+        n_o = oracle.search_by_projection_last(cam_o, kp2, de2, a_o, usable, xyz, kp1["octave"], kp1["angle"], de1, sf, th, check_ori)
+        np.testing.assert_array_equal(a_g, a_o)
+        assert n_g == n_o
+    assert n_o > 200
+    m.close()

@@ -409,3 +409,99 @@ def test_haloc_hash_by_hand(oracle):
     assert h[0] == np.float32(np.float32(10 + 10 - 30) / np.float32(3)) and h[5] == np.float32(np.float32(1 - 255) / np.float32(3))
     assert h[32] == np.float32(np.float32(40) / np.float32(3)) and h[32 + 5] == 0 and h[1] == 0
     assert (oracle.haloc_hash(proj, desc[:0]) == 0).all()
+
+
+# ---- the four ORBmatcher members without a caller in the reference (src/ORBmatcher.cc:409-713, :1507-1620) ----------
+def _desc(bits):
+    """32-byte descriptor with the first `bits` bits set."""
+    d = np.zeros(256, np.uint8)
+    d[:bits] = 1
+    return np.packbits(d)
+
+
+def test_window_search_rule_exclusivity_and_level_filter(oracle):
+    """:409-516 -- accept iff best <= nnratio * second (second = INT_MAX when alone) and best <= TH_HIGH; a target taken by an earlier
+    F1 keypoint is skipped; F1 keypoints without a map point or outside [minScaleLevel, maxScaleLevel] are not searched."""
+    bounds = (0, 0, 640, 480)
+    kp2 = _kps([(100, 100), (104, 100), (300, 300)], [0, 0, 1])
+    kp2["angle"] = [10, 10, 10]
+    d2 = np.stack([_desc(0), _desc(30), _desc(0)])
+    kp1 = _kps([(101, 100), (102, 100), (300, 301), (300, 299), (500, 50)], [0, 0, 1, 1, 0])
+    kp1["angle"] = [10, 10, 10, 10, 10]
+    d1 = np.stack([_desc(10), _desc(2), _desc(120), _desc(5), _desc(0)])
+    has = np.array([1, 1, 1, 1, 1], np.uint8)
+    # query 0: d(t0) = 10, d(t1) = 20 -> 10 <= 0.9 * 20 -> takes t0; query 1: t0 is taken, t1 alone at d = 28 -> accepted (second = INT_MAX);
+    # query 2 (level 1): t2 at 120 > TH_HIGH -> rejected; query 3: t2 at 5 -> accepted; query 4: empty window
+    m21, n = oracle.window_search(kp1, d1, has, kp2, d2, bounds, 10, -1, 0x7fffffff, 0.9, False)
+    assert m21.tolist() == [0, 1, 3] and n == 3
+    # ratio: with nnratio 0.4 query 0 fails (10 > 0.4 * 20) and leaves t0 free for query 1 (d = 2, second 28)
+    m21, n = oracle.window_search(kp1, d1, has, kp2, d2, bounds, 10, -1, 0x7fffffff, 0.4, False)
+    assert m21.tolist() == [1, -1, 3] and n == 2
+    # keypoints without a map point are skipped; maxScaleLevel = 0 drops the level-1 queries, minScaleLevel = 1 the level-0 ones
+    m21, n = oracle.window_search(kp1, d1, np.array([0, 1, 1, 1, 1], np.uint8), kp2, d2, bounds, 10, -1, 0x7fffffff, 0.9, False)
+    assert m21.tolist() == [1, -1, 3]
+    assert oracle.window_search(kp1, d1, has, kp2, d2, bounds, 10, -1, 0, 0.9, False)[0].tolist() == [0, 1, -1]
+    assert oracle.window_search(kp1, d1, has, kp2, d2, bounds, 10, 1, 0x7fffffff, 0.9, False)[0].tolist() == [-1, -1, 3]
+    # rotation check: three matches in bin 0 and one at 90 degrees (bin 3): 1 >= 0.1 * 3, so nothing is removed ...
+    kp1b = kp1.copy()
+    kp1b["angle"][3] = 100
+    assert oracle.window_search(kp1b, d1, has, kp2, d2, bounds, 10, -1, 0x7fffffff, 0.9, True)[1] == 3
+
+
+def test_search_for_initialization_takes_over_a_target_only_with_a_smaller_distance(oracle):
+    """:598-713 -- vMatchedDistance: a later F1 keypoint replaces the holder of a target iff its distance is strictly smaller; the loser
+    drops to -1; candidates matched at <= the query's distance are invisible to it (they do not even count as second best); only
+    level-0 keypoints are searched; matched keypoints get the target's position as their new vbPrevMatched."""
+    bounds = (0, 0, 640, 480)
+    kp2 = _kps([(100, 100), (106, 100)], [0, 0])
+    d2 = np.stack([_desc(0), _desc(200)])
+    kp1 = _kps([(100, 101), (101, 100), (100, 99), (99, 100), (100, 100)], [0, 0, 0, 0, 1])
+    d1 = np.stack([_desc(20), _desc(10), _desc(10), _desc(15), _desc(0)])
+    prev = np.array([[100, 100]] * 5, np.float32)
+    m12, n = oracle.search_for_initialization(kp1, d1, kp2, d2, bounds, prev, 10, 0.9, False)
+    # q0 takes t0 at 20; q1 (10 < 20) takes it over; q2 (10, not < 10) and q3 (15) do not see t0 at all and t1 is too far (190/185 > TH_LOW);
+    # q4 is on level 1
+    assert m12.tolist() == [-1, 0, -1, -1, -1] and n == 1
+    assert prev.tolist() == [[100, 100]] * 5                     # q1's new prev = t0's position = what it was
+    prev = np.array([[100, 100]] * 5, np.float32)
+    prev[1] = [103, 100]
+    m12, n = oracle.search_for_initialization(kp1, d1, kp2, d2, bounds, prev, 10, 0.9, False)
+    assert m12[1] == 0 and prev[1].tolist() == [100, 100]       # :705-708
+    # the rotation histogram counts every accept, the displaced one included: q0 (bin 0) and q1 (bin 3) -> both bins survive
+    kp1r = kp1.copy()
+    kp1r["angle"][1] = 90
+    prev = np.array([[100, 100]] * 5, np.float32)
+    m12, n = oracle.search_for_initialization(kp1r, d1, kp2, d2, bounds, prev, 10, 0.9, True)
+    assert m12.tolist() == [-1, 0, -1, -1, -1] and n == 1
+
+
+def test_projection_searches_between_two_frames(oracle):
+    """SearchByProjection(F1, F2, windowSize) :519-594 and SearchByProjection(CurrentFrame, LastFrame, th) :1507-1620 on an identity pose:
+    a point (X, Y, Z) lands at (fx X / Z + cx, fy Y / Z + cy); pre-assigned keypoints are skipped; the second form tests the image
+    bounds and searches levels [octave - 1, octave + 1] within th * scale[octave]."""
+    fx = fy = 100.0
+    cx, cy = 320.0, 240.0
+    cam = np.concatenate([np.eye(3).reshape(9), np.zeros(3), np.zeros(3), [fx, fy, cx, cy], [0, 640, 0, 480]]).astype(np.float32)
+    kp2 = _kps([(320, 240), (420, 240), (326, 240)], [0, 1, 0])
+    d2 = np.stack([_desc(0), _desc(0), _desc(40)])
+    kp1 = _kps([(0, 0), (0, 0), (0, 0)], [0, 1, 0])
+    d1 = np.stack([_desc(3), _desc(3), _desc(3)])
+    xyz = np.array([[0, 0, 2], [2, 0, 2], [0, 0, -2]], np.float32)   # -> (320, 240), (420, 240), (320, 240): no depth test in this member
+    a2 = np.array([-1, -1, -1], np.int32)
+    n = oracle.search_by_projection_frames(kp1, d1, np.ones(3, np.uint8), xyz, cam, kp2, d2, a2, 10, 0.9)
+    # point 0 -> t0 (3 <= 0.9 * 37); point 1 (level 1) -> t1; point 2 projects to the same pixel, t0 is taken, t2 alone at 37 -> accepted
+    assert n == 3 and a2.tolist() == [0, 1, 2]
+    a2 = np.array([7, -1, -1], np.int32)                              # t0 already holds a map point
+    n = oracle.search_by_projection_frames(kp1, d1, np.array([1, 0, 0], np.uint8), xyz, cam, kp2, d2, a2, 10, 0.9)
+    assert n == 1 and a2.tolist() == [7, -1, 0]
+    # last-frame form: the point behind the camera still projects (no depth test) but a point outside the image is dropped
+    sf = np.float32([1.0, 1.2, 1.44])
+    a = np.array([-1, -1, -1], np.int32)
+    xyz2 = np.array([[0, 0, 2], [2, 0, 2], [8, 0, 2]], np.float32)   # the third lands at u = 720 > maxX
+    n = oracle.search_by_projection_last(cam, kp2, d2, a, np.ones(3, np.uint8), xyz2, np.array([0, 1, 0], np.int32), np.zeros(3, np.float32), d1, sf, 7.0,
+                                         False)
+    assert n == 2 and a.tolist() == [0, 1, -1]                        # t2 (6 px away, d = 37) loses to t0 (d = 3) for point 0
+    a = np.array([-1, -1, -1], np.int32)
+    n = oracle.search_by_projection_last(cam, kp2, d2, a, np.ones(3, np.uint8), xyz2, np.array([0, 1, 0], np.int32), np.zeros(3, np.float32), d1, sf, 3.0,
+                                         False)
+    assert n == 2 and a.tolist() == [0, 1, -1]

@@ -74,8 +74,8 @@ class CameraPose(ctypes.Structure):
         return np.frombuffer(bytes(self), np.float32).copy()
 
 
-PROJECT_FRUSTUM, PROJECT_KF_RELOC, PROJECT_FUSE = range(3)
-RULE_BEST_RATIO_SAME_LEVEL, RULE_BEST_ONLY, RULE_BEST_RATIO_LE, RULE_BEST_RATIO_LT, RULE_TRIANGULATION = range(5)
+PROJECT_FRUSTUM, PROJECT_KF_RELOC, PROJECT_FUSE, PROJECT_PIXEL_BOUNDED, PROJECT_PIXEL = range(5)
+RULE_BEST_RATIO_SAME_LEVEL, RULE_BEST_ONLY, RULE_BEST_RATIO_LE, RULE_BEST_RATIO_LT, RULE_TRIANGULATION, RULE_BEST_RATIO_LEQ, RULE_INIT_STEAL = range(7)
 
 
 class FeatureVector:
@@ -711,9 +711,9 @@ class ORBmatcher:
         Returns (valid, u, v, level, view_cos)."""
         xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
         nrm = None if normal is None else np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
-        mx = np.ascontiguousarray(max_distance, np.float32)
-        mn_inv = (np.float32(0.8) * np.ascontiguousarray(min_distance, np.float32)).astype(np.float32)
-        mx_inv = (np.float32(1.2) * mx).astype(np.float32)
+        mx = None if max_distance is None else np.ascontiguousarray(max_distance, np.float32)
+        mn_inv = None if min_distance is None else (np.float32(0.8) * np.ascontiguousarray(min_distance, np.float32)).astype(np.float32)
+        mx_inv = None if mx is None else (np.float32(1.2) * mx).astype(np.float32)
         us = None if usable is None else np.ascontiguousarray(usable, np.uint8)
         sf = np.ascontiguousarray(scale_factors, np.float32)
         n = len(xyz)
@@ -724,6 +724,63 @@ class ORBmatcher:
         if rc:
             raise UvoError(rc, "uvo_project_points")
         return valid, u, v, level, vc
+
+    # ---- the four members of the reference class that nothing in the reference calls (src/ORBmatcher.cc:409-713, :1507-1620) ----
+    def WindowSearch(self, kp1, desc1, has_mp1, kp2, desc2, bounds2, windowSize, minScaleLevel=-1, maxScaleLevel=0x7fffffff):
+        """WindowSearch(F1, F2, windowSize, vpMapPointMatches2, minScaleLevel, maxScaleLevel) (:409-516).  has_mp1[i1] = F1's keypoint
+        holds a good map point.  Returns (match21[n2] = index into F1 or -1, nmatches)."""
+        kp1 = np.ascontiguousarray(kp1, KEYPOINT_DTYPE)
+        lv = kp1["octave"].astype(np.int32)
+        valid = np.ascontiguousarray(has_mp1, np.uint8).copy()
+        if minScaleLevel > 0:
+            valid &= (lv >= minScaleLevel).astype(np.uint8)
+        if maxScaleLevel < 0x7fffffff:
+            valid &= (lv <= maxScaleLevel).astype(np.uint8)
+        m12, _, nm = self.match_windows(kp2, desc2, bounds2, kp1["x"], kp1["y"], np.full(len(kp1), float(windowSize), np.float32), lv, lv, valid, desc1,
+                                        RULE_BEST_RATIO_LEQ, 100, qangle=kp1["angle"], exclusive=True, check_orientation=self.mbCheckOrientation)
+        m21 = np.full(len(kp2), -1, np.int32)
+        sel = np.nonzero(m12 >= 0)[0]
+        m21[m12[sel]] = sel
+        return m21, nm
+
+    def SearchByProjectionFrames(self, kp1, desc1, usable1, xyz1, cam2, kp2, desc2, assigned2, windowSize):
+        """SearchByProjection(F1, F2, windowSize, vpMapPointMatches2) (:519-594).  usable1[i1]: F1's map point exists, is good and is not
+        one of F2's already; cam2: F2's pose / intrinsics / bounds; assigned2 in/out (>= 0 = F2's keypoint holds a map point; new
+        matches get the F1 index).  Returns nmatches."""
+        kp1 = np.ascontiguousarray(kp1, KEYPOINT_DTYPE)
+        n1 = len(kp1)
+        valid, u, v, _, _ = self.project_points(PROJECT_PIXEL, cam2, xyz1, None, None, None, usable1, np.ones(1, np.float32))
+        lv = kp1["octave"].astype(np.int32)
+        bounds = (int(cam2.min_x), int(cam2.min_y), int(cam2.max_x), int(cam2.max_y))
+        m12, _, nm = self.match_windows(kp2, desc2, bounds, u, v, np.full(n1, float(windowSize), np.float32), lv, lv, valid, desc1, RULE_BEST_RATIO_LEQ, 100,
+                                        blocked=(assigned2 >= 0).astype(np.uint8), exclusive=True, check_orientation=False)
+        sel = np.nonzero(m12 >= 0)[0]
+        assigned2[m12[sel]] = sel
+        return nm
+
+    def SearchForInitialization(self, kp1, desc1, kp2, desc2, bounds2, prev_matched, windowSize=10):
+        """SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (:598-713).  prev_matched: float32 [n1][2], updated in
+        place for the matched keypoints (:705-708).  Returns (vnMatches12[n1], nmatches)."""
+        kp1, kp2 = np.ascontiguousarray(kp1, KEYPOINT_DTYPE), np.ascontiguousarray(kp2, KEYPOINT_DTYPE)
+        n1 = len(kp1)
+        assert prev_matched.dtype == np.float32 and prev_matched.shape == (n1, 2)
+        lv = kp1["octave"].astype(np.int32)
+        valid = (lv <= 0).astype(np.uint8)                                   # :621-622: level 0 only
+        m12, _, nm = self.match_windows(kp2, desc2, bounds2, prev_matched[:, 0].copy(), prev_matched[:, 1].copy(), np.full(n1, float(windowSize), np.float32),
+                                        lv, lv, valid, desc1, RULE_INIT_STEAL, 50, qangle=kp1["angle"], exclusive=False,
+                                        check_orientation=self.mbCheckOrientation)
+        sel = np.nonzero(m12 >= 0)[0]
+        prev_matched[sel, 0], prev_matched[sel, 1] = kp2["x"][m12[sel]], kp2["y"][m12[sel]]
+        return m12, nm
+
+    def SearchByProjectionLast(self, kp, desc, assigned, cam, usable_last, xyz_last, octave_last, angle_last, desc_last, scale_factors, th):
+        """SearchByProjection(CurrentFrame, LastFrame, th) (:1507-1620): LastFrame's map points projected with the current pose, window
+        th * scale[octave] on levels [octave-1, octave+1], best <= TH_HIGH, first come first served, rotation histogram.  assigned
+        in/out (new matches hold the LastFrame index).  Returns nmatches."""
+        valid, u, v, _, _ = self.project_points(PROJECT_PIXEL_BOUNDED, cam, xyz_last, None, None, None, usable_last, scale_factors)
+        bounds = (int(cam.min_x), int(cam.min_y), int(cam.max_x), int(cam.max_y))
+        return self.SearchByProjectionKF(kp, desc, bounds, assigned, u, v, np.ascontiguousarray(octave_last, np.int32), valid, desc_last, angle_last,
+                                         scale_factors, th, 100)
 
     def haloc_hash(self, proj, desc):
         """haloc::Hash::getHash (src/hash.cpp:57-85): proj [num_proj][>= n] float32, desc [n][32] -> hash [num_proj * 32]."""

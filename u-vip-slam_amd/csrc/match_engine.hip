@@ -251,6 +251,9 @@ __device__ __forceinline__ int rule_choice(const MatchRule& R, int i, const int3
     case UVO_RULE_BEST_RATIO_LT:  // :786-788
       ok = bestDist < R.max_dist && (float)bestDist < R.nn_ratio * (float)bestDist2;
       break;
+    case UVO_RULE_BEST_RATIO_LEQ:  // WindowSearch :475, SearchByProjection(F1, F2, windowSize) :583 (bestDist2 = INT_MAX when there is no second)
+      ok = (float)bestDist <= (float)bestDist2 * R.nn_ratio && bestDist <= R.max_dist;
+      break;
     default:
       break;
   }
@@ -296,6 +299,78 @@ __global__ __launch_bounds__(1024) void k_match_resolve(int nq, int nt, const in
   __syncthreads();
   int c = 0;
   for (int i = threadIdx.x; i < nq; i += blockDim.x) c += match[i] >= 0;
+  if (c) atomicAdd(&s_count, c);
+  __syncthreads();
+  if (threadIdx.x == 0) *n_matches = s_count;
+}
+
+// SearchForInitialization (src/ORBmatcher.cc:598-713): no exclusivity -- a target keeps the distance it was last matched at
+// (vMatchedDistance) and a later query takes it over when its own distance is strictly smaller; candidates whose current matched
+// distance is <= the query's distance are skipped before best / second are formed (:635-636).  Solved as a fixed point like the
+// exclusive rules: what query i sees at target t is min{ dist(j, t) : j < i accepted t } -- every accept lowers the target's distance,
+// so that is the state the sequential loop is in when it reaches i.  The accepts of one sweep hang off their target as a linked list
+// (head[t], nxt[i]); query 0 is final after one sweep, query i once all j < i are.  Outputs: match[i] = the target query i accepted
+// (displaced or not: the rotation histogram counts every accept, :662-670), owner[t] = the last query that accepted t (vnMatches21).
+__global__ __launch_bounds__(1024) void k_match_resolve_steal(int nq, int nt, const int32_t* __restrict__ cand_start, const uint32_t* __restrict__ cand,
+                                                              int max_dist, float nn_ratio, int32_t* head, int32_t* nxt, int32_t* tmp_choice,
+                                                              int32_t* tmp_dist, int32_t* match, int32_t* mdist) {
+  __shared__ int s_changed;
+  for (int t = threadIdx.x; t < nt; t += blockDim.x) head[t] = -1;
+  for (int i = threadIdx.x; i < nq; i += blockDim.x) match[i] = -1, mdist[i] = -1, nxt[i] = -1;
+  __syncthreads();
+  for (int iter = 0; iter <= nq; ++iter) {
+    if (threadIdx.x == 0) s_changed = 0;
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+      int bestDist = 0x7fffffff, bestDist2 = 0x7fffffff, bestIdx = -1;
+      for (int c = cand_start[i]; c < cand_start[i + 1]; ++c) {
+        const uint32_t v = cand[c];
+        const int t = (int)(v & 0xffffu), d = (int)((v >> 16) & 0x1ffu);
+        int md = 0x7fffffff;  // vMatchedDistance[t] as query i finds it
+        for (int j = head[t]; j >= 0; j = nxt[j])
+          if (j < i) md = min(md, mdist[j]);
+        if (md <= d) continue;  // :635
+        if (d < bestDist) {
+          bestDist2 = bestDist, bestDist = d, bestIdx = t;
+        } else if (d < bestDist2) {
+          bestDist2 = d;
+        }
+      }
+      const bool ok = bestIdx >= 0 && bestDist <= max_dist && (float)bestDist < (float)bestDist2 * nn_ratio;  // :649-651
+      tmp_choice[i] = ok ? bestIdx : -1;
+      tmp_dist[i] = ok ? bestDist : -1;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nt; t += blockDim.x) head[t] = -1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+      const int ch = tmp_choice[i];
+      if (ch != match[i] || tmp_dist[i] != mdist[i]) s_changed = 1;
+      match[i] = ch, mdist[i] = tmp_dist[i];
+      nxt[i] = ch >= 0 ? atomicExch(&head[ch], i) : -1;
+    }
+    __syncthreads();
+    const int changed = s_changed;
+    __syncthreads();
+    if (!changed) break;
+  }
+  // vnMatches21[t] = the last query that accepted t
+  for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+    int last = -1;
+    for (int j = head[t]; j >= 0; j = nxt[j]) last = max(last, j);
+    head[t] = last;
+  }
+}
+// after the optional rotation filter: a query keeps its match only while it still holds the target (:653-657), count the survivors
+__global__ __launch_bounds__(1024) void k_steal_finalize(int nq, const int32_t* __restrict__ holder, int32_t* match, int32_t* mdist, int32_t* n_matches) {
+  __shared__ int s_count;
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  int c = 0;
+  for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+    const int t = match[i];
+    if (t >= 0 && holder[t] != i) match[i] = -1, mdist[i] = -1;
+    c += match[i] >= 0;
+  }
   if (c) atomicAdd(&s_count, c);
   __syncthreads();
   if (threadIdx.x == 0) *n_matches = s_count;
@@ -435,6 +510,14 @@ __global__ __launch_bounds__(256) void k_project(int mode, ProjCam C, int n, con
         for (int k = 0; k < 3; ++k) s += (double)C.r[3 * k + c] * (double)C.t[k];
         ow[c] = (float)(s * -1.0);
       }
+    }
+    if (mode == UVO_PROJECT_PIXEL || mode == UVO_PROJECT_PIXEL_BOUNDED) {
+      // SearchByProjection(F1, F2, windowSize) :541-550 (no test at all) / SearchByProjection(CurrentFrame, LastFrame, th) :1530-1545
+      const float invz = (float)(1.0 / (double)Z);
+      u = C.fx * X * invz + C.cx, v = C.fy * Y * invz + C.cy;
+      if (mode == UVO_PROJECT_PIXEL_BOUNDED && (u < C.min_x || u > C.max_x || v < C.min_y || v > C.max_y)) break;
+      ok = 1;
+      break;
     }
     if (mode == UVO_PROJECT_FUSE) {
       if (Z < 0.0f) break;                 // :1040
@@ -605,6 +688,15 @@ void launch_match_resolve(hipStream_t s, int nq, int nt, const int32_t* d_cand_s
   MatchRule R{rule, max_dist, nn_ratio, exclusive};
   hipLaunchKernelGGL(k_match_resolve, dim3(1), dim3(1024), 0, s, nq, nt, d_cand_start, d_cand, d_blocked, R, d_owner, d_owner_next, d_match,
                      d_mdist, d_n_matches);
+}
+
+void launch_match_resolve_steal(hipStream_t s, int nq, int nt, const int32_t* d_cand_start, const uint32_t* d_cand, int max_dist, float nn_ratio,
+                                int32_t* d_head, int32_t* d_nxt, int32_t* d_tmp, int32_t* d_match, int32_t* d_mdist) {
+  hipLaunchKernelGGL(k_match_resolve_steal, dim3(1), dim3(1024), 0, s, nq, nt, d_cand_start, d_cand, max_dist, nn_ratio, d_head, d_nxt, d_tmp, d_tmp + nq,
+                     d_match, d_mdist);
+}
+void launch_steal_finalize(hipStream_t s, int nq, const int32_t* d_holder, int32_t* d_match, int32_t* d_mdist, int32_t* d_n_matches) {
+  hipLaunchKernelGGL(k_steal_finalize, dim3(1), dim3(1024), 0, s, nq, d_holder, d_match, d_mdist, d_n_matches);
 }
 
 void launch_rot_filter(hipStream_t s, int nq, const float* d_qangle, const float* d_tangle, int32_t* d_match, int32_t* d_mdist,

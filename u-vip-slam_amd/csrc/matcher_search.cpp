@@ -24,6 +24,9 @@ void launch_group_dist(hipStream_t s, int nq, int total, const int32_t* d_cand_s
 void launch_match_resolve(hipStream_t s, int nq, int nt, const int32_t* d_cand_start, const uint32_t* d_cand, const uint8_t* d_blocked, int rule,
                           int max_dist, float nn_ratio, int exclusive, int32_t* d_owner, int32_t* d_owner_next, int32_t* d_match,
                           int32_t* d_mdist, int32_t* d_n_matches);
+void launch_match_resolve_steal(hipStream_t s, int nq, int nt, const int32_t* d_cand_start, const uint32_t* d_cand, int max_dist, float nn_ratio,
+                                int32_t* d_head, int32_t* d_nxt, int32_t* d_tmp, int32_t* d_match, int32_t* d_mdist);
+void launch_steal_finalize(hipStream_t s, int nq, const int32_t* d_holder, int32_t* d_match, int32_t* d_mdist, int32_t* d_n_matches);
 void launch_rot_filter(hipStream_t s, int nq, const float* d_qangle, const float* d_tangle, int32_t* d_match, int32_t* d_mdist,
                        int32_t* d_n_matches);
 void launch_project_sim3(hipStream_t s, const float* r_own, const float* t_own, const float* s_r, const float* t, const uvo_camera_pose& cam, int n,
@@ -95,7 +98,7 @@ int reserve(uvo_matcher* m, int slot, size_t count, T** dev) {
 
 int check_rule(const uvo_match_rule* r) {
   if (!r) return matcher_fail(UVO_E_BADARG, "null rule");
-  if (r->rule < UVO_RULE_BEST_RATIO_SAME_LEVEL || r->rule > UVO_RULE_TRIANGULATION) return matcher_fail(UVO_E_BADARG, "unknown rule");
+  if (r->rule < UVO_RULE_BEST_RATIO_SAME_LEVEL || r->rule > UVO_RULE_INIT_STEAL) return matcher_fail(UVO_E_BADARG, "unknown rule");
   if (r->max_dist < 0 || r->max_dist > 256) return matcher_fail(UVO_E_BADARG, "max_dist outside 0..256");
   return UVO_OK;
 }
@@ -110,9 +113,18 @@ int finish(uvo_matcher* m, int nq, int nt, const int32_t* d_start, const uint32_
   RC(reserve(m, S_MATCH, (size_t)2 * nq + 1, &d_match));
   int32_t* d_mdist = d_match + nq;
   int32_t* d_nm = d_match + 2 * nq;
-  launch_match_resolve(s, nq, nt, d_start, d_cand, d_blocked, rule->rule, rule->max_dist, rule->nn_ratio, rule->exclusive ? 1 : 0, d_owner, d_owner2,
-                       d_match, d_mdist, d_nm);
-  if (rule->check_orientation) launch_rot_filter(s, nq, d_qangle, d_tangle, d_match, d_mdist, d_nm);
+  if (rule->rule == UVO_RULE_INIT_STEAL) {
+    // accepts (displaced ones included) -> rotation filter over all of them -> only the queries still holding their target survive
+    int32_t* d_tmp;
+    RC(reserve(m, S_OWNER2, (size_t)3 * nq + 1, &d_tmp));  // accept list links [nq] + the sweep's scratch [2 nq]
+    launch_match_resolve_steal(s, nq, nt, d_start, d_cand, rule->max_dist, rule->nn_ratio, d_owner, d_tmp, d_tmp + nq, d_match, d_mdist);
+    if (rule->check_orientation) launch_rot_filter(s, nq, d_qangle, d_tangle, d_match, d_mdist, d_nm);
+    launch_steal_finalize(s, nq, d_owner, d_match, d_mdist, d_nm);
+  } else {
+    launch_match_resolve(s, nq, nt, d_start, d_cand, d_blocked, rule->rule, rule->max_dist, rule->nn_ratio, rule->exclusive ? 1 : 0, d_owner, d_owner2,
+                         d_match, d_mdist, d_nm);
+    if (rule->check_orientation) launch_rot_filter(s, nq, d_qangle, d_tangle, d_match, d_mdist, d_nm);
+  }
   UVO_HIP_CHECK(hipGetLastError());
   int32_t nm = 0;
   UVO_HIP_CHECK(hipMemcpyAsync(match, d_match, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
@@ -414,21 +426,23 @@ int uvo_project_points(uvo_matcher* m, int mode, const uvo_camera_pose* cam, int
                        const float* scale_factors, int nlevels, float scale_factor, float viewing_cos_limit, uint8_t* valid, float* u, float* v,
                        int32_t* level, float* view_cos) {
   if (!m || !cam) return matcher_fail(UVO_E_BADARG, "null pointer");
-  if (mode < UVO_PROJECT_FRUSTUM || mode > UVO_PROJECT_FUSE) return matcher_fail(UVO_E_BADARG, "unknown projection mode");
+  if (mode < UVO_PROJECT_FRUSTUM || mode > UVO_PROJECT_PIXEL) return matcher_fail(UVO_E_BADARG, "unknown projection mode");
+  const bool pixel_only = mode == UVO_PROJECT_PIXEL || mode == UVO_PROJECT_PIXEL_BOUNDED;  // u, v and at most the image-bounds test
   if (npts < 0 || nlevels < 1 || nlevels > 64) return matcher_fail(UVO_E_BADARG, "bad sizes");
   if (npts == 0) return UVO_OK;
-  if (!xyz || !min_distance_inv || !scale_factors || !valid || !u || !v || !level) return matcher_fail(UVO_E_BADARG, "null pointer");
-  if (mode != UVO_PROJECT_KF_RELOC && !max_distance_inv) return matcher_fail(UVO_E_BADARG, "this mode needs the maximum invariance distance");
+  if (!xyz || !scale_factors || !valid || !u || !v || !level) return matcher_fail(UVO_E_BADARG, "null pointer");
+  if (!pixel_only && !min_distance_inv) return matcher_fail(UVO_E_BADARG, "this mode needs the minimum invariance distance");
+  if (!pixel_only && mode != UVO_PROJECT_KF_RELOC && !max_distance_inv) return matcher_fail(UVO_E_BADARG, "this mode needs the maximum invariance distance");
   if (mode == UVO_PROJECT_FRUSTUM && !max_distance) return matcher_fail(UVO_E_BADARG, "PredictScale needs the raw mfMaxDistance");
-  if (mode != UVO_PROJECT_KF_RELOC && !normal) return matcher_fail(UVO_E_BADARG, "this mode needs the point normals");
+  if (!pixel_only && mode != UVO_PROJECT_KF_RELOC && !normal) return matcher_fail(UVO_E_BADARG, "this mode needs the point normals");
   if (mode == UVO_PROJECT_FRUSTUM && !(scale_factor > 1.0f)) return matcher_fail(UVO_E_BADARG, "scale_factor must be > 1");
   UVO_HIP_CHECK(hipSetDevice(m->device));
   hipStream_t s = m->stream;
-  float *d_xyz, *d_normal = nullptr, *d_min, *d_max = nullptr, *d_max_raw = nullptr, *d_sf, *d_u;
+  float *d_xyz, *d_normal = nullptr, *d_min = nullptr, *d_max = nullptr, *d_max_raw = nullptr, *d_sf, *d_u;
   uint8_t *d_usable = nullptr, *d_valid;
   RC(upload(m, S_QX, xyz, (size_t)npts * 3, &d_xyz));
   if (normal) RC(upload(m, S_QY, normal, (size_t)npts * 3, &d_normal));
-  RC(upload(m, S_QR, min_distance_inv, (size_t)npts, &d_min));
+  if (min_distance_inv) RC(upload(m, S_QR, min_distance_inv, (size_t)npts, &d_min));
   if (max_distance_inv) RC(upload(m, S_QANGLE, max_distance_inv, (size_t)npts, &d_max));
   if (max_distance) RC(upload(m, S_MISC, max_distance, (size_t)npts, &d_max_raw));
   if (usable) RC(upload(m, S_QVALID, usable, (size_t)npts, &d_usable));
