@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Pin kit, step 1: the inputs tools/pin/dump_reference.cpp reads -- the same seeded synthetic frames the tests use, plus the small
+inputs of the primitive-level dumps.  Plain binary files + a whitespace-separated manifest (`cases.txt`), numpy only.
+
+  python tools/pin/make_inputs.py --out /tmp/pin_in
+"""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+synth = importlib.import_module("u-vip-slam_amd.synth")
+
+KP = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+
+def frames():
+    """name -> (image, nfeatures, fastTh)"""
+    seq = synth.make_sequence(0, 3, 640, 512)
+    out = {"c2_f0": (seq[0], 1000, 20), "c2_f1": (seq[1], 1000, 20), "c2_f2_th7": (seq[2], 1000, 7),
+           "euroc": (synth.make_frame(31337, 752, 480), 1000, 7),
+           "hd": (synth.make_frame(7000, 1920, 1080, n_shapes=2500), 2000, 20),
+           "harbor400": (synth.make_frame(4711, 640, 512), 400, 20),
+           "small": (synth.make_frame(99, 320, 256, n_shapes=120), 300, 20)}
+    flat = np.full((256, 320), 128, np.uint8)
+    out["flat"] = (flat, 300, 20)
+    return out
+
+
+def topup_inputs(w, h, nfeat, seed=1, n_in=330, d=20):
+    """The caller side of src/Tracking.cc:925-946: tracked keypoints + their occupancy grid (Eigen::MatrixXi, column-major)."""
+    rng = np.random.default_rng(seed)
+    kin = np.zeros(n_in, KP)
+    kin["x"], kin["y"] = rng.uniform(20, w - 21, n_in).astype(np.float32), rng.uniform(20, h - 21, n_in).astype(np.float32)
+    kin["size"], kin["angle"], kin["octave"], kin["class_id"] = 31, -1, 0, -1
+    rows, cols = h // d + 2, w // d + 2
+    grid = np.zeros((rows, cols), np.int32, order="F")
+    for k in kin:
+        grid[int(k["y"] / d), int(k["x"] / d)] += 1
+    return kin, grid, d, nfeat - n_in
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    lines = []
+
+    def put(name, arr):
+        arr = np.ascontiguousarray(arr)
+        arr.tofile(os.path.join(a.out, name + ".bin"))
+        return name + ".bin"
+
+    rng = np.random.default_rng(2024)
+    for name, (img, nfeat, th) in frames().items():
+        h, w = img.shape
+        lines.append("frame %s %d %d %d %d %s" % (name, w, h, nfeat, th, put("frame_" + name, img)))
+    # top-up mode (FullDetect = false) on the harbor frame, parameters of Data/Settings_VI_Aqualoc_harbor.yaml:67-79
+    kin, grid, d, need = topup_inputs(640, 512, 400)
+    lines.append("topup harbor400 %d %d %d %d %d %s %s" % (len(kin), grid.shape[0], grid.shape[1], d, need, put("topup_kp", kin),
+                                                          put("topup_grid", np.asfortranarray(grid).ravel(order="F"))))
+    # cv::FAST on ROIs of c2_f0: x y w h threshold
+    for k in range(12):
+        rw, rh = int(rng.integers(20, 70)), int(rng.integers(20, 70))
+        x, y = int(rng.integers(0, 640 - rw)), int(rng.integers(0, 512 - rh))
+        lines.append("fast c2_f0 %d %d %d %d %d" % (x, y, rw, rh, 20 if k % 2 == 0 else 7))
+    # cv::fastAtan2 on a grid of (y, x) incl. zeros, equal magnitudes, negative and tiny values
+    v = np.concatenate([np.float32([0, 1, -1, 1e-12, -1e-12, 3e7]), rng.normal(0, 50000, 2000).astype(np.float32), rng.integers(-200000, 200000, 2000).astype(np.float32)])
+    yy, xx = rng.permutation(v)[:4000], rng.permutation(v)[:4000]
+    yy[:6], xx[:6] = [0, 0, 1, -1, 5, -5], [0, 1, 0, 0, 5, 5]
+    lines.append("atan2 %d %s %s" % (len(yy), put("atan2_y", yy.astype(np.float32)), put("atan2_x", xx.astype(np.float32))))
+    # DistributeOctTree on candidate lists: n minX maxX minY maxY N level file   (keypoints: pt relative to (minX, minY), response)
+    for k, (W, H, N, P) in enumerate([(614, 486, 217, 2600), (1894, 1054, 434, 9000), (153, 117, 60, 400), (614, 486, 217, 120), (300, 200, 50, 700)]):
+        pts = np.unique(np.stack([rng.integers(0, W, P), rng.integers(0, H, P)], 1), axis=0)
+        nC, nR = W // 30, H // 30
+        wC, hC = -(-W // nC), -(-H // nR)
+        j, i = np.minimum(np.maximum(pts[:, 0] - 3, 0) // wC, nC - 1), np.minimum(np.maximum(pts[:, 1] - 3, 0) // hC, nR - 1)
+        pts = pts[np.lexsort((pts[:, 0], pts[:, 1], j, i))]            # the reference's candidate order: cell-major, raster inside a cell
+        kp = np.zeros(len(pts), KP)
+        kp["x"], kp["y"], kp["response"], kp["size"], kp["angle"], kp["class_id"] = pts[:, 0], pts[:, 1], rng.integers(7, 200, len(pts)), 7, -1, -1
+        lines.append("octree %d %d %d %d %d %d %d %d %s" % (k, len(kp), 13, 13 + W, 13, 13 + H, N, 0, put("oct_%d_in" % k, kp)))
+    # cv::Mat arithmetic of the projection prologues: R (3x3), P (3x1), t (3x1), CV_32F
+    n = 64
+    R = rng.normal(0, 1, (n, 3, 3)).astype(np.float32)
+    P = (rng.normal(0, 5, (n, 3)) * rng.choice([1, 1e-3, 1e3], (n, 1))).astype(np.float32)
+    t = rng.normal(0, 2, (n, 3)).astype(np.float32)
+    lines.append("gemm %d %s %s %s" % (n, put("gemm_R", R), put("gemm_P", P), put("gemm_t", t)))
+    # CLAHE (src/Tracking.cc:425-431) and the KLT step (src/FrameKTL.cc:76, src/Tracking.cc:1046-1047) on c2_f0 -> c2_f1
+    lines.append("clahe c2_f0 4.0 12 12")
+    lines.append("clahe small 4.0 12 12")
+    seq = synth.make_sequence(0, 2, 640, 512)
+    pts = np.stack([rng.uniform(30, 610, 800), rng.uniform(30, 480, 800)], 1).astype(np.float32)
+    lines.append("klt c2_f0 c2_f1 21 21 5 30 0.01 0.0001 %d %s" % (len(pts), put("klt_pts", pts)))
+    with open(os.path.join(a.out, "cases.txt"), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    print("wrote %d cases to %s" % (len(lines), a.out))
+
+
+if __name__ == "__main__":
+    main()
