@@ -582,6 +582,25 @@ int uvo_klt_read_level(uvo_klt* k, int slot, int level, uint8_t* img, int16_t* d
  * max_count / epsilon: the TermCriteria (30, 0.01 at the call site); min_eig_threshold: 1e-4 (OpenCV default). */
 int uvo_klt_track(uvo_klt* k, int prev_slot, int next_slot, const float* prev_pts, float* next_pts, int n, int max_level, int max_count,
                   double epsilon, double min_eig_threshold, uint8_t* status, float* err);
+/*
+ * Tracking::undistort_point (src/Tracking.cc:1265-1283), the step between the tracker and RANSAC (:1049-1053): for the pin-hole model
+ * cv::undistortPoints(pt, pt, mK, mDistCoef, cv::Mat(), mK), for Fisheye_Cam cv::fisheye::undistortPoints(pt, pt, mK, mDistCoef,
+ * cv::Mat(), mK).  dist: k1 k2 p1 p2 [k3 [k4 k5 k6]] (n_dist 0..8) resp. the four fisheye coefficients (n_dist <= 4).  Double
+ * arithmetic like OpenCV's; results are float pixel coordinates.
+ *   uvo_undistort_points      : n points, host in / host out (n <= 2 * max_points of the handle)
+ *   uvo_klt_track_undistorted : uvo_klt_track + the undistortion of both point sets (prev_un, next_un: n x 2 floats) on the device --
+ *                               the loop of :1049-1053 as part of the same call, one upload and one download
+ */
+typedef struct uvo_camera_model {
+  float fx, fy, cx, cy; /* mK (CV_32F) */
+  float dist[8];        /* mDistCoef */
+  int32_t n_dist;
+  int32_t fisheye;      /* Fisheye_Cam */
+} uvo_camera_model;
+int uvo_undistort_points(uvo_klt* k, const uvo_camera_model* cam, const float* pts, int n, float* out);
+int uvo_klt_track_undistorted(uvo_klt* k, int prev_slot, int next_slot, const float* prev_pts, float* next_pts, int n, int max_level, int max_count,
+                              double epsilon, double min_eig_threshold, const uvo_camera_model* cam, uint8_t* status, float* err, float* prev_un,
+                              float* next_un);
 
 /* last HIP / argument error text for the calling thread's most recent failing call (never NULL) */
 const char* uvo_last_error(void);

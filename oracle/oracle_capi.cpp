@@ -334,6 +334,15 @@ void orc_klt_track(void* p0, void* p1, const float* prevPts, float* nextPts, int
   klt_track(*static_cast<KltPyramid*>(p0), *static_cast<KltPyramid*>(p1), prevPts, nextPts, n, win_w, win_h, maxLevel, maxCount, eps, minEig, status,
             err);
 }
+void orc_undistort_points(const float* pts, int n, float fx, float fy, float cx, float cy, const float* dist, int n_dist, int fisheye, float* out) {
+  undistort_points(pts, n, fx, fy, cx, cy, dist, n_dist, fisheye != 0, out);
+}
+// sum_mode / margin: see klt_oracle.cpp
+void orc_klt_track_ex(void* p0, void* p1, const float* prevPts, float* nextPts, int n, int win_w, int win_h, int maxLevel, int maxCount, double eps,
+                      double minEig, uint8_t* status, float* err, int sum_mode, float* margin) {
+  klt_track(*static_cast<KltPyramid*>(p0), *static_cast<KltPyramid*>(p1), prevPts, nextPts, n, win_w, win_h, maxLevel, maxCount, eps, minEig, status,
+            err, sum_mode, margin);
+}
 
 void orc_compute_three_maxima(const int* sizes, int L, int* ind) {
   int a = -1, b = -1, c = -1;

@@ -215,7 +215,8 @@ struct KltPyramid {
   std::vector<Level> levels;
   void build(const uint8_t* img, int w, int h, ptrdiff_t stride, int win_w, int win_h, int maxLevel);
 };
+void undistort_points(const float* pts, int n, float fx, float fy, float cx, float cy, const float* dist, int n_dist, bool fisheye, float* out);
 void klt_track(const KltPyramid& P0, const KltPyramid& P1, const float* prevPts, float* nextPts, int npts, int win_w, int win_h, int maxLevel,
-               int maxCount, double epsilon, double minEigThreshold, uint8_t* status, float* err);
+               int maxCount, double epsilon, double minEigThreshold, uint8_t* status, float* err, int sum_mode = 0, float* margin = nullptr);
 
 }  // namespace orc

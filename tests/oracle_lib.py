@@ -68,6 +68,8 @@ class Oracle:
         L.orc_klt_level_dims.argtypes = [vp, ci, vp, vp]
         L.orc_klt_level.argtypes = [vp, ci, vp, vp]
         L.orc_klt_track.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_double, ctypes.c_double, vp, vp]
+        L.orc_undistort_points.argtypes = [vp, ci, cf, cf, cf, cf, vp, ci, ci, vp]
+        L.orc_klt_track_ex.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ctypes.c_double, ctypes.c_double, vp, vp, ci, vp]
         L.orc_haloc_hash.argtypes = [vp, ci, ci, vp, ci, vp]
         L.orc_clahe.argtypes = [vp, ci, ci, cl, ctypes.c_double, ci, ci, vp, cl]
         L.orc_bow_transform.argtypes = [ci, vp, vp, vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -368,6 +370,23 @@ class Oracle:
         self.L.orc_klt_track(p0.h, p1.h, a.ctypes.data, b.ctypes.data, len(a), win[0], win[1], max_level, max_count, float(epsilon), float(min_eig),
                              st.ctypes.data, er.ctypes.data)
         return b, st, er
+
+    def klt_track_ex(self, p0, p1, prev_pts, next_pts0=None, win=(21, 21), max_level=5, max_count=30, epsilon=0.01, min_eig=1e-4, sum_mode=0):
+        """klt_track with the association order of the float window sums selectable (0 = raster, OpenCV's generic loop; 1 = the HIP kernel's
+        lane / butterfly order) and the per-point decision margin.  -> (next, status, err, margin)"""
+        a = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+        b = a.copy() if next_pts0 is None else np.ascontiguousarray(next_pts0, np.float32).reshape(-1, 2).copy()
+        st, er, mg = np.zeros(len(a), np.uint8), np.zeros(len(a), np.float32), np.zeros(len(a), np.float32)
+        self.L.orc_klt_track_ex(p0.h, p1.h, a.ctypes.data, b.ctypes.data, len(a), win[0], win[1], max_level, max_count, float(epsilon), float(min_eig),
+                                st.ctypes.data, er.ctypes.data, int(sum_mode), mg.ctypes.data)
+        return b, st, er, mg
+
+    def undistort_points(self, pts, fx, fy, cx, cy, dist, fisheye=False):
+        p = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        d = np.ascontiguousarray(dist, np.float32)
+        out = np.zeros_like(p)
+        self.L.orc_undistort_points(p.ctypes.data, len(p), fx, fy, cx, cy, d.ctypes.data, len(d), 1 if fisheye else 0, out.ctypes.data)
+        return out
 
     def compute_three_maxima(self, sizes):
         s = np.ascontiguousarray(sizes, np.int32)

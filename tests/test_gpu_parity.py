@@ -903,9 +903,11 @@ def test_haloc_hash(uvo, oracle, synth):
 
 
 def test_klt_pyramid_and_tracking(uvo, oracle, synth):
-    """cv::buildOpticalFlowPyramid + cv::calcOpticalFlowPyrLK: pyramid levels and derivatives bit-exact; tracked positions to float
-    rounding (the wavefront reduction associates the float sums differently from the raster-order CPU loop; an iteration that
-    lands exactly on a termination threshold may stop one step apart)."""
+    """cv::buildOpticalFlowPyramid + cv::calcOpticalFlowPyrLK: pyramid levels and derivatives bit-exact.  The tracker's window sums are
+    float accumulations, so their value depends on the order of the additions: the kernel must equal -- bit for bit, positions, status
+    and error -- the oracle run in the kernel's own order (sum_mode 1: lane-strided partial sums + xor butterfly); how far that is from
+    the raster order of OpenCV's generic loop (sum_mode 0) is a property of the algorithm, bounded here and examined on the CPU in
+    tests/test_oracle_kat.py::test_klt_association_order_only_moves_decisions_at_their_thresholds."""
     rng = np.random.default_rng(80)
     for (w, h), win, ml in (((640, 512), (21, 21), 5), ((752, 480), (15, 15), 3), ((331, 257), (21, 21), 5)):
         a = synth.make_frame(6000 + w, w, h)
@@ -923,18 +925,22 @@ def test_klt_pyramid_and_tracking(uvo, oracle, synth):
         pts = np.stack([rng.uniform(-5, w + 5, n), rng.uniform(-5, h + 5, n)], 1).astype(np.float32)   # some outside / at the border
         init = (pts + rng.normal(0, 1.0, (n, 2))).astype(np.float32)                                   # OPTFLOW_USE_INITIAL_FLOW
         g_next, g_st, g_err = k.track(0, 1, pts, init)
-        o_next, o_st, o_err = oracle.klt_track(pa, pb, pts, init, win, ml)
-        assert (g_st == o_st).mean() > 0.995
-        both = (g_st > 0) & (o_st > 0)
-        assert both.sum() > 0.6 * n
-        d = np.abs(g_next[both] - o_next[both]).max(axis=1)
-        assert np.median(d) < 1e-3 and (d < 0.05).mean() > 0.99, (np.median(d), (d < 0.05).mean())
-        same = g_st == o_st
-        np.testing.assert_allclose(g_err[same], o_err[same], rtol=1e-4, atol=1e-6)
-        # second use of a pyramid in the other role (frame t becomes "previous"), slots swapped
-        g2, s2, _ = k.track(1, 0, pts)
-        o2, so2, _ = oracle.klt_track(pb, pa, pts, None, win, ml)
-        assert (s2 == so2).mean() > 0.995
+        o_next, o_st, o_err, _ = oracle.klt_track_ex(pa, pb, pts, init, win, ml, sum_mode=1)
+        np.testing.assert_array_equal(g_st, o_st)
+        np.testing.assert_array_equal(g_next.view(np.uint32), o_next.view(np.uint32))
+        np.testing.assert_array_equal(g_err.view(np.uint32), o_err.view(np.uint32))
+        assert (g_st > 0).sum() > 0.6 * n
+        # against the raster order: same status wherever no decision sits at its threshold, positions to float rounding
+        r_next, r_st, r_err, r_mg = oracle.klt_track_ex(pa, pb, pts, init, win, ml, sum_mode=0)
+        assert ((g_st == r_st) | (r_mg < 1e-3)).all()
+        both = (g_st > 0) & (r_st > 0)
+        d = np.abs(g_next[both] - r_next[both]).max(axis=1)
+        assert np.median(d) < 1e-3 and (d[r_mg[both] > 0.1] < 0.01).all()
+        # second use of a pyramid in the other role (frame t becomes "previous"), slots swapped; default initial flow
+        g2, s2, e2 = k.track(1, 0, pts)
+        o2, so2, eo2, _ = oracle.klt_track_ex(pb, pa, pts, None, win, ml, sum_mode=1)
+        np.testing.assert_array_equal(s2, so2)
+        np.testing.assert_array_equal(g2.view(np.uint32), o2.view(np.uint32))
         k.close()
 
 
@@ -1103,3 +1109,38 @@ def test_projection_searches_between_frames(uvo, oracle, synth, check_ori):
         assert n_g == n_o
     assert n_o > 200
     m.close()
+
+
+def test_undistort_points_and_the_fused_track_call(uvo, oracle, synth):
+    """Tracking::undistort_point (src/Tracking.cc:1265-1283), pin-hole and fisheye, on the device; and uvo_klt_track_undistorted = the
+    tracker + the undistortion of both point sets (:1046-1053) as one call."""
+    rng = np.random.default_rng(12)
+    w, h = 640, 512
+    k = uvo.KLT(w, h, (21, 21), 5, max_points=4096, slots=2)
+    models = [(458.654, 457.296, 367.215, 248.375, [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05], False),      # Data/Settings_VIORB.yaml
+              (458.654, 457.296, 367.215, 248.375, [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.01], False),
+              (413.32595366596017, 413.70198739483686, 305.9507483284928, 259.4439948946375,                             # Settings_VI_Aqualoc_harbor.yaml
+               [-0.06125568297136998, -0.003796743395135256, 0.027326634771204592, -0.030296403142887066], True),
+              (300.0, 300.0, 320.0, 256.0, [], False), (300.0, 300.0, 320.0, 256.0, [0.1], True)]
+    pts = np.stack([rng.uniform(-20, w + 20, 4000), rng.uniform(-20, h + 20, 4000)], 1).astype(np.float32)
+    pts[:3] = [[367.215, 248.375], [305.9507483284928, 259.4439948946375], [0, 0]]
+    for fx, fy, cx, cy, dist, fisheye in models:
+        cam = uvo.CameraModel.make(fx, fy, cx, cy, dist, fisheye)
+        got = k.undistort(cam, pts)
+        ref = oracle.undistort_points(pts, np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy), dist, fisheye)
+        np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32), err_msg="model %s" % ((fx, dist, fisheye),))
+    # fused with the tracker
+    a = synth.make_frame(6640, w, h)
+    b = synth.warp_frame(a, 6641)
+    k.build_pyramid(0, a), k.build_pyramid(1, b)
+    p0 = np.stack([rng.uniform(20, w - 20, 1500), rng.uniform(20, h - 20, 1500)], 1).astype(np.float32)
+    cam = uvo.CameraModel.make(*models[2][:4], models[2][4], True)
+    nxt, st, er, pu, nu = k.track_undistorted(0, 1, p0, cam)
+    n2, s2, e2 = k.track(0, 1, p0)
+    np.testing.assert_array_equal(nxt.view(np.uint32), n2.view(np.uint32))
+    np.testing.assert_array_equal(st, s2)
+    np.testing.assert_array_equal(pu.view(np.uint32), oracle.undistort_points(p0, *[np.float32(v) for v in models[2][:4]], models[2][4], True).view(np.uint32))
+    np.testing.assert_array_equal(nu.view(np.uint32), oracle.undistort_points(nxt, *[np.float32(v) for v in models[2][:4]], models[2][4], True).view(np.uint32))
+    with pytest.raises(uvo.UvoError):
+        k.undistort(uvo.CameraModel.make(0.0, 1.0, 0.0, 0.0, []), pts[:4])
+    k.close()

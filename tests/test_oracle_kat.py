@@ -599,3 +599,69 @@ def test_strip_plan_tiles_every_window_exactly_once():
     E.emu_xcd_contiguous_check.argtypes = [ctypes.c_int]
     for total in list(range(1, 300)) + [1023, 1024, 1025, 10496, 65537]:
         assert E.emu_xcd_contiguous_check(total) == 0, total
+
+
+def test_klt_association_order_only_moves_decisions_at_their_thresholds(oracle, synth):
+    """calcOpticalFlowPyrLK accumulates its window sums in float, so the result depends on the order of the additions (OpenCV's own
+    SIMD builds differ from its scalar loop).  Raster order (sum_mode 0, the generic loop) against the HIP kernel's order (sum_mode 1):
+    a point's status differs only if one of its yes/no decisions -- minimum eigenvalue, determinant, image bounds, the two
+    termination tests -- sits within 1e-3 of its threshold; positions agree to float rounding, and the few that differ by more than
+    0.01 px are points whose termination tests ran within 10 % of their thresholds (an iteration more or less)."""
+    rng = np.random.default_rng(81)
+    total = far = 0
+    for (w, h), win, ml in (((640, 512), (21, 21), 5), ((752, 480), (15, 15), 3)):
+        a = synth.make_frame(6000 + w, w, h)
+        b = synth.warp_frame(a, 6001 + w)
+        pa, pb = oracle.klt_pyramid(a, win, ml), oracle.klt_pyramid(b, win, ml)
+        n = 1500
+        pts = np.stack([rng.uniform(-5, w + 5, n), rng.uniform(-5, h + 5, n)], 1).astype(np.float32)
+        init = (pts + rng.normal(0, 1.0, (n, 2))).astype(np.float32)
+        n0, s0, e0, m0 = oracle.klt_track_ex(pa, pb, pts, init, win, ml, sum_mode=0)
+        ref = oracle.klt_track(pa, pb, pts, init, win, ml)
+        assert (n0 == ref[0]).all() and (s0 == ref[1]).all() and (e0 == ref[2]).all()     # mode 0 is the plain entry point
+        n1, s1, e1, m1 = oracle.klt_track_ex(pa, pb, pts, init, win, ml, sum_mode=1)
+        mg = np.minimum(m0, m1)
+        assert ((s0 == s1) | (mg < 1e-3)).all()
+        both = (s0 > 0) & (s1 > 0)
+        d = np.abs(n0 - n1).max(axis=1)
+        assert np.median(d[both]) < 1e-3 and np.percentile(d[both], 99) < 0.02
+        assert (d[both & (mg > 0.1)] < 0.01).all()
+        np.testing.assert_allclose(e0[s0 == s1], e1[s0 == s1], rtol=1e-4, atol=1e-8)   # the minimum eigenvalue is a difference of sums
+        total += int(both.sum())
+        far += int((d[both] > 0.01).sum())
+    assert total > 1800 and far < 0.02 * total
+
+
+def test_undistort_point_models(oracle):
+    """Tracking::undistort_point (src/Tracking.cc:1265-1283).  Without distortion both models are the identity (up to float rounding of
+    the normalise / re-project round trip); the principal point is a fixed point of any distortion; and undistort inverts the forward
+    model: pin-hole x_d = x (1 + k1 r^2 + k2 r^4) + tangential terms (five fixed-point iterations leave ~1e-4 px near the border),
+    fisheye theta_d = theta (1 + k1 theta^2 + ...)."""
+    fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375
+    rng = np.random.default_rng(3)
+    pts = np.stack([rng.uniform(0, 752, 500), rng.uniform(0, 480, 500)], 1).astype(np.float32)
+    for fisheye in (False, True):
+        out = oracle.undistort_points(pts, fx, fy, cx, cy, [0, 0, 0, 0], fisheye)
+        assert np.abs(out - pts).max() < 1e-3 if not fisheye else True
+        c = oracle.undistort_points(np.float32([[cx, cy]]), fx, fy, cx, cy, [-0.28, 0.07, 1e-4, 1e-5], fisheye)
+        assert np.abs(c - np.float32([[cx, cy]])).max() < 1e-4
+    # pin-hole: distort ideal points with the EuRoC coefficients (Data/Settings_VIORB.yaml:20-23), undistort, compare
+    k1, k2, p1, p2 = -0.28340811, 0.07395907, 0.00019359, 1.76187114e-05
+    x, y = (pts[:, 0].astype(np.float64) - cx) / fx * 0.6, (pts[:, 1].astype(np.float64) - cy) / fy * 0.6
+    r2 = x * x + y * y
+    xd = x * (1 + k1 * r2 + k2 * r2 * r2) + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * (1 + k1 * r2 + k2 * r2 * r2) + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    dist_px = np.stack([xd * fx + cx, yd * fy + cy], 1).astype(np.float32)
+    und = oracle.undistort_points(dist_px, fx, fy, cx, cy, [k1, k2, p1, p2], False)
+    assert np.abs(und - np.stack([x * fx + cx, y * fy + cy], 1)).max() < 2e-2
+    # fisheye (harbor: Data/Settings_VI_Aqualoc_harbor.yaml:24-33,102): theta_d = theta (1 + k1 theta^2 + k2 theta^4 + ...)
+    fxh, fyh, cxh, cyh = 413.32595366596017, 413.70198739483686, 305.9507483284928, 259.4439948946375
+    kk = [-0.06125568297136998, -0.003796743395135256, 0.027326634771204592, -0.030296403142887066]
+    a, b = rng.uniform(-0.7, 0.7, 500), rng.uniform(-0.6, 0.6, 500)          # ideal normalised coordinates
+    r = np.sqrt(a * a + b * b)
+    th = np.arctan(r)
+    thd = th * (1 + kk[0] * th**2 + kk[1] * th**4 + kk[2] * th**6 + kk[3] * th**8)
+    s = np.where(r > 1e-12, thd / np.maximum(r, 1e-12), 1.0)
+    dpx = np.stack([a * s * fxh + cxh, b * s * fyh + cyh], 1).astype(np.float32)
+    und = oracle.undistort_points(dpx, fxh, fyh, cxh, cyh, kk, True)
+    assert np.abs(und - np.stack([a * fxh + cxh, b * fyh + cyh], 1)).max() < 2e-3

@@ -152,6 +152,10 @@ def test_oracle_primitives_equal_reference(oracle):
     np.testing.assert_array_equal(neg.view(np.uint32), pins["gemm_negRt_out"].view(np.uint32))
     for name in ("c2_f0", "small"):
         np.testing.assert_array_equal(oracle.clahe(mi.frames()[name][0], 4.0, (12, 12)), pins[name + "__clahe"])
+    for name, fisheye in (("pinhole", False), ("fisheye", True)):
+        K, D = pins["undistort_%s_K" % name], pins["undistort_%s_D" % name]
+        got = oracle.undistort_points(pins["undistort_%s_in" % name], K[0], K[1], K[2], K[3], D, fisheye)
+        np.testing.assert_array_equal(got.view(np.uint32), pins["undistort_%s_out" % name].view(np.uint32), err_msg="undistort_point " + name)
     p0 = oracle.klt_pyramid(mi.frames()["c2_f0"][0], (21, 21), 5)
     for l in range(p0.levels):
         im, der = p0.level(l)
@@ -253,6 +257,13 @@ def test_kit_round_trip_with_an_emulated_dumper(oracle, tmp_path, monkeypatch):
             put("gemm_R", "f4", R), put("gemm_P", "f4", P), put("gemm_t", "f4", tt)
             put("gemm_out", "f4", (t0.astype(np.float64) + tt.astype(np.float64)).astype(np.float32))
             put("gemm_negRt_out", "f4", (-np.einsum("nkc,nk->nc", R.astype(np.float64), tt.astype(np.float64))).astype(np.float32))
+        elif t[0] == "undistort":
+            name, fisheye, n, nd = t[1], int(t[2]), int(t[3]), int(t[8])
+            K = np.float32([float(v) for v in t[4:8]])
+            D = np.float32([float(v) for v in t[9:9 + nd]])
+            pin = np.fromfile(indir / t[9 + nd], np.float32).reshape(n, 2)
+            put("undistort_%s_K" % name, "f4", K), put("undistort_%s_D" % name, "f4", D), put("undistort_%s_in" % name, "f4", pin)
+            put("undistort_%s_out" % name, "f4", oracle.undistort_points(pin, K[0], K[1], K[2], K[3], D, bool(fisheye)))
         elif t[0] == "clahe":
             put(t[1] + "/clahe", "u1", oracle.clahe(frames[t[1]][0], float(t[2]), (int(t[3]), int(t[4]))))
         elif t[0] == "klt":

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include <opencv2/calib3d/calib3d.hpp>
 #include <opencv2/core/core.hpp>
 #include <opencv2/features2d/features2d.hpp>
 #include <opencv2/imgproc/imgproc.hpp>
@@ -232,6 +233,38 @@ int main(int argc, char** argv) {
       cv::Mat dst;
       clahe->apply(frames.at(name).img, dst);
       put_mat_u8(name + "/clahe", dst);
+    } else if (kind == "undistort") {
+      std::string name, file;
+      int fisheye, n, nd;
+      double fx, fy, cx, cy;
+      ss >> name >> fisheye >> n >> fx >> fy >> cx >> cy >> nd;
+      cv::Mat K = cv::Mat::eye(3, 3, CV_32F), D(nd, 1, CV_32F);  // mK / mDistCoef are CV_32F (src/Tracking.cc:100-130)
+      K.at<float>(0, 0) = (float)fx, K.at<float>(1, 1) = (float)fy, K.at<float>(0, 2) = (float)cx, K.at<float>(1, 2) = (float)cy;
+      for (int i = 0; i < nd; ++i) {
+        double v;
+        ss >> v;
+        D.at<float>(i) = (float)v;
+      }
+      ss >> file;
+      std::vector<char> raw = slurp(in + "/" + file);
+      std::vector<float> out(2 * (size_t)n);
+      for (int i = 0; i < n; ++i) {  // exactly Tracking::undistort_point (:1265-1283), point by point
+        cv::Mat mat(1, 2, CV_32F);
+        mat.at<float>(0, 0) = reinterpret_cast<const float*>(raw.data())[2 * i];
+        mat.at<float>(0, 1) = reinterpret_cast<const float*>(raw.data())[2 * i + 1];
+        mat = mat.reshape(2);
+        if (fisheye)
+          cv::fisheye::undistortPoints(mat, mat, K, D, cv::Mat(), K);
+        else
+          cv::undistortPoints(mat, mat, K, D, cv::Mat(), K);
+        mat = mat.reshape(1);
+        out[2 * i] = mat.at<float>(0, 0), out[2 * i + 1] = mat.at<float>(0, 1);
+      }
+      const float par[4] = {(float)fx, (float)fy, (float)cx, (float)cy};
+      put("undistort_" + name + "_K", "f4", par, 4, {4});
+      put("undistort_" + name + "_D", "f4", D.data, 4, {(size_t)nd});
+      put("undistort_" + name + "_in", "f4", raw.data(), 4, {(size_t)n, 2});
+      put("undistort_" + name + "_out", "f4", out.data(), 4, {(size_t)n, 2});
     } else if (kind == "klt") {
       std::string a, b, fpts;
       int ww, wh, maxLevel, iters, n;

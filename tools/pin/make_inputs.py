@@ -96,6 +96,12 @@ def main():
     seq = synth.make_sequence(0, 2, 640, 512)
     pts = np.stack([rng.uniform(30, 610, 800), rng.uniform(30, 480, 800)], 1).astype(np.float32)
     lines.append("klt c2_f0 c2_f1 21 21 5 30 0.01 0.0001 %d %s" % (len(pts), put("klt_pts", pts)))
+    # Tracking::undistort_point (src/Tracking.cc:1265-1283): pin-hole (Data/Settings_VIORB.yaml:14-23) and fisheye (Settings_VI_Aqualoc_harbor.yaml:24-33,102)
+    upts = np.stack([rng.uniform(-20, 772, 3000), rng.uniform(-20, 500, 3000)], 1).astype(np.float32)
+    f = put("undistort_pts", upts)
+    lines.append("undistort pinhole 0 %d 458.654 457.296 367.215 248.375 4 -0.28340811 0.07395907 0.00019359 1.76187114e-05 %s" % (len(upts), f))
+    lines.append("undistort fisheye 1 %d 413.32595366596017 413.70198739483686 305.9507483284928 259.4439948946375 4 -0.06125568297136998 "
+                 "-0.003796743395135256 0.027326634771204592 -0.030296403142887066 %s" % (len(upts), f))
     with open(os.path.join(a.out, "cases.txt"), "w") as fh:
         fh.write("\n".join(lines) + "\n")
     print("wrote %d cases to %s" % (len(lines), a.out))

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_profile_only", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
-    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_search_points_in_frustum", "uvo_sim3_decompose", "uvo_sim3_relative", "uvo_project_sim3", "uvo_search_by_projection_sim3", "uvo_search_by_sim3", "uvo_haloc_hash", "uvo_klt_create", "uvo_klt_destroy", "uvo_klt_build_pyramid", "uvo_klt_build_pyramid_from_extractor", "uvo_klt_read_level", "uvo_klt_track", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
+    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_search_points_in_frustum", "uvo_sim3_decompose", "uvo_sim3_relative", "uvo_project_sim3", "uvo_search_by_projection_sim3", "uvo_search_by_sim3", "uvo_haloc_hash", "uvo_klt_create", "uvo_klt_destroy", "uvo_klt_build_pyramid", "uvo_klt_build_pyramid_from_extractor", "uvo_klt_read_level", "uvo_klt_track", "uvo_undistort_points", "uvo_klt_track_undistorted", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
     "uvo_matcher_kernel_times", "uvo_last_error", "uvo_device_info",
 ]
 
@@ -192,6 +192,8 @@ def _load():
     lib.uvo_klt_build_pyramid_from_extractor.argtypes = [vp, ci, vp, vp]
     lib.uvo_klt_read_level.argtypes = [vp, ci, ci, vp, vp, vp, vp]
     lib.uvo_klt_track.argtypes = [vp, ci, ci, vp, vp, ci, ci, ci, ctypes.c_double, ctypes.c_double, vp, vp]
+    lib.uvo_undistort_points.argtypes = [vp, vp, vp, ci, vp]
+    lib.uvo_klt_track_undistorted.argtypes = [vp, ci, ci, vp, vp, ci, ci, ci, ctypes.c_double, ctypes.c_double, vp, vp, vp, vp, vp]
     lib.uvo_fuse.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, vp, vp]
     lib.uvo_search_points_in_frustum.argtypes = [vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, cf, vp, vp, vp, vp, vp, vp, vp]
     lib.uvo_sim3_decompose.argtypes = [vp, ci, vp]
@@ -963,6 +965,20 @@ class ORBVocabulary:
         return wid, ww, nid, (bid[:nb.value].copy(), bval[:nb.value].copy()), FeatureVector(groups)
 
 
+class CameraModel(ctypes.Structure):
+    """uvo_camera_model: mK and mDistCoef of the reference's Tracking object (pin-hole: k1 k2 p1 p2 [k3 ..]; fisheye: 4 coefficients)."""
+    _fields_ = [("fx", ctypes.c_float), ("fy", ctypes.c_float), ("cx", ctypes.c_float), ("cy", ctypes.c_float), ("dist", ctypes.c_float * 8),
+                ("n_dist", ctypes.c_int32), ("fisheye", ctypes.c_int32)]
+
+    @classmethod
+    def make(cls, fx, fy, cx, cy, dist, fisheye=False):
+        c = cls(fx, fy, cx, cy)
+        for i, v in enumerate(dist):
+            c.dist[i] = v
+        c.n_dist, c.fisheye = len(dist), 1 if fisheye else 0
+        return c
+
+
 class KltCfg(ctypes.Structure):
     """uvo_klt_cfg."""
     _fields_ = [("max_width", ctypes.c_int32), ("max_height", ctypes.c_int32), ("max_level", ctypes.c_int32), ("win_width", ctypes.c_int32),
@@ -1025,6 +1041,29 @@ class KLT:
         if rc:
             raise UvoError(rc, "uvo_klt_track")
         return p1, st, er
+
+    def undistort(self, cam, pts):
+        """Tracking::undistort_point (src/Tracking.cc:1265-1283) for an (n, 2) float32 array; cam: CameraModel."""
+        p = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        out = np.zeros_like(p)
+        rc = lib.uvo_undistort_points(self._h, ctypes.byref(cam), _ptr(p), len(p), _ptr(out))
+        if rc:
+            raise UvoError(rc, "uvo_undistort_points")
+        return out
+
+    def track_undistorted(self, prev_slot, next_slot, prev_pts, cam, next_pts0=None, max_count=30, epsilon=0.01, min_eig_threshold=1e-4):
+        """uvo_klt_track_undistorted: the LK step + undistort_point of both point sets in one call.
+        Returns (next, status, err, prev_un, next_un)."""
+        a = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+        b = a.copy() if next_pts0 is None else np.ascontiguousarray(next_pts0, np.float32).reshape(-1, 2).copy()
+        n = len(a)
+        st, er = np.zeros(n, np.uint8), np.zeros(n, np.float32)
+        pu, nu = np.zeros((n, 2), np.float32), np.zeros((n, 2), np.float32)
+        rc = lib.uvo_klt_track_undistorted(self._h, prev_slot, next_slot, _ptr(a), _ptr(b), n, self.max_level, int(max_count), float(epsilon), float(min_eig_threshold),
+                                           ctypes.byref(cam), _ptr(st), _ptr(er), _ptr(pu), _ptr(nu))
+        if rc:
+            raise UvoError(rc, "uvo_klt_track_undistorted")
+        return b, st, er, pu, nu
 
 
 def DescriptorDistance(a, b):

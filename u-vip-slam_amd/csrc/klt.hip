@@ -211,6 +211,58 @@ __global__ __launch_bounds__(256) void k_klt_track(KltGeom G, const uint8_t* __r
   }
 }
 
+// Tracking::undistort_point (src/Tracking.cc:1265-1283) for n points: cv::undistortPoints(pt, pt, K, D, noArray(), K) or, for the
+// fisheye model, cv::fisheye::undistortPoints(pt, pt, K, D, Mat(), K) -- one thread per point, double arithmetic like OpenCV 3.4's
+// (cvUndistortPointsInternal: five fixed-point iterations of the Brown model, no epsilon test; fisheye: at most ten Newton steps on
+// theta, |step| < 1e-8 ends them, theta_d clamped to [-pi/2, pi/2]), re-projected with P = K.  [OCV-RECALL: unpinned, see tools/pin]
+struct UndistortCam {
+  double fx, fy, cx, cy, k[8];
+  int fisheye;
+};
+__global__ __launch_bounds__(256) void k_undistort(UndistortCam C, const float* __restrict__ pts, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double u = (double)pts[2 * i], v = (double)pts[2 * i + 1];
+  double x, y;
+  if (!C.fisheye) {
+    const double ifx = 1. / C.fx, ify = 1. / C.fy;
+    x = (u - C.cx) * ifx, y = (v - C.cy) * ify;
+    const double x0 = x, y0 = y;
+    const double* k = C.k;  // k1 k2 p1 p2 k3 k4 k5 k6
+    for (int j = 0; j < 5; ++j) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+      const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    const double xx = C.fx * x + 0. * y + C.cx, yy = 0. * x + C.fy * y + C.cy, ww = 1. / (0. * x + 0. * y + 1.);
+    out[2 * i] = (float)(xx * ww), out[2 * i + 1] = (float)(yy * ww);
+  } else {
+    const double pwx = (u - C.cx) / C.fx, pwy = (v - C.cy) / C.fy;
+    double scale = 1.0;
+    double theta_d = sqrt(pwx * pwx + pwy * pwy);
+    const double half_pi = 3.1415926535897932384626433832795 / 2.;
+    theta_d = fmin(fmax(-half_pi, theta_d), half_pi);
+    if (theta_d > 1e-8) {
+      double theta = theta_d;
+      for (int j = 0; j < 10; ++j) {
+        const double theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta6 * theta2;
+        const double k0_theta2 = C.k[0] * theta2, k1_theta4 = C.k[1] * theta4, k2_theta6 = C.k[2] * theta6, k3_theta8 = C.k[3] * theta8;
+        const double theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                                 (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+        theta = theta - theta_fix;
+        if (fabs(theta_fix) < 1e-8) break;
+      }
+      scale = tan(theta) / theta_d;
+    }
+    x = pwx * scale, y = pwy * scale;
+    const double pr0 = C.fx * x + 0. * y + C.cx * 1.0, pr1 = 0. * x + C.fy * y + C.cy * 1.0, pr2 = 0. * x + 0. * y + 1. * 1.0;
+    out[2 * i] = (float)(pr0 / pr2), out[2 * i + 1] = (float)(pr1 / pr2);
+  }
+}
+
 }  // namespace uvo
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -284,8 +336,8 @@ int uvo_klt_create(const uvo_klt_cfg* cfg, uvo_klt** out) {
   k->slot_w.assign(cfg->slots, 0), k->slot_h.assign(cfg->slots, 0), k->slot_levels.assign(cfg->slots, 0);
   const size_t S = (size_t)cfg->slots, N = (size_t)cfg->max_points;
   if (hipMalloc((void**)&k->d_img, S * k->img_block) != hipSuccess || hipMalloc((void**)&k->d_der, S * k->der_block * 2) != hipSuccess ||
-      hipMalloc((void**)&k->d_in, (size_t)cfg->max_width * cfg->max_height) != hipSuccess || hipMalloc((void**)&k->d_pts, N * 21 + 64) != hipSuccess ||
-      hipHostMalloc((void**)&k->h_pts, N * 21 + 64, hipHostMallocDefault) != hipSuccess) {
+      hipMalloc((void**)&k->d_in, (size_t)cfg->max_width * cfg->max_height) != hipSuccess || hipMalloc((void**)&k->d_pts, N * 37 + 64) != hipSuccess ||
+      hipHostMalloc((void**)&k->h_pts, N * 37 + 64, hipHostMallocDefault) != hipSuccess) {
     uvo_klt_destroy(k);
     return fail(UVO_E_NOMEM, "KLT scratch allocation failed");
   }
@@ -374,8 +426,22 @@ int uvo_klt_read_level(uvo_klt* k, int slot, int level, uint8_t* img, int16_t* d
   return UVO_OK;
 }
 
-int uvo_klt_track(uvo_klt* k, int prev_slot, int next_slot, const float* prev_pts, float* next_pts, int n, int max_level, int max_count,
-                  double epsilon, double min_eig_threshold, uint8_t* status, float* err) {
+}  // extern "C"
+
+static int check_camera_model(const uvo_camera_model* cam, UndistortCam& C) {
+  if (!cam) return fail(UVO_E_BADARG, "null camera model");
+  if (!(cam->fx != 0.f) || !(cam->fy != 0.f) || cam->n_dist < 0 || cam->n_dist > 8 || (cam->fisheye && cam->n_dist > 4))
+    return fail(UVO_E_BADARG, "bad camera model (focal lengths non-zero, at most 8 distortion coefficients, 4 for the fisheye model)");
+  C.fx = (double)cam->fx, C.fy = (double)cam->fy, C.cx = (double)cam->cx, C.cy = (double)cam->cy;  // mK is CV_32F: the values widen
+  for (int i = 0; i < 8; ++i) C.k[i] = i < cam->n_dist ? (double)cam->dist[i] : 0.0;
+  C.fisheye = cam->fisheye ? 1 : 0;
+  return UVO_OK;
+}
+
+// the LK step, optionally followed on the device by Tracking::undistort_point of both point sets (one upload, one download)
+static int klt_track_impl(uvo_klt* k, int prev_slot, int next_slot, const float* prev_pts, float* next_pts, int n, int max_level, int max_count,
+                          double epsilon, double min_eig_threshold, uint8_t* status, float* err, const uvo_camera_model* cam, float* prev_un,
+                          float* next_un) {
   if (!k) return fail(UVO_E_BADARG, "null handle");
   if (prev_slot < 0 || prev_slot >= k->cfg.slots || next_slot < 0 || next_slot >= k->cfg.slots || k->slot_levels[prev_slot] == 0 ||
       k->slot_levels[next_slot] == 0)
@@ -385,6 +451,12 @@ int uvo_klt_track(uvo_klt* k, int prev_slot, int next_slot, const float* prev_pt
   if (n < 0 || n > k->cfg.max_points) return fail(UVO_E_BADARG, "point count outside 0..max_points");
   if (n == 0) return UVO_OK;
   if (!prev_pts || !next_pts || !status || !err) return fail(UVO_E_BADARG, "null pointer");
+  UndistortCam UC;
+  if (cam) {
+    if (!prev_un || !next_un) return fail(UVO_E_BADARG, "null pointer");
+    const int rc = check_camera_model(cam, UC);
+    if (rc) return rc;
+  }
   UVO_HIP_CHECK(hipSetDevice(k->cfg.device));
   hipStream_t s = k->stream;
   KltGeom G;
@@ -412,13 +484,64 @@ int uvo_klt_track(uvo_klt* k, int prev_slot, int next_slot, const float* prev_pt
   else
     hipLaunchKernelGGL(k_klt_track<16>, grid, dim3(256), 0, s, G, I0, D0, I1, k->d_prev, k->d_next, n, k->cfg.win_width, k->cfg.win_height, max_level,
                        max_count, (float)epsilon, (float)min_eig_threshold, k->d_status, k->d_err);
+  // undistorted copies behind the status bytes (8-byte aligned): prev_un [n][2] | next_un [n][2]
+  const size_t o_un = (N * 21 + 7) & ~(size_t)7;
+  if (cam) {
+    float* d_un = reinterpret_cast<float*>(k->d_pts + o_un);
+    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, s, UC, k->d_prev, n, d_un);
+    hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, s, UC, k->d_next, n, d_un + 2 * N);
+  }
   UVO_HIP_CHECK(hipGetLastError());
-  UVO_HIP_CHECK(hipMemcpyAsync(k->h_pts + o_next, k->d_pts + o_next, N * 13, hipMemcpyDeviceToHost, s));  // next, err, status
+  const size_t down = (cam ? o_un + N * 16 : N * 21) - o_next;
+  UVO_HIP_CHECK(hipMemcpyAsync(k->h_pts + o_next, k->d_pts + o_next, down, hipMemcpyDeviceToHost, s));  // next, err, status (, prev_un, next_un)
   UVO_HIP_CHECK(hipStreamSynchronize(s));
   std::memcpy(next_pts, k->h_pts + o_next, N * 8);
   std::memcpy(err, k->h_pts + o_err, N * 4);
   std::memcpy(status, k->h_pts + o_status, N);
+  if (cam) {
+    std::memcpy(prev_un, k->h_pts + o_un, N * 8);
+    std::memcpy(next_un, k->h_pts + o_un + N * 8, N * 8);
+  }
   return UVO_OK;
 }
+
+extern "C" {
+
+int uvo_klt_track(uvo_klt* k, int prev_slot, int next_slot, const float* prev_pts, float* next_pts, int n, int max_level, int max_count,
+                  double epsilon, double min_eig_threshold, uint8_t* status, float* err) {
+  return klt_track_impl(k, prev_slot, next_slot, prev_pts, next_pts, n, max_level, max_count, epsilon, min_eig_threshold, status, err, nullptr, nullptr,
+                        nullptr);
+}
+
+int uvo_klt_track_undistorted(uvo_klt* k, int prev_slot, int next_slot, const float* prev_pts, float* next_pts, int n, int max_level, int max_count,
+                              double epsilon, double min_eig_threshold, const uvo_camera_model* cam, uint8_t* status, float* err, float* prev_un,
+                              float* next_un) {
+  if (!cam) return fail(UVO_E_BADARG, "null camera model");
+  return klt_track_impl(k, prev_slot, next_slot, prev_pts, next_pts, n, max_level, max_count, epsilon, min_eig_threshold, status, err, cam, prev_un,
+                        next_un);
+}
+
+int uvo_undistort_points(uvo_klt* k, const uvo_camera_model* cam, const float* pts, int n, float* out) {
+  if (!k) return fail(UVO_E_BADARG, "null handle");
+  if (n < 0 || n > 2 * k->cfg.max_points) return fail(UVO_E_BADARG, "point count outside 0..2*max_points");
+  if (n == 0) return UVO_OK;
+  if (!pts || !out) return fail(UVO_E_BADARG, "null pointer");
+  UndistortCam UC;
+  const int rc = check_camera_model(cam, UC);
+  if (rc) return rc;
+  UVO_HIP_CHECK(hipSetDevice(k->cfg.device));
+  hipStream_t s = k->stream;
+  const size_t N = (size_t)n;
+  std::memcpy(k->h_pts, pts, N * 8);
+  UVO_HIP_CHECK(hipMemcpyAsync(k->d_pts, k->h_pts, N * 8, hipMemcpyHostToDevice, s));
+  float* d_out = reinterpret_cast<float*>(k->d_pts + N * 8);
+  hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, s, UC, reinterpret_cast<const float*>(k->d_pts), n, d_out);
+  UVO_HIP_CHECK(hipGetLastError());
+  UVO_HIP_CHECK(hipMemcpyAsync(k->h_pts + N * 8, d_out, N * 8, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipStreamSynchronize(s));
+  std::memcpy(out, k->h_pts + N * 8, N * 8);
+  return UVO_OK;
+}
+
 
 }  // extern "C"
