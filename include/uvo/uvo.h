@@ -91,6 +91,16 @@ int uvo_extract(uvo_extractor* h, const uint8_t* img, int width, int height, ptr
                 uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int* n_out);
 
 /*
+ * The top-up call together with the caller's loop in front of it (src/Tracking.cc:896-946): the occupancy grid is built on the
+ * device from the tracked keypoints -- grid_2d((int)(pt.y / min_px_dist), (int)(pt.x / min_px_dist))++ on a zero matrix of
+ * (height / min_px_dist + 2) x (width / min_px_dist + 2) -- and the extraction runs with FullDetect = false on it.  in_kp are the
+ * tracked keypoints (`pts0`, passed through level 0 like `keypoints` on entry of operator()).  grid2d_out (optional): the grid after
+ * the call, column-major, for callers that keep it.  img == NULL: the result of the last uvo_clahe(), as in uvo_extract.
+ */
+int uvo_extract_tracked(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdiff_t stride, const uvo_keypoint* in_kp, int n_in,
+                        int min_px_dist, int num_feats_needed, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int* n_out, int32_t* grid2d_out);
+
+/*
  * Batched form of the same call (B independent frames, one launch per stage).  Host buffers:
  *   imgs           : frame b at imgs + b*frame_stride, rows `stride` bytes apart
  *   in_kp / n_in   : [B][max_input_keypoints] / [B]   (NULL / NULL when there are none)

@@ -167,3 +167,35 @@ def test_topup_grid_smaller_than_the_image_is_rejected(uvo, synth):
     exact = np.zeros(((H - 1) // 20 + 1, (W - 1) // 20 + 1), np.int32, order="F")   # the smallest grid every pixel position fits
     ex(img, None, exact, 20, False, 100)
     ex.close()
+
+
+def test_extract_tracked_builds_the_callers_occupancy_grid_on_the_device(uvo, oracle, synth):
+    """src/Tracking.cc:896-946 as one call: grid_2d((int)(pt.y / d), (int)(pt.x / d))++ for the tracked keypoints, then the top-up
+    extraction -- against the oracle fed with the host-built grid, grid mutation included; also after uvo_clahe (image kept in HBM)."""
+    W, H, d = 640, 512, 20
+    img = synth.make_frame(4711, W, H)
+    oe = oracle.extractor(400, 1.2, 8, 20)
+    ex = uvo.ORBextractor(400, 1.2, 8, 0, 20, max_width=W, max_height=H, max_input_keypoints=800)
+    rng = np.random.default_rng(9)
+    for n_in in (330, 0, 800):
+        kin = np.zeros(n_in, uvo.KEYPOINT_DTYPE)
+        kin["x"], kin["y"] = rng.uniform(20, W - 21, n_in).astype(np.float32), rng.uniform(20, H - 21, n_in).astype(np.float32)
+        kin["x"][: n_in // 4] = np.floor(kin["x"][: n_in // 4] / d) * d          # some exactly on cell boundaries
+        kin["size"], kin["angle"], kin["octave"], kin["class_id"] = 31, -1, 0, -1
+        grid = np.zeros((H // d + 2, W // d + 2), np.int32, order="F")
+        for k in kin:
+            grid[int(np.float32(k["y"]) / np.float32(d)), int(np.float32(k["x"]) / np.float32(d))] += 1
+        need = 400 - n_in // 2
+        kp_o, de_o = oe(img, kin.copy(), grid, d, False, need)
+        kp_g, de_g, grid_g = ex.extract_tracked(img, kin, d, need, want_grid=True)
+        _same(kp_g, de_g, kp_o, de_o, "extract_tracked n_in=%d" % n_in)
+        np.testing.assert_array_equal(grid_g, grid)
+    enh = ex.clahe(img, download=False)
+    kin = kin[:300]
+    grid = np.zeros((H // d + 2, W // d + 2), np.int32, order="F")
+    for k in kin:
+        grid[int(k["y"] / d), int(k["x"] / d)] += 1
+    kp_o, de_o = oe(oracle.clahe(img, 4.0, (12, 12)), kin.copy(), grid, d, False, 150)
+    kp_g, de_g = ex.extract_tracked(None, kin, d, 150)
+    _same(kp_g, de_g, kp_o, de_o, "clahe -> extract_tracked(NULL)")
+    ex.close()

@@ -27,7 +27,7 @@ UVO_TUNE_OCT_WIDE_MAX = 1
 # every symbol include/uvo/uvo.h declares
 ABI_SYMBOLS = [
     "uvo_extractor_create", "uvo_extractor_destroy", "uvo_extractor_levels", "uvo_extractor_max_keypoints", "uvo_extractor_scale_factor", "uvo_extractor_tables",
-    "uvo_extract", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_host_alloc", "uvo_host_free", "uvo_host_register", "uvo_host_unregister", "uvo_shard_plan_make", "uvo_sharder_create", "uvo_sharder_destroy", "uvo_sharder_max_keypoints", "uvo_sharder_run", "uvo_extract_batch_submit", "uvo_extract_batch_wait", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_tune", "uvo_extractor_level_dims",
+    "uvo_extract", "uvo_extract_tracked", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_host_alloc", "uvo_host_free", "uvo_host_register", "uvo_host_unregister", "uvo_shard_plan_make", "uvo_sharder_create", "uvo_sharder_destroy", "uvo_sharder_max_keypoints", "uvo_sharder_run", "uvo_extract_batch_submit", "uvo_extract_batch_wait", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_tune", "uvo_extractor_level_dims",
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_profile_only", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
@@ -139,6 +139,7 @@ def _load():
     lib.uvo_extractor_scale_factor.restype = cf
     lib.uvo_extractor_tables.argtypes = [vp, vp, vp, vp, vp]
     lib.uvo_extract.argtypes = [vp, vp, ci, ci, cl, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp]
+    lib.uvo_extract_tracked.argtypes = [vp, vp, ci, ci, cl, vp, ci, ci, ci, vp, vp, ci, vp, vp]
     lib.uvo_extract_batch.argtypes = [vp, ci, vp, ci, ci, cl, cl, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
     lib.uvo_extract_batch_device.argtypes = [vp, ci, vp, ci, ci, cl, cl, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
     lib.uvo_host_alloc.argtypes = [vp, ctypes.c_size_t]
@@ -382,6 +383,25 @@ class ORBextractor:
             raise UvoError(rc, "uvo_extract")
         n = n_out.value
         return out_kp[:n].copy(), out_desc[:n].copy()
+
+    def extract_tracked(self, image, keypoints, min_px_dist, num_featsneeded, want_grid=False):
+        """uvo_extract_tracked: src/Tracking.cc:896-946 as one call -- occupancy grid from the tracked keypoints on the device, then the
+        top-up extraction.  image None = the last clahe() result.  Returns (keypoints, descriptors[, grid (rows, cols) int32 F-order])."""
+        if image is None:
+            h, w = self._clahe_shape
+        else:
+            image = np.ascontiguousarray(image, dtype=np.uint8)
+            h, w = image.shape
+        kin = np.ascontiguousarray(keypoints, dtype=KEYPOINT_DTYPE)
+        out_kp, out_desc, n_out = np.zeros(self.cap, KEYPOINT_DTYPE), np.zeros((self.cap, 32), np.uint8), ctypes.c_int(0)
+        grid = np.zeros((h // min_px_dist + 2, w // min_px_dist + 2), np.int32, order="F") if want_grid else None
+        rc = lib.uvo_extract_tracked(self._h, _ptr(image), w, h, w if image is None else image.strides[0], _ptr(kin) if len(kin) else None, len(kin),
+                                     int(min_px_dist), int(num_featsneeded), out_kp.ctypes.data, out_desc.ctypes.data, self.cap, ctypes.byref(n_out),
+                                     _ptr(grid))
+        if rc:
+            raise UvoError(rc, "uvo_extract_tracked")
+        n = n_out.value
+        return (out_kp[:n].copy(), out_desc[:n].copy()) + ((grid,) if want_grid else ())
 
     def extract_batch(self, images):
         """FullDetect extraction of a (B, H, W) uint8 stack; returns list of (keypoints, descriptors)."""

@@ -124,6 +124,8 @@ void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const 
                      const int32_t* d_sel_count,
                      const uvo_keypoint* d_in_kp, const int32_t* d_n_in, int in_cap, int32_t* d_grid, int grid_rows, int grid_cols,
                      int min_px_dist, int full_detect, const int32_t* d_nfn, FinalSlot* d_flist, int32_t* d_n_final, int batch);
+void launch_occupancy_grid(hipStream_t s, const uvo_keypoint* d_in_kp, const int32_t* d_n_in, int in_cap, int min_px_dist, int grid_rows, int grid_cols,
+                           int32_t* d_grid, int batch);
 void launch_knn2(hipStream_t s, int pairs, int max_q, const uint8_t* d_q, const int32_t* d_nq, int nq_fixed, int q_stride, const uint8_t* d_t,
                  const int32_t* d_nt, int nt_fixed, int t_stride, const uint8_t* d_mask, int out_stride, int32_t* d_idx0, uint16_t* d_d0,
                  int32_t* d_idx1, uint16_t* d_d1);

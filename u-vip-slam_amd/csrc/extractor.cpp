@@ -710,9 +710,14 @@ int uvo_extractor_set_pipeline(uvo_extractor* h, int depth) {
   return UVO_OK;
 }
 
-int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
-                      const uvo_keypoint* in_kp, const int32_t* n_in, int32_t* grid2d, int grid_rows, int grid_cols, int min_px_dist,
-                      int full_detect, const int32_t* num_feats_needed, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out) {
+}  // extern "C"
+
+// build_grid: the occupancy grid is not an input -- it is built on the device from the caller keypoints (src/Tracking.cc:896-912) and
+// only returned (grid2d may be NULL)
+static int extract_batch_impl(uvo_extractor* h, int batch, const uint8_t* imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
+                              const uvo_keypoint* in_kp, const int32_t* n_in, int32_t* grid2d, int grid_rows, int grid_cols, int min_px_dist,
+                              int full_detect, const int32_t* num_feats_needed, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out,
+                              bool build_grid) {
   if (!h || !out_kp || !out_desc || !n_out) return fail(UVO_E_BADARG, "null pointer");
   if (batch < 1 || batch > h->cfg.max_batch) return fail(UVO_E_BADARG, "batch outside 1..max_batch");
   const bool from_clahe = imgs == nullptr;  // the frame is the result of the last uvo_clahe() call, already in HBM
@@ -757,7 +762,7 @@ int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int widt
   const int dcap = h->cap_flist;  // device staging capacity per frame
   size_t gb = 0;
   if (topup) {
-    if (!grid2d || !num_feats_needed) return fail(UVO_E_BADARG, "top-up mode needs grid2d and num_feats_needed");
+    if ((!grid2d && !build_grid) || !num_feats_needed) return fail(UVO_E_BADARG, "top-up mode needs grid2d and num_feats_needed");
     gb = (size_t)batch * grid_rows * grid_cols * sizeof(int32_t);
     if (gb > h->grid_bytes) {
       UVO_HIP_CHECK(hipStreamSynchronize(s));
@@ -792,13 +797,16 @@ int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int widt
   if (topup) {
     if (bounce) {
       std::memcpy(pin_i + batch, num_feats_needed, sizeof(int32_t) * batch);
-      std::memcpy(h->h_pin + off_grid, grid2d, gb);
       UVO_HIP_CHECK(hipMemcpyAsync(h->d_nfn, pin_i + batch, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
-      UVO_HIP_CHECK(hipMemcpyAsync(h->d_grid, h->h_pin + off_grid, gb, hipMemcpyHostToDevice, s));
+      if (!build_grid) {
+        std::memcpy(h->h_pin + off_grid, grid2d, gb);
+        UVO_HIP_CHECK(hipMemcpyAsync(h->d_grid, h->h_pin + off_grid, gb, hipMemcpyHostToDevice, s));
+      }
     } else {
-      UVO_HIP_CHECK(hipMemcpyAsync(h->d_grid, grid2d, gb, hipMemcpyHostToDevice, s));
+      if (!build_grid) UVO_HIP_CHECK(hipMemcpyAsync(h->d_grid, grid2d, gb, hipMemcpyHostToDevice, s));
       UVO_HIP_CHECK(hipMemcpyAsync(h->d_nfn, num_feats_needed, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
     }
+    if (build_grid) UVO_HIP_CHECK(hipMemsetAsync(h->d_grid, 0, gb, s));
     if (have_in) {
       // only the first n_in[b] entries of a frame's slice are ever read on the device
       if (bounce) {
@@ -820,6 +828,8 @@ int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int widt
       }
     }
   }
+  if (topup && build_grid && have_in)
+    launch_occupancy_grid(s, h->d_in_kp, h->d_n_in, in_cap, min_px_dist, grid_rows, grid_cols, h->d_grid, batch);
   int rc = run_batch_device(h, li, batch, d_frames, width, height, width, (ptrdiff_t)width * height, have_in ? h->d_in_kp : nullptr,
                             have_in ? h->d_n_in : nullptr, topup ? h->d_grid : nullptr, grid_rows, grid_cols, min_px_dist, full_detect,
                             topup ? h->d_nfn : nullptr, h->d_out_kp, h->d_out_desc, dcap, h->d_n_out);
@@ -827,10 +837,10 @@ int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int widt
   if (bounce) {
     // the stream is in order: the keypoint uploads above were consumed before the outputs land in the same pinned region
     UVO_HIP_CHECK(hipMemcpyAsync(pin_i, h->d_n_out, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
-    if (topup) UVO_HIP_CHECK(hipMemcpyAsync(h->h_pin + off_grid, h->d_grid, gb, hipMemcpyDeviceToHost, s));
+    if (topup && grid2d) UVO_HIP_CHECK(hipMemcpyAsync(h->h_pin + off_grid, h->d_grid, gb, hipMemcpyDeviceToHost, s));
     UVO_HIP_CHECK(hipStreamSynchronize(s));
     std::memcpy(n_out, pin_i, sizeof(int32_t) * batch);
-    if (topup) std::memcpy(grid2d, h->h_pin + off_grid, gb);
+    if (topup && grid2d) std::memcpy(grid2d, h->h_pin + off_grid, gb);
   } else {
     UVO_HIP_CHECK(hipMemcpyAsync(n_out, h->d_n_out, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
     UVO_HIP_CHECK(hipStreamSynchronize(s));
@@ -853,7 +863,7 @@ int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int widt
       UVO_HIP_CHECK(hipMemcpyAsync(out_desc + (size_t)b * cap * 32, h->d_out_desc + (size_t)b * dcap * 32, (size_t)32 * n, hipMemcpyDeviceToHost, s));
     }
   }
-  if (!bounce && topup) UVO_HIP_CHECK(hipMemcpyAsync(grid2d, h->d_grid, gb, hipMemcpyDeviceToHost, s));
+  if (!bounce && topup && grid2d) UVO_HIP_CHECK(hipMemcpyAsync(grid2d, h->d_grid, gb, hipMemcpyDeviceToHost, s));
   UVO_HIP_CHECK(hipStreamSynchronize(s));
   if (bounce) {
     pout = h->h_pin + off_kp;
@@ -866,6 +876,28 @@ int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int widt
     }
   }
   return status;
+}
+
+extern "C" {
+
+int uvo_extract_batch(uvo_extractor* h, int batch, const uint8_t* imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
+                      const uvo_keypoint* in_kp, const int32_t* n_in, int32_t* grid2d, int grid_rows, int grid_cols, int min_px_dist,
+                      int full_detect, const int32_t* num_feats_needed, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out) {
+  return extract_batch_impl(h, batch, imgs, width, height, stride, frame_stride, in_kp, n_in, grid2d, grid_rows, grid_cols, min_px_dist, full_detect,
+                            num_feats_needed, out_kp, out_desc, cap, n_out, false);
+}
+
+int uvo_extract_tracked(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdiff_t stride, const uvo_keypoint* in_kp, int n_in,
+                        int min_px_dist, int num_feats_needed, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int* n_out, int32_t* grid2d_out) {
+  if (!h || !n_out) return fail(UVO_E_BADARG, "null pointer");
+  if (n_in < 0 || n_in > h->cfg.max_input_keypoints || min_px_dist < 1) return fail(UVO_E_BADARG, "n_in outside 0..max_input_keypoints / min_px_dist < 1");
+  // Eigen::MatrixXi::Zero((int)(rows / min_px_dist) + 2, (int)(cols / min_px_dist) + 2): src/Tracking.cc:896
+  const int grid_rows = height / min_px_dist + 2, grid_cols = width / min_px_dist + 2;
+  int32_t nin = n_in, nfn = num_feats_needed, nout = 0;
+  int rc = extract_batch_impl(h, 1, img, width, height, stride, (ptrdiff_t)stride * height, in_kp, &nin, grid2d_out, grid_rows, grid_cols, min_px_dist, 0,
+                              &nfn, out_kp, out_desc, cap, &nout, true);
+  *n_out = nout;
+  return rc;
 }
 
 int uvo_host_alloc(void** ptr, size_t bytes) {
