@@ -1144,3 +1144,64 @@ def test_undistort_points_and_the_fused_track_call(uvo, oracle, synth):
     with pytest.raises(uvo.UvoError):
         k.undistort(uvo.CameraModel.make(0.0, 1.0, 0.0, 0.0, []), pts[:4])
     k.close()
+
+
+def _orbvoc_shaped_vocabulary(rng, k=10, L=6):
+    """The shape of the ORBvoc.txt the reference loads (k = 10, L = 6: 1 111 111 nodes, 10^6 words) with random content: a complete
+    tree in level order, every child a noisy copy (p = 1/8 per bit) of its parent, tf-idf-like weights on the leaves."""
+    sizes = [k ** l for l in range(L + 1)]
+    first = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(first[-1])
+    desc = np.zeros((n, 32), np.uint8)
+    desc[0] = rng.integers(0, 256, 32, dtype=np.uint8)
+    for l in range(1, L + 1):
+        parents = np.repeat(desc[first[l - 1]:first[l]], k, axis=0)
+        m = sizes[l]
+        flips = rng.integers(0, 256, (m, 32), dtype=np.uint8) & rng.integers(0, 256, (m, 32), dtype=np.uint8) & rng.integers(0, 256, (m, 32), dtype=np.uint8)
+        desc[first[l]:first[l + 1]] = parents ^ flips
+    child_start = np.zeros(n + 1, np.int32)
+    inner = int(first[L])
+    child_start[1:inner + 1] = np.arange(1, inner + 1, dtype=np.int64) * k
+    child_start[inner + 1:] = inner * k
+    children = np.arange(1, n, dtype=np.int32)                 # level order: the children of node i are 1 + i*k .. 1 + i*k + k - 1
+    word_id = np.full(n, -1, np.int32)
+    word_id[inner:] = np.arange(n - inner)
+    weight = np.zeros(n)
+    weight[inner:] = rng.uniform(0.5, 12.0, n - inner)
+    return dict(child_start=child_start, children=children, descriptor=desc, word_id=word_id, weight=weight, L=L, weighting=0, normalize=1)
+
+
+def test_bow_transform_and_search_on_a_vocabulary_of_orbvoc_shape(uvo, oracle, synth):
+    """k_bow_descend and SearchByBoW at the memory footprint the reference runs with (Vocabulary/ORBvoc.txt: k = 10, L = 6, ~1.1 M nodes,
+    35 MB of node descriptors), levelsup = 4 as at the call sites (src/FrameKTL.cc:439-446, src/KeyFrame.cc:203-210)."""
+    rng = np.random.default_rng(2027)
+    voc = _orbvoc_shaped_vocabulary(rng)
+    assert len(voc["descriptor"]) == 1111111 and (voc["word_id"] >= 0).sum() == 10 ** 6
+    kp1, de1, kp2, de2, sf = _two_views(uvo, synth, 4600)
+    leaves = voc["descriptor"][-10 ** 6:]
+    near = leaves[rng.integers(0, 10 ** 6, 600)] ^ (rng.integers(0, 256, (600, 32), dtype=np.uint8) & rng.integers(0, 256, (600, 32), dtype=np.uint8)
+                                                    & rng.integers(0, 256, (600, 32), dtype=np.uint8) & rng.integers(0, 256, (600, 32), dtype=np.uint8))
+    V = uvo.ORBVocabulary(voc["child_start"], voc["children"], voc["descriptor"], voc["word_id"], voc["weight"], voc["L"], 0, 1)
+    for feats, levelsup in ((np.concatenate([de1, near]), 4), (de2, 4), (near, 2)):
+        g = V.transform(feats, levelsup)
+        o = oracle.bow_transform(voc, feats, levelsup)
+        np.testing.assert_array_equal(g[0], o[0])                                        # word ids
+        np.testing.assert_array_equal(g[1].view(np.uint64), o[1].view(np.uint64))        # word weights
+        np.testing.assert_array_equal(g[2], o[2])                                        # node ids at levelsup
+        np.testing.assert_array_equal(g[3][0], o[3][0])
+        np.testing.assert_array_equal(g[3][1].view(np.uint64), o[3][1].view(np.uint64))  # BowVector values bit for bit
+        fvg = {int(g[4].node[j]): [int(x) for x in g[4].feat[g[4].start[j]:g[4].start[j + 1]]] for j in range(len(g[4].node))}
+        assert fvg == o[4]
+        assert len(set(g[0].tolist())) > 0.5 * len(feats)                                # the descent spreads over the words
+    f1, f2 = V.transform(de1, 4), V.transform(de2, 4)
+    o1, o2 = oracle.bow_transform(voc, de1, 4), oracle.bow_transform(voc, de2, 4)
+    m = uvo.ORBmatcher(0.8, True)
+    usable1 = np.ones(len(de1), np.uint8)
+    for kf_kf in (False, True):
+        mg, ng = m.SearchByBoW(f1[4], de1, kp1["angle"], usable1, f2[4], de2, kp2["angle"], usable2=np.ones(len(de2), np.uint8) if kf_kf else None, kf_kf=kf_kf)
+        mo, no = oracle.search_by_bow(kf_kf, o1[4], de1, kp1["angle"], usable1, o2[4], de2, kp2["angle"], np.ones(len(de2), np.uint8) if kf_kf else None,
+                                      0.8, True)
+        np.testing.assert_array_equal(mg, mo)
+        assert ng == no
+    m.close()
+    V.close()
