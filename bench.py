@@ -531,15 +531,26 @@ def main():
         sf4 = ex4.mvScaleFactor.copy()
         mp = workloads.config4_local_map(kp4, de4, sf4)
         cam = uvo.CameraPose.make(mp["R"], mp["t"], mp["Ow"], workloads.EUROC_FX, workloads.EUROC_FY, workloads.EUROC_CX, workloads.EUROC_CY, (0, 0, W4, H4))
-        ts = []
+        # ... and the host work the reference's tracking thread does between two frames of this configuration: 10 IMU samples (200 Hz
+        # against the 20 Hz camera) through IMUPreintegrator::update (src/IMU/IMUPreintegrator.cpp:81-140, restated in
+        # tools/hoststress/) -- the "IMU-preintegration stress" of configs[4], timed inside the frame
+        imu = workloads.ImuStress()
+        stream = workloads.imu_stream(80)
+        ts, ti = [], []
         for i in range(70):
             t0 = time.perf_counter()
+            pre = imu.preintegrate(stream[i])
+            t1 = time.perf_counter()
             k, d_ = ex4(img4)
             a = np.full(len(k), -1, np.int32)
             nm = m4.SearchPointsInFrustum(k, d_, a, cam, mp["xyz"], mp["normal"], mp["min_distance"], mp["max_distance"], None, mp["mp_desc"], sf4, 1.2, 0.5, 1.0)[0]
             ts.append(time.perf_counter() - t0)
+            ti.append(t1 - t0)
         sub["configs[4] extract + fused frustum search"] = {"ms_per_frame_median": round(float(np.median(ts[10:])) * 1e3, 4), "matches": int(nm), "keypoints": len(kp4),
-                                                            "map_points": 5000, "note": "752x480, fastTh 7, host buffers in and out"}
+                                                            "map_points": 5000, "imu_samples_per_frame": int(stream.shape[1]),
+                                                            "imu_preintegration_ms_per_frame": round(float(np.median(ti[10:])) * 1e3, 4),
+                                                            "imu_delta_time_s": round(float(pre["delta_time"]), 4),
+                                                            "note": "752x480, fastTh 7, host buffers in and out; the frame time includes the 10 host-side IMU updates"}
         cam_o = np.concatenate([mp["R"].reshape(9), mp["t"], mp["Ow"], np.float32([workloads.EUROC_FX, workloads.EUROC_FY, workloads.EUROC_CX, workloads.EUROC_CY]),
                                 np.float32([0, W4, 0, H4])]).astype(np.float32)
         c4_cpu = (kp4, de4, sf4, mp, cam_o)

@@ -47,34 +47,34 @@ def main():
     ex.close()
     del d
     # ---- configs[4] ----
-    W, H = 752, 480
-    rng = np.random.default_rng(7)
+    workloads = importlib.import_module("u-vip-slam_amd.workloads")
+    W, H = workloads.EUROC_W, workloads.EUROC_H
     img = synth.make_frame(31337, W, H)
     ex = uvo.ORBextractor(1000, 1.2, 8, 0, 7, max_width=W, max_height=H)
     m = uvo.ORBmatcher(0.8, max_query=4096, max_map_points=8192)
     kp, de = ex(img)
     sf = ex.mvScaleFactor.copy()
-    n, M = len(kp), 5000
-    fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375
-    R, t, Ow = np.eye(3, dtype=np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)
-    src = rng.integers(0, n, M)
-    z = rng.uniform(2, 12, M)
-    xyz = np.stack([(kp["x"][src] - cx) / fx * z, (kp["y"][src] - cy) / fy * z, z], 1).astype(np.float32)
-    nrm = (xyz / np.linalg.norm(xyz, axis=1, keepdims=True)).astype(np.float32)
-    dist = np.linalg.norm(xyz, axis=1)
-    mxd = (dist * sf[kp["octave"][src]]).astype(np.float32)
-    mnd = (mxd / sf[7]).astype(np.float32)
-    mp_desc = de[src].copy()
-    flip = rng.random((M, 256)) < 0.06
-    mp_desc = np.packbits(np.unpackbits(mp_desc, axis=1) ^ flip, axis=1)
-    cam = uvo.CameraPose.make(R, t, Ow, fx, fy, cx, cy, (0, 0, W, H))
+    n = len(kp)
+    mp = workloads.config4_local_map(kp, de, sf)
+    xyz, nrm, mnd, mxd, mp_desc = mp["xyz"], mp["normal"], mp["min_distance"], mp["max_distance"], mp["mp_desc"]
+    cam = uvo.CameraPose.make(mp["R"], mp["t"], mp["Ow"], workloads.EUROC_FX, workloads.EUROC_FY, workloads.EUROC_CX, workloads.EUROC_CY, (0, 0, W, H))
+    imu = workloads.ImuStress()
+    stream = workloads.imu_stream(64)
+    counter = [0]
+
+    def imu_step():   # the host work between two frames: 10 samples through the restated IMUPreintegrator::update
+        counter[0] += 1
+        return imu.preintegrate(stream[counter[0] % len(stream)])
+
     def frame_two_calls():
+        imu_step()
         k, d_ = ex(img)
         valid, u, v, level, vc = m.project_points(uvo.PROJECT_FRUSTUM, cam, xyz, nrm, mnd, mxd, None, sf, 1.2, 0.5)
         a = np.full(len(k), -1, np.int32)
         return m.SearchByProjection(k, d_, (0, 0, W, H), a, u, v, level, vc, valid, mp_desc, sf, 1.0)
 
     def frame_fused():
+        imu_step()
         k, d_ = ex(img)
         a = np.full(len(k), -1, np.int32)
         return m.SearchPointsInFrustum(k, d_, a, cam, xyz, nrm, mnd, mxd, None, mp_desc, sf, 1.2, 0.5, 1.0)[0]
@@ -91,6 +91,7 @@ def main():
         res[name] = {"ms_per_frame_median": round(float(np.median(ts)), 3), "ms_p95": round(float(np.percentile(ts, 95)), 3), "matches": int(nm)}
     assert res["two_calls"]["matches"] == res["fused"]["matches"]
     res["keypoints"] = int(n)
+    res["imu"] = "10 IMU samples per frame through the restated IMUPreintegrator::update on the host, inside the frame time"
     res["note"] = "fused = uvo_search_points_in_frustum (Tracking::SearchReferencePointsInFrustum as one call); two_calls = uvo_project_points + uvo_search_by_projection"
     out["configs[4]: 752x480 extract + isInFrustum + SearchByProjection vs 5000 map points (host buffers in/out)"] = res
     print(json.dumps(out, indent=1))

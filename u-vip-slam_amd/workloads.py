@@ -39,3 +39,28 @@ def imu_stream(n_frames, rate_hz=200, frame_hz=20, seed=11):
     a = np.stack([0.5 * np.cos(0.9 * tt), 0.4 * np.sin(0.6 * tt), 9.81 + 0.2 * np.sin(1.1 * tt)], 1) + rng.normal(0, 0.02, (len(tt), 3))
     dt = np.full((len(tt), 1), 1.0 / rate_hz)
     return np.concatenate([w, a, dt], 1).reshape(n_frames, per, 7)
+
+
+class ImuStress:
+    """The restated IMUPreintegrator::update (tools/hoststress/imu_preintegrator.cpp; src/IMU/IMUPreintegrator.cpp:81-140) behind ctypes:
+    the host work the reference's tracking thread does between frames in configs[4]."""
+
+    def __init__(self):
+        import ctypes
+        import os
+        import subprocess
+        here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "hoststress")
+        lib = os.path.join(here, "libimu_stress.so")
+        src = os.path.join(here, "imu_preintegrator.cpp")
+        if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+            subprocess.check_call(["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", lib, src])
+        self._L = ctypes.CDLL(lib)
+        self._L.imu_preintegrate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+        self._L.imu_preintegrate.restype = None
+
+    def preintegrate(self, samples, reset_every=0, gyr_cov=(1.6968e-4) ** 2 * 200, acc_cov=(2.0e-3) ** 2 * 200):
+        """samples (n, 7) float64 [wx wy wz ax ay az dt] -> dict(delta_P, delta_V, delta_R, delta_time, cov_trace)"""
+        s = np.ascontiguousarray(samples, np.float64).reshape(-1, 7)
+        out = np.zeros(17)
+        self._L.imu_preintegrate(s.ctypes.data, len(s), int(reset_every), float(gyr_cov), float(acc_cov), out.ctypes.data)
+        return dict(delta_P=out[:3].copy(), delta_V=out[3:6].copy(), delta_R=out[6:15].reshape(3, 3).copy(), delta_time=out[15], cov_trace=out[16])
