@@ -1,16 +1,23 @@
-# per-round profile collection (run through gpurun): kernel-trace stats, then the PMC counters in separate passes
+# per-round profile collection (run through gpurun): kernel-trace stats of the default bench command, then the PMC counters in
+# separate passes (gpurun refuses --pmc combined with other trace domains).
+#   bash tools/profile_round.sh <tag, e.g. r02_a> [config: 2 | 3]
+TAG=${1:-r02_a}
+CFG=${2:-2}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_f -o kt -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_f_bench.json 2> gpurun_out/prof_f.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_a -- python3 bench.py --steps 2 --warmup 1 > /dev/null 2> gpurun_out/pmc_a.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_b -- python3 bench.py --steps 2 --warmup 1 > /dev/null 2> gpurun_out/pmc_b.err
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/pmc_c -- python3 bench.py --steps 2 --warmup 1 > /dev/null 2> gpurun_out/pmc_c.err
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 --output-format csv -d $R/gpurun_out/pmc_d -- python3 bench.py --steps 2 --warmup 1 > /dev/null 2> gpurun_out/pmc_d.err
-python3 tools/pmc_summary.py gpurun_out/pmc_a gpurun_out/pmc_b gpurun_out/pmc_c gpurun_out/pmc_d > gpurun_out/pmc_summary.json
-find gpurun_out/prof_f -name "*kernel_stats.csv" | head -2
-ls gpurun_out/prof_f | head
+O=gpurun_out/$TAG
+mkdir -p $O
+SHORT="--config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-subrecords --no-verify"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kt -o kt -- python3 bench.py --config $CFG --no-cpu-baseline --no-subrecords > $O/bench_under_rocprof.json 2> $O/kt.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_a -- python3 bench.py $SHORT > /dev/null 2> $O/pmc_a.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_b -- python3 bench.py $SHORT > /dev/null 2> $O/pmc_b.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $R/$O/pmc_c -- python3 bench.py $SHORT > /dev/null 2> $O/pmc_c.err
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 --output-format csv -d $R/$O/pmc_d -- python3 bench.py $SHORT > /dev/null 2> $O/pmc_d.err
+python3 tools/pmc_summary.py --config $CFG $O/pmc_a $O/pmc_b $O/pmc_c $O/pmc_d > $O/pmc.json
+find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 # keep the merge small
-find gpurun_out/pmc_a gpurun_out/pmc_b gpurun_out/pmc_c gpurun_out/pmc_d -name "*.csv" -size +2M -delete
-find gpurun_out/prof_f -name "*kernel_trace.csv" -size +8M -delete
-tail -2 gpurun_out/prof_f_bench.json | cut -c1-200
+find $O -name "*.csv" -size +2M -delete
+find $O -name "*kernel_trace.csv" -delete
+head -12 $O/kernel_stats.csv
+tail -1 $O/bench_under_rocprof.json | cut -c1-300
