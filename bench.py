@@ -282,8 +282,8 @@ def load_pmc(config, dom):
         if not e:
             continue
         traffic = int((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024) if "FETCH_SIZE" in e and "WRITE_SIZE" in e else None
-        return traffic, e.get("SQ_INSTS_VALU"), "profiles/" + os.path.basename(path)
-    return None, None, None
+        return traffic, e.get("SQ_INSTS_VALU"), j.get("_frames_per_launch"), "profiles/" + os.path.basename(path)
+    return None, None, None, None
 
 
 def main():
@@ -308,17 +308,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # UVO_BENCH_DRYRUN_ONE_GPU=1 (builder's dry run of the N-rank logic on a one-GPU box): every rank uses device 0 and the barrier /
+    # max-over-ranks go through gloo (RCCL refuses two ranks on one device).  Never set by the driver.
+    dry = os.environ.get("UVO_BENCH_DRYRUN_ONE_GPU") == "1"
+    if dry:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     uvo = importlib.import_module("u-vip-slam_amd")
     synth = importlib.import_module("u-vip-slam_amd.synth")
     workloads = importlib.import_module("u-vip-slam_amd.workloads")
     dev = torch.device("cuda", local_rank)
+    red_dev = None if dry else dev   # where the tensors of the barrier-side reductions live (gloo: host)
 
     # this rank's shard of the global sequence + the neighbour's first frame, in page-locked host memory (the host-to-host leg uploads
     # from here); slot B of the device copy is the halo
@@ -396,7 +405,7 @@ def main():
         mt.profile(True)
     else:
         ex.profile(True, only=dom)
-    dt = timed_steps(step, sync_all, steps, dist, dev)
+    dt = timed_steps(step, sync_all, steps, dist, red_dev)
     ktimes = dict(ex.kernel_times())
     ktimes.update(mt.kernel_times())
     ex.profile(False)
@@ -461,7 +470,7 @@ def main():
         for _ in range(2):
             h2h_run()
         reps = max(4, min(20, steps // 5))
-        dth = timed_steps(h2h_run, lambda: None, reps, dist, dev)
+        dth = timed_steps(h2h_run, lambda: None, reps, dist, red_dev)
         # the gathered region must hold exactly what the HBM-resident leg produced (this rank's block; pair B-1 only where the halo
         # is the true next frame)
         hb = host[0]
@@ -474,7 +483,7 @@ def main():
             nq = int(hb["n"][p])
             ok = ok and (g_i0[first + p, :nq] == hb["i0"][p, :nq]).all() and (g_d0[first + p, :nq] == hb["d0"][p, :nq]).all() and \
                 (g_i1[first + p, :nq] == hb["i1"][p, :nq]).all() and (g_d1[first + p, :nq] == hb["d1"][p, :nq]).all()
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev if red_dev is not None else "cpu")
         if dist is not None:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) != 1:
@@ -570,7 +579,10 @@ def main():
         bytes_per_launch = alg.get(dom, 0) * (B + 1) / launches_per_step
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         total_alg = sum(v for kname, v in alg.items() if kname not in ("k_pad_level0", "k_fast_blur"))
-        traffic, valu_instr, pmc_src = load_pmc(args.config, dom)
+        traffic, valu_instr, pmc_frames, pmc_src = load_pmc(args.config, dom)
+        if pmc_frames and pmc_frames != B + 1:   # the counters were taken at the config's default batch: per-launch figures scale with the frames
+            traffic = int(traffic * (B + 1) / pmc_frames) if traffic else traffic
+            valu_instr = valu_instr * (B + 1) / pmc_frames if valu_instr else valu_instr
         hbm_frac = achieved / HBM_PEAK_GBS
         roof_hbm = {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 5),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch), "measured_device_copy_GBps": sub.get("device_copy_GBps")}

@@ -41,7 +41,8 @@ def main():
     note = ("rocprofv3 --pmc, separate passes (FETCH_SIZE / WRITE_SIZE / SQ_*), mean per launch over bench.py --config %d --steps 2 --warmup 1; "
             "FETCH_SIZE and WRITE_SIZE in KB as reported -- on gfx950 FETCH_SIZE under-reports reads by 2x (MI355X_MICROARCH.md), so HBM read "
             "bytes ~= 2 * FETCH_SIZE_KB * 1024; k_resize_level is the mean over its 7 launches per step; collected with tools/profile_round.sh" % config)
-    print(json.dumps({"_note": note, "_config": config, "kernels": out}, indent=1))
+    frames = {2: 257, 3: 129}.get(config)   # bench.py's default batch of the config + its halo frame
+    print(json.dumps({"_note": note, "_config": config, "_frames_per_launch": frames, "kernels": out}, indent=1))
 
 
 if __name__ == "__main__":
