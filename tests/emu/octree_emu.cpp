@@ -30,6 +30,7 @@ extern "C" int emu_octree_algo(const uint32_t* cand_xy, const uint32_t* cand_sco
   std::vector<int32_t> procRank(M);
   std::vector<int> sc(16, 0);
   std::vector<uint32_t> pstate(P), pyr(pyramid_words(pr.nIni) + 1);
+  std::vector<uint16_t> tab(12 * (size_t)M);  // as on the device: 24 * M bytes
   std::vector<int> stat(16, 0);
   Work w;
   w.boxA = boxA.data(), w.boxB = boxB.data(), w.cntA = cntA.data(), w.cntB = cntB.data(), w.procRank = procRank.data();
@@ -38,6 +39,7 @@ extern "C" int emu_octree_algo(const uint32_t* cand_xy, const uint32_t* cand_sco
   w.nodeOfRank = nodeOfRank.data(), w.baseOfRank = baseOfRank.data(), w.sortbuf = sortbuf.data();
   w.outKey = outKey.data(), w.outPt = outPt.data(), w.part = part.data(), w.sc = sc.data();
   w.pyr = pyr.data(), w.stat = stat.data();
+  w.tab = tab.data(), w.tab_cap = (int)tab.size();
   if (k_regs < 0) k_regs = P <= 8 * OCT_THREADS ? 8 : (P <= 32 * OCT_THREADS ? 32 : 0);
   if (k_regs > 0 && P > k_regs * OCT_THREADS) return -1;
   int n = -1;

@@ -84,16 +84,17 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
     if (flag_lds)
       for (int i = threadIdx.x; i < n_flags; i += NT) s_flag[i] = hi[i];
     __syncthreads();
-    for (int i0 = 0; i0 < n_lo; i0 += 4 * NT) {
-      uint32_t e[4];
-      bool emit[4];
+    constexpr int LU = 8;  // low-list words in flight per thread
+    for (int i0 = 0; i0 < n_lo; i0 += LU * NT) {
+      uint32_t e[LU];
+      bool emit[LU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < LU; ++u) {
         const int i = i0 + u * NT + (int)threadIdx.x;
         e[u] = i < n_lo ? cand_lo[co + i] : 0u;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < LU; ++u) {
         const int i = i0 + u * NT + (int)threadIdx.x;
         emit[u] = false;
         if (i < n_lo) {
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < LU; ++u) {
         const uint64_t m = __ballot(emit[u]);
         if (m == 0) continue;
         int slot = 0;
@@ -165,6 +166,9 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
   w.sortbuf = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mp2max;
   w.part = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * 32;
   w.sc = reinterpret_cast<int*>(p), p += (size_t)4 * 16;
+  // path tables of the closed form: the bytes of ccnt / ccnt2 behind the first 2 * Mmax words (`best` lives in front of them)
+  w.tab = reinterpret_cast<uint16_t*>(w.ccnt + 2 * Mmax);
+  w.tab_cap = 12 * Mmax;  // 24 * Mmax bytes of 2-byte entries
 
   const int64_t so = (int64_t)f * sel_block + g.sel_off;
   // First the closed form over the count pyramid (no pass over the candidates per generation, no per-candidate state).  Trees deeper

@@ -126,6 +126,8 @@ struct Work {
   // count pyramid of the closed-form path (octree_pyramid.hpp)
   uint32_t* pyr;         // [pyramid_words(nIni)]
   int* stat;             // [16]
+  uint16_t* tab;         // path tables of the closed-form path (x part, then y part), tab_cap entries; on the device they share the
+  int tab_cap;           // bytes of ccnt / ccnt2 behind the first 2M words (free whenever the tables are live)
 };
 
 enum { SC_NA = 0, SC_NOUT, SC_NEXP, SC_NPROC, SC_T, SC_NTOEXP, SC_M, SC_TMP };

@@ -59,6 +59,37 @@ OCT_FN uint32_t path_tbin(const Params& pr, int G, uint32_t xy) {
   return b;
 }
 
+// The path is separable: the x splits of DivideNode depend on x (and the root, itself a function of x) only, the y splits on y only
+// (every root spans the full height).  xs[x] = root and the x bits of the T bin, ys[y] = its y bits: tbin = xs[x] | ys[y].  Building
+// the two tables costs the path arithmetic once per column and row (W + H of them) instead of once per candidate and pass.
+OCT_FN uint32_t path_xbits(const Params& pr, int G, int x) {
+  const int r = (int)((float)x / pr.hX);
+  int ulx = (int)(pr.hX * (float)r), urx = (int)(pr.hX * (float)(r + 1));
+  uint32_t b = (uint32_t)r;
+#pragma unroll
+  for (int k = 1; k <= PYR_MAX_DEPTH; ++k) {
+    if (k > G) break;
+    const int mx = ulx + half_ceil(urx - ulx);
+    const int dx = x >= mx ? 1 : 0;
+    ulx = dx ? mx : ulx, urx = dx ? urx : mx;
+    b = b * 4u + (uint32_t)((k & 1) == 0 ? 1 - dx : dx);
+  }
+  return b;
+}
+OCT_FN uint32_t path_ybits(const Params& pr, int G, int y) {
+  int uly = 0, bry = pr.H;
+  uint32_t b = 0;
+#pragma unroll
+  for (int k = 1; k <= PYR_MAX_DEPTH; ++k) {
+    if (k > G) break;
+    const int my = uly + half_ceil(bry - uly);
+    const int dy = y >= my ? 1 : 0;
+    uly = dy ? my : uly, bry = dy ? bry : my;
+    b = b * 4u + 2u * (uint32_t)((k & 1) == 0 ? 1 - dy : dy);
+  }
+  return b;
+}
+
 // adds a wave's worth of predicate counts to an LDS counter with one atomic per wavefront (host emulation: a plain add)
 OCT_FN void stat_add(int* dst, bool pred) {
 #if OCT_DEVICE
@@ -93,16 +124,34 @@ OCT_FN int run_pyramid(const Params& pr, const Work& w, const uint32_t* cand_xy,
   uint32_t* keys_in = reinterpret_cast<uint32_t*>(w.procRank);  // expandable nodes of the next careful round: (0xFFFFF - count) << 12 | position
   uint32_t* Acur = w.cntA;   // careful-born generation: bin of the node at a list position
   uint32_t* Anext = w.cntB;
+  // tables pay when there are clearly more candidates than columns + rows, and need room
+  const bool use_tab = w.tab != nullptr && pr.W + pr.H <= w.tab_cap && P > 2 * (pr.W + pr.H);
+  uint16_t* xs = w.tab;
+  uint16_t* ys = w.tab + pr.W;
+  auto tbin_of = [&](uint32_t xy) -> uint32_t {
+    return use_tab ? ((uint32_t)xs[xy & 0xffff] | (uint32_t)ys[xy >> 16]) : path_tbin(pr, G, xy);
+  };
 
   // ---- histogram of the depth-G prefixes ----
   OCT_PHASE_BEGIN
   for (int i = tid; i < total; i += OCT_NT) pyr[i] = 0;
   if (tid < 16) stat[tid] = 0;
   if (tid == 0) sc[SC_NOUT] = 0, sc[SC_NA] = 0;
+  if (use_tab) {
+    for (int x = tid; x < pr.W; x += OCT_NT) xs[x] = (uint16_t)path_xbits(pr, G, x);
+    for (int y = tid; y < pr.H; y += OCT_NT) ys[y] = (uint16_t)path_ybits(pr, G, y);
+  }
   OCT_PHASE_END
   OCT_PHASE_BEGIN
-#pragma unroll 4
-  for (int p = tid; p < P; p += OCT_NT) OCT_ATOMIC_ADD(&pyr[base[G] + (int)path_tbin(pr, G, cand_xy[p])], 1u);
+  // (the candidates are read eight at a time: the pass is bound by the latency of these loads, not by arithmetic)
+  for (int p0 = tid; p0 < P; p0 += 8 * OCT_NT) {
+    uint32_t xy[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xy[u] = p0 + u * OCT_NT < P ? cand_xy[p0 + u * OCT_NT] : 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (p0 + u * OCT_NT < P) OCT_ATOMIC_ADD(&pyr[base[G] + (int)tbin_of(xy[u])], 1u);
+  }
   OCT_PHASE_END
   // ---- counts of the shallower nodes: sums of four, two levels per phase ----
   for (int g = G; g > 0;) {
@@ -291,27 +340,43 @@ OCT_FN int run_pyramid(const Params& pr, const Work& w, const uint32_t* cand_xy,
     best[i] = 0;
   }
   OCT_PHASE_END
+  if (use_tab) {  // the sorts above went through the tables' bytes: build them again (the sort buffer is dead now)
+    OCT_PHASE_BEGIN
+    for (int x = tid; x < pr.W; x += OCT_NT) xs[x] = (uint16_t)path_xbits(pr, G, x);
+    for (int y = tid; y < pr.H; y += OCT_NT) ys[y] = (uint16_t)path_ybits(pr, G, y);
+    OCT_PHASE_END
+  }
   // ---- per final node the best response, first in candidate order on ties (:1208-1226).  The candidate order of the reference
   //      (cell-major, raster inside a cell) is unique per candidate and invertible, so the winner's coordinates come back out of the
   //      word that won: (score << 32) | ~order ----
   OCT_PHASE_BEGIN
-#pragma unroll 4
-  for (int p = tid; p < P; p += OCT_NT) {
-    const uint32_t xy = cand_xy[p];
-    const uint32_t tb = path_tbin(pr, G, xy);
-    uint32_t slot = 0xFFFFFFFFu;
+  for (int p0 = tid; p0 < P; p0 += 8 * OCT_NT) {
+    uint32_t xys[8], scs[8];
 #pragma unroll
-    for (int d = PYR_MAX_DEPTH; d >= 0; --d) {  // a path crosses exactly one final node; deepest first so that the shallowest wins
-      if (d > G) continue;
-      const uint32_t v = pyr[base[d] + (int)(tb >> (2 * (G - d)))];
-      if (v & PYR_FINAL) slot = v & 0x7FFFFFFFu;
+    for (int u = 0; u < 8; ++u) {
+      const bool in = p0 + u * OCT_NT < P;
+      xys[u] = in ? cand_xy[p0 + u * OCT_NT] : 0u;
+      scs[u] = in ? cand_score[p0 + u * OCT_NT] : 0u;
     }
-    const int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
-    int j = (x - 3) / pr.wCell, i = (y - 3) / pr.hCell;
-    j = j > pr.nCols - 1 ? pr.nCols - 1 : j;
-    i = i > pr.nRows - 1 ? pr.nRows - 1 : i;
-    const uint32_t ord = ((uint32_t)(i * pr.nCols + j) * 128u + (uint32_t)(y - i * pr.hCell)) * 128u + (uint32_t)(x - j * pr.wCell);
-    if (slot != 0xFFFFFFFFu) OCT_ATOMIC_MAX64(&best[slot], ((uint64_t)cand_score[p] << 32) | (uint64_t)(0xFFFFFFFFu - ord));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (p0 + u * OCT_NT >= P) continue;
+      const uint32_t xy = xys[u];
+      const uint32_t tb = tbin_of(xy);
+      uint32_t slot = 0xFFFFFFFFu;
+#pragma unroll
+      for (int d = PYR_MAX_DEPTH; d >= 0; --d) {  // a path crosses exactly one final node; deepest first so that the shallowest wins
+        if (d > G) continue;
+        const uint32_t v = pyr[base[d] + (int)(tb >> (2 * (G - d)))];
+        if (v & PYR_FINAL) slot = v & 0x7FFFFFFFu;
+      }
+      const int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
+      int j = (x - 3) / pr.wCell, i = (y - 3) / pr.hCell;
+      j = j > pr.nCols - 1 ? pr.nCols - 1 : j;
+      i = i > pr.nRows - 1 ? pr.nRows - 1 : i;
+      const uint32_t ord = ((uint32_t)(i * pr.nCols + j) * 128u + (uint32_t)(y - i * pr.hCell)) * 128u + (uint32_t)(x - j * pr.wCell);
+      if (slot != 0xFFFFFFFFu) OCT_ATOMIC_MAX64(&best[slot], ((uint64_t)scs[u] << 32) | (uint64_t)(0xFFFFFFFFu - ord));
+    }
   }
   OCT_PHASE_END
   OCT_PHASE_BEGIN
