@@ -446,7 +446,7 @@ def main():
     h2h = None
     if not args.no_subrecords:
         total = world * B
-        chunk = max(B // 2, 1)            # two chunks per rank in flight: the upload of one under the kernels of the other
+        chunk = max(B // int(os.environ.get("UVO_BENCH_CHUNKS", "4")), 1)   # chunks per rank and job, two in flight: the upload of one under the kernels of the other
         devices = [uvo.UVO_SHARD_REMOTE] * world
         devices[rank] = local_rank
         sh = uvo.Sharder(NFEAT, SCALE, NLEVELS, FAST_TH, max_width=W, max_height=H, devices=devices, chunk_frames=chunk, match=True)
@@ -455,22 +455,39 @@ def main():
         sizes = [((total, scap), uvo.KEYPOINT_DTYPE), ((total, scap, 32), np.uint8), ((total,), np.int32), ((total, scap), np.int32),
                  ((total, scap), np.uint16), ((total, scap), np.int32), ((total, scap), np.uint16)]
         nbytes = sum(int(np.prod(s)) * np.dtype(t).itemsize + 256 for s, t in sizes)
-        region = SharedHostRegion(uvo, nbytes, rank, world, dist)
-        arrs, off = [], 0
-        for s, t in sizes:
-            a, off = region.carve(off, s, t)
-            arrs.append(a)
-        g_kp, g_de, g_n, g_i0, g_d0, g_i1, g_d1 = arrs
+        # two gather regions: a stream of jobs keeps two in flight (job k+1 is submitted before job k is waited for), each gathers into its own
+        region = SharedHostRegion(uvo, 2 * nbytes, rank, world, dist)
+        sets, off = [], 0
+        for _ in range(2):
+            arrs = []
+            for s, t in sizes:
+                a, off = region.carve(off, s, t)
+                arrs.append(a)
+            sets.append(arrs)
+        g_kp, g_de, g_n, g_i0, g_d0, g_i1, g_d1 = sets[0]
+        jobs = [0]
+        pending = [None]
 
         def h2h_run():
             # frames of this rank start at global index `first`; its halo frame sits right behind them in `frames` (for the last
-            # rank the job simply ends there: the wrap-around pair exists only in the HBM-resident leg)
-            sh.run(frames, first, total, g_kp, g_de, g_n, g_i0, g_d0, g_i1, g_d1)
+            # rank the job simply ends there: the wrap-around pair exists only in the HBM-resident leg).  One call = one job submitted;
+            # the job before it is waited for afterwards, so two are in flight and the lanes never drain.
+            t = sh.submit(frames, first, total, *sets[jobs[0] % 2])
+            jobs[0] += 1
+            if pending[0] is not None:
+                sh.wait(pending[0])
+            pending[0] = t
 
-        for _ in range(2):
+        def h2h_drain():
+            if pending[0] is not None:
+                sh.wait(pending[0])
+                pending[0] = None
+
+        for _ in range(3):
             h2h_run()
-        reps = max(4, min(20, steps // 5))
-        dth = timed_steps(h2h_run, lambda: None, reps, dist, red_dev)
+        h2h_drain()
+        reps = max(6, min(30, steps // 4))
+        dth = timed_steps(h2h_run, h2h_drain, reps, dist, red_dev)
         # the gathered region must hold exactly what the HBM-resident leg produced (this rank's block; pair B-1 only where the halo
         # is the true next frame)
         hb = host[0]
@@ -493,7 +510,7 @@ def main():
         up = B * W * H + (W * H if first + B < total else 0)
         down = B * scap * (28 + 32) + B * 4 + npairs * scap * 12
         h2h = {"value": round(total * reps / dth, 1), "unit": "frames/s", "ms_per_job": round(dth / reps * 1e3, 3), "frames_per_job": total,
-               "chunk_frames": chunk, "pcie_bytes_up_per_rank": up, "pcie_bytes_down_per_rank": down, "gather": "device-to-host copies at precomputed "
+               "chunk_frames": chunk, "jobs_in_flight": 2, "pcie_bytes_up_per_rank": up, "pcie_bytes_down_per_rank": down, "gather": "device-to-host copies at precomputed "
                "offsets of one page-locked region shared by all ranks (%s)" % ("uvo_host_alloc" if world == 1 else "/dev/shm mapping + uvo_host_register" +
                                                                                   ("" if region.registered else " [registration failed: pageable]")),
                "gathered_equals_hbm_resident": True}

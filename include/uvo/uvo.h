@@ -165,13 +165,21 @@ int uvo_sharder_create(const uvo_sharder_cfg* cfg, uvo_sharder** out);
 void uvo_sharder_destroy(uvo_sharder* s);
 int uvo_sharder_max_keypoints(const uvo_sharder* s); /* smallest `cap` uvo_sharder_run accepts */
 /*
- * Run the local shards of a job (blocks until their results are in the output arrays).
+ * Run the local shards of a job.  uvo_sharder_submit() queues the job for the shard threads and returns a ticket at once,
+ * uvo_sharder_wait() blocks until the job's results are in the output arrays; uvo_sharder_run() is the two together.  Jobs run in
+ * submission order and the lanes are not drained between them: with a second job submitted before the first is waited for, the
+ * uploads of one run under the kernels of the other (a stream of jobs moves at the steady-state rate of the pipeline lanes).
  *   imgs             : host frames, frame g at imgs + (g - imgs_first_frame) * frame_stride (a process that owns only some shards
  *                      need only hold their frames and each block's halo frame); page-locked memory makes the uploads asynchronous
  *   out_kp / out_desc / n_out : [total][cap] / [total][cap][32] / [total]   (cap >= uvo_sharder_max_keypoints())
  *   idx0 / d0 / idx1 / d1     : [total - 1][cap] knn-2 rows of pair p (row q = keypoint q of frame p; as uvo_hamming_knn2), or all NULL
- * Only the elements of the local shards' frames / pairs are written.
+ * Only the elements of the local shards' frames / pairs are written.  All buffers of a job must stay valid and untouched until its
+ * wait returns; jobs in flight at the same time need their own output arrays.
  */
+int uvo_sharder_submit(uvo_sharder* s, const uint8_t* imgs, int imgs_first_frame, int total_frames, int width, int height, ptrdiff_t stride,
+                       ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int32_t* idx0, uint16_t* d0,
+                       int32_t* idx1, uint16_t* d1, int* ticket);
+int uvo_sharder_wait(uvo_sharder* s, int ticket);
 int uvo_sharder_run(uvo_sharder* s, const uint8_t* imgs, int imgs_first_frame, int total_frames, int width, int height, ptrdiff_t stride,
                     ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int32_t* idx0, uint16_t* d0,
                     int32_t* idx1, uint16_t* d1);

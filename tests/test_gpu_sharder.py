@@ -66,6 +66,27 @@ def test_shards_on_one_device_gather_the_single_handle_result(uvo, job, n_shards
     sh.close()
 
 
+def test_jobs_stream_through_the_lanes_without_draining(uvo, job):
+    """uvo_sharder_submit / _wait: three jobs queued back to back (different output arrays, different frame ranges of the same
+    sequence), waited for in order; a ticket cannot be waited for twice."""
+    frames, (ref, rows) = job
+    total = len(frames)
+    sh = uvo.Sharder(NFEAT, 1.2, 6, 20, max_width=W, max_height=H, devices=[0, 0], chunk_frames=6, match=True)
+    spans = [(0, total), (0, 31), (0, 17)]          # a job is always frames [0, n) of what `imgs` holds
+    outs = [_alloc(uvo, n, sh.cap) for _, n in spans]
+    for o in outs:
+        for a in o:
+            a.view(np.uint8)[...] = 0xEE
+    tickets = [sh.submit(frames, 0, n, *o) for (_, n), o in zip(spans, outs)]
+    assert len(set(tickets)) == 3
+    for (_, n), o, t in zip(spans, outs, tickets):
+        sh.wait(t)
+        _check(ref[:n], rows[:n - 1], *o, "streamed job of %d frames" % n)
+    with pytest.raises(uvo.UvoError):
+        sh.wait(tickets[0])
+    sh.close()
+
+
 def test_one_process_per_shard_form_fills_the_same_region(uvo, job):
     """The multi-process form: every sharder owns one shard (the others are UVO_SHARD_REMOTE), all write into the same arrays, and a
     process holds only its own frames + its block's halo frame."""

@@ -27,7 +27,7 @@ UVO_TUNE_OCT_WIDE_MAX = 1
 # every symbol include/uvo/uvo.h declares
 ABI_SYMBOLS = [
     "uvo_extractor_create", "uvo_extractor_destroy", "uvo_extractor_levels", "uvo_extractor_max_keypoints", "uvo_extractor_scale_factor", "uvo_extractor_tables",
-    "uvo_extract", "uvo_extract_tracked", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_host_alloc", "uvo_host_free", "uvo_host_register", "uvo_host_unregister", "uvo_shard_plan_make", "uvo_sharder_create", "uvo_sharder_destroy", "uvo_sharder_max_keypoints", "uvo_sharder_run", "uvo_extract_batch_submit", "uvo_extract_batch_wait", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_tune", "uvo_extractor_level_dims",
+    "uvo_extract", "uvo_extract_tracked", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_host_alloc", "uvo_host_free", "uvo_host_register", "uvo_host_unregister", "uvo_shard_plan_make", "uvo_sharder_create", "uvo_sharder_destroy", "uvo_sharder_max_keypoints", "uvo_sharder_run", "uvo_sharder_submit", "uvo_sharder_wait", "uvo_extract_batch_submit", "uvo_extract_batch_wait", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_tune", "uvo_extractor_level_dims",
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_profile_only", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
@@ -152,6 +152,8 @@ def _load():
     lib.uvo_sharder_destroy.restype = None
     lib.uvo_sharder_max_keypoints.argtypes = [vp]
     lib.uvo_sharder_run.argtypes = [vp, vp, ci, ci, ci, ci, cl, cl, vp, vp, ci, vp, vp, vp, vp, vp]
+    lib.uvo_sharder_submit.argtypes = [vp, vp, ci, ci, ci, ci, cl, cl, vp, vp, ci, vp, vp, vp, vp, vp, vp]
+    lib.uvo_sharder_wait.argtypes = [vp, ci]
     lib.uvo_extract_batch_submit.argtypes = [vp, ci, vp, ci, ci, cl, cl, vp, vp, ci, vp, vp]
     lib.uvo_extract_batch_wait.argtypes = [vp, ci]
     lib.uvo_extractor_synchronize.argtypes = [vp]
@@ -283,10 +285,8 @@ class Sharder:
     def plan(self, total_frames, shard):
         return shard_plan(total_frames, self.n_shards, shard, self.chunk_frames)
 
-    def run(self, imgs, imgs_first_frame, total_frames, out_kp, out_desc, n_out, idx0=None, d0=None, idx1=None, d1=None):
-        """imgs: (n, H, W) uint8 C-contiguous holding frames imgs_first_frame .. ; outputs as uvo_sharder_run documents them."""
+    def _check(self, imgs, total_frames, out_kp, out_desc, n_out, idx0, d0, idx1, d1):
         assert imgs.dtype == np.uint8 and imgs.ndim == 3 and imgs.flags.c_contiguous
-        _, h, w = imgs.shape
         cap = out_kp.shape[1]
         assert out_kp.dtype == KEYPOINT_DTYPE and out_kp.shape[0] >= total_frames and out_kp.flags.c_contiguous
         assert out_desc.dtype == np.uint8 and out_desc.shape[1:] == (cap, 32) and out_desc.flags.c_contiguous
@@ -294,23 +294,28 @@ class Sharder:
         if idx0 is not None:
             for a, dt in ((idx0, np.int32), (idx1, np.int32), (d0, np.uint16), (d1, np.uint16)):
                 assert a.dtype == dt and a.shape[1] == cap and a.shape[0] >= total_frames - 1 and a.flags.c_contiguous
-        rc = lib.uvo_sharder_run(self._h, imgs.ctypes.data, imgs_first_frame, total_frames, w, h, w, w * h, out_kp.ctypes.data, out_desc.ctypes.data, cap,
-                                 n_out.ctypes.data, _ptr(idx0), _ptr(d0), _ptr(idx1), _ptr(d1))
+        return cap
+
+    def submit(self, imgs, imgs_first_frame, total_frames, out_kp, out_desc, n_out, idx0=None, d0=None, idx1=None, d1=None):
+        """uvo_sharder_submit: queue a job, return its ticket at once.  imgs: (n, H, W) uint8 C-contiguous holding frames
+        imgs_first_frame .. ; outputs as uvo_sharder_submit documents them (untouched until wait(ticket) returns)."""
+        cap = self._check(imgs, total_frames, out_kp, out_desc, n_out, idx0, d0, idx1, d1)
+        _, h, w = imgs.shape
+        t = ctypes.c_int()
+        rc = lib.uvo_sharder_submit(self._h, imgs.ctypes.data, imgs_first_frame, total_frames, w, h, w, w * h, out_kp.ctypes.data, out_desc.ctypes.data, cap,
+                                    n_out.ctypes.data, _ptr(idx0), _ptr(d0), _ptr(idx1), _ptr(d1), ctypes.byref(t))
         if rc:
-            raise UvoError(rc, "uvo_sharder_run")
+            raise UvoError(rc, "uvo_sharder_submit")
+        return t.value
 
+    def wait(self, ticket):
+        rc = lib.uvo_sharder_wait(self._h, int(ticket))
+        if rc:
+            raise UvoError(rc, "uvo_sharder_wait")
 
-def host_register(arr):
-    """Page-lock memory the caller owns (uvo_host_register), e.g. a mapping shared between processes."""
-    rc = lib.uvo_host_register(arr.ctypes.data, arr.nbytes)
-    if rc:
-        raise UvoError(rc, "uvo_host_register")
-
-
-def host_unregister(arr):
-    rc = lib.uvo_host_unregister(arr.ctypes.data)
-    if rc:
-        raise UvoError(rc, "uvo_host_unregister")
+    def run(self, imgs, imgs_first_frame, total_frames, out_kp, out_desc, n_out, idx0=None, d0=None, idx1=None, d1=None):
+        """submit + wait."""
+        self.wait(self.submit(imgs, imgs_first_frame, total_frames, out_kp, out_desc, n_out, idx0, d0, idx1, d1))
 
 
 class ORBextractor:

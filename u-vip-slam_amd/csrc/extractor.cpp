@@ -982,6 +982,17 @@ int uvo_extract_batch_submit(uvo_extractor* h, int batch, const uint8_t* imgs, i
                                            nullptr, nullptr);
 }
 
+// 1: the lane's batch has delivered everything (uvo_extract_batch_wait would not block), 0: still running, < 0: error
+int uvo_extract_batch_done_internal(uvo_extractor* h, int ticket) {
+  if (!h || ticket < 0 || ticket >= kMaxLanes || !h->lane[ticket].stream) return fail(UVO_E_BADARG, "bad ticket");
+  if (hipSetDevice(h->device) != hipSuccess) return fail(UVO_E_HIP, "hipSetDevice failed");
+  const hipError_t e = hipStreamQuery(h->lane[ticket].stream);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) return 0;
+  hip_err_set(e, "hipStreamQuery");
+  return UVO_E_HIP;
+}
+
 int uvo_extract_batch_wait(uvo_extractor* h, int ticket) {
   if (!h || ticket < 0 || ticket >= kMaxLanes || !h->lane[ticket].stream) return fail(UVO_E_BADARG, "bad ticket");
   Lane& L = h->lane[ticket];

@@ -7,13 +7,24 @@
 // descriptors: a chunk therefore extracts one frame more than it owns (its halo: the first frame of the next chunk, which at a
 // shard's end belongs to the neighbouring shard) instead of exchanging descriptors between devices; +1/chunk extra work.
 //
+// Every local shard has a persistent host thread with a queue of jobs: uvo_sharder_submit() hands a job to the queues and returns,
+// uvo_sharder_wait() blocks until its results are in host memory, uvo_sharder_run() is the two together.  A shard's thread keeps at
+// most two chunks in flight (one per pipeline lane) and does NOT drain them at the end of a job: the first chunk of the next job is
+// uploaded under the kernels of the last chunk of this one, so a stream of jobs runs at the steady-state rate of the lanes.
+//
 // Shards whose device is UVO_SHARD_REMOTE are owned by another process (one process per GPU under a launcher such as
 // torch.distributed.run): the same plan, the same offsets, each process runs its own shards, and the output arrays are one shared
 // mapping registered with uvo_host_register() in every process.
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <thread>
+#include <string>
 #include <vector>
 
 #include "common.hpp"
@@ -23,6 +34,7 @@ extern "C" int uvo_extract_batch_submit_internal(uvo_extractor* h, int batch, in
                                                   int32_t* n_out, int* ticket, hipEvent_t after_kernels, const uint8_t** d_desc,
                                                   const int32_t** d_n);
 extern "C" hipStream_t uvo_matcher_stream_internal(uvo_matcher* m);
+extern "C" int uvo_extract_batch_done_internal(uvo_extractor* h, int ticket);
 
 using namespace uvo;
 
@@ -37,8 +49,27 @@ struct Shard {
   uint16_t *d_d0[2] = {nullptr, nullptr}, *d_d1[2] = {nullptr, nullptr};
   hipEvent_t kernels_done[2] = {nullptr, nullptr};  // extractor lane: descriptors of the chunk are final
   hipEvent_t rows_sent[2] = {nullptr, nullptr};     // matcher stream: the chunk's rows are on their way to the host
+  std::thread worker;
+};
+
+struct RunArgs {
+  const uint8_t* imgs;
+  int imgs_first_frame, total, width, height;
+  ptrdiff_t stride, frame_stride;
+  uvo_keypoint* out_kp;
+  uint8_t* out_desc;
+  int cap;
+  int32_t* n_out;
+  int32_t *idx0, *idx1;
+  uint16_t *d0, *d1;
+};
+
+struct Job {
+  int id = 0;
+  RunArgs a;
+  int remaining = 0;  // local shards that have not delivered yet
   int rc = UVO_OK;
-  char err[512] = "";
+  std::string err;
 };
 
 }  // namespace
@@ -47,7 +78,17 @@ struct uvo_sharder {
   uvo_sharder_cfg cfg;
   std::vector<Shard> shards;
   int dcap = 0;  // keypoints a frame can return (uvo_extractor_max_keypoints)
+  // job queue shared by the shard threads (every local shard works through the jobs in submission order)
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::deque<std::shared_ptr<Job>> jobs;  // submitted, not yet waited for
+  int next_id = 1;
+  bool stopping = false;
 };
+
+namespace {
+void shard_worker(uvo_sharder* s, int shard_index);
+}
 
 extern "C" {
 
@@ -67,6 +108,13 @@ int uvo_shard_plan_make(int total_frames, int n_shards, int shard, int chunk_fra
 
 void uvo_sharder_destroy(uvo_sharder* s) {
   if (!s) return;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->stopping = true;
+  }
+  s->cv_work.notify_all();
+  for (Shard& sh : s->shards)
+    if (sh.worker.joinable()) sh.worker.join();
   for (Shard& sh : s->shards) {
     if (sh.device == UVO_SHARD_REMOTE) continue;
     (void)hipSetDevice(sh.device);
@@ -141,6 +189,8 @@ int uvo_sharder_create(const uvo_sharder_cfg* cfg, uvo_sharder** out) {
     uvo_sharder_destroy(s);
     return fail(UVO_E_BADARG, "no local shard (every device is UVO_SHARD_REMOTE)");
   }
+  for (int i = 0; i < cfg->n_shards; ++i)
+    if (s->shards[i].device != UVO_SHARD_REMOTE) s->shards[i].worker = std::thread(shard_worker, s, i);
   *out = s;
   return UVO_OK;
 }
@@ -151,120 +201,199 @@ int uvo_sharder_max_keypoints(const uvo_sharder* s) { return s ? s->dcap : fail(
 
 namespace {
 
-struct RunArgs {
-  const uint8_t* imgs;
-  int imgs_first_frame, total, width, height;
-  ptrdiff_t stride, frame_stride;
-  uvo_keypoint* out_kp;
-  uint8_t* out_desc;
-  int cap;
-  int32_t* n_out;
-  int32_t *idx0, *idx1;
-  uint16_t *d0, *d1;
+// A chunk in flight on one of the shard's two lanes.
+struct InFlight {
+  int ticket = -1;
+  std::shared_ptr<Job> job;
+  bool last_of_job = false, match = false;
 };
 
-#define SH_CHECK(expr)                                                                   \
-  do {                                                                                   \
-    int _rc = (expr);                                                                    \
-    if (_rc != UVO_OK) {                                                                 \
-      sh.rc = _rc;                                                                       \
-      snprintf(sh.err, sizeof(sh.err), "shard %d: %s", shard_index, uvo_last_error());   \
-      return;                                                                            \
-    }                                                                                    \
-  } while (0)
-#define SH_HIP(expr)                                                                                            \
-  do {                                                                                                          \
-    hipError_t _e = (expr);                                                                                     \
-    if (_e != hipSuccess) {                                                                                     \
-      sh.rc = UVO_E_HIP;                                                                                        \
-      snprintf(sh.err, sizeof(sh.err), "shard %d: HIP error %d (%s) in %s", shard_index, (int)_e, hipGetErrorString(_e), #expr); \
-      return;                                                                                                   \
-    }                                                                                                           \
-  } while (0)
+void job_delivered(uvo_sharder* s, const std::shared_ptr<Job>& job, int rc, const char* msg) {
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (rc != UVO_OK && job->rc == UVO_OK) job->rc = rc, job->err = msg;
+  if (--job->remaining == 0) s->cv_done.notify_all();
+}
 
-// One shard's block, chunk by chunk through the two lanes.  Runs on the shard's own host thread.
-void run_shard(uvo_sharder* s, int shard_index, const RunArgs& a) {
+// One shard's thread: its block of every job, chunk by chunk through the two lanes.
+void shard_worker(uvo_sharder* s, int shard_index) {
   Shard& sh = s->shards[shard_index];
-  sh.rc = UVO_OK, sh.err[0] = 0;
-  uvo_shard_plan pl;
-  SH_CHECK(uvo_shard_plan_make(a.total, s->cfg.n_shards, shard_index, s->cfg.chunk_frames, &pl));
-  if (pl.n_frames == 0) return;
-  SH_HIP(hipSetDevice(sh.device));
+  (void)hipSetDevice(sh.device);
   const int C = s->cfg.chunk_frames, dcap = s->dcap;
-  const bool match = s->cfg.match != 0 && a.idx0 != nullptr;
-  hipStream_t ms = match ? uvo_matcher_stream_internal(sh.mt) : nullptr;
-  int inflight[2] = {-1, -1};  // tickets, oldest first
-  int n_inflight = 0;
-  auto retire_oldest = [&]() -> int {
-    const int t = inflight[0];
-    int rc = uvo_extract_batch_wait(sh.ex, t);
-    if (rc) return rc;
-    if (match && hipEventSynchronize(sh.rows_sent[t]) != hipSuccess) return fail(UVO_E_HIP, "hipEventSynchronize failed");
-    inflight[0] = inflight[1], inflight[1] = -1, --n_inflight;
-    return UVO_OK;
+  hipStream_t ms = sh.mt ? uvo_matcher_stream_internal(sh.mt) : nullptr;
+  std::deque<InFlight> inflight;           // oldest first, at most two
+  std::shared_ptr<Job> cur;                // the job whose chunks are being submitted
+  int cur_f0 = 0, cur_end = 0;             // next chunk's first frame / end of the shard's block
+  int last_seen = 0;                       // id of the last job taken from the queue
+  bool cur_failed = false;
+  char msg[600];
+  auto retire_oldest = [&]() {
+    InFlight f = inflight.front();
+    inflight.pop_front();
+    int rc = uvo_extract_batch_wait(sh.ex, f.ticket);
+    if (rc == UVO_OK && f.match && hipEventSynchronize(sh.rows_sent[f.ticket]) != hipSuccess) rc = fail(UVO_E_HIP, "hipEventSynchronize failed");
+    if (rc != UVO_OK) {
+      snprintf(msg, sizeof(msg), "shard %d: %s", shard_index, uvo_last_error());
+      std::lock_guard<std::mutex> lk(s->mu);
+      if (f.job->rc == UVO_OK) f.job->rc = rc, f.job->err = msg;
+    }
+    if (f.last_of_job) job_delivered(s, f.job, UVO_OK, "");
   };
-  const int end = pl.first_frame + pl.n_frames;
-  for (int f0 = pl.first_frame; f0 < end; f0 += C) {
-    const int nb = std::min(C, end - f0);               // frames this chunk owns
-    const int ne = nb + (f0 + nb < a.total ? 1 : 0);    // + the halo frame (the next chunk's / the neighbouring shard's first frame)
-    if (n_inflight == 2) SH_CHECK(retire_oldest());     // the lane about to be reused must have delivered its results
-    int t = -1;
+  for (;;) {
+    if (!cur) {  // take the next job, or -- with nothing queued -- finish what is in flight, or sleep
+      std::unique_lock<std::mutex> lk(s->mu);
+      std::shared_ptr<Job> nxt;
+      for (const auto& j : s->jobs)
+        if (j->id > last_seen) {
+          nxt = j;
+          break;
+        }
+      if (!nxt) {
+        if (!inflight.empty()) {
+          // nothing to submit right now: retire the oldest chunk once it has landed, but keep an eye on the queue meanwhile -- the
+          // caller typically submits its next job the moment this one is delivered, and that job must not wait behind the chunk
+          // that is still running on the other lane
+          lk.unlock();
+          const InFlight& f = inflight.front();
+          const int done = uvo_extract_batch_done_internal(sh.ex, f.ticket);
+          const bool rows = !f.match || hipEventQuery(sh.rows_sent[f.ticket]) != hipErrorNotReady;
+          if (done != 0 && rows) {
+            retire_oldest();
+          } else {
+            lk.lock();
+            s->cv_work.wait_for(lk, std::chrono::microseconds(20));
+          }
+          continue;
+        }
+        if (s->stopping) return;
+        s->cv_work.wait(lk);
+        continue;
+      }
+      lk.unlock();
+      last_seen = nxt->id;
+      uvo_shard_plan pl;
+      if (uvo_shard_plan_make(nxt->a.total, s->cfg.n_shards, shard_index, C, &pl) != UVO_OK || pl.n_frames == 0) {
+        job_delivered(s, nxt, UVO_OK, "");  // nothing of this job lives here
+        continue;
+      }
+      cur = nxt, cur_f0 = pl.first_frame, cur_end = pl.first_frame + pl.n_frames, cur_failed = false;
+    }
+    const RunArgs& a = cur->a;
+    const bool match = s->cfg.match != 0 && a.idx0 != nullptr;
+    const int f0 = cur_f0;
+    const int nb = std::min(C, cur_end - f0);               // frames this chunk owns
+    const int ne = nb + (f0 + nb < a.total ? 1 : 0);        // + the halo frame (the next chunk's / the neighbouring shard's first frame)
+    const bool last = f0 + nb >= cur_end;
+    if (inflight.size() == 2) retire_oldest();              // the lane about to be reused must have delivered its results
+    int rc = UVO_OK, t = -1;
     const uint8_t* d_desc = nullptr;
     const int32_t* d_n = nullptr;
-    // both events of a lane are free again: its previous batch was retired above
-    SH_CHECK(uvo_extract_batch_submit_internal(sh.ex, ne, nb, a.imgs + (ptrdiff_t)(f0 - a.imgs_first_frame) * a.frame_stride, a.width, a.height, a.stride,
-                                               a.frame_stride, a.out_kp + (size_t)f0 * a.cap, a.out_desc + (size_t)f0 * a.cap * 32, a.cap, a.n_out + f0,
-                                               &t, nullptr, &d_desc, &d_n));
-    if (match) {
-      const int np = ne - 1;  // pairs (f0 + j, f0 + j + 1)
-      // the matcher reads the lane's descriptors in HBM: order its stream behind the extraction (uvo_matcher_wait_extractor refers to
-      // the lane just submitted to), and the lane's next batch behind the matcher via retire_oldest()
-      SH_CHECK(uvo_matcher_wait_extractor(sh.mt, sh.ex));
-      if (np > 0) {
-        SH_CHECK(uvo_hamming_knn2_batch_device(sh.mt, np, d_desc, d_n, dcap, d_desc + (size_t)dcap * 32, d_n + 1, dcap, sh.d_idx0[t], sh.d_d0[t],
-                                               sh.d_idx1[t], sh.d_d1[t]));
-        const size_t row4 = (size_t)dcap * 4, row2 = (size_t)dcap * 2;
-        SH_HIP(hipMemcpy2DAsync(a.idx0 + (size_t)f0 * a.cap, (size_t)a.cap * 4, sh.d_idx0[t], row4, row4, np, hipMemcpyDeviceToHost, ms));
-        SH_HIP(hipMemcpy2DAsync(a.idx1 + (size_t)f0 * a.cap, (size_t)a.cap * 4, sh.d_idx1[t], row4, row4, np, hipMemcpyDeviceToHost, ms));
-        SH_HIP(hipMemcpy2DAsync(a.d0 + (size_t)f0 * a.cap, (size_t)a.cap * 2, sh.d_d0[t], row2, row2, np, hipMemcpyDeviceToHost, ms));
-        SH_HIP(hipMemcpy2DAsync(a.d1 + (size_t)f0 * a.cap, (size_t)a.cap * 2, sh.d_d1[t], row2, row2, np, hipMemcpyDeviceToHost, ms));
+    if (!cur_failed) {
+      rc = uvo_extract_batch_submit_internal(sh.ex, ne, nb, a.imgs + (ptrdiff_t)(f0 - a.imgs_first_frame) * a.frame_stride, a.width, a.height, a.stride,
+                                             a.frame_stride, a.out_kp + (size_t)f0 * a.cap, a.out_desc + (size_t)f0 * a.cap * 32, a.cap, a.n_out + f0, &t,
+                                             nullptr, &d_desc, &d_n);
+      if (rc == UVO_OK && match) {
+        const int np = ne - 1;  // pairs (f0 + j, f0 + j + 1)
+        // the matcher reads the lane's descriptors in HBM: order its stream behind the extraction (uvo_matcher_wait_extractor refers
+        // to the lane just submitted to); the lane's next batch waits for the matcher through retire_oldest()
+        rc = uvo_matcher_wait_extractor(sh.mt, sh.ex);
+        if (rc == UVO_OK && np > 0) {
+          rc = uvo_hamming_knn2_batch_device(sh.mt, np, d_desc, d_n, dcap, d_desc + (size_t)dcap * 32, d_n + 1, dcap, sh.d_idx0[t], sh.d_d0[t], sh.d_idx1[t],
+                                             sh.d_d1[t]);
+          const size_t row4 = (size_t)dcap * 4, row2 = (size_t)dcap * 2;
+          // (pitched copies on purpose, also when the pitches agree: they overlap the other lane's upload, large linear ones do not)
+          if (rc == UVO_OK &&
+              (hipMemcpy2DAsync(a.idx0 + (size_t)f0 * a.cap, (size_t)a.cap * 4, sh.d_idx0[t], row4, row4, np, hipMemcpyDeviceToHost, ms) != hipSuccess ||
+               hipMemcpy2DAsync(a.idx1 + (size_t)f0 * a.cap, (size_t)a.cap * 4, sh.d_idx1[t], row4, row4, np, hipMemcpyDeviceToHost, ms) != hipSuccess ||
+               hipMemcpy2DAsync(a.d0 + (size_t)f0 * a.cap, (size_t)a.cap * 2, sh.d_d0[t], row2, row2, np, hipMemcpyDeviceToHost, ms) != hipSuccess ||
+               hipMemcpy2DAsync(a.d1 + (size_t)f0 * a.cap, (size_t)a.cap * 2, sh.d_d1[t], row2, row2, np, hipMemcpyDeviceToHost, ms) != hipSuccess))
+            rc = fail(UVO_E_HIP, "copy of the knn-2 rows failed");
+        }
+        if (rc == UVO_OK && hipEventRecord(sh.rows_sent[t], ms) != hipSuccess) rc = fail(UVO_E_HIP, "hipEventRecord failed");
       }
-      SH_HIP(hipEventRecord(sh.rows_sent[t], ms));
+      if (rc != UVO_OK) {
+        snprintf(msg, sizeof(msg), "shard %d: %s", shard_index, uvo_last_error());
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (cur->rc == UVO_OK) cur->rc = rc, cur->err = msg;
+        cur_failed = true;
+      }
     }
-    inflight[n_inflight++] = t;
+    if (t >= 0) {
+      InFlight f;
+      f.ticket = t, f.job = cur, f.last_of_job = last, f.match = match && !cur_failed;
+      inflight.push_back(f);
+    } else if (last) {  // (error path) nothing in flight carries the job's end: let what is in flight land first
+      while (!inflight.empty()) retire_oldest();
+      job_delivered(s, cur, UVO_OK, "");
+    }
+    cur_f0 += nb;
+    if (last) cur.reset();
   }
-  while (n_inflight > 0) SH_CHECK(retire_oldest());
 }
 
 }  // namespace
 
 extern "C" {
 
-int uvo_sharder_run(uvo_sharder* s, const uint8_t* imgs, int imgs_first_frame, int total_frames, int width, int height, ptrdiff_t stride,
-                    ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int32_t* idx0, uint16_t* d0,
-                    int32_t* idx1, uint16_t* d1) {
-  if (!s || !imgs || !out_kp || !out_desc || !n_out) return fail(UVO_E_BADARG, "null pointer");
+int uvo_sharder_submit(uvo_sharder* s, const uint8_t* imgs, int imgs_first_frame, int total_frames, int width, int height, ptrdiff_t stride,
+                       ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int32_t* idx0, uint16_t* d0,
+                       int32_t* idx1, uint16_t* d1, int* ticket) {
+  if (!s || !imgs || !out_kp || !out_desc || !n_out || !ticket) return fail(UVO_E_BADARG, "null pointer");
+  *ticket = 0;
   if (total_frames < 1 || imgs_first_frame < 0 || width < 1 || height < 1 || stride < width || frame_stride < (ptrdiff_t)stride * (height - 1) + width)
     return fail(UVO_E_BADARG, "bad frame count / geometry");
+  if (width > s->cfg.extractor.max_width || height > s->cfg.extractor.max_height) return fail(UVO_E_BADARG, "image size outside what the sharder was sized for");
   if (cap < s->dcap) return fail(UVO_E_CAPACITY, "cap must be at least uvo_sharder_max_keypoints()");
   const bool any_match_ptr = idx0 || d0 || idx1 || d1, all_match_ptr = idx0 && d0 && idx1 && d1;
   if (any_match_ptr && (!all_match_ptr || !s->cfg.match)) return fail(UVO_E_BADARG, "match outputs need all four arrays and a sharder created with match = 1");
-  RunArgs a{imgs, imgs_first_frame, total_frames, width, height, stride, frame_stride, out_kp, out_desc, cap, n_out, idx0, idx1, d0, d1};
   // the local shards' frames (+ halo) must lie inside what `imgs` holds from imgs_first_frame on; the caller guarantees the upper end
+  int local = 0;
   for (int i = 0; i < s->cfg.n_shards; ++i) {
     if (s->shards[i].device == UVO_SHARD_REMOTE) continue;
+    ++local;
     uvo_shard_plan pl;
     int rc = uvo_shard_plan_make(total_frames, s->cfg.n_shards, i, s->cfg.chunk_frames, &pl);
     if (rc) return rc;
     if (pl.n_frames > 0 && pl.first_frame < imgs_first_frame) return fail(UVO_E_BADARG, "imgs does not hold a local shard's first frame");
   }
-  std::vector<std::thread> th;
-  for (int i = 0; i < s->cfg.n_shards; ++i)
-    if (s->shards[i].device != UVO_SHARD_REMOTE) th.emplace_back(run_shard, s, i, std::cref(a));
-  for (std::thread& t : th) t.join();
-  for (const Shard& sh : s->shards)
-    if (sh.device != UVO_SHARD_REMOTE && sh.rc != UVO_OK) return fail(sh.rc, sh.err);
+  auto job = std::make_shared<Job>();
+  job->a = RunArgs{imgs, imgs_first_frame, total_frames, width, height, stride, frame_stride, out_kp, out_desc, cap, n_out, idx0, idx1, d0, d1};
+  job->remaining = local;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    job->id = s->next_id++;
+    s->jobs.push_back(job);
+    *ticket = job->id;
+  }
+  s->cv_work.notify_all();
   return UVO_OK;
+}
+
+int uvo_sharder_wait(uvo_sharder* s, int ticket) {
+  if (!s) return fail(UVO_E_BADARG, "null handle");
+  std::unique_lock<std::mutex> lk(s->mu);
+  std::shared_ptr<Job> job;
+  for (const auto& j : s->jobs)
+    if (j->id == ticket) job = j;
+  if (!job) return fail(UVO_E_BADARG, "no such job (already waited for?)");
+  s->cv_done.wait(lk, [&] { return job->remaining == 0; });
+  for (auto it = s->jobs.begin(); it != s->jobs.end(); ++it)
+    if ((*it)->id == ticket) {
+      s->jobs.erase(it);
+      break;
+    }
+  lk.unlock();
+  if (job->rc != UVO_OK) return fail(job->rc, job->err.c_str());
+  return UVO_OK;
+}
+
+int uvo_sharder_run(uvo_sharder* s, const uint8_t* imgs, int imgs_first_frame, int total_frames, int width, int height, ptrdiff_t stride,
+                    ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int32_t* idx0, uint16_t* d0,
+                    int32_t* idx1, uint16_t* d1) {
+  int ticket = 0;
+  int rc = uvo_sharder_submit(s, imgs, imgs_first_frame, total_frames, width, height, stride, frame_stride, out_kp, out_desc, cap, n_out, idx0, d0, idx1,
+                              d1, &ticket);
+  if (rc) return rc;
+  return uvo_sharder_wait(s, ticket);
 }
 
 }  // extern "C"
