@@ -446,7 +446,7 @@ def main():
     h2h = None
     if not args.no_subrecords:
         total = world * B
-        chunk = max(B // int(os.environ.get("UVO_BENCH_CHUNKS", "4")), 1)   # chunks per rank and job, two in flight: the upload of one under the kernels of the other
+        chunk = max(B // int(os.environ.get("UVO_BENCH_CHUNKS", "2")), 1)   # chunks per rank and job, two in flight: the upload of one under the kernels of the other
         devices = [uvo.UVO_SHARD_REMOTE] * world
         devices[rank] = local_rank
         sh = uvo.Sharder(NFEAT, SCALE, NLEVELS, FAST_TH, max_width=W, max_height=H, devices=devices, chunk_frames=chunk, match=True)

@@ -318,6 +318,19 @@ class Sharder:
         self.wait(self.submit(imgs, imgs_first_frame, total_frames, out_kp, out_desc, n_out, idx0, d0, idx1, d1))
 
 
+def host_register(arr):
+    """Page-lock memory the caller owns (uvo_host_register), e.g. a mapping shared between processes."""
+    rc = lib.uvo_host_register(arr.ctypes.data, arr.nbytes)
+    if rc:
+        raise UvoError(rc, "uvo_host_register")
+
+
+def host_unregister(arr):
+    rc = lib.uvo_host_unregister(arr.ctypes.data)
+    if rc:
+        raise UvoError(rc, "uvo_host_unregister")
+
+
 class ORBextractor:
     """Mirror of USLAM::ORBextractor (include/ORBextractor.h:47-95).
 
