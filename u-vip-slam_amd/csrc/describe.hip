@@ -207,7 +207,10 @@ __device__ __forceinline__ int wave_sum(int v) {
 constexpr int DK_PER_WAVE = 4;
 constexpr int DW_ROWS = 37, DW_ROW_DWORDS = 10, DW_DWORDS = DW_ROWS * DW_ROW_DWORDS;  // steered sample points reach +-18 px
 
-__global__ __launch_bounds__(256) void k_describe(const LevelGeom* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
+#ifndef UVO_OCC_DESCRIBE
+#define UVO_OCC_DESCRIBE 1  // more workgroups per CU change nothing here (measured)
+#endif
+__global__ __launch_bounds__(256, UVO_OCC_DESCRIBE) void k_describe(const LevelGeom* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blur, int64_t pyr_block,
                                                   const FinalSlot* __restrict__ flist, int flist_cap, const int32_t* __restrict__ n_final,
                                                   const uvo_keypoint* __restrict__ in_kp, int in_cap, const float* __restrict__ pattern,

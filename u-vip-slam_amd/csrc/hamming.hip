@@ -97,7 +97,10 @@ __device__ __forceinline__ v4i spread16(uint32_t x) {  // 16 bits -> 16 bytes
 // C/D layout of the 32x32 shapes: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 // A / B fragments of k-step s: lane (r = lane & 31, h = lane >> 5) supplies bits 32s + 16h .. +15 of train row r / query column r
 // (any k order is fine as long as A and B use the same one: both come from spread16 of the same 16-bit field).
-__global__ __launch_bounds__(256) void k_knn2_mfma(const uint8_t* __restrict__ q, const int32_t* __restrict__ nq_arr, int nq_fixed, int q_stride,
+#ifndef UVO_OCC_KNN
+#define UVO_OCC_KNN 6  // six workgroups per CU: 0.102 -> 0.098 ms per step; eight: 0.130 ms
+#endif
+__global__ __launch_bounds__(256, UVO_OCC_KNN) void k_knn2_mfma(const uint8_t* __restrict__ q, const int32_t* __restrict__ nq_arr, int nq_fixed, int q_stride,
                                                    const uint8_t* __restrict__ t, const int32_t* __restrict__ nt_arr, int nt_fixed, int t_stride,
                                                    int out_stride, int32_t* __restrict__ idx0, uint16_t* __restrict__ d0,
                                                    int32_t* __restrict__ idx1, uint16_t* __restrict__ d1) {

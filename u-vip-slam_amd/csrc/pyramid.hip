@@ -89,7 +89,10 @@ __device__ __forceinline__ uint32_t vrow(uint32_t q0, uint32_t q1, uint32_t b0s,
 
 constexpr int RZ_ROWS = 4;  // output rows per thread: one column-table fetch, RZ_ROWS x 2 independent row fetches in flight
 
-__global__ __launch_bounds__(256) void k_resize_level(uint8_t* __restrict__ pyr, int64_t pyr_block, int64_t src_off, int src_pitch, int sw,
+#ifndef UVO_OCC_RESIZE
+#define UVO_OCC_RESIZE 6  // six workgroups per CU (80 VGPRs): 0.208 -> 0.197 ms per step; eight (64 VGPRs) spill: 0.263 ms
+#endif
+__global__ __launch_bounds__(256, UVO_OCC_RESIZE) void k_resize_level(uint8_t* __restrict__ pyr, int64_t pyr_block, int64_t src_off, int src_pitch, int sw,
                                                       int64_t dst_off, int dst_pitch, int dst_ph, int dw, int fast_ok,
                                                       const ResizeCol* __restrict__ ctab, const ResizeRow* __restrict__ rtab,
                                                       uint32_t nwx_magic) {
