@@ -30,6 +30,9 @@
 
 namespace uvo {
 
+#ifndef UVO_FAST_WAVES
+#define UVO_FAST_WAVES 4       // wavefronts (regions) per workgroup
+#endif
 #define UVO_FAST_MIN_BLOCKS 5  // workgroups per CU the register allocation is held to; LDS: 31 KB per workgroup -> five fit (at
                                // exactly 32 KB only four do: measured, 0.87 instead of 0.76 ms per 256-frame launch)
 constexpr int FL_CAP = 320;       // corner records a wavefront keeps in LDS (a 248 x 24 region of these frames holds ~250); a busier region
@@ -39,40 +42,45 @@ constexpr int FQ_CAP = 212;       // queue entries per wavefront: < 64 left over
 
 // max over the 16 arcs of 9 contiguous ring pixels of min(d).  A 9-window always straddles the two 8-pixel halves of the
 // ring, so with running minima towards the end of each half (S) and from the start of each half (P) every arc minimum is
-// one more min: arc(k) = min(S[k], P[(k + 8) & 15]).  28 + 16 two-operand minima, then a max3 fold -- branch free.
-__device__ __forceinline__ int arc9_maxmin(const int* d) {
-  int S[16], P[16];
+// one more min: arc(k) = min(S[k], P[(k + 8) & 15]).  28 + 16 two-operand minima, then a max fold -- branch free.
+// The differences fit 9 bits, so everything runs on 16-bit two-operand min / max: on gfx950 v_min_i16 / v_max_i16 issue in
+// 2.4 cycles per wavefront, the 32-bit and three-operand forms in 4.4 (tools/ubench/valu_rate3.hip).
+typedef short d16;
+__device__ __forceinline__ d16 mn16(d16 a, d16 b) { return a < b ? a : b; }
+__device__ __forceinline__ d16 mx16(d16 a, d16 b) { return a > b ? a : b; }
+__device__ __forceinline__ d16 arc9_maxmin(const d16* d) {
+  d16 S[16], P[16];
   S[7] = d[7], S[15] = d[15], P[0] = d[0], P[8] = d[8];
 #pragma unroll
-  for (int k = 6; k >= 0; --k) S[k] = min(d[k], S[k + 1]), S[k + 8] = min(d[k + 8], S[k + 9]);
+  for (int k = 6; k >= 0; --k) S[k] = mn16(d[k], S[k + 1]), S[k + 8] = mn16(d[k + 8], S[k + 9]);
 #pragma unroll
-  for (int k = 1; k < 8; ++k) P[k] = min(d[k], P[k - 1]), P[k + 8] = min(d[k + 8], P[k + 7]);
-  int m9[16];
+  for (int k = 1; k < 8; ++k) P[k] = mn16(d[k], P[k - 1]), P[k + 8] = mn16(d[k + 8], P[k + 7]);
+  d16 m9[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) m9[k] = min(S[k], P[(k + 8) & 15]);
-  int r[6];
+  for (int k = 0; k < 16; ++k) m9[k] = mn16(S[k], P[(k + 8) & 15]);
 #pragma unroll
-  for (int k = 0; k < 5; ++k) r[k] = max(m9[3 * k], max(m9[3 * k + 1], m9[3 * k + 2]));
-  r[5] = m9[15];
-  return max(max(r[0], max(r[1], r[2])), max(r[3], max(r[4], r[5])));
+  for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+    for (int k = 0; k < w; ++k) m9[k] = mx16(m9[k], m9[k + w]);
+  return m9[0];
 }
 
 // min over the 16 arcs of max(d): the darker polarity without negating d (max over arcs of min(-d) = -this)
-__device__ __forceinline__ int arc9_minmax(const int* d) {
-  int S[16], P[16];
+__device__ __forceinline__ d16 arc9_minmax(const d16* d) {
+  d16 S[16], P[16];
   S[7] = d[7], S[15] = d[15], P[0] = d[0], P[8] = d[8];
 #pragma unroll
-  for (int k = 6; k >= 0; --k) S[k] = max(d[k], S[k + 1]), S[k + 8] = max(d[k + 8], S[k + 9]);
+  for (int k = 6; k >= 0; --k) S[k] = mx16(d[k], S[k + 1]), S[k + 8] = mx16(d[k + 8], S[k + 9]);
 #pragma unroll
-  for (int k = 1; k < 8; ++k) P[k] = max(d[k], P[k - 1]), P[k + 8] = max(d[k + 8], P[k + 7]);
-  int m9[16];
+  for (int k = 1; k < 8; ++k) P[k] = mx16(d[k], P[k - 1]), P[k + 8] = mx16(d[k + 8], P[k + 7]);
+  d16 m9[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) m9[k] = max(S[k], P[(k + 8) & 15]);
-  int r[6];
+  for (int k = 0; k < 16; ++k) m9[k] = mx16(S[k], P[(k + 8) & 15]);
 #pragma unroll
-  for (int k = 0; k < 5; ++k) r[k] = min(m9[3 * k], min(m9[3 * k + 1], m9[3 * k + 2]));
-  r[5] = m9[15];
-  return min(min(r[0], min(r[1], r[2])), min(r[3], min(r[4], r[5])));
+  for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+    for (int k = 0; k < w; ++k) m9[k] = mn16(m9[k], m9[k + w]);
+  return m9[0];
 }
 
 // Screening of two pixels packed as 16-bit halves (see k_fast_score): non-zero half <=> that pixel may be a corner.
@@ -117,15 +125,15 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
     constexpr int RB = FR_PITCH * 4;
     const uint8_t* r0 = rows + (meta & 0x1fffu) - 3;  // 3 bytes left of the pixel
     const uint8_t *rp1 = r0 + RB, *rp2 = r0 + 2 * RB, *rp3 = r0 + 3 * RB, *rm1 = r0 - RB, *rm2 = r0 - 2 * RB, *rm3 = r0 - 3 * RB;
-    const int v = r0[3];
-    int d[16];
+    const d16 v = (d16)r0[3];
+    d16 d[16];
     d[0] = rp3[3], d[1] = rp3[4], d[2] = rp2[5], d[3] = rp1[6], d[4] = r0[6], d[5] = rm1[6], d[6] = rm2[5], d[7] = rm3[4];
     d[8] = rm3[3], d[9] = rm3[2], d[10] = rm2[1], d[11] = rm1[0], d[12] = r0[0], d[13] = rp1[0], d[14] = rp2[1], d[15] = rp3[2];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) d[k] -= v;
+    for (int k = 0; k < 16; ++k) d[k] = (d16)(d[k] - v);
     // corner at t  <=>  some 9-arc has all diffs > t (brighter) or all < -t (darker)  <=>  max(sb, sd) > t;
     // cornerScore = max(sb, sd) - 1.  No masks, no divergent branches.
-    const int best = max(arc9_maxmin(d), -arc9_minmax(d));
+    const int best = max((int)arc9_maxmin(d), -(int)arc9_minmax(d));
     if (best > t_min) {
       const int sc = best - 1;
       corner = sc > 0;  // a score of 0 (only possible at t_min = 0) can never survive NMS nor suppress anything
@@ -151,19 +159,19 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
 // into a dense byte tile that reuses the LDS of the row ring + queue, the eight neighbours of every corner are read from it
 // (neighbours outside the corner's own FAST cell count as 0), survivors are compacted in place and mark their cell when they
 // reach fastTh.  No score plane in HBM, no zero fill, no second gather pass.
-__global__ __launch_bounds__(256, UVO_FAST_MIN_BLOCKS) void k_fast_score(const uint8_t* __restrict__ pyr, int64_t pyr_block, FastLevels L, int t_min, int fast_th,
+__global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fast_score(const uint8_t* __restrict__ pyr, int64_t pyr_block, FastLevels L, int t_min, int fast_th,
                                                     uint32_t* __restrict__ cor, uint8_t* __restrict__ cell_hi, uint32_t* __restrict__ cand_xy,
                                                     uint32_t* __restrict__ cand_sc, uint32_t* __restrict__ cand_lo, int64_t cand_block,
                                                     int32_t* __restrict__ cursor) {
-  __shared__ uint32_t s_mem[4][FW_DWORDS];
-  __shared__ uint32_t s_list[4][FL_CAP];
+  __shared__ uint32_t s_mem[UVO_FAST_WAVES][FW_DWORDS];
+  __shared__ uint32_t s_list[UVO_FAST_WAVES][FL_CAP];
   const int wv = wave_in_block(), lane = threadIdx.x & 63;
   uint32_t* rows32 = s_mem[wv];
   uint32_t* q = rows32 + FW_RING_DW;
   const uint8_t* rows8 = reinterpret_cast<const uint8_t*>(rows32);
   // work item (one per wavefront) -> (level, strip, segment); window = padded cols [32, w) x rows [32, h)
   const int vb = xcd_contiguous((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
-  const int item = (vb % (int)gridDim.x) * 4 + wv, f = vb / (int)gridDim.x;  // an XCD walks whole frames, region after region
+  const int item = (vb % (int)gridDim.x) * UVO_FAST_WAVES + wv, f = vb / (int)gridDim.x;  // an XCD walks whole frames, region after region
   int level, X0, py0, nsub;
   if (!fast_region(L, item, level, X0, py0, nsub)) return;
   const FastLevel g = L.l[level];
@@ -464,8 +472,8 @@ void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, c
                        uint32_t* d_cand_xy, uint32_t* d_cand_sc, uint32_t* d_cand_lo, int64_t cand_block, int32_t* d_cursor, int batch) {
   const int t_min = fast_th < 7 ? fast_th : 7;
   const FastLevels L = fast_levels(g, batch);
-  const dim3 grid((L.items_per_frame + 3) / 4, batch);
-  hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, s, d_pyr, pyr_block, L, t_min, fast_th, d_cor, d_cell_hi, d_cand_xy, d_cand_sc, d_cand_lo,
+  const dim3 grid((L.items_per_frame + UVO_FAST_WAVES - 1) / UVO_FAST_WAVES, batch);
+  hipLaunchKernelGGL(k_fast_score, grid, dim3(64 * UVO_FAST_WAVES), 0, s, d_pyr, pyr_block, L, t_min, fast_th, d_cor, d_cell_hi, d_cand_xy, d_cand_sc, d_cand_lo,
                      cand_block, d_cursor);
 }
 
