@@ -6,7 +6,10 @@
 // pixels which computeOrbDescriptor samples up to 2 px deep.  Here the blur is out of place: the output plane
 // holds the blurred interior plus a 4-px ring copied from the un-blurred pad -- all the descriptor can reach.
 // Arithmetic is OpenCV's symmetric-smooth integer engine: taps round(g*256) per pass (18,34,49,55,49,34,18),
-// row pass u8 -> int, column pass (sum + 2^15) >> 16 saturated to u8.
+// row pass u8 -> int, column pass (sum + 2^15) >> 16 saturated to u8.  The column pass runs on the fp32 pipe and is still exact:
+// row sums (< 2^16) times taps (sum 257) stay below 2^24 wherever the result is not saturated, fp32 add / fma issue in 2.4
+// cycles per wavefront on gfx950 where the 24-bit integer multiply takes 4.4 (tools/ubench/valu_rate3.hip), and with the
+// wavefront's fp32 rounding mode set to round-toward-zero v_cvt_pk_u8_f32 is floor + saturate + byte insert in one instruction.
 //
 // Streaming stencil without LDS: one wavefront owns a vertical strip of 64 lanes x 4 pixels (lanes 0 and 63 are halo,
 // 248 useful columns) and walks down the rows.  Per row a lane issues ONE aligned dword load, takes its neighbours'
@@ -36,11 +39,11 @@ __device__ __forceinline__ int gauss_row1(uint32_t L, uint32_t C, uint32_t R, ui
   const uint32_t a = win4<K + 1>(L, C, R), b = win4<K + 5>(L, C, R);
   return (int)__builtin_amdgcn_udot4(b, T2, __builtin_amdgcn_udot4(a, T1, 0u, false), false);
 }
-__device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t R, uint32_t T1, uint32_t T2, int* h) {
-  h[0] = gauss_row1<0>(L, C, R, T1, T2);
-  h[1] = gauss_row1<1>(L, C, R, T1, T2);
-  h[2] = gauss_row1<2>(L, C, R, T1, T2);
-  h[3] = gauss_row1<3>(L, C, R, T1, T2);
+__device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t R, uint32_t T1, uint32_t T2, float* h) {
+  h[0] = (float)(uint32_t)gauss_row1<0>(L, C, R, T1, T2);  // < 2^16: exact
+  h[1] = (float)(uint32_t)gauss_row1<1>(L, C, R, T1, T2);
+  h[2] = (float)(uint32_t)gauss_row1<2>(L, C, R, T1, T2);
+  h[3] = (float)(uint32_t)gauss_row1<3>(L, C, R, T1, T2);
 }
 
 __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int64_t pyr_block,
@@ -81,7 +84,11 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
 
   const uint32_t T1 = (uint32_t)taps.x | ((uint32_t)taps.y << 8) | ((uint32_t)taps.z << 16) | ((uint32_t)taps.w << 24);
   const uint32_t T2 = (uint32_t)taps.z | ((uint32_t)taps.y << 8) | ((uint32_t)taps.x << 16);
-  int hring[7][4];
+  // column taps scaled by 2^-16 (exact): the column sum comes out as sum / 65536, and + 0.5 makes its floor the rounded result
+  const float c0 = (float)taps.x * (1.0f / 65536.0f), c1 = (float)taps.y * (1.0f / 65536.0f), c2 = (float)taps.z * (1.0f / 65536.0f),
+              c3 = (float)taps.w * (1.0f / 65536.0f);
+  __builtin_amdgcn_s_setreg(0x801, 3);  // MODE.fp_round[1:0] (fp32) = toward zero: nothing below rounds except the final float -> byte conversion
+  float hring[7][4];
   uint32_t cring[7];
   // Row loads are issued one unrolled block (7 rows) ahead of their use: a wavefront walks ~70 rows one after another, so
   // without the prefetch every row would expose a full memory round trip.
@@ -107,26 +114,23 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
         cring[u] = C;
         if (j >= 6) {
           const int py = py0l + j - 6;  // output row; its 7 source rows sit in ring slots (u+1)%7 .. (u+7)%7
-          const int* r0 = hring[(u + 1) % 7];
-          const int* r1 = hring[(u + 2) % 7];
-          const int* r2 = hring[(u + 3) % 7];
-          const int* r3 = hring[(u + 4) % 7];
-          const int* r4 = hring[(u + 5) % 7];
-          const int* r5 = hring[(u + 6) % 7];
-          const int* r6 = hring[u];
+          const float* r0 = hring[(u + 1) % 7];
+          const float* r1 = hring[(u + 2) % 7];
+          const float* r2 = hring[(u + 3) % 7];
+          const float* r3 = hring[(u + 4) % 7];
+          const float* r4 = hring[(u + 5) % 7];
+          const float* r5 = hring[(u + 6) % 7];
+          const float* r6 = hring[u];
           const uint32_t centre = cring[(u + 4) % 7];
           const bool row_in = py >= kPad && py < g.h + kPad;
-          // column pass; (s + 2^15) >> 16 is the upper half of the sum, so two pixels' results are picked into one dword with a
-          // byte permute, clamped to 255 as a 16-bit pair, and the four bytes gathered with a second permute
-          uint32_t sum[4];
+          // column pass: sum / 2^16 + 0.5, every partial sum an exact multiple of 2^-16 below 2^8 (a larger one belongs to a result
+          // that saturates anyway); floor, clamp to 255 and the byte insert are the conversion itself
+          uint32_t blurred = 0;
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            sum[k] = (uint32_t)(__mul24(taps.x, r0[k] + r6[k]) + __mul24(taps.y, r1[k] + r5[k]) + __mul24(taps.z, r2[k] + r4[k]) +
-                                __mul24(taps.w, r3[k]) + (1 << 15));
-          const u16x2 lim = {255, 255};
-          const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(pk(__builtin_amdgcn_perm(sum[1], sum[0], 0x07060302u)), lim));
-          const uint32_t p23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(pk(__builtin_amdgcn_perm(sum[3], sum[2], 0x07060302u)), lim));
-          const uint32_t blurred = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
+          for (int k = 0; k < 4; ++k) {
+            const float z = __builtin_fmaf(c0, r0[k] + r6[k], __builtin_fmaf(c1, r1[k] + r5[k], __builtin_fmaf(c2, r2[k] + r4[k], __builtin_fmaf(c3, r3[k], 0.5f))));
+            blurred = __builtin_amdgcn_cvt_pk_u8_f32(z, (uint32_t)k, blurred);
+          }
           // pad ring and anything outside the image: the un-blurred centre pixel (byte mask per lane, rows uniform)
           const uint32_t m = row_in ? inmask : 0u;
           const uint32_t out = (blurred & m) | (centre & ~m);
