@@ -610,6 +610,15 @@ def main():
             ginstr = valu_instr / avg_launch_s / 1e9
             roof_valu = {"achieved": round(ginstr, 2), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": round(ginstr / VALU_PEAK_GINSTR, 5),
                          "valu_wave_instructions_per_launch": int(valu_instr)}
+            # the same kernel alone on the chip (no second pipeline lane beside it), and against the issue rate of the instruction class most
+            # of its instructions belong to: on gfx950 only plain two-operand 32-bit / 16-bit ALU ops and fp32 add / mul / fma issue every
+            # 2 cycles per SIMD; packed, three-operand, compare, 32-bit min / max, integer multiply and conversion instructions take 4
+            # (measured: tools/ubench/valu_rate3.hip)
+            if dom in serial and serial[dom][0] > 0:
+                alone_s = serial[dom][0] / 3 * 1e-3 / launches_per_step
+                g1 = valu_instr / alone_s / 1e9
+                roof_valu["alone_on_the_chip"] = {"launch_ms": round(alone_s * 1e3, 5), "achieved": round(g1, 2), "frac": round(g1 / VALU_PEAK_GINSTR, 5),
+                                                  "frac_of_4_cycle_class_peak": round(g1 / (VALU_PEAK_GINSTR / 2), 5)}
             if roof_valu["frac"] > hbm_frac:
                 bound, roof = "valu", dict(roof_valu)
         out = {

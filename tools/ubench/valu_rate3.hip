@@ -69,6 +69,27 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t a0) 
   if (OP == 52) BODY("v_max_i16 %0, %0, %1")
     if (OP == 54) BODY("v_addc_co_u32 %0, vcc, %0, %1, vcc")
   if (OP == 55) BODY("v_add_co_u32 %0, vcc, %0, %1")
+  if (OP == 60) BODY("v_cndmask_b32 %0, %0, %1, s[20:21]")
+  if (OP == 61) BODY("v_cmp_gt_u32 s[20:21], %0, %1")
+  if (OP == 62) BODY("v_bfi_b32 %0, %0, %1, %2")
+  if (OP == 63) BODY("v_lshl_or_b32 %0, %0, 8, %1")
+  if (OP == 64) BODY("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x6c")
+  if (OP == 65) BODY("v_pk_add_u16 %0, %0, %1")
+  if (OP == 66) BODY("v_floor_f32 %0, %0")
+  if (OP == 67) BODY("v_rndne_f32 %0, %0")
+  if (OP == 68) BODY("v_cvt_u32_f32 %0, %0")
+  if (OP == 71) BODY("v_max_f32 %0, %0, %1")
+  if (OP == 72) BODY("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf")
+  if (OP == 73) BODY("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf")
+  if (OP == 74) BODY("v_add_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf")
+  if (OP == 75) BODY("v_cvt_f32_ubyte2 %0, %0")
+  if (OP == 76) BODY("v_subrev_u32 %0, %0, %1")
+  if (OP == 77) BODY("v_mad_u32_u16 %0, %0, %1, %2")
+  if (OP == 78) BODY("v_add_u32 %0, 5, %0")
+  if (OP == 79) BODY("v_add_u32 %0, s20, %0")
+  if (OP == 80) BODY("v_add_u32 %0, 0x12345, %0")
+  if (OP == 81) BODY("v_sub_f32 %0, %0, %1")
+  if (OP == 82) BODY("v_mul_u32_u24 %0, 3, %0")
   uint32_t s = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += a[i];
@@ -103,6 +124,10 @@ int main() {
   run<51>("v_add_u16"); run<33>("v_sub_u16"); run<34>("v_max_u16"); run<52>("v_max_i16"); run<46>("v_mad_u16"); run<47>("v_mul_lo_u16"); run<48>("v_pk_mul_lo_u16"); run<49>("v_pk_mad_u16");
   run<35>("v_add_f32"); run<43>("v_mul_f32"); run<36>("v_fma_f32"); run<44>("v_fmac_f32"); run<37>("v_min_f32"); run<38>("v_cvt_f32_ubyte0"); run<50>("v_cvt_f32_u32");
   run<39>("v_dot4_u32_u8"); run<40>("v_mul_lo_u32"); run<41>("v_mul_hi_u32"); run<55>("v_add_co_u32"); run<54>("v_addc_co_u32");
+  run<60>("v_cndmask_b32 (sgpr mask)"); run<61>("v_cmp_gt_u32 -> sgpr"); run<62>("v_bfi_b32"); run<63>("v_lshl_or_b32"); run<64>("v_bitop3_b32"); run<65>("v_pk_add_u16");
+  run<66>("v_floor_f32"); run<67>("v_rndne_f32"); run<68>("v_cvt_u32_f32"); run<71>("v_max_f32"); run<81>("v_sub_f32");
+  run<72>("v_mov_b32_dpp row_shr:1"); run<73>("v_mov_b32_dpp wave_shr:1"); run<74>("v_add_u32_dpp row_shr:1"); run<75>("v_cvt_f32_ubyte2"); run<76>("v_subrev_u32"); run<77>("v_mad_u32_u16");
+  run<78>("v_add_u32 inline const"); run<79>("v_add_u32 sgpr"); run<80>("v_add_u32 literal"); run<82>("v_mul_u32_u24 const");
   run<21>("min_i32+max_i32", 2); run<22>("pk_max_i16+pk_min_i16", 2);
   return 0;
 }
