@@ -356,6 +356,8 @@ def main():
     DEPTH = int(os.environ.get("UVO_PIPELINE_DEPTH", "2"))
     outs = [Out() for _ in range(DEPTH)]
     ex.set_pipeline(DEPTH)
+    if os.environ.get("UVO_BENCH_OCT_WIDE_MAX"):   # experiment knob: quad-tree launch shape (uvo_extractor_tune)
+        ex.tune(uvo.UVO_TUNE_OCT_WIDE_MAX, int(os.environ["UVO_BENCH_OCT_WIDE_MAX"]))
     torch.cuda.synchronize()
     counter = [0]
 

@@ -111,6 +111,40 @@ def test_degenerate_images(uvo, oracle):
     ex.close()
 
 
+def test_blur_planes_at_the_saturation_edge(uvo, oracle):
+    """k_gauss7's column pass runs on the fp32 pipe: exact while the result is not saturated, i.e. the images to try are the ones whose
+    sums sit at and across 2^24 -- constant 253 / 254 / 255 (taps sum to 257 per pass, so 254 already blurs to 255), bright noise,
+    0 / 255 salt, a bright ramp -- plus corners in them so that the oracle blurs every level (it skips levels without keypoints)."""
+    rng = np.random.default_rng(77)
+    H, W = 256, 320
+    yy, xx = np.indices((H, W))
+    marks = (rng.random((H, W)) < 0.02)
+    imgs = {}
+    for c in (253, 254, 255):
+        im = np.full((H, W), c, np.uint8)
+        im[marks] = 0
+        imgs["const%d" % c] = im
+    imgs["bright_noise"] = rng.integers(236, 256, (H, W)).astype(np.uint8)
+    imgs["salt"] = np.where(rng.random((H, W)) < 0.5, 255, 0).astype(np.uint8)
+    ramp = np.clip(200 + (xx + yy) // 6, 0, 255).astype(np.uint8)
+    ramp[marks] = 40
+    imgs["bright_ramp"] = ramp
+    ex = uvo.ORBextractor(500, 1.2, 6, 0, 20, max_width=W, max_height=H)
+    oe = oracle.extractor(500, 1.2, 6, 20)
+    for name, img in imgs.items():
+        kp_g, de_g = ex(img)
+        kp_o, de_o = oe(img)
+        compared = 0
+        for l in range(6):
+            if (kp_o["octave"] == l).any():
+                bo, bg = oe.level_plane(l, blurred=True), ex.read_plane(l, blurred=True)
+                np.testing.assert_array_equal(bg[14:-14, 14:-14], bo[14:-14, 14:-14], err_msg="%s: blurred level %d" % (name, l))
+                compared += 1
+        assert compared >= 1 or len(kp_o) == 0, name
+        _assert_same_features(kp_g, de_g, kp_o, de_o, name)
+    ex.close()
+
+
 def test_topup_mode(uvo, oracle, frames):
     """FullDetect=false: caller keypoints pass through level 0, occupancy grid filters and is mutated (src/ORBextractor.cc:872-909)."""
     img = frames[0]
