@@ -406,17 +406,19 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
       off_hi += (int)__popcll(mh), off_lo += (int)__popcll(ml);
     }
   };
-  // (generic pointer from here on: the list is in LDS unless the region overflowed it)
-  uint32_t* C = list;
+  // two instances of the tail, so that each knows its address space: the list still in LDS (a quiet region), or in the region's slice
+  // of memory once it has overflowed (the rule on corner-rich frames) -- a generic pointer would make every access a flat one
   if (nflushed) {
     for (int i = lane; i < ncorner; i += 64) region[nflushed + i] = list[i];
     ncorner += nflushed;
-    C = region;
     __threadfence_block();  // the list in memory was written by this wavefront's own global stores
+    const int nkeep = nms_list(region);
+    __threadfence_block();
+    emit(region, nkeep);
+  } else {
+    const int nkeep = nms_list(list);
+    emit(list, nkeep);
   }
-  const int nkeep = nms_list(C);
-  if (nflushed) __threadfence_block();
-  emit(C, nkeep);
 }
 
 // Rows per (strip, segment) work item.  A wavefront lives for the whole item, so long segments leave a long under-filled
