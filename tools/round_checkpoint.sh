@@ -9,3 +9,8 @@ python bench.py --config 3 > $O/bench_config3.json 2> $O/bench3.err; tail -1 $O/
 python tools/latency.py > $O/latency_batch1.json 2>/dev/null; tail -1 $O/latency_batch1.json | cut -c1-300
 bash tools/profile_round.sh $TAG 2
 bash tools/profile_round.sh ${TAG}_hd 3
+# two ranks on this one GPU (gloo rendezvous, both on device 0): the N>1 code path of bench.py end to end
+UVO_BENCH_DRYRUN_ONE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --steps 10 --warmup 2 > $O/bench_2ranks_one_gpu.json 2> $O/bench2.err; tail -1 $O/bench_2ranks_one_gpu.json | cut -c1-200
+timeout 900 python tools/soak_parity.py 60 7 > $O/soak_parity.log 2>&1; tail -1 $O/soak_parity.log
+timeout 600 python tools/soak_matcher.py > $O/soak_matcher.log 2>&1; tail -1 $O/soak_matcher.log
+timeout 600 python tools/soak_misc.py > $O/soak_misc.log 2>&1; tail -1 $O/soak_misc.log
