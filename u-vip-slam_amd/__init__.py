@@ -437,15 +437,15 @@ class ORBextractor:
     def submit(self, images, out_kp, out_desc, n_out):
         """Asynchronous FullDetect extraction of a (B, H, W) uint8 stack into caller arrays out_kp (B, cap) KEYPOINT_DTYPE,
         out_desc (B, cap, 32) uint8, n_out (B,) int32 -- ideally all from pinned_empty(); returns the ticket for wait()."""
-        assert images.dtype == np.uint8 and images.flags.c_contiguous and images.ndim == 3
+        assert images.dtype == np.uint8 and images.ndim == 3 and images.strides[2] == 1   # rows contiguous; row / frame strides are free
         b, h, w = images.shape
         cap = out_kp.shape[1]
         assert out_kp.dtype == KEYPOINT_DTYPE and out_kp.flags.c_contiguous and out_kp.shape[0] >= b
         assert out_desc.dtype == np.uint8 and out_desc.flags.c_contiguous and out_desc.shape[1:] == (cap, 32)
         assert n_out.dtype == np.int32 and len(n_out) >= b
         t = ctypes.c_int()
-        rc = lib.uvo_extract_batch_submit(self._h, b, images.ctypes.data, w, h, w, w * h, out_kp.ctypes.data, out_desc.ctypes.data, cap,
-                                          n_out.ctypes.data, ctypes.byref(t))
+        rc = lib.uvo_extract_batch_submit(self._h, b, images.ctypes.data, w, h, images.strides[1], images.strides[0], out_kp.ctypes.data,
+                                          out_desc.ctypes.data, cap, n_out.ctypes.data, ctypes.byref(t))
         if rc:
             raise UvoError(rc, "uvo_extract_batch_submit")
         return t.value
