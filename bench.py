@@ -585,6 +585,22 @@ def main():
         ex4.close()
         m4.close()
         sub["device_copy_GBps"] = round(device_copy_gbps(torch, dev), 1)
+        # the same step on the frames of rounds 1-2's generator, whose noise grows along a 32-frame chain (synth.make_sequence,
+        # noise="cumulative": 5 -> 18 % of the pixels pass as FAST corners instead of a steady 4 %): extraction time follows the corner
+        # density.  Last, because it overwrites the device frames.
+        fr_c = synth.make_sequence(first, B + 1, W, H, n_shapes=cfg["n_shapes"], noise="cumulative")
+        d_imgs.copy_(torch.from_numpy(fr_c).to(dev))
+        for _ in range(DEPTH + 1):
+            step()
+        sync_all()
+        n_c = max(10, steps // 3)
+        t0 = time.perf_counter()
+        for _ in range(n_c):
+            step()
+        sync_all()
+        sub["frames with noise accumulating along a chain (rounds 1-2 generator)"] = {
+            "frames_per_s": round(B * n_c / (time.perf_counter() - t0), 1),
+            "note": "extract + match of the same batch size; every frame = the previous noisy frame resampled + N(0,2)"}
 
     if rank == 0:
         frames_total = B * steps * world
@@ -639,6 +655,8 @@ def main():
             "config": {"workload": "%s: 1xMI355X per rank, batch=%d synthetic %dx%d mono frames (+1 halo frame: the neighbouring rank's first), %d feats, "
                                    "%d levels, fastTh %d, FullDetect extract + all-pairs 256-bit Hamming knn-2 of consecutive frames, HBM-resident I/O"
                                    % (cfg["name"], B, W, H, NFEAT, NLEVELS, FAST_TH),
+                       "generator": "SURVEY.md 8(d): value-noise texture + %d shapes + N(0,3) sensor noise per frame; camera motion = a small affine per "
+                                    "frame inside 32-frame chains (u-vip-slam_amd/synth.py make_sequence, noise='sensor')" % cfg["n_shapes"],
                        "batch_per_gpu": B, "sharding": "contiguous frame blocks of one global sequence, 1-frame halo from the neighbour, no collective",
                        "pipeline_depth": DEPTH, "mean_keypoints_per_frame": round(k_mean, 1)},
             "verified_frames": verified["frames"] if verified else 0,

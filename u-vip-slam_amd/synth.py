@@ -25,7 +25,9 @@ def _value_noise(rng, h, w, cell):
     return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
 
 
-def make_frame(seed, w=640, h=512, n_shapes=400):
+def make_frame(seed, w=640, h=512, n_shapes=400, noise=True):
+    """One frame.  noise=False returns the float scene (texture + shapes) before the N(0,3) pixel noise, rounding and clipping; the
+    random stream is the same either way."""
     rng = np.random.default_rng(seed)
     img = np.full((h, w), 110.0, dtype=np.float32)
     for cell, amp in ((64, 30.0), (32, 20.0), (16, 10.0)):
@@ -55,8 +57,21 @@ def make_frame(seed, w=640, h=512, n_shapes=400):
         else:  # disc
             m = lx * lx + ly * ly <= (sz / 2) ** 2
         sub[m] += contrast
+    if not noise:
+        return img
     img += rng.normal(0.0, 3.0, size=(h, w)).astype(np.float32)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def _step_affine(seed, w, h):
+    """The small random affine of one sequence step (<= 3 px shift, <= 2 deg rotation about the image centre) as a 3x3 matrix that maps
+    destination pixel coordinates to source coordinates -- the same draw as warp_frame(seed)."""
+    rng = np.random.default_rng(seed)
+    ang = np.deg2rad(rng.uniform(-2, 2))
+    tx, ty = rng.uniform(-3, 3, size=2)
+    c, s = np.cos(ang), np.sin(ang)
+    cx, cy = w / 2, h / 2
+    return np.array([[c, s, cx - tx - c * cx - s * cy], [-s, c, cy - ty + s * cx - c * cy], [0.0, 0.0, 1.0]])
 
 
 def warp_frame(img, seed):
@@ -80,16 +95,38 @@ def make_batch(n, w=640, h=512, seed0=1000):
     return np.stack([make_frame(seed0 + i, w, h) for i in range(n)])
 
 
-def make_sequence(first, count, w=640, h=512, chain=32, n_shapes=400, seed_base=1000):
-    """Frames [first, first + count) of the global synthetic sequence bench.py and the sharding tests use: frame g starts a new
-    chain when g % chain == 0 (make_frame, seed seed_base + g), otherwise it is the previous frame warped (seed seed_base + g), so
-    consecutive frames truly correspond.  Any shard of the sequence can be generated on its own (it replays its first chain from
-    the chain's start), which is what lets every rank / device produce its frames and its neighbour's halo frame independently."""
+def make_sequence(first, count, w=640, h=512, chain=32, n_shapes=400, seed_base=1000, noise="sensor"):
+    """Frames [first, first + count) of the global synthetic sequence bench.py and the sharding tests use.  Frame g starts a new chain
+    when g % chain == 0; inside a chain the camera moves by a small random affine per frame (seed seed_base + g), so consecutive frames
+    truly correspond.  Any shard of the sequence can be generated on its own (it replays its chain from the chain's start), which is
+    what lets every rank / device produce its frames and its neighbour's halo frame independently.
+
+    noise="sensor" (default, SURVEY.md 8(d): N(0,3) pixel noise): a frame is the chain's noise-free scene sampled through the composed
+    motion of the chain so far, plus fresh N(0,3) noise -- every frame has the same noise level, as frames of one camera do.
+    noise="cumulative": the round-2 generator kept for comparison -- every frame is the previous *noisy* frame resampled plus N(0,2),
+    so the noise grows along a chain (sigma 3 -> 11.5 over 32 frames) and with it the share of pixels that pass as FAST corners
+    (5 % -> 18 % at threshold 7)."""
     out = []
     g = first - first % chain
     prev = None
+    scene, T = None, None
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
     while g < first + count:
-        prev = make_frame(seed_base + g, w, h, n_shapes) if g % chain == 0 else warp_frame(prev, seed_base + g)
+        if noise == "cumulative":
+            prev = make_frame(seed_base + g, w, h, n_shapes) if g % chain == 0 else warp_frame(prev, seed_base + g)
+        else:
+            if g % chain == 0:
+                scene, T = make_frame(seed_base + g, w, h, n_shapes, noise=False), np.eye(3)
+                if g >= first:
+                    prev = make_frame(seed_base + g, w, h, n_shapes)  # the chain's first frame is make_frame itself
+            else:
+                T = T @ _step_affine(seed_base + g, w, h)           # destination pixel -> the scene's coordinates
+                if g >= first:
+                    sx = np.clip(np.rint(T[0, 0] * xx + T[0, 1] * yy + T[0, 2]), 0, w - 1).astype(np.int32)
+                    sy = np.clip(np.rint(T[1, 0] * xx + T[1, 1] * yy + T[1, 2]), 0, h - 1).astype(np.int32)
+                    rng = np.random.default_rng((seed_base + g) * 7919 + 17)
+                    img = scene[sy, sx] + rng.normal(0.0, 3.0, size=(h, w)).astype(np.float32)
+                    prev = np.clip(np.rint(img), 0, 255).astype(np.uint8)
         if g >= first:
             out.append(prev)
         g += 1
