@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
     const int xs = ls * 4 + K;
     okv[K] = nrows_l > 0 && xs >= 3 && xs <= sub_px - 4 && X + K >= 32 && X + K < g.w;
   }
-  const bool ok0 = okv[0], ok1 = okv[1], ok2 = okv[2], ok3 = okv[3];
+  const uint32_t mk0 = okv[0] ? 0x0000ffffu : 0u, mk1 = okv[1] ? 0x0000ffffu : 0u, mk2 = okv[2] ? 0xffff0000u : 0u, mk3 = okv[3] ? 0xffff0000u : 0u;
   const uint32_t t_even = (uint32_t)t_min * 0x00010001u, t_odd = t_even << 8;
 
   // Row loads run one unrolled block (7 rows) ahead of their use so that a wavefront never waits on the row it needs next.
@@ -234,16 +234,18 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
           const int jc = j - 3;           // loop index of the centre row; rows jc-3 .. jc+3 sit in register slots (u+1)%7 .. u
           const int rrp = j - 6;          // centre row relative to the sub-strip: 0 = halo row above, nrows + 1 = halo row below
           const int pcl = py0l - 1 + rrp;  // the lane's centre row in the padded plane
-          const bool row_ok = pcl >= 32 && pcl < g.h && rrp <= nrows_l + 1;
+          const uint32_t rowm = (pcl >= 32 && pcl < g.h && rrp <= nrows_l + 1) ? 0xffffffffu : 0u;  // this lane screens this row
           {
             const int sm3 = (u + 1) % 7, sm2 = (u + 2) % 7, s0 = (u + 4) % 7, sp2 = (u + 6) % 7, sp3 = u;
             const uint32_t Cc = Cr[s0], Cu = Cr[sm3], Cd = Cr[sp3], C2 = Cr[sp2], Cm2 = Cr[sm2];
-            // neighbour dwords of the centre row and of the rows two above / below it from the LDS row ring (written by this wavefront, in order)
-            const uint32_t* rc = rows32 + (jc & (FR_ROWS - 1)) * FR_PITCH;
-            const uint32_t* r2 = rows32 + ((jc + 2) & (FR_ROWS - 1)) * FR_PITCH;
-            const uint32_t* rm = rows32 + ((jc - 2) & (FR_ROWS - 1)) * FR_PITCH;
-            const uint32_t Lc = rc[lm], Rc = rc[lp], L2 = r2[lm], R2 = r2[lp], Lm2 = rm[lm], Rm2 = rm[lp];
+            // neighbour dwords of the centre row and of the rows two above / below it from the LDS row ring (written by this wavefront, in
+            // order).  With the centre taken from the mirror when it is one of the first three slots, rows jc-3 .. jc+3 are seven
+            // consecutive slots: one address per neighbour lane, the other rows are immediate offsets.
             const int cslot = (jc & (FR_ROWS - 1)) < 3 ? (jc & (FR_ROWS - 1)) + FR_ROWS : (jc & (FR_ROWS - 1));
+            const uint32_t* rc = rows32 + cslot * FR_PITCH;
+            const uint32_t* r2 = rc + 2 * FR_PITCH;
+            const uint32_t* rm = rc - 2 * FR_PITCH;
+            const uint32_t Lc = rc[lm], Rc = rc[lp], L2 = r2[lm], R2 = r2[lp], Lm2 = rm[lm], Rm2 = rm[lp];
             const uint32_t row_entry = (uint32_t)(cslot * (FR_PITCH * 4)) | ((uint32_t)rrp << 21);
             // ---- screen the lane's 4 pixels with four opposite ring pairs, queue the ones that pass ----
             // Packed 16-bit arithmetic, two pixels per instruction: the even bytes of a pixel dword sit in the two 16-bit
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
             const uint32_t ro = screen2(Cc, Cd, Cu, P4, P12, P2, P10, P6, P14, t_odd);
 #define UVO_FAST_PUSH(K, COND)                                                                                    \
   {                                                                                                               \
-    const bool pass = (COND) & ok##K & row_ok;                                                                    \
+    const bool pass = (COND);                                                                                     \
     const uint64_t m = __ballot(pass);                                                                            \
     if (m) {                                                                                                      \
       if (qn == 0) qoldest = jc;                                                                                  \
@@ -270,14 +272,16 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
       qn += __popcll(m);                                                                                          \
     }                                                                                                             \
   }
-            UVO_FAST_PUSH(0, (re & 0xffffu) != 0u)
-            UVO_FAST_PUSH(1, (ro & 0xffffu) != 0u)
+            // (the lane's column flags and the row flag are folded into one AND per pixel: mk0..3 select the pixel's half of the word)
+            const uint32_t rem = re & rowm, rom = ro & rowm;
+            UVO_FAST_PUSH(0, (rem & mk0) != 0u)
+            UVO_FAST_PUSH(1, (rom & mk1) != 0u)
             while (qn >= 64) {  // keeps the queue within FQ_CAP
               qn -= 64;
               fast_score_chunk(q, rows8, qn, 64, lane, t_min, list, region, ncorner, nflushed);
             }
-            UVO_FAST_PUSH(2, re > 0xffffu)
-            UVO_FAST_PUSH(3, ro > 0xffffu)
+            UVO_FAST_PUSH(2, (rem & mk2) != 0u)
+            UVO_FAST_PUSH(3, (rom & mk3) != 0u)
 #undef UVO_FAST_PUSH
           }
           // ---- drain full batches (newest first); a stale remainder is flushed before its rows leave the ring ----
