@@ -90,6 +90,24 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t a0) 
   if (OP == 80) BODY("v_add_u32 %0, 0x12345, %0")
   if (OP == 81) BODY("v_sub_f32 %0, %0, %1")
   if (OP == 82) BODY("v_mul_u32_u24 %0, 3, %0")
+  if (OP == 90 || OP == 91 || OP == 92) {   // 64-bit address arithmetic
+    uint64_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = ((uint64_t)a[i] << 32) | a[i + 4];
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (OP == 90) asm volatile("v_mad_i64_i32 %0, s[20:21], %1, %2, %0" : "+v"(w[i]) : "v"(b), "v"(c));
+          if (OP == 91) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(w[i]) : "v"(b), "v"(c));
+          if (OP == 92) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(w[i]) : "v"(w[(i + 1) & 3]));
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (uint32_t)w[i] ^ (uint32_t)(w[i] >> 32);
+  }
   uint32_t s = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += a[i];
@@ -128,6 +146,7 @@ int main() {
   run<66>("v_floor_f32"); run<67>("v_rndne_f32"); run<68>("v_cvt_u32_f32"); run<71>("v_max_f32"); run<81>("v_sub_f32");
   run<72>("v_mov_b32_dpp row_shr:1"); run<73>("v_mov_b32_dpp wave_shr:1"); run<74>("v_add_u32_dpp row_shr:1"); run<75>("v_cvt_f32_ubyte2"); run<76>("v_subrev_u32"); run<77>("v_mad_u32_u16");
   run<78>("v_add_u32 inline const"); run<79>("v_add_u32 sgpr"); run<80>("v_add_u32 literal"); run<82>("v_mul_u32_u24 const");
+  run<90>("v_mad_i64_i32"); run<91>("v_mad_u64_u32"); run<92>("v_lshl_add_u64");
   run<21>("min_i32+max_i32", 2); run<22>("pk_max_i16+pk_min_i16", 2);
   return 0;
 }

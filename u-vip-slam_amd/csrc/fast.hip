@@ -30,6 +30,9 @@
 
 namespace uvo {
 
+// the lane mask of a predicate, straight from the compare (HIP's __ballot(int) goes through a 0 / 1 integer and a second compare)
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 #ifndef UVO_FAST_WAVES
 #define UVO_FAST_WAVES 4       // wavefronts (regions) per workgroup
 #endif
@@ -134,13 +137,11 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
     // corner at t  <=>  some 9-arc has all diffs > t (brighter) or all < -t (darker)  <=>  max(sb, sd) > t;
     // cornerScore = max(sb, sd) - 1.  No masks, no divergent branches.
     const int best = max((int)arc9_maxmin(d), -(int)arc9_minmax(d));
-    if (best > t_min) {
-      const int sc = best - 1;
-      corner = sc > 0;  // a score of 0 (only possible at t_min = 0) can never survive NMS nor suppress anything
-      packed = (uint32_t)xl | ((uint32_t)rrp << 8) | ((uint32_t)sc << 16);
-    }
+    // a score of 0 (only possible at t_min = 0) can never survive NMS nor suppress anything: one compare against max(t_min, 1)
+    corner = best > (t_min > 1 ? t_min : 1);
+    packed = (uint32_t)xl | ((uint32_t)rrp << 8) | ((uint32_t)(best - 1) << 16);
   }
-  const uint64_t m = __ballot(corner);
+  const uint64_t m = ballot64(corner);
   if (m) {
     const int add = (int)__popcll(m);
     if (ncorner + add > FL_CAP) {  // wave-uniform, rare: the LDS list is flushed to the region's slice in memory and starts again
@@ -202,7 +203,10 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
     const int xs = ls * 4 + K;
     okv[K] = nrows_l > 0 && xs >= 3 && xs <= sub_px - 4 && X + K >= 32 && X + K < g.w;
   }
-  const uint32_t mk0 = okv[0] ? 0x0000ffffu : 0u, mk1 = okv[1] ? 0x0000ffffu : 0u, mk2 = okv[2] ? 0xffff0000u : 0u, mk3 = okv[3] ? 0xffff0000u : 0u;
+  uint32_t mk0 = okv[0] ? 0x0000ffffu : 0u, mk1 = okv[1] ? 0x0000ffffu : 0u, mk2 = okv[2] ? 0xffff0000u : 0u, mk3 = okv[3] ? 0xffff0000u : 0u;
+  // (opaque to the optimiser, which would otherwise turn `(x & mk) != 0` back into a compare AND a lane flag -- two mask
+  // operations and a 0 / 1 round trip through a register instead of one AND and one compare)
+  asm volatile("" : "+v"(mk0), "+v"(mk1), "+v"(mk2), "+v"(mk3));
   const uint32_t t_even = (uint32_t)t_min * 0x00010001u, t_odd = t_even << 8;
 
   // Row loads run one unrolled block (7 rows) ahead of their use so that a wavefront never waits on the row it needs next.
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
 #define UVO_FAST_PUSH(K, COND)                                                                                    \
   {                                                                                                               \
     const bool pass = (COND);                                                                                     \
-    const uint64_t m = __ballot(pass);                                                                            \
+    const uint64_t m = ballot64(pass);                                                                            \
     if (m) {                                                                                                      \
       if (qn == 0) qoldest = jc;                                                                                  \
       if (pass)                                                                                                   \
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
       // in-place compaction: survivors land at or before the start of the group that was just read
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
-        const uint64_t m = __ballot(keep[u]);
+        const uint64_t m = ballot64(keep[u]);
         if (m) {
           if (keep[u]) C[nkeep + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = out[u];
           nkeep += (int)__popcll(m);
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
     for (int base = 0; base < nkeep; base += 64) {
       const bool valid = base + lane < nkeep;
       const uint32_t e = valid ? C[base + lane] : 0u;
-      n_hi += (int)__popcll(__ballot(valid && (int)(e >> 24) >= fast_th));
+      n_hi += (int)__popcll(ballot64(valid && (int)(e >> 24) >= fast_th));
     }
     const int n_lo = nkeep - n_hi;
     int32_t* cur = cursor + 2 * ((int64_t)f * L.nlevels + level);
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
       const bool valid = base + lane < nkeep;
       const uint32_t e = valid ? C[base + lane] : 0u;
       const bool is_hi = valid && (int)(e >> 24) >= fast_th, is_lo = valid && !is_hi;
-      const uint64_t mh = __ballot(is_hi), ml = __ballot(is_lo);
+      const uint64_t mh = ballot64(is_hi), ml = ballot64(is_lo);
       if (is_hi) {
         const int pos = off_hi + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mh, 0u));
         if (pos < g.cand_cap) {
