@@ -117,17 +117,19 @@ __device__ __noinline__ void flush_corner_list(const uint32_t* list, uint32_t* d
 // Full segment test + cornerScore of the queued pixels [first, first+count), one per lane.  The 16 ring pixels are read
 // back from the wavefront's LDS row ring: the queue entry carries the byte address of the pixel in the ring (rows 0..5 are
 // mirrored into slots 16..21, so the seven rows around any centre are consecutive slots and every read is base + immediate).
-// entry = ring byte address | xl << 13 | (row - py0 + 1) << 21.  Corners go to the wavefront's list as xl | row' << 8 | score << 16.
+// entry = byte address of (pixel - 3 rows - 3 columns) in the workgroup's LDS block | xl << 15 | (row - py0 + 1) << 23.  Corners go to the wavefront's list as xl | row' << 8 | score << 16.
 __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_t* rows, int first, int count, int lane, int t_min,
                                                  uint32_t* list, uint32_t* __restrict__ region, int& ncorner, int& nflushed) {
   bool corner = false;
   uint32_t packed = 0;
   if (lane < count) {
     const uint32_t meta = q[first + lane];
-    const int xl = (int)((meta >> 13) & 0xff), rrp = (int)(meta >> 21);
+    const int xl = (int)((meta >> 15) & 0xff), rrp = (int)(meta >> 23);
     constexpr int RB = FR_PITCH * 4;
-    const uint8_t* r0 = rows + (meta & 0x1fffu) - 3;  // 3 bytes left of the pixel
-    const uint8_t *rp1 = r0 + RB, *rp2 = r0 + 2 * RB, *rp3 = r0 + 3 * RB, *rm1 = r0 - RB, *rm2 = r0 - 2 * RB, *rm3 = r0 - 3 * RB;
+    // the entry's address field points 3 rows above and 3 bytes left of the pixel, relative to the workgroup's LDS block: every ring
+    // pixel is that one register + an immediate offset
+    const uint8_t* rm3 = rows + (meta & 0x7fffu);
+    const uint8_t *rm2 = rm3 + RB, *rm1 = rm3 + 2 * RB, *r0 = rm3 + 3 * RB, *rp1 = rm3 + 4 * RB, *rp2 = rm3 + 5 * RB, *rp3 = rm3 + 6 * RB;
     const d16 v = (d16)r0[3];
     d16 d[16];
     d[0] = rp3[3], d[1] = rp3[4], d[2] = rp2[5], d[3] = rp1[6], d[4] = r0[6], d[5] = rm1[6], d[6] = rm2[5], d[7] = rm3[4];
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   const int wv = wave_in_block(), lane = threadIdx.x & 63;
   uint32_t* rows32 = s_mem[wv];
   uint32_t* q = rows32 + FW_RING_DW;
-  const uint8_t* rows8 = reinterpret_cast<const uint8_t*>(rows32);
+  const uint8_t* rows8 = reinterpret_cast<const uint8_t*>(&s_mem[0][0]);  // queue entries address the ring relative to the workgroup's block
   // work item (one per wavefront) -> (level, strip, segment); window = padded cols [32, w) x rows [32, h)
   const int vb = xcd_contiguous((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
   const int item = (vb % (int)gridDim.x) * UVO_FAST_WAVES + wv, f = vb / (int)gridDim.x;  // an XCD walks whole frames, region after region
@@ -215,7 +217,8 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
     const int r = min(py0l - 4 + j, last_row);  // rows past the plane belong to a sub-strip below the level: never used
     return *reinterpret_cast<const uint32_t*>(src + (int64_t)r * g.pitch + Xc);
   };
-  const uint32_t lane_entry = (uint32_t)(lane * 4) * ((1u << 13) + 1u);
+  // address part (this wavefront's ring + the lane's first pixel - 3 rows - 3 columns; the row part added per row makes it >= 0) + xl part
+  const uint32_t lane_entry = (uint32_t)(wv * FW_DWORDS * 4 + lane * 4 - 3 * FR_PITCH * 4 - 3) + ((uint32_t)(lane * 4) << 15);
   uint32_t Cr[7], nxt[7];
 #pragma unroll
   for (int u = 0; u < 7; ++u) nxt[u] = u < nsrc ? load_row(u) : 0u;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
             const uint32_t* r2 = rc + 2 * FR_PITCH;
             const uint32_t* rm = rc - 2 * FR_PITCH;
             const uint32_t Lc = rc[lm], Rc = rc[lp], L2 = r2[lm], R2 = r2[lp], Lm2 = rm[lm], Rm2 = rm[lp];
-            const uint32_t row_entry = (uint32_t)(cslot * (FR_PITCH * 4)) | ((uint32_t)rrp << 21);
+            const uint32_t row_entry = (uint32_t)(cslot * (FR_PITCH * 4)) | ((uint32_t)rrp << 23);
             // ---- screen the lane's 4 pixels with four opposite ring pairs, queue the ones that pass ----
             // Packed 16-bit arithmetic, two pixels per instruction: the even bytes of a pixel dword sit in the two 16-bit
             // halves as they are (x & 0x00ff00ff), the odd bytes scaled by 256 (x & 0xff00ff00); all compares are unsigned.
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
       if (qn == 0) qoldest = jc;                                                                                  \
       if (pass)                                                                                                   \
         q[qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = \
-            lane_entry + (row_entry + (uint32_t)K * ((1u << 13) + 1u));                                           \
+            lane_entry + (row_entry + (uint32_t)K * ((1u << 15) + 1u));                                           \
       qn += __popcll(m);                                                                                          \
     }                                                                                                             \
   }
