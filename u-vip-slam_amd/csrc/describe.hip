@@ -276,28 +276,32 @@ __global__ __launch_bounds__(256, UVO_OCC_DESCRIBE) void k_describe(const LevelG
       kp[k].octave = level;
       kp[k].class_id = -1;
     }
-    const LevelGeom& g = lv[level];
+    const LevelGeom& g = lv[__builtin_amdgcn_readfirstlane(level)];
     pitch[k] = g.pitch;
     scale[k] = g.scale;
     rescale[k] = !is_input && level != 0;
-    const int cx = cv_round(kp[k].x), cy = cv_round(kp[k].y);
+    // (every lane holds the same keypoint; saying so puts the addresses below into scalar registers)
+    const int cx = __builtin_amdgcn_readfirstlane(cv_round(kp[k].x)), cy = __builtin_amdgcn_readfirstlane(cv_round(kp[k].y));
     center_off[k] = f * pyr_block + g.plane_off + (int64_t)(cy + kPad) * g.pitch + (cx + kPad);
+    // Addresses = a wave-uniform base (18 rows above and 18 bytes left of the keypoint: the corner of the blurred window, which the
+    // loads below reach anyway) + a non-negative 32-bit lane offset: one multiply-add per load instead of 64-bit arithmetic per lane.
+    const int64_t corner_off = center_off[k] - (int64_t)18 * g.pitch - 18;
     // IC_Angle: the circular patch (rows v in [-15,15], |u| <= umax[|v|]) is read as 31 rows x 8 dwords starting at u = -16;
     // a table masks the bytes outside the circle (slots 248..255 = "row 31" are masked out entirely)
-    const uint8_t* center = pyr + center_off[k];
+    const uint8_t* pcorner = pyr + corner_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int vr = vv[i] <= 15 ? vv[i] : 15;  // keep the (masked) load of row 31 inside the plane
       uint32_t d;
-      __builtin_memcpy(&d, center + (int64_t)vr * pitch[k] + u0[i], 4);
+      __builtin_memcpy(&d, pcorner + (uint32_t)((vr + 18) * pitch[k] + (u0[i] + 18)), 4);
       px[k][i] = d & pmask[i];
     }
     // blurred window: coalesced row segments (6 rows per load instruction) instead of 512 scattered byte gathers
-    const uint8_t* bcen = blur + center_off[k];
+    const uint8_t* bcorner = blur + corner_off;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       uint32_t d;
-      __builtin_memcpy(&d, bcen + (int64_t)wrow[i] * pitch[k] + wcol[i], 4);
+      __builtin_memcpy(&d, bcorner + (uint32_t)((wrow[i] + 18) * pitch[k] + (wcol[i] + 18)), 4);
       wv[k][i] = d;
     }
   }
