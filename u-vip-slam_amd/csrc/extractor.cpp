@@ -222,7 +222,7 @@ static int build_geom(const uvo_extractor* h, int width, int height, Geom& g, st
     L.scale = h->scale[l];
     L.patch_size = (float)(int)(31 * h->scale[l]);
     L.xtab_off = xt, L.ytab_off = yt;
-    if (l > 0) xt += L.pitch, yt += L.ph;
+    if (l > 0) xt += L.pitch, yt += (L.ph + 3) & ~3;  // row tables are padded to whole groups of 4 rows (k_resize_level reads a group at once)
   }
   g.total_cells = (int)cells.size();
   g.pyr_block = off;
@@ -283,7 +283,7 @@ static void build_resize_tables(const Geom& g, std::vector<ResizeCol>& ctab, std
       e[0].pad = (uint16_t)base, e[1].pad = (uint16_t)(sel & 0xffff), e[2].pad = (uint16_t)(sel >> 16), e[3].pad = 0;
       for (int i = 0; i < 4; ++i) ctab.push_back(e[i]);
     }
-    for (int py = 0; py < g.lv[l].ph; ++py) rtab.push_back(row[reflect101_host(py - kPad, dh)]);
+    for (int py = 0; py < ((g.lv[l].ph + 3) & ~3); ++py) rtab.push_back(row[reflect101_host(std::min(py, g.lv[l].ph - 1) - kPad, dh)]);  // padded to groups of 4
   }
 }
 
@@ -489,7 +489,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   h->cap_sel_block = g.sel_block;
   h->cap_flist = g.flist_cap;
   h->cap_xtab = 0, h->cap_ytab = 0;
-  for (int l = 1; l < g.nlevels; ++l) h->cap_xtab += g.lv[l].pitch + 64, h->cap_ytab += g.lv[l].ph + 1;
+  for (int l = 1; l < g.nlevels; ++l) h->cap_xtab += g.lv[l].pitch + 64, h->cap_ytab += g.lv[l].ph + 8;  // (row tables are padded to groups of 4 rows; smaller images of the same area have other level heights)
   const size_t B = (size_t)cfg->max_batch;
   hipError_t e = hipSetDevice(h->device);
   if (e != hipSuccess) {

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
   const float c0 = (float)taps.x * (1.0f / 65536.0f), c1 = (float)taps.y * (1.0f / 65536.0f), c2 = (float)taps.z * (1.0f / 65536.0f),
               c3 = (float)taps.w * (1.0f / 65536.0f);
   __builtin_amdgcn_s_setreg(0x801, 3);  // MODE.fp_round[1:0] (fp32) = toward zero: nothing below rounds except the final float -> byte conversion
+  const int lane_up = (lane > 0 ? lane - 1 : lane) * 4, lane_down = (lane < 63 ? lane + 1 : lane) * 4;  // ds_bpermute byte addresses
   float hring[7][4];
   uint32_t cring[7];
   // Row loads are issued one unrolled block (7 rows) ahead of their use: a wavefront walks ~70 rows one after another, so
@@ -108,8 +109,8 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
       const int j = base + u;
       if (j < nsrc) {
         const uint32_t C = cur[u];
-        const uint32_t L = (uint32_t)__shfl_up((int)C, 1, 64);
-        const uint32_t R = (uint32_t)__shfl_down((int)C, 1, 64);
+        const uint32_t L = (uint32_t)__builtin_amdgcn_ds_bpermute(lane_up, (int)C);    // the neighbours' dwords: source lanes fixed for the
+        const uint32_t R = (uint32_t)__builtin_amdgcn_ds_bpermute(lane_down, (int)C);  // whole strip (__shfl_up / _down recompute them per call)
         gauss_row_pass(L, C, R, T1, T2, hring[u]);
         cring[u] = C;
         if (j >= 6) {

@@ -121,13 +121,21 @@ __global__ __launch_bounds__(256, UVO_OCC_RESIZE) void k_resize_level(uint8_t* _
   const bool interior = fast_ok != 0;
   const uint32_t base = cw[1] >> 16;
   const uint32_t sel = (cw[3] >> 16) | (cw[5] & 0xffff0000u);
+  // the row group's four table entries in two 16-byte loads (the table is padded to whole groups), then all eight source rows at once:
+  // nothing here waits for anything but the two table fetches
+  static_assert(RZ_ROWS == 4 && sizeof(ResizeRow) == 8, "the row group is read as 2 x uint4");
+  const uint4 t01 = reinterpret_cast<const uint4*>(rtab)[rg * 2], t23 = reinterpret_cast<const uint4*>(rtab)[rg * 2 + 1];
+  const uint32_t tw[8] = {t01.x, t01.y, t01.z, t01.w, t23.x, t23.y, t23.z, t23.w};
   ResizeRow rr[RZ_ROWS];
   uint32_t u[RZ_ROWS][3], w[RZ_ROWS][3];
 #pragma unroll
   for (int j = 0; j < RZ_ROWS; ++j) {
-    const int py = py0 + j < dst_ph ? py0 + j : dst_ph - 1;  // rows past the plane repeat the last one and are not stored
-    rr[j] = rtab[py];
-    if (interior) {
+    rr[j].sy0 = (int16_t)(tw[2 * j] & 0xffffu), rr[j].sy1 = (int16_t)(tw[2 * j] >> 16);
+    rr[j].b0 = (int16_t)(tw[2 * j + 1] & 0xffffu), rr[j].b1 = (int16_t)(tw[2 * j + 1] >> 16);
+  }
+  if (interior) {
+#pragma unroll
+    for (int j = 0; j < RZ_ROWS; ++j) {
       const uint32_t* p0 = reinterpret_cast<const uint32_t*>(S + (int64_t)rr[j].sy0 * src_pitch + base);
       const uint32_t* p1 = reinterpret_cast<const uint32_t*>(S + (int64_t)rr[j].sy1 * src_pitch + base);
       u[j][0] = p0[0], u[j][1] = p0[1], u[j][2] = p0[2];
