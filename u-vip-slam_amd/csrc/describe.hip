@@ -257,44 +257,52 @@ __global__ __launch_bounds__(256, UVO_OCC_DESCRIBE) void k_describe(const LevelG
     u0[i] = -16 + 4 * (slot & 7);
     pmask[i] = patch[slot];
   }
-  // ---- stage A: slot -> keypoint, issue the patch loads ----
+  // ---- stage A: slot -> keypoint -> level geometry -> the patch / window loads.  Three dependent fetches per keypoint; written as
+  // three passes over the group so that the four keypoints' fetches of a pass are in flight together (as one loop over the keypoints
+  // the compiler chains them: every scalar load drains the previous keypoint's) ----
+  FinalSlot fs[DK_PER_WAVE];
 #pragma unroll
   for (int k = 0; k < DK_PER_WAVE; ++k) {
     live[k] = slot0 + k < n;
     const int slot = live[k] ? slot0 + k : slot0;  // dead entries repeat the first slot and are never stored
-    const FinalSlot fs = flist[(int64_t)f * flist_cap + slot];
-    const bool is_input = fs.level < 0;
-    int level;
-    if (is_input) {
-      kp[k] = in_kp[(int64_t)f * in_cap + fs.aux];
-      level = 0;
+    fs[k] = flist[(int64_t)f * flist_cap + slot];
+  }
+  int level[DK_PER_WAVE];
+  bool is_input[DK_PER_WAVE];
+#pragma unroll
+  for (int k = 0; k < DK_PER_WAVE; ++k) {
+    is_input[k] = fs[k].level < 0;
+    level[k] = __builtin_amdgcn_readfirstlane(is_input[k] ? 0 : fs[k].level);
+    if (is_input[k]) {
+      kp[k] = in_kp[(int64_t)f * in_cap + fs[k].aux];
     } else {
-      level = fs.level;
-      kp[k].x = fs.x, kp[k].y = fs.y;
-      kp[k].size = lv[level].patch_size;
-      kp[k].response = (float)fs.aux;
-      kp[k].octave = level;
+      kp[k].x = fs[k].x, kp[k].y = fs[k].y;
+      kp[k].response = (float)fs[k].aux;
+      kp[k].octave = level[k];
       kp[k].class_id = -1;
     }
-    const LevelGeom& g = lv[__builtin_amdgcn_readfirstlane(level)];
+    const LevelGeom& g = lv[level[k]];
     pitch[k] = g.pitch;
     scale[k] = g.scale;
-    rescale[k] = !is_input && level != 0;
+    if (!is_input[k]) kp[k].size = g.patch_size;
+    rescale[k] = !is_input[k] && level[k] != 0;
+    center_off[k] = f * pyr_block + g.plane_off;  // completed below
+  }
+#pragma unroll
+  for (int k = 0; k < DK_PER_WAVE; ++k) {
     // (every lane holds the same keypoint; saying so puts the addresses below into scalar registers)
     const int cx = __builtin_amdgcn_readfirstlane(cv_round(kp[k].x)), cy = __builtin_amdgcn_readfirstlane(cv_round(kp[k].y));
-    center_off[k] = f * pyr_block + g.plane_off + (int64_t)(cy + kPad) * g.pitch + (cx + kPad);
+    center_off[k] += (int64_t)(cy + kPad) * pitch[k] + (cx + kPad);
     // Addresses = a wave-uniform base (18 rows above and 18 bytes left of the keypoint: the corner of the blurred window, which the
     // loads below reach anyway) + a non-negative 32-bit lane offset: one multiply-add per load instead of 64-bit arithmetic per lane.
-    const int64_t corner_off = center_off[k] - (int64_t)18 * g.pitch - 18;
+    const int64_t corner_off = center_off[k] - (int64_t)18 * pitch[k] - 18;
     // IC_Angle: the circular patch (rows v in [-15,15], |u| <= umax[|v|]) is read as 31 rows x 8 dwords starting at u = -16;
-    // a table masks the bytes outside the circle (slots 248..255 = "row 31" are masked out entirely)
+    // a table masks the bytes outside the circle (slots 248..255 = "row 31" are masked out entirely) -- applied in stage B
     const uint8_t* pcorner = pyr + corner_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int vr = vv[i] <= 15 ? vv[i] : 15;  // keep the (masked) load of row 31 inside the plane
-      uint32_t d;
-      __builtin_memcpy(&d, pcorner + (uint32_t)((vr + 18) * pitch[k] + (u0[i] + 18)), 4);
-      px[k][i] = d & pmask[i];
+      __builtin_memcpy(&px[k][i], pcorner + (uint32_t)((vr + 18) * pitch[k] + (u0[i] + 18)), 4);
     }
     // blurred window: coalesced row segments (6 rows per load instruction) instead of 512 scattered byte gathers
     const uint8_t* bcorner = blur + corner_off;
@@ -327,8 +335,9 @@ __global__ __launch_bounds__(256, UVO_OCC_DESCRIBE) void k_describe(const LevelG
     int m01 = 0, m10 = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int sum = (int)__builtin_amdgcn_udot4(px[k][i], 0x01010101u, 0u, false);
-      const int wsum = (int)__builtin_amdgcn_udot4(px[k][i], 0x03020100u, 0u, false);
+      const uint32_t pm = px[k][i] & pmask[i];  // the bytes of this dword inside the circle
+      const int sum = (int)__builtin_amdgcn_udot4(pm, 0x01010101u, 0u, false);
+      const int wsum = (int)__builtin_amdgcn_udot4(pm, 0x03020100u, 0u, false);
       m10 += u0[i] * sum + wsum;
       m01 += vv[i] * sum;
     }
