@@ -128,11 +128,15 @@ __global__ __launch_bounds__(256, UVO_OCC_KNN) void k_knn2_mfma(const uint8_t* _
   }
   int k0 = 0x7fffffff, k1 = 0x7fffffff;  // two smallest keys ((pop(t) - 2 dot) << 16 | train index), signed
   const int erow = threadIdx.x >> 3, ec = threadIdx.x & 7;  // expansion: thread -> (train row of the tile, 32-bit chunk)
+  // the next tile's word is fetched while this tile is expanded and multiplied: a workgroup walks ~30 tiles one after another, and
+  // without the prefetch every one of them exposes a full memory round trip
+  uint32_t wnext = erow < nt ? T[(int64_t)erow * 8 + ec] : 0u;
   for (int base = 0; base < nt; base += 32) {
     __syncthreads();
     {
       const int tr = base + erow;
-      const uint32_t w = tr < nt ? T[(int64_t)tr * 8 + ec] : 0u;
+      const uint32_t w = wnext;
+      wnext = tr + 32 < nt ? T[(int64_t)(tr + 32) * 8 + ec] : 0u;
       v4i* dst = reinterpret_cast<v4i*>(s_exp + erow * KM_ROW + ec * 32);
       dst[0] = spread16(w), dst[1] = spread16(w >> 16);
       int pc = __popc(w);  // pop(t) of the row: sum over its 8 chunk threads (adjacent lanes)
