@@ -221,13 +221,14 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   const uint32_t lane_entry = (uint32_t)(wv * FW_DWORDS * 4 + lane * 4 - 3 * FR_PITCH * 4 - 3) + ((uint32_t)(lane * 4) << 15);
   uint32_t Cr[7], nxt[7];
 #pragma unroll
-  for (int u = 0; u < 7; ++u) nxt[u] = u < nsrc ? load_row(u) : 0u;
+  for (int u = 0; u < 7; ++u) nxt[u] = load_row(u);  // unconditional (the row index is clamped into the plane): with a branch around a load
+                                                     // the compiler cannot count the loads in flight and waits for all of them
   for (int base = 0; base < nsrc; base += 7) {
     uint32_t cur[7];
 #pragma unroll
     for (int u = 0; u < 7; ++u) cur[u] = nxt[u];
 #pragma unroll
-    for (int u = 0; u < 7; ++u) nxt[u] = base + 7 + u < nsrc ? load_row(base + 7 + u) : 0u;
+    for (int u = 0; u < 7; ++u) nxt[u] = load_row(base + 7 + u);
 #pragma unroll
     for (int u = 0; u < 7; ++u) {
       const int j = base + u;

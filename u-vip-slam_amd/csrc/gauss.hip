@@ -100,10 +100,11 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
   };
   uint32_t cur[7], nxt[7];
 #pragma unroll
-  for (int u = 0; u < 7; ++u) cur[u] = u < nsrc ? load_row(u) : 0u;
+  for (int u = 0; u < 7; ++u) cur[u] = load_row(u);  // unconditional (the row index is clamped into the plane): with a branch around a load
+                                                     // the compiler cannot count the loads in flight and waits for all of them
   for (int base = 0; base < nsrc; base += 7) {
 #pragma unroll
-    for (int u = 0; u < 7; ++u) nxt[u] = base + 7 + u < nsrc ? load_row(base + 7 + u) : 0u;
+    for (int u = 0; u < 7; ++u) nxt[u] = load_row(base + 7 + u);
 #pragma unroll
     for (int u = 0; u < 7; ++u) {
       const int j = base + u;
