@@ -619,7 +619,7 @@ def main():
             traffic = int(traffic * (B + 1) / pmc_frames) if traffic else traffic
             valu_instr = valu_instr * (B + 1) / pmc_frames if valu_instr else valu_instr
         hbm_frac = achieved / HBM_PEAK_GBS
-        roof_hbm = {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 5),
+        roof_hbm = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(bytes_per_launch), "measured_device_copy_GBps": sub.get("device_copy_GBps")}
         roof = dict(roof_hbm)
         bound = "hbm"
