@@ -835,18 +835,35 @@ static int extract_batch_impl(uvo_extractor* h, int batch, const uint8_t* imgs, 
                             topup ? h->d_nfn : nullptr, h->d_out_kp, h->d_out_desc, dcap, h->d_n_out);
   if (rc) return rc;
   if (bounce) {
-    // the stream is in order: the keypoint uploads above were consumed before the outputs land in the same pinned region
+    // Small batches: the counts, the grid and every frame's whole result slice (dcap records: a frame rarely fills less than 90 % of it)
+    // come back in one go -- one synchronisation per call instead of one for the counts and a second for the records they size.
+    // The stream is in order: the keypoint uploads above were consumed before the outputs land in the same pinned region.
     UVO_HIP_CHECK(hipMemcpyAsync(pin_i, h->d_n_out, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
     if (topup && grid2d) UVO_HIP_CHECK(hipMemcpyAsync(h->h_pin + off_grid, h->d_grid, gb, hipMemcpyDeviceToHost, s));
+    uint8_t* const pkp = h->h_pin + off_kp;
+    uint8_t* const pde = pkp + (size_t)batch * dcap * sizeof(uvo_keypoint);
+    UVO_HIP_CHECK(hipMemcpyAsync(pkp, h->d_out_kp, (size_t)batch * dcap * sizeof(uvo_keypoint), hipMemcpyDeviceToHost, s));
+    UVO_HIP_CHECK(hipMemcpyAsync(pde, h->d_out_desc, (size_t)batch * dcap * 32, hipMemcpyDeviceToHost, s));
     UVO_HIP_CHECK(hipStreamSynchronize(s));
     std::memcpy(n_out, pin_i, sizeof(int32_t) * batch);
     if (topup && grid2d) std::memcpy(grid2d, h->h_pin + off_grid, gb);
-  } else {
-    UVO_HIP_CHECK(hipMemcpyAsync(n_out, h->d_n_out, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
-    UVO_HIP_CHECK(hipStreamSynchronize(s));
+    int status = UVO_OK;
+    for (int b = 0; b < batch; ++b) {
+      int n = n_out[b];
+      if (n > cap) {
+        status = fail(UVO_E_CAPACITY, "output capacity too small; n_out holds the required size");
+        n = cap;
+      }
+      n = std::min(n, dcap);
+      if (n <= 0) continue;
+      std::memcpy(out_kp + (size_t)b * cap, pkp + (size_t)b * dcap * sizeof(uvo_keypoint), sizeof(uvo_keypoint) * n);
+      std::memcpy(out_desc + (size_t)b * cap * 32, pde + (size_t)b * dcap * 32, (size_t)32 * n);
+    }
+    return status;
   }
+  UVO_HIP_CHECK(hipMemcpyAsync(n_out, h->d_n_out, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+  UVO_HIP_CHECK(hipStreamSynchronize(s));
   int status = UVO_OK;
-  uint8_t* pout = h->h_pin + off_kp;
   for (int b = 0; b < batch; ++b) {
     int n = n_out[b];
     if (n > cap) {
@@ -854,27 +871,11 @@ static int extract_batch_impl(uvo_extractor* h, int batch, const uint8_t* imgs, 
       n = cap;
     }
     if (n <= 0) continue;
-    if (bounce) {
-      UVO_HIP_CHECK(hipMemcpyAsync(pout, h->d_out_kp + (size_t)b * dcap, sizeof(uvo_keypoint) * n, hipMemcpyDeviceToHost, s));
-      UVO_HIP_CHECK(hipMemcpyAsync(pout + sizeof(uvo_keypoint) * n, h->d_out_desc + (size_t)b * dcap * 32, (size_t)32 * n, hipMemcpyDeviceToHost, s));
-      pout += (sizeof(uvo_keypoint) + 32) * (size_t)n;
-    } else {
-      UVO_HIP_CHECK(hipMemcpyAsync(out_kp + (size_t)b * cap, h->d_out_kp + (size_t)b * dcap, sizeof(uvo_keypoint) * n, hipMemcpyDeviceToHost, s));
-      UVO_HIP_CHECK(hipMemcpyAsync(out_desc + (size_t)b * cap * 32, h->d_out_desc + (size_t)b * dcap * 32, (size_t)32 * n, hipMemcpyDeviceToHost, s));
-    }
+    UVO_HIP_CHECK(hipMemcpyAsync(out_kp + (size_t)b * cap, h->d_out_kp + (size_t)b * dcap, sizeof(uvo_keypoint) * n, hipMemcpyDeviceToHost, s));
+    UVO_HIP_CHECK(hipMemcpyAsync(out_desc + (size_t)b * cap * 32, h->d_out_desc + (size_t)b * dcap * 32, (size_t)32 * n, hipMemcpyDeviceToHost, s));
   }
-  if (!bounce && topup && grid2d) UVO_HIP_CHECK(hipMemcpyAsync(grid2d, h->d_grid, gb, hipMemcpyDeviceToHost, s));
+  if (topup && grid2d) UVO_HIP_CHECK(hipMemcpyAsync(grid2d, h->d_grid, gb, hipMemcpyDeviceToHost, s));
   UVO_HIP_CHECK(hipStreamSynchronize(s));
-  if (bounce) {
-    pout = h->h_pin + off_kp;
-    for (int b = 0; b < batch; ++b) {
-      const int n = std::min(n_out[b], cap);
-      if (n <= 0) continue;
-      std::memcpy(out_kp + (size_t)b * cap, pout, sizeof(uvo_keypoint) * n);
-      std::memcpy(out_desc + (size_t)b * cap * 32, pout + sizeof(uvo_keypoint) * n, (size_t)32 * n);
-      pout += (sizeof(uvo_keypoint) + 32) * (size_t)n;
-    }
-  }
   return status;
 }
 
