@@ -95,6 +95,15 @@ def test_configs2_throughput_path_every_frame_vs_oracle(uvo, oracle, synth, batc
     _check_against_oracle(uvo, oracle, frames, 1000, 20, res, "configs[2] batch %d" % batch, 1000)
 
 
+def test_corner_rich_frames_at_scale_every_frame_vs_oracle(uvo, oracle, synth):
+    """The round-2 generator's frames (noise accumulating along a chain: up to 18 % of the pixels pass as FAST corners, 1100 per
+    248 x 24 region): nearly every region of k_fast_score overflows its LDS corner list and finishes its non-max suppression out of
+    memory, the quad-tree gathers 50 000 candidates per frame -- the paths the sensor-noise frames of the test above leave cold."""
+    frames = synth.make_sequence(0, 96, 640, 512, noise="cumulative")
+    res = _run_bench_path(uvo, frames, 1000, 20)
+    _check_against_oracle(uvo, oracle, frames, 1000, 20, res, "corner-rich batch 96", 1000)
+
+
 def test_configs3_hd_share_of_one_gpu_every_frame_vs_oracle(uvo, oracle, synth):
     """BASELINE.json configs[3]: 1920x1080 @ 2000 features, 128 frames per GPU (two quad-tree roots per level, 6594 FAST cells)."""
     frames = synth.make_sequence(0, 128, 1920, 1080, n_shapes=2500)
