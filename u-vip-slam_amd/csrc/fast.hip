@@ -98,7 +98,7 @@ __device__ __forceinline__ uint32_t screen2(uint32_t v, uint32_t p0, uint32_t p8
   const u16x2 hi = __builtin_elementwise_add_sat(pk(v), pk(t2)), lo = __builtin_elementwise_sub_sat(pk(v), pk(t2));
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mx, hi)) | __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(lo, mn));
 }
-constexpr uint32_t kEven = 0x00ff00ffu, kOdd = 0xff00ff00u;
+constexpr uint32_t kEven = 0x00ff00ffu;
 
 constexpr int FR_ROWS = 16;         // LDS row ring depth per wavefront
 constexpr int FR_MIRROR = 6;        // ring slots 0..5 are mirrored into slots 16..21 (see fast_score_chunk)

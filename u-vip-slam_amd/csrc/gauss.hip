@@ -21,7 +21,6 @@
 
 namespace uvo {
 
-constexpr int GS_COLS = FS_COLS;  // useful columns per wavefront strip (the strip plan of fast_geom.hpp is shared)
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 pk(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
 

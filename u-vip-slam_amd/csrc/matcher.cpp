@@ -342,7 +342,7 @@ int uvo_search_points_in_frustum(uvo_matcher* m, const uvo_keypoint* kp, int n, 
   UVO_HIP_CHECK(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, s));
   uint8_t* d_valid = D + o_valid;
   float *d_u = (float*)(D + o_u), *d_v = (float*)(D + o_v), *d_vc = (float*)(D + o_vc);
-  int32_t *d_lvl = (int32_t*)(D + o_lvl), *d_asg = (int32_t*)(D + o_asg), *d_tail = (int32_t*)(D + o_tail);
+  int32_t *d_lvl = (int32_t*)(D + o_lvl), *d_asg = (int32_t*)(D + o_asg);
   const float* d_sf = (const float*)(D + o_sf);
   {
     Profiler::Scope ps(&m->prof, "k_project", s);
