@@ -296,6 +296,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--fast-mode", choices=["adaptive", "two_pass", "single_pass"], default="adaptive",
+                    help="UVO_TUNE_FAST_MODE of the extractor (speed only; the keypoints are the same in every mode)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     W, H, NFEAT = cfg["W"], cfg["H"], cfg["nfeat"]
@@ -356,6 +358,8 @@ def main():
     DEPTH = int(os.environ.get("UVO_PIPELINE_DEPTH", "2"))
     outs = [Out() for _ in range(DEPTH)]
     ex.set_pipeline(DEPTH)
+    ex.tune(uvo.UVO_TUNE_FAST_MODE, {"adaptive": uvo.UVO_FAST_MODE_ADAPTIVE, "two_pass": uvo.UVO_FAST_MODE_TWO_PASS,
+                                     "single_pass": uvo.UVO_FAST_MODE_SINGLE_PASS}[args.fast_mode])
     if os.environ.get("UVO_BENCH_OCT_WIDE_MAX"):   # experiment knob: quad-tree launch shape (uvo_extractor_tune)
         ex.tune(uvo.UVO_TUNE_OCT_WIDE_MAX, int(os.environ["UVO_BENCH_OCT_WIDE_MAX"]))
     torch.cuda.synchronize()

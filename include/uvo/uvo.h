@@ -208,7 +208,27 @@ int uvo_extractor_set_pipeline(uvo_extractor* h, int depth);
  *                           (default 256; 0 = always the 256-thread form, a large value = always the 1024-thread form).
  */
 #define UVO_TUNE_OCT_WIDE_MAX 1
+/*
+ *   UVO_TUNE_FAST_MODE    : how the per-cell threshold fallback of src/ORBextractor.cc:792-799 (`FAST(cell, fastTh)`, and
+ *                           `FAST(cell, 7)` when that finds nothing) is computed when fastTh > 7.
+ *                           UVO_FAST_MODE_TWO_PASS    every level streams once at fastTh; the cells left without a keypoint are
+ *                                                     redone at the literal 7 by a sparse per-cell kernel;
+ *                           UVO_FAST_MODE_SINGLE_PASS every level streams once at 7 and the per-cell vote picks the class;
+ *                           UVO_FAST_MODE_ADAPTIVE    (default) per level and pipeline lane, whichever was cheaper for the previous
+ *                                                     batch's share of fall-back cells (decided on the device, no host round trip).
+ *                           The keypoints are the same in every mode.
+ */
+#define UVO_TUNE_FAST_MODE 2
+#define UVO_FAST_MODE_ADAPTIVE 0
+#define UVO_FAST_MODE_TWO_PASS 1
+#define UVO_FAST_MODE_SINGLE_PASS 2
 int uvo_extractor_tune(uvo_extractor* h, int knob, int value);
+/*
+ * State of the adaptive FAST mode after the most recent batch (waits for it): per level the threshold the NEXT batch on that
+ * pipeline lane streams at (fastTh = two-pass form, <= 7 = single pass), the fall-back cells the last batch counted (cells without a
+ * keypoint at fastTh, summed over its frames) and the level's cells per frame.  Arrays of uvo_extractor_levels() entries; any may be NULL.
+ */
+int uvo_extractor_fast_state(uvo_extractor* h, int32_t* pass_threshold, int32_t* fallback_cells, int32_t* cells_per_frame);
 
 /*
  * Grid-bucketed FAST -- Grider_FAST::perform_griding(img, pts, num_features, grid_x, grid_y, threshold, nonmaxSuppression)

@@ -111,6 +111,96 @@ def test_degenerate_images(uvo, oracle):
     ex.close()
 
 
+def _fast_mode_images(synth):
+    """Frames that put the per-cell fallback of src/ORBextractor.cc:792-799 in every state: no cell falls back (textured), all do (flat,
+    low contrast), some do (textured left half / low-contrast right half; a dim frame), cells whose only corners >= fastTh are
+    equal-score neighbours that suppress each other (so `FAST(cell, 20)` is empty although pixels score >= 20, and in the second
+    call those pixels still suppress their weaker neighbours), and dense noise."""
+    rng = np.random.default_rng(11)
+    H, W = 512, 640
+    tex = synth.make_frame(4242, W, H)
+    low = (rng.integers(0, 12, (H, W)) + 100).astype(np.uint8)
+    half = tex.copy()
+    half[:, W // 2:] = low[:, W // 2:]
+    dim = (tex.astype(np.float32) * 0.22 + 90).astype(np.uint8)   # contrast cut to a fifth: most corners score below 20
+    # pairs of identical bright 2x1 blobs on a flat background: both pixels of a pair get the same score and annihilate
+    ties = np.full((H, W), 100, np.uint8)
+    ties += rng.integers(0, 9, (H, W)).astype(np.uint8)           # weak corners (score >= 7) around them
+    for y in range(40, H - 40, 37):
+        for x in range(40, W - 40, 41):
+            ties[y, x] = ties[y, x + 1] = 190
+    noise = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    flat = np.full((H, W), 77, np.uint8)
+    return (("textured", tex), ("lowcontrast", low), ("half", half), ("dim", dim), ("ties", ties), ("noise", noise), ("flat", flat))
+
+
+@pytest.mark.parametrize("mode", ["two_pass", "single_pass", "adaptive"])
+def test_fast_modes_give_the_reference_candidates(uvo, oracle, synth, mode):
+    """UVO_TUNE_FAST_MODE: the threshold-adaptive two-pass form (stream at fastTh + sparse literal-7 pass over the empty cells), the
+    single pass at 7 with the per-cell vote, and the adaptive choice between them must all produce the reference's per-cell
+    `FAST(cell, fastTh)`, else `FAST(cell, 7)` candidates (as sets, per level) and the same final keypoints / descriptors."""
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=640, max_height=512)
+    ex.tune(uvo.UVO_TUNE_FAST_MODE, {"two_pass": uvo.UVO_FAST_MODE_TWO_PASS, "single_pass": uvo.UVO_FAST_MODE_SINGLE_PASS,
+                                     "adaptive": uvo.UVO_FAST_MODE_ADAPTIVE}[mode])
+    oe = oracle.extractor(1000, 1.2, 8, 20)
+    seen_fallback = False
+    for rep in range(2 if mode == "adaptive" else 1):   # adaptive: the second round starts from whatever the first left behind
+        for name, img in _fast_mode_images(synth):
+            kp_g, de_g = ex(img)
+            kp_o, de_o = oe(img)
+            for l in range(8):
+                c_g = ex.read_candidates(l)
+                c_o = oe.level_candidates(l)
+                set_g = sorted(map(tuple, c_g.tolist()))
+                set_o = sorted(zip(c_o["x"].astype(int).tolist(), c_o["y"].astype(int).tolist(), c_o["response"].astype(int).tolist()))
+                assert set_g == set_o, "%s / %s: FAST candidates of level %d: %d vs %d" % (mode, name, l, len(set_g), len(set_o))
+            _assert_same_features(kp_g, de_g, kp_o, de_o, "%s / %s" % (mode, name))
+            t, fb, cells = ex.fast_state()
+            assert (fb >= 0).all() and (fb <= cells).all(), (name, fb, cells)
+            if name in ("lowcontrast", "flat"):
+                assert (fb == cells).all(), "every cell of a %s frame falls back: %s of %s" % (name, fb, cells)
+            if name == "textured":
+                assert fb.sum() * 10 < cells.sum(), "a textured frame should leave few cells empty at fastTh: %s of %s" % (fb, cells)
+            seen_fallback = seen_fallback or fb.sum() > 0
+            if mode == "two_pass":
+                assert (t == 20).all()
+            elif mode == "single_pass":
+                assert (t == 7).all()
+            else:   # hysteresis of k_octree's last workgroup: > 22 % fall-back cells -> one pass, < 14 % -> two
+                for l in range(8):
+                    if fb[l] * 100 > cells[l] * 22:
+                        assert t[l] == 7, (name, l, fb[l], cells[l], t[l])
+                    elif fb[l] * 100 < cells[l] * 14:
+                        assert t[l] == 20, (name, l, fb[l], cells[l], t[l])
+    assert seen_fallback
+    ex.close()
+
+
+@pytest.mark.parametrize("shape,nfeat,th,nlev", [((480, 752), 1000, 12, 8), ((1080, 1920), 2000, 20, 8), ((200, 1300), 600, 30, 4), ((96, 128), 300, 10, 3), ((85, 118), 200, 15, 2)])
+def test_two_pass_fast_at_other_geometries(uvo, oracle, synth, shape, nfeat, th, nlev):
+    """The sparse per-cell pass on other cell sizes / grids (two quad-tree roots, a very wide image, a tiny one, one whose levels are a
+    single row of cells up to 65 px high: the large LDS geometry of k_fast_cells), on a frame whose
+    contrast fades from left to right so that every level has cells of both kinds; both forced modes against the oracle."""
+    h, w = shape
+    img = synth.make_frame(123, w, h, n_shapes=max(40, w * h // 800)).astype(np.float32)
+    fade = np.linspace(1.0, 0.05, w, dtype=np.float32)[None, :]
+    img = (img * fade + 110 * (1 - fade)).astype(np.uint8)
+    oe = oracle.extractor(nfeat, 1.2, nlev, th)
+    kp_o, de_o = oe(img)
+    for mode in (uvo.UVO_FAST_MODE_TWO_PASS, uvo.UVO_FAST_MODE_SINGLE_PASS):
+        ex = uvo.ORBextractor(nfeat, 1.2, nlev, 0, th, max_width=w, max_height=h)
+        ex.tune(uvo.UVO_TUNE_FAST_MODE, mode)
+        kp_g, de_g = ex(img)
+        for l in range(nlev):
+            c_g, c_o = ex.read_candidates(l), oe.level_candidates(l)
+            assert sorted(map(tuple, c_g.tolist())) == sorted(zip(c_o["x"].astype(int).tolist(), c_o["y"].astype(int).tolist(), c_o["response"].astype(int).tolist())), \
+                "mode %d level %d" % (mode, l)
+        _assert_same_features(kp_g, de_g, kp_o, de_o, "%dx%d mode %d" % (w, h, mode))
+        t, fb, cells = ex.fast_state()
+        assert (fb <= cells).all() and (cells.sum() < 50 or 0 < fb.sum() < cells.sum()), (fb, cells)   # (the tiny image has 10 cells)
+        ex.close()
+
+
 def test_blur_planes_at_the_saturation_edge(uvo, oracle):
     """k_gauss7's column pass runs on the fp32 pipe: exact while the result is not saturated, i.e. the images to try are the ones whose
     sums sit at and across 2^24 -- constant 253 / 254 / 255 (taps sum to 257 per pass, so 254 already blurs to 255), bright noise,

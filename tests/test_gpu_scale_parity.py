@@ -104,6 +104,54 @@ def test_corner_rich_frames_at_scale_every_frame_vs_oracle(uvo, oracle, synth):
     _check_against_oracle(uvo, oracle, frames, 1000, 20, res, "corner-rich batch 96", 1000)
 
 
+def _run_bench_path_mode(uvo, frames, nfeat, fast_th, mode):
+    import torch
+    B, H, W = frames.shape
+    dev = torch.device("cuda", 0)
+    ex = uvo.ORBextractor(nfeat, 1.2, 8, 0, fast_th, max_width=W, max_height=H, max_batch=B)
+    ex.tune(uvo.UVO_TUNE_FAST_MODE, mode)
+    ex.set_pipeline(2)
+    cap = ex.cap
+    d_img = torch.from_numpy(frames).to(dev)
+    outs = [(torch.zeros((B, cap, 7), dtype=torch.float32, device=dev), torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev),
+             torch.zeros(B, dtype=torch.int32, device=dev)) for _ in range(2)]
+    torch.cuda.synchronize()
+    states = []
+    for k in range(4):
+        o = outs[k % 2]
+        ex.extract_batch_device(d_img.data_ptr(), B, W, H, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), cap)
+        if k >= 2:
+            states.append(ex.fast_state())
+    ex.synchronize()
+    res = [dict(n=o[2].cpu().numpy(), kp=o[0].cpu().numpy(), de=o[1].cpu().numpy()) for o in outs]
+    ex.close()
+    return res, states
+
+
+@pytest.mark.parametrize("mode", ["adaptive", "two_pass"])
+def test_low_contrast_batch_256_every_frame_vs_oracle(uvo, oracle, synth, mode):
+    """Batch 256 of frames whose contrast is cut to a fraction (every cell of the upper levels and most of the lower ones falls back to
+    the literal 7, src/ORBextractor.cc:797): the sparse per-cell pass at scale when forced, and the adaptive mode, which must have
+    moved the levels that fall back to the single pass by its third batch on each lane."""
+    frames = synth.make_sequence(0, 256, 640, 512)
+    frames = (frames.astype(np.float32) * 0.12 + 100).astype(np.uint8)
+    res, states = _run_bench_path_mode(uvo, frames, 1000, 20, uvo.UVO_FAST_MODE_ADAPTIVE if mode == "adaptive" else uvo.UVO_FAST_MODE_TWO_PASS)
+    oe = oracle.extractor(1000, 1.2, 8, 20)
+    ref = [oe(frames[b]) for b in range(len(frames))]
+    for li, r in enumerate(res):
+        for b in range(len(frames)):
+            n = int(r["n"][b])
+            kp_g = np.ascontiguousarray(r["kp"][b, :n]).view(uvo.KEYPOINT_DTYPE).reshape(-1)
+            _same(kp_g, r["de"][b, :n], ref[b][0], ref[b][1], "low contrast %s lane %d frame %d" % (mode, li, b))
+    for t, fb, cells in states:
+        assert fb.sum() * 2 > cells.sum() * 256, "these frames should leave most cells empty at fastTh: %s of %s x 256" % (fb, cells)
+        for l in range(8):
+            if mode == "two_pass":
+                assert t[l] == 20
+            elif fb[l] * 100 > cells[l] * 256 * 22:
+                assert t[l] == 7, (l, fb[l], cells[l], t[l])
+
+
 def test_configs3_hd_share_of_one_gpu_every_frame_vs_oracle(uvo, oracle, synth):
     """BASELINE.json configs[3]: 1920x1080 @ 2000 features, 128 frames per GPU (two quad-tree roots per level, 6594 FAST cells)."""
     frames = synth.make_sequence(0, 128, 1920, 1080, n_shapes=2500)

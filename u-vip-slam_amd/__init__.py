@@ -23,11 +23,13 @@ assert KEYPOINT_DTYPE.itemsize == 28
 
 UVO_OK, UVO_E_BADARG, UVO_E_NODEVICE, UVO_E_HIP, UVO_E_CAPACITY, UVO_E_UNSUPPORTED, UVO_E_NOMEM = 0, -1, -2, -3, -4, -5, -6
 UVO_TUNE_OCT_WIDE_MAX = 1
+UVO_TUNE_FAST_MODE = 2
+UVO_FAST_MODE_ADAPTIVE, UVO_FAST_MODE_TWO_PASS, UVO_FAST_MODE_SINGLE_PASS = 0, 1, 2
 
 # every symbol include/uvo/uvo.h declares
 ABI_SYMBOLS = [
     "uvo_extractor_create", "uvo_extractor_destroy", "uvo_extractor_levels", "uvo_extractor_max_keypoints", "uvo_extractor_scale_factor", "uvo_extractor_tables",
-    "uvo_extract", "uvo_extract_tracked", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_host_alloc", "uvo_host_free", "uvo_host_register", "uvo_host_unregister", "uvo_shard_plan_make", "uvo_sharder_create", "uvo_sharder_destroy", "uvo_sharder_max_keypoints", "uvo_sharder_run", "uvo_sharder_submit", "uvo_sharder_wait", "uvo_extract_batch_submit", "uvo_extract_batch_wait", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_tune", "uvo_extractor_level_dims",
+    "uvo_extract", "uvo_extract_tracked", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_host_alloc", "uvo_host_free", "uvo_host_register", "uvo_host_unregister", "uvo_shard_plan_make", "uvo_sharder_create", "uvo_sharder_destroy", "uvo_sharder_max_keypoints", "uvo_sharder_run", "uvo_sharder_submit", "uvo_sharder_wait", "uvo_extract_batch_submit", "uvo_extract_batch_wait", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_tune", "uvo_extractor_fast_state", "uvo_extractor_level_dims",
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_profile_only", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
@@ -160,6 +162,7 @@ def _load():
     lib.uvo_extractor_set_pipeline.argtypes = [vp, ci]
     lib.uvo_extractor_tune.argtypes = [vp, ci, ci]
     lib.uvo_extractor_level_dims.argtypes = [vp, ci, vp, vp]
+    lib.uvo_extractor_fast_state.argtypes = [vp, vp, vp, vp]
     lib.uvo_clahe.argtypes = [vp, vp, ci, ci, cl, ctypes.c_double, ci, ci, vp, cl]
     lib.uvo_clahe_batch_device.argtypes = [vp, ci, vp, ci, ci, cl, cl, ctypes.c_double, ci, ci, vp, cl, cl]
     lib.uvo_grider_fast.argtypes = [vp, vp, ci, ci, cl, ci, ci, ci, ci, ci, vp, ci, vp]
@@ -489,6 +492,16 @@ class ORBextractor:
         rc = lib.uvo_extractor_tune(self._h, knob, value)
         if rc:
             raise UvoError(rc, "uvo_extractor_tune")
+
+    def fast_state(self):
+        """uvo_extractor_fast_state: per level (threshold the next batch of the current lane streams at, fall-back cells counted in the
+        last batch, cells per frame)."""
+        n = lib.uvo_extractor_levels(self._h)
+        t, f, c = (np.zeros(n, np.int32) for _ in range(3))
+        rc = lib.uvo_extractor_fast_state(self._h, t.ctypes.data, f.ctypes.data, c.ctypes.data)
+        if rc:
+            raise UvoError(rc, "uvo_extractor_fast_state")
+        return t, f, c
 
     # ---- stage taps used by the parity tests ----
     def level_dims(self, level):

@@ -104,8 +104,11 @@ void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const
                          const ResizeRow* d_rtab, int fast_ok, int batch);
 void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g, int4 taps,
                    int batch);
-void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, int fast_th, uint32_t* d_cor, uint8_t* d_cell_hi,
-                       uint32_t* d_cand_xy, uint32_t* d_cand_sc, uint32_t* d_cand_lo, int64_t cand_block, int32_t* d_cursor, int batch);
+void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, int fast_th, const int32_t* d_tpass, uint32_t* d_cor,
+                       uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, uint32_t* d_cand_lo, int64_t cand_block, int32_t* d_cursor, int batch);
+void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, const CellDesc* d_cells, const int32_t* d_flag_cell,
+                       const int32_t* d_tpass, const uint8_t* d_cell_hi, uint2* d_list, int32_t* d_n_list, uint32_t* d_cand_xy, uint32_t* d_cand_sc,
+                       int64_t cand_block, int32_t* d_cursor, int batch);
 void launch_grider(hipStream_t s, const uint8_t* d_img, int w, int h, int64_t stride, int num_features, int grid_x, int grid_y, int threshold,
                    int nms, uint8_t* d_score, uint32_t* d_lists, int32_t* d_counts, uvo_keypoint* d_out, int cap, int32_t* d_n_out);
 int fast_rows_per_seg(int batch);
@@ -115,10 +118,12 @@ int fast_flags_per_frame(const Geom& g);
 // threads coexist in one process).  wide_max_problems: up to this many (frame, level) problems run as 1024-thread workgroups.
 struct OctLaunchState {
   int wide_max_problems = 256;
+  int adapt = 1;      // k_octree's last workgroup re-decides each level's FAST mode from the batch's share of fall-back cells
+  int fast_th = 20;   // the handle's fastTh (the threshold a threshold-adaptive level streams at)
   size_t lds_configured = 0;  // dynamic-LDS limit already raised on this handle's device for both instantiations
 };
 int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_lo, int32_t* d_cursor,
-                   uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate,
+                   int32_t* d_tpass, int32_t* d_fstat, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate,
                    uint32_t* d_sel_xy, uint32_t* d_sel_sc, int32_t* d_sel_count, int batch);
 void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_sel_xy, const uint32_t* d_sel_sc,
                      const int32_t* d_sel_count,

@@ -53,6 +53,10 @@ struct Lane {
   int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_n_final = nullptr, *d_cor_n = nullptr, *d_cursor = nullptr;
   uint32_t* d_cor = nullptr;     // FAST corner lists, one region per k_fast_score wavefront
   uint8_t* d_cell_hi = nullptr;  // per cell: owns an NMS survivor >= fastTh
+  // the lane's adaptive FAST mode: d_tpass[level] = threshold of the level's streaming pass (fastTh: threshold-adaptive two-pass form;
+  // min(fastTh, 7): one pass + vote); d_fstat = the fall-back-cell sums k_octree turns into next batch's d_tpass (octree.hip)
+  int32_t *d_tpass = nullptr, *d_fstat = nullptr;
+  uint2* d_cell_list = nullptr;  // (cell, frame) of the fall-back cells of the batch in flight (k_fast_cells_list -> k_fast_cells)
   FinalSlot* d_flist = nullptr;
   Profiler prof;
   // staging of the asynchronous host-buffer form (allocated on first use): a lane's frames and results must not be touched by the
@@ -80,6 +84,8 @@ struct uvo_extractor {
   Geom geom;
   bool have_geom = false;
   std::vector<CellDesc> cells;
+  std::vector<int32_t> cell_flag;  // per entry of a frame's cell-flag array (the full nRows x nCols grids of all levels): cell | level << 24, -1 = no cell
+  int fast_mode = UVO_FAST_MODE_ADAPTIVE;
   // capacities fixed at create time (from max_width x max_height)
   int64_t cap_pyr_block = 0, cap_cand_block = 0;
   int cap_cells = 0, cap_sel_block = 0, cap_flist = 0, cap_xtab = 0, cap_ytab = 0;
@@ -88,6 +94,7 @@ struct uvo_extractor {
   // shared read-only tables
   LevelGeom* d_lv = nullptr;
   CellDesc* d_cells = nullptr;
+  int32_t* d_cell_flag = nullptr;
   ResizeCol* d_ctab = nullptr;
   uint8_t* d_clahe_lut = nullptr;  // [max_batch][tiles][256], grown on demand
   size_t clahe_lut_bytes = 0;
@@ -113,6 +120,17 @@ namespace uvo {
 
 static int sync_all_lanes(uvo_extractor* h);
 static int alloc_lane(uvo_extractor* h, int li);
+
+// (Re)starts lane li's per-level FAST mode.  Adaptive and two-pass start threshold-adaptive (stream at fastTh, sparse literal-7 pass);
+// single-pass streams at min(fastTh, 7) and votes.  With fastTh <= 7 the second call of src/ORBextractor.cc:797 can find nothing the
+// first did not, so there is only one form.
+static int set_lane_fast_mode(uvo_extractor* h, int li) {
+  int32_t t[kMaxLevels];
+  const int th = h->cfg.fast_th;
+  for (int l = 0; l < kMaxLevels; ++l) t[l] = (th > 7 && h->fast_mode != UVO_FAST_MODE_SINGLE_PASS) ? th : (th < 7 ? th : 7);
+  UVO_HIP_CHECK(hipMemcpy(h->lane[li].d_tpass, t, sizeof(t), hipMemcpyHostToDevice));
+  return UVO_OK;
+}
 
 // ORBextractor::ORBextractor: src/ORBextractor.cc:458-512
 static void build_ctor_tables(uvo_extractor* h) {
@@ -158,13 +176,14 @@ static void build_ctor_tables(uvo_extractor* h) {
 
 // Geometry of one resolution: pyramid sizes (:966-969), detection window and FAST cells (:755-790),
 // quad-tree roots (:1010-1012), scratch offsets.
-static int build_geom(const uvo_extractor* h, int width, int height, Geom& g, std::vector<CellDesc>& cells) {
+static int build_geom(const uvo_extractor* h, int width, int height, Geom& g, std::vector<CellDesc>& cells, std::vector<int32_t>* cell_flag = nullptr) {
   const int nl = h->cfg.nlevels;
   memset(&g, 0, sizeof(g));
   g.width = width, g.height = height, g.nlevels = nl;
   cells.clear();
+  if (cell_flag) cell_flag->clear();
   int64_t off = 0, coff = 0;
-  int soff = 0, xt = 0, yt = 0;
+  int soff = 0, xt = 0, yt = 0, flag_base = 0;
   for (int l = 0; l < nl; ++l) {
     LevelGeom& L = g.lv[l];
     L.w = cv_round_host((float)width * h->inv_scale[l]);
@@ -203,8 +222,15 @@ static int build_geom(const uvo_extractor* h, int width, int height, Geom& g, st
         if (iw <= 0 || ih <= 0) continue;  // FAST on an ROI without interior finds nothing
         cap += ((iw + 1) / 2) * ((ih + 1) / 2);
         cells.push_back(c);
+        if (cell_flag) {
+          cell_flag->resize((size_t)flag_base + (size_t)L.nRows * L.nCols, -1);
+          (*cell_flag)[flag_base + i * L.nCols + j] = (int32_t)(cells.size() - 1) | (l << 24);
+        }
       }
     }
+    flag_base += L.nRows * L.nCols;  // the same running base as fast_levels() (fast.hip)
+    if (cell_flag) cell_flag->resize((size_t)flag_base, -1);
+    if (cells.size() >= (1u << 24)) return fail(UVO_E_UNSUPPORTED, "more than 2^24 FAST cells per frame");
     L.n_cells = (int)cells.size() - L.cell_base;
     L.quota = h->quota[l];
     if (L.quota > kMaxOctN) return fail(UVO_E_UNSUPPORTED, "per-level feature quota above the quad-tree kernel's capacity");
@@ -302,7 +328,8 @@ static int set_geometry(uvo_extractor* h, int width, int height) {
   if (h->have_geom && h->geom.width == width && h->geom.height == height) return UVO_OK;
   Geom g;
   std::vector<CellDesc> cells;
-  int rc = build_geom(h, width, height, g, cells);
+  std::vector<int32_t> cell_flag;
+  int rc = build_geom(h, width, height, g, cells, &cell_flag);
   if (rc) return rc;
   if (g.pyr_block > h->cap_pyr_block || g.cand_block > h->cap_cand_block || g.total_cells > h->cap_cells || g.sel_block > h->cap_sel_block ||
       g.flist_cap > h->cap_flist)
@@ -326,12 +353,14 @@ static int set_geometry(uvo_extractor* h, int width, int height) {
   }
   UVO_HIP_CHECK(hipMemcpy(h->d_lv, g.lv, sizeof(LevelGeom) * g.nlevels, hipMemcpyHostToDevice));
   UVO_HIP_CHECK(hipMemcpy(h->d_cells, cells.data(), sizeof(CellDesc) * cells.size(), hipMemcpyHostToDevice));
+  UVO_HIP_CHECK(hipMemcpy(h->d_cell_flag, cell_flag.data(), sizeof(int32_t) * cell_flag.size(), hipMemcpyHostToDevice));
   if (!ctab.empty()) {
     UVO_HIP_CHECK(hipMemcpy(h->d_ctab, ctab.data(), ctab.size() * sizeof(ResizeCol), hipMemcpyHostToDevice));
     UVO_HIP_CHECK(hipMemcpy(h->d_rtab, rtab.data(), rtab.size() * sizeof(ResizeRow), hipMemcpyHostToDevice));
   }
   h->geom = g;
   h->cells = cells;
+  h->cell_flag = cell_flag;
   h->have_geom = true;
   return UVO_OK;
 }
@@ -377,8 +406,15 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   }
   {  // the per-cell threshold vote + candidate emit run inside k_octree
     ProfScope p(h, "k_fast_score");
-    launch_fast_score(s, L.d_pyr, g.pyr_block, g, h->cfg.fast_th, L.d_cor, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, L.d_cand_lo, g.cand_block, L.d_cursor,
-                      batch);
+    launch_fast_score(s, L.d_pyr, g.pyr_block, g, h->cfg.fast_th, L.d_tpass, L.d_cor, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, L.d_cand_lo, g.cand_block,
+                      L.d_cursor, batch);
+  }
+  if (h->cfg.fast_th > 7 && h->fast_mode != UVO_FAST_MODE_SINGLE_PASS) {
+    // second call of src/ORBextractor.cc:797 for the cells of threshold-adaptive levels that the pass at fastTh left empty (nearly all
+    // wavefronts find nothing to do on textured frames).  With the mode pinned to one pass no level can be adaptive: not launched.
+    ProfScope p(h, "k_fast_cells");
+    launch_fast_cells(s, L.d_pyr, g.pyr_block, g, h->d_cells, h->d_cell_flag, L.d_tpass, L.d_cell_hi, L.d_cell_list, L.d_fstat + 3 * kMaxLevels, L.d_cand_xy,
+                      L.d_cand_sc, g.cand_block, L.d_cursor, batch);
   }
   {
     ProfScope p(h, "k_gauss7");
@@ -386,7 +422,7 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   }
   {
     ProfScope p(h, "k_octree");
-    rc = launch_octree(s, h->oct, h->d_lv, g, L.d_cand_lo, L.d_cursor, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count,
+    rc = launch_octree(s, h->oct, h->d_lv, g, L.d_cand_lo, L.d_cursor, L.d_tpass, L.d_fstat, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count,
                        L.d_pstate, L.d_sel_xy, L.d_sel_sc, L.d_sel_count, batch);
     if (rc) return rc;
   }
@@ -435,6 +471,12 @@ static int alloc_lane(uvo_extractor* h, int li) {
   AL(dev_alloc(&L.d_cor, h->cap_cor));
   AL(dev_alloc(&L.d_cor_n, h->cap_cor_n));
   AL(dev_alloc(&L.d_cell_hi, h->cap_flags));
+  AL(dev_alloc(&L.d_tpass, (size_t)kMaxLevels));
+  // [level] 64-bit accumulators (problems done << 32 | fall-back cells), the last sums, the length of d_cell_list
+  AL(dev_alloc(&L.d_fstat, (size_t)3 * kMaxLevels + 4));
+  AL(dev_alloc(&L.d_cell_list, B * (size_t)h->cap_cells));
+  if ((rc = set_lane_fast_mode(h, li)) != UVO_OK) return rc;
+  if (hipMemset(L.d_fstat, 0, (3 * kMaxLevels + 4) * sizeof(int32_t)) != hipSuccess) return fail(UVO_E_HIP, "hipMemset failed");
   // the cell flags and the fill cursors are zero between calls: k_fast_score sets / advances them, k_octree clears what it has consumed
   if (hipMemset(L.d_cell_hi, 0, h->cap_flags) != hipSuccess || hipMemset(L.d_cursor, 0, B * kMaxLevels * 2 * sizeof(int32_t)) != hipSuccess)
     return fail(UVO_E_HIP, "hipMemset failed");
@@ -474,6 +516,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   uvo_extractor* h = new uvo_extractor();
   h->cfg = *cfg;
   h->device = cfg->device;
+  h->oct.fast_th = cfg->fast_th;
   build_ctor_tables(h);
   Geom g;
   std::vector<CellDesc> cells;
@@ -519,6 +562,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   A(alloc_lane(h, 0));
   A(dev_alloc(&h->d_lv, (size_t)kMaxLevels));
   A(dev_alloc(&h->d_cells, (size_t)h->cap_cells));
+  A(dev_alloc(&h->d_cell_flag, h->cap_flags / B + 64));
   A(dev_alloc(&h->d_ctab, (size_t)h->cap_xtab));
   A(dev_alloc(&h->d_rtab, (size_t)h->cap_ytab));
   A(dev_alloc(&h->d_pattern, (size_t)1024));
@@ -562,12 +606,12 @@ void uvo_extractor_destroy(uvo_extractor* h) {
     if (L.stream) (void)hipStreamSynchronize(L.stream);
     L.prof.clear();
     void* lp[] = {L.d_pyr,   L.d_blur,   L.d_cand_xy,   L.d_cand_sc, L.d_pstate, L.d_sel_xy, L.d_sel_sc,
-                  L.d_cand_count, L.d_sel_count, L.d_n_final, L.d_cor_n, L.d_cor, L.d_cell_hi, L.d_cand_lo, L.d_cursor, L.d_flist, L.a_imgs, L.a_kp, L.a_desc, L.a_n};
+                  L.d_cand_count, L.d_sel_count, L.d_n_final, L.d_cor_n, L.d_cor, L.d_cell_hi, L.d_cand_lo, L.d_cursor, L.d_tpass, L.d_fstat, L.d_cell_list, L.d_flist, L.a_imgs, L.a_kp, L.a_desc, L.a_n};
     for (void* p : lp)
       if (p) (void)hipFree(p);
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
-  void* ptrs[] = {h->d_clahe_lut, h->d_clahe_out, h->d_lv, h->d_cells, h->d_ctab, h->d_rtab, h->d_pattern, h->d_patch, h->d_imgs, h->d_out_kp,
+  void* ptrs[] = {h->d_clahe_lut, h->d_clahe_out, h->d_lv, h->d_cells, h->d_cell_flag, h->d_ctab, h->d_rtab, h->d_pattern, h->d_patch, h->d_imgs, h->d_out_kp,
                   h->d_out_desc, h->d_n_out, h->d_in_kp, h->d_n_in, h->d_nfn, h->d_grid, h->d_grid_score};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -691,9 +735,38 @@ int uvo_extractor_tune(uvo_extractor* h, int knob, int value) {
       if (value < 0) return fail(UVO_E_BADARG, "knob value must be >= 0");
       h->oct.wide_max_problems = value;
       return UVO_OK;
+    case UVO_TUNE_FAST_MODE: {
+      if (value != UVO_FAST_MODE_ADAPTIVE && value != UVO_FAST_MODE_TWO_PASS && value != UVO_FAST_MODE_SINGLE_PASS)
+        return fail(UVO_E_BADARG, "UVO_TUNE_FAST_MODE takes UVO_FAST_MODE_ADAPTIVE / _TWO_PASS / _SINGLE_PASS");
+      UVO_HIP_CHECK(hipSetDevice(h->device));
+      int rc = sync_all_lanes(h);
+      if (rc) return rc;
+      h->fast_mode = value;
+      h->oct.adapt = value == UVO_FAST_MODE_ADAPTIVE ? 1 : 0;
+      for (int i = 0; i < kMaxLanes; ++i)
+        if (h->lane[i].stream && (rc = set_lane_fast_mode(h, i)) != UVO_OK) return rc;
+      return UVO_OK;
+    }
     default:
       return fail(UVO_E_BADARG, "unknown knob");
   }
+}
+
+int uvo_extractor_fast_state(uvo_extractor* h, int32_t* pass_threshold, int32_t* fallback_cells, int32_t* cells_per_frame) {
+  if (!h) return fail(UVO_E_BADARG, "null handle");
+  if (!h->have_geom) return fail(UVO_E_BADARG, "no batch has run yet");
+  UVO_HIP_CHECK(hipSetDevice(h->device));
+  Lane& L = h->lane[h->cur];
+  UVO_HIP_CHECK(hipStreamSynchronize(L.stream));
+  int32_t t[kMaxLevels], f[3 * kMaxLevels];
+  UVO_HIP_CHECK(hipMemcpy(t, L.d_tpass, sizeof(t), hipMemcpyDeviceToHost));
+  UVO_HIP_CHECK(hipMemcpy(f, L.d_fstat, sizeof(f), hipMemcpyDeviceToHost));
+  for (int l = 0; l < h->geom.nlevels; ++l) {
+    if (pass_threshold) pass_threshold[l] = t[l];
+    if (fallback_cells) fallback_cells[l] = f[2 * kMaxLevels + l];
+    if (cells_per_frame) cells_per_frame[l] = h->geom.lv[l].n_cells;
+  }
+  return UVO_OK;
 }
 
 int uvo_extractor_set_pipeline(uvo_extractor* h, int depth) {

@@ -24,6 +24,7 @@
 //   the per-cell vote (survivors >= fastTh if the cell has any, else the literal-7 fallback) needs every region of a cell to
 //   be finished, so it is taken by the quad-tree kernel, which appends the low survivors of cells without a high one to the
 //   level's candidates (octree.hip).  Candidate order in HBM is arbitrary: the quad-tree orders by coordinates.
+#include <algorithm>
 #include <cstdlib>
 #include "common.hpp"
 #include "fast_geom.hpp"
@@ -114,6 +115,22 @@ __device__ __noinline__ void flush_corner_list(const uint32_t* list, uint32_t* d
   for (int i = lane; i < n; i += 64) dst[i] = list[i];
 }
 
+// max(brighter, darker) arc strength of the pixel whose (-3 rows, -3 columns) corner is rm3 in a byte tile of row pitch RB:
+// the pixel is a FAST-9 corner at threshold t iff the result is > t, and cornerScore = result - 1.
+template <int RB>
+__device__ __forceinline__ int ring_strength(const uint8_t* rm3) {
+  const uint8_t *rm2 = rm3 + RB, *rm1 = rm3 + 2 * RB, *r0 = rm3 + 3 * RB, *rp1 = rm3 + 4 * RB, *rp2 = rm3 + 5 * RB, *rp3 = rm3 + 6 * RB;
+  const d16 v = (d16)r0[3];
+  d16 d[16];
+  d[0] = rp3[3], d[1] = rp3[4], d[2] = rp2[5], d[3] = rp1[6], d[4] = r0[6], d[5] = rm1[6], d[6] = rm2[5], d[7] = rm3[4];
+  d[8] = rm3[3], d[9] = rm3[2], d[10] = rm2[1], d[11] = rm1[0], d[12] = r0[0], d[13] = rp1[0], d[14] = rp2[1], d[15] = rp3[2];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) d[k] = (d16)(d[k] - v);
+  // corner at t  <=>  some 9-arc has all diffs > t (brighter) or all < -t (darker)  <=>  max(sb, sd) > t;
+  // cornerScore = max(sb, sd) - 1.  No masks, no divergent branches.
+  return max((int)arc9_maxmin(d), -(int)arc9_minmax(d));
+}
+
 // Full segment test + cornerScore of the queued pixels [first, first+count), one per lane.  The 16 ring pixels are read
 // back from the wavefront's LDS row ring: the queue entry carries the byte address of the pixel in the ring (rows 0..5 are
 // mirrored into slots 16..21, so the seven rows around any centre are consecutive slots and every read is base + immediate).
@@ -125,20 +142,9 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
   if (lane < count) {
     const uint32_t meta = q[first + lane];
     const int xl = (int)((meta >> 15) & 0xff), rrp = (int)(meta >> 23);
-    constexpr int RB = FR_PITCH * 4;
     // the entry's address field points 3 rows above and 3 bytes left of the pixel, relative to the workgroup's LDS block: every ring
     // pixel is that one register + an immediate offset
-    const uint8_t* rm3 = rows + (meta & 0x7fffu);
-    const uint8_t *rm2 = rm3 + RB, *rm1 = rm3 + 2 * RB, *r0 = rm3 + 3 * RB, *rp1 = rm3 + 4 * RB, *rp2 = rm3 + 5 * RB, *rp3 = rm3 + 6 * RB;
-    const d16 v = (d16)r0[3];
-    d16 d[16];
-    d[0] = rp3[3], d[1] = rp3[4], d[2] = rp2[5], d[3] = rp1[6], d[4] = r0[6], d[5] = rm1[6], d[6] = rm2[5], d[7] = rm3[4];
-    d[8] = rm3[3], d[9] = rm3[2], d[10] = rm2[1], d[11] = rm1[0], d[12] = r0[0], d[13] = rp1[0], d[14] = rp2[1], d[15] = rp3[2];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) d[k] = (d16)(d[k] - v);
-    // corner at t  <=>  some 9-arc has all diffs > t (brighter) or all < -t (darker)  <=>  max(sb, sd) > t;
-    // cornerScore = max(sb, sd) - 1.  No masks, no divergent branches.
-    const int best = max((int)arc9_maxmin(d), -(int)arc9_minmax(d));
+    const int best = ring_strength<FR_PITCH * 4>(rows + (meta & 0x7fffu));
     // a score of 0 (only possible at t_min = 0) can never survive NMS nor suppress anything: one compare against max(t_min, 1)
     corner = best > (t_min > 1 ? t_min : 1);
     packed = (uint32_t)xl | ((uint32_t)rrp << 8) | ((uint32_t)(best - 1) << 16);
@@ -162,7 +168,7 @@ __device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_
 // into a dense byte tile that reuses the LDS of the row ring + queue, the eight neighbours of every corner are read from it
 // (neighbours outside the corner's own FAST cell count as 0), survivors are compacted in place and mark their cell when they
 // reach fastTh.  No score plane in HBM, no zero fill, no second gather pass.
-__global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fast_score(const uint8_t* __restrict__ pyr, int64_t pyr_block, FastLevels L, int t_min, int fast_th,
+__global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fast_score(const uint8_t* __restrict__ pyr, int64_t pyr_block, FastLevels L, const int32_t* __restrict__ tpass, int fast_th,
                                                     uint32_t* __restrict__ cor, uint8_t* __restrict__ cell_hi, uint32_t* __restrict__ cand_xy,
                                                     uint32_t* __restrict__ cand_sc, uint32_t* __restrict__ cand_lo, int64_t cand_block,
                                                     int32_t* __restrict__ cursor) {
@@ -178,6 +184,9 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   int level, X0, py0, nsub;
   if (!fast_region(L, item, level, X0, py0, nsub)) return;
   const FastLevel g = L.l[level];
+  // threshold of this level's streaming pass (wave-uniform): fastTh when the level runs threshold-adaptive -- the cells left without a
+  // survivor are then redone at the literal 7 by k_fast_cells -- or min(fastTh, 7), one pass that keeps the low survivors for the vote
+  const int t_min = tpass[level];
   const int64_t region_id = (int64_t)f * L.items_per_frame + item;
   uint32_t* region = cor + region_id * (int64_t)FS_REGION_ENTRIES;  // only touched when the LDS list overflows
   uint32_t* list = s_list[wv];
@@ -433,6 +442,228 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   }
 }
 
+// ---- the sparse second pass of the threshold-adaptive form: FAST(cellROI, 7, nms) for the cells the streaming pass left empty ----
+// src/ORBextractor.cc:792-799: `FAST(cell, kps, fastTh, true); if (kps.empty()) FAST(cell, kps, 7, true);`.  When a level's streaming
+// pass ran at fastTh (tpass[level] > 7) its NMS survivors are exactly the first call's keypoints (a corner >= fastTh can only be
+// suppressed by a neighbour >= fastTh), and cell_hi marks the cells that own one.  Every other cell is redone here, literally: the
+// scores of ALL interior pixels at threshold 7 -- also those >= fastTh that annihilated each other in the first call; they still
+// suppress their weaker neighbours in the second -- then the 3x3 suppression inside the cell's interior.  One wavefront per cell,
+// `cpw` cells looked at per wavefront (most are skipped: a flag read and a ballot); survivors are appended to the level's
+// candidates at the same cursor the streaming pass used.
+constexpr int FC_WAVES = 4;
+constexpr int FC_QCAP = 128;   // < 64 left over + <= 64 pushed per step
+// LDS geometry of a wavefront, two sizes: cells up to 48 x 48 (every level whose detection window is at least 90 px wide and high: 3
+// or more cells across, each at most 40 + 6) leave room for seven workgroups per CU; cells up to 66 x 66 (build_geom refuses larger
+// ones) for three.  The kernel is a chain of short dependent phases per cell: wavefronts in flight are what it runs on.
+template <int MAXROI>
+struct FcGeom {
+  static constexpr int TPITCH = (MAXROI + 3 + 3) / 4 * 4;   // ROI row pitch in bytes: the ROI + up to 3 bytes of dword alignment, whole dwords
+  static constexpr int ND = TPITCH / 4;
+  static constexpr int SPITCH = (MAXROI - 6 + 2 + 3) / 4 * 4, SROWS = MAXROI - 6 + 2;   // score tile: the interior inside a ring of zeros
+  static constexpr int TILE_DW = MAXROI * ND;               // also holds the survivor list (<= (MAXROI - 6)^2 / 4 words)
+  static constexpr int CCAP = MAXROI <= 48 ? 256 : 512;     // corner positions remembered per cell (16 bit each); a busier cell scans its whole score tile
+  static_assert(TILE_DW >= ((MAXROI - 5) / 2) * ((MAXROI - 5) / 2), "survivor list must fit the ROI tile");
+  static_assert(SROWS <= 64 && SPITCH <= 64, "corner positions are packed as ix | iy << 6");
+};
+
+// k_fast_cells_list: one thread per entry of a frame's cell-flag array (coalesced byte reads; flag_cell maps the entry back to its cell
+// and level, -1 where the grid position is no cell) -- is the level threshold-adaptive and did the streaming pass leave the cell empty?
+// Those cells are appended to `list` as (cell, frame), one reservation per workgroup; n_list counts them (zeroed again by k_octree,
+// which runs behind both kernels).
+constexpr int FCL_THREADS = 1024;
+__global__ __launch_bounds__(FCL_THREADS) void k_fast_cells_list(const int32_t* __restrict__ flag_cell, int flags_per_frame, int nlevels, const int32_t* __restrict__ tpass,
+                                                               const uint8_t* __restrict__ cell_hi, uint2* __restrict__ list, int32_t* __restrict__ n_list) {
+  __shared__ int s_n, s_base;
+  __shared__ uint32_t s_adaptive;  // bit l: level l is threshold-adaptive in this batch
+  const int idx = (int)(blockIdx.x * FCL_THREADS + threadIdx.x), f = blockIdx.y, lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) {
+    uint32_t m = 0;
+    for (int l = 0; l < nlevels; ++l) m |= tpass[l] > 7 ? 1u << l : 0u;
+    s_adaptive = m, s_n = 0;
+  }
+  int fc = -1;
+  uint8_t flag = 1;
+  if (idx < flags_per_frame) fc = flag_cell[idx], flag = cell_hi[(int64_t)f * flags_per_frame + idx];
+  __syncthreads();
+  const bool todo = fc >= 0 && flag == 0 && ((s_adaptive >> (fc >> 24)) & 1u);
+  const uint64_t m = ballot64(todo);
+  int at = 0;
+  if (m) {
+    if (lane == 0) at = atomicAdd(&s_n, (int)__popcll(m));
+    at = __builtin_amdgcn_readfirstlane(at) + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  }
+  __syncthreads();
+  if (s_n == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(n_list, s_n);
+  __syncthreads();
+  if (todo) list[s_base + at] = make_uint2((uint32_t)(fc & 0xffffff), (uint32_t)f);
+}
+
+// k_fast_cells: a fixed grid of wavefronts shares the listed cells evenly (fall-back cells cluster in the smooth parts of a frame: dealt
+// by position, some wavefronts would redo a dozen cells in a row while most find none).
+template <int MAXROI>
+__global__ __launch_bounds__(64 * FC_WAVES) void k_fast_cells(const uint8_t* __restrict__ pyr, int64_t pyr_block, FastLevels L, const CellDesc* __restrict__ cells,
+                                                            const uint2* __restrict__ list, const int32_t* __restrict__ n_list,
+                                                            uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc, int64_t cand_block,
+                                                            int32_t* __restrict__ cursor) {
+  typedef FcGeom<MAXROI> G;
+  constexpr int FC_TPITCH = G::TPITCH, FC_ND = G::ND, FC_SPITCH = G::SPITCH, FC_SROWS = G::SROWS, FC_CCAP = G::CCAP;
+  __shared__ uint32_t s_tile[FC_WAVES][G::TILE_DW];
+  __shared__ uint32_t s_score[FC_WAVES][FC_SROWS * FC_SPITCH / 4];
+  __shared__ uint32_t s_q[FC_WAVES][FC_QCAP];
+  __shared__ uint16_t s_corner[FC_WAVES][FC_CCAP];
+  const int wv = wave_in_block(), lane = threadIdx.x & 63;
+  const int n_items = *n_list;
+  const int wave_id = (int)blockIdx.x * FC_WAVES + wv, n_waves = (int)gridDim.x * FC_WAVES;
+  if (wave_id >= n_items) return;
+  uint32_t* tile32 = s_tile[wv];
+  const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(tile32);
+  uint32_t* score32 = s_score[wv];
+  uint8_t* score8 = reinterpret_cast<uint8_t*>(score32);
+  uint32_t* q = s_q[wv];
+  uint16_t* clist = s_corner[wv];
+  // the score tile is zero between cells: cleared once here, afterwards every cell wipes the corners it wrote
+  for (int i = lane; i < FC_SROWS * FC_SPITCH / 4; i += 64) score32[i] = 0u;
+  for (int item = wave_id; item < n_items; item += n_waves) {
+    const uint2 it = list[item];
+    const int cell = __builtin_amdgcn_readfirstlane((int)it.x), f = __builtin_amdgcn_readfirstlane((int)it.y);
+    const CellDesc c = cells[cell];
+    const int level = __builtin_amdgcn_readfirstlane((int)c.level);
+    const int rw = __builtin_amdgcn_readfirstlane((int)c.rw), rh = __builtin_amdgcn_readfirstlane((int)c.rh);
+    const int x0 = __builtin_amdgcn_readfirstlane((int)c.x0), y0 = __builtin_amdgcn_readfirstlane((int)c.y0);
+    const int ox = __builtin_amdgcn_readfirstlane((int)c.ox), oy = __builtin_amdgcn_readfirstlane((int)c.oy);
+    const FastLevel g = L.l[level];
+    const int iw = rw - 6, ih = rh - 6, npix = iw * ih;
+    (void)ih;
+    // ---- the ROI into LDS as aligned dwords: padded plane columns [a0, a0 + 4 nd), `sh` bytes of slack in front ----
+    const int px0 = kPad + x0, py0 = kPad + y0, a0 = px0 & ~3, sh = px0 - a0, nd = (sh + rw + 3) >> 2;
+    const uint8_t* src = pyr + f * pyr_block + g.plane_off + (int64_t)py0 * g.pitch + a0;
+    {
+      // dword k * 64 + lane of the ROI's rh x nd dwords, eight loads in flight at a time (the address of a dword past the end is
+      // clamped to the last one: unconditional loads, so that the compiler counts them instead of waiting for each)
+      const int ndw = rh * nd;
+      const float rcp_nd = 1.0f / (float)nd;
+      for (int k0 = 0; k0 < ndw; k0 += 8 * 64) {
+        uint32_t w[8];
+        int dst[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = min(k0 + u * 64 + lane, ndw - 1);
+          const int r = (int)(((float)idx + 0.5f) * rcp_nd), d = idx - r * nd;
+          dst[u] = r * FC_ND + d;
+          w[u] = *reinterpret_cast<const uint32_t*>(src + (int64_t)r * g.pitch + 4 * d);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + u * 64 + lane < ndw) tile32[dst[u]] = w[u];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- scores at threshold 7: screen with four opposite ring pairs, queue the pixels that pass, exact test on full batches ----
+    const float rcp_iw = 1.0f / (float)iw;
+    int qn = 0, nc = 0;  // queue length; corners found (their positions remembered while they fit)
+    auto score_batch = [&](int firstq, int count) {
+      bool corner = false;
+      uint32_t pos = 0;
+      if (lane < count) {
+        const uint32_t e = q[firstq + lane];
+        const int best = ring_strength<FC_TPITCH>(tile8 + (e & 0x1fffu));
+        pos = e >> 13;  // ix | iy << 6
+        corner = best > 7;
+        if (corner) score8[((pos >> 6) + 1) * FC_SPITCH + (pos & 0x3f) + 1] = (uint8_t)(best - 1);
+      }
+      const uint64_t m = ballot64(corner);
+      if (m) {
+        const int at = nc + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (corner && at < FC_CCAP) clist[at] = (uint16_t)pos;
+        nc += (int)__popcll(m);
+      }
+    };
+    for (int p0 = 0; p0 < npix; p0 += 64) {
+      const int p = p0 + lane;
+      bool pass = false;
+      uint32_t entry = 0;
+      if (p < npix) {
+        const int iy = (int)(((float)p + 0.5f) * rcp_iw), ix = p - iy * iw;
+        const int off = iy * FC_TPITCH + sh + ix;  // (pixel - 3 rows - 3 columns)
+        const uint8_t* rm3 = tile8 + off;
+        const int v = rm3[3 * FC_TPITCH + 3];
+        const int a0p = rm3[6 * FC_TPITCH + 3], a8 = rm3[3], a4 = rm3[3 * FC_TPITCH + 6], a12 = rm3[3 * FC_TPITCH];
+        const int a2 = rm3[5 * FC_TPITCH + 5], a10 = rm3[FC_TPITCH + 1], a6 = rm3[FC_TPITCH + 5], a14 = rm3[5 * FC_TPITCH + 1];
+        const int mx = min(min(max(a0p, a8), max(a4, a12)), min(max(a2, a10), max(a6, a14)));
+        const int mn = max(max(min(a0p, a8), min(a4, a12)), max(min(a2, a10), min(a6, a14)));
+        pass = mx > v + 7 || mn < v - 7;
+        entry = (uint32_t)off | ((uint32_t)ix << 13) | ((uint32_t)iy << 19);
+      }
+      const uint64_t m = ballot64(pass);
+      if (m) {
+        if (pass) q[qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = entry;
+        qn += (int)__popcll(m);
+        if (qn >= 64) {
+          qn -= 64;
+          __builtin_amdgcn_wave_barrier();
+          score_batch(qn, 64);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (qn > 0) score_batch(0, qn);
+    __builtin_amdgcn_wave_barrier();
+    // ---- 3x3 suppression inside the interior (neighbours outside it sit in the zero ring); survivors are compacted into the dead ROI
+    // tile as x | y << 12 | score << 24, coordinates relative to (minBorder, minBorder) as the candidate array wants them ----
+    int nk = 0;
+    auto nms_at = [&](bool valid, int ix, int iy) {
+      bool keep = false;
+      uint32_t out = 0;
+      if (valid) {
+        const uint8_t* sc = score8 + (iy + 1) * FC_SPITCH + ix + 1;
+        const int ss = sc[0];
+        const int nb = max(max(max((int)sc[-FC_SPITCH - 1], (int)sc[-FC_SPITCH]), max((int)sc[-FC_SPITCH + 1], (int)sc[-1])),
+                           max(max((int)sc[1], (int)sc[FC_SPITCH - 1]), max((int)sc[FC_SPITCH], (int)sc[FC_SPITCH + 1])));
+        keep = ss > nb;  // a score is >= 7: zero (no corner) never passes
+        out = (uint32_t)(ox + 3 + ix) | ((uint32_t)(oy + 3 + iy) << 12) | ((uint32_t)ss << 24);
+      }
+      const uint64_t m = ballot64(keep);
+      if (m) {
+        if (keep) tile32[nk + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = out;
+        nk += (int)__popcll(m);
+      }
+    };
+    if (nc <= FC_CCAP) {  // the usual case: only the remembered corners are looked at, and wiped afterwards
+      for (int i0 = 0; i0 < nc; i0 += 64) {
+        const bool valid = i0 + lane < nc;
+        const int pos = valid ? (int)clist[i0 + lane] : 0;
+        nms_at(valid, pos & 0x3f, pos >> 6);
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < nc; i += 64) {
+        const int pos = clist[i];
+        score8[((pos >> 6) + 1) * FC_SPITCH + (pos & 0x3f) + 1] = 0;
+      }
+    } else {
+      for (int p0 = 0; p0 < npix; p0 += 64) {
+        const int p = p0 + lane;
+        const int iy = (int)(((float)p + 0.5f) * rcp_iw), ix = p - iy * iw;
+        nms_at(p < npix, ix, iy);
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < FC_SROWS * FC_SPITCH / 4; i += 64) score32[i] = 0u;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (nk > 0) {
+      int off = 0;
+      if (lane == 0) off = atomicAdd(&cursor[2 * ((int64_t)f * L.nlevels + level)], nk);
+      off = __builtin_amdgcn_readfirstlane(off);
+      const int64_t co = (int64_t)f * cand_block + g.cand_off;
+      for (int i = lane; i < nk; i += 64) {
+        const uint32_t e = tile32[i];
+        if (off + i < g.cand_cap) cand_xy[co + off + i] = (e & 0xfffu) | (((e >> 12) & 0xfffu) << 16), cand_sc[co + off + i] = e >> 24;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // Rows per (strip, segment) work item.  A wavefront lives for the whole item, so long segments leave a long under-filled
 // tail at the end of the launch (96 rows: +20 % kernel time over 24..32), and the NMS tile of a region has to fit its LDS.
 // A single frame has only ~160 items of 24 rows for 1024 SIMDs: short segments (8 rows of work under 8 halo rows) spread it over
@@ -481,14 +712,35 @@ FastLevels fast_levels(const Geom& g, int batch) {
   return L;
 }
 
-// scores + in-cell NMS per region; survivors to the candidate array / the low list of their (frame, level) (the per-cell vote: octree.hip)
-void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, int fast_th, uint32_t* d_cor, uint8_t* d_cell_hi,
-                       uint32_t* d_cand_xy, uint32_t* d_cand_sc, uint32_t* d_cand_lo, int64_t cand_block, int32_t* d_cursor, int batch) {
-  const int t_min = fast_th < 7 ? fast_th : 7;
+// scores + in-cell NMS per region; survivors to the candidate array / the low list of their (frame, level) (the per-cell vote: octree.hip).
+// d_tpass[level] = threshold of the level's streaming pass (the lane's adaptive state, see k_octree)
+void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, int fast_th, const int32_t* d_tpass, uint32_t* d_cor,
+                       uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, uint32_t* d_cand_lo, int64_t cand_block, int32_t* d_cursor, int batch) {
   const FastLevels L = fast_levels(g, batch);
   const dim3 grid((L.items_per_frame + UVO_FAST_WAVES - 1) / UVO_FAST_WAVES, batch);
-  hipLaunchKernelGGL(k_fast_score, grid, dim3(64 * UVO_FAST_WAVES), 0, s, d_pyr, pyr_block, L, t_min, fast_th, d_cor, d_cell_hi, d_cand_xy, d_cand_sc, d_cand_lo,
+  hipLaunchKernelGGL(k_fast_score, grid, dim3(64 * UVO_FAST_WAVES), 0, s, d_pyr, pyr_block, L, d_tpass, fast_th, d_cor, d_cell_hi, d_cand_xy, d_cand_sc, d_cand_lo,
                      cand_block, d_cursor);
+}
+
+// the sparse second pass at the literal 7 over the cells of threshold-adaptive levels that own no survivor (only needed when fastTh > 7):
+// list them, then redo them with a fixed grid of wavefronts (most of which leave at once on textured frames)
+void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, const CellDesc* d_cells, const int32_t* d_flag_cell,
+                       const int32_t* d_tpass, const uint8_t* d_cell_hi, uint2* d_list, int32_t* d_n_list, uint32_t* d_cand_xy, uint32_t* d_cand_sc,
+                       int64_t cand_block, int32_t* d_cursor, int batch) {
+  const FastLevels L = fast_levels(g, batch);
+  hipLaunchKernelGGL(k_fast_cells_list, dim3((L.flags_per_frame + FCL_THREADS - 1) / FCL_THREADS, batch), dim3(FCL_THREADS), 0, s, d_flag_cell, L.flags_per_frame,
+                     g.nlevels, d_tpass, d_cell_hi, d_list, d_n_list);
+  int max_roi = 0;
+  for (int l = 0; l < g.nlevels; ++l) max_roi = std::max(max_roi, std::max(g.lv[l].wCell, g.lv[l].hCell) + 6);
+  const bool small = max_roi <= 48;
+  // a fixed grid that fills the chip once (seven / three workgroups of four wavefronts per CU: LDS); fewer when the batch cannot hold that many cells
+  const int64_t max_items = (int64_t)g.total_cells * batch;
+  const int waves = (int)std::min<int64_t>(max_items, 256 * (small ? 7 : 3) * FC_WAVES);
+  const dim3 grid((waves + FC_WAVES - 1) / FC_WAVES);
+  if (small)
+    hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64 * FC_WAVES), 0, s, d_pyr, pyr_block, L, d_cells, d_list, d_n_list, d_cand_xy, d_cand_sc, cand_block, d_cursor);
+  else
+    hipLaunchKernelGGL(k_fast_cells<66>, grid, dim3(64 * FC_WAVES), 0, s, d_pyr, pyr_block, L, d_cells, d_list, d_n_list, d_cand_xy, d_cand_sc, cand_block, d_cursor);
 }
 
 }  // namespace uvo

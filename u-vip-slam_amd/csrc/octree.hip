@@ -44,7 +44,7 @@ static inline size_t oct_lds_bytes(int M, int Mp2, int pyr_words) {
 template <int NT>
 __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max, int pyr_words, int box_region, int lds_bytes,
                                                         FastLevels FL, const uint32_t* __restrict__ cand_lo,
-                                                        int32_t* __restrict__ cursor, uint8_t* cell_hi,
+                                                        int32_t* __restrict__ cursor, int32_t* tpass, int32_t* fstat, int adapt, int fast_th, uint8_t* cell_hi,
                                                         uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc,
                                                         int64_t cand_block, int32_t* __restrict__ cand_count,
                                                         uint32_t* __restrict__ pstate, uint32_t* __restrict__ sel_xy,
@@ -68,12 +68,12 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
   // (n_hi of them); the others (7 <= score < fastTh) wait in the level's low list for the per-cell vote, which needs every region of
   // a cell finished: FAST(cell, fastTh); if empty FAST(cell, 7) (src/ORBextractor.cc:792-799) -- a low survivor is a candidate iff its
   // cell holds no survivor >= fastTh.  One contiguous read of the low list, appended behind the first n_hi candidates. ----
-  __shared__ int s_pcount;
+  __shared__ int s_pcount, s_zero;
   {
     const FastLevel fg = FL.l[level];
     int32_t* cur = cursor + 2 * ((int64_t)f * nlevels + level);
     const int n_hi = min(cur[0], g.cand_cap), n_lo = min(cur[1], g.cand_cap);
-    if (threadIdx.x == 0) s_pcount = n_hi;
+    if (threadIdx.x == 0) s_pcount = n_hi, s_zero = 0;
     uint8_t* hi = cell_hi + (int64_t)f * FL.flags_per_frame + fg.flag_base;
     const int lane = threadIdx.x & 63;
     // the level's cell flags go to LDS first (the node tables are not live yet: the staging shares their bytes); levels with more
@@ -84,6 +84,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
     if (flag_lds)
       for (int i = threadIdx.x; i < n_flags; i += NT) s_flag[i] = hi[i];
     __syncthreads();
+    {  // cells of this (frame, level) without a survivor >= fastTh: the batch's fall-back share steers the level's FAST mode (below)
+      int z = 0;
+      for (int i = threadIdx.x; i < n_flags; i += NT) z += (flag_lds ? s_flag[i] : hi[i]) == 0 ? 1 : 0;
+      if (z) atomicAdd(&s_zero, z);
+    }
     constexpr int LU = 8;  // low-list words in flight per thread
     for (int i0 = 0; i0 < n_lo; i0 += LU * NT) {
       uint32_t e[LU];
@@ -127,7 +132,37 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
     // sets / advances them)
     for (int i = threadIdx.x; i < n_flags; i += NT) hi[i] = 0;
     if (threadIdx.x == 0) cur[0] = 0, cur[1] = 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fstat[3 * kMaxLevels] = 0;  // the consumed list of fall-back cells (k_fast_cells_list)
   }
+  // the lane's adaptive FAST mode.  A level streams either at fastTh, with the sparse literal-7 pass over the cells left empty
+  // (k_fast_cells), or once at 7 with the vote above; both give the same candidates, the cheaper one depends on how many cells fall
+  // back.  fstat[level] sums the batch's fall-back cells (flag grid minus the grid positions that are no cell at all); the last
+  // problem of a level turns the sum into next batch's tpass[level] (above 22 % -> one pass at 7, below 14 % -> adaptive; measured break-even: a fall-back cell costs 5.5 x what the two-pass form saves per cell, 18 %)
+  // and keeps it in fstat[2 * kMaxLevels + level] for whoever wants to look.  Stream order makes the new values visible to this
+  // lane's next k_fast_score; no other lane reads them.
+  // One 64-bit atomic per workgroup carries both the count of finished (frame, level) problems (high half) and the sum of their
+  // fall-back cells (low half): whoever completes the level's count owns the sum -- no fence, no second atomic to order against (an
+  // agent-scope fence writes back and invalidates this XCD's L2 on gfx950: 2000 of them per launch cost 60 % of the kernel).  Issued
+  // when the problem is done, so that nobody waits for its round trip.
+  const int fallback_here = s_zero - (FL.l[level].nRows * FL.l[level].nCols - g.n_cells);
+  auto report_fallback = [&]() {
+    if (threadIdx.x != 0) return;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(fstat) + level;
+    const unsigned long long mine = (1ull << 32) | (unsigned long long)(uint32_t)fallback_here;
+    const unsigned long long tot = atomicAdd(acc, mine) + mine;
+    if ((uint32_t)(tot >> 32) == gridDim.x) {  // this level's last problem of the batch
+      *acc = 0ull;
+      const int64_t zc = (int64_t)(uint32_t)tot, cells = (int64_t)g.n_cells * gridDim.x;
+      fstat[2 * kMaxLevels + level] = (int32_t)zc;
+      if (adapt && fast_th > 7 && cells > 0) {
+        const int cur_t = tpass[level];
+        if (cur_t > 7 && zc * 100 > cells * 22)
+          tpass[level] = 7;
+        else if (cur_t <= 7 && zc * 100 < cells * 14)
+          tpass[level] = fast_th;
+      }
+    }
+  };
   OCT_TRACE_MARK()  // end of the candidate gather
   int P = s_pcount;
   if (threadIdx.x == 0) cand_count[f * nlevels + level] = P;
@@ -135,6 +170,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
   int32_t* out_n = sel_count + f * nlevels + level;
   if (P == 0) {
     if (threadIdx.x == 0) *out_n = 0;
+    report_fallback();
     return;
   }
   oct::Params pr;
@@ -182,10 +218,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
       n = oct::run<0>(pr, w, cand_xy + co, cand_sc + co, pstate + co, sel_xy + so, sel_sc + so, g.sel_cap);
   }
   if (threadIdx.x == 0) *out_n = n;
+  report_fallback();
 }
 
 int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_lo, int32_t* d_cursor,
-                   uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
+                   int32_t* d_tpass, int32_t* d_fstat, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
                    int32_t* d_sel_count, int batch) {
   int M = 0;
   for (int l = 0; l < g.nlevels; ++l) {
@@ -220,10 +257,10 @@ int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, cons
 #endif
   if (wide)
     hipLaunchKernelGGL(k_octree<1024>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), (int)lds, fast_levels(g, batch), d_cand_lo,
-                       d_cursor, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count);
+                       d_cursor, d_tpass, d_fstat, st.adapt, st.fast_th, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count);
   else
     hipLaunchKernelGGL(k_octree<OCT_THREADS>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), (int)lds, fast_levels(g, batch),
-                       d_cand_lo, d_cursor, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block,
+                       d_cand_lo, d_cursor, d_tpass, d_fstat, st.adapt, st.fast_th, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block,
                        d_sel_count);
   return UVO_OK;
 }
