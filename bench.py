@@ -10,12 +10,17 @@ With N GPUs (one process per GPU) rank r owns frames [r*B, (r+1)*B) of ONE globa
 the NEIGHBOURING rank's first frame, recomputed locally as a 1-frame halo: weak scaling, no data-path collective
 (torch.distributed / RCCL carries the timing barrier and the max-over-ranks only).
 
-`value` is the HBM-resident rate.  The same line carries: the host-to-host rate through uvo_sharder_run (uploads of page-locked
-frames + the gather of all ranks' results into one page-locked host region, `host_to_host`), sub-records for configs[1] (batch-1
-latency), extract-only and configs[4] (fused frustum search), both roofs of the dominant kernel (`roofline`: HBM bytes and VALU
-issue), a measured device-copy bandwidth next to the 8 TB/s spec, `verified_frames` (outputs of the TIMED buffers compared with
-the CPU oracle after the timed region; a mismatch fails the run) and `cpu_baseline` (the CPU oracle -- a line-by-line port of the
-reference path -- timed on this host's cores on bounded samples).  Prints ONE JSON line on rank 0.
+`value` is the HBM-resident rate; consecutive steps read four DISTINCT input batches in turn (the sequence and its three mirror
+images: same statistics, 4 x 84 MB, more than the 256 MB Infinity Cache keeps).  The same line carries: `roofline` = the HBM
+roofline of the dominant kernel (algorithmic bytes per launch / its live launch duration, HIP events on the library's stream inside
+the timed region, against 8 TB/s) with `roofline.per_kernel` for every kernel of the step, top-level `whole_path_frac` (the step's
+algorithmic bytes x frames/s against 8 TB/s) and `valu_frac` (the dominant kernel's VALU issue rate against the chip's issue peak --
+what actually bounds it); the host-to-host rate through uvo_sharder (uploads of page-locked frames + the gather of all ranks'
+results into one page-locked host region, `host_to_host`); sub-records for configs[1] (batch-1 latency), extract-only and
+configs[4] (fused frustum search); a measured device-copy bandwidth next to the 8 TB/s spec; `verified_frames` (outputs of the TIMED
+buffers compared with the CPU oracle after the timed region; a mismatch fails the run; the oracle is this repo's restatement of the
+reference -- parity unpinned) and `cpu_baseline` (the same oracle timed on this host's cores on bounded
+samples).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import importlib
@@ -138,7 +143,7 @@ def _time_extract_match(o, frames, nfeat, budget_s, match=True):
     return n, time.perf_counter() - t0
 
 
-def _time_threads(o, frames, nfeat, budget_s, threads):
+def _time_threads(o, frames, nfeat, budget_s, threads, match=True):
     """One frame per thread (ctypes releases the GIL inside the oracle; every thread owns its extractor)."""
     from concurrent.futures import ThreadPoolExecutor
     counts = [0] * threads
@@ -149,7 +154,7 @@ def _time_threads(o, frames, nfeat, budget_s, threads):
         prev, n = None, 0
         while time.perf_counter() - t0 < budget_s:
             kp, de = oe(frames[(i + n * threads) % len(frames)])
-            if prev is not None and len(prev) and len(de):
+            if match and prev is not None and len(prev) and len(de):
                 o.knn2(prev, de)
             prev = de
             n += 1
@@ -176,8 +181,25 @@ def cpu_baseline(frames, cfg, c4=None):
         n, dt = _time_threads(on, frames, nfeat, 5.0, phys)
         rows["CPU-N"] = {"frames_per_s": round(n / dt, 3), "cores": phys, "flags": "-O3 -march=native", "frames": n,
                          "what": "same, one frame per thread on all physical cores"}
+        # CPU-HD: extraction of 1920x1080 frames at 2000 features, one frame per thread on all physical cores
+        synth = importlib.import_module("u-vip-slam_amd.synth")
+        hd = synth.make_sequence(0, 8, 1920, 1080, n_shapes=2500)
+        n, dt = _time_threads(on, hd, 2000, 4.0, phys, match=False)
+        rows["CPU-HD"] = {"frames_per_s": round(n / dt, 3), "cores": phys, "flags": "-O3 -march=native", "frames": n,
+                          "what": "extract only, 1920x1080, 2000 feats, %d levels, fastTh %d, one frame per thread" % (NLEVELS, FAST_TH)}
     except (OSError, subprocess.CalledProcessError) as e:  # no compiler on the box: the rows are simply absent
         rows["CPU-1n"] = {"error": str(e)[:200]}
+    # CPU-400 (footnote row): the harbor YAML as shipped -- 400 features, CLAHE pre-processing on (Data/Settings_VI_Aqualoc_harbor.yaml:67-79,
+    # src/Tracking.cc:425-431) -- extract only, 1 core
+    oe400 = o.extractor(400, SCALE, NLEVELS, FAST_TH)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 2.0:
+        oe400(o.clahe(frames[n % len(frames)], 4.0, (12, 12)))
+        n += 1
+    dt = time.perf_counter() - t0
+    rows["CPU-400"] = {"frames_per_s": round(n / dt, 3), "cores": 1, "flags": "-O3", "frames": n,
+                       "what": "CLAHE (clip 4, 12x12 tiles) + extract, %dx%d, 400 feats, %d levels, fastTh %d" % (cfg["W"], cfg["H"], NLEVELS, FAST_TH)}
     # CPU-M: the matcher alone (all-pairs knn-2 + ratio test of include/utils.h:81-111 on two consecutive frames' descriptors)
     oe = o.extractor(nfeat, SCALE, NLEVELS, FAST_TH)
     d0, d1 = oe(frames[0])[1], oe(frames[1])[1]
@@ -202,6 +224,8 @@ def cpu_baseline(frames, cfg, c4=None):
         rows["CPU-P"] = {"calls_per_s": round(n / dt, 2), "ms_per_call": round(dt / n * 1e3, 3), "cores": 1, "flags": "-O3", "matches": int(nm),
                          "what": "isInFrustum + SearchByProjection, 752x480 frame (%d kp) vs 5000 map points" % len(kp)}
     return {"value": rows["CPU-1"]["frames_per_s"], "unit": "frames/s", "cores": 1, "kind": "port",
+            "note": "a scalar line-by-line port of the reference path (OpenCV's own cv::FAST / GaussianBlur / resize are SIMD and several times "
+                    "faster): a reported baseline, not a speed-up claim over the reference",
             "sample": "%d frames drawn in order from this run's batch: oracle extract (%s) + knn-2 match of consecutive frames, 1 thread, g++ -O3 "
                       "without -march=native (BASELINE.md row CPU-1)" % (n1, what),
             "host": {"cpu_model": model, "physical_cores": phys, "logical_cpus": logical}, "rows": rows}
@@ -265,10 +289,11 @@ def device_copy_gbps(torch, dev):
     return 2.0 * n * 10 / dt / 1e9
 
 
-def load_pmc(config, dom):
-    """Counters of the dominant kernel from the committed rocprofv3 PMC passes of this same command (separate --pmc runs; the newest
-    profiles/r*_pmc.json recorded for this config): HBM bytes per launch (2 * FETCH_SIZE + WRITE_SIZE, in KB as counted: FETCH_SIZE
-    under-reports reads by 2x on gfx950) and VALU wave-instructions per launch."""
+def load_pmc(config):
+    """Per-kernel counters from the committed rocprofv3 PMC passes of this same command (separate --pmc runs; the newest
+    profiles/r*_pmc.json recorded for this config).  HBM bytes per launch = fetch_factor * FETCH_SIZE + WRITE_SIZE (KB as counted).
+    fetch_factor is the file's `_fetch_factor` (per kernel: calibrated with tools/ubench/stream_read.hip at the kernel's load width,
+    profiles/r*_fetch_calibration.json) -- older files without it get the guide's blanket 2.0."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
         try:
@@ -276,14 +301,16 @@ def load_pmc(config, dom):
                 j = json.load(fh)
         except (OSError, ValueError):
             continue
-        if int(j.get("_config", 2)) != config:
+        if int(j.get("_config", 2)) != config or not j.get("kernels"):
             continue
-        e = j.get("kernels", {}).get(dom)
-        if not e:
-            continue
-        traffic = int((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024) if "FETCH_SIZE" in e and "WRITE_SIZE" in e else None
-        return traffic, e.get("SQ_INSTS_VALU"), j.get("_frames_per_launch"), "profiles/" + os.path.basename(path)
-    return None, None, None, None
+        ff = j.get("_fetch_factor", {})
+        out = {}
+        for name, e in j["kernels"].items():
+            f = float(ff.get(name, ff.get("_default", 2.0)))
+            traffic = int((f * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024) if "FETCH_SIZE" in e and "WRITE_SIZE" in e else None
+            out[name] = {"traffic": traffic, "valu": e.get("SQ_INSTS_VALU"), "salu": e.get("SQ_INSTS_SALU"), "fetch_factor": f}
+        return out, j.get("_frames_per_launch"), "profiles/" + os.path.basename(path)
+    return {}, None, None
 
 
 def main():
@@ -337,7 +364,21 @@ def main():
     frames = uvo.pinned_empty((B + 1, H, W), np.uint8)
     frames[:B] = synth.make_sequence(first, B, W, H, n_shapes=cfg["n_shapes"])
     frames[B] = synth.make_sequence(halo, 1, W, H, n_shapes=cfg["n_shapes"])[0]
-    d_imgs = torch.from_numpy(frames).to(dev)
+    # four distinct input batches, read in turn by consecutive steps: the sequence and its mirror images (left-right, up-down, both) --
+    # the same corner statistics, different bytes, so that no step finds its 84 MB of input in the Infinity Cache of the step before
+    NRING = 4
+    d_ring = [torch.from_numpy(frames).to(dev)]
+    for k in range(1, NRING):
+        d_ring.append(torch.flip(d_ring[0], dims=[d for d, on in ((2, k & 1), (1, k & 2)) if on]).contiguous())
+    d_imgs = d_ring[0]
+
+    def host_variant(k):
+        a = frames
+        if k & 1:
+            a = a[:, :, ::-1]
+        if k & 2:
+            a = a[:, ::-1, :]
+        return np.ascontiguousarray(a)
 
     ex = uvo.ORBextractor(NFEAT, SCALE, NLEVELS, 0, FAST_TH, max_width=W, max_height=H, max_batch=B + 1, device=local_rank)
     cap = ex.cap
@@ -364,11 +405,14 @@ def main():
         ex.tune(uvo.UVO_TUNE_OCT_WIDE_MAX, int(os.environ["UVO_BENCH_OCT_WIDE_MAX"]))
     torch.cuda.synchronize()
     counter = [0]
+    lane_variant = [0] * DEPTH   # which input batch a lane's output buffers hold
 
     def extract_only():
-        o = outs[counter[0] % DEPTH]
+        li, k = counter[0] % DEPTH, counter[0] % NRING
+        o = outs[li]
+        lane_variant[li] = k
         counter[0] += 1
-        ex.extract_batch_device(d_imgs.data_ptr(), B + 1, W, H, o.kp.data_ptr(), o.desc.data_ptr(), o.n.data_ptr(), cap)
+        ex.extract_batch_device(d_ring[k].data_ptr(), B + 1, W, H, o.kp.data_ptr(), o.desc.data_ptr(), o.n.data_ptr(), cap)
         return o
 
     def step():
@@ -418,10 +462,25 @@ def main():
     mt.profile(False)
 
     # ---- the timed buffers, on the host (both lanes' last results) ----
-    host = []
-    for o in outs:
-        host.append(dict(n=o.n.cpu().numpy(), kp=o.kp.cpu().numpy().view(np.uint8).reshape(B + 1, cap, 28), de=o.desc.cpu().numpy(), i0=o.idx0.cpu().numpy(),
-                         i1=o.idx1.cpu().numpy(), d0=o.d0.cpu().numpy().astype(np.uint16), d1=o.d1.cpu().numpy().astype(np.uint16)))
+    def download(o):
+        return dict(n=o.n.cpu().numpy(), kp=o.kp.cpu().numpy().view(np.uint8).reshape(B + 1, cap, 28), de=o.desc.cpu().numpy(), i0=o.idx0.cpu().numpy(),
+                    i1=o.idx1.cpu().numpy(), d0=o.d0.cpu().numpy().astype(np.uint16), d1=o.d1.cpu().numpy().astype(np.uint16))
+
+    host = [download(o) for o in outs]
+    timed_variants = list(lane_variant)
+
+    # ---- live per-kernel durations: the same pipelined step with every launch bracketed by events (outside the timed region: the
+    # event records cost 3 % of the throughput) -- what each kernel takes with the other lane's kernels beside it ----
+    ex.profile(True)
+    mt.profile(True)
+    n_live = max(8, min(20, steps // 4))
+    for _ in range(n_live):
+        step()
+    sync_all()
+    live = dict(ex.kernel_times())
+    live.update(mt.kernel_times())
+    ex.profile(False)
+    mt.profile(False)
     n_kp = host[0]["n"][:B]
 
     # ---- verification of the timed outputs against the CPU oracle (rank 0; a mismatch fails the run) ----
@@ -432,8 +491,9 @@ def main():
         oe = orc.extractor(NFEAT, SCALE, NLEVELS, FAST_TH)
         pairs = sorted(set([0, B // 4, B // 2 - 1, B - 2, B - 1]))   # (p, p + 1); B - 1 pairs with the halo frame
         need = sorted(set(pairs) | set(p + 1 for p in pairs))
-        ref = {f: oe(frames[f]) for f in need}
         for li, hb in enumerate(host):
+            hv = host_variant(timed_variants[li])
+            ref = {f: oe(hv[f]) for f in need}
             for f in need:
                 kp_o, de_o = ref[f]
                 n = int(hb["n"][f])
@@ -445,7 +505,8 @@ def main():
                 got = (hb["i0"][p, :nq], hb["d0"][p, :nq].astype(np.int32), hb["i1"][p, :nq], hb["d1"][p, :nq].astype(np.int32))
                 if not all((g == e).all() for g, e in zip(got, r)):
                     raise SystemExit("bench.py: VERIFICATION FAILED -- lane %d knn-2 rows of pair %d differ from the oracle" % (li, p))
-        verified = {"frames": len(need) * len(host), "distinct_frames": need, "knn2_pairs": pairs, "lanes": len(host), "against": "CPU oracle, byte for byte"}
+        verified = {"frames": len(need) * len(host), "distinct_frames": need, "knn2_pairs": pairs, "lanes": len(host), "input_batches_of_the_lanes": timed_variants,
+                    "against": "CPU oracle (this repo's restatement of the reference; parity unpinned), byte for byte"}
 
     # ---- host-to-host leg: the sharder (uploads from page-locked frames, results gathered into ONE host region shared by all ranks) ----
     sub = {}
@@ -494,9 +555,12 @@ def main():
         h2h_drain()
         reps = max(6, min(30, steps // 4))
         dth = timed_steps(h2h_run, h2h_drain, reps, dist, red_dev)
-        # the gathered region must hold exactly what the HBM-resident leg produced (this rank's block; pair B-1 only where the halo
-        # is the true next frame)
-        hb = host[0]
+        # the gathered region must hold exactly what the HBM-resident leg produces for the same frames (input batch 0 of the ring;
+        # this rank's block; pair B-1 only where the halo is the true next frame)
+        counter[0] = 0
+        step()
+        sync_all()
+        hb = download(outs[0])
         ok = (g_n[first:first + B] == hb["n"][:B]).all()
         for f in range(B):
             n = int(hb["n"][f])
@@ -593,7 +657,9 @@ def main():
         # noise="cumulative": 5 -> 18 % of the pixels pass as FAST corners instead of a steady 4 %): extraction time follows the corner
         # density.  Last, because it overwrites the device frames.
         fr_c = synth.make_sequence(first, B + 1, W, H, n_shapes=cfg["n_shapes"], noise="cumulative")
-        d_imgs.copy_(torch.from_numpy(fr_c).to(dev))
+        d_ring[0].copy_(torch.from_numpy(fr_c).to(dev))
+        for k in range(1, NRING):
+            d_ring[k].copy_(torch.flip(d_ring[0], dims=[d for d, on in ((2, k & 1), (1, k & 2)) if on]))
         for _ in range(DEPTH + 1):
             step()
         sync_all()
@@ -618,20 +684,43 @@ def main():
         bytes_per_launch = alg.get(dom, 0) * (B + 1) / launches_per_step
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         total_alg = sum(v for kname, v in alg.items() if kname not in ("k_pad_level0", "k_fast_blur"))
-        traffic, valu_instr, pmc_frames, pmc_src = load_pmc(args.config, dom)
-        if pmc_frames and pmc_frames != B + 1:   # the counters were taken at the config's default batch: per-launch figures scale with the frames
-            traffic = int(traffic * (B + 1) / pmc_frames) if traffic else traffic
-            valu_instr = valu_instr * (B + 1) / pmc_frames if valu_instr else valu_instr
+        pmc, pmc_frames, pmc_src = load_pmc(args.config)
+        scale = (B + 1) / pmc_frames if pmc_frames else 1.0   # the counters were taken at the config's default batch: per-launch figures scale with the frames
+
+        def pmc_of(name):   # profiler name -> summed counters of the device kernels behind it (k_knn2 -> k_knn2_mfma, k_fast_cells -> + _list)
+            hit = [v for k, v in pmc.items() if k == name or k.startswith(name + "_")]
+            if not hit:
+                return None, None
+            tr = [h["traffic"] for h in hit if h["traffic"] is not None]
+            va = [h["valu"] for h in hit if h["valu"] is not None]
+            return (int(sum(tr) * scale) if tr else None), (sum(va) * scale if va else None)
+
+        # ---- per-kernel table: algorithmic bytes per step, duration with the other lane's kernels beside it (live)
+        # and alone on the chip, achieved GB/s and fraction of 8 TB/s on the live duration, HBM bytes from the counters and their ratio
+        # to the algorithmic bytes.  Durations are per step (k_resize_level: its 7 launches together). ----
+        per_kernel = {}
+        for kname in sorted(set(live) | set(serial)):
+            ab = int(alg.get(kname, 0) * (B + 1))
+            live_ms = live[kname][0] / n_live if kname in live else None
+            alone_ms = serial[kname][0] / 3 if kname in serial else None
+            if kname == dom:   # the dominant kernel's live duration comes from the timed region itself
+                live_ms = ktimes[dom][0] / steps
+            tr, _ = pmc_of(kname)
+            if tr is not None and kname == "k_resize_level":
+                tr *= 7    # the counter file holds the mean over its 7 launches
+            gbps = ab / (live_ms * 1e-3) / 1e9 if live_ms and ab else None
+            per_kernel[kname] = {"alg_bytes": ab, "live_ms": round(live_ms, 5) if live_ms is not None else None,
+                                 "alone_ms": round(alone_ms, 5) if alone_ms is not None else None, "GBps": round(gbps, 1) if gbps else None,
+                                 "frac": round(gbps / HBM_PEAK_GBS, 5) if gbps else None, "counter_bytes": tr,
+                                 "ratio": round(tr / ab, 3) if tr and ab else None}
+        traffic, valu_instr = pmc_of(dom)
         hbm_frac = achieved / HBM_PEAK_GBS
-        roof_hbm = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(bytes_per_launch), "measured_device_copy_GBps": sub.get("device_copy_GBps")}
-        roof = dict(roof_hbm)
-        bound = "hbm"
         roof_valu = None
         if valu_instr:
             ginstr = valu_instr / avg_launch_s / 1e9
             roof_valu = {"achieved": round(ginstr, 2), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": round(ginstr / VALU_PEAK_GINSTR, 5),
-                         "valu_wave_instructions_per_launch": int(valu_instr)}
+                         "valu_wave_instructions_per_launch": int(valu_instr),
+                         "lane_instructions_per_pixel": round(valu_instr * 64 / (alg["k_fast_score"] * (B + 1)), 2) if dom == "k_fast_score" else None}
             # the same kernel alone on the chip (no second pipeline lane beside it), and against the issue rate of the instruction class most
             # of its instructions belong to: on gfx950 only plain two-operand 32-bit / 16-bit ALU ops and fp32 add / mul / fma issue every
             # 2 cycles per SIMD; packed, three-operand, compare, 32-bit min / max, integer multiply and conversion instructions take 4
@@ -641,8 +730,18 @@ def main():
                 g1 = valu_instr / alone_s / 1e9
                 roof_valu["alone_on_the_chip"] = {"launch_ms": round(alone_s * 1e3, 5), "achieved": round(g1, 2), "frac": round(g1 / VALU_PEAK_GINSTR, 5),
                                                   "frac_of_4_cycle_class_peak": round(g1 / (VALU_PEAK_GINSTR / 2), 5)}
-            if roof_valu["frac"] > hbm_frac:
-                bound, roof = "valu", dict(roof_valu)
+        whole_path_frac = total_alg * value / world / 1e9 / HBM_PEAK_GBS
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 5), "traffic": traffic,
+                    "kernel": dom, "avg_launch_ms": round(avg_launch_s * 1e3, 5), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                    "traffic_source": pmc_src, "measured_device_copy_GBps": sub.get("device_copy_GBps"),
+                    "per_kernel": per_kernel, "valu": roof_valu, "whole_path_GBps": round(total_alg * value / world / 1e9, 2),
+                    "whole_path_algorithmic_bytes_per_frame": int(total_alg),
+                    "kernel_ms_per_step_in_timed_region": {k: round(v[0] / steps, 4) for k, v in sorted(ktimes.items())},
+                    "kernel_ms_per_step_unoverlapped": {k: round(v[0] / 3, 4) for k, v in sorted(serial.items())},
+                    "note": "frac = algorithmic bytes per launch of the dominant kernel / its live launch duration (HIP events on the library's stream, "
+                            "timed region) / 8 TB/s; traffic = HBM bytes per launch from the committed rocprofv3 --pmc passes of this command "
+                            "(fetch factor per kernel: profiles/*_fetch_calibration.json); the kernel is bound by VALU issue, not HBM: see valu / "
+                            "the top-level valu_frac"}
         out = {
             "metric": "frames/sec ORB extract+match, %dx%d @%d kp" % (W, H, NFEAT),
             "value": round(value, 1),
@@ -662,16 +761,13 @@ def main():
                        "generator": "SURVEY.md 8(d): value-noise texture + %d shapes + N(0,3) sensor noise per frame; camera motion = a small affine per "
                                     "frame inside 32-frame chains (u-vip-slam_amd/synth.py make_sequence, noise='sensor')" % cfg["n_shapes"],
                        "batch_per_gpu": B, "sharding": "contiguous frame blocks of one global sequence, 1-frame halo from the neighbour, no collective",
-                       "pipeline_depth": DEPTH, "mean_keypoints_per_frame": round(k_mean, 1)},
+                       "pipeline_depth": DEPTH, "mean_keypoints_per_frame": round(k_mean, 1),
+                       "input_batches_in_rotation": NRING, "fast_mode": args.fast_mode},
             "verified_frames": verified["frames"] if verified else 0,
             "verification": verified,
-            "roofline": dict(roof, bound=bound, kernel=dom, traffic=traffic, traffic_source=pmc_src, avg_launch_ms=round(avg_launch_s * 1e3, 5),
-                             hbm=roof_hbm, valu=roof_valu, whole_path_GBps=round(total_alg * value / world / 1e9, 2),
-                             kernel_ms_per_step_in_timed_region={k: round(v[0] / steps, 4) for k, v in sorted(ktimes.items())},
-                             kernel_ms_per_step_unoverlapped={k: round(v[0] / 3, 4) for k, v in sorted(serial.items())},
-                             note="both roofs of the dominant kernel: HBM = algorithmic bytes / live launch time against 8 TB/s; VALU = SQ_INSTS_VALU per "
-                                  "launch (committed rocprofv3 --pmc pass of this command) / live launch time against the chip's wave-instruction issue "
-                                  "peak; `bound` is the larger fraction"),
+            "roofline": roofline,
+            "whole_path_frac": round(whole_path_frac, 5),
+            "valu_frac": roof_valu["frac"] if roof_valu else None,
             "host_to_host": h2h,
             "sub_records": sub,
         }

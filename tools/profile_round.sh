@@ -14,7 +14,13 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_a -- python3 bench.p
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_b -- python3 bench.py $SHORT > /dev/null 2> $O/pmc_b.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $R/$O/pmc_c -- python3 bench.py $SHORT > /dev/null 2> $O/pmc_c.err
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 --output-format csv -d $R/$O/pmc_d -- python3 bench.py $SHORT > /dev/null 2> $O/pmc_d.err
-python3 tools/pmc_summary.py --config $CFG $O/pmc_a $O/pmc_b $O/pmc_c $O/pmc_d > $O/pmc.json
+# FETCH_SIZE / WRITE_SIZE calibration at the load widths the kernels use (once per tag)
+if [ ! -f $O/fetch_calibration.json ]; then
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/cal_a -- $R/tools/ubench/stream_read > /dev/null 2> $O/cal_a.err
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$O/cal_b -- $R/tools/ubench/stream_read > /dev/null 2> $O/cal_b.err
+  python3 tools/fetch_calibration.py $O/cal_a $O/cal_b > $O/fetch_calibration.json
+fi
+python3 tools/pmc_summary.py --config $CFG --calibration $O/fetch_calibration.json $O/pmc_a $O/pmc_b $O/pmc_c $O/pmc_d > $O/pmc.json
 find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 # keep the merge small
 find $O -name "*.csv" -size +2M -delete
