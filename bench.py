@@ -323,6 +323,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--h2h", action="store_true", help="run the host-to-host sharder leg even with --no-subrecords")
     ap.add_argument("--fast-mode", choices=["adaptive", "two_pass", "single_pass"], default="adaptive",
                     help="UVO_TUNE_FAST_MODE of the extractor (speed only; the keypoints are the same in every mode)")
     args = ap.parse_args()
@@ -511,7 +512,7 @@ def main():
     # ---- host-to-host leg: the sharder (uploads from page-locked frames, results gathered into ONE host region shared by all ranks) ----
     sub = {}
     h2h = None
-    if not args.no_subrecords:
+    if not args.no_subrecords or args.h2h:
         total = world * B
         chunk = max(B // int(os.environ.get("UVO_BENCH_CHUNKS", "2")), 1)   # chunks per rank and job, two in flight: the upload of one under the kernels of the other
         devices = [uvo.UVO_SHARD_REMOTE] * world

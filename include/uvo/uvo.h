@@ -93,9 +93,11 @@ int uvo_extract(uvo_extractor* h, const uint8_t* img, int width, int height, ptr
 /*
  * The top-up call together with the caller's loop in front of it (src/Tracking.cc:896-946): the occupancy grid is built on the
  * device from the tracked keypoints -- grid_2d((int)(pt.y / min_px_dist), (int)(pt.x / min_px_dist))++ on a zero matrix of
- * (height / min_px_dist + 2) x (width / min_px_dist + 2) -- and the extraction runs with FullDetect = false on it.  in_kp are the
- * tracked keypoints (`pts0`, passed through level 0 like `keypoints` on entry of operator()).  grid2d_out (optional): the grid after
- * the call, column-major, for callers that keep it.  img == NULL: the result of the last uvo_clahe(), as in uvo_extract.
+ * (height / min_px_dist + 2) x (width / min_px_dist + 2) -- and the extraction runs with FullDetect = false on it, with an EMPTY
+ * keypoint vector as at :946 (`pts0_ext`): in_kp are the tracked keypoints `pts0`, which only fill the grid (they must lie inside the
+ * image); out_kp / out_desc hold the NEW keypoints and descriptors alone (`pts0_ext`, `New_Descriptors`), which the caller appends
+ * to its own (:948-959).  grid2d_out (optional): the grid after the call, column-major, for callers that keep it.  img == NULL: the
+ * result of the last uvo_clahe(), as in uvo_extract.
  */
 int uvo_extract_tracked(uvo_extractor* h, const uint8_t* img, int width, int height, ptrdiff_t stride, const uvo_keypoint* in_kp, int n_in,
                         int min_px_dist, int num_feats_needed, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int* n_out, int32_t* grid2d_out);
@@ -169,19 +171,21 @@ int uvo_sharder_max_keypoints(const uvo_sharder* s); /* smallest `cap` uvo_shard
  * uvo_sharder_wait() blocks until the job's results are in the output arrays; uvo_sharder_run() is the two together.  Jobs run in
  * submission order and the lanes are not drained between them: with a second job submitted before the first is waited for, the
  * uploads of one run under the kernels of the other (a stream of jobs moves at the steady-state rate of the pipeline lanes).
- *   imgs             : host frames, frame g at imgs + (g - imgs_first_frame) * frame_stride (a process that owns only some shards
- *                      need only hold their frames and each block's halo frame); page-locked memory makes the uploads asynchronous
+ *   imgs, n_imgs     : n_imgs host frames, frame g at imgs + (g - imgs_first_frame) * frame_stride (a process that owns only some
+ *                      shards need only hold their frames and each block's halo frame: UVO_E_BADARG when a local shard's frames or
+ *                      its halo frame lie outside [imgs_first_frame, imgs_first_frame + n_imgs)); page-locked memory makes the
+ *                      uploads asynchronous
  *   out_kp / out_desc / n_out : [total][cap] / [total][cap][32] / [total]   (cap >= uvo_sharder_max_keypoints())
  *   idx0 / d0 / idx1 / d1     : [total - 1][cap] knn-2 rows of pair p (row q = keypoint q of frame p; as uvo_hamming_knn2), or all NULL
  * Only the elements of the local shards' frames / pairs are written.  All buffers of a job must stay valid and untouched until its
  * wait returns; jobs in flight at the same time need their own output arrays.
  */
-int uvo_sharder_submit(uvo_sharder* s, const uint8_t* imgs, int imgs_first_frame, int total_frames, int width, int height, ptrdiff_t stride,
-                       ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int32_t* idx0, uint16_t* d0,
+int uvo_sharder_submit(uvo_sharder* s, const uint8_t* imgs, int n_imgs, int imgs_first_frame, int total_frames, int width, int height,
+                       ptrdiff_t stride, ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int32_t* idx0, uint16_t* d0,
                        int32_t* idx1, uint16_t* d1, int* ticket);
 int uvo_sharder_wait(uvo_sharder* s, int ticket);
-int uvo_sharder_run(uvo_sharder* s, const uint8_t* imgs, int imgs_first_frame, int total_frames, int width, int height, ptrdiff_t stride,
-                    ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int32_t* idx0, uint16_t* d0,
+int uvo_sharder_run(uvo_sharder* s, const uint8_t* imgs, int n_imgs, int imgs_first_frame, int total_frames, int width, int height,
+                    ptrdiff_t stride, ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int32_t* idx0, uint16_t* d0,
                     int32_t* idx1, uint16_t* d1);
 
 /*

@@ -243,16 +243,21 @@ def test_extract_tracked_builds_the_callers_occupancy_grid_on_the_device(uvo, or
         for k in kin:
             grid[int(np.float32(k["y"]) / np.float32(d)), int(np.float32(k["x"]) / np.float32(d))] += 1
         need = 400 - n_in // 2
-        kp_o, de_o = oe(img, kin.copy(), grid, d, False, need)
+        # the reference calls the extractor with an EMPTY keypoint vector (pts0_ext, src/Tracking.cc:943-946) and the grid the tracked
+        # points filled: only the new points come back; the oracle's grid ends as the reference's would (mutated by the accepted points)
+        grid_o = grid.copy(order="F")
+        kp_o, de_o = oe(img, None, grid_o, d, False, need)
         kp_g, de_g, grid_g = ex.extract_tracked(img, kin, d, need, want_grid=True)
         _same(kp_g, de_g, kp_o, de_o, "extract_tracked n_in=%d" % n_in)
-        np.testing.assert_array_equal(grid_g, grid)
+        np.testing.assert_array_equal(grid_g, grid_o)
+        assert n_in == 0 or not (set(zip(kp_g["x"].tolist(), kp_g["y"].tolist())) & set(zip(kin["x"].tolist(), kin["y"].tolist()))), \
+            "tracked points must not come back as new ones"
     enh = ex.clahe(img, download=False)
     kin = kin[:300]
     grid = np.zeros((H // d + 2, W // d + 2), np.int32, order="F")
     for k in kin:
         grid[int(k["y"] / d), int(k["x"] / d)] += 1
-    kp_o, de_o = oe(oracle.clahe(img, 4.0, (12, 12)), kin.copy(), grid, d, False, 150)
+    kp_o, de_o = oe(oracle.clahe(img, 4.0, (12, 12)), None, grid, d, False, 150)
     kp_g, de_g = ex.extract_tracked(None, kin, d, 150)
     _same(kp_g, de_g, kp_o, de_o, "clahe -> extract_tracked(NULL)")
     ex.close()

@@ -84,6 +84,13 @@ def test_jobs_stream_through_the_lanes_without_draining(uvo, job):
         _check(ref[:n], rows[:n - 1], *o, "streamed job of %d frames" % n)
     with pytest.raises(uvo.UvoError):
         sh.wait(tickets[0])
+    # a stack that ends before a local shard's last frame (or its halo frame) is refused instead of read past its end
+    with pytest.raises(uvo.UvoError):
+        sh.submit(frames[:20], 0, 31, *outs[1])
+    with pytest.raises(uvo.UvoError):
+        sh.submit(frames[:total - 1], 0, total, *outs[0])
+    sh.run(frames, 0, 17, *outs[2])               # and the handle still works afterwards
+    _check(ref[:17], rows[:16], *outs[2], "after the refused jobs")
     sh.close()
 
 

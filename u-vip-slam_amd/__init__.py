@@ -153,8 +153,8 @@ def _load():
     lib.uvo_sharder_destroy.argtypes = [vp]
     lib.uvo_sharder_destroy.restype = None
     lib.uvo_sharder_max_keypoints.argtypes = [vp]
-    lib.uvo_sharder_run.argtypes = [vp, vp, ci, ci, ci, ci, cl, cl, vp, vp, ci, vp, vp, vp, vp, vp]
-    lib.uvo_sharder_submit.argtypes = [vp, vp, ci, ci, ci, ci, cl, cl, vp, vp, ci, vp, vp, vp, vp, vp, vp]
+    lib.uvo_sharder_run.argtypes = [vp, vp, ci, ci, ci, ci, ci, cl, cl, vp, vp, ci, vp, vp, vp, vp, vp]
+    lib.uvo_sharder_submit.argtypes = [vp, vp, ci, ci, ci, ci, ci, cl, cl, vp, vp, ci, vp, vp, vp, vp, vp, vp]
     lib.uvo_sharder_wait.argtypes = [vp, ci]
     lib.uvo_extract_batch_submit.argtypes = [vp, ci, vp, ci, ci, cl, cl, vp, vp, ci, vp, vp]
     lib.uvo_extract_batch_wait.argtypes = [vp, ci]
@@ -305,7 +305,7 @@ class Sharder:
         cap = self._check(imgs, total_frames, out_kp, out_desc, n_out, idx0, d0, idx1, d1)
         _, h, w = imgs.shape
         t = ctypes.c_int()
-        rc = lib.uvo_sharder_submit(self._h, imgs.ctypes.data, imgs_first_frame, total_frames, w, h, w, w * h, out_kp.ctypes.data, out_desc.ctypes.data, cap,
+        rc = lib.uvo_sharder_submit(self._h, imgs.ctypes.data, imgs.shape[0], imgs_first_frame, total_frames, w, h, w, w * h, out_kp.ctypes.data, out_desc.ctypes.data, cap,
                                     n_out.ctypes.data, _ptr(idx0), _ptr(d0), _ptr(idx1), _ptr(d1), ctypes.byref(t))
         if rc:
             raise UvoError(rc, "uvo_sharder_submit")

@@ -118,14 +118,18 @@ int fast_flags_per_frame(const Geom& g);
 // threads coexist in one process).  wide_max_problems: up to this many (frame, level) problems run as 1024-thread workgroups.
 struct OctLaunchState {
   int wide_max_problems = 256;
-  int adapt = 1;      // k_octree's last workgroup re-decides each level's FAST mode from the batch's share of fall-back cells
-  int fast_th = 20;   // the handle's fastTh (the threshold a threshold-adaptive level streams at)
-  size_t lds_configured = 0;  // dynamic-LDS limit already raised on this handle's device for both instantiations
 };
 int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_lo, int32_t* d_cursor,
-                   int32_t* d_tpass, int32_t* d_fstat, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate,
+                   int32_t* d_fcount, int32_t* d_n_cell_list, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate,
                    uint32_t* d_sel_xy, uint32_t* d_sel_sc, int32_t* d_sel_count, int batch);
-void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_sel_xy, const uint32_t* d_sel_sc,
+// FAST mode feedback handed to k_assemble (its workgroup 0 sums the batch's fall-back cells and re-decides each level's mode)
+struct FastAdapt {
+  const int32_t* fcount;  // [batch][nlevels] fall-back cells per (frame, level), written by k_octree
+  int32_t* tpass;         // [kMaxLevels] the lane's pass thresholds
+  int32_t* last;          // [kMaxLevels] the batch's sums, kept for uvo_extractor_fast_state
+  int adapt, fast_th;
+};
+void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, FastAdapt fa, const uint32_t* d_sel_xy, const uint32_t* d_sel_sc,
                      const int32_t* d_sel_count,
                      const uvo_keypoint* d_in_kp, const int32_t* d_n_in, int in_cap, int32_t* d_grid, int grid_rows, int grid_cols,
                      int min_px_dist, int full_detect, const int32_t* d_nfn, FinalSlot* d_flist, int32_t* d_n_final, int batch);

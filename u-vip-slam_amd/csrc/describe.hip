@@ -16,14 +16,47 @@ namespace uvo {
 //             incremented; per-level cap num_featsneeded*(8-level)/30 with a counter that carries across levels
 //             (:878,:892-897), global cap num_featsneeded (:898-901).  Order dependent -> one thread walks it.
 // TOPUP = false is the FullDetect concatenation alone: no LDS, so its workgroups find room next to the other lane's kernels
+// The adaptive FAST mode of a pipeline lane (fast.hip, octree.hip): k_octree left every (frame, level) problem's count of fall-back
+// cells -- cells without a keypoint at fastTh, src/ORBextractor.cc:795 -- in fa.fcount; workgroup 0 of k_assemble sums the batch and
+// sets the threshold each level streams at in the lane's NEXT batch: above 22 % fall-back cells one pass at 7 with the per-cell vote,
+// below 14 % the two-pass form (measured break-even: a fall-back cell costs 5.5 x what the two-pass form saves per cell, 18 %).
+// Both forms give the same candidates.  Stream order makes the new values visible to this lane's next k_fast_score; no other lane
+// reads them.
+__device__ __forceinline__ void adapt_fast_mode(const LevelGeom* __restrict__ lv, int nlevels, int batch, const FastAdapt& fa) {
+  __shared__ int s_sum[kMaxLevels];
+  if (threadIdx.x < kMaxLevels) s_sum[threadIdx.x] = 0;
+  __syncthreads();
+  for (int l = 0; l < nlevels; ++l) {
+    int z = 0;
+    for (int f = threadIdx.x; f < batch; f += blockDim.x) z += fa.fcount[f * nlevels + l];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) z += __shfl_xor(z, o, 64);
+    if ((threadIdx.x & 63) == 0 && z) atomicAdd(&s_sum[l], z);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nlevels) {
+    const int l = threadIdx.x;
+    const int64_t zc = s_sum[l], cells = (int64_t)lv[l].n_cells * batch;
+    fa.last[l] = (int32_t)zc;
+    if (fa.adapt && fa.fast_th > 7 && cells > 0) {
+      const int cur_t = fa.tpass[l];
+      if (cur_t > 7 && zc * 100 > cells * 22)
+        fa.tpass[l] = 7;
+      else if (cur_t <= 7 && zc * 100 < cells * 14)
+        fa.tpass[l] = fa.fast_th;
+    }
+  }
+}
+
 template <bool TOPUP>
-__global__ __launch_bounds__(256) void k_assemble(const LevelGeom* __restrict__ lv, int nlevels, const uint32_t* __restrict__ sel_xy,
+__global__ __launch_bounds__(256) void k_assemble(const LevelGeom* __restrict__ lv, int nlevels, FastAdapt fa, const uint32_t* __restrict__ sel_xy,
                                                   const uint32_t* __restrict__ sel_sc, int sel_block,
                                                   const int32_t* __restrict__ sel_count, const int32_t* __restrict__ n_in, int in_cap,
                                                   int32_t* __restrict__ grid, int grid_rows, int grid_cols, int min_px_dist,
                                                   int full_detect, const int32_t* __restrict__ nfn, FinalSlot* __restrict__ flist,
                                                   int flist_cap, int32_t* __restrict__ n_final) {
   const int f = blockIdx.x;
+  if (f == 0) adapt_fast_mode(lv, nlevels, (int)gridDim.x, fa);
   const uint32_t* sxy = sel_xy + (int64_t)f * sel_block;
   const uint32_t* ssc = sel_sc + (int64_t)f * sel_block;
   const int32_t* cnt = sel_count + f * nlevels;
@@ -431,16 +464,16 @@ void launch_occupancy_grid(hipStream_t s, const uvo_keypoint* d_in_kp, const int
   hipLaunchKernelGGL(k_occupancy_grid, dim3((in_cap + 255) / 256, batch), dim3(256), 0, s, d_in_kp, d_n_in, in_cap, min_px_dist, grid_rows, grid_cols, d_grid);
 }
 
-void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_sel_xy, const uint32_t* d_sel_sc,
+void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, FastAdapt fa, const uint32_t* d_sel_xy, const uint32_t* d_sel_sc,
                      const int32_t* d_sel_count, const uvo_keypoint* d_in_kp, const int32_t* d_n_in, int in_cap, int32_t* d_grid, int grid_rows,
                      int grid_cols, int min_px_dist, int full_detect, const int32_t* d_nfn, FinalSlot* d_flist, int32_t* d_n_final,
                      int batch) {
   (void)d_in_kp;
   if (full_detect)
-    hipLaunchKernelGGL(k_assemble<false>, dim3(batch), dim3(256), 0, s, d_lv, g.nlevels, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count, d_n_in, in_cap,
+    hipLaunchKernelGGL(k_assemble<false>, dim3(batch), dim3(256), 0, s, d_lv, g.nlevels, fa, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count, d_n_in, in_cap,
                        d_grid, grid_rows, grid_cols, min_px_dist, full_detect, d_nfn, d_flist, g.flist_cap, d_n_final);
   else
-    hipLaunchKernelGGL(k_assemble<true>, dim3(batch), dim3(256), 0, s, d_lv, g.nlevels, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count, d_n_in, in_cap,
+    hipLaunchKernelGGL(k_assemble<true>, dim3(batch), dim3(256), 0, s, d_lv, g.nlevels, fa, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count, d_n_in, in_cap,
                        d_grid, grid_rows, grid_cols, min_px_dist, full_detect, d_nfn, d_flist, g.flist_cap, d_n_final);
 }
 

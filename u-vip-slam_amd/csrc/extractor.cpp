@@ -55,7 +55,7 @@ struct Lane {
   uint8_t* d_cell_hi = nullptr;  // per cell: owns an NMS survivor >= fastTh
   // the lane's adaptive FAST mode: d_tpass[level] = threshold of the level's streaming pass (fastTh: threshold-adaptive two-pass form;
   // min(fastTh, 7): one pass + vote); d_fstat = the fall-back-cell sums k_octree turns into next batch's d_tpass (octree.hip)
-  int32_t *d_tpass = nullptr, *d_fstat = nullptr;
+  int32_t *d_tpass = nullptr, *d_fstat = nullptr, *d_fcount = nullptr;
   uint2* d_cell_list = nullptr;  // (cell, frame) of the fall-back cells of the batch in flight (k_fast_cells_list -> k_fast_cells)
   FinalSlot* d_flist = nullptr;
   Profiler prof;
@@ -413,7 +413,7 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
     // second call of src/ORBextractor.cc:797 for the cells of threshold-adaptive levels that the pass at fastTh left empty (nearly all
     // wavefronts find nothing to do on textured frames).  With the mode pinned to one pass no level can be adaptive: not launched.
     ProfScope p(h, "k_fast_cells");
-    launch_fast_cells(s, L.d_pyr, g.pyr_block, g, h->d_cells, h->d_cell_flag, L.d_tpass, L.d_cell_hi, L.d_cell_list, L.d_fstat + 3 * kMaxLevels, L.d_cand_xy,
+    launch_fast_cells(s, L.d_pyr, g.pyr_block, g, h->d_cells, h->d_cell_flag, L.d_tpass, L.d_cell_hi, L.d_cell_list, L.d_fstat + kMaxLevels, L.d_cand_xy,
                       L.d_cand_sc, g.cand_block, L.d_cursor, batch);
   }
   {
@@ -422,13 +422,14 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   }
   {
     ProfScope p(h, "k_octree");
-    rc = launch_octree(s, h->oct, h->d_lv, g, L.d_cand_lo, L.d_cursor, L.d_tpass, L.d_fstat, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count,
+    rc = launch_octree(s, h->oct, h->d_lv, g, L.d_cand_lo, L.d_cursor, L.d_fcount, L.d_fstat + kMaxLevels, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count,
                        L.d_pstate, L.d_sel_xy, L.d_sel_sc, L.d_sel_count, batch);
     if (rc) return rc;
   }
   {
     ProfScope p(h, "k_assemble");
-    launch_assemble(s, h->d_lv, g, L.d_sel_xy, L.d_sel_sc, L.d_sel_count, d_in_kp, d_n_in, h->cfg.max_input_keypoints, d_grid2d, grid_rows, grid_cols,
+    const FastAdapt fa{L.d_fcount, L.d_tpass, L.d_fstat, h->fast_mode == UVO_FAST_MODE_ADAPTIVE ? 1 : 0, h->cfg.fast_th};
+    launch_assemble(s, h->d_lv, g, fa, L.d_sel_xy, L.d_sel_sc, L.d_sel_count, d_in_kp, d_n_in, h->cfg.max_input_keypoints, d_grid2d, grid_rows, grid_cols,
                     min_px_dist, full_detect, d_nfn, L.d_flist, L.d_n_final, batch);
   }
   {
@@ -472,11 +473,12 @@ static int alloc_lane(uvo_extractor* h, int li) {
   AL(dev_alloc(&L.d_cor_n, h->cap_cor_n));
   AL(dev_alloc(&L.d_cell_hi, h->cap_flags));
   AL(dev_alloc(&L.d_tpass, (size_t)kMaxLevels));
-  // [level] 64-bit accumulators (problems done << 32 | fall-back cells), the last sums, the length of d_cell_list
-  AL(dev_alloc(&L.d_fstat, (size_t)3 * kMaxLevels + 4));
+  // the last batch's fall-back cells per level, then the length of d_cell_list; per (frame, level) counts of the batch in flight
+  AL(dev_alloc(&L.d_fstat, (size_t)kMaxLevels + 4));
+  AL(dev_alloc(&L.d_fcount, B * kMaxLevels));
   AL(dev_alloc(&L.d_cell_list, B * (size_t)h->cap_cells));
   if ((rc = set_lane_fast_mode(h, li)) != UVO_OK) return rc;
-  if (hipMemset(L.d_fstat, 0, (3 * kMaxLevels + 4) * sizeof(int32_t)) != hipSuccess) return fail(UVO_E_HIP, "hipMemset failed");
+  if (hipMemset(L.d_fstat, 0, (kMaxLevels + 4) * sizeof(int32_t)) != hipSuccess) return fail(UVO_E_HIP, "hipMemset failed");
   // the cell flags and the fill cursors are zero between calls: k_fast_score sets / advances them, k_octree clears what it has consumed
   if (hipMemset(L.d_cell_hi, 0, h->cap_flags) != hipSuccess || hipMemset(L.d_cursor, 0, B * kMaxLevels * 2 * sizeof(int32_t)) != hipSuccess)
     return fail(UVO_E_HIP, "hipMemset failed");
@@ -516,7 +518,6 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   uvo_extractor* h = new uvo_extractor();
   h->cfg = *cfg;
   h->device = cfg->device;
-  h->oct.fast_th = cfg->fast_th;
   build_ctor_tables(h);
   Geom g;
   std::vector<CellDesc> cells;
@@ -606,7 +607,7 @@ void uvo_extractor_destroy(uvo_extractor* h) {
     if (L.stream) (void)hipStreamSynchronize(L.stream);
     L.prof.clear();
     void* lp[] = {L.d_pyr,   L.d_blur,   L.d_cand_xy,   L.d_cand_sc, L.d_pstate, L.d_sel_xy, L.d_sel_sc,
-                  L.d_cand_count, L.d_sel_count, L.d_n_final, L.d_cor_n, L.d_cor, L.d_cell_hi, L.d_cand_lo, L.d_cursor, L.d_tpass, L.d_fstat, L.d_cell_list, L.d_flist, L.a_imgs, L.a_kp, L.a_desc, L.a_n};
+                  L.d_cand_count, L.d_sel_count, L.d_n_final, L.d_cor_n, L.d_cor, L.d_cell_hi, L.d_cand_lo, L.d_cursor, L.d_tpass, L.d_fstat, L.d_fcount, L.d_cell_list, L.d_flist, L.a_imgs, L.a_kp, L.a_desc, L.a_n};
     for (void* p : lp)
       if (p) (void)hipFree(p);
     if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -742,7 +743,6 @@ int uvo_extractor_tune(uvo_extractor* h, int knob, int value) {
       int rc = sync_all_lanes(h);
       if (rc) return rc;
       h->fast_mode = value;
-      h->oct.adapt = value == UVO_FAST_MODE_ADAPTIVE ? 1 : 0;
       for (int i = 0; i < kMaxLanes; ++i)
         if (h->lane[i].stream && (rc = set_lane_fast_mode(h, i)) != UVO_OK) return rc;
       return UVO_OK;
@@ -758,12 +758,12 @@ int uvo_extractor_fast_state(uvo_extractor* h, int32_t* pass_threshold, int32_t*
   UVO_HIP_CHECK(hipSetDevice(h->device));
   Lane& L = h->lane[h->cur];
   UVO_HIP_CHECK(hipStreamSynchronize(L.stream));
-  int32_t t[kMaxLevels], f[3 * kMaxLevels];
+  int32_t t[kMaxLevels], f[kMaxLevels];
   UVO_HIP_CHECK(hipMemcpy(t, L.d_tpass, sizeof(t), hipMemcpyDeviceToHost));
   UVO_HIP_CHECK(hipMemcpy(f, L.d_fstat, sizeof(f), hipMemcpyDeviceToHost));
   for (int l = 0; l < h->geom.nlevels; ++l) {
     if (pass_threshold) pass_threshold[l] = t[l];
-    if (fallback_cells) fallback_cells[l] = f[2 * kMaxLevels + l];
+    if (fallback_cells) fallback_cells[l] = f[l];
     if (cells_per_frame) cells_per_frame[l] = h->geom.lv[l].n_cells;
   }
   return UVO_OK;
@@ -814,6 +814,11 @@ static int extract_batch_impl(uvo_extractor* h, int batch, const uint8_t* imgs, 
       if (n_in[b] < 0 || n_in[b] > in_cap) return fail(UVO_E_BADARG, "n_in outside 0..max_input_keypoints");
       for (int i = 0; i < n_in[b]; ++i) {
         const uvo_keypoint& k = in_kp[(size_t)b * in_cap + i];
+        if (build_grid) {
+          // the keypoints only mark grid cells ((int)(pt / min_px_dist), src/Tracking.cc:903-907): they must lie inside the image
+          if (!(k.x >= 0.f && k.x < (float)width && k.y >= 0.f && k.y < (float)height)) return fail(UVO_E_BADARG, "tracked keypoint outside the image");
+          continue;
+        }
         const int cx = (int)lrintf(k.x), cy = (int)lrintf(k.y);
         if (!(cx >= 2 && cx <= width - 3 && cy >= 2 && cy <= height - 3)) return fail(UVO_E_BADARG, "caller keypoint too close to the border");
       }
@@ -832,6 +837,9 @@ static int extract_batch_impl(uvo_extractor* h, int batch, const uint8_t* imgs, 
   const uint8_t* d_frames = from_clahe ? h->d_clahe_out : h->d_imgs;
   const bool topup = !full_detect;
   const bool have_in = topup && in_kp && n_in && in_cap > 0;
+  // build_grid (uvo_extract_tracked): the caller's keypoints are the TRACKED points, which only fill the occupancy grid -- the extractor
+  // itself is called with an empty keypoint vector (`pts0_ext`, src/Tracking.cc:943-946) and returns the new points alone
+  const bool describe_in = have_in && !build_grid;
   const int dcap = h->cap_flist;  // device staging capacity per frame
   size_t gb = 0;
   if (topup) {
@@ -903,8 +911,8 @@ static int extract_batch_impl(uvo_extractor* h, int batch, const uint8_t* imgs, 
   }
   if (topup && build_grid && have_in)
     launch_occupancy_grid(s, h->d_in_kp, h->d_n_in, in_cap, min_px_dist, grid_rows, grid_cols, h->d_grid, batch);
-  int rc = run_batch_device(h, li, batch, d_frames, width, height, width, (ptrdiff_t)width * height, have_in ? h->d_in_kp : nullptr,
-                            have_in ? h->d_n_in : nullptr, topup ? h->d_grid : nullptr, grid_rows, grid_cols, min_px_dist, full_detect,
+  int rc = run_batch_device(h, li, batch, d_frames, width, height, width, (ptrdiff_t)width * height, describe_in ? h->d_in_kp : nullptr,
+                            describe_in ? h->d_n_in : nullptr, topup ? h->d_grid : nullptr, grid_rows, grid_cols, min_px_dist, full_detect,
                             topup ? h->d_nfn : nullptr, h->d_out_kp, h->d_out_desc, dcap, h->d_n_out);
   if (rc) return rc;
   if (bounce) {
@@ -1032,9 +1040,14 @@ int uvo_extract_batch_submit_internal(uvo_extractor* h, int batch, int n_downloa
       UVO_HIP_CHECK(hipMemcpy2DAsync(L.a_imgs + (size_t)b * width * height, width, imgs + (size_t)b * frame_stride, stride, width, (size_t)height,
                                      hipMemcpyHostToDevice, s));
   }
+  const int prev_lane = h->cur;
   rc = run_batch_device(h, li, batch, L.a_imgs, width, height, width, (ptrdiff_t)width * height, nullptr, nullptr, nullptr, 0, 0, 0, 1, nullptr, L.a_kp,
                         L.a_desc, dcap, L.a_n);
-  if (rc) return rc;
+  if (rc) {  // no ticket is issued: leave the handle as it was (whatever was enqueued has run out, the lane order is unchanged)
+    (void)hipStreamSynchronize(s);
+    h->cur = prev_lane;
+    return rc;
+  }
   if (after_kernels) UVO_HIP_CHECK(hipEventRecord(after_kernels, s));
   // results: whole per-frame slices (a frame holds at most dcap records), frame b lands at b * cap of the caller's arrays
   if (n_download > 0) {
@@ -1072,8 +1085,12 @@ int uvo_extract_batch_wait(uvo_extractor* h, int ticket) {
   Lane& L = h->lane[ticket];
   if (!L.a_batch) return fail(UVO_E_BADARG, "no batch in flight on this lane");
   UVO_HIP_CHECK(hipSetDevice(h->device));
-  UVO_HIP_CHECK(hipStreamSynchronize(L.stream));
-  L.a_batch = 0;
+  const hipError_t e = hipStreamSynchronize(L.stream);
+  L.a_batch = 0;  // the lane is free again whatever the wait reports: a failed batch must not block every later one
+  if (e != hipSuccess) {
+    hip_err_set(e, "hipStreamSynchronize");
+    return UVO_E_HIP;
+  }
   return UVO_OK;
 }
 
@@ -1205,6 +1222,7 @@ int uvo_extractor_kernel_times(uvo_extractor* h, char* names, int names_cap, flo
 
 hipStream_t uvo_extractor_stream_internal(uvo_extractor* h) { return h->lane[h->cur].stream; }
 int uvo_extractor_device_internal(uvo_extractor* h) { return h->device; }
+int uvo_extractor_next_lane_internal(const uvo_extractor* h) { return next_lane(h); }
 const uint8_t* uvo_extractor_clahe_internal(uvo_extractor* h, int* width, int* height) {
   *width = h->clahe_w, *height = h->clahe_h;
   return h->d_clahe_out;

@@ -501,9 +501,13 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fast_cells_list(const int32_t* 
 
 // k_fast_cells: a fixed grid of wavefronts shares the listed cells evenly (fall-back cells cluster in the smooth parts of a frame: dealt
 // by position, some wavefronts would redo a dozen cells in a row while most find none).
-template <int MAXROI>
+// With DIRECT (one or two frames: a latency call, nothing to balance) there is no list: wavefront w of frame blockIdx.y looks at entry w of
+// the frame's cell-flag array itself and redoes the cell if it has to -- one launch instead of two.
+template <int MAXROI, bool DIRECT>
 __global__ __launch_bounds__(64 * FC_WAVES) void k_fast_cells(const uint8_t* __restrict__ pyr, int64_t pyr_block, FastLevels L, const CellDesc* __restrict__ cells,
                                                             const uint2* __restrict__ list, const int32_t* __restrict__ n_list,
+                                                            const int32_t* __restrict__ flag_cell, const int32_t* __restrict__ tpass,
+                                                            const uint8_t* __restrict__ cell_hi,
                                                             uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc, int64_t cand_block,
                                                             int32_t* __restrict__ cursor) {
   typedef FcGeom<MAXROI> G;
@@ -513,9 +517,18 @@ __global__ __launch_bounds__(64 * FC_WAVES) void k_fast_cells(const uint8_t* __r
   __shared__ uint32_t s_q[FC_WAVES][FC_QCAP];
   __shared__ uint16_t s_corner[FC_WAVES][FC_CCAP];
   const int wv = wave_in_block(), lane = threadIdx.x & 63;
-  const int n_items = *n_list;
-  const int wave_id = (int)blockIdx.x * FC_WAVES + wv, n_waves = (int)gridDim.x * FC_WAVES;
-  if (wave_id >= n_items) return;
+  const int wave_id = (int)blockIdx.x * FC_WAVES + wv, n_waves = DIRECT ? 1 : (int)gridDim.x * FC_WAVES;
+  int n_items, direct_cell = 0;
+  if (DIRECT) {
+    if (wave_id >= L.flags_per_frame) return;
+    const int fc = flag_cell[wave_id];
+    if (fc < 0 || tpass[fc >> 24] <= 7 || cell_hi[(int64_t)blockIdx.y * L.flags_per_frame + wave_id] != 0) return;
+    direct_cell = fc & 0xffffff;
+    n_items = wave_id + 1;  // exactly one trip through the loop below
+  } else {
+    n_items = *n_list;
+    if (wave_id >= n_items) return;
+  }
   uint32_t* tile32 = s_tile[wv];
   const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(tile32);
   uint32_t* score32 = s_score[wv];
@@ -525,7 +538,7 @@ __global__ __launch_bounds__(64 * FC_WAVES) void k_fast_cells(const uint8_t* __r
   // the score tile is zero between cells: cleared once here, afterwards every cell wipes the corners it wrote
   for (int i = lane; i < FC_SROWS * FC_SPITCH / 4; i += 64) score32[i] = 0u;
   for (int item = wave_id; item < n_items; item += n_waves) {
-    const uint2 it = list[item];
+    const uint2 it = DIRECT ? make_uint2((uint32_t)direct_cell, blockIdx.y) : list[item];
     const int cell = __builtin_amdgcn_readfirstlane((int)it.x), f = __builtin_amdgcn_readfirstlane((int)it.y);
     const CellDesc c = cells[cell];
     const int level = __builtin_amdgcn_readfirstlane((int)c.level);
@@ -728,19 +741,31 @@ void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, c
                        const int32_t* d_tpass, const uint8_t* d_cell_hi, uint2* d_list, int32_t* d_n_list, uint32_t* d_cand_xy, uint32_t* d_cand_sc,
                        int64_t cand_block, int32_t* d_cursor, int batch) {
   const FastLevels L = fast_levels(g, batch);
-  hipLaunchKernelGGL(k_fast_cells_list, dim3((L.flags_per_frame + FCL_THREADS - 1) / FCL_THREADS, batch), dim3(FCL_THREADS), 0, s, d_flag_cell, L.flags_per_frame,
-                     g.nlevels, d_tpass, d_cell_hi, d_list, d_n_list);
   int max_roi = 0;
   for (int l = 0; l < g.nlevels; ++l) max_roi = std::max(max_roi, std::max(g.lv[l].wCell, g.lv[l].hCell) + 6);
   const bool small = max_roi <= 48;
+  if (batch <= 2) {  // a latency call: one launch, a wavefront per flag entry
+    const dim3 grid((L.flags_per_frame + FC_WAVES - 1) / FC_WAVES, batch);
+    if (small)
+      hipLaunchKernelGGL((k_fast_cells<48, true>), grid, dim3(64 * FC_WAVES), 0, s, d_pyr, pyr_block, L, d_cells, d_list, d_n_list, d_flag_cell, d_tpass, d_cell_hi, d_cand_xy,
+                         d_cand_sc, cand_block, d_cursor);
+    else
+      hipLaunchKernelGGL((k_fast_cells<66, true>), grid, dim3(64 * FC_WAVES), 0, s, d_pyr, pyr_block, L, d_cells, d_list, d_n_list, d_flag_cell, d_tpass, d_cell_hi, d_cand_xy,
+                         d_cand_sc, cand_block, d_cursor);
+    return;
+  }
+  hipLaunchKernelGGL(k_fast_cells_list, dim3((L.flags_per_frame + FCL_THREADS - 1) / FCL_THREADS, batch), dim3(FCL_THREADS), 0, s, d_flag_cell, L.flags_per_frame,
+                     g.nlevels, d_tpass, d_cell_hi, d_list, d_n_list);
   // a fixed grid that fills the chip once (seven / three workgroups of four wavefronts per CU: LDS); fewer when the batch cannot hold that many cells
   const int64_t max_items = (int64_t)g.total_cells * batch;
   const int waves = (int)std::min<int64_t>(max_items, 256 * (small ? 7 : 3) * FC_WAVES);
   const dim3 grid((waves + FC_WAVES - 1) / FC_WAVES);
   if (small)
-    hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64 * FC_WAVES), 0, s, d_pyr, pyr_block, L, d_cells, d_list, d_n_list, d_cand_xy, d_cand_sc, cand_block, d_cursor);
+    hipLaunchKernelGGL((k_fast_cells<48, false>), grid, dim3(64 * FC_WAVES), 0, s, d_pyr, pyr_block, L, d_cells, d_list, d_n_list, d_flag_cell, d_tpass, d_cell_hi, d_cand_xy,
+                       d_cand_sc, cand_block, d_cursor);
   else
-    hipLaunchKernelGGL(k_fast_cells<66>, grid, dim3(64 * FC_WAVES), 0, s, d_pyr, pyr_block, L, d_cells, d_list, d_n_list, d_cand_xy, d_cand_sc, cand_block, d_cursor);
+    hipLaunchKernelGGL((k_fast_cells<66, false>), grid, dim3(64 * FC_WAVES), 0, s, d_pyr, pyr_block, L, d_cells, d_list, d_n_list, d_flag_cell, d_tpass, d_cell_hi, d_cand_xy,
+                       d_cand_sc, cand_block, d_cursor);
 }
 
 }  // namespace uvo

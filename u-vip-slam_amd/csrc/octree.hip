@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include "common.hpp"
 #include "fast_geom.hpp"
 #include "octree_pyramid.hpp"
@@ -44,7 +45,7 @@ static inline size_t oct_lds_bytes(int M, int Mp2, int pyr_words) {
 template <int NT>
 __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max, int pyr_words, int box_region, int lds_bytes,
                                                         FastLevels FL, const uint32_t* __restrict__ cand_lo,
-                                                        int32_t* __restrict__ cursor, int32_t* tpass, int32_t* fstat, int adapt, int fast_th, uint8_t* cell_hi,
+                                                        int32_t* __restrict__ cursor, int32_t* __restrict__ fcount, int32_t* __restrict__ n_cell_list, uint8_t* cell_hi,
                                                         uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc,
                                                         int64_t cand_block, int32_t* __restrict__ cand_count,
                                                         uint32_t* __restrict__ pstate, uint32_t* __restrict__ sel_xy,
@@ -68,12 +69,12 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
   // (n_hi of them); the others (7 <= score < fastTh) wait in the level's low list for the per-cell vote, which needs every region of
   // a cell finished: FAST(cell, fastTh); if empty FAST(cell, 7) (src/ORBextractor.cc:792-799) -- a low survivor is a candidate iff its
   // cell holds no survivor >= fastTh.  One contiguous read of the low list, appended behind the first n_hi candidates. ----
-  __shared__ int s_pcount, s_zero;
+  __shared__ int s_pcount, s_zero[NT / 64];  // candidates so far; per wavefront: cell flags found zero
   {
     const FastLevel fg = FL.l[level];
     int32_t* cur = cursor + 2 * ((int64_t)f * nlevels + level);
     const int n_hi = min(cur[0], g.cand_cap), n_lo = min(cur[1], g.cand_cap);
-    if (threadIdx.x == 0) s_pcount = n_hi, s_zero = 0;
+    if (threadIdx.x == 0) s_pcount = n_hi;
     uint8_t* hi = cell_hi + (int64_t)f * FL.flags_per_frame + fg.flag_base;
     const int lane = threadIdx.x & 63;
     // the level's cell flags go to LDS first (the node tables are not live yet: the staging shares their bytes); levels with more
@@ -81,14 +82,20 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
     uint8_t* s_flag = lds;
     const int n_flags = fg.nRows * fg.nCols;
     const bool flag_lds = n_flags <= lds_bytes;
-    if (flag_lds)
-      for (int i = threadIdx.x; i < n_flags; i += NT) s_flag[i] = hi[i];
-    __syncthreads();
-    {  // cells of this (frame, level) without a survivor >= fastTh: the batch's fall-back share steers the level's FAST mode (below)
+    // (while they pass by: the cells of this (frame, level) without a survivor >= fastTh are counted -- the batch's fall-back share
+    // steers the level's FAST mode, below)
+    {
       int z = 0;
-      for (int i = threadIdx.x; i < n_flags; i += NT) z += (flag_lds ? s_flag[i] : hi[i]) == 0 ? 1 : 0;
-      if (z) atomicAdd(&s_zero, z);
+      for (int i = threadIdx.x; i < n_flags; i += NT) {
+        const uint8_t fl = hi[i];
+        if (flag_lds) s_flag[i] = fl;
+        z += fl == 0 ? 1 : 0;
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) z += __shfl_xor(z, o, 64);
+      if (lane == 0) s_zero[threadIdx.x >> 6] = z;
     }
+    __syncthreads();
     constexpr int LU = 8;  // low-list words in flight per thread
     for (int i0 = 0; i0 < n_lo; i0 += LU * NT) {
       uint32_t e[LU];
@@ -132,37 +139,20 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
     // sets / advances them)
     for (int i = threadIdx.x; i < n_flags; i += NT) hi[i] = 0;
     if (threadIdx.x == 0) cur[0] = 0, cur[1] = 0;
-    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fstat[3 * kMaxLevels] = 0;  // the consumed list of fall-back cells (k_fast_cells_list)
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) *n_cell_list = 0;  // the consumed list of fall-back cells (k_fast_cells_list)
   }
-  // the lane's adaptive FAST mode.  A level streams either at fastTh, with the sparse literal-7 pass over the cells left empty
+  // The lane's adaptive FAST mode: a level streams either at fastTh, with the sparse literal-7 pass over the cells left empty
   // (k_fast_cells), or once at 7 with the vote above; both give the same candidates, the cheaper one depends on how many cells fall
-  // back.  fstat[level] sums the batch's fall-back cells (flag grid minus the grid positions that are no cell at all); the last
-  // problem of a level turns the sum into next batch's tpass[level] (above 22 % -> one pass at 7, below 14 % -> adaptive; measured break-even: a fall-back cell costs 5.5 x what the two-pass form saves per cell, 18 %)
-  // and keeps it in fstat[2 * kMaxLevels + level] for whoever wants to look.  Stream order makes the new values visible to this
-  // lane's next k_fast_score; no other lane reads them.
-  // One 64-bit atomic per workgroup carries both the count of finished (frame, level) problems (high half) and the sum of their
-  // fall-back cells (low half): whoever completes the level's count owns the sum -- no fence, no second atomic to order against (an
-  // agent-scope fence writes back and invalidates this XCD's L2 on gfx950: 2000 of them per launch cost 60 % of the kernel).  Issued
-  // when the problem is done, so that nobody waits for its round trip.
-  const int fallback_here = s_zero - (FL.l[level].nRows * FL.l[level].nCols - g.n_cells);
-  auto report_fallback = [&]() {
-    if (threadIdx.x != 0) return;
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(fstat) + level;
-    const unsigned long long mine = (1ull << 32) | (unsigned long long)(uint32_t)fallback_here;
-    const unsigned long long tot = atomicAdd(acc, mine) + mine;
-    if ((uint32_t)(tot >> 32) == gridDim.x) {  // this level's last problem of the batch
-      *acc = 0ull;
-      const int64_t zc = (int64_t)(uint32_t)tot, cells = (int64_t)g.n_cells * gridDim.x;
-      fstat[2 * kMaxLevels + level] = (int32_t)zc;
-      if (adapt && fast_th > 7 && cells > 0) {
-        const int cur_t = tpass[level];
-        if (cur_t > 7 && zc * 100 > cells * 22)
-          tpass[level] = 7;
-        else if (cur_t <= 7 && zc * 100 < cells * 14)
-          tpass[level] = fast_th;
-      }
-    }
-  };
+  // back.  This problem's count of fall-back cells (its zero flags minus the grid positions that are no cell at all) goes to
+  // fcount[frame][level]; k_assemble, next on the stream, sums the batch and re-decides every level (describe.hip: adapt_fast_mode).
+  // (Summing here -- an atomic per workgroup plus a last-one-out test -- cost the kernel 14 %; an agent-scope fence, which writes
+  // back and invalidates an XCD's L2 on gfx950, 60 %.)
+  if (threadIdx.x == 0) {
+    int z = -(FL.l[level].nRows * FL.l[level].nCols - g.n_cells);
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) z += s_zero[w];
+    fcount[f * nlevels + level] = z;
+  }
   OCT_TRACE_MARK()  // end of the candidate gather
   int P = s_pcount;
   if (threadIdx.x == 0) cand_count[f * nlevels + level] = P;
@@ -170,7 +160,6 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
   int32_t* out_n = sel_count + f * nlevels + level;
   if (P == 0) {
     if (threadIdx.x == 0) *out_n = 0;
-    report_fallback();
     return;
   }
   oct::Params pr;
@@ -218,11 +207,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
       n = oct::run<0>(pr, w, cand_xy + co, cand_sc + co, pstate + co, sel_xy + so, sel_sc + so, g.sel_cap);
   }
   if (threadIdx.x == 0) *out_n = n;
-  report_fallback();
 }
 
 int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_lo, int32_t* d_cursor,
-                   int32_t* d_tpass, int32_t* d_fstat, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
+                   int32_t* d_fcount, int32_t* d_n_cell_list, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
                    int32_t* d_sel_count, int batch) {
   int M = 0;
   for (int l = 0; l < g.nlevels; ++l) {
@@ -237,10 +225,19 @@ int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, cons
   const bool wide = batch * g.nlevels <= st.wide_max_problems;
   const int threads = wide ? 1024 : OCT_THREADS;
   const size_t lds = oct_lds_bytes(M, Mp2, pyr_words);
-  if (lds > 64 * 1024 && lds > st.lds_configured) {  // the attribute is per device: every handle raises it for its own
-    UVO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<OCT_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    UVO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    st.lds_configured = lds;
+  if (lds > 64 * 1024) {
+    // hipFuncSetAttribute SETS the function's limit on the current device -- it does not raise it -- so several handles on one device
+    // (different nfeatures -> different sizes) must agree on the largest request: a per-device maximum, raised under a lock
+    static std::mutex mu;
+    static size_t dev_max[64] = {0};
+    int dev = 0;
+    UVO_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 64 || lds > dev_max[dev]) {
+      UVO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<OCT_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      UVO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (dev >= 0 && dev < 64) dev_max[dev] = lds;
+    }
   }
 #ifdef UVO_OCT_TRACE
   {
@@ -257,10 +254,10 @@ int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, cons
 #endif
   if (wide)
     hipLaunchKernelGGL(k_octree<1024>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), (int)lds, fast_levels(g, batch), d_cand_lo,
-                       d_cursor, d_tpass, d_fstat, st.adapt, st.fast_th, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count);
+                       d_cursor, d_fcount, d_n_cell_list, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count);
   else
     hipLaunchKernelGGL(k_octree<OCT_THREADS>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), (int)lds, fast_levels(g, batch),
-                       d_cand_lo, d_cursor, d_tpass, d_fstat, st.adapt, st.fast_th, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block,
+                       d_cand_lo, d_cursor, d_fcount, d_n_cell_list, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block,
                        d_sel_count);
   return UVO_OK;
 }

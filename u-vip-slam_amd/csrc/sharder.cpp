@@ -34,6 +34,7 @@ extern "C" int uvo_extract_batch_submit_internal(uvo_extractor* h, int batch, in
                                                   int32_t* n_out, int* ticket, hipEvent_t after_kernels, const uint8_t** d_desc,
                                                   const int32_t** d_n);
 extern "C" hipStream_t uvo_matcher_stream_internal(uvo_matcher* m);
+extern "C" int uvo_extractor_next_lane_internal(const uvo_extractor* h);
 extern "C" int uvo_extract_batch_done_internal(uvo_extractor* h, int ticket);
 
 using namespace uvo;
@@ -229,8 +230,9 @@ void shard_worker(uvo_sharder* s, int shard_index) {
   auto retire_oldest = [&]() {
     InFlight f = inflight.front();
     inflight.pop_front();
-    int rc = uvo_extract_batch_wait(sh.ex, f.ticket);
-    if (rc == UVO_OK && f.match && hipEventSynchronize(sh.rows_sent[f.ticket]) != hipSuccess) rc = fail(UVO_E_HIP, "hipEventSynchronize failed");
+    int rc = uvo_extract_batch_wait(sh.ex, f.ticket);  // (frees the lane also when it fails)
+    // the matcher's rows are waited for whatever the extraction reported: the lane's buffers are about to be reused
+    if (f.match && hipEventSynchronize(sh.rows_sent[f.ticket]) != hipSuccess && rc == UVO_OK) rc = fail(UVO_E_HIP, "hipEventSynchronize failed");
     if (rc != UVO_OK) {
       snprintf(msg, sizeof(msg), "shard %d: %s", shard_index, uvo_last_error());
       std::lock_guard<std::mutex> lk(s->mu);
@@ -288,14 +290,17 @@ void shard_worker(uvo_sharder* s, int shard_index) {
     const uint8_t* d_desc = nullptr;
     const int32_t* d_n = nullptr;
     if (!cur_failed) {
+      // the lane this chunk will run on: its `kernels_done` event is recorded right behind the extraction kernels, in front of the lane's
+      // result copies, so that the matcher starts under the download instead of behind it
+      const int ln = uvo_extractor_next_lane_internal(sh.ex);
       rc = uvo_extract_batch_submit_internal(sh.ex, ne, nb, a.imgs + (ptrdiff_t)(f0 - a.imgs_first_frame) * a.frame_stride, a.width, a.height, a.stride,
                                              a.frame_stride, a.out_kp + (size_t)f0 * a.cap, a.out_desc + (size_t)f0 * a.cap * 32, a.cap, a.n_out + f0, &t,
-                                             nullptr, &d_desc, &d_n);
+                                             match ? sh.kernels_done[ln] : nullptr, &d_desc, &d_n);
       if (rc == UVO_OK && match) {
         const int np = ne - 1;  // pairs (f0 + j, f0 + j + 1)
-        // the matcher reads the lane's descriptors in HBM: order its stream behind the extraction (uvo_matcher_wait_extractor refers
-        // to the lane just submitted to); the lane's next batch waits for the matcher through retire_oldest()
-        rc = uvo_matcher_wait_extractor(sh.mt, sh.ex);
+        // the matcher reads the lane's descriptors in HBM: its stream waits for the lane's kernels (not for the lane's downloads);
+        // the lane's next batch waits for the matcher through retire_oldest()
+        if (hipStreamWaitEvent(ms, sh.kernels_done[t], 0) != hipSuccess) rc = fail(UVO_E_HIP, "hipStreamWaitEvent failed");
         if (rc == UVO_OK && np > 0) {
           rc = uvo_hamming_knn2_batch_device(sh.mt, np, d_desc, d_n, dcap, d_desc + (size_t)dcap * 32, d_n + 1, dcap, sh.d_idx0[t], sh.d_d0[t], sh.d_idx1[t],
                                              sh.d_d1[t]);
@@ -334,18 +339,18 @@ void shard_worker(uvo_sharder* s, int shard_index) {
 
 extern "C" {
 
-int uvo_sharder_submit(uvo_sharder* s, const uint8_t* imgs, int imgs_first_frame, int total_frames, int width, int height, ptrdiff_t stride,
-                       ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int32_t* idx0, uint16_t* d0,
+int uvo_sharder_submit(uvo_sharder* s, const uint8_t* imgs, int n_imgs, int imgs_first_frame, int total_frames, int width, int height,
+                       ptrdiff_t stride, ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int32_t* idx0, uint16_t* d0,
                        int32_t* idx1, uint16_t* d1, int* ticket) {
   if (!s || !imgs || !out_kp || !out_desc || !n_out || !ticket) return fail(UVO_E_BADARG, "null pointer");
   *ticket = 0;
-  if (total_frames < 1 || imgs_first_frame < 0 || width < 1 || height < 1 || stride < width || frame_stride < (ptrdiff_t)stride * (height - 1) + width)
+  if (total_frames < 1 || imgs_first_frame < 0 || n_imgs < 1 || width < 1 || height < 1 || stride < width || frame_stride < (ptrdiff_t)stride * (height - 1) + width)
     return fail(UVO_E_BADARG, "bad frame count / geometry");
   if (width > s->cfg.extractor.max_width || height > s->cfg.extractor.max_height) return fail(UVO_E_BADARG, "image size outside what the sharder was sized for");
   if (cap < s->dcap) return fail(UVO_E_CAPACITY, "cap must be at least uvo_sharder_max_keypoints()");
   const bool any_match_ptr = idx0 || d0 || idx1 || d1, all_match_ptr = idx0 && d0 && idx1 && d1;
   if (any_match_ptr && (!all_match_ptr || !s->cfg.match)) return fail(UVO_E_BADARG, "match outputs need all four arrays and a sharder created with match = 1");
-  // the local shards' frames (+ halo) must lie inside what `imgs` holds from imgs_first_frame on; the caller guarantees the upper end
+  // the local shards' frames (+ halo) must lie inside the n_imgs frames `imgs` holds from imgs_first_frame on
   int local = 0;
   for (int i = 0; i < s->cfg.n_shards; ++i) {
     if (s->shards[i].device == UVO_SHARD_REMOTE) continue;
@@ -354,6 +359,8 @@ int uvo_sharder_submit(uvo_sharder* s, const uint8_t* imgs, int imgs_first_frame
     int rc = uvo_shard_plan_make(total_frames, s->cfg.n_shards, i, s->cfg.chunk_frames, &pl);
     if (rc) return rc;
     if (pl.n_frames > 0 && pl.first_frame < imgs_first_frame) return fail(UVO_E_BADARG, "imgs does not hold a local shard's first frame");
+    if (pl.n_frames > 0 && pl.first_frame + pl.n_frames + (pl.halo_frame >= 0 ? 1 : 0) > imgs_first_frame + n_imgs)
+      return fail(UVO_E_BADARG, "imgs ends before a local shard's last frame / halo frame");
   }
   auto job = std::make_shared<Job>();
   job->a = RunArgs{imgs, imgs_first_frame, total_frames, width, height, stride, frame_stride, out_kp, out_desc, cap, n_out, idx0, idx1, d0, d1};
@@ -386,11 +393,11 @@ int uvo_sharder_wait(uvo_sharder* s, int ticket) {
   return UVO_OK;
 }
 
-int uvo_sharder_run(uvo_sharder* s, const uint8_t* imgs, int imgs_first_frame, int total_frames, int width, int height, ptrdiff_t stride,
-                    ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int32_t* idx0, uint16_t* d0,
+int uvo_sharder_run(uvo_sharder* s, const uint8_t* imgs, int n_imgs, int imgs_first_frame, int total_frames, int width, int height,
+                    ptrdiff_t stride, ptrdiff_t frame_stride, uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int32_t* idx0, uint16_t* d0,
                     int32_t* idx1, uint16_t* d1) {
   int ticket = 0;
-  int rc = uvo_sharder_submit(s, imgs, imgs_first_frame, total_frames, width, height, stride, frame_stride, out_kp, out_desc, cap, n_out, idx0, d0, idx1,
+  int rc = uvo_sharder_submit(s, imgs, n_imgs, imgs_first_frame, total_frames, width, height, stride, frame_stride, out_kp, out_desc, cap, n_out, idx0, d0, idx1,
                               d1, &ticket);
   if (rc) return rc;
   return uvo_sharder_wait(s, ticket);
