@@ -62,6 +62,21 @@ typedef struct uvo_extractor_cfg {
   int32_t device;                /* HIP device ordinal */
 } uvo_extractor_cfg;
 
+/*
+ * The supported envelope.  The reference has none of these limits (it allocates as it goes); here they bound the kernels' LDS and
+ * register budgets, and a configuration or image outside them is refused with UVO_E_UNSUPPORTED -- by uvo_extractor_create() for
+ * max_width x max_height, and by every extract call for the size it is given -- never computed approximately:
+ *   - every pyramid level must measure 56 .. 4096 px on each side (level l is round(size * invScaleFactor^l),
+ *     src/ORBextractor.cc:966-969; below 56 px the 30-px FAST cell grid of :755-770 has no cell);
+ *   - a FAST cell ROI (wCell + 6 x hCell + 6, :773-790) may not exceed 66 x 66 px (true whenever the detection window of the
+ *     level is at least 30 px on each side);
+ *   - a level's feature quota mnFeaturesPerLevel[l] (:472-485) may not exceed 2000 (with the reference's 1.2 / 8 levels that is
+ *     nfeatures <= ~9200);
+ *   - the number of quad-tree roots of a level, round(window width / window height) (:1010), must be 1 .. 64 (`nIni = 0`, an image
+ *     more than twice as high as wide, divides by zero in the reference too);
+ *   - at most 2^24 FAST cells per frame; nlevels <= 16.
+ * uvo_sharder additionally needs uvo_extractor_max_keypoints() <= 65535 when it matches (train indices are packed in 16 bits).
+ */
 int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out);
 void uvo_extractor_destroy(uvo_extractor* h);
 

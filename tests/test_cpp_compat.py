@@ -28,6 +28,22 @@ def test_adaptor_headers_compile_as_cxx11():
     assert os.path.exists(DRIVER)
 
 
+def test_opencv_signature_branches_type_check():
+    """The UVO_COMPAT_WITH_OPENCV branches -- USLAM::ORBextractor::operator() with the reference's signature
+    (include/ORBextractor.h:56-58), the cv::Mat overloads and every search member of the ORBmatcher adaptor instantiated with types
+    that declare what the reference's FrameKTL / KeyFrame / MapPoint declare, Grider_FAST::perform_griding -- must compile as C++11 at
+    the reference's own call sites (src/Tracking.cc:946, :2228, :2500, :2561; src/LocalMapping.cc:1080, :1236, :1261; the loop-closing
+    calls).  OpenCV and Eigen are declaration-only stand-ins (tests/cpp/opencv_decl_stub/: no behaviour, nothing linked or run, they
+    pin nothing); the check is g++ -fsyntax-only."""
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "tests", "cpp", "opencv_decl_stub"),
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "compile_opencv_branch.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    # and the branch is really there: without the macro the cv:: members do not exist
+    probe = "#include \"uvo/compat/ORBextractor.h\"\nint f(USLAM::ORBextractor* e) { return sizeof(&USLAM::ORBextractor::operator()); }\n"
+    r2 = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), "-x", "c++", "-"], input=probe, capture_output=True, text=True)
+    assert r2.returncode != 0
+
+
 @pytest.mark.gpu
 def test_cpp_adaptors_match_oracle(tmp_path, oracle, synth):
     build_driver()
