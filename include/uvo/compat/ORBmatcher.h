@@ -18,6 +18,9 @@
  *   SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th)          :286-407   (loop closing)
  *   Fuse(KeyFrame*, Scw, vpPoints, th)                                   :1136-1265 (loop closing; map mutation here)
  *   SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)             :1267-1505
+ * the two loops of the LocalMapping thread in batched form (one device round trip per loop instead of one to three per key frame):
+ *   SearchForTriangulationBegin / SearchForTriangulationNext             the loop of src/LocalMapping.cc:1058-1080
+ *   FuseTargets(vpTargetKFs, vpMapPoints, th)                            the loop of src/LocalMapping.cc:1228-1236
  * and the four members nothing in the reference calls (kept so that the class is complete):
  *   WindowSearch(F1, F2, windowSize, vpMapPointMatches2, minOctave, maxOctave)   :409-516
  *   SearchByProjection(F1, F2, windowSize, vpMapPointMatches2)                   :519-594
@@ -334,6 +337,184 @@ class UVO_COMPAT_MATCHER_NAME {
       nFused++;
     }
     return nFused;
+  }
+
+  /* The loop of LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:1058-1080) as one device round trip: Begin computes the descriptor
+   * distances and epipolar tests of SearchForTriangulation(pKF1, vpKF2[k], vF12[k], ...) for every neighbour at once; Next(k) then is
+   * the k-th call of the loop -- same outputs as SearchForTriangulation -- evaluated on the host with pKF1's map points as they are at
+   * that moment (the loop gives features map points between two calls, src/LocalMapping.cc:1177).  Call Next for k = 0, 1, ... in the
+   * loop's order, each before the map-point creation that follows it in the reference. */
+  template <class KeyFrameT, class Mat33>
+  int SearchForTriangulationBegin(KeyFrameT* pKF1, const std::vector<KeyFrameT*>& vpKF2, const std::vector<Mat33>& vF12) {
+    typedef decltype(pKF1->GetKeyPointUn(0)) KeyPointT;
+    static_assert(sizeof(KeyPointT) == sizeof(uvo_keypoint), "keypoint layout must be cv::KeyPoint");
+    const std::vector<KeyPointT> vKeysUn1 = pKF1->GetKeyPointsUn();
+    const auto vpMapPoints1 = pKF1->GetMapPointMatches();
+    const int n1 = (int)vKeysUn1.size(), np = (int)vpKF2.size();
+    int nmax = n1;
+    for (int k = 0; k < np; ++k) nmax = (int)vpKF2[k]->N > nmax ? (int)vpKF2[k]->N : nmax;
+    if (vF12.size() != vpKF2.size() || ensure(nmax, 1) != UVO_OK) return UVO_E_BADARG;
+    FlatFeatureVector f1(pKF1->GetFeatureVector());
+    std::vector<uint8_t> d1((size_t)n1 * 32), has1(n1);
+    for (int i = 0; i < n1; ++i) {
+      auto d = pKF1->GetDescriptor(i);
+      std::memcpy(&d1[(size_t)i * 32], d.ptr(0), 32);
+      has1[i] = vpMapPoints1[i] != NULL;
+    }
+    // per pair: everything the single call marshals (see SearchForTriangulation above), kept alive until the batch call returns
+    std::vector<FlatFeatureVector> f2;
+    std::vector<uvo_feature_vector> c2(np);
+    std::vector<std::vector<KeyPointT> > keys2(np);
+    std::vector<std::vector<uint8_t> > d2(np), has2(np);
+    std::vector<std::vector<float> > sigma2(np);
+    std::vector<uvo_triangulation_pair> pairs(np);
+    f2.reserve(np);
+    for (int k = 0; k < np; ++k) {
+      KeyFrameT* pKF2 = vpKF2[k];
+      keys2[k] = pKF2->GetKeyPointsUn();
+      const auto vpMapPoints2 = pKF2->GetMapPointMatches();
+      const int n2 = (int)keys2[k].size();
+      d2[k].resize((size_t)n2 * 32), has2[k].resize(n2);
+      for (int j = 0; j < n2; ++j) {
+        auto d = pKF2->GetDescriptor(j);
+        std::memcpy(&d2[k][(size_t)j * 32], d.ptr(0), 32);
+        has2[k][j] = vpMapPoints2[j] != NULL;
+      }
+      f2.push_back(FlatFeatureVector(pKF2->GetFeatureVector()));
+      c2[k] = f2.back().c();
+      const int nlev = pKF2->GetScaleLevels();
+      sigma2[k].resize(nlev);
+      for (int l = 0; l < nlev; ++l) sigma2[k][l] = pKF2->GetSigma2(l);
+      uvo_triangulation_pair& P = pairs[k];
+      P.fv2 = &c2[k], P.kp2 = reinterpret_cast<const uvo_keypoint*>(keys2[k].data()), P.n2 = n2, P.desc2 = d2[k].data(), P.has_mp2 = has2[k].data();
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) P.f12[3 * r + c] = vF12[k].template at<float>(r, c);
+      P.sigma2 = sigma2[k].data(), P.nlevels = nlev;
+    }
+    uvo_feature_vector c1 = f1.c();
+    const int rc = uvo_search_for_triangulation_batch(m_, &c1, reinterpret_cast<const uvo_keypoint*>(vKeysUn1.data()), n1, d1.data(), has1.data(), np,
+                                                      pairs.data());
+    if (rc != UVO_OK) err_ = uvo_last_error();
+    return rc;
+  }
+  template <class KeyFrameT, class KeyPointT>
+  int SearchForTriangulationNext(KeyFrameT* pKF1, KeyFrameT* pKF2, int k, std::vector<KeyPointT>& vMatchedKeys1, std::vector<KeyPointT>& vMatchedKeys2,
+                                 std::vector<std::pair<size_t, size_t> >& vMatchedPairs) {
+    const auto vpMapPoints1 = pKF1->GetMapPointMatches();
+    const std::vector<KeyPointT> vKeysUn1 = pKF1->GetKeyPointsUn(), vKeysUn2 = pKF2->GetKeyPointsUn();
+    const int n1 = (int)vKeysUn1.size();
+    vMatchedKeys1.clear(), vMatchedKeys2.clear(), vMatchedPairs.clear();
+    std::vector<uint8_t> has1(n1);
+    for (int i = 0; i < n1; ++i) has1[i] = vpMapPoints1[i] != NULL;
+    std::vector<int32_t> match(n1, -1);
+    int nmatches = 0;
+    if (uvo_search_for_triangulation_next(m_, k, has1.data(), mbCheckOrientation ? 1 : 0, match.data(), &nmatches) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    for (int i = 0; i < n1; ++i) {  // :1000-1009
+      if (match[i] < 0) continue;
+      vMatchedKeys1.push_back(vKeysUn1[i]);
+      vMatchedKeys2.push_back(vKeysUn2[match[i]]);
+      vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)match[i]));
+    }
+    return nmatches;
+  }
+
+  /* The loop of LocalMapping::SearchInNeighbors (src/LocalMapping.cc:1228-1236): `matcher.Fuse(pKFi, vpMapPointMatches)` for every target
+   * key frame, as one device round trip.  The projection tests and best key points of every (target, map point) come from
+   * uvo_fuse_batch; the loop below then is the reference's, target after target: the tests that look at the map as it is by then
+   * (isBad(), IsInKeyFrame(pKFi), :1031-1035) and the mutation (:1104-1118) run here.  A map point whose descriptor an earlier
+   * target's Replace() recomputed (src/MapPoint.cc:166) is searched again with its new descriptor before it is used.  Returns the sum of
+   * the per-target nFused. */
+  template <class KeyFrameT, class MapPointT>
+  int FuseTargets(const std::vector<KeyFrameT*>& vpTargetKFs, std::vector<MapPointT*>& vpMapPoints, const float th = 3.0) {
+    const int nt = (int)vpTargetKFs.size(), nmp = (int)vpMapPoints.size();
+    if (nt == 0 || nmp == 0) return 0;
+    int nmax = 1;
+    for (int t = 0; t < nt; ++t) nmax = (int)vpTargetKFs[t]->N > nmax ? (int)vpTargetKFs[t]->N : nmax;
+    if (ensure(nmax, nmp) != UVO_OK) return 0;
+    std::vector<float> xyz((size_t)nmp * 3, 0.f), nrm((size_t)nmp * 3, 0.f), mind(nmp, 1.f), maxd(nmp, 1.f);
+    std::vector<uint8_t> usable(nmp, 0), mdesc((size_t)nmp * 32);
+    for (int i = 0; i < nmp; ++i) {
+      MapPointT* pMP = vpMapPoints[i];
+      if (!pMP) continue;
+      usable[i] = 1;
+      auto p = pMP->GetWorldPos();
+      auto pn = pMP->GetNormal();
+      for (int k = 0; k < 3; ++k) xyz[(size_t)i * 3 + k] = p.template at<float>(k), nrm[(size_t)i * 3 + k] = pn.template at<float>(k);
+      mind[i] = pMP->GetMinDistanceInvariance(), maxd[i] = pMP->GetMaxDistanceInvariance();
+      auto d = pMP->GetDescriptor();
+      std::memcpy(&mdesc[(size_t)i * 32], d.ptr(0), 32);
+    }
+    std::vector<uvo_fuse_target> targets(nt);
+    std::vector<std::vector<uvo_keypoint> > kps(nt);
+    std::vector<std::vector<uint8_t> > kdesc(nt);
+    std::vector<std::vector<float> > sfs(nt);
+    for (int t = 0; t < nt; ++t) {
+      KeyFrameT* pKF = vpTargetKFs[t];
+      const int n = (int)pKF->N;
+      kps[t].resize(n), kdesc[t].resize((size_t)n * 32);
+      for (int k = 0; k < n; ++k) {
+        auto d = pKF->GetDescriptor(k);
+        std::memcpy(&kdesc[t][(size_t)k * 32], d.ptr(0), 32);
+        const auto kp = pKF->GetKeyPointUn(k);
+        std::memcpy(&kps[t][k], &kp, sizeof(uvo_keypoint));
+      }
+      sfs[t] = pKF->GetScaleFactors();
+      uvo_fuse_target& T = targets[t];
+      T.kp = kps[t].data(), T.n = n, T.desc = kdesc[t].data();
+      T.min_x = (int)pKF->mnMinX, T.min_y = (int)pKF->mnMinY, T.max_x = (int)pKF->mnMaxX, T.max_y = (int)pKF->mnMaxY;
+      fill_cam(pKF, T.cam);
+      T.scale_factors = sfs[t].data(), T.nlevels = (int)sfs[t].size();
+    }
+    std::vector<int32_t> best((size_t)nt * nmp, -1), bdist((size_t)nt * nmp, -1);
+    if (uvo_fuse_batch(m_, nt, targets.data(), nmp, xyz.data(), nrm.data(), mind.data(), maxd.data(), usable.data(), mdesc.data(), th, best.data(),
+                       bdist.data()) != UVO_OK) {
+      err_ = uvo_last_error();
+      return 0;
+    }
+    std::set<MapPointT*> redescribed;  // points whose descriptor changed after the batch was computed
+    int nFusedTotal = 0;
+    for (int t = 0; t < nt; ++t) {
+      KeyFrameT* pKF = vpTargetKFs[t];
+      int32_t* bt = &best[(size_t)t * nmp];
+      // the reference evaluates isBad() / IsInKeyFrame(pKF) per point as the loop reaches it; like Fuse() above, up front for the target
+      std::vector<uint8_t> take(nmp, 0);
+      for (int i = 0; i < nmp; ++i) {
+        MapPointT* pMP = vpMapPoints[i];
+        take[i] = pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKF);
+        if (take[i] && redescribed.count(pMP)) {  // stale row: redo this one point against this target with its current descriptor
+          auto d = pMP->GetDescriptor();
+          uint8_t one_valid = 0;
+          float u1 = 0.f, v1 = 0.f;
+          int32_t l1 = 0, b1 = -1, bd1 = -1;
+          const uint8_t one_usable = 1;
+          bt[i] = -1;
+          if (uvo_project_points(m_, UVO_PROJECT_FUSE, &targets[t].cam, 1, &xyz[(size_t)i * 3], &nrm[(size_t)i * 3], &mind[i], &maxd[i], nullptr, &one_usable,
+                                 targets[t].scale_factors, targets[t].nlevels, 0.f, 0.f, &one_valid, &u1, &v1, &l1, nullptr) == UVO_OK &&
+              uvo_fuse(m_, targets[t].kp, targets[t].n, targets[t].desc, targets[t].min_x, targets[t].min_y, targets[t].max_x, targets[t].max_y, 1, &u1, &v1, &l1,
+                       &one_valid, d.ptr(0), targets[t].scale_factors, targets[t].nlevels, th, &b1, &bd1) == UVO_OK)
+            bt[i] = b1;
+        }
+      }
+      for (int i = 0; i < nmp; ++i) {  // :1101-1119
+        if (!take[i] || bt[i] < 0) continue;
+        MapPointT* pMP = vpMapPoints[i];
+        MapPointT* pMPinKF = pKF->GetMapPoint(bt[i]);
+        if (pMPinKF) {
+          if (!pMPinKF->isBad()) {
+            pMP->Replace(pMPinKF);
+            redescribed.insert(pMPinKF);
+          }
+        } else {
+          pMP->AddObservation(pKF, bt[i]);
+          pKF->AddMapPoint(pMP, bt[i]);
+        }
+        nFusedTotal++;
+      }
+    }
+    return nFusedTotal;
   }
 
   /* int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th) */
@@ -739,6 +920,19 @@ class UVO_COMPAT_MATCHER_NAME {
       return v;
     }
   };
+  template <class KeyFrameT>
+  static void fill_cam(KeyFrameT* pKF, uvo_camera_pose& cam) {
+    auto Rcw = pKF->GetRotation();
+    auto tcw = pKF->GetTranslation();
+    auto Ow = pKF->GetCameraCenter();
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) cam.rcw[3 * r + c] = Rcw.template at<float>(r, c);
+      cam.tcw[r] = tcw.template at<float>(r);
+      cam.ow[r] = Ow.template at<float>(r);
+    }
+    cam.fx = pKF->fx, cam.fy = pKF->fy, cam.cx = pKF->cx, cam.cy = pKF->cy;
+    cam.min_x = pKF->mnMinX, cam.max_x = pKF->mnMaxX, cam.min_y = pKF->mnMinY, cam.max_y = pKF->mnMaxY;
+  }
   template <class KeyFrameT, class MapPointT>
   static void fill_kf(KeyFrameT* pKF, const std::vector<MapPointT*>& mps, std::vector<uint8_t>& desc, std::vector<float>& angle,
                       std::vector<uint8_t>& usable) {

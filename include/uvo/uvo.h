@@ -508,6 +508,62 @@ int uvo_project_points(uvo_matcher* m, int mode, const uvo_camera_pose* cam, int
                        int32_t* level, float* view_cos);
 
 /*
+ * Batched forms of the two matcher loops of the LocalMapping thread: one device round trip for the whole loop, results identical to
+ * the single calls made one after the other.
+ *
+ * LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:1058-1180) calls SearchForTriangulation(mpCurrentKeyFrame, pKF2, F12, ...) for
+ * up to 20 neighbour key frames; between two calls it triangulates the pair's matches and the accepted ones get map points
+ * (mpCurrentKeyFrame->AddMapPoint, :1177), which removes those features from the later pairs (`if(pMP1) continue;`,
+ * src/ORBmatcher.cc:885-889).  uvo_search_for_triangulation_batch() computes the descriptor distances and the epipolar test of EVERY
+ * pair in one launch (one upload, one host wait) for the features of key frame 1 that have no map point yet, and keeps the candidate
+ * lists in the handle; uvo_search_for_triangulation_next(pair, has_mp1 as it is NOW, ...) replays the reference's acceptance loop
+ * (:886-984: candidates still free, distance <= TH_LOW, sorted, walk to round(2 * best), first one on the epipolar line; rotation
+ * histogram) for that pair on the host -- no device work.  Pairs may be replayed in any order and more than once; the caller passes
+ * the has_mp1 the reference would see at that point (a feature may only GAIN a map point while a batch is alive: UVO_E_BADARG if one
+ * lost it).  A new batch replaces the old one.
+ */
+typedef struct uvo_triangulation_pair {
+  const uvo_feature_vector* fv2; /* pKF2->GetFeatureVector() */
+  const uvo_keypoint* kp2;       /* pKF2->GetKeyPointsUn() */
+  int32_t n2;
+  const uint8_t* desc2;          /* [n2][32] */
+  const uint8_t* has_mp2;        /* [n2] pKF2->GetMapPointMatches()[k] != NULL */
+  float f12[9];                  /* row-major */
+  const float* sigma2;           /* [nlevels] pKF2->GetSigma2(level) */
+  int32_t nlevels;
+} uvo_triangulation_pair;
+int uvo_search_for_triangulation_batch(uvo_matcher* m, const uvo_feature_vector* fv1, const uvo_keypoint* kp1, int n1, const uint8_t* desc1,
+                                       const uint8_t* has_mp1, int n_pairs, const uvo_triangulation_pair* pairs);
+int uvo_search_for_triangulation_next(uvo_matcher* m, int pair, const uint8_t* has_mp1_now, int check_orientation, int32_t* match12,
+                                      int* n_matches);
+/*
+ * LocalMapping::SearchInNeighbors (src/LocalMapping.cc:1228-1236) calls Fuse(pKFi, vpMapPointMatches) for every target key frame.  The
+ * search core of Fuse has no exclusivity among the map points, so the projection tests (:1037-1075, with each target's own pose) and the
+ * best key point (:1077-1101) of EVERY (target, map point) are computed in one pass: the map points are uploaded once, each target adds
+ * its grid + projection + window walk to the stream, one download, one host wait.
+ *   usable[nmp]            : 0 = the point is NULL (never searched); NULL = all usable.  The tests that depend on the map as the loop
+ *                            mutates it -- isBad(), IsInKeyFrame(pKFi), :1031-1035 -- stay with the caller, who discards the results of
+ *                            points that fail them when target i's turn comes (the search of a point depends on nothing else).
+ *   best_idx / best_dist   : [n_targets][nmp] key point of target t and distance, or -1 (as uvo_fuse).
+ * One thing the caller must watch: pMP->Replace(pMPinKF) (:1107) recomputes pMPinKF's descriptor; if pMPinKF is itself one of the nmp
+ * points, its rows of the LATER targets were computed with the old descriptor and must be redone (uvo_project_points + uvo_fuse for
+ * that point).  include/uvo/compat/ORBmatcher.h FuseTargets() does exactly that.
+ */
+typedef struct uvo_fuse_target {
+  const uvo_keypoint* kp; /* pKF->GetKeyPointUn(k) for all k */
+  int32_t n;
+  const uint8_t* desc;    /* [n][32] */
+  int32_t min_x, min_y, max_x, max_y; /* mnMinX .. mnMaxY */
+  uvo_camera_pose cam;    /* pose, intrinsics and image bounds of the target */
+  const float* scale_factors;
+  int32_t nlevels;
+} uvo_fuse_target;
+int uvo_fuse_batch(uvo_matcher* m, int n_targets, const uvo_fuse_target* targets, int nmp, const float* xyz, const float* normal,
+                   const float* min_distance_inv, const float* max_distance_inv, const uint8_t* usable, const uint8_t* mp_desc, float th,
+                   int32_t* best_idx, int32_t* best_dist);
+
+
+/*
  * Tracking::SearchReferencePointsInFrustum (src/Tracking.cc:2176-2230) as one call: FrameKTL::isInFrustum(pMP, viewing_cos_limit) on
  * every local map point (UVO_PROJECT_FRUSTUM above), then SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th) (:49-125) on the
  * points in view -- same results as uvo_project_points followed by uvo_search_by_projection, but the inputs travel as one block,

@@ -133,5 +133,11 @@ void mapping_and_loop_call_sites(KeyFrame* mpCurrentKeyFrame, KeyFrame* pKF2, st
   const float s12 = 1.f;
   (void)matcher.SearchBySim3(mpCurrentKeyFrame, pKF2, vpMatches12, s12, R12, t12, 7.5f);
   (void)matcher.SearchByProjection(mpCurrentKeyFrame, Scw, vpMapPointMatches, vpMatched, 10);
+  // the batched forms of the two LocalMapping loops (src/LocalMapping.cc:1058-1080, :1228-1236)
+  std::vector<KeyFrame*> vpNeighKFs(20, pKF2);
+  std::vector<cv::Mat> vF12(20, F12);
+  (void)matcher.SearchForTriangulationBegin(mpCurrentKeyFrame, vpNeighKFs, vF12);
+  (void)matcher.SearchForTriangulationNext(mpCurrentKeyFrame, pKF2, 0, vMatchedKeysUn1, vMatchedKeysUn2, vMatchedIndices);
+  (void)matcher.FuseTargets(vpNeighKFs, vpMapPointMatches);
   (void)matcher.Fuse(pKF2, Scw, vpMapPointMatches, 4);
 }

@@ -610,6 +610,132 @@ def test_fuse_search_and_generic_windows(uvo, oracle, synth):
     m.close()
 
 
+def test_search_for_triangulation_batch_equals_twenty_single_calls(uvo, oracle, synth):
+    """CreateNewMapPoints' loop (src/LocalMapping.cc:1058-1180): SearchForTriangulation(current KF, neighbour k) for 20 neighbours, and
+    between two calls some of the matched features of the current key frame get a map point (the triangulation accepted them).  The
+    batched form -- one launch for all pairs, then the acceptance loop of :886-984 replayed per pair on the host -- must give, pair by
+    pair, exactly what the single calls made in the same order give (and what the oracle's sequential restatement gives), with the
+    has_mp1 that evolves in between."""
+    rng = np.random.default_rng(2301)
+    W, H = 752, 480
+    base = synth.make_frame(7100, W, H)
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 7, max_width=W, max_height=H)
+    kp1, de1 = ex(base)
+    sigma2 = (ex.mvScaleFactor * ex.mvScaleFactor).astype(np.float32)
+    neigh = []
+    for k in range(20):
+        kp2, de2 = ex(synth.warp_frame(base, 7200 + k))
+        if k == 7:
+            kp2, de2 = kp2[:0], de2[:0]                      # a neighbour without key points
+        g2 = _bow_groups(rng, de2, 40) if len(de2) else {}
+        has2 = (rng.random(len(kp2)) < 0.3).astype(np.uint8)
+        F12 = (np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) + rng.normal(0, 3e-4, (3, 3)).astype(np.float32))
+        s2 = (sigma2 * np.float32(rng.choice([1.0, 40.0, 400.0]))).astype(np.float32)
+        neigh.append((g2, kp2, de2, has2, F12, s2))
+    ex.close()
+    g1 = _bow_groups(rng, de1, 40)
+    fv1 = uvo.FeatureVector(g1)
+    has1_0 = (rng.random(len(kp1)) < 0.25).astype(np.uint8)
+    for ori in (False, True):
+        m = uvo.ORBmatcher(0.6, ori)
+        mb = uvo.ORBmatcher(0.6, ori)
+        fv2s = [uvo.FeatureVector(g) for g, *_ in neigh]
+        mb.SearchForTriangulationBatch(fv1, kp1, de1, has1_0, [(fv2s[k],) + neigh[k][1:] for k in range(20)])
+        has1 = has1_0.copy()
+        accept = np.random.default_rng(99)
+        total = 0
+        for k, (g2, kp2, de2, has2, F12, s2) in enumerate(neigh):
+            mo, no = oracle.search_for_triangulation(g1, kp1, de1, has1, g2, kp2, de2, has2, F12, s2, ori) if len(kp2) else (np.full(len(kp1), -1, np.int32), 0)
+            ms, ns = m.SearchForTriangulation(fv1, kp1, de1, has1, fv2s[k], kp2, de2, has2, F12, s2)
+            mbk, nbk = mb.SearchForTriangulationNext(k, has1)
+            np.testing.assert_array_equal(ms, mo, err_msg="single call, pair %d" % k)
+            np.testing.assert_array_equal(mbk, mo, err_msg="batched form, pair %d" % k)
+            assert ns == no and nbk == no
+            total += no
+            # the triangulation accepts about two thirds of the pair's matches: those features now hold a map point
+            won = np.nonzero(mo >= 0)[0]
+            has1[won[accept.random(len(won)) < 0.66]] = 1
+        assert total > 150
+        # replaying an earlier pair with the has_mp1 of that time gives that time's result again; a feature that LOST its point is refused
+        again, _ = mb.SearchForTriangulationNext(0, has1_0)
+        ref0, _ = oracle.search_for_triangulation(g1, kp1, de1, has1_0, neigh[0][0], neigh[0][1], neigh[0][2], neigh[0][3], neigh[0][4], neigh[0][5], ori)
+        np.testing.assert_array_equal(again, ref0)
+        lost = has1_0.copy()
+        lost[np.nonzero(has1_0)[0][0]] = 0
+        with pytest.raises(uvo.UvoError):
+            mb.SearchForTriangulationNext(0, lost)
+        m.close()
+        mb.close()
+
+
+def test_fuse_batch_equals_the_single_calls(uvo, oracle, synth):
+    """SearchInNeighbors' loop (src/LocalMapping.cc:1228-1236): Fuse(target k, the current key frame's map points) for 20 targets with
+    their own poses -- uvo_fuse_batch (projection tests + search core for every (target, point) in one pass) against
+    uvo_project_points + uvo_fuse per target and against the oracle."""
+    rng = np.random.default_rng(2401)
+    W, H = 752, 480
+    base = synth.make_frame(7400, W, H)
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 7, max_width=W, max_height=H)
+    sf = ex.mvScaleFactor.copy()
+    M = 2500
+    xyz = (rng.normal(0, 1, (M, 3)) * [3, 2, 1.5] + [0, 0, 6]).astype(np.float32)
+    targets, per_target = [], []
+    fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375
+    for t in range(20):
+        kp, de = ex(synth.warp_frame(base, 7500 + t))
+        if t == 5:
+            kp, de = kp[:0], de[:0]
+        R, tv, Ow = _random_pose(rng)
+        cam = uvo.CameraPose.make(R, tv, Ow, fx, fy, cx, cy, (0.0, 0.0, float(W), float(H)))
+        cam_o = np.concatenate([R.reshape(9), tv, Ow, np.float32([fx, fy, cx, cy]), np.float32([0, W, 0, H])]).astype(np.float32)
+        targets.append((kp, de, cam, sf))
+        per_target.append(cam_o)
+    ex.close()
+    # map points: most are key points of some "home" target back-projected to a depth (so they project onto that key point there, with a
+    # descriptor close to its own, a normal facing the home camera and a distance range that predicts the key point's level); the rest random
+    nrm = rng.normal(0, 1, (M, 3))
+    mn = np.full(M, 1.0, np.float32)
+    mp_desc = rng.integers(0, 256, (M, 32), dtype=np.uint8)
+    real = [t for t in range(20) if len(targets[t][0])]
+    for i in range(M):
+        if rng.random() < 0.15:
+            continue
+        t = real[rng.integers(len(real))]
+        kp, de, cam, _ = targets[t]
+        j = rng.integers(len(kp))
+        R, tv, Ow = np.array(cam.rcw, np.float64).reshape(3, 3), np.array(cam.tcw, np.float64), np.array(cam.ow, np.float64)
+        z = rng.uniform(3, 9)
+        xc = np.array([(kp["x"][j] + rng.normal(0, 0.7) - cx) / fx * z, (kp["y"][j] + rng.normal(0, 0.7) - cy) / fy * z, z])
+        xw = R.T @ (xc - tv)
+        xyz[i] = xw
+        nrm[i] = (xw - Ow) + rng.normal(0, 0.2, 3)
+        dist = np.linalg.norm(xw - Ow)
+        mn[i] = dist / (0.8 * sf[int(kp["octave"][j])]) * rng.uniform(0.9, 1.15)
+        mp_desc[i] = np.packbits(np.unpackbits(de[j]) ^ (rng.random(256) < 0.04))
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    mx = (mn * rng.uniform(3.0, 8.0, M)).astype(np.float32)
+    usable = (rng.random(M) < 0.9).astype(np.uint8)
+    m = uvo.ORBmatcher(0.6, True, max_map_points=4096)
+    for th in (3.0, 12.0):
+        bi, bd = m.FuseBatch(targets, xyz, nrm, mn, mx, usable, mp_desc, th)
+        hits = 0
+        for t, (kp, de, cam, _) in enumerate(targets):
+            valid, u, v, level, _ = m.project_points(uvo.PROJECT_FUSE, cam, xyz, nrm, mn, mx, usable, sf)
+            ov, ou, ovv, ol, _ = oracle.project_points(uvo.PROJECT_FUSE, per_target[t], xyz, nrm, mn, mx, usable, sf, 1.2, 0.5)
+            np.testing.assert_array_equal(valid, ov)
+            if len(kp):
+                si, sd = m.FuseSearch(kp, de, (0, 0, W, H), u, v, level, valid, mp_desc, sf, th)
+                oi, od = oracle.fuse_search(kp, de, (0, 0, W, H), ou, ovv, ol, ov, mp_desc, sf, th)
+            else:
+                si = sd = oi = od = np.full(M, -1, np.int32)
+            np.testing.assert_array_equal(si, oi, err_msg="single call, target %d" % t)
+            np.testing.assert_array_equal(bi[t], oi, err_msg="batched form, target %d th %g" % (t, th))
+            np.testing.assert_array_equal(bd[t], od, err_msg="batched form (distances), target %d" % t)
+            hits += int((oi >= 0).sum())
+        assert hits > 1500, hits
+    m.close()
+
+
 def test_window_search_on_a_frame_larger_than_the_lds_grid_build(uvo, oracle):
     """More key points than k_grid_build keeps in LDS (4096): the global-memory phases of the same kernel."""
     rng = np.random.default_rng(77)

@@ -94,6 +94,65 @@ def main():
     res["imu"] = "10 IMU samples per frame through the restated IMUPreintegrator::update on the host, inside the frame time"
     res["note"] = "fused = uvo_search_points_in_frustum (Tracking::SearchReferencePointsInFrustum as one call); two_calls = uvo_project_points + uvo_search_by_projection"
     out["configs[4]: 752x480 extract + isInFrustum + SearchByProjection vs 5000 map points (host buffers in/out)"] = res
+    # ---- the LocalMapping loops: 20 single calls against the batched forms (src/LocalMapping.cc:1058-1080, :1228-1236) ----
+    rng = np.random.default_rng(5)
+    kp1, de1 = ex(img)
+    sigma2 = (sf * sf).astype(np.float32)
+
+    def groups(de):   # stand-in vocabulary nodes (tests/test_gpu_parity.py: _bow_groups)
+        bits = np.unpackbits(de, axis=1)[:, [3, 41, 77, 130, 201, 250]]
+        node = (bits * (1 << np.arange(6))).sum(1) % 40
+        g = {}
+        for i in range(len(de)):
+            g.setdefault(int(node[i]) * 7 + 3, []).append(i)
+        return g
+    fv1 = uvo.FeatureVector(groups(de1))
+    has1 = (rng.random(len(kp1)) < 0.25).astype(np.uint8)
+    neigh = []
+    for k in range(20):
+        kp2, de2 = ex(synth.warp_frame(img, 900 + k))
+        F12 = (np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) + rng.normal(0, 3e-4, (3, 3)).astype(np.float32))
+        neigh.append((uvo.FeatureVector(groups(de2)), kp2, de2, (rng.random(len(kp2)) < 0.3).astype(np.uint8), F12, (sigma2 * np.float32(40)).astype(np.float32)))
+    mt = uvo.ORBmatcher(0.6, False)
+
+    def tri_single():
+        return sum(mt.SearchForTriangulation(fv1, kp1, de1, has1, *nb)[1] for nb in neigh)
+
+    def tri_batch():
+        mt.SearchForTriangulationBatch(fv1, kp1, de1, has1, neigh)
+        return sum(mt.SearchForTriangulationNext(k, has1)[1] for k in range(20))
+    M = 1000
+    xyz2 = (rng.normal(0, 1, (M, 3)) * [3, 2, 1.5] + [0, 0, 6]).astype(np.float32)
+    nrm2 = xyz2 / np.linalg.norm(xyz2, axis=1, keepdims=True)
+    mn2 = (np.linalg.norm(xyz2, axis=1) * 0.5).astype(np.float32)
+    mx2 = (mn2 * 6).astype(np.float32)
+    md2 = rng.integers(0, 256, (M, 32), dtype=np.uint8)
+    targets = [(nb[1], nb[2], cam, sf) for nb in neigh]
+
+    def fuse_single():
+        tot = 0
+        for kp2, de2, c, _ in targets:
+            valid, u, v, level, _ = mt.project_points(uvo.PROJECT_FUSE, c, xyz2, nrm2, mn2, mx2, None, sf)
+            tot += int((mt.FuseSearch(kp2, de2, (0, 0, W, H), u, v, level, valid, md2, sf, 3.0)[0] >= 0).sum())
+        return tot
+
+    def fuse_batch():
+        return int((mt.FuseBatch(targets, xyz2, nrm2, mn2, mx2, None, md2, 3.0)[0] >= 0).sum())
+    lm = {}
+    for name, fn in (("SearchForTriangulation x 20, single calls", tri_single), ("SearchForTriangulation x 20, batched", tri_batch),
+                     ("Fuse x 20 targets, single calls (project + search)", fuse_single), ("Fuse x 20 targets, batched", fuse_batch)):
+        for _ in range(3):
+            r = fn()
+        ts = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        lm[name] = {"ms_median": round(float(np.median(ts)) * 1e3, 3), "result": int(r)}
+    assert lm["SearchForTriangulation x 20, single calls"]["result"] == lm["SearchForTriangulation x 20, batched"]["result"]
+    assert lm["Fuse x 20 targets, single calls (project + search)"]["result"] == lm["Fuse x 20 targets, batched"]["result"]
+    lm["host_waits"] = {"SearchForTriangulation": "20 -> 1", "Fuse (project + window count + resolve)": "60 -> 1"}
+    out["LocalMapping loops, 752x480 key frames of ~1000 key points, 20 neighbours"] = lm
     print(json.dumps(out, indent=1))
 
 

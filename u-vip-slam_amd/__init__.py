@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_profile_only", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
-    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_fuse", "uvo_project_points", "uvo_search_points_in_frustum", "uvo_sim3_decompose", "uvo_sim3_relative", "uvo_project_sim3", "uvo_search_by_projection_sim3", "uvo_search_by_sim3", "uvo_haloc_hash", "uvo_klt_create", "uvo_klt_destroy", "uvo_klt_build_pyramid", "uvo_klt_build_pyramid_from_extractor", "uvo_klt_read_level", "uvo_klt_track", "uvo_undistort_points", "uvo_klt_track_undistorted", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
+    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_search_for_triangulation_batch", "uvo_search_for_triangulation_next", "uvo_fuse", "uvo_fuse_batch", "uvo_project_points", "uvo_search_points_in_frustum", "uvo_sim3_decompose", "uvo_sim3_relative", "uvo_project_sim3", "uvo_search_by_projection_sim3", "uvo_search_by_sim3", "uvo_haloc_hash", "uvo_klt_create", "uvo_klt_destroy", "uvo_klt_build_pyramid", "uvo_klt_build_pyramid_from_extractor", "uvo_klt_read_level", "uvo_klt_track", "uvo_undistort_points", "uvo_klt_track_undistorted", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
     "uvo_matcher_kernel_times", "uvo_last_error", "uvo_device_info",
 ]
 
@@ -74,6 +74,18 @@ class CameraPose(ctypes.Structure):
 
     def as_array(self):
         return np.frombuffer(bytes(self), np.float32).copy()
+
+
+class TriangulationPairC(ctypes.Structure):
+    """uvo_triangulation_pair."""
+    _fields_ = [("fv2", ctypes.c_void_p), ("kp2", ctypes.c_void_p), ("n2", ctypes.c_int32), ("desc2", ctypes.c_void_p), ("has_mp2", ctypes.c_void_p),
+                ("f12", ctypes.c_float * 9), ("sigma2", ctypes.c_void_p), ("nlevels", ctypes.c_int32)]
+
+
+class FuseTargetC(ctypes.Structure):
+    """uvo_fuse_target."""
+    _fields_ = [("kp", ctypes.c_void_p), ("n", ctypes.c_int32), ("desc", ctypes.c_void_p), ("min_x", ctypes.c_int32), ("min_y", ctypes.c_int32),
+                ("max_x", ctypes.c_int32), ("max_y", ctypes.c_int32), ("cam", CameraPose), ("scale_factors", ctypes.c_void_p), ("nlevels", ctypes.c_int32)]
 
 
 PROJECT_FRUSTUM, PROJECT_KF_RELOC, PROJECT_FUSE, PROJECT_PIXEL_BOUNDED, PROJECT_PIXEL = range(5)
@@ -201,6 +213,9 @@ def _load():
     lib.uvo_undistort_points.argtypes = [vp, vp, vp, ci, vp]
     lib.uvo_klt_track_undistorted.argtypes = [vp, ci, ci, vp, vp, ci, ci, ci, ctypes.c_double, ctypes.c_double, vp, vp, vp, vp, vp]
     lib.uvo_fuse.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, vp, vp]
+    lib.uvo_search_for_triangulation_batch.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp]
+    lib.uvo_search_for_triangulation_next.argtypes = [vp, ci, vp, ci, vp, vp]
+    lib.uvo_fuse_batch.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp]
     lib.uvo_search_points_in_frustum.argtypes = [vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, cf, cf, vp, vp, vp, vp, vp, vp, vp]
     lib.uvo_sim3_decompose.argtypes = [vp, ci, vp]
     lib.uvo_sim3_relative.argtypes = [cf, vp, vp, vp, vp, vp]
@@ -756,6 +771,65 @@ class ORBmatcher:
         if rc:
             raise UvoError(rc, "uvo_search_for_triangulation")
         return match, nm.value
+
+    def SearchForTriangulationBatch(self, fv1, kp1, desc1, has_mp1, pairs):
+        """uvo_search_for_triangulation_batch: the distances + epipolar tests of every (pKF1, pKF2_k) pair of CreateNewMapPoints' loop
+        (src/LocalMapping.cc:1058-1080) in one launch.  pairs = [(fv2, kp2, desc2, has_mp2, F12, sigma2), ...].  Follow with
+        SearchForTriangulationNext(k, has_mp1 as it is then) per pair."""
+        kp1 = np.ascontiguousarray(kp1, KEYPOINT_DTYPE)
+        d1, h1 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(has_mp1, np.uint8)
+        keep = [kp1, d1, h1, fv1]
+        arr = (TriangulationPairC * max(len(pairs), 1))()
+        for k, (fv2, kp2, desc2, has_mp2, F12, sigma2) in enumerate(pairs):
+            kp2 = np.ascontiguousarray(kp2, KEYPOINT_DTYPE)
+            d2, h2 = np.ascontiguousarray(desc2, np.uint8), np.ascontiguousarray(has_mp2, np.uint8)
+            s2 = np.ascontiguousarray(sigma2, np.float32)
+            keep += [fv2, kp2, d2, h2, s2]
+            arr[k].fv2, arr[k].kp2, arr[k].n2, arr[k].desc2, arr[k].has_mp2 = ctypes.addressof(fv2.c), _ptr(kp2), len(kp2), _ptr(d2), _ptr(h2)
+            arr[k].f12[:] = [float(x) for x in np.asarray(F12, np.float32).reshape(9)]
+            arr[k].sigma2, arr[k].nlevels = _ptr(s2), len(s2)
+        rc = lib.uvo_search_for_triangulation_batch(self._h, ctypes.byref(fv1.c), _ptr(kp1), len(kp1), _ptr(d1), _ptr(h1), len(pairs), arr)
+        if rc:
+            raise UvoError(rc, "uvo_search_for_triangulation_batch")
+        self._tri_n1 = len(kp1)
+
+    def SearchForTriangulationNext(self, pair, has_mp1_now):
+        """uvo_search_for_triangulation_next: the acceptance loop of src/ORBmatcher.cc:886-984 for one pair of the batch, on the host.
+        Returns (match12[n1], nmatches)."""
+        h1 = np.ascontiguousarray(has_mp1_now, np.uint8)
+        match = np.full(self._tri_n1, -1, np.int32)
+        nm = ctypes.c_int()
+        rc = lib.uvo_search_for_triangulation_next(self._h, int(pair), _ptr(h1), 1 if self.mbCheckOrientation else 0, _ptr(match), ctypes.byref(nm))
+        if rc:
+            raise UvoError(rc, "uvo_search_for_triangulation_next")
+        return match, nm.value
+
+    def FuseBatch(self, targets, xyz, normal, min_distance, max_distance, usable, mp_desc, th=3.0):
+        """uvo_fuse_batch: projection tests + search core of Fuse (:1037-1101) for every (target key frame, map point) in one pass.
+        targets = [(kp, desc, cam (CameraPose), scale_factors), ...]; min_distance / max_distance = the map points' mfMinDistance /
+        mfMaxDistance (the invariance bounds x 0.8f / x 1.2f are formed here, as in project_points).  Returns
+        (best_idx[n_targets][nmp], best_dist[n_targets][nmp])."""
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        nrm = np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+        mn_inv = (np.float32(0.8) * np.ascontiguousarray(min_distance, np.float32)).astype(np.float32)
+        mx_inv = (np.float32(1.2) * np.ascontiguousarray(max_distance, np.float32)).astype(np.float32)
+        us = None if usable is None else np.ascontiguousarray(usable, np.uint8)
+        md = np.ascontiguousarray(mp_desc, np.uint8)
+        nmp = len(xyz)
+        keep = []
+        arr = (FuseTargetC * max(len(targets), 1))()
+        for t, (kp, desc, cam, sf) in enumerate(targets):
+            kp, desc, sf = np.ascontiguousarray(kp, KEYPOINT_DTYPE), np.ascontiguousarray(desc, np.uint8), np.ascontiguousarray(sf, np.float32)
+            keep += [kp, desc, sf]
+            arr[t].kp, arr[t].n, arr[t].desc = _ptr(kp), len(kp), _ptr(desc)
+            arr[t].min_x, arr[t].min_y, arr[t].max_x, arr[t].max_y = int(cam.min_x), int(cam.min_y), int(cam.max_x), int(cam.max_y)
+            arr[t].cam = cam
+            arr[t].scale_factors, arr[t].nlevels = _ptr(sf), len(sf)
+        bi, bd = np.full((len(targets), nmp), -1, np.int32), np.full((len(targets), nmp), -1, np.int32)
+        rc = lib.uvo_fuse_batch(self._h, len(targets), arr, nmp, _ptr(xyz), _ptr(nrm), _ptr(mn_inv), _ptr(mx_inv), _ptr(us), _ptr(md), float(th), _ptr(bi), _ptr(bd))
+        if rc:
+            raise UvoError(rc, "uvo_fuse_batch")
+        return bi, bd
 
     def project_points(self, mode, cam, xyz, normal, min_distance, max_distance, usable, scale_factors, scale_factor=1.2, viewing_cos_limit=0.5):
         """uvo_project_points: FrameKTL::isInFrustum (PROJECT_FRUSTUM), the projection prologue of SearchByProjection(F, pKF, ...)

@@ -682,6 +682,114 @@ void launch_group_dist(hipStream_t s, int nq, int total, const int32_t* d_cand_s
                        d_cand);
 }
 
+// ---- batched forms for the LocalMapping thread (src/LocalMapping.cc:1058-1080, :1228-1236) ----
+// k_group_dist over the queries of SEVERAL (key frame 1, key frame 2) pairs at once: entry e belongs to query q (binary search), query q
+// to pair q_pair[q]; candidate indices are global (pair_base[p] + index in key frame 2 of pair p); every pair has its own fundamental
+// matrix (f12 + 9 p) and sigma table (sigma2 + sig_stride p).  The packed word holds the index inside the pair's key frame.
+__global__ __launch_bounds__(256) void k_group_dist_pairs(int nq, const int32_t* __restrict__ cand_start, const int32_t* __restrict__ cand_idx,
+                                                          const uint8_t* __restrict__ qdesc, const uint8_t* __restrict__ tdesc,
+                                                          const int32_t* __restrict__ tlevel, const int32_t* __restrict__ q_pair,
+                                                          const int32_t* __restrict__ pair_base, const float* __restrict__ f12,
+                                                          const float* __restrict__ q_x, const float* __restrict__ q_y, const float* __restrict__ t_x,
+                                                          const float* __restrict__ t_y, const float* __restrict__ sigma2, int sig_stride,
+                                                          uint32_t* __restrict__ cand) {
+  const int total = cand_start[nq];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  int lo = 0, hi = nq - 1;  // last query with cand_start[q] <= e
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (cand_start[mid] <= e)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  const int q = lo, t = cand_idx[e], p = q_pair[q];
+  const int d = ham256(qdesc + (int64_t)q * 32, tdesc + (int64_t)t * 32);
+  const int oct = tlevel[t];
+  const float* F = f12 + 9 * p;
+  // ORBmatcher::CheckDistEpipolarLine (src/ORBmatcher.cc:136-153), as in k_group_dist
+  const float x1 = q_x[q], y1 = q_y[q], x2 = t_x[t], y2 = t_y[t];
+  const float a = x1 * F[0] + y1 * F[3] + F[6];
+  const float b = x1 * F[1] + y1 * F[4] + F[7];
+  const float c = x1 * F[2] + y1 * F[5] + F[8];
+  const float num = a * x2 + b * y2 + c;
+  const float den = a * a + b * b;
+  uint32_t ok = 0;
+  if (den != 0) {
+    const float dsqr = num * num / den;
+    ok = (double)dsqr < 3.84 * (double)sigma2[(int64_t)p * sig_stride + oct] ? 1u : 0u;
+  }
+  cand[e] = (uint32_t)(t - pair_base[p]) | ((uint32_t)d << 16) | ((uint32_t)(oct & 63) << 25) | (ok << 31);
+}
+
+void launch_group_dist_pairs(hipStream_t s, int nq, int total, const int32_t* d_cand_start, const int32_t* d_cand_idx, const uint8_t* d_qdesc,
+                             const uint8_t* d_tdesc, const int32_t* d_tlevel, const int32_t* d_q_pair, const int32_t* d_pair_base, const float* d_f12,
+                             const float* d_qx, const float* d_qy, const float* d_tx, const float* d_ty, const float* d_sigma2, int sig_stride,
+                             uint32_t* d_cand) {
+  if (total > 0)
+    hipLaunchKernelGGL(k_group_dist_pairs, dim3((total + 255) / 256), dim3(256), 0, s, nq, d_cand_start, d_cand_idx, d_qdesc, d_tdesc, d_tlevel, d_q_pair,
+                       d_pair_base, d_f12, d_qx, d_qy, d_tx, d_ty, d_sigma2, sig_stride, d_cand);
+}
+
+// Search core of ORBmatcher::Fuse (src/ORBmatcher.cc:1077-1101) for one target key frame, straight to the result: per projected map point
+// the key points KeyFrame::GetFeaturesInArea(u, v, th * scale[level]) returns, in its (ix, iy, insertion) order, on levels
+// [level - 1, level], the smallest descriptor distance (strict <: the first of equals wins), accepted at <= TH_LOW.  No candidate lists
+// and no ownership (Fuse has no exclusivity), so nothing needs a host round trip between the targets of a batch.
+__global__ __launch_bounds__(256) void k_fuse_walk(WinFrame F, int nmp, const uint8_t* __restrict__ valid, const float* __restrict__ qu,
+                                                   const float* __restrict__ qv, const int32_t* __restrict__ qlevel, const uint8_t* __restrict__ mp_desc,
+                                                   const float* __restrict__ sf, float th, const int32_t* __restrict__ cell_start,
+                                                   const int32_t* __restrict__ cell_items, int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nmp) return;
+  int bestDist = 0x7fffffff, bestIdx = -1;
+  if (valid[i]) {
+    const float x = qu[i], y = qv[i];
+    const int level = qlevel[i];
+    const float r = th * sf[level];
+    const int minLevel = level - 1, maxLevel = level;
+    int x0 = (int)floorf((x - (float)F.min_x - r) * F.inv_w);
+    x0 = max(0, x0);
+    int x1 = (int)ceilf((x - (float)F.min_x + r) * F.inv_w);
+    x1 = min(GR_COLS - 1, x1);
+    int y0 = (int)floorf((y - (float)F.min_y - r) * F.inv_h);
+    y0 = max(0, y0);
+    int y1 = (int)ceilf((y - (float)F.min_y + r) * F.inv_h);
+    y1 = min(GR_ROWS - 1, y1);
+    if (x0 < GR_COLS && x1 >= 0 && y0 < GR_ROWS && y1 >= 0) {
+      const uint4* QD = reinterpret_cast<const uint4*>(mp_desc + (int64_t)i * 32);
+      const uint4 q0 = QD[0], q1 = QD[1];
+      for (int ix = x0; ix <= x1; ++ix) {
+        const int k_end = cell_start[ix * GR_ROWS + y1 + 1];
+        for (int k = cell_start[ix * GR_ROWS + y0]; k < k_end; ++k) {
+          const int idx = cell_items[k];
+          const uvo_keypoint* kp = F.kp + idx;
+          const int oct = kp->octave;
+          if (oct < minLevel || oct > maxLevel) continue;
+          if (fabsf(kp->x - x) > r || fabsf(kp->y - y) > r) continue;
+          const uint4* D = reinterpret_cast<const uint4*>(F.desc + (int64_t)idx * 32);
+          const uint4 d0 = D[0], d1 = D[1];
+          const int d = __popc(q0.x ^ d0.x) + __popc(q0.y ^ d0.y) + __popc(q0.z ^ d0.z) + __popc(q0.w ^ d0.w) + __popc(q1.x ^ d1.x) +
+                        __popc(q1.y ^ d1.y) + __popc(q1.z ^ d1.z) + __popc(q1.w ^ d1.w);
+          if (d < bestDist) bestDist = d, bestIdx = idx;
+        }
+      }
+    }
+  }
+  const bool ok = bestIdx >= 0 && bestDist <= 50;  // TH_LOW, src/ORBmatcher.cc:41,:1101
+  best_idx[i] = ok ? bestIdx : -1;
+  best_dist[i] = ok ? bestDist : -1;
+}
+
+void launch_fuse_walk(hipStream_t s, const uvo_keypoint* d_kp, const uint8_t* d_desc, int n, int min_x, int min_y, int max_x, int max_y, int nmp,
+                      const uint8_t* d_valid, const float* d_u, const float* d_v, const int32_t* d_level, const uint8_t* d_mp_desc, const float* d_sf, float th,
+                      int32_t* d_cell_start, int32_t* d_cell_items, int32_t* d_cell_of_kp, int32_t* d_best_idx, int32_t* d_best_dist) {
+  launch_grid_build(s, d_kp, d_desc, n, min_x, min_y, max_x, max_y, d_cell_start, d_cell_items, d_cell_of_kp);
+  WinFrame F{d_kp, d_desc, n, min_x, min_y, (float)GR_COLS / (float)(max_x - min_x), (float)GR_ROWS / (float)(max_y - min_y)};
+  hipLaunchKernelGGL(k_fuse_walk, dim3((nmp + 255) / 256), dim3(256), 0, s, F, nmp, d_valid, d_u, d_v, d_level, d_mp_desc, d_sf, th, d_cell_start, d_cell_items,
+                     d_best_idx, d_best_dist);
+}
+
 void launch_match_resolve(hipStream_t s, int nq, int nt, const int32_t* d_cand_start, const uint32_t* d_cand, const uint8_t* d_blocked, int rule,
                           int max_dist, float nn_ratio, int exclusive, int32_t* d_owner, int32_t* d_owner_next, int32_t* d_match,
                           int32_t* d_mdist, int32_t* d_n_matches) {

@@ -98,6 +98,7 @@ void uvo_matcher_destroy(uvo_matcher* m) {
     if (p) hipFree(p);
   for (DevBuf& b : m->scratch)
     if (b.p) hipFree(b.p);
+  uvo::tri_batch_free(m->tri_batch);
   if (m->d_arena) hipFree(m->d_arena);
   if (m->h_arena) (void)hipHostFree(m->h_arena);
   m->prof.clear();

@@ -33,7 +33,8 @@ struct uvo_matcher {
   int32_t *d_moff = nullptr, *d_mres = nullptr;
   size_t md_rows = 0, md_points = 0;
   hipEvent_t ev = nullptr;
-  DevBuf scratch[24];  // matcher_search.cpp staging, see the slot enum there
+  DevBuf scratch[32];  // staging: slots 0..23 matcher_search.cpp, 24..31 matcher_batch.cpp (see the slot enums there)
+  void* tri_batch = nullptr;  // candidate lists of uvo_search_for_triangulation_batch (uvo::TriBatch, matcher_batch.cpp)
   // uvo_search_points_in_frustum: one packed input block (pinned host mirror -> device arena, one copy each way)
   uint8_t *d_arena = nullptr, *h_arena = nullptr;
   size_t arena_bytes = 0;
@@ -43,6 +44,7 @@ struct uvo_matcher {
 
 namespace uvo {
 int matcher_fail(int code, const char* msg);
+void tri_batch_free(void* p);
 template <class T>
 static int m_alloc(T** p, size_t n) {
   if (n == 0) n = 1;
