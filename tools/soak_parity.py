@@ -31,15 +31,24 @@ def main():
             nlev -= 1
         nfeat = int(rng.integers(50, 2500))
         th = int(rng.choice([3, 7, 12, 20, 20, 35]))
-        kind = t % 5
-        if kind == 3:
+        kind = t % 6
+        fast_mode = int(rng.integers(0, 3))   # UVO_TUNE_FAST_MODE: adaptive / two-pass / single pass -- the keypoints must not depend on it
+        if kind == 5:   # contrast fading from left to right: every level has cells that fall back to the literal threshold 7 and cells that do not
+            img = synth.make_frame(int(rng.integers(1 << 30)), w, h, n_shapes=max(20, w * h // 900)).astype(np.float32)
+            fade = np.linspace(1.0, 0.05, w, dtype=np.float32)[None, :]
+            img = (img * fade + 110 * (1 - fade)).astype(np.uint8)
+        elif kind == 3:
             img = rng.integers(0, 256, (h, w), dtype=np.uint8)
         elif kind == 4:
             img = (rng.integers(0, 30, (h, w)) + 100).astype(np.uint8)
         else:
             img = synth.make_frame(int(rng.integers(1 << 30)), w, h, n_shapes=max(20, w * h // 900))
+        def make_ex(**kw):
+            e = uvo.ORBextractor(nfeat, scale, nlev, 0, th, max_width=w, max_height=h, **kw)
+            e.tune(uvo.UVO_TUNE_FAST_MODE, fast_mode)
+            return e
         try:
-            ex = uvo.ORBextractor(nfeat, scale, nlev, 0, th, max_width=w, max_height=h)
+            ex = make_ex()
         except uvo.UvoError as e:
             print("skip (unsupported geometry):", w, h, nlev, scale, str(e)[:60])
             continue
@@ -58,7 +67,7 @@ def main():
                 grid[int(k["y"] / min_px), int(k["x"] / min_px)] += 1
             gg, go = grid.copy(order="F"), grid.copy(order="F")
             ex.close()
-            ex = uvo.ORBextractor(nfeat, scale, nlev, 0, th, max_width=w, max_height=h, max_input_keypoints=max(n_in, 1))
+            ex = make_ex(max_input_keypoints=max(n_in, 1))
             kg, dg = ex(img, kin.copy(), gg, min_px, False, need)
             ko, do = oe(img, kin.copy(), go, min_px, False, need)
             ok = len(kg) == len(ko) and kg.tobytes() == ko.tobytes() and np.array_equal(dg, do) and np.array_equal(gg, go)
@@ -67,7 +76,7 @@ def main():
             mode = "batch"
             B = int(rng.choice([2, 5, 17]))
             ex.close()
-            ex = uvo.ORBextractor(nfeat, scale, nlev, 0, th, max_width=w, max_height=h, max_batch=B)
+            ex = make_ex(max_batch=B)
             frames = np.stack([img] + [synth.make_frame(int(rng.integers(1 << 30)), w, h, n_shapes=max(20, w * h // 1500)) for _ in range(B - 1)])
             res = ex.extract_batch(frames)
             ok = True
@@ -81,7 +90,7 @@ def main():
             ok = len(kg) == len(ko) and kg.tobytes() == ko.tobytes() and np.array_equal(dg, do)
         if not ok:
             bad += 1
-            print("MISMATCH trial", t, mode, dict(w=w, h=h, nlev=nlev, scale=scale, nfeat=nfeat, th=th, kind=kind, n_gpu=len(kg), n_oracle=len(ko)))
+            print("MISMATCH trial", t, mode, dict(w=w, h=h, nlev=nlev, scale=scale, nfeat=nfeat, th=th, kind=kind, fast_mode=fast_mode, n_gpu=len(kg), n_oracle=len(ko)))
         ex.close()
     print("trials", n_trials, "mismatches", bad)
     return 1 if bad else 0
