@@ -132,6 +132,18 @@ def test_oracle_primitives_equal_reference(oracle):
         assert got.tobytes() == pins["c2_f0__fast_%d" % k].tobytes(), "cv::FAST ROI %d" % k
         k += 1
     assert k >= 8
+    # BFMatcher(NORM_HAMMING).knnMatch(q, t, 2) as Utils::ratioMatching calls it (include/utils.h:92-101): the tie-break among equal distances
+    for name in ("ties", "dups", "one", "two"):
+        if "knn_%s_q" % name not in pins:
+            continue                      # pins made before the kit dumped them
+        q, t = pins["knn_%s_q" % name], pins["knn_%s_t" % name]
+        i0, d0, i1, d1 = oracle.knn2(q, t)
+        ref_i, ref_d = pins["knn_%s_idx" % name], pins["knn_%s_dist" % name]
+        np.testing.assert_array_equal(i0, ref_i[:, 0], err_msg="knnMatch nearest, set " + name)
+        np.testing.assert_array_equal(d0, ref_d[:, 0])
+        if len(t) >= 2:
+            np.testing.assert_array_equal(i1, ref_i[:, 1], err_msg="knnMatch second nearest, set " + name)
+            np.testing.assert_array_equal(d1, ref_d[:, 1])
     deg = np.float32([oracle.fast_atan2(float(a), float(b)) for a, b in zip(pins["atan2_y"], pins["atan2_x"])])
     np.testing.assert_array_equal(deg.view(np.uint32), pins["atan2_deg"].view(np.uint32))
     k = 0
@@ -237,6 +249,13 @@ def test_kit_round_trip_with_an_emulated_dumper(oracle, tmp_path, monkeypatch):
             put("%s/fast_%d_roi" % (name, nfast), "i4", np.int32([x, y, w, h, th]))
             put("%s/fast_%d" % (name, nfast), "kp", oracle.fast(frames[name][0][y:y + h, x:x + w], th, True))
             nfast += 1
+        elif t[0] == "knn":
+            name, nq, nt = t[1], int(t[2]), int(t[3])
+            q, tr = np.fromfile(indir / t[4], np.uint8).reshape(nq, 32), np.fromfile(indir / t[5], np.uint8).reshape(nt, 32)
+            i0, d0, i1, d1 = oracle.knn2(q, tr)
+            put("knn_%s_q" % name, "u1", q), put("knn_%s_t" % name, "u1", tr)
+            put("knn_%s_idx" % name, "i4", np.stack([i0, i1 if nt >= 2 else np.full(nq, -1)], 1).astype(np.int32))
+            put("knn_%s_dist" % name, "i4", np.stack([d0, d1 if nt >= 2 else np.full(nq, -1)], 1).astype(np.int32))
         elif t[0] == "atan2":
             yy, xx = np.fromfile(indir / t[2], np.float32), np.fromfile(indir / t[3], np.float32)
             put("atan2_y", "f4", yy), put("atan2_x", "f4", xx)

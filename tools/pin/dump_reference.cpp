@@ -177,6 +177,23 @@ int main(int argc, char** argv) {
       put(name + "/fast_" + std::to_string(nfast) + "_roi", "i4", roi, 4, {5});
       put_keypoints(name + "/fast_" + std::to_string(nfast), k);
       ++nfast;
+    } else if (kind == "knn") {
+      // Utils::ratioMatching (include/utils.h:92-101): BFMatcher(NORM_HAMMING).knnMatch(descriptors_1, descriptors_2, matches, 2)
+      std::string name, fq, ft;
+      int nq, nt;
+      ss >> name >> nq >> nt >> fq >> ft;
+      std::vector<char> rq = slurp(in + "/" + fq), rt = slurp(in + "/" + ft);
+      cv::Mat Q(nq, 32, CV_8U, rq.data()), T(nt, 32, CV_8U, rt.data());
+      cv::BFMatcher matcher(cv::NORM_HAMMING);
+      std::vector<std::vector<cv::DMatch> > m;
+      matcher.knnMatch(Q, T, m, 2);
+      std::vector<int32_t> idx(2 * (size_t)nq, -1), dist(2 * (size_t)nq, -1);
+      for (int i = 0; i < nq; ++i)
+        for (size_t k = 0; k < m[i].size() && k < 2; ++k) idx[2 * i + k] = m[i][k].trainIdx, dist[2 * i + k] = (int32_t)m[i][k].distance;
+      put("knn_" + name + "_q", "u1", rq.data(), 1, {(size_t)nq, (size_t)32});
+      put("knn_" + name + "_t", "u1", rt.data(), 1, {(size_t)nt, (size_t)32});
+      put("knn_" + name + "_idx", "i4", idx.data(), 4, {(size_t)nq, (size_t)2});
+      put("knn_" + name + "_dist", "i4", dist.data(), 4, {(size_t)nq, (size_t)2});
     } else if (kind == "atan2") {
       int n;
       std::string fy, fx;

@@ -69,6 +69,24 @@ def main():
         rw, rh = int(rng.integers(20, 70)), int(rng.integers(20, 70))
         x, y = int(rng.integers(0, 640 - rw)), int(rng.integers(0, 512 - rh))
         lines.append("fast c2_f0 %d %d %d %d %d" % (x, y, rw, rh, 20 if k % 2 == 0 else 7))
+    # ... and the border cases of an ROI: the smallest one with an interior pixel (7 x 7), interiors one pixel wide / high, and ROIs that
+    # touch each corner and edge of the parent image (cv::FAST must not look outside the ROI; NMS rows at the ROI's first / last row)
+    for x, y, rw, rh in ((0, 0, 7, 7), (0, 0, 7, 40), (0, 0, 40, 7), (0, 0, 36, 36), (640 - 36, 0, 36, 36), (0, 512 - 36, 36, 36), (640 - 36, 512 - 36, 36, 36),
+                         (640 - 7, 512 - 7, 7, 7), (300, 0, 45, 9), (0, 200, 9, 45), (640 - 8, 100, 8, 60), (100, 512 - 8, 60, 8)):
+        for th in (20, 7):
+            lines.append("fast c2_f0 %d %d %d %d %d" % (x, y, rw, rh, th))
+    # cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, 2) as Utils::ratioMatching calls it (include/utils.h:92-101): which train index
+    # wins among EQUAL distances, first and second neighbour -- low-entropy descriptors (many exact ties), duplicated train rows, a
+    # train set of one and of two rows
+    def lowent(n, bits):
+        d = np.zeros((n, 32), np.uint8)
+        d[:, :bits // 8 + 1] = rng.integers(0, 256, (n, bits // 8 + 1), dtype=np.uint8) & np.uint8(0x0f)
+        return d
+    sets = {"ties": (lowent(300, 20), lowent(400, 20)), "dups": (rng.integers(0, 256, (100, 32), dtype=np.uint8),
+                                                                 np.repeat(rng.integers(0, 256, (50, 32), dtype=np.uint8), 3, axis=0)),
+            "one": (lowent(40, 12), lowent(1, 12)), "two": (lowent(40, 12), lowent(2, 12))}
+    for name, (q, t) in sets.items():
+        lines.append("knn %s %d %d %s %s" % (name, len(q), len(t), put("knn_%s_q" % name, q), put("knn_%s_t" % name, t)))
     # cv::fastAtan2 on a grid of (y, x) incl. zeros, equal magnitudes, negative and tiny values
     v = np.concatenate([np.float32([0, 1, -1, 1e-12, -1e-12, 3e7]), rng.normal(0, 50000, 2000).astype(np.float32), rng.integers(-200000, 200000, 2000).astype(np.float32)])
     yy, xx = rng.permutation(v)[:4000], rng.permutation(v)[:4000]
