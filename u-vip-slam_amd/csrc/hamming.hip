@@ -93,6 +93,13 @@ __device__ __forceinline__ v4i spread16(uint32_t x) {  // 16 bits -> 16 bytes
   return r;
 }
 
+// median of three signed integers (v_med3_i32; clang has no builtin for the integer form)
+__device__ __forceinline__ int med3_i32(int a, int b, int c) {
+  int r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // grid: (ceil(max_query/128), pairs); 4 wavefronts, each owns 32 queries (MFMA columns); train descriptors = MFMA rows.
 // C/D layout of the 32x32 shapes: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 // A / B fragments of k-step s: lane (r = lane & 31, h = lane >> 5) supplies bits 32s + 16h .. +15 of train row r / query column r
@@ -117,14 +124,15 @@ __global__ __launch_bounds__(256, UVO_OCC_KNN) void k_knn2_mfma(const uint8_t* _
   const int qi = blockIdx.x * 128 + wv * 32 + r;
   const uint32_t* Q = reinterpret_cast<const uint32_t*>(q + (int64_t)pair * q_stride * 32);
   const uint32_t* T = reinterpret_cast<const uint32_t*>(t + (int64_t)pair * t_stride * 32);
-  // query fragments, held for the whole train loop (8 k-steps x 4 VGPRs) + pop(q)
+  // query fragments, held for the whole train loop (8 k-steps x 4 VGPRs) + pop(q).  The query bits are expanded to 0 / -1 (bytes 0x00 /
+  // 0xff), the train bits to 0 / 1: the accumulator then holds -<q, t>, and the key of the epilogue is one shift-add away
   v4i bq[8];
   int popq = 0;
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     const uint32_t w = qi < nq ? Q[(int64_t)qi * 8 + s] : 0u;
     popq += __popc(w);
-    bq[s] = spread16(w >> (16 * h));
+    bq[s] = spread16(w >> (16 * h)) * 0xff;  // 0x01 -> 0xff per byte (no carries between bytes)
   }
   int k0 = 0x7fffffff, k1 = 0x7fffffff;  // two smallest keys ((pop(t) - 2 dot) << 16 | train index), signed
   const int erow = threadIdx.x >> 3, ec = threadIdx.x & 7;  // expansion: thread -> (train row of the tile, 32-bit chunk)
@@ -159,8 +167,10 @@ __global__ __launch_bounds__(256, UVO_OCC_KNN) void k_knn2_mfma(const uint8_t* _
       const int kbv[4] = {kb.x, kb.y, kb.z, kb.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int key = kbv[e] - (acc[4 * g + e] << 17);
-        k1 = min(k1, max(k0, key));
+        // key = (pop(t) - 2 <q, t>) << 16 | train index, with acc = -<q, t>: v_lshl_add_u32; the two smallest of {k0 <= k1, key} are
+        // min(k0, key) and the median of the three: v_med3_i32 + v_min_i32 -- three instructions per distance
+        const int key = (int)(((uint32_t)acc[4 * g + e] << 17) + (uint32_t)kbv[e]);
+        k1 = med3_i32(k0, k1, key);
         k0 = min(k0, key);
       }
     }
