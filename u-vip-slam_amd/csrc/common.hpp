@@ -6,7 +6,9 @@
 //              wavefront keeps its corner list in LDS and moves it here when a region holds more than 384 corners
 //   cand     : [frame][level][cap_l] FAST candidates, SoA words {x | y<<16} and {score}, count in cand_count[frame][level]
 //   cand_lo  : [frame][level][cap_l] NMS survivors below fastTh (x | y<<12 | score<<24) waiting for the per-cell threshold vote
-//   cursor   : [frame][level][2] fill counts of cand (survivors >= fastTh) and cand_lo; zero between batches
+//   cursor   : [frame][level][2] fill counts of cand (survivors >= fastTh, and the literal-7 survivors of k_fast_cells) and cand_lo; zero
+//              between batches
+//   cell_hi  : [frame][sum of nRows x nCols] a cell owns a survivor >= fastTh; tpass / fcount / cell list: the adaptive FAST mode (fast.hip)
 //   sel      : [frame][level][quota_l+4] quad-tree survivors in the reference's list order
 //   flist    : [frame][flist_cap] final (level, x, y, aux) slots in output order
 #pragma once

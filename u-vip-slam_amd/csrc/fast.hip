@@ -24,6 +24,15 @@
 //   the per-cell vote (survivors >= fastTh if the cell has any, else the literal-7 fallback) needs every region of a cell to
 //   be finished, so it is taken by the quad-tree kernel, which appends the low survivors of cells without a high one to the
 //   level's candidates (octree.hip).  Candidate order in HBM is arbitrary: the quad-tree orders by coordinates.
+//
+// That is the SINGLE-PASS form (the level streams at min(fastTh, 7)).  When fastTh > 7 a level can instead take the THRESHOLD-
+// ADAPTIVE TWO-PASS form: k_fast_score streams it at fastTh -- a corner >= fastTh can only be suppressed by a neighbour >= fastTh,
+// so the survivors are exactly the first call's keypoints, and far fewer pixels reach the exact test -- and
+//   k_fast_cells_list / k_fast_cells : redo the cells left without a keypoint at the literal 7, per cell, literally (the second call
+//                   of :797), appending their survivors at the same cursor.
+// tpass[level] (device memory, per pipeline lane) says which form a level takes in a batch; k_octree counts the batch's fall-back
+// cells and k_assemble re-decides the levels for the lane's next batch (describe.hip: adapt_fast_mode).  Both forms give the same
+// candidates; the parity tests force each (UVO_TUNE_FAST_MODE).
 #include <algorithm>
 #include <cstdlib>
 #include "common.hpp"
