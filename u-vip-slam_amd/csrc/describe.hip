@@ -238,7 +238,10 @@ __device__ __forceinline__ int wave_sum(int v) {
 // wavefront keeps several keypoints in flight: all patch loads are issued before the first reduction, all blurred-pixel
 // loads before the first ballot, and the pattern table is read once for the group.
 constexpr int DK_PER_WAVE = 4;
-constexpr int DW_ROWS = 37, DW_ROW_DWORDS = 10, DW_DWORDS = DW_ROWS * DW_ROW_DWORDS;  // steered sample points reach +-18 px
+// The blurred plane is tiled (gauss.hip): 16 x 8-pixel tiles of one 128-byte line.  A keypoint's window (u in [-18, 21], v in [-18, 18])
+// lies inside a grid of at most 4 x 6 tiles; the tiles are copied whole -- one dwordx4 per lane, eight lanes per line -- into a
+// row-major LDS window of 48 rows x 64 bytes, from which the sample points are read as before.
+constexpr int DW_TX = 4, DW_TY = 6, DW_PITCH = DW_TX * 16, DW_ROWS = DW_TY * 8, DW_DWORDS = DW_ROWS * DW_PITCH / 4;
 
 #ifndef UVO_OCC_DESCRIBE
 #define UVO_OCC_DESCRIBE 1  // more workgroups per CU change nothing here (measured)
@@ -270,15 +273,15 @@ __global__ __launch_bounds__(256, UVO_OCC_DESCRIBE) void k_describe(const LevelG
   float scale[DK_PER_WAVE];
   bool rescale[DK_PER_WAVE], live[DK_PER_WAVE];
   uint32_t px[DK_PER_WAVE][4];
-  uint32_t wv[DK_PER_WAVE][6];
-  // window dwords of this lane: index = row * 10 + column dword (6 x 64 >= 370)
-  int wrow[6], wcol[6];
+  uint4 wv[DK_PER_WAVE][3];
+  int wcy[DK_PER_WAVE], wcx[DK_PER_WAVE];  // (u, v) = (0, 0) inside the LDS window: row / byte column
+  // tile rows of this lane: lane-load L = lane + 64 i covers row (L & 7) of tile (L >> 3) of the 4 x 6 grid, i.e. the 24 tiles are
+  // spread over the three loads, eight lanes each
+  int t_ty[3], t_tx[3];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int idx = lane + 64 * i;
-    const int row = (idx * 6554) >> 16;  // idx / 10 for idx < 16384
-    wrow[i] = (row < DW_ROWS ? row : DW_ROWS - 1) - 18;
-    wcol[i] = -18 + 4 * (idx - row * 10);
+  for (int i = 0; i < 3; ++i) {
+    const int t = (lane + 64 * i) >> 3;
+    t_ty[i] = t >> 2, t_tx[i] = t & 3;
   }
   // orientation-patch slots of this lane (same for every keypoint): row * 8 + chunk, see below
   int vv[4], u0[4];
@@ -337,20 +340,25 @@ __global__ __launch_bounds__(256, UVO_OCC_DESCRIBE) void k_describe(const LevelG
       const int vr = vv[i] <= 15 ? vv[i] : 15;  // keep the (masked) load of row 31 inside the plane
       __builtin_memcpy(&px[k][i], pcorner + (uint32_t)((vr + 18) * pitch[k] + (u0[i] + 18)), 4);
     }
-    // blurred window: coalesced row segments (6 rows per load instruction) instead of 512 scattered byte gathers
-    const uint8_t* bcorner = blur + corner_off;
+    // blurred window: whole tiles of the tiled plane.  Window corner in padded coordinates (x0, y0) = (cx + 16 - 18, cy + 16 - 18);
+    // tile grid origin (x0 / 16, y0 / 8); tiles beyond the window's last column / row are clamped onto the last one (loaded twice,
+    // stored twice with the same bytes)
+    const int x0 = cx + kPad - 18, y0 = cy + kPad - 18;
+    const int tx0 = x0 >> 4, ty0 = y0 >> 3, ntx = ((x0 + 39) >> 4) - tx0, nty = ((y0 + 36) >> 3) - ty0;  // last tile index of the window in the grid
+    wcx[k] = (x0 & 15) + 18, wcy[k] = (y0 & 7) + 18;
+    const uint8_t* bplane = blur + f * pyr_block + lv[level[k]].plane_off;
+    const int tiles_x = pitch[k] >> 4;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      uint32_t d;
-      __builtin_memcpy(&d, bcorner + (uint32_t)((wrow[i] + 18) * pitch[k] + (wcol[i] + 18)), 4);
-      wv[k][i] = d;
+    for (int i = 0; i < 3; ++i) {
+      const int ty = ty0 + (t_ty[i] < nty ? t_ty[i] : nty), tx = tx0 + (t_tx[i] < ntx ? t_tx[i] : ntx);
+      wv[k][i] = *reinterpret_cast<const uint4*>(bplane + ((int64_t)ty * tiles_x + tx) * 128 + ((lane & 7) << 4));
     }
   }
 #pragma unroll
   for (int k = 0; k < DK_PER_WAVE; ++k)
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-      if (lane + 64 * i < DW_DWORDS) win[k][lane + 64 * i] = wv[k][i];
+    for (int i = 0; i < 3; ++i)  // tile (t_ty, t_tx), row lane & 7 -> LDS row t_ty * 8 + (lane & 7), bytes t_tx * 16 ..
+      *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(win[k]) + (t_ty[i] * 8 + (lane & 7)) * DW_PITCH + t_tx[i] * 16) = wv[k][i];
   // pattern: lane l evaluates pairs l, l+64, l+128, l+192
   float4 pq[4];
 #pragma unroll
@@ -419,13 +427,13 @@ __global__ __launch_bounds__(256, UVO_OCC_DESCRIBE) void k_describe(const LevelG
   uint8_t t0[DK_PER_WAVE][4], t1[DK_PER_WAVE][4];
 #pragma unroll
   for (int k = 0; k < DK_PER_WAVE; ++k) {
-    const uint8_t* wb = reinterpret_cast<const uint8_t*>(win[k]) + 18 * (DW_ROW_DWORDS * 4) + 18;  // byte of (u, v) = (0, 0)
+    const uint8_t* wb = reinterpret_cast<const uint8_t*>(win[k]) + wcy[k] * DW_PITCH + wcx[k];  // byte of (u, v) = (0, 0)
     const float a = ca[k], b = sa[k];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float x0 = pq[j].x, y0 = pq[j].y, x1 = pq[j].z, y1 = pq[j].w;
-      t0[k][j] = wb[cv_round(x0 * b + y0 * a) * (DW_ROW_DWORDS * 4) + cv_round(x0 * a - y0 * b)];
-      t1[k][j] = wb[cv_round(x1 * b + y1 * a) * (DW_ROW_DWORDS * 4) + cv_round(x1 * a - y1 * b)];
+      t0[k][j] = wb[cv_round(x0 * b + y0 * a) * DW_PITCH + cv_round(x0 * a - y0 * b)];
+      t1[k][j] = wb[cv_round(x1 * b + y1 * a) * DW_PITCH + cv_round(x1 * a - y1 * b)];
     }
   }
 #pragma unroll

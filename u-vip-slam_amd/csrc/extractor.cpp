@@ -192,7 +192,7 @@ static int build_geom(const uvo_extractor* h, int width, int height, Geom& g, st
     L.pw = L.w + 2 * kPad, L.ph = L.h + 2 * kPad;
     L.pitch = (L.pw + 63) / 64 * 64;
     L.plane_off = off;
-    off += (int64_t)L.pitch * L.ph;
+    off += (int64_t)L.pitch * ((L.ph + 7) & ~7);  // whole 16 x 8 tiles: the blurred plane is stored tiled (gauss.hip), same offsets for both
     off = (off + 255) / 256 * 256;
     L.bw = L.w - 2 * kMinBorder, L.bh = L.h - 2 * kMinBorder;
     const float fw = (float)L.bw, fh = (float)L.bh;
@@ -1159,7 +1159,18 @@ int uvo_extractor_read_plane(uvo_extractor* h, int frame, int level, int which, 
   UVO_HIP_CHECK(hipStreamSynchronize(h->lane[h->cur].stream));
   const LevelGeom& L = h->geom.lv[level];
   const uint8_t* src = (which ? h->lane[h->cur].d_blur : h->lane[h->cur].d_pyr) + (size_t)frame * h->geom.pyr_block + L.plane_off;
-  UVO_HIP_CHECK(hipMemcpy2D(dst, L.pw, src, L.pitch, L.pw, L.ph, hipMemcpyDeviceToHost));
+  if (!which) {
+    UVO_HIP_CHECK(hipMemcpy2D(dst, L.pw, src, L.pitch, L.pw, L.ph, hipMemcpyDeviceToHost));
+    return UVO_OK;
+  }
+  // the blurred plane lives in HBM as 16 x 8-pixel tiles of 128 bytes (one cache line each: k_describe's windows touch a third of the
+  // lines a row-major plane would cost them); pixel (x, y) = tile (y / 8, x / 16), byte (y % 8) * 16 + x % 16
+  const size_t bytes = (size_t)L.pitch * ((L.ph + 7) & ~7);
+  std::vector<uint8_t> tiled(bytes);
+  UVO_HIP_CHECK(hipMemcpy(tiled.data(), src, bytes, hipMemcpyDeviceToHost));
+  const int tiles_x = L.pitch >> 4;
+  for (int y = 0; y < L.ph; ++y)
+    for (int x = 0; x < L.pw; ++x) dst[(size_t)y * L.pw + x] = tiled[((size_t)(y >> 3) * tiles_x + (x >> 4)) * 128 + (y & 7) * 16 + (x & 15)];
   return UVO_OK;
 }
 

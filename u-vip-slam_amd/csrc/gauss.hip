@@ -5,6 +5,8 @@
 // so border taps read the real, un-blurred REFLECT_101 pad, and after the call the pad still holds un-blurred
 // pixels which computeOrbDescriptor samples up to 2 px deep.  Here the blur is out of place: the output plane
 // holds the blurred interior plus a 4-px ring copied from the un-blurred pad -- all the descriptor can reach.
+// The output plane is TILED: 16 x 8-pixel tiles of 128 bytes (one cache line), tile (ty, tx) at ((ty * pitch / 16) + tx) * 128 of
+// the plane.  Its only reader is k_describe, whose 37 x 40-byte windows touch 18.7 lines this way instead of 48 (describe.hip).
 // Arithmetic is OpenCV's symmetric-smooth integer engine: taps round(g*256) per pass (18,34,49,55,49,34,18),
 // row pass u8 -> int, column pass (sum + 2^15) >> 16 saturated to u8.  The column pass runs on the fp32 pipe and is still exact:
 // row sums (< 2^16) times taps (sum 257) stay below 2^24 wherever the result is not saturated, fp32 add / fma issue in 2.4
@@ -45,6 +47,7 @@ __device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t 
   h[3] = (float)(uint32_t)gauss_row1<3>(L, C, R, T1, T2);
 }
 
+constexpr int GS_TILES = 16;  // tiles a wavefront collects per 8-row group: 15 of a full strip, 2 x 7 / 4 x 3 of the narrow ones
 __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int64_t pyr_block,
                                                 const LevelGeom* __restrict__ lv, int nlevels, int4 taps, int rows_per_seg) {
   // work item (one per wavefront) -> (level, strip, segment group); narrow remainder strips hold 2 or 4 row segments side by side
@@ -53,6 +56,7 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
   const int vbx = vb % (int)gridDim.x, f = vb / (int)gridDim.x;  // an XCD walks whole frames, item after item
   int item = vbx * 4 + wave_in_block();
   const int lane = threadIdx.x & 63;
+  __shared__ __attribute__((aligned(16))) uint32_t s_tile[4][GS_TILES * 32];
   int level = 0;
   StripPlan plan;
   for (;; ++level) {
@@ -76,6 +80,48 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
   const int py0l = py0 + sub * rows_per_seg;
   const int py1l = min(py0l + rows_per_seg, g.h + 20);
   const bool lane_out = ls >= 1 && ls <= lps - 2 && X >= 12 && X < g.w + 20 && py1l > py0l;
+  const int tile_col = (X >> 4) * 128 + (X & 15);   // the lane's place inside a row of tiles
+  const int64_t tile_row_bytes = (int64_t)g.pitch * 8;  // (pitch / 16) tiles of 128 bytes
+  // Output goes to the plane in whole cache lines: the tiles a sub-strip's output lanes cover completely (columns
+  // [16 t_first, 16 (t_last + 1)) of its output range) are collected in LDS -- eight rows of the walk fill them -- and written out as
+  // 16 bytes per lane, eight lanes per 128-byte line; the few columns left and right of them are stored directly, a dword per row.
+  const int x_lo = max(12, 8 + strip_x + 4), x_hi = min(g.w + 20, 8 + strip_x + 4 * (lps - 1));  // output columns of the sub-strip
+  const int t_first = (x_lo + 15) >> 4, nts = max((x_hi >> 4) - t_first, 0);                    // its full tiles: t_first .. t_first + nts - 1
+  const int ts_shift = nsub == 1 ? 4 : (nsub == 2 ? 3 : 2), TS = 1 << ts_shift;                 // LDS tile slots per sub-strip (16 / nsub >= nts)
+  const bool via_lds = lane_out && (X >> 4) >= t_first && (X >> 4) < t_first + nts;
+  uint32_t* stile = s_tile[wave_in_block()];
+  const int lds_slot = ((sub * TS + ((X >> 4) - t_first)) << 5) + ((X & 15) >> 2);  // + (py & 7) * 4: dword of the lane's pixels in the tile
+  // The write-out of a group: task t = lane + 64 it (it = 0, 1) is row t & 7 of tile slot t >> 3; everything about a task that does not
+  // depend on the group is worked out here, once.
+  // (row addresses: a sub-strip's rows lie s * rows_per_seg below sub-strip 0's, a whole number of tile rows, so every address is
+  // "tile row of sub-strip 0" -- wave-uniform, scalar arithmetic -- plus a per-lane constant)
+  const int64_t seg_tile_rows = (int64_t)(rows_per_seg >> 3) * tile_row_bytes;
+  const int64_t lane_goff = (int64_t)sub * seg_tile_rows + tile_col;  // the lane's own dword relative to sub-strip 0's tile row
+  int f_lds[2], f_p0[2], f_p1[2], f_rowoff[2];
+  int64_t f_goff[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int t = lane + 64 * it, row = t & 7, slot = t >> 3, s_ = slot >> ts_shift, ti = slot & (TS - 1);
+    const int p0 = py0 + s_ * rows_per_seg;
+    f_lds[it] = (slot << 5) + (row << 2);
+    f_goff[it] = (int64_t)s_ * seg_tile_rows + (t_first + ti) * 128 + (row << 4);
+    f_rowoff[it] = s_ * rows_per_seg + row;
+    f_p0[it] = p0, f_p1[it] = (s_ < nsub && ti < nts) ? min(p0 + rows_per_seg, g.h + 20) : p0;  // empty range: no such tile
+  }
+  // writes rows 0 .. r_hi of the 8-row group that starts at padded row pyg (of sub-strip 0) of every collected tile to the plane
+  auto flush_tiles = [&](int pyg, int r_hi, int64_t group_base) {  // group_base = byte offset of the group's tile row (sub-strip 0)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int prow = pyg + f_rowoff[it];  // the row of the task's own sub-strip in the plane
+      if ((lane & 7) <= r_hi && prow >= f_p0[it] && prow < f_p1[it]) {
+        const uint4 v = *reinterpret_cast<const uint4*>(stile + f_lds[it]);
+        *reinterpret_cast<uint4*>(dst + (group_base + f_goff[it])) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
   uint32_t inmask = 0;  // bytes of the lane's dword that lie inside the image columns
 #pragma unroll
   for (int k = 0; k < 4; ++k) inmask |= (X + k >= kPad && X + k < g.w + kPad) ? 0xffu << (8 * k) : 0u;
@@ -97,6 +143,9 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
     prow = prow > g.ph - 1 ? g.ph - 1 : prow;  // rows past the plane are never used by a valid output
     return *reinterpret_cast<const uint32_t*>(src + (int64_t)prow * g.pitch + Xc);
   };
+  // byte offset of sub-strip 0's current output row inside its tile column: tile row * tile_row_bytes + (row % 8) * 16, advanced row by
+  // row (one scalar add instead of a 64-bit multiply per row)
+  int64_t rowb = (int64_t)(py0 >> 3) * tile_row_bytes + ((py0 & 7) << 4);
   uint32_t cur[7], nxt[7];
 #pragma unroll
   for (int u = 0; u < 7; ++u) cur[u] = load_row(u);  // unconditional (the row index is clamped into the plane): with a branch around a load
@@ -135,12 +184,30 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
           // pad ring and anything outside the image: the un-blurred centre pixel (byte mask per lane, rows uniform)
           const uint32_t m = row_in ? inmask : 0u;
           const uint32_t out = (blurred & m) | (centre & ~m);
-          if (lane_out && py < py1l) *reinterpret_cast<uint32_t*>(dst + (int64_t)py * g.pitch + X) = out;
+          // tiled store: pixel (x, y) of the blurred plane lives in tile (y / 8, x / 16) -- 128 bytes, one cache line -- at byte
+          // (y % 8) * 16 + x % 16 (a lane's four pixels never straddle a tile: X is a multiple of 4).  Four lanes fill a tile row,
+          // eight consecutive rows of the walk complete the line in L2.
+          // (py & 7 is the same for every sub-strip: their first rows differ by multiples of rows_per_seg, a multiple of 8)
+          const int py_u = py0 + j - 6;  // the row of sub-strip 0: wave-uniform
+          if (via_lds)
+            stile[lds_slot + ((py_u & 7) << 2)] = out;
+          else if (lane_out && py < py1l)
+            *reinterpret_cast<uint32_t*>(dst + rowb + lane_goff) = out;
+          if ((py_u & 7) == 7) {
+            flush_tiles(py_u & ~7, 7, rowb - 112);
+            rowb += tile_row_bytes - 112;
+          } else {
+            rowb += 16;
+          }
         }
       }
     }
 #pragma unroll
     for (int u = 0; u < 7; ++u) cur[u] = nxt[u];
+  }
+  {  // the rows of the last, incomplete group
+    const int py_last = py0 + nsrc - 7;  // last output row of sub-strip 0
+    if ((py_last & 7) != 7) flush_tiles(py_last & ~7, py_last & 7, (int64_t)(py_last >> 3) * tile_row_bytes);
   }
 }
 
