@@ -246,7 +246,12 @@ constexpr int DW_TX = 4, DW_TY = 6, DW_PITCH = DW_TX * 16, DW_ROWS = DW_TY * 8, 
 #ifndef UVO_OCC_DESCRIBE
 #define UVO_OCC_DESCRIBE 1  // more workgroups per CU change nothing here (measured)
 #endif
-__global__ __launch_bounds__(256, UVO_OCC_DESCRIBE) void k_describe(const LevelGeom* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
+#ifndef UVO_DESC_WAVES
+#define UVO_DESC_WAVES 2   // wavefronts per workgroup: 24.6 KB of LDS -- fits beside four k_fast_score workgroups of the other pipeline lane (a
+                           // four-wavefront workgroup's 49 KB only beside three): +2 % frames/s at 640x512, +-0 at 1920x1080
+#endif
+constexpr int DK_WAVES = UVO_DESC_WAVES;
+__global__ __launch_bounds__(64 * DK_WAVES, UVO_OCC_DESCRIBE) void k_describe(const LevelGeom* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blur, int64_t pyr_block,
                                                   const FinalSlot* __restrict__ flist, int flist_cap, const int32_t* __restrict__ n_final,
                                                   const uvo_keypoint* __restrict__ in_kp, int in_cap, const float* __restrict__ pattern,
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256, UVO_OCC_DESCRIBE) void k_describe(const LevelG
   const int vb = xcd_contiguous((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
   const int bx = vb % (int)gridDim.x, f = vb / (int)gridDim.x;
   const int lane = threadIdx.x & 63;
-  const int slot0 = (bx * 4 + wave_in_block()) * DK_PER_WAVE;
+  const int slot0 = (bx * DK_WAVES + wave_in_block()) * DK_PER_WAVE;
   int n = n_final[f];
   if (bx == 0 && threadIdx.x == 0) n_out[f] = n;
   n = n > flist_cap ? flist_cap : n;
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256, UVO_OCC_DESCRIBE) void k_describe(const LevelG
   if (slot0 >= n) return;
 
   // blurred 37-row x 40-byte windows (u in [-18, 21], v in [-18, 18]) of the group's keypoints, wavefront-private
-  __shared__ uint32_t s_win[4][DK_PER_WAVE][DW_DWORDS];
+  __shared__ uint32_t s_win[DK_WAVES][DK_PER_WAVE][DW_DWORDS];
   uint32_t(*win)[DW_DWORDS] = s_win[wave_in_block()];
   uvo_keypoint kp[DK_PER_WAVE];
   int64_t center_off[DK_PER_WAVE];
@@ -489,7 +494,7 @@ void launch_describe(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const 
                      const FinalSlot* d_flist, const int32_t* d_n_final, const uvo_keypoint* d_in_kp, int in_cap, const float* d_pattern,
                      const uint32_t* d_patch, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch) {
   const int slots = g.flist_cap < cap ? g.flist_cap : cap;
-  hipLaunchKernelGGL(k_describe, dim3((slots + 4 * DK_PER_WAVE - 1) / (4 * DK_PER_WAVE), batch), dim3(256), 0, s, d_lv, g.nlevels, d_pyr, d_blur, pyr_block, d_flist,
+  hipLaunchKernelGGL(k_describe, dim3((slots + DK_WAVES * DK_PER_WAVE - 1) / (DK_WAVES * DK_PER_WAVE), batch), dim3(64 * DK_WAVES), 0, s, d_lv, g.nlevels, d_pyr, d_blur, pyr_block, d_flist,
                      g.flist_cap, d_n_final, d_in_kp, in_cap, d_pattern, d_patch, d_out_kp, d_out_desc, cap, d_n_out);
 }
 
