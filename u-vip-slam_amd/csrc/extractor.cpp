@@ -66,6 +66,7 @@ struct Lane {
   uint8_t* a_desc = nullptr;
   int32_t* a_n = nullptr;
   int a_batch = 0;  // frames of the batch in flight on this lane (0 = none)
+  hipEvent_t a_uploaded = nullptr;  // recorded behind the lane's frame upload (asynchronous host form)
 };
 
 struct uvo_extractor {
@@ -114,6 +115,12 @@ struct uvo_extractor {
   // memory stall the stream once per call; a pinned bounce keeps them asynchronous behind one wait)
   uint8_t* h_pin = nullptr;
   size_t pin_bytes = 0;
+  // asynchronous host form: the event behind the most recent frame upload of ANY lane.  The next upload waits for it, so that uploads
+  // follow one another instead of sharing the link: two lanes that upload at the same time finish together, then compute together,
+  // then download together -- link idle while the GPU works and the GPU idle while the link works (measured: 2.36 instead of 1.87 ms
+  // per 256-frame job, and the in-phase pattern is stable once entered).  One after the other, lane B's upload runs under lane A's
+  // kernels whatever the kernels' durations are.
+  hipEvent_t last_upload = nullptr;
 };
 
 namespace uvo {
@@ -610,6 +617,7 @@ void uvo_extractor_destroy(uvo_extractor* h) {
                   L.d_cand_count, L.d_sel_count, L.d_n_final, L.d_cor_n, L.d_cor, L.d_cell_hi, L.d_cand_lo, L.d_cursor, L.d_tpass, L.d_fstat, L.d_fcount, L.d_cell_list, L.d_flist, L.a_imgs, L.a_kp, L.a_desc, L.a_n};
     for (void* p : lp)
       if (p) (void)hipFree(p);
+    if (L.a_uploaded) (void)hipEventDestroy(L.a_uploaded);
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
   void* ptrs[] = {h->d_clahe_lut, h->d_clahe_out, h->d_lv, h->d_cells, h->d_cell_flag, h->d_ctab, h->d_rtab, h->d_pattern, h->d_patch, h->d_imgs, h->d_out_kp,
@@ -1033,6 +1041,8 @@ int uvo_extract_batch_submit_internal(uvo_extractor* h, int batch, int n_downloa
       return rc;
   }
   hipStream_t s = L.stream;
+  if (!L.a_uploaded) UVO_HIP_CHECK(hipEventCreateWithFlags(&L.a_uploaded, hipEventDisableTiming));
+  if (h->last_upload) UVO_HIP_CHECK(hipStreamWaitEvent(s, h->last_upload, 0));  // uploads take turns on the link (see uvo_extractor::last_upload)
   if (stride == width && (batch == 1 || frame_stride == (ptrdiff_t)width * height)) {
     UVO_HIP_CHECK(hipMemcpyAsync(L.a_imgs, imgs, (size_t)batch * width * height, hipMemcpyHostToDevice, s));
   } else {
@@ -1040,6 +1050,8 @@ int uvo_extract_batch_submit_internal(uvo_extractor* h, int batch, int n_downloa
       UVO_HIP_CHECK(hipMemcpy2DAsync(L.a_imgs + (size_t)b * width * height, width, imgs + (size_t)b * frame_stride, stride, width, (size_t)height,
                                      hipMemcpyHostToDevice, s));
   }
+  UVO_HIP_CHECK(hipEventRecord(L.a_uploaded, s));
+  h->last_upload = L.a_uploaded;
   const int prev_lane = h->cur;
   rc = run_batch_device(h, li, batch, L.a_imgs, width, height, width, (ptrdiff_t)width * height, nullptr, nullptr, nullptr, 0, 0, 0, 1, nullptr, L.a_kp,
                         L.a_desc, dcap, L.a_n);
