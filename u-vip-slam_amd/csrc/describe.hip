@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256) void k_assemble(const LevelGeom* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ballot_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(64 * DK_WAVES, UVO_OCC_DESCRIBE) void k_describe(co
   // keypoints) are reduced together: every exchange step halves the number of values a lane carries (xor 32: 8 -> 4, xor 16:
   // 4 -> 2, xor 8: 2 -> 1, then xor 4/2/1 on the last one), 10 exchanges instead of 48, and value j ends up in lanes 8j..8j+7.
   // The angle and its sine / cosine are then computed once, on the lanes that own the keypoint, and broadcast. ----
-  static_assert(DK_PER_WAVE == 4, "the grouped reduction below is written for 4 keypoints (8 moments)");
+  static_assert(DK_PER_WAVE == 4, "the grouped reduction and the descriptor store below are written for 4 keypoints");
   int mv[8];
 #pragma unroll
   for (int k = 0; k < DK_PER_WAVE; ++k) {
@@ -429,27 +430,60 @@ __global__ __launch_bounds__(64 * DK_WAVES, UVO_OCC_DESCRIBE) void k_describe(co
     sa[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sin), 16 * k));  // b = sin
   }
   // ---- stage C: steered rBRIEF on the blurred level, sample points read from the LDS windows ----
+  // cvRound (round half to even) and the LDS address in five fast-class instructions per sample point instead of six slow ones
+  // (v_rndne + v_cvt_i32 twice, a shift and a three-operand add): adding 1.5 * 2^23 rounds a float of magnitude < 2^22 to an integer
+  // under the default round-to-nearest-even mode -- ties go to the even integer because the constant is even -- and leaves that integer
+  // in the low mantissa bits.  The low 16 bits of the two results are all the address needs: row * 64 + column + the byte address
+  // of (u, v) = (0, 0) in the workgroup's LDS, in 16-bit arithmetic (negative rows / columns wrap and the sum comes out right).
   uint8_t t0[DK_PER_WAVE][4], t1[DK_PER_WAVE][4];
+  const uint8_t* lds0 = reinterpret_cast<const uint8_t*>(&s_win[0][0][0]);
+  const uint32_t wave_base = (uint32_t)(wave_in_block() * DK_PER_WAVE * DW_DWORDS * 4);
+  float magic = 12582912.f;
+  asm volatile("" : "+v"(magic));  // in a vector register: a fast-class instruction that reads a scalar register or a literal is a slow one
 #pragma unroll
   for (int k = 0; k < DK_PER_WAVE; ++k) {
-    const uint8_t* wb = reinterpret_cast<const uint8_t*>(win[k]) + wcy[k] * DW_PITCH + wcx[k];  // byte of (u, v) = (0, 0)
+    uint32_t origin = wave_base + (uint32_t)(k * DW_DWORDS * 4 + wcy[k] * DW_PITCH + wcx[k]);
+    asm volatile("" : "+v"(origin));
     const float a = ca[k], b = sa[k];
+    auto sample = [&](float x, float y) -> uint8_t {
+      const float fy = (x * b + y * a) + magic, fx = (x * a - y * b) + magic;
+      uint32_t ad;
+      asm("v_mul_lo_u16_e32 %0, 64, %1\n\tv_add_u16_e32 %0, %0, %2\n\tv_add_u16_e32 %0, %0, %3"
+          : "=&v"(ad)
+          : "v"(__builtin_bit_cast(uint32_t, fy)), "v"(__builtin_bit_cast(uint32_t, fx)), "v"(origin));
+      return lds0[ad];
+    };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float x0 = pq[j].x, y0 = pq[j].y, x1 = pq[j].z, y1 = pq[j].w;
-      t0[k][j] = wb[cv_round(x0 * b + y0 * a) * DW_PITCH + cv_round(x0 * a - y0 * b)];
-      t1[k][j] = wb[cv_round(x1 * b + y1 * a) * DW_PITCH + cv_round(x1 * a - y1 * b)];
+      t0[k][j] = sample(pq[j].x, pq[j].y);
+      t1[k][j] = sample(pq[j].z, pq[j].w);
     }
+  }
+  // the group's descriptors are 128 consecutive bytes: the sixteen 64-bit ballots are dropped into lanes 0..15 (v_writelane takes the
+  // scalar register the compare wrote) and leave in one store.  (s_nop 1: on gfx90a and later a vector instruction that reads a scalar
+  // register must keep two wait states from the vector instruction that wrote it; the compiler inserts them for its own code only.)
+  uint32_t dlo = 0, dhi = 0;
+#define UVO_DESC_WORD(K, J)                                                                                         \
+  {                                                                                                                 \
+    const uint64_t w = ballot_mask(t0[K][J] < t1[K][J]);                                                            \
+    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"                                  \
+        : "+v"(dlo), "+v"(dhi)                                                                                     \
+        : "s"((uint32_t)w), "s"((uint32_t)(w >> 32)), "n"(4 * K + J));                                             \
+  }
+  UVO_DESC_WORD(0, 0) UVO_DESC_WORD(0, 1) UVO_DESC_WORD(0, 2) UVO_DESC_WORD(0, 3)
+  UVO_DESC_WORD(1, 0) UVO_DESC_WORD(1, 1) UVO_DESC_WORD(1, 2) UVO_DESC_WORD(1, 3)
+  UVO_DESC_WORD(2, 0) UVO_DESC_WORD(2, 1) UVO_DESC_WORD(2, 2) UVO_DESC_WORD(2, 3)
+  UVO_DESC_WORD(3, 0) UVO_DESC_WORD(3, 1) UVO_DESC_WORD(3, 2) UVO_DESC_WORD(3, 3)
+#undef UVO_DESC_WORD
+  {
+    const int nlive = n - slot0 < DK_PER_WAVE ? n - slot0 : DK_PER_WAVE;
+    uint2* dd = reinterpret_cast<uint2*>(out_desc + ((int64_t)f * cap + slot0) * 32);
+    if (lane < 4 * nlive) dd[lane] = make_uint2(dlo, dhi);
   }
 #pragma unroll
   for (int k = 0; k < DK_PER_WAVE; ++k) {
-    uint64_t words[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) words[j] = __ballot(t0[k][j] < t1[k][j]);
     if (!live[k]) continue;
     const int slot = slot0 + k;
-    uint64_t* dd = reinterpret_cast<uint64_t*>(out_desc + ((int64_t)f * cap + slot) * 32);
-    if (lane < 4) dd[lane] = words[lane];
     if (lane == 0) {
       uvo_keypoint o = kp[k];
       if (rescale[k]) {

@@ -228,6 +228,13 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   // operations and a 0 / 1 round trip through a register instead of one AND and one compare)
   asm volatile("" : "+v"(mk0), "+v"(mk1), "+v"(mk2), "+v"(mk3));
   const uint32_t t_even = (uint32_t)t_min * 0x00010001u, t_odd = t_even << 8;
+  // bit rrp: the lane screens centre row rrp of its sub-strip (0 = halo row above, nrows_l + 1 = halo row below) -- the row lies in the
+  // detection window, pcl = py0l - 1 + rrp in [32, g.h).  One bit-field extract per row instead of three compares and two selects.
+  uint32_t rowbits;
+  {
+    const int lo = max(33 - py0l, 0), hi = min(min(nrows_l + 1, g.h - py0l), 31);
+    rowbits = hi >= lo ? ((2u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+  }
 
   // Row loads run one unrolled block (7 rows) ahead of their use so that a wavefront never waits on the row it needs next.
   const int last_row = g.h + 15;  // last row of the padded plane
@@ -259,8 +266,7 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
         if (j >= 6) {
           const int jc = j - 3;           // loop index of the centre row; rows jc-3 .. jc+3 sit in register slots (u+1)%7 .. u
           const int rrp = j - 6;          // centre row relative to the sub-strip: 0 = halo row above, nrows + 1 = halo row below
-          const int pcl = py0l - 1 + rrp;  // the lane's centre row in the padded plane
-          const uint32_t rowm = (pcl >= 32 && pcl < g.h && rrp <= nrows_l + 1) ? 0xffffffffu : 0u;  // this lane screens this row
+          const uint32_t rowm = (uint32_t)__builtin_amdgcn_sbfe((int)rowbits, (uint32_t)rrp, 1u);  // 0 / ~0: this lane screens this row
           {
             const int sm3 = (u + 1) % 7, sm2 = (u + 2) % 7, s0 = (u + 4) % 7, sp2 = (u + 6) % 7, sp3 = u;
             const uint32_t Cc = Cr[s0], Cu = Cr[sm3], Cd = Cr[sp3], C2 = Cr[sp2], Cm2 = Cr[sm2];
