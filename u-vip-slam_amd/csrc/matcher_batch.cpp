@@ -151,7 +151,7 @@ int uvo_search_for_triangulation_batch(uvo_matcher* m, const uvo_feature_vector*
   size_t nt = 0;
   for (int p = 0; p < n_pairs; ++p) {
     const uvo_triangulation_pair& P = pairs[p];
-    if (P.n2 < 0 || P.n2 > 65535 || P.nlevels < 1) return matcher_fail(UVO_E_BADARG, "bad pair (at most 65535 keypoints, nlevels >= 1)");
+    if (P.n2 < 0 || P.n2 > 65535 || P.nlevels < 1 || P.nlevels > 64) return matcher_fail(UVO_E_BADARG, "bad pair (at most 65535 keypoints, 1 <= nlevels <= 64)");
     if (P.n2 > 0 && (!P.kp2 || !P.desc2 || !P.has_mp2 || !P.sigma2)) return matcher_fail(UVO_E_BADARG, "null pointer in a pair");
     RC(check_fv(P.fv2, P.n2));
     for (int k = 0; k < P.n2; ++k)
@@ -196,6 +196,14 @@ int uvo_search_for_triangulation_batch(uvo_matcher* m, const uvo_feature_vector*
   tb->cand.assign((size_t)total, 0u);
   if (total > 0) {
     UVO_HIP_CHECK(hipSetDevice(m->device));
+    // the uploads below read local staging vectors asynchronously: whatever way this block is left, the stream is drained first
+    struct Drain {
+      hipStream_t s;
+      bool armed;
+      ~Drain() {
+        if (armed) (void)hipStreamSynchronize(s);
+      }
+    } drain{m->stream, true};
     std::vector<uint8_t> qdesc((size_t)nq * 32), tdesc(nt * 32);
     std::vector<float> qx(nq), qy(nq);
     for (int i = 0; i < nq; ++i) {
@@ -232,6 +240,7 @@ int uvo_search_for_triangulation_batch(uvo_matcher* m, const uvo_feature_vector*
     UVO_HIP_CHECK(hipGetLastError());
     UVO_HIP_CHECK(hipMemcpyAsync(tb->cand.data(), d_cand, (size_t)total * 4, hipMemcpyDeviceToHost, m->stream));
     UVO_HIP_CHECK(hipStreamSynchronize(m->stream));  // the only host wait of the batch
+    drain.armed = false;
   }
   guard.t = nullptr;
   m->tri_batch = tb;
@@ -327,6 +336,13 @@ int uvo_fuse_batch(uvo_matcher* m, int n_targets, const uvo_fuse_target* targets
   hipStream_t s = m->stream;
   // the map points once: xyz | normal | min | max as one float block, usable, descriptors
   std::vector<float> fl((size_t)nmp * 8);
+  struct Drain {  // declared after the staging block: runs before it is freed, on every way out
+    hipStream_t s;
+    bool armed;
+    ~Drain() {
+      if (armed) (void)hipStreamSynchronize(s);
+    }
+  } drain{s, true};
   memcpy(&fl[0], xyz, (size_t)nmp * 3 * sizeof(float));
   memcpy(&fl[(size_t)nmp * 3], normal, (size_t)nmp * 3 * sizeof(float));
   memcpy(&fl[(size_t)nmp * 6], min_distance_inv, (size_t)nmp * sizeof(float));
@@ -378,6 +394,7 @@ int uvo_fuse_batch(uvo_matcher* m, int n_targets, const uvo_fuse_target* targets
   UVO_HIP_CHECK(hipMemcpyAsync(best_idx, d_best, (size_t)n_targets * nmp * 4, hipMemcpyDeviceToHost, s));
   UVO_HIP_CHECK(hipMemcpyAsync(best_dist, d_best + (size_t)n_targets * nmp, (size_t)n_targets * nmp * 4, hipMemcpyDeviceToHost, s));
   UVO_HIP_CHECK(hipStreamSynchronize(s));  // the only host wait of the batch
+  drain.armed = false;
   return UVO_OK;
 }
 
