@@ -53,8 +53,6 @@ __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_b
                                // exactly 32 KB only four do: measured, 0.87 instead of 0.76 ms per 256-frame launch)
 constexpr int FL_CAP = 320;       // corner records a wavefront keeps in LDS (a 248 x 24 region of these frames holds ~250); a busier region
                                   // flushes its list to the region's slice of the HBM list array and carries on
-constexpr int FQ_CAP = 212;       // queue entries per wavefront: < 64 left over + <= 128 pushed per half row (drained in between); sized so
-                                  // that ring + queue = the NMS tile = 6656 B per wavefront, six workgroups per CU
 
 // max over the 16 arcs of 9 contiguous ring pixels of min(d).  A 9-window always straddles the two 8-pixel halves of the
 // ring, so with running minima towards the end of each half (S) and from the start of each half (P) every arc minimum is
@@ -138,12 +136,15 @@ __device__ __forceinline__ Screen4 screen4_centre(uint32_t c, uint32_t thv, uint
   return r;
 }
 
-constexpr int FR_ROWS = 16;         // LDS row ring depth per wavefront
-constexpr int FR_MIRROR = 6;        // ring slots 0..5 are mirrored into slots 16..21 (see fast_score_chunk)
+// LDS row ring of a wavefront.  The streaming loop is unrolled by seven rows (the register ring), so the ring's period is two blocks:
+// a block of parity pb writes its row u to slot 7 pb + u, and the rows of the even blocks are mirrored into slots 14 .. 20.  The seven
+// rows j-6 .. j around a centre are then always seven consecutive slots -- 8 + u .. 14 + u in an even block, 1 + u .. 7 + u in an odd one
+// -- so that every LDS address of the loop is a per-block base + a compile-time offset: no scalar arithmetic per row.
+constexpr int FR_SLOTS = 21;
 constexpr int FR_PITCH = 66;        // row pitch in dwords: 64 + 2 so that the same column of consecutive rows hits different banks
-constexpr int FR_MAXAGE = FR_ROWS - 8;  // a queued pixel needs rows -3..+3 around it: drain before they are overwritten
-static_assert(6 <= FR_MAXAGE, "the queue is emptied every seven rows: an entry is at most six rows old");
-constexpr int FW_RING_DW = (FR_ROWS + FR_MIRROR) * FR_PITCH;  // row ring, then the queue: one LDS block per wavefront
+constexpr int FW_RING_DW = FR_SLOTS * FR_PITCH;  // row ring, then the queue: one LDS block per wavefront
+constexpr int FQ_CAP = (FS_ROWS_MAX + 2) * 64 - FW_RING_DW;  // the queue takes what the NMS tile leaves beside the ring
+static_assert(FQ_CAP >= 64 + 128 + 16, "queue: < 64 left over + <= 128 pushed per half row (drained in between)");
 constexpr int FW_DWORDS = FW_RING_DW + FQ_CAP;
 constexpr int FT_PITCH = 256, FT_ROWS = FS_ROWS_MAX + 2;      // NMS score tile, laid over ring + queue at the end of the segment
 static_assert(FT_PITCH * FT_ROWS <= FW_DWORDS * 4, "NMS tile must fit the wavefront's LDS block");
@@ -170,15 +171,15 @@ __device__ __forceinline__ int ring_strength(const uint8_t* rm3) {
 }
 
 // Full segment test + cornerScore of the queued pixels [first, first+count), one per lane.  The 16 ring pixels are read
-// back from the wavefront's LDS row ring: the queue entry carries the byte address of the pixel in the ring (rows 0..5 are
-// mirrored into slots 16..21, so the seven rows around any centre are consecutive slots and every read is base + immediate).
+// back from the wavefront's LDS row ring: the queue entry carries the byte address of the pixel in the ring (the seven rows around
+// any centre are consecutive slots, see FR_SLOTS, and every read is base + immediate).
 // entry = byte address of (pixel - 3 rows - 3 columns) in the workgroup's LDS block | xl << 15 | (row - py0 + 1) << 23.  Corners go to the wavefront's list as xl | row' << 8 | score << 16.
-__device__ __forceinline__ void fast_score_chunk(const uint32_t* q, const uint8_t* rows, int first, int count, int lane, int t_min,
+__device__ __forceinline__ void fast_score_chunk(const uint8_t* rows, uint32_t first_byte, int count, int lane, int t_min,
                                                  uint32_t* list, uint32_t* __restrict__ region, int& ncorner, int& nflushed) {
   bool corner = false;
   uint32_t packed = 0;
   if (lane < count) {
-    const uint32_t meta = q[first + lane];
+    const uint32_t meta = *reinterpret_cast<const uint32_t*>(rows + first_byte + lane * 4);  // the queue lives in the same LDS block
     const int xl = (int)((meta >> 15) & 0xff), rrp = (int)(meta >> 23);
     // the entry's address field points 3 rows above and 3 bytes left of the pixel, relative to the workgroup's LDS block: every ring
     // pixel is that one register + an immediate offset
@@ -214,8 +215,6 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   __shared__ uint32_t s_list[UVO_FAST_WAVES][FL_CAP];
   const int wv = wave_in_block(), lane = threadIdx.x & 63;
   uint32_t* rows32 = s_mem[wv];
-  uint32_t* q = rows32 + FW_RING_DW;
-  const uint8_t* rows8 = reinterpret_cast<const uint8_t*>(&s_mem[0][0]);  // queue entries address the ring relative to the workgroup's block
   // work item (one per wavefront) -> (level, strip, segment); window = padded cols [32, w) x rows [32, h)
   const int vb = xcd_contiguous((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
   const int item = (vb % (int)gridDim.x) * UVO_FAST_WAVES + wv, f = vb / (int)gridDim.x;  // an XCD walks whole frames, region after region
@@ -242,7 +241,6 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   const int Xc = X > g.pitch - 4 ? g.pitch - 4 : X;
   const int nrows = min(py0 + L.rows_per_seg, g.h) - py0;  // sub-strip 0 has the most rows
   const int nsrc = nrows + 8;  // centre rows py0-1 .. py1 need source rows py0-4 .. py1+3
-  int qn = 0;                  // wavefront-uniform queue length
   const int lm = ls > 0 ? lane - 1 : lane, lp = ls < lps - 1 ? lane + 1 : lane;
   // pixel K of the lane is screened when it lies in the sub-strip or its one-pixel halo and in the detection window
   bool okv[4];
@@ -277,59 +275,65 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
     const int r = min(py0l - 4 + j, last_row);  // rows past the plane belong to a sub-strip below the level: never used
     return *reinterpret_cast<const uint32_t*>(src + (int64_t)r * g.pitch + Xc);
   };
-  // address part (this wavefront's ring + the lane's first pixel - 3 rows - 3 columns; the row part added per row makes it >= 0) + xl part
-  const uint32_t lane_entry = (uint32_t)(wv * FW_DWORDS * 4 + lane * 4 - 3 * FR_PITCH * 4 - 3) + ((uint32_t)(lane * 4) << 15);
+  // queue entry of the lane's pixel K in row u of a block = ent_blk + u * kEntRow + K * kEntPix:
+  //   address part: this wavefront's ring + the window's first slot (row j - 6) + the lane's pixel K - 3 columns; xl part; row part
+  constexpr uint32_t kEntRow = (uint32_t)(FR_PITCH * 4) + (1u << 23), kEntPix = (1u << 15) + 1u;
+  const uint32_t lane_entry = (uint32_t)(wv * FW_DWORDS * 4 + lane * 4 - 3) + ((uint32_t)(lane * 4) << 15);
+  const uint32_t q0 = (uint32_t)((wv * FW_DWORDS + FW_RING_DW) * 4);  // byte address of the queue in the workgroup's LDS block
+  uint32_t qa = q0;                                                    // ... of its first free entry (wavefront-uniform)
+  uint8_t* lds8 = reinterpret_cast<uint8_t*>(&s_mem[0][0]);
   uint32_t Cr[7], nxt[7];
 #pragma unroll
   for (int u = 0; u < 7; ++u) nxt[u] = load_row(u);  // unconditional (the row index is clamped into the plane): with a branch around a load
                                                      // the compiler cannot count the loads in flight and waits for all of them
-  for (int base = 0; base < nsrc; base += 7) {
+  int pbo = 0;  // 7 * parity of the block
+  for (int base = 0; base < nsrc; base += 7, pbo ^= 7) {
     uint32_t cur[7];
 #pragma unroll
     for (int u = 0; u < 7; ++u) cur[u] = nxt[u];
 #pragma unroll
     for (int u = 0; u < 7; ++u) nxt[u] = load_row(base + 7 + u);
+    // everything of the block that depends on its parity or its first row, once: the rows below only add compile-time offsets
+    uint32_t* wr = rows32 + pbo * FR_PITCH + lane;          // slot 7 pb + u
+    uint32_t* wr2 = rows32 + (14 - pbo) * FR_PITCH + lane;  // its mirror 14 + u in an even block (an odd block stores the same slot twice)
+    const uint32_t* wl = rows32 + (8 - pbo) * FR_PITCH + lm;  // row j - 6 of u = 0 in the left / right neighbour's column
+    const uint32_t* wp = rows32 + (8 - pbo) * FR_PITCH + lp;
+    const uint32_t rowbits_blk = base ? rowbits >> (base - 6) : rowbits << 6;  // bit u: the lane screens the centre row of loop row base + u
+    const uint32_t ent_blk = lane_entry + ((uint32_t)((8 - pbo) * FR_PITCH * 4) + ((uint32_t)(base - 6) << 23));
 #pragma unroll
     for (int u = 0; u < 7; ++u) {
       const int j = base + u;
       if (j < nsrc) {
         const uint32_t C = cur[u];
         Cr[u] = C;
-        const int slot = j & (FR_ROWS - 1);  // ring slots follow the loop index: the same for every sub-strip
-        rows32[slot * FR_PITCH + lane] = C;
-        if (slot < FR_MIRROR) rows32[(slot + FR_ROWS) * FR_PITCH + lane] = C;
+        wr[u * FR_PITCH] = C;
+        wr2[u * FR_PITCH] = C;
         if (j >= 6) {
-          const int jc = j - 3;           // loop index of the centre row; rows jc-3 .. jc+3 sit in register slots (u+1)%7 .. u
-          const int rrp = j - 6;          // centre row relative to the sub-strip: 0 = halo row above, nrows + 1 = halo row below
-          const uint32_t rowm = (uint32_t)__builtin_amdgcn_sbfe((int)rowbits, (uint32_t)rrp, 1u);  // 0 / ~0: this lane screens this row
+          // centre row jc = j - 3, relative to the sub-strip rrp = j - 6 (0 = halo row above, nrows + 1 = halo row below); rows jc-3 .. jc+3
+          // sit in register slots (u+1)%7 .. u and in the ring slots the window pointers start at
+          const uint32_t rowm = (uint32_t)__builtin_amdgcn_sbfe((int)rowbits_blk, (uint32_t)u, 1u);  // 0 / ~0: this lane screens this row
           {
             const int sm3 = (u + 1) % 7, sm2 = (u + 2) % 7, s0 = (u + 4) % 7, sp2 = (u + 6) % 7, sp3 = u;
             const uint32_t Cc = Cr[s0], Cu = Cr[sm3], Cd = Cr[sp3], C2 = Cr[sp2], Cm2 = Cr[sm2];
-            // neighbour dwords of the centre row and of the rows two above / below it from the LDS row ring (written by this wavefront, in
-            // order).  With the centre taken from the mirror when it is one of the first three slots, rows jc-3 .. jc+3 are seven
-            // consecutive slots: one address per neighbour lane, the other rows are immediate offsets.
-            const int cslot = (jc & (FR_ROWS - 1)) < 3 ? (jc & (FR_ROWS - 1)) + FR_ROWS : (jc & (FR_ROWS - 1));
-            const uint32_t* rc = rows32 + cslot * FR_PITCH;
-            const uint32_t* r2 = rc + 2 * FR_PITCH;
-            const uint32_t* rm = rc - 2 * FR_PITCH;
-            const uint32_t Lc = rc[lm], Rc = rc[lp], L2 = r2[lm], R2 = r2[lp], Lm2 = rm[lm], Rm2 = rm[lp];
-            const uint32_t row_entry = (uint32_t)(cslot * (FR_PITCH * 4)) | ((uint32_t)rrp << 23);
+            // neighbour dwords of the centre row and of the rows two above / below it from the LDS row ring (written by this wavefront, in order)
+            const uint32_t Lc = wl[(u + 3) * FR_PITCH], Rc = wp[(u + 3) * FR_PITCH], L2 = wl[(u + 5) * FR_PITCH], R2 = wp[(u + 5) * FR_PITCH];
+            const uint32_t Lm2 = wl[(u + 1) * FR_PITCH], Rm2 = wp[(u + 1) * FR_PITCH];
             // ---- screen the lane's 4 pixels with four opposite ring pairs, queue the ones that pass ----
-            // Packed 16-bit arithmetic, two pixels per instruction: the even bytes of a pixel dword sit in the two 16-bit
-            // halves as they are (x & 0x00ff00ff), the odd bytes scaled by 256 (x & 0xff00ff00); all compares are unsigned.
-            // bright <=> min over the pairs of max(pair) > v + t ; dark <=> max over the pairs of min(pair) < v - t
-            // (saturating add / sub keep v +- t in range; a saturated bound can never be crossed by a pixel value).
             const uint32_t P4 = __builtin_amdgcn_alignbyte(Rc, Cc, 3), P12 = __builtin_amdgcn_alignbyte(Cc, Lc, 1);
             const uint32_t P2 = __builtin_amdgcn_alignbyte(R2, C2, 2), P14 = __builtin_amdgcn_alignbyte(C2, L2, 2);
             const uint32_t P6 = __builtin_amdgcn_alignbyte(Rm2, Cm2, 2), P10 = __builtin_amdgcn_alignbyte(Cm2, Lm2, 2);
 #if UVO_FAST_SCREEN_SWAR
             const Screen4 sc = screen4_centre(Cc, thv, m7, h7);
-            const uint32_t q0 = seven(Cd, m7), q8 = seven(Cu, m7), q4 = seven(P4, m7), q12 = seven(P12, m7);
+            const uint32_t q0_ = seven(Cd, m7), q8 = seven(Cu, m7), q4 = seven(P4, m7), q12 = seven(P12, m7);
             const uint32_t q2 = seven(P2, m7), q10 = seven(P10, m7), q6 = seven(P6, m7), q14 = seven(P14, m7);
-            const uint32_t bright = ((q0 + sc.cb) | (q8 + sc.cb)) & ((q4 + sc.cb) | (q12 + sc.cb)) & ((q2 + sc.cb) | (q10 + sc.cb)) & ((q6 + sc.cb) | (q14 + sc.cb));
-            const uint32_t dark = ((sc.cd - q0) | (sc.cd - q8)) & ((sc.cd - q4) | (sc.cd - q12)) & ((sc.cd - q2) | (sc.cd - q10)) & ((sc.cd - q6) | (sc.cd - q14));
+            const uint32_t bright = ((q0_ + sc.cb) | (q8 + sc.cb)) & ((q4 + sc.cb) | (q12 + sc.cb)) & ((q2 + sc.cb) | (q10 + sc.cb)) & ((q6 + sc.cb) | (q14 + sc.cb));
+            const uint32_t dark = ((sc.cd - q0_) | (sc.cd - q8)) & ((sc.cd - q4) | (sc.cd - q12)) & ((sc.cd - q2) | (sc.cd - q10)) & ((sc.cd - q6) | (sc.cd - q14));
             const uint32_t rem = (bright | dark) & rowm, rom = rem;  // bit 7 of byte K: pixel K passes
 #else
+            // Packed 16-bit arithmetic, two pixels per instruction: the even bytes of a pixel dword sit in the two 16-bit
+            // halves as they are (x & 0x00ff00ff), the odd bytes scaled by 256 (x & 0xff00ff00); all compares are unsigned.
+            // bright <=> min over the pairs of max(pair) > v + t ; dark <=> max over the pairs of min(pair) < v - t
+            // (saturating add / sub keep v +- t in range; a saturated bound can never be crossed by a pixel value).
             const uint32_t re = screen2(Cc & kEven, Cd & kEven, Cu & kEven, P4 & kEven, P12 & kEven, P2 & kEven, P10 & kEven, P6 & kEven,
                                         P14 & kEven, t_even);
             // odd pixels: unmasked words.  The even byte below the odd one only acts as a tie-breaker between equal odd bytes, which
@@ -337,42 +341,42 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
             const uint32_t ro = screen2(Cc, Cd, Cu, P4, P12, P2, P10, P6, P14, t_odd);
             const uint32_t rem = re & rowm, rom = ro & rowm;
 #endif
-#define UVO_FAST_PUSH(K, COND)                                                                                    \
-  {                                                                                                               \
-    const bool pass = (COND);                                                                                     \
-    const uint64_t m = ballot64(pass);                                                                            \
-    if (m) {                                                                                                      \
-      if (pass)                                                                                                   \
-        q[qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = \
-            lane_entry + (row_entry + (uint32_t)K * ((1u << 15) + 1u));                                           \
-      qn += __popcll(m);                                                                                          \
-    }                                                                                                             \
+            // one compaction per pixel column: the lanes that pass store their entry behind the queue's end, which moves on by their number
+            // (a scalar byte address: one population count and one shift-add per push)
+#define UVO_FAST_PUSH(K, COND)                                                                                                          \
+  {                                                                                                                                     \
+    const bool pass = (COND);                                                                                                           \
+    const uint64_t m = ballot64(pass);                                                                                                  \
+    if (pass)                                                                                                                           \
+      *reinterpret_cast<uint32_t*>(lds8 + (qa + 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)))) = \
+          ent_blk + ((uint32_t)u * kEntRow + (uint32_t)K * kEntPix);                                                                    \
+    qa += 4u * (uint32_t)__popcll(m);                                                                                                   \
   }
             // (the lane's column flags and the row flag are folded into one AND per pixel: mk0..3 select the pixel's part of the word)
             UVO_FAST_PUSH(0, (rem & mk0) != 0u)
             UVO_FAST_PUSH(1, (rom & mk1) != 0u)
-            while (qn >= 64) {  // keeps the queue within FQ_CAP
-              qn -= 64;
-              fast_score_chunk(q, rows8, qn, 64, lane, t_min, list, region, ncorner, nflushed);
+            while (qa >= q0 + 256u) {  // keeps the queue within FQ_CAP
+              qa -= 256u;
+              fast_score_chunk(lds8, qa, 64, lane, t_min, list, region, ncorner, nflushed);
             }
             UVO_FAST_PUSH(2, (rem & mk2) != 0u)
             UVO_FAST_PUSH(3, (rom & mk3) != 0u)
 #undef UVO_FAST_PUSH
           }
           // ---- drain full batches (newest first); the remainder is flushed at the end of every seven-row block, before its rows leave the ring ----
-          while (qn >= 64) {
-            qn -= 64;
-            fast_score_chunk(q, rows8, qn, 64, lane, t_min, list, region, ncorner, nflushed);
+          while (qa >= q0 + 256u) {
+            qa -= 256u;
+            fast_score_chunk(lds8, qa, 64, lane, t_min, list, region, ncorner, nflushed);
           }
-          if (u == 6 && qn > 0) {  // end of a seven-row block: no entry is ever older than six rows (FR_MAXAGE), no bookkeeping of ages
-            fast_score_chunk(q, rows8, 0, qn, lane, t_min, list, region, ncorner, nflushed);
-            qn = 0;
+          if (u == 6 && qa > q0) {  // end of a seven-row block: no entry is ever older than six rows, no bookkeeping of ages
+            fast_score_chunk(lds8, q0, (int)((qa - q0) >> 2), lane, t_min, list, region, ncorner, nflushed);
+            qa = q0;
           }
         }
       }
     }
   }
-  if (qn > 0) fast_score_chunk(q, rows8, 0, qn, lane, t_min, list, region, ncorner, nflushed);
+  if (qa > q0) fast_score_chunk(lds8, q0, (int)((qa - q0) >> 2), lane, t_min, list, region, ncorner, nflushed);
 
   // ---- in-cell 3x3 non-max suppression of the region's corners (cv::FAST with nonmaxSuppression on the cell ROI) ----
   uint8_t* tile = reinterpret_cast<uint8_t*>(rows32);  // [row' = row - py0 + 1][xl], FT_PITCH bytes per row; ring and queue are dead
