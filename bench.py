@@ -324,6 +324,8 @@ def main():
     ap.add_argument("--no-subrecords", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--h2h", action="store_true", help="run the host-to-host sharder leg even with --no-subrecords")
+    ap.add_argument("--matcher-stream", choices=["lane", "own"], default="lane",
+                    help="where the matching of a batch is enqueued: in the extracting lane's stream (default) or in the matcher's own stream behind events")
     ap.add_argument("--fast-mode", choices=["adaptive", "two_pass", "single_pass"], default="adaptive",
                     help="UVO_TUNE_FAST_MODE of the extractor (speed only; the keypoints are the same in every mode)")
     args = ap.parse_args()
@@ -416,13 +418,22 @@ def main():
         ex.extract_batch_device(d_ring[k].data_ptr(), B + 1, W, H, o.kp.data_ptr(), o.desc.data_ptr(), o.n.data_ptr(), cap)
         return o
 
+    # The matching of a batch runs in the stream of the pipeline lane that extracted it (uvo_matcher_attach_extractor); with
+    # --matcher-stream own it runs in the matcher's own stream behind an event, and the lane waits for another event before its next batch
+    # (two hand-offs between queues per batch: the lane idles 0.3 ms around a 0.13 ms kernel, tools/step_trace_summary.py).
+    own_stream = args.matcher_stream == "own"
+
     def step():
         o = extract_only()
-        mt.wait_extractor(ex)
+        if own_stream:
+            mt.wait_extractor(ex)
+        else:
+            mt.attach(ex)
         # pair p = (frame p, frame p + 1), p < B; pair B-1's partner is the halo frame in slot B
         mt.knn2_batch_device(B, o.desc.data_ptr(), o.n.data_ptr(), cap, o.desc.data_ptr() + cap * 32, o.n.data_ptr() + 4, cap,
                              o.idx0.data_ptr(), o.d0.data_ptr(), o.idx1.data_ptr(), o.d1.data_ptr())
-        mt.release_to_extractor(ex)
+        if own_stream:
+            mt.release_to_extractor(ex)
 
     def sync_all():
         ex.synchronize()

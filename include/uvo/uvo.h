@@ -664,6 +664,15 @@ int uvo_haloc_hash(uvo_matcher* m, const float* proj, int num_proj, int proj_str
  */
 int uvo_matcher_wait_extractor(uvo_matcher* m, uvo_extractor* h);
 int uvo_extractor_wait_matcher(uvo_extractor* h, uvo_matcher* m);
+/*
+ * The cheaper form of the same ordering: from this call on the matcher enqueues its work in the stream of the extractor's current
+ * pipeline lane (the lane of the most recent batch call), directly behind that batch's kernels and in front of whatever the lane
+ * runs next -- no events, no hand-off between queues (each costs tens of microseconds; a lane of the batch-256 pipeline idled
+ * 0.3 ms per batch on the two hand-offs around uvo_hamming_knn2_batch_device).  Call it after every uvo_extract_batch_device() whose
+ * results the matcher reads next (the lane alternates).  h = NULL: back to the matcher's own stream.  While attached, calls that
+ * wait for the matcher's stream (every host-buffer entry point) wait for that lane; the extractor must outlive the attachment.
+ */
+int uvo_matcher_attach_extractor(uvo_matcher* m, uvo_extractor* h);
 /* per-kernel timing of the matcher, same contract as uvo_extractor_profile / uvo_extractor_kernel_times */
 int uvo_matcher_profile(uvo_matcher* m, int enable);
 int uvo_matcher_kernel_times(uvo_matcher* m, char* names, int names_cap, float* ms, int32_t* launches, int cap, int* n);

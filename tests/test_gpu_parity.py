@@ -353,8 +353,10 @@ def test_search_by_projection(uvo, oracle, synth):
     m.close()
 
 
-def test_hbm_resident_pipeline_depth2(uvo, oracle, synth):
-    """uvo_extract_batch_device with two alternating scratch sets / streams feeding the batched HBM-resident matcher."""
+@pytest.mark.parametrize("matcher_stream", ["own", "lane"])
+def test_hbm_resident_pipeline_depth2(uvo, oracle, synth, matcher_stream):
+    """uvo_extract_batch_device with two alternating scratch sets / streams feeding the batched HBM-resident matcher -- on its own stream
+    behind events, or attached to the extracting lane's stream; a host-buffer matcher call while attached waits for that lane."""
     import torch
     B, W, H = 4, 640, 512
     batches = [synth.make_batch(B, W, H, seed0=3000 + 10 * k) for k in range(3)]
@@ -377,13 +379,25 @@ def test_hbm_resident_pipeline_depth2(uvo, oracle, synth):
     torch.cuda.synchronize()
     for d_img, kp, de, n, i0, i1, d0, d1 in outs:   # three calls back to back, no host sync in between
         ex.extract_batch_device(d_img.data_ptr(), B, W, H, kp.data_ptr(), de.data_ptr(), n.data_ptr(), cap)
-        mt.wait_extractor(ex)
+        if matcher_stream == "own":
+            mt.wait_extractor(ex)
+        else:
+            mt.attach(ex)
         # pair p = (frame p, frame p+1) for p < B-1
         mt.knn2_batch_device(B - 1, de.data_ptr(), n.data_ptr(), cap, de.data_ptr() + cap * 32, n.data_ptr() + 4, cap, i0.data_ptr(),
                              d0.data_ptr(), i1.data_ptr(), d1.data_ptr())
-        mt.release_to_extractor(ex)
+        if matcher_stream == "own":
+            mt.release_to_extractor(ex)
+    if matcher_stream == "lane":   # a host-buffer call in the attached state: enqueued in, and waiting for, the lane's stream
+        rng = np.random.default_rng(5)
+        a, b = rng.integers(0, 256, (70, 32), dtype=np.uint8), rng.integers(0, 256, (90, 32), dtype=np.uint8)
+        got = mt.knn2(a, b)
+        want = oracle.knn2(a, b)
+        np.testing.assert_array_equal(got[0], want[0])
+        np.testing.assert_array_equal(got[1].astype(np.int32), want[1])
     ex.synchronize()
     mt.synchronize()
+    mt.attach(None)
     oe = oracle.extractor(1000, 1.2, 8, 20)
     for k, (d_img, kp, de, n, i0, i1, d0, d1) in enumerate(outs):
         n_h = n.cpu().numpy()

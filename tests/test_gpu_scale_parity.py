@@ -23,7 +23,7 @@ def _same(kp_g, de_g, kp_o, de_o, what):
     assert (de_g == de_o).all(), "%s: descriptors differ" % what
 
 
-def _run_bench_path(uvo, frames, nfeat, fast_th, passes=3, tune=None):
+def _run_bench_path(uvo, frames, nfeat, fast_th, passes=3, tune=None, matcher_stream="lane"):
     """bench.py's step: extract_batch_device on alternating lanes + knn-2 of (frame i, frame i+1), `passes` steps back to back
     without a host synchronisation; returns the outputs of the LAST step on each lane (so both lanes' scratch sets are checked)."""
     import torch
@@ -52,12 +52,17 @@ def _run_bench_path(uvo, frames, nfeat, fast_th, passes=3, tune=None):
     for k in range(passes):
         o = outs[k % 2]
         ex.extract_batch_device(d_img.data_ptr(), B, W, H, o.kp.data_ptr(), o.de.data_ptr(), o.n.data_ptr(), cap)
-        mt.wait_extractor(ex)
+        if matcher_stream == "lane":   # bench.py's default: the matching queues up behind the batch in the lane's own stream
+            mt.attach(ex)
+        else:                          # the matcher's own stream, ordered by events
+            mt.wait_extractor(ex)
         mt.knn2_batch_device(B - 1, o.de.data_ptr(), o.n.data_ptr(), cap, o.de.data_ptr() + cap * 32, o.n.data_ptr() + 4, cap,
                              o.i0.data_ptr(), o.d0.data_ptr(), o.i1.data_ptr(), o.d1.data_ptr())
-        mt.release_to_extractor(ex)
+        if matcher_stream != "lane":
+            mt.release_to_extractor(ex)
     ex.synchronize()
     mt.synchronize()
+    mt.attach(None)
     res = []
     for o in outs:
         res.append(dict(n=o.n.cpu().numpy(), kp=o.kp.cpu().numpy(), de=o.de.cpu().numpy(), i0=o.i0.cpu().numpy(), i1=o.i1.cpu().numpy(),
@@ -87,11 +92,12 @@ def _check_against_oracle(uvo, oracle, frames, nfeat, fast_th, res, what, min_kp
     return ref
 
 
-@pytest.mark.parametrize("batch", [64, 256])
-def test_configs2_throughput_path_every_frame_vs_oracle(uvo, oracle, synth, batch):
-    """BASELINE.json configs[2] as bench.py runs it (batch 256: 2048 quad-tree problems -> k_octree<256>, four per CU)."""
+@pytest.mark.parametrize("batch,matcher_stream", [(64, "lane"), (64, "own"), (256, "lane")])
+def test_configs2_throughput_path_every_frame_vs_oracle(uvo, oracle, synth, batch, matcher_stream):
+    """BASELINE.json configs[2] as bench.py runs it (batch 256: 2048 quad-tree problems -> k_octree<256>, four per CU); the matching in
+    the extracting lane's stream (uvo_matcher_attach_extractor, bench.py's default) and in the matcher's own stream behind events."""
     frames = synth.make_sequence(0, batch, 640, 512)
-    res = _run_bench_path(uvo, frames, 1000, 20)
+    res = _run_bench_path(uvo, frames, 1000, 20, matcher_stream=matcher_stream)
     _check_against_oracle(uvo, oracle, frames, 1000, 20, res, "configs[2] batch %d" % batch, 1000)
 
 

@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_profile_only", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
-    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_search_for_triangulation_batch", "uvo_search_for_triangulation_next", "uvo_fuse", "uvo_fuse_batch", "uvo_project_points", "uvo_search_points_in_frustum", "uvo_sim3_decompose", "uvo_sim3_relative", "uvo_project_sim3", "uvo_search_by_projection_sim3", "uvo_search_by_sim3", "uvo_haloc_hash", "uvo_klt_create", "uvo_klt_destroy", "uvo_klt_build_pyramid", "uvo_klt_build_pyramid_from_extractor", "uvo_klt_read_level", "uvo_klt_track", "uvo_undistort_points", "uvo_klt_track_undistorted", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_profile",
+    "uvo_search_by_projection_kf", "uvo_search_by_bow", "uvo_search_for_triangulation", "uvo_search_for_triangulation_batch", "uvo_search_for_triangulation_next", "uvo_fuse", "uvo_fuse_batch", "uvo_project_points", "uvo_search_points_in_frustum", "uvo_sim3_decompose", "uvo_sim3_relative", "uvo_project_sim3", "uvo_search_by_projection_sim3", "uvo_search_by_sim3", "uvo_haloc_hash", "uvo_klt_create", "uvo_klt_destroy", "uvo_klt_build_pyramid", "uvo_klt_build_pyramid_from_extractor", "uvo_klt_read_level", "uvo_klt_track", "uvo_undistort_points", "uvo_klt_track_undistorted", "uvo_vocabulary_create", "uvo_vocabulary_destroy", "uvo_bow_transform", "uvo_matcher_wait_extractor", "uvo_extractor_wait_matcher", "uvo_matcher_attach_extractor", "uvo_matcher_profile",
     "uvo_matcher_kernel_times", "uvo_last_error", "uvo_device_info",
 ]
 
@@ -224,6 +224,7 @@ def _load():
     lib.uvo_search_by_sim3.argtypes = [vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci, cf, vp, vp]
     lib.uvo_matcher_wait_extractor.argtypes = [vp, vp]
     lib.uvo_extractor_wait_matcher.argtypes = [vp, vp]
+    lib.uvo_matcher_attach_extractor.argtypes = [vp, vp]
     lib.uvo_matcher_profile.argtypes = [vp, ci]
     lib.uvo_matcher_kernel_times.argtypes = [vp, ctypes.c_char_p, ci, vp, vp, ci, vp]
     return lib
@@ -661,6 +662,12 @@ class ORBmatcher:
         rc = lib.uvo_matcher_wait_extractor(self._h, ex._h)
         if rc:
             raise UvoError(rc, "uvo_matcher_wait_extractor")
+
+    def attach(self, ex):
+        """Enqueue the matcher's work in the stream of the extractor's current lane from now on (None: back to its own stream)."""
+        rc = lib.uvo_matcher_attach_extractor(self._h, ex._h if ex is not None else None)
+        if rc:
+            raise UvoError(rc, "uvo_matcher_attach_extractor")
 
     def release_to_extractor(self, ex):
         rc = lib.uvo_extractor_wait_matcher(ex._h, self._h)

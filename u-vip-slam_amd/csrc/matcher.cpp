@@ -42,10 +42,11 @@ int uvo_matcher_create(const uvo_matcher_cfg* cfg, uvo_matcher** out) {
   uvo_matcher* m = new uvo_matcher();
   m->cfg = *cfg;
   m->device = cfg->device;
-  if (hipSetDevice(m->device) != hipSuccess || hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(m->device) != hipSuccess || hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete m;
     return matcher_fail(UVO_E_HIP, "stream creation failed");
   }
+  m->stream = m->own_stream;
   const size_t B = cfg->max_batch, Q = cfg->max_query, T = cfg->max_train, MP = std::max(cfg->max_map_points, 1);
   int rc;
 #define A(call)                  \
@@ -90,6 +91,7 @@ void uvo_matcher_destroy(uvo_matcher* m) {
   if (!m) return;
   hipSetDevice(m->device);
   if (m->stream) hipStreamSynchronize(m->stream);
+  if (m->own_stream && m->own_stream != m->stream) hipStreamSynchronize(m->own_stream);
   void* ptrs[] = {m->d_q,      m->d_t,     m->d_mask,       m->d_idx0,       m->d_idx1,       m->d_d0,    m->d_d1,         m->d_dist,  m->d_kp,
                   m->d_px,     m->d_py,    m->d_vc,         m->d_scale,      m->d_level,      m->d_assigned, m->d_cell_start, m->d_cell_items,
                   m->d_cell_of_kp, m->d_cand_cnt, m->d_cand_start, m->d_owner, m->d_owner_next, m->d_choice, m->d_nm, m->d_inview, m->d_mpdesc,
@@ -103,7 +105,7 @@ void uvo_matcher_destroy(uvo_matcher* m) {
   if (m->h_arena) (void)hipHostFree(m->h_arena);
   m->prof.clear();
   if (m->ev) (void)hipEventDestroy(m->ev);
-  if (m->stream) hipStreamDestroy(m->stream);
+  if (m->own_stream) hipStreamDestroy(m->own_stream);
   delete m;
 }
 
@@ -431,6 +433,22 @@ int uvo_extractor_wait_matcher(uvo_extractor* h, uvo_matcher* m) {
   UVO_HIP_CHECK(hipSetDevice(m->device));
   UVO_HIP_CHECK(hipEventRecord(m->ev, m->stream));
   UVO_HIP_CHECK(hipStreamWaitEvent(uvo_extractor_stream_internal(h), m->ev, 0));
+  return UVO_OK;
+}
+
+// Event hand-offs between two queues cost tens of microseconds each on this runtime (tools/step_trace_summary.py: 0.32 ms between a
+// lane's k_describe and its next k_pad_level0 with the matcher on its own stream -- two hand-offs around a 0.13 ms kernel); in the
+// extractor lane's own stream the matcher's kernels simply queue up behind the batch that feeds them.
+int uvo_matcher_attach_extractor(uvo_matcher* m, uvo_extractor* h) {
+  if (!m) return matcher_fail(UVO_E_BADARG, "null handle");
+  UVO_HIP_CHECK(hipSetDevice(m->device));
+  if (!h) {
+    m->stream = m->own_stream;
+    return UVO_OK;
+  }
+  if (uvo_extractor_device_internal(h) != m->device) return matcher_fail(UVO_E_BADARG, "handles live on different devices");
+  if (m->prof.on) UVO_HIP_CHECK(hipStreamSynchronize(m->stream));  // the profiler's open events belong to the stream they were recorded on
+  m->stream = uvo_extractor_stream_internal(h);
   return UVO_OK;
 }
 

@@ -14,7 +14,8 @@ struct DevBuf {
 struct uvo_matcher {
   uvo_matcher_cfg cfg;
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // where the handle's work is enqueued: its own stream, or an extractor lane's (uvo_matcher_attach_extractor)
+  hipStream_t own_stream = nullptr;
   // knn2 staging
   uint8_t *d_q = nullptr, *d_t = nullptr, *d_mask = nullptr;
   size_t mask_bytes = 0;
