@@ -201,6 +201,36 @@ def test_two_pass_fast_at_other_geometries(uvo, oracle, synth, shape, nfeat, th,
         ex.close()
 
 
+@pytest.mark.parametrize("th", [1, 2, 4, 6, 8, 9, 13, 21, 60, 127, 128, 200, 254, 255])
+def test_fast_threshold_sweep_with_extreme_pixels(uvo, oracle, synth, th):
+    """The streaming screen of k_fast_score compares pixels at seven bits ((t + 1) >> 1 against p >> 1 - v >> 1, bit 7 of every byte as
+    the carry stop): every parity of t, the thresholds where v + t or v - t leave the byte range, and frames that hold the extreme
+    values next to each other (0 / 1 / 254 / 255 blobs on dark, bright and mid-grey ground, saturated noise) -- candidates of every level
+    and the final features against the oracle, in both FAST forms."""
+    rng = np.random.default_rng(1000 + th)
+    H, W = 240, 320
+    base = synth.make_frame(555, W, H, n_shapes=120)
+    ext = np.choose(rng.integers(0, 3, (H, W)), [np.full((H, W), 3, np.uint8), np.full((H, W), 128, np.uint8), np.full((H, W), 252, np.uint8)])
+    ext = (ext.astype(np.int16) + rng.integers(-3, 4, (H, W))).clip(0, 255).astype(np.uint8)
+    for _ in range(600):
+        y, x = int(rng.integers(20, H - 20)), int(rng.integers(20, W - 20))
+        ext[y:y + int(rng.integers(1, 5)), x:x + int(rng.integers(1, 5))] = int(rng.choice([0, 1, 2, 127, 128, 129, 253, 254, 255]))
+    sat = rng.choice(np.array([0, 255], np.uint8), (H, W), p=[0.7, 0.3])
+    oe = oracle.extractor(500, 1.2, 4, th)
+    for mode in (uvo.UVO_FAST_MODE_TWO_PASS, uvo.UVO_FAST_MODE_SINGLE_PASS):
+        ex = uvo.ORBextractor(500, 1.2, 4, 0, th, max_width=W, max_height=H)
+        ex.tune(uvo.UVO_TUNE_FAST_MODE, mode)
+        for name, img in (("textured", base), ("extremes", ext), ("saturated", sat)):
+            kp_g, de_g = ex(img)
+            kp_o, de_o = oe(img)
+            for l in range(4):
+                c_g, c_o = ex.read_candidates(l), oe.level_candidates(l)
+                assert sorted(map(tuple, c_g.tolist())) == sorted(zip(c_o["x"].astype(int).tolist(), c_o["y"].astype(int).tolist(), c_o["response"].astype(int).tolist())), \
+                    "fastTh %d mode %d %s level %d" % (th, mode, name, l)
+            _assert_same_features(kp_g, de_g, kp_o, de_o, "fastTh %d mode %d %s" % (th, mode, name))
+        ex.close()
+
+
 def test_blur_planes_at_the_saturation_edge(uvo, oracle):
     """k_gauss7's column pass runs on the fp32 pipe: exact while the result is not saturated, i.e. the images to try are the ones whose
     sums sit at and across 2^24 -- constant 253 / 254 / 255 (taps sum to 257 per pass, so 254 already blurs to 255), bright noise,
