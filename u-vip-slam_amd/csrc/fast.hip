@@ -282,6 +282,18 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   const uint32_t q0 = (uint32_t)((wv * FW_DWORDS + FW_RING_DW) * 4);  // byte address of the queue in the workgroup's LDS block
   uint32_t qa = q0;                                                    // ... of its first free entry (wavefront-uniform)
   uint8_t* lds8 = reinterpret_cast<uint8_t*>(&s_mem[0][0]);
+  uint32_t qold = 0;  // bytes at the bottom of the queue that were already there at the last checkpoint
+  // the 64 oldest entries are scored, the (< 128) younger ones move down to the bottom of the queue
+  auto drain_oldest = [&]() {
+    fast_score_chunk(lds8, q0, 64, lane, t_min, list, region, ncorner, nflushed);
+    uint32_t* qq = reinterpret_cast<uint32_t*>(lds8 + q0);
+    const uint32_t rem = qa - q0 - 256u, l4 = (uint32_t)lane * 4u;
+    const uint32_t e0 = l4 < rem ? qq[64 + lane] : 0u, e1 = l4 + 256u < rem ? qq[128 + lane] : 0u;
+    if (l4 < rem) qq[lane] = e0;
+    if (l4 + 256u < rem) qq[64 + lane] = e1;
+    qa -= 256u;
+    qold = qold > 256u ? qold - 256u : 0u;
+  };
   uint32_t Cr[7], nxt[7];
 #pragma unroll
   for (int u = 0; u < 7; ++u) nxt[u] = load_row(u);  // unconditional (the row index is clamped into the plane): with a branch around a load
@@ -355,22 +367,23 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
             // (the lane's column flags and the row flag are folded into one AND per pixel: mk0..3 select the pixel's part of the word)
             UVO_FAST_PUSH(0, (rem & mk0) != 0u)
             UVO_FAST_PUSH(1, (rom & mk1) != 0u)
-            while (qa >= q0 + 256u) {  // keeps the queue within FQ_CAP
-              qa -= 256u;
-              fast_score_chunk(lds8, qa, 64, lane, t_min, list, region, ncorner, nflushed);
-            }
+            while (qa >= q0 + 256u) drain_oldest();  // keeps the queue within FQ_CAP
             UVO_FAST_PUSH(2, (rem & mk2) != 0u)
             UVO_FAST_PUSH(3, (rom & mk3) != 0u)
 #undef UVO_FAST_PUSH
           }
-          // ---- drain full batches (newest first); the remainder is flushed at the end of every seven-row block, before its rows leave the ring ----
-          while (qa >= q0 + 256u) {
-            qa -= 256u;
-            fast_score_chunk(lds8, qa, 64, lane, t_min, list, region, ncorner, nflushed);
-          }
-          if (u == 6 && qa > q0) {  // end of a seven-row block: no entry is ever older than six rows, no bookkeeping of ages
-            fast_score_chunk(lds8, q0, (int)((qa - q0) >> 2), lane, t_min, list, region, ncorner, nflushed);
-            qa = q0;
+          // ---- drain full batches, oldest first.  What stays behind is younger than what left, and only what has stayed behind for two
+          // checkpoints in a row (after rows 2 and 6 of a block: 7 rows apart) is scored as an incomplete batch.  A queued pixel's oldest
+          // ring row (j - 6) is overwritten 14 rows after it was written, i.e. 8 rows after the pixel was queued; it waits <= 6.
+          // (Three generations of checkpoints two rows apart -- an incomplete batch only after 4 - 6 quiet rows -- issue the same number of
+          // instructions: on these frames the incomplete batches that are left belong to sparse strips and pyramid levels.) ----
+          while (qa >= q0 + 256u) drain_oldest();
+          if (u == 2 || u == 6) {
+            if (qold) {
+              fast_score_chunk(lds8, q0, (int)((qa - q0) >> 2), lane, t_min, list, region, ncorner, nflushed);
+              qa = q0;
+            }
+            qold = qa - q0;
           }
         }
       }
