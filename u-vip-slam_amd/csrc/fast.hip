@@ -49,9 +49,14 @@ __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_b
 #ifndef UVO_FAST_WAVES
 #define UVO_FAST_WAVES 4       // wavefronts (regions) per workgroup
 #endif
+#ifndef UVO_FAST_MIN_BLOCKS
 #define UVO_FAST_MIN_BLOCKS 5  // workgroups per CU the register allocation is held to; LDS: 31 KB per workgroup -> five fit (at
                                // exactly 32 KB only four do: measured, 0.87 instead of 0.76 ms per 256-frame launch)
-constexpr int FL_CAP = 320;       // corner records a wavefront keeps in LDS (a 248 x 24 region of these frames holds ~250); a busier region
+#endif
+#ifndef UVO_FAST_LIST_CAP
+#define UVO_FAST_LIST_CAP 320
+#endif
+constexpr int FL_CAP = UVO_FAST_LIST_CAP;       // corner records a wavefront keeps in LDS (a 248 x 24 region of these frames holds ~250); a busier region
                                   // flushes its list to the region's slice of the HBM list array and carries on
 
 // max over the 16 arcs of 9 contiguous ring pixels of min(d).  A 9-window always straddles the two 8-pixel halves of the

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
   const int vbx = vb % (int)gridDim.x, f = vb / (int)gridDim.x;  // an XCD walks whole frames, item after item
   int item = vbx * 4 + wave_in_block();
   const int lane = threadIdx.x & 63;
-  __shared__ __attribute__((aligned(16))) uint32_t s_tile[4][GS_TILES * 32];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tile[4][GS_TILES * 32 + 96];  // the tiles + a dword per lane (and row phase) for the lanes that collect nothing
   int level = 0;
   StripPlan plan;
   for (;; ++level) {
@@ -90,7 +90,9 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
   const int ts_shift = nsub == 1 ? 4 : (nsub == 2 ? 3 : 2), TS = 1 << ts_shift;                 // LDS tile slots per sub-strip (16 / nsub >= nts)
   const bool via_lds = lane_out && (X >> 4) >= t_first && (X >> 4) < t_first + nts;
   uint32_t* stile = s_tile[wave_in_block()];
-  const int lds_slot = ((sub * TS + ((X >> 4) - t_first)) << 5) + ((X & 15) >> 2);  // + (py & 7) * 4: dword of the lane's pixels in the tile
+  // + (py & 7) * 4: dword of the lane's pixels in the tile.  Lanes that collect nothing write their own dword behind the tiles -- the
+  // LDS write of a row is then unconditional (no exec mask to set up and restore: scalar instructions are not free)
+  const int lds_slot = via_lds ? ((sub * TS + ((X >> 4) - t_first)) << 5) + ((X & 15) >> 2) : GS_TILES * 32 + lane;
   // The write-out of a group: task t = lane + 64 it (it = 0, 1) is row t & 7 of tile slot t >> 3; everything about a task that does not
   // depend on the group is worked out here, once.
   // (row addresses: a sub-strip's rows lie s * rows_per_seg below sub-strip 0's, a whole number of tile rows, so every address is
@@ -126,6 +128,10 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
 #pragma unroll
   for (int k = 0; k < 4; ++k) inmask |= (X + k >= kPad && X + k < g.w + kPad) ? 0xffu << (8 * k) : 0u;
   const int nsrc = min(py0 + rows_per_seg, g.h + 20) - py0 + 6;  // source rows py0-3 .. py1+2 of sub-strip 0 (the longest)
+  // per lane, in loop rows: output row py = py0l + j - 6 lies inside the image rows for j in [j_in0, j_in0 + n_in), and the lane stores
+  // it directly (an output lane outside the collected tiles) for j < j_edge1
+  const uint32_t j_in0 = (uint32_t)(kPad - py0l + 6), n_in = (uint32_t)g.h;
+  const uint32_t j_edge1 = (lane_out && !via_lds) ? (uint32_t)max(py1l - py0l + 6, 0) : 0u;
 
   const uint32_t T1 = (uint32_t)taps.x | ((uint32_t)taps.y << 8) | ((uint32_t)taps.z << 16) | ((uint32_t)taps.w << 24);
   const uint32_t T2 = (uint32_t)taps.z | ((uint32_t)taps.y << 8) | ((uint32_t)taps.x << 16);
@@ -146,6 +152,7 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
   // byte offset of sub-strip 0's current output row inside its tile column: tile row * tile_row_bytes + (row % 8) * 16, advanced row by
   // row (one scalar add instead of a 64-bit multiply per row)
   int64_t rowb = (int64_t)(py0 >> 3) * tile_row_bytes + ((py0 & 7) << 4);
+  int phase = (py0 - 6) & 7;  // (row of sub-strip 0) & 7 of loop row j = 0, advanced with it
   uint32_t cur[7], nxt[7];
 #pragma unroll
   for (int u = 0; u < 7; ++u) cur[u] = load_row(u);  // unconditional (the row index is clamped into the plane): with a branch around a load
@@ -162,8 +169,10 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
         const uint32_t R = (uint32_t)__builtin_amdgcn_ds_bpermute(lane_down, (int)C);  // whole strip (__shfl_up / _down recompute them per call)
         gauss_row_pass(L, C, R, T1, T2, hring[u]);
         cring[u] = C;
+        const int phase_now = phase;
+        phase = (phase + 1) & 7;
         if (j >= 6) {
-          const int py = py0l + j - 6;  // output row; its 7 source rows sit in ring slots (u+1)%7 .. (u+7)%7
+          // output row py = py0l + j - 6; its 7 source rows sit in ring slots (u+1)%7 .. (u+7)%7
           const float* r0 = hring[(u + 1) % 7];
           const float* r1 = hring[(u + 2) % 7];
           const float* r2 = hring[(u + 3) % 7];
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
           const float* r5 = hring[(u + 6) % 7];
           const float* r6 = hring[u];
           const uint32_t centre = cring[(u + 4) % 7];
-          const bool row_in = py >= kPad && py < g.h + kPad;
+          const bool row_in = (uint32_t)j - j_in0 < n_in;
           // column pass: sum / 2^16 + 0.5, every partial sum an exact multiple of 2^-16 below 2^8 (a larger one belongs to a result
           // that saturates anyway); floor, clamp to 255 and the byte insert are the conversion itself
           uint32_t blurred = 0;
@@ -188,13 +197,10 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
           // (y % 8) * 16 + x % 16 (a lane's four pixels never straddle a tile: X is a multiple of 4).  Four lanes fill a tile row,
           // eight consecutive rows of the walk complete the line in L2.
           // (py & 7 is the same for every sub-strip: their first rows differ by multiples of rows_per_seg, a multiple of 8)
-          const int py_u = py0 + j - 6;  // the row of sub-strip 0: wave-uniform
-          if (via_lds)
-            stile[lds_slot + ((py_u & 7) << 2)] = out;
-          else if (lane_out && py < py1l)
-            *reinterpret_cast<uint32_t*>(dst + rowb + lane_goff) = out;
-          if ((py_u & 7) == 7) {
-            flush_tiles(py_u & ~7, 7, rowb - 112);
+          stile[lds_slot + (phase_now << 2)] = out;
+          if ((uint32_t)j < j_edge1) *reinterpret_cast<uint32_t*>(dst + rowb + lane_goff) = out;
+          if (phase_now == 7) {
+            flush_tiles(py0 + j - 6 - 7, 7, rowb - 112);
             rowb += tile_row_bytes - 112;
           } else {
             rowb += 16;
