@@ -4,11 +4,13 @@ TAG=${1:-r02_b}
 O=gpurun_out/$TAG
 mkdir -p $O
 python -m pytest tests -x -q -m gpu > $O/gputests.log 2>&1; tail -3 $O/gputests.log
+# counters first: the bench lines below quote the newest profiles/r*_pmc.json (traffic, instruction counts), which must be this build's
+bash tools/profile_round.sh $TAG 2
+bash tools/profile_round.sh ${TAG}_hd 3
+cp $O/pmc.json profiles/${TAG}_pmc.json; cp gpurun_out/${TAG}_hd/pmc.json profiles/${TAG}_hd_pmc.json; cp $O/fetch_calibration.json profiles/${TAG}_fetch_calibration.json
 python bench.py > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | cut -c1-400
 python bench.py --config 3 > $O/bench_config3.json 2> $O/bench3.err; tail -1 $O/bench_config3.json | cut -c1-300
 python tools/latency.py > $O/latency_batch1.json 2>/dev/null; tail -1 $O/latency_batch1.json | cut -c1-300
-bash tools/profile_round.sh $TAG 2
-bash tools/profile_round.sh ${TAG}_hd 3
 # two ranks on this one GPU (gloo rendezvous, both on device 0): the N>1 code path of bench.py end to end
 UVO_BENCH_DRYRUN_ONE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --steps 10 --warmup 2 > $O/bench_2ranks_one_gpu.json 2> $O/bench2.err; tail -1 $O/bench_2ranks_one_gpu.json | cut -c1-200
 timeout 900 python tools/soak_parity.py 60 7 > $O/soak_parity.log 2>&1; tail -1 $O/soak_parity.log
