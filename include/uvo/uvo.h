@@ -54,7 +54,7 @@ typedef struct uvo_extractor_cfg {
   float scale_factor;
   int32_t nlevels;
   int32_t score_type; /* accepted and ignored, exactly like the live reference path */
-  int32_t fast_th;
+  int32_t fast_th;    /* >= 0; values above 255 act as 255 (cv::FAST clamps its threshold the same way) */
   /* sizing of the device scratch owned by the handle */
   int32_t max_width, max_height; /* largest frame; every pyramid level must keep >= 56 px per side */
   int32_t max_batch;             /* frames per uvo_extract_batch* call */

@@ -201,7 +201,7 @@ def test_two_pass_fast_at_other_geometries(uvo, oracle, synth, shape, nfeat, th,
         ex.close()
 
 
-@pytest.mark.parametrize("th", [1, 2, 4, 6, 8, 9, 13, 21, 60, 127, 128, 200, 254, 255])
+@pytest.mark.parametrize("th", [1, 2, 4, 6, 8, 9, 13, 21, 60, 127, 128, 200, 254, 255, 300])
 def test_fast_threshold_sweep_with_extreme_pixels(uvo, oracle, synth, th):
     """The streaming screen of k_fast_score compares pixels at seven bits ((t + 1) >> 1 against p >> 1 - v >> 1, bit 7 of every byte as
     the carry stop): every parity of t, the thresholds where v + t or v - t leave the byte range, and frames that hold the extreme

@@ -535,6 +535,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   if (cfg->device < 0 || cfg->device >= ndev) return fail(UVO_E_BADARG, "device ordinal out of range");
   uvo_extractor* h = new uvo_extractor();
   h->cfg = *cfg;
+  h->cfg.fast_th = std::min(cfg->fast_th, 255);  // cv::FAST clamps its threshold to 0 .. 255 (no byte differs from another by more)
   h->device = cfg->device;
   build_ctor_tables(h);
   Geom g;
