@@ -207,6 +207,8 @@ int uvo_sharder_run(uvo_sharder* s, const uint8_t* imgs, int n_imgs, int imgs_fi
  * HBM-resident form: every pointer is a device pointer on the handle's GPU and the call only enqueues work
  * on the handle's stream (uvo_extractor_synchronize() waits for it).  Same argument meaning as above.
  * d_n_out[b] may exceed `cap`; only the first `cap` records of a frame are written in that case.
+ * A pipeline lane keeps at most two batches outstanding: the call first waits (on the host) for the lane's last but one batch, so a
+ * caller that enqueues in a loop runs two to four batches ahead of the device and no further.
  */
 int uvo_extract_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, int width, int height, ptrdiff_t stride,
                              ptrdiff_t frame_stride, const uvo_keypoint* d_in_kp, const int32_t* d_n_in, int32_t* d_grid2d, int grid_rows,
