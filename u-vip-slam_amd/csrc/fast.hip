@@ -9,10 +9,11 @@
 // depend on the threshold, so the work is split in two:
 //   k_fast_score  : a streaming pass over each level.  One wavefront owns a (strip, segment) region of 248 x 24 pixels plus a
 //                   one-pixel halo ring and walks down the rows with the last 7 row dwords in a register ring (one aligned
-//                   dword load per lane per row, also kept in a 16-row wavefront-private LDS ring) -- no workgroup
-//                   barriers.  Every pixel is screened with four opposite ring pairs (any 9-arc contains one pixel of
-//                   every opposite pair, of one polarity) in packed 16-bit min/max arithmetic.  The ~20 % that pass are
-//                   compacted into a wavefront-private LDS queue and the exact test runs on full 64-lane batches of it:
+//                   dword load per lane per row, also kept in a wavefront-private LDS ring of 14 + 7 mirrored rows whose every
+//                   address is a per-block pointer + a compile-time offset) -- no workgroup barriers.  Every pixel is screened
+//                   with four opposite ring pairs (any 9-arc contains one pixel of every opposite pair, of one polarity), four
+//                   pixels per instruction in 32-bit arithmetic at seven bits per pixel (Screen4).  The 7 - 12 % that pass are
+//                   compacted into a wavefront-private LDS queue, drained oldest first, and the exact test runs on 64-lane batches:
 //                   max over the 16 arcs of the arc minimum (branch free) is both the corner test (> t_min = min(fastTh, 7))
 //                   and cornerScore + 1.  Corners (3-4 % of the pixels) are appended to a list in the wavefront's LDS -- no
 //                   atomics, the count lives in a scalar register (a region with more corners than the list holds flushes it to
