@@ -64,6 +64,7 @@ def algorithmic_bytes_per_frame(w, h, k):
     return {
         "k_pad_level0": 2 * s[0],                       # not in the survey's model (a design that reads the input in place needs none)
         "k_resize_level": sum(s[:-1]) + sum(s[1:]),     # reads S0..S6, writes S1..S7 (all 7 launches)
+        "k_pyramid_stage": sum(s[:-1]) + sum(s[1:]),    # the same model for the pyramid launches together (k_pyr_stream1 + k_pyr_stream + k_pyramid)
         "k_fast_score": tot,                            # reads every level once
         "k_gauss7": 2 * tot,
         "k_fast_blur": 3 * tot,                         # the fused form: one read serves FAST and the blur, one write
@@ -404,6 +405,15 @@ def main():
     ex.set_pipeline(DEPTH)
     ex.tune(uvo.UVO_TUNE_FAST_MODE, {"adaptive": uvo.UVO_FAST_MODE_ADAPTIVE, "two_pass": uvo.UVO_FAST_MODE_TWO_PASS,
                                      "single_pass": uvo.UVO_FAST_MODE_SINGLE_PASS}[args.fast_mode])
+    if os.environ.get("UVO_BENCH_PYR"):   # experiment knob: pyramid mode: "chain" (default) or the split mode's "tail,bands,run"
+        if os.environ["UVO_BENCH_PYR"] in ("legacy", "chain", "none"):
+            ex.tune(uvo.UVO_TUNE_PYR_MODE, uvo.UVO_PYR_MODE_CHAIN)
+        else:
+            t_, b_, r_ = (int(x) for x in os.environ["UVO_BENCH_PYR"].split(","))
+            ex.tune(uvo.UVO_TUNE_PYR_MODE, uvo.UVO_PYR_MODE_SPLIT)
+            ex.tune(uvo.UVO_TUNE_PYR_TAIL, t_)
+            ex.tune(uvo.UVO_TUNE_PYR_BANDS, b_)
+            ex.tune(uvo.UVO_TUNE_PYR_RUN, r_)
     if os.environ.get("UVO_BENCH_OCT_WIDE_MAX"):   # experiment knob: quad-tree launch shape (uvo_extractor_tune)
         ex.tune(uvo.UVO_TUNE_OCT_WIDE_MAX, int(os.environ["UVO_BENCH_OCT_WIDE_MAX"]))
     torch.cuda.synchronize()
@@ -443,6 +453,8 @@ def main():
     for _ in range(args.warmup + DEPTH):
         step()
     sync_all()
+    if os.environ.get("UVO_BENCH_PYR") == "none":   # development probe: the step without its pyramid launches (planes of the warm-up batches stay)
+        ex.tune(uvo.UVO_TUNE_PYR_MODE, 2)
 
     # Per-kernel durations first, without cross-batch overlap (pipeline depth 1, every launch bracketed by HIP events on the
     # library's stream; 3 untimed steps): they name the dominant kernel.

@@ -243,6 +243,30 @@ int uvo_extractor_set_pipeline(uvo_extractor* h, int depth);
 #define UVO_FAST_MODE_ADAPTIVE 0
 #define UVO_FAST_MODE_TWO_PASS 1
 #define UVO_FAST_MODE_SINGLE_PASS 2
+/*
+ *   UVO_TUNE_PYR_MODE     : launch shape of ComputePyramid (src/ORBextractor.cc:963-1004); the planes are the same in both.
+ *                           UVO_PYR_MODE_CHAIN (default) one launch per level (+ the border copy of level 0): the fastest on the
+ *                                                     benchmark's batches;
+ *                           UVO_PYR_MODE_SPLIT        the large levels stream over static blocks of 7 source rows with the horizontal
+ *                                                     pass shared between output rows (level 1 reads the image in place, the border
+ *                                                     copy rides along); the levels from UVO_TUNE_PYR_TAIL on share ONE launch in which
+ *                                                     a workgroup walks a (frame, band of rows) through all of them, a barrier per
+ *                                                     step (three launches instead of eight, 4 % slower end to end).
+ *   UVO_TUNE_PYR_TAIL     : split mode: first level of the shared launch (0: every level; >= nlevels: none; default 3)
+ *   UVO_TUNE_PYR_RUN      : split mode: blocks of 7 source rows a wavefront of a streaming launch walks (0: by batch size)
+ *   UVO_TUNE_PYR_BANDS    : split mode: bands per frame of the shared launch: 0 (default) = by batch size, or 1 / 2 / 4 / 8 / 16
+ *   UVO_TUNE_PYR_WAVES    : split mode: at least this many wavefronts per workgroup of the shared launch (0 (default) = the smallest
+ *                           of 4 / 8 / 16 that holds the image's column roles, or 4, 8, 16)
+ *   UVO_TUNE_PYR_ROWS     : split mode: level-0 rows a workgroup of the shared launch advances per barrier (1 .. 7, default 7)
+ */
+#define UVO_TUNE_PYR_BANDS 3
+#define UVO_TUNE_PYR_WAVES 4
+#define UVO_TUNE_PYR_ROWS 5
+#define UVO_TUNE_PYR_MODE 6
+#define UVO_PYR_MODE_CHAIN 0
+#define UVO_PYR_MODE_SPLIT 1
+#define UVO_TUNE_PYR_TAIL 7
+#define UVO_TUNE_PYR_RUN 8
 int uvo_extractor_tune(uvo_extractor* h, int knob, int value);
 /*
  * State of the adaptive FAST mode after the most recent batch (waits for it): per level the threshold the NEXT batch on that

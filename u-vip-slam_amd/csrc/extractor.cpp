@@ -45,6 +45,7 @@ using namespace uvo;
 // lanes, so the latency-bound stages of one batch (quad-tree, sparse NMS, small pyramid levels) overlap with the
 // throughput stages of the next.
 constexpr int kMaxLanes = 4;
+constexpr int kPyrPlans = 5;  // band counts 1, 2, 4, 8, 16
 
 struct Lane {
   hipStream_t stream = nullptr;
@@ -109,6 +110,18 @@ struct uvo_extractor {
   int clahe_w = 0, clahe_h = 0;
   int resize_fast[kMaxLevels] = {0};  // per level: the 12-byte-window path of k_resize_level applies
   ResizeRow* d_rtab = nullptr;
+  // the fused pyramid kernel (pyramid.hip, pyr_schedule.hpp): row tables per ROI row, and one compiled schedule per band count
+  PyrPlanDev pyr_plan[kPyrPlans];
+  int pyr_bands_forced = 0;  // UVO_TUNE_PYR_BANDS: 0 = by batch size
+  int pyr_waves = 0;         // UVO_TUNE_PYR_WAVES: at least this many wavefronts per workgroup (0: the smallest shape that holds the roles)
+  int pyr_rows = 7;          // level-0 rows per macro-step
+  int pyr_mode = UVO_PYR_MODE_CHAIN;  // UVO_TUNE_PYR_MODE (2 = development probe: no pyramid launch at all)
+  int pyr_tail_from = 3;     // UVO_TUNE_PYR_TAIL: levels below it stream (one launch each), it and the levels above share the fused launch; 0 = everything fused
+  int pyr_blocks_per_item = 0;  // UVO_TUNE_PYR_RUN: blocks of 7 source rows a streaming wavefront walks (0 = by batch size)
+  PyrStepLevel* d_pyr_blocks = nullptr;  // per level >= 1: the static blocks of the streaming form
+  int cap_pyr_blocks = 0;
+  int pyr_block_off[kMaxLevels] = {0}, pyr_nblocks[kMaxLevels] = {0};
+  int pyr_tail_built = -1;   // first level of the fused launch the plans were compiled for
   float* d_pattern = nullptr;   // 256 point pairs (x0, y0, x1, y1) of the rBRIEF pattern as floats
   uint32_t* d_patch = nullptr;  // 256 byte masks: which of the 4 pixels of an orientation-patch dword lie inside the circle
   // staging for the host-buffer entry points
@@ -203,7 +216,7 @@ static int build_geom(const uvo_extractor* h, int width, int height, Geom& g, st
     L.h = cv_round_host((float)height * h->inv_scale[l]);
     if (L.w < 56 || L.h < 56 || L.w > 4096 || L.h > 4096) return fail(UVO_E_UNSUPPORTED, "pyramid level outside 56..4096 px");
     L.pw = L.w + 2 * kPad, L.ph = L.h + 2 * kPad;
-    L.pitch = (L.pw + 63) / 64 * 64;
+    L.pitch = (L.pw + kPyrPitchAlign - 1) / kPyrPitchAlign * kPyrPitchAlign;  // whole cache lines: a line never holds bytes of two rows (pyr_schedule.hpp)
     L.plane_off = off;
     off += (int64_t)L.pitch * ((L.ph + 7) & ~7);  // whole 16 x 8 tiles: the blurred plane is stored tiled (gauss.hip), same offsets for both
     off = (off + 255) / 256 * 256;
@@ -337,6 +350,69 @@ static int dev_alloc(T** p, size_t n) {
   return UVO_OK;
 }
 
+static void free_pyr_plans(uvo_extractor* h) {
+  for (PyrPlanDev& P : h->pyr_plan) {
+    if (P.d_roles) (void)hipFree(P.d_roles);
+    if (P.d_steps) (void)hipFree(P.d_steps);
+    if (P.d_band_step) (void)hipFree(P.d_band_step);
+    P = PyrPlanDev();
+  }
+}
+
+// Everything the pyramid launches read, for one geometry: the static blocks of the streaming form per level, and one compiled schedule
+// per band count of the fused launch for the levels from pyr_tail_from on (pyr_schedule.hpp).  Called with every lane idle.
+static int build_pyr_plans(uvo_extractor* h, const Geom& g) {
+  std::vector<PyrRow> rows[kMaxLevels];
+  PyrDims dims[kMaxLevels];
+  std::vector<PyrStepLevel> all, one;
+  for (int l = 0; l < g.nlevels; ++l) {
+    dims[l] = PyrDims{g.lv[l].w, g.lv[l].h, g.lv[l].pitch};
+    h->pyr_block_off[l] = (int)all.size(), h->pyr_nblocks[l] = 0;
+    if (l > 0) {
+      pyr_build_rows(g.lv[l - 1].h, g.lv[l].h, rows[l]);
+      if (!pyr_build_blocks(rows[l], dims[l], g.lv[l - 1].h, one)) return fail(UVO_E_UNSUPPORTED, "pyramid blocks: scale factor outside the supported range");
+      h->pyr_nblocks[l] = (int)one.size();
+      all.insert(all.end(), one.begin(), one.end());
+    }
+  }
+  if ((int)all.size() > h->cap_pyr_blocks) return fail(UVO_E_BADARG, "image larger than the handle was sized for");
+  if (!all.empty()) UVO_HIP_CHECK(hipMemcpy(h->d_pyr_blocks, all.data(), all.size() * sizeof(PyrStepLevel), hipMemcpyHostToDevice));
+  free_pyr_plans(h);
+  const int first = std::min(std::max(h->pyr_tail_from, 0), g.nlevels);
+  h->pyr_tail_built = first;
+  if (first >= g.nlevels) return UVO_OK;  // every level streams
+  int nresize, ncopy, nwaves, nslots;
+  pyr_role_count(dims, first, g.nlevels, nresize, ncopy);
+  if (!pyr_shape_for_roles(nresize, ncopy, h->pyr_waves, nwaves, nslots) && !pyr_shape_for_roles(nresize, ncopy, 0, nwaves, nslots))
+    return fail(UVO_E_UNSUPPORTED, "image too wide for the pyramid kernel's workgroup shapes");
+  for (int k = 0; k < kPyrPlans; ++k) {
+    const int nb = 1 << k;
+    if (k > 0 && g.lv[g.nlevels - 1].h / nb < 4) break;  // bands of fewer than four rows of the top level: the shared rows outweigh the owned ones
+    PyrSchedule S;
+    if (!pyr_build_schedule(dims, first, g.nlevels, rows, nb, nwaves, nslots, h->pyr_rows, S)) return fail(UVO_E_UNSUPPORTED, "pyramid schedule: scale factor outside the supported range");
+    PyrPlanDev& P = h->pyr_plan[k];
+    P.nbands = nb, P.nwaves = nwaves, P.nslots = nslots, P.nsteps = (int)S.band_step.back();
+    int rc;
+    if ((rc = dev_alloc(&P.d_roles, S.roles.size())) != UVO_OK || (rc = dev_alloc(&P.d_steps, S.steps.size())) != UVO_OK ||
+        (rc = dev_alloc(&P.d_band_step, S.band_step.size())) != UVO_OK)
+      return rc;
+    UVO_HIP_CHECK(hipMemcpy(P.d_roles, S.roles.data(), S.roles.size() * sizeof(PyrRole), hipMemcpyHostToDevice));
+    UVO_HIP_CHECK(hipMemcpy(P.d_steps, S.steps.data(), S.steps.size() * sizeof(PyrStepLevel), hipMemcpyHostToDevice));
+    UVO_HIP_CHECK(hipMemcpy(P.d_band_step, S.band_step.data(), S.band_step.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  return UVO_OK;
+}
+
+// band count of a batch: enough workgroups to fill the chip (one per frame when the batch does that by itself; a single frame is cut
+// into up to sixteen bands -- the latency path)
+static const PyrPlanDev& pick_pyr_plan(const uvo_extractor* h, int batch) {
+  int want = h->pyr_bands_forced;
+  if (want <= 0) want = batch >= 256 ? 1 : (batch >= 96 ? 2 : (batch >= 32 ? 4 : (batch >= 8 ? 8 : 16)));
+  int k = 0;
+  while (k + 1 < kPyrPlans && (1 << (k + 1)) <= want && h->pyr_plan[k + 1].nbands) ++k;
+  return h->pyr_plan[k];
+}
+
 static int set_geometry(uvo_extractor* h, int width, int height) {
   if (h->have_geom && h->geom.width == width && h->geom.height == height) return UVO_OK;
   Geom g;
@@ -370,6 +446,10 @@ static int set_geometry(uvo_extractor* h, int width, int height) {
   if (!ctab.empty()) {
     UVO_HIP_CHECK(hipMemcpy(h->d_ctab, ctab.data(), ctab.size() * sizeof(ResizeCol), hipMemcpyHostToDevice));
     UVO_HIP_CHECK(hipMemcpy(h->d_rtab, rtab.data(), rtab.size() * sizeof(ResizeRow), hipMemcpyHostToDevice));
+  }
+  {
+    int rcp = build_pyr_plans(h, g);
+    if (rcp) return rcp;
   }
   h->geom = g;
   h->cells = cells;
@@ -411,14 +491,63 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   hipEvent_t& done = L.done[L.n_enqueued & 1];  // recorded behind the lane's last but one batch
   if (done) UVO_HIP_CHECK(hipEventSynchronize(done));
   else UVO_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-  {
-    ProfScope p(h, "k_pad_level0");
-    launch_pad_level0(s, d_imgs, width, height, stride, frame_stride, L.d_pyr, g.pyr_block, g.lv[0], batch);
-  }
-  for (int l = 1; l < g.nlevels; ++l) {
-    ProfScope p(h, "k_resize_level");
-    launch_resize_level(s, L.d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_ctab + g.lv[l].xtab_off, h->d_rtab + g.lv[l].ytab_off, h->resize_fast[l],
-                        batch);
+  if (h->pyr_mode == 2) {
+    // development probe: no pyramid launch at all (the planes of an earlier batch stay): what the stage costs the step
+  } else if (h->pyr_mode == UVO_PYR_MODE_SPLIT) {
+    // ComputePyramid (src/ORBextractor.cc:963-1004): the large levels stream (one launch each, the border copy of level 0 riding along
+    // with level 1), the levels from pyr_tail_built on share one row-pipelined launch
+    const int first = h->pyr_tail_built;
+    bool fast = true;
+    for (int l = 1; l < g.nlevels; ++l) fast = fast && h->resize_fast[l];
+    const int bpi = h->pyr_blocks_per_item > 0 ? h->pyr_blocks_per_item : (batch >= 64 ? 5 : (batch >= 8 ? 3 : 2));
+    if (first > 0) {
+      // level 1 reads the caller's image in place when its rows are dword-aligned; otherwise from the padded plane behind a copy-only launch
+      const bool inplace = first > 1 && (uintptr_t)d_imgs % 4 == 0 && stride % 4 == 0 && frame_stride % 4 == 0;
+      for (int l = (inplace ? 1 : 0); l < first; ++l) {
+        ProfScope p(h, l <= 1 ? "k_pyr_stream1" : "k_pyr_stream");
+        PyrStreamArgs A;
+        memset(&A, 0, sizeof(A));
+        A.pyr = L.d_pyr, A.pyr_block = g.pyr_block;
+        if (l >= 1) {
+          const LevelGeom &S = g.lv[l - 1], &D = g.lv[l];
+          if (l == 1 && inplace) {
+            A.src = d_imgs, A.src_frame_stride = frame_stride, A.src_origin = 0, A.src_pitch = (int)stride;
+            A.src_bytes = (uint32_t)(stride * (height - 1) + width);
+          } else {
+            A.src = L.d_pyr, A.src_frame_stride = g.pyr_block, A.src_origin = S.plane_off + (int64_t)kPad * S.pitch + kPad, A.src_pitch = S.pitch;
+            A.src_bytes = (uint32_t)(S.pitch * (S.h + kPad) - kPad);
+          }
+          A.sw = S.w, A.sh = S.h;
+          A.dst_plane_off = D.plane_off, A.dst_pitch = D.pitch, A.dst_h = D.h;
+          A.ctab = h->d_ctab + D.xtab_off, A.blocks = h->d_pyr_blocks + h->pyr_block_off[l];
+          A.nblocks = h->pyr_nblocks[l], A.blocks_per_item = bpi;
+          A.nchunks = (D.pitch / 4 + 63) / 64, A.nsegs = (A.nblocks + bpi - 1) / bpi;
+        }
+        if (l == 0 || (l == 1 && inplace)) {
+          A.img = d_imgs, A.img_stride = stride, A.img_frame_stride = frame_stride, A.img_w = width, A.img_h = height;
+          A.l0_pitch = g.lv[0].pitch, A.l0_plane_off = g.lv[0].plane_off;
+          A.copy_chunks = (g.lv[0].pitch / 16 + 63) / 64, A.copy_rows_per_item = bpi * kPyrMaxSrcRows;
+          A.copy_segs = (height + A.copy_rows_per_item - 1) / A.copy_rows_per_item;
+        }
+        A.items_per_frame = A.nchunks * A.nsegs + A.copy_chunks * A.copy_segs;
+        launch_pyr_stream(s, A, fast, batch);
+      }
+    }
+    if (first < g.nlevels) {
+      ProfScope p(h, "k_pyramid");
+      if (launch_pyramid(s, d_imgs, stride, frame_stride, L.d_pyr, g.pyr_block, g, h->resize_fast, pick_pyr_plan(h, batch), h->d_ctab, batch))
+        return fail(UVO_E_UNSUPPORTED, "no pyramid kernel for this workgroup shape");
+    }
+  } else {
+    {
+      ProfScope p(h, "k_pad_level0");
+      launch_pad_level0(s, d_imgs, width, height, stride, frame_stride, L.d_pyr, g.pyr_block, g.lv[0], batch);
+    }
+    for (int l = 1; l < g.nlevels; ++l) {
+      ProfScope p(h, "k_resize_level");
+      launch_resize_level(s, L.d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_ctab + g.lv[l].xtab_off, h->d_rtab + g.lv[l].ytab_off, h->resize_fast[l],
+                          batch);
+    }
   }
   {  // the per-cell threshold vote + candidate emit run inside k_octree
     ProfScope p(h, "k_fast_score");
@@ -552,7 +681,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   h->cap_sel_block = g.sel_block;
   h->cap_flist = g.flist_cap;
   h->cap_xtab = 0, h->cap_ytab = 0;
-  for (int l = 1; l < g.nlevels; ++l) h->cap_xtab += g.lv[l].pitch + 64, h->cap_ytab += g.lv[l].ph + 8;  // (row tables are padded to groups of 4 rows; smaller images of the same area have other level heights)
+  for (int l = 1; l < g.nlevels; ++l) h->cap_xtab += g.lv[l].pitch + 64, h->cap_ytab += g.lv[l].ph + 8, h->cap_pyr_blocks += g.lv[l - 1].h / kPyrMaxSrcRows + 4;  // (row tables are padded to groups of 4 rows; smaller images of the same area have other level heights)
   const size_t B = (size_t)cfg->max_batch;
   hipError_t e = hipSetDevice(h->device);
   if (e != hipSuccess) {
@@ -585,6 +714,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   A(dev_alloc(&h->d_cell_flag, h->cap_flags / B + 64));
   A(dev_alloc(&h->d_ctab, (size_t)h->cap_xtab));
   A(dev_alloc(&h->d_rtab, (size_t)h->cap_ytab));
+  A(dev_alloc(&h->d_pyr_blocks, (size_t)h->cap_pyr_blocks));
   A(dev_alloc(&h->d_pattern, (size_t)1024));
   A(dev_alloc(&h->d_patch, (size_t)256));
   // staging for host-buffer calls
@@ -639,6 +769,8 @@ void uvo_extractor_destroy(uvo_extractor* h) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->h_pin) (void)hipHostFree(h->h_pin);
+  uvo::free_pyr_plans(h);
+  if (h->d_pyr_blocks) (void)hipFree(h->d_pyr_blocks);
   delete h;
 }
 
@@ -769,6 +901,36 @@ int uvo_extractor_tune(uvo_extractor* h, int knob, int value) {
         if (h->lane[i].stream && (rc = set_lane_fast_mode(h, i)) != UVO_OK) return rc;
       return UVO_OK;
     }
+    case UVO_TUNE_PYR_BANDS:
+      if (value < 0 || value > 16 || (value & (value - 1))) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_BANDS takes 0 (by batch size), 1, 2, 4, 8 or 16");
+      h->pyr_bands_forced = value;
+      return UVO_OK;
+    case UVO_TUNE_PYR_WAVES:
+    case UVO_TUNE_PYR_ROWS: {
+      if (knob == UVO_TUNE_PYR_WAVES && value != 0 && value != 4 && value != 8 && value != 16) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_WAVES takes 0, 4, 8 or 16");
+      if (knob == UVO_TUNE_PYR_ROWS && (value < 1 || value > kPyrMaxSrcRows)) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_ROWS takes 1 .. 7");
+      UVO_HIP_CHECK(hipSetDevice(h->device));
+      int rc = sync_all_lanes(h);
+      if (rc) return rc;
+      (knob == UVO_TUNE_PYR_WAVES ? h->pyr_waves : h->pyr_rows) = value;
+      return h->have_geom ? build_pyr_plans(h, h->geom) : UVO_OK;
+    }
+    case UVO_TUNE_PYR_TAIL: {
+      if (value < 0 || value > kMaxLevels) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_TAIL takes 0 .. 16");
+      UVO_HIP_CHECK(hipSetDevice(h->device));
+      int rc = sync_all_lanes(h);
+      if (rc) return rc;
+      h->pyr_tail_from = value;
+      return h->have_geom ? build_pyr_plans(h, h->geom) : UVO_OK;
+    }
+    case UVO_TUNE_PYR_RUN:
+      if (value < 0 || value > 64) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_RUN takes 0 .. 64");
+      h->pyr_blocks_per_item = value;
+      return UVO_OK;
+    case UVO_TUNE_PYR_MODE:
+      if (value != UVO_PYR_MODE_CHAIN && value != UVO_PYR_MODE_SPLIT && value != 2) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_MODE takes UVO_PYR_MODE_CHAIN / _SPLIT");
+      h->pyr_mode = value;
+      return UVO_OK;
     default:
       return fail(UVO_E_BADARG, "unknown knob");
   }
