@@ -244,6 +244,19 @@ int uvo_extractor_set_pipeline(uvo_extractor* h, int depth);
 #define UVO_FAST_MODE_TWO_PASS 1
 #define UVO_FAST_MODE_SINGLE_PASS 2
 /*
+ *   UVO_TUNE_BLUR_ROUNDING : the ONE knob that changes results -- which OpenCV build's GaussianBlur (src/ORBextractor.cc:942) is
+ *                           reproduced where the two differ: an exact .5 in the column pass of the 7 x 7 blur (about one pixel in
+ *                           65 536, by one grey level; descriptors follow).
+ *                           UVO_BLUR_ROUNDING_SCALAR (default) the generic C++ column filter: (sum + 2^15) >> 16, half up, on every column;
+ *                           UVO_BLUR_ROUNDING_SSE2    x86-64 builds: SymmColumnVec_32s8u's vector body (image columns 0 .. (w & ~3) - 1)
+ *                                                     rounds half to even (cvtps2dq), only the last w % 4 columns round half up.
+ *                           Which of the two the reference's binary executes is not decidable without OpenCV 3.4.x at hand
+ *                           (tools/pin/ dumps both cases' evidence: the day it runs, this knob's default follows).
+ */
+#define UVO_TUNE_BLUR_ROUNDING 9
+#define UVO_BLUR_ROUNDING_SCALAR 0
+#define UVO_BLUR_ROUNDING_SSE2 1
+/*
  *   UVO_TUNE_PYR_MODE     : launch shape of ComputePyramid (src/ORBextractor.cc:963-1004); the planes are the same in both.
  *                           UVO_PYR_MODE_CHAIN (default) one launch per level (+ the border copy of level 0): the fastest on the
  *                                                     benchmark's batches;
@@ -694,9 +707,11 @@ int uvo_extractor_wait_matcher(uvo_extractor* h, uvo_matcher* m);
  * The cheaper form of the same ordering: from this call on the matcher enqueues its work in the stream of the extractor's current
  * pipeline lane (the lane of the most recent batch call), directly behind that batch's kernels and in front of whatever the lane
  * runs next -- no events, no hand-off between queues (each costs tens of microseconds; a lane of the batch-256 pipeline idled
- * 0.3 ms per batch on the two hand-offs around uvo_hamming_knn2_batch_device).  Call it after every uvo_extract_batch_device() whose
- * results the matcher reads next (the lane alternates).  h = NULL: back to the matcher's own stream.  While attached, calls that
- * wait for the matcher's stream (every host-buffer entry point) wait for that lane; the extractor must outlive the attachment.
+ * 0.3 ms per batch on the two hand-offs around uvo_hamming_knn2_batch_device).  One call is enough: the extractor keeps a list of the
+ * matchers attached to it and moves them along whenever a batch goes to another pipeline lane, so the matcher always works behind the
+ * most recent batch (calling it again after a batch is harmless).  h = NULL: back to the matcher's own stream.  While attached, calls
+ * that wait for the matcher's stream (every host-buffer entry point) wait for that lane.  Either handle may be destroyed first: a
+ * destroyed extractor hands its matchers back to their own streams, a destroyed matcher leaves the list.
  */
 int uvo_matcher_attach_extractor(uvo_matcher* m, uvo_extractor* h);
 /* per-kernel timing of the matcher, same contract as uvo_extractor_profile / uvo_extractor_kernel_times */

@@ -91,6 +91,14 @@ void orc_gauss7_padded(uint8_t* plane, int w, int hgt, int pad) {
   View full{plane, w + 2 * pad, hgt + 2 * pad, w + 2 * pad};
   gaussian_blur7_roi_inplace(full.roi(pad, pad, pad + w, pad + hgt));
 }
+void orc_gauss7_padded_ex(uint8_t* plane, int w, int hgt, int pad, int rounding) {
+  View full{plane, w + 2 * pad, hgt + 2 * pad, w + 2 * pad};
+  gaussian_blur7_roi_inplace(full.roi(pad, pad, pad + w, pad + hgt), rounding);
+}
+void orc_extractor_set_blur_rounding(void* h, int rounding) { ((Extractor*)h)->blur_rounding = rounding; }
+void orc_extractor_pattern(void* h, int* out1024) {  // the 512 (x, y) points of bit_pattern_31_ as the extractor holds them
+  for (int i = 0; i < 1024; ++i) out1024[i] = ((Extractor*)h)->pattern[i];
+}
 float orc_fast_atan2(float y, float x) { return fast_atan2(y, x); }
 float orc_ic_angle(void* h, const uint8_t* plane, int w, int hgt, int pad, float x, float y) {
   Extractor* e = (Extractor*)h;

@@ -225,7 +225,12 @@ void gaussian_taps_7_sigma2(int taps[7]) {
   for (int i = 0; i < n; ++i) taps[i] = cv_round_f(cf[i] * 256.f);
 }
 
-void gaussian_blur7_roi_inplace(const View& roi) {
+// `rounding`: how the column pass rounds an exact .5 (every other sum rounds the same either way).
+//   kBlurRoundScalar (default): (s + 2^15) >> 16 on every column -- FixedPtCastEx<int, uchar>(16), the generic C++ column filter;
+//   kBlurRoundSse2: what an x86-64 OpenCV 3.4.x build executes [OCV-RECALL]: SymmColumnVec_32s8u's vector body takes the columns
+//     0 .. (w & ~3) - 1 (16 and then 4 at a time), computes the sum in fp32 -- exact here: every partial sum is a multiple of 2^-16 below
+//     2^8 -- and converts with cvtps2dq, round-half-to-EVEN; only the last w % 4 columns fall to the scalar loop above.
+void gaussian_blur7_roi_inplace(const View& roi, int rounding) {
   int k[7];
   gaussian_taps_7_sigma2(k);
   const int w = roi.w, h = roi.h;
@@ -245,6 +250,7 @@ void gaussian_blur7_roi_inplace(const View& roi) {
       int s = 0;
       for (int j = 0; j < 7; ++j) s += k[j] * rows[(size_t)(y + j) * w + x];
       int v = (s + (1 << 15)) >> 16;  // FixedPtCastEx<int,uchar>(16)
+      if (rounding == kBlurRoundSse2 && x < (w & ~3) && (s & 0xffff) == 0x8000) v &= ~1;  // an exact tie: to even
       D[x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
     }
   }
@@ -649,7 +655,7 @@ void Extractor::extract(const View& image, std::vector<KeyPoint>& _keypoints, st
     std::vector<KeyPoint>& keypoints = allKeypoints[level];
     int nkeypointsLevel = (int)keypoints.size();
     if (nkeypointsLevel == 0) continue;
-    gaussian_blur7_roi_inplace(pyr[level]);
+    gaussian_blur7_roi_inplace(pyr[level], blur_rounding);
     for (int i = 0; i < nkeypointsLevel; ++i) compute_orb_descriptor(keypoints[i], pyr[level], pattern, &_descriptors[(size_t)(offset + i) * 32]);
     offset += nkeypointsLevel;
     if (level != 0) {

@@ -54,7 +54,8 @@ void fast9_16_bruteforce(const View& img, int threshold, bool nms, std::vector<K
 void gaussian_taps_7_sigma2(int taps[7]);
 // blur the ROI `roi` (which must sit >= 3 px inside its parent buffer) in place,
 // border taps read the parent's pixels (non-isolated sub-matrix semantics)
-void gaussian_blur7_roi_inplace(const View& roi);
+enum { kBlurRoundScalar = 0, kBlurRoundSse2 = 1 };
+void gaussian_blur7_roi_inplace(const View& roi, int rounding = kBlurRoundScalar);
 float fast_atan2(float y, float x);
 
 // ---- reference glue ----
@@ -64,6 +65,7 @@ struct Extractor {
   int nfeatures;
   double scaleFactor;  // member is `double` in include/ORBextractor.h:79
   int nlevels, fastTh;
+  int blur_rounding = kBlurRoundScalar;  // which contract the column pass of GaussianBlur rounds exact ties under (orb_oracle.cpp)
   std::vector<float> mvScaleFactor, mvInvScaleFactor;
   std::vector<int> mnFeaturesPerLevel;
   std::vector<int> umax;

@@ -39,6 +39,9 @@ class Oracle:
         L.orc_fast_bruteforce.argtypes = [vp, ci, ci, cl, ci, ci, vp, ci]
         L.orc_gauss_taps.argtypes = [vp]
         L.orc_gauss7_padded.argtypes = [vp, ci, ci, ci]
+        L.orc_gauss7_padded_ex.argtypes = [vp, ci, ci, ci, ci]
+        L.orc_extractor_set_blur_rounding.argtypes = [vp, ci]
+        L.orc_extractor_pattern.argtypes = [vp, vp]
         L.orc_fast_atan2.restype = cf
         L.orc_fast_atan2.argtypes = [cf, cf]
         L.orc_ic_angle.restype = cf
@@ -118,6 +121,13 @@ class Oracle:
         t = np.zeros(7, np.int32)
         self.L.orc_gauss_taps(t.ctypes.data)
         return t
+
+    def gauss7_padded_ex(self, plane, pad=16, rounding=0):
+        """rounding: 0 = the generic column filter (half up), 1 = the x86-64 SSE2 contract (vector-body columns: exact ties to even)"""
+        plane = np.ascontiguousarray(plane, np.uint8).copy()
+        ph, pw = plane.shape
+        self.L.orc_gauss7_padded_ex(plane.ctypes.data, pw - 2 * pad, ph - 2 * pad, pad, int(rounding))
+        return plane
 
     def gauss7_padded(self, plane, pad=16):
         plane = np.array(plane, np.uint8, copy=True, order="C")
@@ -457,6 +467,14 @@ class OracleExtractor:
                                int(num_featsneeded), out_kp.ctypes.data, out_desc.ctypes.data, cap)
         assert n >= 0, "oracle capacity"
         return out_kp[:n].copy(), out_desc[:n].copy()
+
+    def pattern(self):
+        out = np.zeros(1024, np.int32)
+        self.L.orc_extractor_pattern(self.h, out.ctypes.data)
+        return out
+
+    def set_blur_rounding(self, rounding):
+        self.L.orc_extractor_set_blur_rounding(self.h, int(rounding))
 
     def level_dims(self, level):
         w, h = ctypes.c_int(), ctypes.c_int()

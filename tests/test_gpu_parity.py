@@ -265,6 +265,43 @@ def test_blur_planes_at_the_saturation_edge(uvo, oracle):
     ex.close()
 
 
+@pytest.mark.parametrize("shape", [(640, 512), (638, 510), (321, 243)])
+def test_blur_rounding_contracts(uvo, oracle, synth, shape):
+    """UVO_TUNE_BLUR_ROUNDING: the generic column filter rounds an exact .5 up on every column; an x86-64 OpenCV build's SSE2 column filter
+    rounds it to even on the image columns 0 .. (w & ~3) - 1 and up on the last w % 4 (src/ORBextractor.cc:942).  The HIP
+    path follows whichever contract is selected, byte for byte -- blurred planes and features -- on images that hold such ties (the two
+    oracles differ on them), including widths with a scalar tail, saturating images, and ties planted in the tail columns."""
+    w, h = shape
+    rng = np.random.default_rng(w)
+    imgs = [synth.make_frame(8100 + w, w, h, n_shapes=max(60, w * h // 1500)), rng.integers(0, 256, (h, w)).astype(np.uint8),
+            rng.integers(230, 256, (h, w)).astype(np.uint8)]
+    ex = uvo.ORBextractor(800, 1.2, 6, 0, 15, max_width=w, max_height=h)
+    oe = oracle.extractor(800, 1.2, 6, 15)
+    differing = 0
+    for img in imgs:
+        planes = {}
+        for mode, tune in ((0, uvo.UVO_BLUR_ROUNDING_SCALAR), (1, uvo.UVO_BLUR_ROUNDING_SSE2)):
+            oe.set_blur_rounding(mode)
+            ex.tune(uvo.UVO_TUNE_BLUR_ROUNDING, tune)
+            kp_g, de_g = ex(img)
+            kp_o, de_o = oe(img)
+            for l in range(6):
+                if (kp_o["octave"] == l).any():
+                    bo, bg = oe.level_plane(l, blurred=True), ex.read_plane(l, blurred=True)
+                    np.testing.assert_array_equal(bg[14:-14, 14:-14], bo[14:-14, 14:-14], err_msg="contract %d: blurred level %d" % (mode, l))
+                    planes[(mode, l)] = bo[16:-16, 16:-16]
+            _assert_same_features(kp_g, de_g, kp_o, de_o, "contract %d" % mode)
+        for l in range(6):
+            if (0, l) in planes and (1, l) in planes:
+                d = planes[(0, l)] != planes[(1, l)]
+                differing += int(d.sum())
+                lw = planes[(0, l)].shape[1]
+                assert not d[:, lw & ~3:].any()          # the scalar tail rounds the same under both contracts
+                assert (np.abs(planes[(0, l)].astype(int) - planes[(1, l)].astype(int)) <= 1).all()
+    assert differing > 0, "no exact tie in these images: the test would prove nothing"
+    ex.close()
+
+
 def test_topup_mode(uvo, oracle, frames):
     """FullDetect=false: caller keypoints pass through level 0, occupancy grid filters and is mutated (src/ORBextractor.cc:872-909)."""
     img = frames[0]
@@ -383,10 +420,11 @@ def test_search_by_projection(uvo, oracle, synth):
     m.close()
 
 
-@pytest.mark.parametrize("matcher_stream", ["own", "lane"])
+@pytest.mark.parametrize("matcher_stream", ["own", "lane", "lane_once"])
 def test_hbm_resident_pipeline_depth2(uvo, oracle, synth, matcher_stream):
     """uvo_extract_batch_device with two alternating scratch sets / streams feeding the batched HBM-resident matcher -- on its own stream
-    behind events, or attached to the extracting lane's stream; a host-buffer matcher call while attached waits for that lane."""
+    behind events, or attached to the extracting lane's stream; a host-buffer matcher call while attached waits for that lane.
+    lane_once: attached ONCE before the first batch -- the extractor moves its followers along when a batch goes to the other lane."""
     import torch
     B, W, H = 4, 640, 512
     batches = [synth.make_batch(B, W, H, seed0=3000 + 10 * k) for k in range(3)]
@@ -407,18 +445,20 @@ def test_hbm_resident_pipeline_depth2(uvo, oracle, synth, matcher_stream):
         d1 = torch.zeros((B, cap), dtype=torch.int16, device=dev)
         outs.append((d_img, kp, de, n, i0, i1, d0, d1))
     torch.cuda.synchronize()
+    if matcher_stream == "lane_once":
+        mt.attach(ex)
     for d_img, kp, de, n, i0, i1, d0, d1 in outs:   # three calls back to back, no host sync in between
         ex.extract_batch_device(d_img.data_ptr(), B, W, H, kp.data_ptr(), de.data_ptr(), n.data_ptr(), cap)
         if matcher_stream == "own":
             mt.wait_extractor(ex)
-        else:
+        elif matcher_stream == "lane":
             mt.attach(ex)
         # pair p = (frame p, frame p+1) for p < B-1
         mt.knn2_batch_device(B - 1, de.data_ptr(), n.data_ptr(), cap, de.data_ptr() + cap * 32, n.data_ptr() + 4, cap, i0.data_ptr(),
                              d0.data_ptr(), i1.data_ptr(), d1.data_ptr())
         if matcher_stream == "own":
             mt.release_to_extractor(ex)
-    if matcher_stream == "lane":   # a host-buffer call in the attached state: enqueued in, and waiting for, the lane's stream
+    if matcher_stream != "own":   # a host-buffer call in the attached state: enqueued in, and waiting for, the lane's stream
         rng = np.random.default_rng(5)
         a, b = rng.integers(0, 256, (70, 32), dtype=np.uint8), rng.integers(0, 256, (90, 32), dtype=np.uint8)
         got = mt.knn2(a, b)

@@ -258,8 +258,30 @@ def test_extract_tracked_builds_the_callers_occupancy_grid_on_the_device(uvo, or
         np.testing.assert_array_equal(grid_g, grid_o)
         assert n_in == 0 or not (set(zip(kp_g["x"].tolist(), kp_g["y"].tolist())) & set(zip(kin["x"].tolist(), kin["y"].tolist()))), \
             "tracked points must not come back as new ones"
+    # KLT-tracked points a fraction of a cell outside the image: the reference's grid has two cells of slack and (int)(pt / d) truncates
+    # towards zero, so they mark a cell like any other (src/Tracking.cc:901-907); only what the reference would index outside its grid
+    # is refused
+    kin = np.zeros(6, uvo.KEYPOINT_DTYPE)
+    kin["x"] = np.float32([-0.4, -19.0, W + 3.5, 100.0, 200.0, W + 2 * d - 0.5])
+    kin["y"] = np.float32([50.0, 60.0, 70.0, -7.25, H + 11.0, (H // d + 2) * d - 0.5])
+    kin["size"], kin["angle"], kin["octave"], kin["class_id"] = 31, -1, 0, -1
+    grid = np.zeros((H // d + 2, W // d + 2), np.int32, order="F")
+    for k in kin:
+        grid[int(np.float32(k["y"]) / np.float32(d)), int(np.float32(k["x"]) / np.float32(d))] += 1
+    grid_o = grid.copy(order="F")
+    kp_o, de_o = oe(img, None, grid_o, d, False, 300)
+    kp_g, de_g, grid_g = ex.extract_tracked(img, kin, d, 300, want_grid=True)
+    _same(kp_g, de_g, kp_o, de_o, "extract_tracked with points outside the image")
+    np.testing.assert_array_equal(grid_g, grid_o)
+    for bad in ((-20.5, 50.0), (W + 2 * d + 0.5, 50.0), (50.0, -d - 1.0), (50.0, float("nan"))):
+        kin["x"][0], kin["y"][0] = bad
+        with pytest.raises(uvo.UvoError):
+            ex.extract_tracked(img, kin, d, 300)
     enh = ex.clahe(img, download=False)
-    kin = kin[:300]
+    rng = np.random.default_rng(10)
+    kin = np.zeros(300, uvo.KEYPOINT_DTYPE)
+    kin["x"], kin["y"] = rng.uniform(20, W - 21, 300).astype(np.float32), rng.uniform(20, H - 21, 300).astype(np.float32)
+    kin["size"], kin["angle"], kin["octave"], kin["class_id"] = 31, -1, 0, -1
     grid = np.zeros((H // d + 2, W // d + 2), np.int32, order="F")
     for k in kin:
         grid[int(k["y"] / d), int(k["x"] / d)] += 1
@@ -267,3 +289,63 @@ def test_extract_tracked_builds_the_callers_occupancy_grid_on_the_device(uvo, or
     kp_g, de_g = ex.extract_tracked(None, kin, d, 150)
     _same(kp_g, de_g, kp_o, de_o, "clahe -> extract_tracked(NULL)")
     ex.close()
+
+
+def test_attached_handles_may_die_in_either_order(uvo, oracle):
+    """uvo_matcher_attach_extractor: a destroyed extractor hands its matchers back to their own streams (they used to keep a dead stream),
+    a destroyed matcher leaves the extractor's list (the extractor used to move a dead handle along)."""
+    rng = np.random.default_rng(3)
+    a, b = rng.integers(0, 256, (50, 32), dtype=np.uint8), rng.integers(0, 256, (60, 32), dtype=np.uint8)
+    want = oracle.knn2(a, b)
+    img = rng.integers(0, 256, (256, 320)).astype(np.uint8)
+    ex = uvo.ORBextractor(300, 1.2, 4, 0, 20, max_width=320, max_height=256)
+    ex.set_pipeline(2)
+    m1, m2 = uvo.ORBmatcher(0.8), uvo.ORBmatcher(0.8)
+    m1.attach(ex), m2.attach(ex)
+    ex(img)
+    np.testing.assert_array_equal(m1.knn2(a, b)[0], want[0])
+    m2.close()                      # leaves the list ...
+    ex(img), ex(img)                # ... so the lane changes move only m1
+    np.testing.assert_array_equal(m1.knn2(a, b)[0], want[0])
+    ex.close()                      # m1 is back on its own stream
+    np.testing.assert_array_equal(m1.knn2(a, b)[0], want[0])
+    m1.synchronize()
+    m1.close()
+
+
+def test_adaptive_fast_mode_follows_a_stream_that_changes_contrast(uvo, oracle, synth):
+    """The adaptive FAST form of a level (`FAST(cell, fastTh)` then `FAST(cell, 7)` for empty cells, src/ORBextractor.cc:792-799) is chosen on
+    the device from the PREVIOUS batch of the same pipeline lane: > 22 % fall-back cells -> one pass at 7, < 14 % -> two passes.  A stream
+    that alternates textured and low-contrast batches therefore runs every batch in the form its predecessor asked for -- one batch of lag
+    per lane -- and the keypoints must not notice.  One lane: the form flips after every batch (the recorded thresholds alternate 7 / fastTh).
+    Two lanes: lane 0 only ever sees textured batches, lane 1 low-contrast ones, so each settles in its own form after its first batch."""
+    w, h, B, TH = 320, 256, 24, 20
+    tex = synth.make_batch(B, w, h, seed0=8800)
+    low = [(f.astype(np.float32) * 0.12 + 110 * 0.88).astype(np.uint8) for f in synth.make_batch(B, w, h, seed0=8900)]
+    oe = oracle.extractor(400, 1.2, 5, TH)
+    ref = {"tex": [oe(f) for f in (tex[0], tex[B // 2], tex[-1])], "low": [oe(f) for f in (low[0], low[B // 2], low[-1])]}
+
+    def check(res, kind):
+        for (kp_o, de_o), f in zip(ref[kind], (0, B // 2, B - 1)):
+            kp, de = res[f]
+            assert kp.tobytes() == kp_o.tobytes() and (de == de_o).all(), (kind, f)
+
+    for depth in (1, 2):
+        ex = uvo.ORBextractor(400, 1.2, 5, 0, TH, max_width=w, max_height=h, max_batch=B)
+        ex.set_pipeline(depth)
+        seen = []
+        for i in range(8):
+            kind = "tex" if i % 2 == 0 else "low"
+            res = ex.extract_batch(tex if kind == "tex" else low)
+            check(res, kind)
+            t, fb, cells = ex.fast_state()          # thresholds the NEXT batch of this lane streams at; fall-back cells of this batch
+            share = fb.sum() / float(cells.sum() * B)
+            assert (share < 0.10) if kind == "tex" else (share > 0.5), (kind, share)
+            seen.append(int(t[0]))
+        if depth == 1:
+            # every batch decides for the next one: after a textured batch two passes (fastTh), after a low-contrast one a single pass (7)
+            assert seen == [TH, 7] * 4, seen
+        else:
+            # lane 0 = batches 0, 2, 4, 6 (textured), lane 1 = batches 1, 3, 5, 7 (low contrast): no flip-flop inside a lane
+            assert seen[0::2] == [TH] * 4 and seen[1::2] == [7] * 4, seen
+        ex.close()

@@ -54,6 +54,25 @@ def _oracle_stand_in(oracle):
     return out
 
 
+def pinned_blur_contract(pins, oracle):
+    """Which rounding contract of the blur's column pass the reference's binary executes (0: half up on every column, 1: the SSE2 column
+    filter's half-to-even on the vector-body columns): decided by the kit's `gauss_<k>` cases -- padded noise planes that hold exact .5
+    sums.  Exactly one contract must reproduce every case; archives made before the kit dumped them say nothing (-> 0, the default)."""
+    if "gauss_0_in" not in pins:
+        return 0
+    ok = {0: True, 1: True}
+    k, differ = 0, False
+    while "gauss_%d_in" % k in pins:
+        a = {c: oracle.gauss7_padded_ex(pins["gauss_%d_in" % k], 16, c) for c in (0, 1)}
+        differ = differ or (a[0] != a[1]).any()
+        for c in (0, 1):
+            ok[c] = ok[c] and (a[c] == pins["gauss_%d_out" % k]).all()
+        k += 1
+    assert differ, "the gauss cases hold no exact tie: they cannot tell the contracts apart"
+    assert ok[0] != ok[1], "GaussianBlur of the reference matches %s rounding contract" % ("BOTH" if ok[0] else "NEITHER")
+    return 0 if ok[0] else 1
+
+
 def check_extractor_against(pins, run, what, planes=True):
     """run(name, img, nfeat, th) -> (kp, desc, plane(level, blurred)) of the implementation under test."""
     mi = _cases()
@@ -77,12 +96,21 @@ def check_extractor_against(pins, run, what, planes=True):
     return n
 
 
-def _oracle_run(oracle):
+def _oracle_run(oracle, contract=0):
     def run(name, img, nfeat, th):
         oe = oracle.extractor(nfeat, 1.2, 8, th)
+        oe.set_blur_rounding(contract)
         kp, de = oe(img)
         return kp, de, lambda l, b: oe.level_plane(l, b)
     return run
+
+
+def _oracle_topup(oracle, contract=0):
+    def topup(img, nf, th, kin, g, d, need):
+        oe = oracle.extractor(nf, 1.2, 8, th)
+        oe.set_blur_rounding(contract)
+        return oe(img, kin, g, d, False, need)
+    return topup
 
 
 def check_topup_against(pins, extract, what):
@@ -116,8 +144,10 @@ def test_pin_status_is_reported():
 # ---- the oracle against the reference (CPU) ----
 def test_oracle_extractor_equals_reference(oracle):
     pins = _pins()
-    check_extractor_against(pins, _oracle_run(oracle), "oracle")
-    check_topup_against(pins, lambda img, nf, th, kin, g, d, need: oracle.extractor(nf, 1.2, 8, th)(img, kin, g, d, False, need), "oracle")
+    c = pinned_blur_contract(pins, oracle)
+    print("blur rounding contract of the reference's OpenCV build:", ("scalar (half up)", "SSE2 (vector columns half to even)")[c])
+    check_extractor_against(pins, _oracle_run(oracle, c), "oracle")
+    check_topup_against(pins, _oracle_topup(oracle, c), "oracle")
 
 
 def test_oracle_primitives_equal_reference(oracle):
@@ -179,13 +209,15 @@ def test_oracle_primitives_equal_reference(oracle):
 
 # ---- the HIP path against the reference (MI355X) ----
 @pytest.mark.gpu
-def test_hip_extractor_equals_reference():
+def test_hip_extractor_equals_reference(oracle):
     pins = _pins()
     uvo = importlib.import_module("u-vip-slam_amd")
+    contract = pinned_blur_contract(pins, oracle)   # (the checker decides which contract the archive was made under; the HIP path is then set to it)
 
     def run(name, img, nfeat, th):
         h, w = img.shape
         ex = uvo.ORBextractor(nfeat, 1.2, 8, 0, th, max_width=w, max_height=h)
+        ex.tune(uvo.UVO_TUNE_BLUR_ROUNDING, contract)
         kp, de = ex(img)
         planes = {(l, b): ex.read_plane(l, b) for l in range(8) for b in (False, True)}
         ex.close()
@@ -194,15 +226,18 @@ def test_hip_extractor_equals_reference():
 
     def topup(img, nf, th, kin, g, d, need):
         ex = uvo.ORBextractor(nf, 1.2, 8, 0, th, max_width=img.shape[1], max_height=img.shape[0], max_input_keypoints=800)
+        ex.tune(uvo.UVO_TUNE_BLUR_ROUNDING, contract)
         r = ex(img, kin, g, d, False, need)
         ex.close()
         return r
     check_topup_against(pins, topup, "HIP")
 
 
-def test_kit_round_trip_with_an_emulated_dumper(oracle, tmp_path, monkeypatch):
+@pytest.mark.parametrize("contract", [0, 1])
+def test_kit_round_trip_with_an_emulated_dumper(oracle, tmp_path, monkeypatch, contract):
     """make_inputs.py -> (the dumper, emulated here by the oracle, writing the dumper's manifest format) -> pack_npz.py -> the reference
-    checks: every file name, dtype tag and array name of the kit is exercised end to end without OpenCV."""
+    checks: every file name, dtype tag and array name of the kit is exercised end to end without OpenCV.  The emulated "OpenCV build"
+    rounds the blur under one contract or the other: the checks find out which from the gauss cases and pass under both."""
     import make_inputs
     import pack_npz
     indir, outdir = tmp_path / "in", tmp_path / "out"
@@ -229,6 +264,7 @@ def test_kit_round_trip_with_an_emulated_dumper(oracle, tmp_path, monkeypatch):
             if name == "hd":
                 continue                      # (kept out of the emulation for time; the real dumper does it)
             oe = oracle.extractor(nf, 1.2, 8, th)
+            oe.set_blur_rounding(contract)
             kp, de = oe(img)
             put(name + "/kp", "kp", kp)
             put(name + "/desc", "u1", de.reshape(-1, 32))
@@ -240,7 +276,7 @@ def test_kit_round_trip_with_an_emulated_dumper(oracle, tmp_path, monkeypatch):
             img, nf, th = frames[name]
             kin = np.fromfile(indir / t[7], make_inputs.KP)
             g = np.asfortranarray(np.fromfile(indir / t[8], np.int32).reshape(cols, rows).T)
-            kp, de = oracle.extractor(nf, 1.2, 8, th)(img, kin, g, d, False, need)
+            kp, de = _oracle_topup(oracle, contract)(img, nf, th, kin, g, d, need)
             put(name + "/kp_topup", "kp", kp)
             put(name + "/desc_topup", "u1", de.reshape(-1, 32))
             put(name + "/grid_topup", "i4", np.ascontiguousarray(g.T))
@@ -256,6 +292,10 @@ def test_kit_round_trip_with_an_emulated_dumper(oracle, tmp_path, monkeypatch):
             put("knn_%s_q" % name, "u1", q), put("knn_%s_t" % name, "u1", tr)
             put("knn_%s_idx" % name, "i4", np.stack([i0, i1 if nt >= 2 else np.full(nq, -1)], 1).astype(np.int32))
             put("knn_%s_dist" % name, "i4", np.stack([d0, d1 if nt >= 2 else np.full(nq, -1)], 1).astype(np.int32))
+        elif t[0] == "gauss":
+            k, gw, gh = int(t[1]), int(t[2]), int(t[3])
+            parent = np.fromfile(indir / t[4], np.uint8).reshape(gh + 32, gw + 32)
+            put("gauss_%d_in" % k, "u1", parent), put("gauss_%d_out" % k, "u1", oracle.gauss7_padded_ex(parent, 16, contract))
         elif t[0] == "atan2":
             yy, xx = np.fromfile(indir / t[2], np.float32), np.fromfile(indir / t[3], np.float32)
             put("atan2_y", "f4", yy), put("atan2_x", "f4", xx)
@@ -296,5 +336,6 @@ def test_kit_round_trip_with_an_emulated_dumper(oracle, tmp_path, monkeypatch):
     monkeypatch.setattr(sys, "argv", ["pack_npz.py", str(outdir), str(npz)])
     pack_npz.main()
     monkeypatch.setattr(sys.modules[__name__], "PINS", str(npz))
+    assert pinned_blur_contract(_pins(), oracle) == contract
     test_oracle_extractor_equals_reference(oracle)
     test_oracle_primitives_equal_reference(oracle)

@@ -194,6 +194,17 @@ int main(int argc, char** argv) {
       put("knn_" + name + "_t", "u1", rt.data(), 1, {(size_t)nt, (size_t)32});
       put("knn_" + name + "_idx", "i4", idx.data(), 4, {(size_t)nq, (size_t)2});
       put("knn_" + name + "_dist", "i4", dist.data(), 4, {(size_t)nq, (size_t)2});
+    } else if (kind == "gauss") {
+      // the blur exactly as operator() applies it (:942): in place on the ROI of a padded parent, border flag without BORDER_ISOLATED
+      int k, w, h;
+      std::string file;
+      ss >> k >> w >> h >> file;
+      std::vector<char> raw = slurp(in + "/" + file);
+      cv::Mat parent = cv::Mat(h + 32, w + 32, CV_8UC1, raw.data()).clone();
+      put_mat_u8("gauss_" + std::to_string(k) + "_in", parent);
+      cv::Mat roi = parent(cv::Rect(16, 16, w, h));
+      cv::GaussianBlur(roi, roi, cv::Size(7, 7), 2, 2, cv::BORDER_REFLECT_101);
+      put_mat_u8("gauss_" + std::to_string(k) + "_out", parent);
     } else if (kind == "atan2") {
       int n;
       std::string fy, fx;

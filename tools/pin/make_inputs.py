@@ -87,6 +87,13 @@ def main():
             "one": (lowent(40, 12), lowent(1, 12)), "two": (lowent(40, 12), lowent(2, 12))}
     for name, (q, t) in sets.items():
         lines.append("knn %s %d %d %s %s" % (name, len(q), len(t), put("knn_%s_q" % name, q), put("knn_%s_t" % name, t)))
+    # cv::GaussianBlur(roi, roi, Size(7, 7), 2, 2, BORDER_REFLECT_101) on the ROI of a padded parent (src/ORBextractor.cc:942), on noise tall
+    # enough to hold exact .5 column sums (one pixel in 65 536): THE case that tells the two rounding contracts apart -- the generic column
+    # filter rounds them up everywhere, an SSE2 build's SymmColumnVec_32s8u to even on the columns 0 .. (w & ~3) - 1 (UVO_TUNE_BLUR_ROUNDING).
+    # Widths with a scalar tail of 0, 2 and 1 columns.  File = the padded parent, (h + 32) x (w + 32), REFLECT_101 of the noise.
+    for k, (gw, gh) in enumerate(((320, 1200), (318, 1200), (157, 2400))):
+        noise = np.random.default_rng(700 + k).integers(0, 256, (gh, gw)).astype(np.uint8)
+        lines.append("gauss %d %d %d %s" % (k, gw, gh, put("gauss_%d_in" % k, np.pad(noise, 16, mode="reflect"))))
     # cv::fastAtan2 on a grid of (y, x) incl. zeros, equal magnitudes, negative and tiny values
     v = np.concatenate([np.float32([0, 1, -1, 1e-12, -1e-12, 3e7]), rng.normal(0, 50000, 2000).astype(np.float32), rng.integers(-200000, 200000, 2000).astype(np.float32)])
     yy, xx = rng.permutation(v)[:4000], rng.permutation(v)[:4000]

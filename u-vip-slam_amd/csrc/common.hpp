@@ -138,7 +138,7 @@ bool pyr_shape_for_roles(int nresize, int ncopy, int min_waves, int& nwaves, int
 int launch_pyramid(hipStream_t s, const uint8_t* d_img, int64_t stride, int64_t frame_stride, uint8_t* d_pyr, int64_t pyr_block, const Geom& g,
                    const int* fast_ok, const PyrPlanDev& plan, const ResizeCol* d_ctab, int batch);
 void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g, int4 taps,
-                   int batch);
+                   int batch, int sse2_rounding);
 void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, int fast_th, const int32_t* d_tpass, uint32_t* d_cor,
                        uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, uint32_t* d_cand_lo, int64_t cand_block, int32_t* d_cursor, int batch);
 void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, const CellDesc* d_cells, const int32_t* d_flag_cell,
@@ -154,6 +154,7 @@ int fast_flags_per_frame(const Geom& g);
 struct OctLaunchState {
   int wide_max_problems = 256;
 };
+int prepare_octree(const Geom& g);  // the part of the quad-tree launch that can fail (called before a batch's first kernel)
 int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_lo, int32_t* d_cursor,
                    int32_t* d_fcount, int32_t* d_n_cell_list, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate,
                    uint32_t* d_sel_xy, uint32_t* d_sel_sc, int32_t* d_sel_count, int batch);

@@ -76,8 +76,13 @@ struct Lane {
   unsigned n_enqueued = 0;
 };
 
+struct uvo_matcher;
+extern "C" void uvo_matcher_follow_internal(uvo_matcher* m, hipStream_t s);
+extern "C" void uvo_matcher_orphaned_internal(uvo_matcher* m);
+
 struct uvo_extractor {
   uvo_extractor_cfg cfg;
+  std::vector<uvo_matcher*> followers;  // matchers attached to this handle (uvo_matcher_attach_extractor): they enqueue in the current lane's stream
   int device = 0;
   Lane lane[kMaxLanes];
   int nlanes = 1, cur = 0;  // cur = the lane of the most recent batch
@@ -94,6 +99,7 @@ struct uvo_extractor {
   std::vector<CellDesc> cells;
   std::vector<int32_t> cell_flag;  // per entry of a frame's cell-flag array (the full nRows x nCols grids of all levels): cell | level << 24, -1 = no cell
   int fast_mode = UVO_FAST_MODE_ADAPTIVE;
+  int blur_rounding = UVO_BLUR_ROUNDING_SCALAR;  // UVO_TUNE_BLUR_ROUNDING
   // capacities fixed at create time (from max_width x max_height)
   int64_t cap_pyr_block = 0, cap_cand_block = 0;
   int cap_cells = 0, cap_sel_block = 0, cap_flist = 0, cap_xtab = 0, cap_ytab = 0;
@@ -483,9 +489,11 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   UVO_HIP_CHECK(hipSetDevice(h->device));
   int rc = set_geometry(h, width, height);
   if (rc) return rc;
+  if ((rc = prepare_octree(h->geom)) != UVO_OK) return rc;  // nothing below this line fails once the first kernel is in the stream
   h->cur = li;
   Lane& L = h->lane[li];
   hipStream_t s = L.stream;
+  for (uvo_matcher* m : h->followers) uvo_matcher_follow_internal(m, s);  // attached matchers work behind THIS batch
   h->last_batch = batch;
   const Geom& g = h->geom;
   hipEvent_t& done = L.done[L.n_enqueued & 1];  // recorded behind the lane's last but one batch
@@ -563,7 +571,7 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   }
   {
     ProfScope p(h, "k_gauss7");
-    launch_gauss7(s, L.d_pyr, L.d_blur, g.pyr_block, h->d_lv, g, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), batch);
+    launch_gauss7(s, L.d_pyr, L.d_blur, g.pyr_block, h->d_lv, g, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), batch, h->blur_rounding);
   }
   {
     ProfScope p(h, "k_octree");
@@ -751,6 +759,10 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
 void uvo_extractor_destroy(uvo_extractor* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  for (int i = 0; i < kMaxLanes; ++i)
+    if (h->lane[i].stream) (void)hipStreamSynchronize(h->lane[i].stream);
+  for (uvo_matcher* m : h->followers) uvo_matcher_orphaned_internal(m);  // their work in these streams is done; they outlive the streams
+  h->followers.clear();
   for (int i = 0; i < kMaxLanes; ++i) {
     Lane& L = h->lane[i];
     if (L.stream) (void)hipStreamSynchronize(L.stream);
@@ -927,6 +939,10 @@ int uvo_extractor_tune(uvo_extractor* h, int knob, int value) {
       if (value < 0 || value > 64) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_RUN takes 0 .. 64");
       h->pyr_blocks_per_item = value;
       return UVO_OK;
+    case UVO_TUNE_BLUR_ROUNDING:
+      if (value != UVO_BLUR_ROUNDING_SCALAR && value != UVO_BLUR_ROUNDING_SSE2) return fail(UVO_E_BADARG, "UVO_TUNE_BLUR_ROUNDING takes UVO_BLUR_ROUNDING_SCALAR / _SSE2");
+      h->blur_rounding = value;
+      return UVO_OK;
     case UVO_TUNE_PYR_MODE:
       if (value != UVO_PYR_MODE_CHAIN && value != UVO_PYR_MODE_SPLIT && value != 2) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_MODE takes UVO_PYR_MODE_CHAIN / _SPLIT");
       h->pyr_mode = value;
@@ -999,8 +1015,12 @@ static int extract_batch_impl(uvo_extractor* h, int batch, const uint8_t* imgs, 
       for (int i = 0; i < n_in[b]; ++i) {
         const uvo_keypoint& k = in_kp[(size_t)b * in_cap + i];
         if (build_grid) {
-          // the keypoints only mark grid cells ((int)(pt / min_px_dist), src/Tracking.cc:903-907): they must lie inside the image
-          if (!(k.x >= 0.f && k.x < (float)width && k.y >= 0.f && k.y < (float)height)) return fail(UVO_E_BADARG, "tracked keypoint outside the image");
+          // the keypoints only mark grid cells, x = (int)(pt.y / d), y = (int)(pt.x / d) (src/Tracking.cc:905-907): the conversion
+          // truncates towards zero and the grid has two cells of slack, so a KLT-tracked point a fraction of a cell outside the image
+          // marks a cell like any other (the reference accepts it); what the reference would index OUT of its grid is refused here
+          const int gx = (int)(k.y / (float)min_px_dist), gy = (int)(k.x / (float)min_px_dist);
+          if (!(k.x == k.x && k.y == k.y) || fabsf(k.x) > 1e9f || fabsf(k.y) > 1e9f || gx < 0 || gx >= grid_rows || gy < 0 || gy >= grid_cols)
+            return fail(UVO_E_BADARG, "tracked keypoint outside the occupancy grid");
           continue;
         }
         const int cx = (int)lrintf(k.x), cy = (int)lrintf(k.y);
@@ -1420,6 +1440,12 @@ int uvo_extractor_kernel_times(uvo_extractor* h, char* names, int names_cap, flo
 }
 
 hipStream_t uvo_extractor_stream_internal(uvo_extractor* h) { return h->lane[h->cur].stream; }
+void uvo_extractor_add_follower_internal(uvo_extractor* h, uvo_matcher* m) {
+  if (std::find(h->followers.begin(), h->followers.end(), m) == h->followers.end()) h->followers.push_back(m);
+}
+void uvo_extractor_drop_follower_internal(uvo_extractor* h, uvo_matcher* m) {
+  h->followers.erase(std::remove(h->followers.begin(), h->followers.end(), m), h->followers.end());
+}
 int uvo_extractor_device_internal(uvo_extractor* h) { return h->device; }
 int uvo_extractor_next_lane_internal(const uvo_extractor* h) { return next_lane(h); }
 const uint8_t* uvo_extractor_clahe_internal(uvo_extractor* h, int* width, int* height) {

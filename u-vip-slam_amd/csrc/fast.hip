@@ -553,7 +553,8 @@ struct FcGeom {
 // which runs behind both kernels).
 constexpr int FCL_THREADS = 1024;
 __global__ __launch_bounds__(FCL_THREADS) void k_fast_cells_list(const int32_t* __restrict__ flag_cell, int flags_per_frame, int nlevels, const int32_t* __restrict__ tpass,
-                                                               const uint8_t* __restrict__ cell_hi, uint2* __restrict__ list, int32_t* __restrict__ n_list) {
+                                                               const uint8_t* __restrict__ cell_hi, uint2* __restrict__ list, int32_t* __restrict__ n_list,
+                                                               int list_cap) {
   __shared__ int s_n, s_base;
   __shared__ uint32_t s_adaptive;  // bit l: level l is threshold-adaptive in this batch
   const int idx = (int)(blockIdx.x * FCL_THREADS + threadIdx.x), f = blockIdx.y, lane = threadIdx.x & 63;
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(FCL_THREADS) void k_fast_cells_list(const int32_t* 
   if (s_n == 0) return;
   if (threadIdx.x == 0) s_base = atomicAdd(n_list, s_n);
   __syncthreads();
-  if (todo) list[s_base + at] = make_uint2((uint32_t)(fc & 0xffffff), (uint32_t)f);
+  if (todo && s_base + at < list_cap) list[s_base + at] = make_uint2((uint32_t)(fc & 0xffffff), (uint32_t)f);  // (the list holds every cell of the batch: the bound only bites if the counter was left stale)
 }
 
 // k_fast_cells: a fixed grid of wavefronts shares the listed cells evenly (fall-back cells cluster in the smooth parts of a frame: dealt
@@ -836,7 +837,7 @@ void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, c
     return;
   }
   hipLaunchKernelGGL(k_fast_cells_list, dim3((L.flags_per_frame + FCL_THREADS - 1) / FCL_THREADS, batch), dim3(FCL_THREADS), 0, s, d_flag_cell, L.flags_per_frame,
-                     g.nlevels, d_tpass, d_cell_hi, d_list, d_n_list);
+                     g.nlevels, d_tpass, d_cell_hi, d_list, d_n_list, (int)std::min<int64_t>((int64_t)g.total_cells * batch, INT32_MAX));
   // a fixed grid that fills the chip once (seven / three workgroups of four wavefronts per CU: LDS); fewer when the batch cannot hold that many cells
   const int64_t max_items = (int64_t)g.total_cells * batch;
   const int waves = (int)std::min<int64_t>(max_items, 256 * (small ? 7 : 3) * FC_WAVES);

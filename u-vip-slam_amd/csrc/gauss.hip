@@ -48,6 +48,11 @@ __device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t 
 }
 
 constexpr int GS_TILES = 16;  // tiles a wavefront collects per 8-row group: 15 of a full strip, 2 x 7 / 4 x 3 of the narrow ones
+// SSE2: the rounding contract of an x86-64 OpenCV build (UVO_TUNE_BLUR_ROUNDING): SymmColumnVec_32s8u's vector body -- image columns
+// 0 .. (w & ~3) - 1 -- converts the exact fp32 column sum with cvtps2dq, i.e. an exact .5 goes to the EVEN neighbour; the last w % 4
+// columns (its scalar tail) and the default contract round .5 up.  A lane's four pixels are an aligned group of four image columns, so
+// a lane is wholly one or the other.
+template <bool SSE2>
 __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int64_t pyr_block,
                                                 const LevelGeom* __restrict__ lv, int nlevels, int4 taps, int rows_per_seg) {
   // work item (one per wavefront) -> (level, strip, segment group); narrow remainder strips hold 2 or 4 row segments side by side
@@ -124,6 +129,7 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
     __builtin_amdgcn_wave_barrier();
   };
 
+  const bool even_ties = SSE2 && (X - kPad) < (g.w & ~3);  // the lane's image columns belong to the vector body
   uint32_t inmask = 0;  // bytes of the lane's dword that lie inside the image columns
 #pragma unroll
   for (int k = 0; k < 4; ++k) inmask |= (X + k >= kPad && X + k < g.w + kPad) ? 0xffu << (8 * k) : 0u;
@@ -184,12 +190,15 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
           const bool row_in = (uint32_t)j - j_in0 < n_in;
           // column pass: sum / 2^16 + 0.5, every partial sum an exact multiple of 2^-16 below 2^8 (a larger one belongs to a result
           // that saturates anyway); floor, clamp to 255 and the byte insert are the conversion itself
-          uint32_t blurred = 0;
+          uint32_t blurred = 0, ties = 0;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float z = __builtin_fmaf(c0, r0[k] + r6[k], __builtin_fmaf(c1, r1[k] + r5[k], __builtin_fmaf(c2, r2[k] + r4[k], __builtin_fmaf(c3, r3[k], 0.5f))));
             blurred = __builtin_amdgcn_cvt_pk_u8_f32(z, (uint32_t)k, blurred);
+            // sum / 2^16 + 1/2 a whole number: the sum sat exactly between two bytes (and below the saturation edge)
+            if (SSE2) ties |= (__builtin_amdgcn_fractf(z) == 0.0f && z < 256.0f) ? 1u << (8 * k) : 0u;
           }
+          if (SSE2 && even_ties) blurred -= ties & blurred;  // half up gave the upper neighbour: where that one is odd, the even one is below it
           // pad ring and anything outside the image: the un-blurred centre pixel (byte mask per lane, rows uniform)
           const uint32_t m = row_in ? inmask : 0u;
           const uint32_t out = (blurred & m) | (centre & ~m);
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
 }
 
 void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g, int4 taps,
-                   int batch) {
+                   int batch, int sse2_rounding) {
   // fewer, longer segments when the batch already fills the chip (6 halo rows are re-read per segment)
   const int rows_per_seg = batch >= 16 ? 64 : 16;
   int items = 0;
@@ -227,7 +236,10 @@ void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t
     fast_strip_plan(g.lv[l].w + 8, g.lv[l].h + 8, rows_per_seg, plan);
     items += plan.items;
   }
-  hipLaunchKernelGGL(k_gauss7, dim3((items + 3) / 4, batch), dim3(256), 0, s, d_pyr, d_blur, pyr_block, d_lv, g.nlevels, taps, rows_per_seg);
+  if (sse2_rounding)
+    hipLaunchKernelGGL(k_gauss7<true>, dim3((items + 3) / 4, batch), dim3(256), 0, s, d_pyr, d_blur, pyr_block, d_lv, g.nlevels, taps, rows_per_seg);
+  else
+    hipLaunchKernelGGL(k_gauss7<false>, dim3((items + 3) / 4, batch), dim3(256), 0, s, d_pyr, d_blur, pyr_block, d_lv, g.nlevels, taps, rows_per_seg);
 }
 
 }  // namespace uvo

@@ -92,6 +92,17 @@ __device__ __forceinline__ v4i spread16(uint32_t x) {  // 16 bits -> 16 bytes
   r.x = (int)spread4(x), r.y = (int)spread4(x >> 4), r.z = (int)spread4(x >> 8), r.w = (int)spread4(x >> 12);
   return r;
 }
+// the same with 0xff where a bit is set (0 / -1 as signed bytes): (b << 8) - b per word, in unsigned arithmetic -- no carries between
+// bytes, no signed overflow
+__device__ __forceinline__ uint32_t spread4_ff(uint32_t t) {
+  const uint32_t b = spread4(t);
+  return (b << 8) - b;
+}
+__device__ __forceinline__ v4i spread16_ff(uint32_t x) {
+  v4i r;
+  r.x = (int)spread4_ff(x), r.y = (int)spread4_ff(x >> 4), r.z = (int)spread4_ff(x >> 8), r.w = (int)spread4_ff(x >> 12);
+  return r;
+}
 
 // median of three signed integers (v_med3_i32; clang has no builtin for the integer form)
 __device__ __forceinline__ int med3_i32(int a, int b, int c) {
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(256, UVO_OCC_KNN) void k_knn2_mfma(const uint8_t* _
   for (int s = 0; s < 8; ++s) {
     const uint32_t w = qi < nq ? Q[(int64_t)qi * 8 + s] : 0u;
     popq += __popc(w);
-    bq[s] = spread16(w >> (16 * h)) * 0xff;  // 0x01 -> 0xff per byte (no carries between bytes)
+    bq[s] = spread16_ff(w >> (16 * h));  // 0x01 -> 0xff per byte
   }
   int k0 = 0x7fffffff, k1 = 0x7fffffff;  // two smallest keys ((pop(t) - 2 dot) << 16 | train index), signed
   const int erow = threadIdx.x >> 3, ec = threadIdx.x & 7;  // expansion: thread -> (train row of the tile, 32-bit chunk)

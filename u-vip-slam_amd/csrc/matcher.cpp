@@ -21,6 +21,8 @@ int matcher_fail(int code, const char* msg);
 }  // namespace uvo
 extern "C" hipStream_t uvo_extractor_stream_internal(uvo_extractor* h);
 extern "C" int uvo_extractor_device_internal(uvo_extractor* h);
+extern "C" void uvo_extractor_add_follower_internal(uvo_extractor* h, uvo_matcher* m);
+extern "C" void uvo_extractor_drop_follower_internal(uvo_extractor* h, uvo_matcher* m);
 
 using namespace uvo;
 
@@ -90,6 +92,7 @@ int uvo_matcher_create(const uvo_matcher_cfg* cfg, uvo_matcher** out) {
 void uvo_matcher_destroy(uvo_matcher* m) {
   if (!m) return;
   hipSetDevice(m->device);
+  if (m->attached_to) uvo_extractor_drop_follower_internal(m->attached_to, m);
   if (m->stream) hipStreamSynchronize(m->stream);
   if (m->own_stream && m->own_stream != m->stream) hipStreamSynchronize(m->own_stream);
   void* ptrs[] = {m->d_q,      m->d_t,     m->d_mask,       m->d_idx0,       m->d_idx1,       m->d_d0,    m->d_d1,         m->d_dist,  m->d_kp,
@@ -417,6 +420,18 @@ int uvo_search_points_in_frustum(uvo_matcher* m, const uvo_keypoint* kp, int n, 
 }
 
 hipStream_t uvo_matcher_stream_internal(uvo_matcher* m) { return m->stream; }
+// Called by the extractor a matcher is attached to: whenever a batch moves to another pipeline lane the followers move with it (a
+// matcher that kept the previous lane's stream would read the new batch's descriptors with no ordering at all), and when the
+// extractor is destroyed they go back to their own streams instead of keeping a dead one.
+void uvo_matcher_follow_internal(uvo_matcher* m, hipStream_t s) {
+  if (m->stream == s) return;
+  if (m->prof.on) (void)hipStreamSynchronize(m->stream);  // the profiler's open events belong to the stream they were recorded on
+  m->stream = s;
+}
+void uvo_matcher_orphaned_internal(uvo_matcher* m) {
+  m->attached_to = nullptr;
+  m->stream = m->own_stream;
+}
 
 int uvo_matcher_wait_extractor(uvo_matcher* m, uvo_extractor* h) {
   if (!m || !h) return matcher_fail(UVO_E_BADARG, "null handle");
@@ -442,12 +457,15 @@ int uvo_extractor_wait_matcher(uvo_extractor* h, uvo_matcher* m) {
 int uvo_matcher_attach_extractor(uvo_matcher* m, uvo_extractor* h) {
   if (!m) return matcher_fail(UVO_E_BADARG, "null handle");
   UVO_HIP_CHECK(hipSetDevice(m->device));
+  if (h && uvo_extractor_device_internal(h) != m->device) return matcher_fail(UVO_E_BADARG, "handles live on different devices");
+  if (m->prof.on) UVO_HIP_CHECK(hipStreamSynchronize(m->stream));  // the profiler's open events belong to the stream they were recorded on
+  if (m->attached_to && m->attached_to != h) uvo_extractor_drop_follower_internal(m->attached_to, m);
+  m->attached_to = h;
   if (!h) {
     m->stream = m->own_stream;
     return UVO_OK;
   }
-  if (uvo_extractor_device_internal(h) != m->device) return matcher_fail(UVO_E_BADARG, "handles live on different devices");
-  if (m->prof.on) UVO_HIP_CHECK(hipStreamSynchronize(m->stream));  // the profiler's open events belong to the stream they were recorded on
+  uvo_extractor_add_follower_internal(h, m);  // from now on the extractor moves this handle's stream with its batches
   m->stream = uvo_extractor_stream_internal(h);
   return UVO_OK;
 }

@@ -16,6 +16,7 @@ struct uvo_matcher {
   int device = 0;
   hipStream_t stream = nullptr;      // where the handle's work is enqueued: its own stream, or an extractor lane's (uvo_matcher_attach_extractor)
   hipStream_t own_stream = nullptr;
+  uvo_extractor* attached_to = nullptr;  // the extractor whose current lane `stream` follows (it keeps a list of its followers and lets go of them when it dies)
   // knn2 staging
   uint8_t *d_q = nullptr, *d_t = nullptr, *d_mask = nullptr;
   size_t mask_bytes = 0;

@@ -209,22 +209,25 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
   if (threadIdx.x == 0) *out_n = n;
 }
 
-int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_lo, int32_t* d_cursor,
-                   int32_t* d_fcount, int32_t* d_n_cell_list, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
-                   int32_t* d_sel_count, int batch) {
-  int M = 0;
+// LDS the quad-tree kernel needs for this geometry (M = the largest node table, its power of two, the count pyramid)
+static size_t octree_lds(const Geom& g, int& M, int& Mp2, int& pyr_words) {
+  M = 0;
   for (int l = 0; l < g.nlevels; ++l) {
     const int m = oct_capacity(g.lv[l].quota, g.lv[l].nIni);
     M = m > M ? m : M;
   }
-  const int Mp2 = pow2_ge(M);
-  int pyr_words = 0;
+  Mp2 = pow2_ge(M);
+  pyr_words = 0;
   for (int l = 0; l < g.nlevels; ++l) pyr_words = std::max(pyr_words, oct::pyramid_words(g.lv[l].nIni));
-  // The kernel is latency bound (a few dozen dependent phases per problem): the per-candidate state lives in registers,
-  // the node tables in LDS, and the grid is level-major so that the long level-0 problems are dispatched first.
-  const bool wide = batch * g.nlevels <= st.wide_max_problems;
-  const int threads = wide ? 1024 : OCT_THREADS;
-  const size_t lds = oct_lds_bytes(M, Mp2, pyr_words);
+  return oct_lds_bytes(M, Mp2, pyr_words);
+}
+
+// Everything about the quad-tree launch that can fail, done BEFORE the batch's first kernel is enqueued: k_octree is also what zeroes
+// the fill cursors, cell flags and the fall-back cell list for the lane's next batch, so the launch itself must not be skipped once the
+// FAST kernels of the batch are in the stream.
+int prepare_octree(const Geom& g) {
+  int M, Mp2, pyr_words;
+  const size_t lds = octree_lds(g, M, Mp2, pyr_words);
   if (lds > 64 * 1024) {
     // hipFuncSetAttribute SETS the function's limit on the current device -- it does not raise it -- so several handles on one device
     // (different nfeatures -> different sizes) must agree on the largest request: a per-device maximum, raised under a lock
@@ -239,6 +242,18 @@ int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, cons
       if (dev >= 0 && dev < 64) dev_max[dev] = lds;
     }
   }
+  return UVO_OK;
+}
+
+int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_lo, int32_t* d_cursor,
+                   int32_t* d_fcount, int32_t* d_n_cell_list, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
+                   int32_t* d_sel_count, int batch) {
+  int M, Mp2, pyr_words;
+  const size_t lds = octree_lds(g, M, Mp2, pyr_words);  // (prepare_octree has raised the kernel's limit for it)
+  // The kernel is latency bound (a few dozen dependent phases per problem): the per-candidate state lives in registers,
+  // the node tables in LDS, and the grid is level-major so that the long level-0 problems are dispatched first.
+  const bool wide = batch * g.nlevels <= st.wide_max_problems;
+  const int threads = wide ? 1024 : OCT_THREADS;
 #ifdef UVO_OCT_TRACE
   {
     static bool once = false;

@@ -314,6 +314,9 @@ void shard_worker(uvo_sharder* s, int shard_index) {
             rc = fail(UVO_E_HIP, "copy of the knn-2 rows failed");
         }
         if (rc == UVO_OK && hipEventRecord(sh.rows_sent[t], ms) != hipSuccess) rc = fail(UVO_E_HIP, "hipEventRecord failed");
+        // the matcher part failed half way: whatever did get enqueued (the knn-2 kernel reading this lane's descriptors, copies into the
+        // caller's arrays) must have landed before the error is reported -- the caller may free those arrays, the lane is resubmitted
+        if (rc != UVO_OK) (void)hipStreamSynchronize(ms);
       }
       if (rc != UVO_OK) {
         snprintf(msg, sizeof(msg), "shard %d: %s", shard_index, uvo_last_error());
