@@ -67,6 +67,7 @@ def algorithmic_bytes_per_frame(w, h, k):
         "k_pyramid_stage": sum(s[:-1]) + sum(s[1:]),    # the same model for the pyramid launches together (k_pyr_stream1 + k_pyr_stream + k_pyramid)
         "k_fast_score": tot,                            # reads every level once
         "k_gauss7": 2 * tot,
+        "k_octree_gauss": 2 * tot,                      # the quad-tree and the blur as one launch: the blur's bytes
         "k_fast_blur": 3 * tot,                         # the fused form: one read serves FAST and the blur, one write
         "k_octree": 0,
         "k_assemble": 0,
@@ -414,6 +415,10 @@ def main():
             ex.tune(uvo.UVO_TUNE_PYR_TAIL, t_)
             ex.tune(uvo.UVO_TUNE_PYR_BANDS, b_)
             ex.tune(uvo.UVO_TUNE_PYR_RUN, r_)
+    if os.environ.get("UVO_BENCH_FUSE"):   # experiment knob: quad-tree + blur as one launch (1, default) or two (0)
+        ex.tune(uvo.UVO_TUNE_FUSE_BLUR_TREE, int(os.environ["UVO_BENCH_FUSE"]))
+    if os.environ.get("UVO_BENCH_DELAY_US"):   # development probe: an idle kernel of that many microseconds in every lane's batch
+        ex.tune(100, int(os.environ["UVO_BENCH_DELAY_US"]))
     if os.environ.get("UVO_BENCH_OCT_WIDE_MAX"):   # experiment knob: quad-tree launch shape (uvo_extractor_tune)
         ex.tune(uvo.UVO_TUNE_OCT_WIDE_MAX, int(os.environ["UVO_BENCH_OCT_WIDE_MAX"]))
     torch.cuda.synchronize()
@@ -707,16 +712,16 @@ def main():
         avg_launch_s = dom_ms * 1e-3 / dom_launches
         bytes_per_launch = alg.get(dom, 0) * (B + 1) / launches_per_step
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        total_alg = sum(v for kname, v in alg.items() if kname not in ("k_pad_level0", "k_fast_blur"))
+        total_alg = sum(v for kname, v in alg.items() if kname not in ("k_pad_level0", "k_fast_blur", "k_pyramid_stage", "k_octree_gauss"))
         pmc, pmc_frames, pmc_src = load_pmc(args.config)
         scale = (B + 1) / pmc_frames if pmc_frames else 1.0   # the counters were taken at the config's default batch: per-launch figures scale with the frames
 
-        def pmc_of(name):   # profiler name -> summed counters of the device kernels behind it (k_knn2 -> k_knn2_mfma, k_fast_cells -> + _list)
+        def pmc_of(name, key="valu"):   # profiler name -> summed counters of the device kernels behind it (k_knn2 -> k_knn2_mfma, k_fast_cells -> + _list)
             hit = [v for k, v in pmc.items() if k == name or k.startswith(name + "_")]
             if not hit:
                 return None, None
             tr = [h["traffic"] for h in hit if h["traffic"] is not None]
-            va = [h["valu"] for h in hit if h["valu"] is not None]
+            va = [h[key] for h in hit if h.get(key) is not None]
             return (int(sum(tr) * scale) if tr else None), (sum(va) * scale if va else None)
 
         # ---- per-kernel table: algorithmic bytes per step, duration with the other lane's kernels beside it (live)
@@ -754,6 +759,19 @@ def main():
                 g1 = valu_instr / alone_s / 1e9
                 roof_valu["alone_on_the_chip"] = {"launch_ms": round(alone_s * 1e3, 5), "achieved": round(g1, 2), "frac": round(g1 / VALU_PEAK_GINSTR, 5),
                                                   "frac_of_4_cycle_class_peak": round(g1 / (VALU_PEAK_GINSTR / 2), 5)}
+        # the roof that actually binds the dominant kernel: instruction issue.  VALU + SALU wavefront-instructions per launch (counters)
+        # / live launch duration, against the chip's issue peak of the 2-cycle class (and of the 4-cycle class most stencil arithmetic is in)
+        issue_roofline = None
+        _, salu_instr = pmc_of(dom, "salu")
+        if valu_instr and avg_launch_s > 0:
+            tot = valu_instr + (salu_instr or 0)
+            gi = tot / avg_launch_s / 1e9
+            issue_roofline = {"bound": "issue", "kernel": dom, "valu_wave_instructions": int(valu_instr), "salu_wave_instructions": int(salu_instr or 0),
+                              "achieved": round(gi, 2), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": round(gi / VALU_PEAK_GINSTR, 5),
+                              "frac_of_4_cycle_class_peak": round(gi / (VALU_PEAK_GINSTR / 2), 5), "source": pmc_src,
+                              "note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles (add / sub / logic / fp32 fma class); packed, three-operand, compare, "
+                                      "convert and integer-multiply instructions issue every 4 cycles (tools/ubench/valu_rate3.hip), and the CU's one scalar "
+                                      "unit makes a scalar instruction cost a vector slot at this density (tools/ubench/valu_issue.hip)"}
         whole_path_frac = total_alg * value / world / 1e9 / HBM_PEAK_GBS
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 5), "traffic": traffic,
                     "kernel": dom, "avg_launch_ms": round(avg_launch_s * 1e3, 5), "algorithmic_bytes_per_launch": int(bytes_per_launch),
@@ -792,6 +810,7 @@ def main():
             "roofline": roofline,
             "whole_path_frac": round(whole_path_frac, 5),
             "valu_frac": roof_valu["frac"] if roof_valu else None,
+            "issue_roofline": issue_roofline,
             "host_to_host": h2h,
             "sub_records": sub,
         }

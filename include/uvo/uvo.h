@@ -253,6 +253,8 @@ int uvo_extractor_set_pipeline(uvo_extractor* h, int depth);
  *                           Which of the two the reference's binary executes is not decidable without OpenCV 3.4.x at hand
  *                           (tools/pin/ dumps both cases' evidence: the day it runs, this knob's default follows).
  */
+#define UVO_TUNE_FUSE_BLUR_TREE 10 /* 1 (default): DistributeOctTree and GaussianBlur share one launch when the batch is large enough for the
+                                     256-thread quad-tree form (neither reads what the other writes); 0: two launches */
 #define UVO_TUNE_BLUR_ROUNDING 9
 #define UVO_BLUR_ROUNDING_SCALAR 0
 #define UVO_BLUR_ROUNDING_SSE2 1

@@ -28,6 +28,7 @@ UVO_FAST_MODE_ADAPTIVE, UVO_FAST_MODE_TWO_PASS, UVO_FAST_MODE_SINGLE_PASS = 0, 1
 UVO_TUNE_PYR_BANDS, UVO_TUNE_PYR_WAVES, UVO_TUNE_PYR_ROWS, UVO_TUNE_PYR_MODE, UVO_TUNE_PYR_TAIL, UVO_TUNE_PYR_RUN = 3, 4, 5, 6, 7, 8
 UVO_PYR_MODE_CHAIN, UVO_PYR_MODE_SPLIT = 0, 1
 UVO_TUNE_BLUR_ROUNDING, UVO_BLUR_ROUNDING_SCALAR, UVO_BLUR_ROUNDING_SSE2 = 9, 0, 1
+UVO_TUNE_FUSE_BLUR_TREE = 10
 
 # every symbol include/uvo/uvo.h declares
 ABI_SYMBOLS = [

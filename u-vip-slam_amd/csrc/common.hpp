@@ -137,6 +137,7 @@ void launch_pyr_stream(hipStream_t s, const PyrStreamArgs& A, bool fast, int bat
 bool pyr_shape_for_roles(int nresize, int ncopy, int min_waves, int& nwaves, int& nslots);
 int launch_pyramid(hipStream_t s, const uint8_t* d_img, int64_t stride, int64_t frame_stride, uint8_t* d_pyr, int64_t pyr_block, const Geom& g,
                    const int* fast_ok, const PyrPlanDev& plan, const ResizeCol* d_ctab, int batch);
+void launch_probe_delay(hipStream_t s, int us);
 void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g, int4 taps,
                    int batch, int sse2_rounding);
 void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, int fast_th, const int32_t* d_tpass, uint32_t* d_cor,
@@ -154,6 +155,11 @@ int fast_flags_per_frame(const Geom& g);
 struct OctLaunchState {
   int wide_max_problems = 256;
 };
+bool octree_gauss_applies(const OctLaunchState& st, const Geom& g, int batch);
+void launch_octree_gauss(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, int4 taps, int sse2_rounding,
+                         const uint32_t* d_cand_lo, int32_t* d_cursor, int32_t* d_fcount, int32_t* d_n_cell_list, uint8_t* d_cell_hi, uint32_t* d_cand_xy,
+                         uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
+                         int32_t* d_sel_count, int batch);
 int prepare_octree(const Geom& g);  // the part of the quad-tree launch that can fail (called before a batch's first kernel)
 int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_lo, int32_t* d_cursor,
                    int32_t* d_fcount, int32_t* d_n_cell_list, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate,

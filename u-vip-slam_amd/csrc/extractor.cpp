@@ -121,6 +121,8 @@ struct uvo_extractor {
   int pyr_bands_forced = 0;  // UVO_TUNE_PYR_BANDS: 0 = by batch size
   int pyr_waves = 0;         // UVO_TUNE_PYR_WAVES: at least this many wavefronts per workgroup (0: the smallest shape that holds the roles)
   int pyr_rows = 7;          // level-0 rows per macro-step
+  int fuse_blur_tree = 1;    // UVO_TUNE_FUSE_BLUR_TREE: quad-tree and blur as one launch when the batch takes the 256-thread quad-tree form
+  int probe_delay_us = 0;    // development probe (UVO_TUNE 100): an idle single-wavefront kernel of this many microseconds behind the pyramid
   int pyr_mode = UVO_PYR_MODE_CHAIN;  // UVO_TUNE_PYR_MODE (2 = development probe: no pyramid launch at all)
   int pyr_tail_from = 3;     // UVO_TUNE_PYR_TAIL: levels below it stream (one launch each), it and the levels above share the fused launch; 0 = everything fused
   int pyr_blocks_per_item = 0;  // UVO_TUNE_PYR_RUN: blocks of 7 source rows a streaming wavefront walks (0 = by batch size)
@@ -557,6 +559,10 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
                           batch);
     }
   }
+  if (h->probe_delay_us > 0) {
+    ProfScope p(h, "k_probe_delay");
+    launch_probe_delay(s, h->probe_delay_us);
+  }
   {  // the per-cell threshold vote + candidate emit run inside k_octree
     ProfScope p(h, "k_fast_score");
     launch_fast_score(s, L.d_pyr, g.pyr_block, g, h->cfg.fast_th, L.d_tpass, L.d_cor, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, L.d_cand_lo, g.cand_block,
@@ -569,15 +575,24 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
     launch_fast_cells(s, L.d_pyr, g.pyr_block, g, h->d_cells, h->d_cell_flag, L.d_tpass, L.d_cell_hi, L.d_cell_list, L.d_fstat + kMaxLevels, L.d_cand_xy,
                       L.d_cand_sc, g.cand_block, L.d_cursor, batch);
   }
-  {
-    ProfScope p(h, "k_gauss7");
-    launch_gauss7(s, L.d_pyr, L.d_blur, g.pyr_block, h->d_lv, g, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), batch, h->blur_rounding);
-  }
-  {
-    ProfScope p(h, "k_octree");
-    rc = launch_octree(s, h->oct, h->d_lv, g, L.d_cand_lo, L.d_cursor, L.d_fcount, L.d_fstat + kMaxLevels, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count,
-                       L.d_pstate, L.d_sel_xy, L.d_sel_sc, L.d_sel_count, batch);
-    if (rc) return rc;
+  if (h->fuse_blur_tree && octree_gauss_applies(h->oct, g, batch)) {
+    // the quad-tree (a chain of dependent phases per (frame, level)) and the blur (a streaming kernel) read nothing of each other:
+    // one grid, the quad-tree problems first, and the blur fills the issue slots they leave idle
+    ProfScope p(h, "k_octree_gauss");
+    launch_octree_gauss(s, h->d_lv, g, L.d_pyr, L.d_blur, g.pyr_block, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), h->blur_rounding, L.d_cand_lo, L.d_cursor,
+                        L.d_fcount, L.d_fstat + kMaxLevels, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count, L.d_pstate, L.d_sel_xy, L.d_sel_sc, L.d_sel_count,
+                        batch);
+  } else {
+    {
+      ProfScope p(h, "k_gauss7");
+      launch_gauss7(s, L.d_pyr, L.d_blur, g.pyr_block, h->d_lv, g, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), batch, h->blur_rounding);
+    }
+    {
+      ProfScope p(h, "k_octree");
+      rc = launch_octree(s, h->oct, h->d_lv, g, L.d_cand_lo, L.d_cursor, L.d_fcount, L.d_fstat + kMaxLevels, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count,
+                         L.d_pstate, L.d_sel_xy, L.d_sel_sc, L.d_sel_count, batch);
+      if (rc) return rc;
+    }
   }
   {
     ProfScope p(h, "k_assemble");
@@ -938,6 +953,12 @@ int uvo_extractor_tune(uvo_extractor* h, int knob, int value) {
     case UVO_TUNE_PYR_RUN:
       if (value < 0 || value > 64) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_RUN takes 0 .. 64");
       h->pyr_blocks_per_item = value;
+      return UVO_OK;
+    case UVO_TUNE_FUSE_BLUR_TREE:
+      h->fuse_blur_tree = value != 0;
+      return UVO_OK;
+    case 100:  // development probe
+      h->probe_delay_us = value;
       return UVO_OK;
     case UVO_TUNE_BLUR_ROUNDING:
       if (value != UVO_BLUR_ROUNDING_SCALAR && value != UVO_BLUR_ROUNDING_SSE2) return fail(UVO_E_BADARG, "UVO_TUNE_BLUR_ROUNDING takes UVO_BLUR_ROUNDING_SCALAR / _SSE2");

@@ -1,0 +1,216 @@
+// The blur's device code (see gauss.hip for the description): shared by k_gauss7 and by k_octree_gauss (octree.hip), whose workgroups
+// that are not quad-tree problems run it.
+#pragma once
+#include "common.hpp"
+#include "fast_geom.hpp"
+
+namespace uvo {
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 pk(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
+
+// Row pass for the lane's 4 pixels with the packed-byte dot product (v_dot4_u32_u8): pixel k needs window bytes
+// k+1 .. k+7 of [L C R]; they are fetched as two byte-aligned dwords (v_alignbyte) and multiplied with the taps packed as
+// (t0,t1,t2,t3) and (t2,t1,t0,0).  Exact integer arithmetic, 4 instructions per pixel.
+template <int S>
+__device__ __forceinline__ uint32_t win4(uint32_t L, uint32_t C, uint32_t R) {  // bytes S..S+3 of the 12-byte window
+  if (S < 4) return S == 0 ? L : __builtin_amdgcn_alignbyte(C, L, (uint32_t)S);
+  if (S < 8) return S == 4 ? C : __builtin_amdgcn_alignbyte(R, C, (uint32_t)(S - 4));
+  return R;
+}
+template <int K>
+__device__ __forceinline__ int gauss_row1(uint32_t L, uint32_t C, uint32_t R, uint32_t T1, uint32_t T2) {
+  const uint32_t a = win4<K + 1>(L, C, R), b = win4<K + 5>(L, C, R);
+  return (int)__builtin_amdgcn_udot4(b, T2, __builtin_amdgcn_udot4(a, T1, 0u, false), false);
+}
+__device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t R, uint32_t T1, uint32_t T2, float* h) {
+  h[0] = (float)(uint32_t)gauss_row1<0>(L, C, R, T1, T2);  // < 2^16: exact
+  h[1] = (float)(uint32_t)gauss_row1<1>(L, C, R, T1, T2);
+  h[2] = (float)(uint32_t)gauss_row1<2>(L, C, R, T1, T2);
+  h[3] = (float)(uint32_t)gauss_row1<3>(L, C, R, T1, T2);
+}
+
+constexpr int GS_TILES = 16;  // tiles a wavefront collects per 8-row group: 15 of a full strip, 2 x 7 / 4 x 3 of the narrow ones
+// SSE2: the rounding contract of an x86-64 OpenCV build (UVO_TUNE_BLUR_ROUNDING): SymmColumnVec_32s8u's vector body -- image columns
+// 0 .. (w & ~3) - 1 -- converts the exact fp32 column sum with cvtps2dq, i.e. an exact .5 goes to the EVEN neighbour; the last w % 4
+// columns (its scalar tail) and the default contract round .5 up.  A lane's four pixels are an aligned group of four image columns, so
+// a lane is wholly one or the other.
+constexpr int GS_TILE_DW = GS_TILES * 32 + 96;   // LDS dwords per wavefront: the tiles + a dword per lane (and row phase) for the lanes that collect nothing
+constexpr int GS_LDS_BYTES = 4 * GS_TILE_DW * 4;  // per 4-wavefront workgroup
+// The body of a k_gauss7 workgroup: `block` of `blocks_x * batch` (frame-major in an XCD-contiguous order), LDS = GS_LDS_BYTES at s_tile.
+// Also run by the workgroups of k_octree_gauss (octree.hip) that are not quad-tree problems.
+template <bool SSE2>
+__device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, uint32_t (*s_tile)[GS_TILE_DW], const uint8_t* __restrict__ pyr,
+                                            uint8_t* __restrict__ blur, int64_t pyr_block, const LevelGeom* __restrict__ lv, int nlevels, int4 taps, int rows_per_seg) {
+  // work item (one per wavefront) -> (level, strip, segment group); narrow remainder strips hold 2 or 4 row segments side by side
+  // (fast_strip_plan), so a level costs about as many wavefront-rows as its width needs
+  const int vb = xcd_contiguous(block, blocks_x * batch);
+  const int vbx = vb % blocks_x, f = vb / blocks_x;  // an XCD walks whole frames, item after item
+  int item = vbx * 4 + wave_in_block();
+  const int lane = threadIdx.x & 63;
+  int level = 0;
+  StripPlan plan;
+  for (;; ++level) {
+    fast_strip_plan(lv[level].w + 8, lv[level].h + 8, rows_per_seg, plan);
+    if (item < plan.items) break;
+    item -= plan.items;
+    if (level == nlevels - 1) return;
+  }
+  const LevelGeom g = lv[level];
+  int strip_x, seg, nsub;
+  fast_strip_item(plan, item, strip_x, seg, nsub);
+  const uint8_t* src = pyr + f * pyr_block + g.plane_off;
+  uint8_t* dst = blur + f * pyr_block + g.plane_off;
+
+  const int lps = 64 / nsub, sub = (lane * nsub) >> 6, ls = lane - sub * lps;
+  // padded-plane column of this lane's dword; the first lane of a sub-strip is its left halo.  Region = padded cols [12, w+20).
+  const int X = 8 + strip_x + ls * 4;
+  const int Xc = X > g.pitch - 4 ? g.pitch - 4 : X;  // clamp loads into the row (only halo / out-of-region lanes)
+  // padded-plane rows: region rows [12, h+20); the lane's segment rows [py0l, py1l)
+  const int py0 = 12 + seg * rows_per_seg;
+  const int py0l = py0 + sub * rows_per_seg;
+  const int py1l = min(py0l + rows_per_seg, g.h + 20);
+  const bool lane_out = ls >= 1 && ls <= lps - 2 && X >= 12 && X < g.w + 20 && py1l > py0l;
+  const int tile_col = (X >> 4) * 128 + (X & 15);   // the lane's place inside a row of tiles
+  const int64_t tile_row_bytes = (int64_t)g.pitch * 8;  // (pitch / 16) tiles of 128 bytes
+  // Output goes to the plane in whole cache lines: the tiles a sub-strip's output lanes cover completely (columns
+  // [16 t_first, 16 (t_last + 1)) of its output range) are collected in LDS -- eight rows of the walk fill them -- and written out as
+  // 16 bytes per lane, eight lanes per 128-byte line; the few columns left and right of them are stored directly, a dword per row.
+  const int x_lo = max(12, 8 + strip_x + 4), x_hi = min(g.w + 20, 8 + strip_x + 4 * (lps - 1));  // output columns of the sub-strip
+  const int t_first = (x_lo + 15) >> 4, nts = max((x_hi >> 4) - t_first, 0);                    // its full tiles: t_first .. t_first + nts - 1
+  const int ts_shift = nsub == 1 ? 4 : (nsub == 2 ? 3 : 2), TS = 1 << ts_shift;                 // LDS tile slots per sub-strip (16 / nsub >= nts)
+  const bool via_lds = lane_out && (X >> 4) >= t_first && (X >> 4) < t_first + nts;
+  uint32_t* stile = s_tile[wave_in_block()];
+  // + (py & 7) * 4: dword of the lane's pixels in the tile.  Lanes that collect nothing write their own dword behind the tiles -- the
+  // LDS write of a row is then unconditional (no exec mask to set up and restore: scalar instructions are not free)
+  const int lds_slot = via_lds ? ((sub * TS + ((X >> 4) - t_first)) << 5) + ((X & 15) >> 2) : GS_TILES * 32 + lane;
+  // The write-out of a group: task t = lane + 64 it (it = 0, 1) is row t & 7 of tile slot t >> 3; everything about a task that does not
+  // depend on the group is worked out here, once.
+  // (row addresses: a sub-strip's rows lie s * rows_per_seg below sub-strip 0's, a whole number of tile rows, so every address is
+  // "tile row of sub-strip 0" -- wave-uniform, scalar arithmetic -- plus a per-lane constant)
+  const int64_t seg_tile_rows = (int64_t)(rows_per_seg >> 3) * tile_row_bytes;
+  const int64_t lane_goff = (int64_t)sub * seg_tile_rows + tile_col;  // the lane's own dword relative to sub-strip 0's tile row
+  int f_lds[2], f_p0[2], f_p1[2], f_rowoff[2];
+  int64_t f_goff[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int t = lane + 64 * it, row = t & 7, slot = t >> 3, s_ = slot >> ts_shift, ti = slot & (TS - 1);
+    const int p0 = py0 + s_ * rows_per_seg;
+    f_lds[it] = (slot << 5) + (row << 2);
+    f_goff[it] = (int64_t)s_ * seg_tile_rows + (t_first + ti) * 128 + (row << 4);
+    f_rowoff[it] = s_ * rows_per_seg + row;
+    f_p0[it] = p0, f_p1[it] = (s_ < nsub && ti < nts) ? min(p0 + rows_per_seg, g.h + 20) : p0;  // empty range: no such tile
+  }
+  // writes rows 0 .. r_hi of the 8-row group that starts at padded row pyg (of sub-strip 0) of every collected tile to the plane
+  auto flush_tiles = [&](int pyg, int r_hi, int64_t group_base) {  // group_base = byte offset of the group's tile row (sub-strip 0)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int prow = pyg + f_rowoff[it];  // the row of the task's own sub-strip in the plane
+      if ((lane & 7) <= r_hi && prow >= f_p0[it] && prow < f_p1[it]) {
+        const uint4 v = *reinterpret_cast<const uint4*>(stile + f_lds[it]);
+        *reinterpret_cast<uint4*>(dst + (group_base + f_goff[it])) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  const bool even_ties = SSE2 && (X - kPad) < (g.w & ~3);  // the lane's image columns belong to the vector body
+  uint32_t inmask = 0;  // bytes of the lane's dword that lie inside the image columns
+#pragma unroll
+  for (int k = 0; k < 4; ++k) inmask |= (X + k >= kPad && X + k < g.w + kPad) ? 0xffu << (8 * k) : 0u;
+  const int nsrc = min(py0 + rows_per_seg, g.h + 20) - py0 + 6;  // source rows py0-3 .. py1+2 of sub-strip 0 (the longest)
+  // per lane, in loop rows: output row py = py0l + j - 6 lies inside the image rows for j in [j_in0, j_in0 + n_in), and the lane stores
+  // it directly (an output lane outside the collected tiles) for j < j_edge1
+  const uint32_t j_in0 = (uint32_t)(kPad - py0l + 6), n_in = (uint32_t)g.h;
+  const uint32_t j_edge1 = (lane_out && !via_lds) ? (uint32_t)max(py1l - py0l + 6, 0) : 0u;
+
+  const uint32_t T1 = (uint32_t)taps.x | ((uint32_t)taps.y << 8) | ((uint32_t)taps.z << 16) | ((uint32_t)taps.w << 24);
+  const uint32_t T2 = (uint32_t)taps.z | ((uint32_t)taps.y << 8) | ((uint32_t)taps.x << 16);
+  // column taps scaled by 2^-16 (exact): the column sum comes out as sum / 65536, and + 0.5 makes its floor the rounded result
+  const float c0 = (float)taps.x * (1.0f / 65536.0f), c1 = (float)taps.y * (1.0f / 65536.0f), c2 = (float)taps.z * (1.0f / 65536.0f),
+              c3 = (float)taps.w * (1.0f / 65536.0f);
+  __builtin_amdgcn_s_setreg(0x801, 3);  // MODE.fp_round[1:0] (fp32) = toward zero: nothing below rounds except the final float -> byte conversion
+  const int lane_up = (lane > 0 ? lane - 1 : lane) * 4, lane_down = (lane < 63 ? lane + 1 : lane) * 4;  // ds_bpermute byte addresses
+  float hring[7][4];
+  uint32_t cring[7];
+  // Row loads are issued one unrolled block (7 rows) ahead of their use: a wavefront walks ~70 rows one after another, so
+  // without the prefetch every row would expose a full memory round trip.
+  auto load_row = [&](int j) -> uint32_t {
+    int prow = py0l - 3 + j;
+    prow = prow > g.ph - 1 ? g.ph - 1 : prow;  // rows past the plane are never used by a valid output
+    return *reinterpret_cast<const uint32_t*>(src + (int64_t)prow * g.pitch + Xc);
+  };
+  // byte offset of sub-strip 0's current output row inside its tile column: tile row * tile_row_bytes + (row % 8) * 16, advanced row by
+  // row (one scalar add instead of a 64-bit multiply per row)
+  int64_t rowb = (int64_t)(py0 >> 3) * tile_row_bytes + ((py0 & 7) << 4);
+  int phase = (py0 - 6) & 7;  // (row of sub-strip 0) & 7 of loop row j = 0, advanced with it
+  uint32_t cur[7], nxt[7];
+#pragma unroll
+  for (int u = 0; u < 7; ++u) cur[u] = load_row(u);  // unconditional (the row index is clamped into the plane): with a branch around a load
+                                                     // the compiler cannot count the loads in flight and waits for all of them
+  for (int base = 0; base < nsrc; base += 7) {
+#pragma unroll
+    for (int u = 0; u < 7; ++u) nxt[u] = load_row(base + 7 + u);
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int j = base + u;
+      if (j < nsrc) {
+        const uint32_t C = cur[u];
+        const uint32_t L = (uint32_t)__builtin_amdgcn_ds_bpermute(lane_up, (int)C);    // the neighbours' dwords: source lanes fixed for the
+        const uint32_t R = (uint32_t)__builtin_amdgcn_ds_bpermute(lane_down, (int)C);  // whole strip (__shfl_up / _down recompute them per call)
+        gauss_row_pass(L, C, R, T1, T2, hring[u]);
+        cring[u] = C;
+        const int phase_now = phase;
+        phase = (phase + 1) & 7;
+        if (j >= 6) {
+          // output row py = py0l + j - 6; its 7 source rows sit in ring slots (u+1)%7 .. (u+7)%7
+          const float* r0 = hring[(u + 1) % 7];
+          const float* r1 = hring[(u + 2) % 7];
+          const float* r2 = hring[(u + 3) % 7];
+          const float* r3 = hring[(u + 4) % 7];
+          const float* r4 = hring[(u + 5) % 7];
+          const float* r5 = hring[(u + 6) % 7];
+          const float* r6 = hring[u];
+          const uint32_t centre = cring[(u + 4) % 7];
+          const bool row_in = (uint32_t)j - j_in0 < n_in;
+          // column pass: sum / 2^16 + 0.5, every partial sum an exact multiple of 2^-16 below 2^8 (a larger one belongs to a result
+          // that saturates anyway); floor, clamp to 255 and the byte insert are the conversion itself
+          uint32_t blurred = 0, ties = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float z = __builtin_fmaf(c0, r0[k] + r6[k], __builtin_fmaf(c1, r1[k] + r5[k], __builtin_fmaf(c2, r2[k] + r4[k], __builtin_fmaf(c3, r3[k], 0.5f))));
+            blurred = __builtin_amdgcn_cvt_pk_u8_f32(z, (uint32_t)k, blurred);
+            // sum / 2^16 + 1/2 a whole number: the sum sat exactly between two bytes (and below the saturation edge)
+            if (SSE2) ties |= (__builtin_amdgcn_fractf(z) == 0.0f && z < 256.0f) ? 1u << (8 * k) : 0u;
+          }
+          if (SSE2 && even_ties) blurred -= ties & blurred;  // half up gave the upper neighbour: where that one is odd, the even one is below it
+          // pad ring and anything outside the image: the un-blurred centre pixel (byte mask per lane, rows uniform)
+          const uint32_t m = row_in ? inmask : 0u;
+          const uint32_t out = (blurred & m) | (centre & ~m);
+          // tiled store: pixel (x, y) of the blurred plane lives in tile (y / 8, x / 16) -- 128 bytes, one cache line -- at byte
+          // (y % 8) * 16 + x % 16 (a lane's four pixels never straddle a tile: X is a multiple of 4).  Four lanes fill a tile row,
+          // eight consecutive rows of the walk complete the line in L2.
+          // (py & 7 is the same for every sub-strip: their first rows differ by multiples of rows_per_seg, a multiple of 8)
+          stile[lds_slot + (phase_now << 2)] = out;
+          if ((uint32_t)j < j_edge1) *reinterpret_cast<uint32_t*>(dst + rowb + lane_goff) = out;
+          if (phase_now == 7) {
+            flush_tiles(py0 + j - 6 - 7, 7, rowb - 112);
+            rowb += tile_row_bytes - 112;
+          } else {
+            rowb += 16;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) cur[u] = nxt[u];
+  }
+  {  // the rows of the last, incomplete group
+    const int py_last = py0 + nsrc - 7;  // last output row of sub-strip 0
+    if ((py_last & 7) != 7) flush_tiles(py_last & ~7, py_last & 7, (int64_t)(py_last >> 3) * tile_row_bytes);
+  }
+}
+
+
+}  // namespace uvo

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <mutex>
 #include "common.hpp"
+#include "gauss_body.hpp"
 #include "fast_geom.hpp"
 #include "octree_pyramid.hpp"
 
@@ -43,15 +44,12 @@ static inline size_t oct_lds_bytes(int M, int Mp2, int pyr_words) {
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max, int pyr_words, int box_region, int lds_bytes,
-                                                        FastLevels FL, const uint32_t* __restrict__ cand_lo,
-                                                        int32_t* __restrict__ cursor, int32_t* __restrict__ fcount, int32_t* __restrict__ n_cell_list, uint8_t* cell_hi,
-                                                        uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc,
-                                                        int64_t cand_block, int32_t* __restrict__ cand_count,
-                                                        uint32_t* __restrict__ pstate, uint32_t* __restrict__ sel_xy,
-                                                        uint32_t* __restrict__ sel_sc, int sel_block, int32_t* __restrict__ sel_count) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  const int level = blockIdx.y, f = blockIdx.x;  // level-major dispatch: the long level-0 problems start first
+__device__ __forceinline__ void octree_body(uint8_t* lds, const int level, const int f, const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max, int pyr_words,
+                                            int box_region, int lds_bytes, const FastLevels& FL, const uint32_t* __restrict__ cand_lo,
+                                            int32_t* __restrict__ cursor, int32_t* __restrict__ fcount, int32_t* __restrict__ n_cell_list, uint8_t* cell_hi,
+                                            uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc, int64_t cand_block, int32_t* __restrict__ cand_count,
+                                            uint32_t* __restrict__ pstate, uint32_t* __restrict__ sel_xy, uint32_t* __restrict__ sel_sc, int sel_block,
+                                            int32_t* __restrict__ sel_count) {
 #ifdef UVO_OCT_TRACE
   const unsigned long long t_begin = wall_clock64();
   struct Stamp {
@@ -139,7 +137,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
     // sets / advances them)
     for (int i = threadIdx.x; i < n_flags; i += NT) hi[i] = 0;
     if (threadIdx.x == 0) cur[0] = 0, cur[1] = 0;
-    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) *n_cell_list = 0;  // the consumed list of fall-back cells (k_fast_cells_list)
+    if (threadIdx.x == 0 && level == 0 && f == 0) *n_cell_list = 0;  // the consumed list of fall-back cells (k_fast_cells_list)
   }
   // The lane's adaptive FAST mode: a level streams either at fastTh, with the sparse literal-7 pass over the cells left empty
   // (k_fast_cells), or once at 7 with the vote above; both give the same candidates, the cheaper one depends on how many cells fall
@@ -209,6 +207,58 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
   if (threadIdx.x == 0) *out_n = n;
 }
 
+template <int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max, int pyr_words, int box_region, int lds_bytes,
+                                                        FastLevels FL, const uint32_t* __restrict__ cand_lo,
+                                                        int32_t* __restrict__ cursor, int32_t* __restrict__ fcount, int32_t* __restrict__ n_cell_list, uint8_t* cell_hi,
+                                                        uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc,
+                                                        int64_t cand_block, int32_t* __restrict__ cand_count,
+                                                        uint32_t* __restrict__ pstate, uint32_t* __restrict__ sel_xy,
+                                                        uint32_t* __restrict__ sel_sc, int sel_block, int32_t* __restrict__ sel_count) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  // level-major dispatch: the long level-0 problems start first
+  octree_body<NT>(lds, (int)blockIdx.y, (int)blockIdx.x, lv, nlevels, Mmax, Mp2max, pyr_words, box_region, lds_bytes, FL, cand_lo, cursor, fcount, n_cell_list, cell_hi, cand_xy,
+                  cand_sc, cand_block, cand_count, pstate, sel_xy, sel_sc, sel_block, sel_count);
+}
+
+// DistributeOctTree and GaussianBlur in ONE launch (src/ORBextractor.cc:1006-1287 and :942: neither reads what the other writes).  The
+// quad-tree is a chain of dependent phases per (frame, level) -- two thousand workgroups that mostly wait -- the blur a streaming kernel
+// that fills the chip: as two launches of one stream they run one after the other (and another lane's kernels hide little of it: every
+// heavy kernel fills the chip by itself); as one grid -- the quad-tree problems first, level-major, the blur's
+// workgroups behind them -- the blur streams through the issue slots the quad-tree leaves idle.
+struct GaussArgs {
+  const uint8_t* pyr;
+  uint8_t* blur;
+  int64_t pyr_block;
+  int4 taps;
+  int rows_per_seg, blocks_x, batch;
+};
+template <bool SSE2>
+__global__ __launch_bounds__(256, 4) void k_octree_gauss(int n_oct, GaussArgs G, const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max, int pyr_words, int box_region,
+                                                        int lds_bytes, FastLevels FL, const uint32_t* __restrict__ cand_lo, int32_t* __restrict__ cursor,
+                                                        int32_t* __restrict__ fcount, int32_t* __restrict__ n_cell_list, uint8_t* cell_hi,
+                                                        uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc, int64_t cand_block,
+                                                        int32_t* __restrict__ cand_count, uint32_t* __restrict__ pstate, uint32_t* __restrict__ sel_xy,
+                                                        uint32_t* __restrict__ sel_sc, int sel_block, int32_t* __restrict__ sel_count) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  // Workgroups are dispatched in index order, and all of them reserve the same LDS: with the quad-tree problems in front they would take
+  // every slot of every CU and the blur would start when they are done.  Interleaved -- every third workgroup a quad-tree problem (level-
+  // major: the long level-0 problems first), the others the blur -- a CU holds both kinds from the start.
+  int b = (int)blockIdx.x, o = -1;
+  if (b < 3 * n_oct) {
+    if (b % 3 == 0) o = b / 3;
+    else b -= b / 3 + 1;
+  } else {
+    b -= n_oct;
+  }
+  if (o >= 0) {
+    octree_body<256>(lds, o / G.batch, o % G.batch, lv, nlevels, Mmax, Mp2max, pyr_words, box_region, lds_bytes, FL, cand_lo, cursor, fcount, n_cell_list, cell_hi, cand_xy, cand_sc,
+                     cand_block, cand_count, pstate, sel_xy, sel_sc, sel_block, sel_count);
+  } else {
+    gauss7_body<SSE2>(b, G.blocks_x, G.batch, reinterpret_cast<uint32_t(*)[GS_TILE_DW]>(lds), G.pyr, G.blur, G.pyr_block, lv, nlevels, G.taps, G.rows_per_seg);
+  }
+}
+
 // LDS the quad-tree kernel needs for this geometry (M = the largest node table, its power of two, the count pyramid)
 static size_t octree_lds(const Geom& g, int& M, int& Mp2, int& pyr_words) {
   M = 0;
@@ -275,6 +325,39 @@ int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, cons
                        d_cand_lo, d_cursor, d_fcount, d_n_cell_list, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block,
                        d_sel_count);
   return UVO_OK;
+}
+
+
+int gauss7_rows_per_seg(int batch);
+int gauss7_blocks_per_frame(const Geom& g, int rows_per_seg);
+
+// true when the batch's quad-tree problems take the 256-thread form, i.e. when launch_octree_gauss applies (small batches run the
+// quad-tree as 1024-thread workgroups, one per CU: the two kernels stay apart there)
+bool octree_gauss_applies(const OctLaunchState& st, const Geom& g, int batch) {
+  int M, Mp2, pyr_words;
+  return batch * g.nlevels > st.wide_max_problems && octree_lds(g, M, Mp2, pyr_words) <= 64 * 1024 &&
+         gauss7_blocks_per_frame(g, gauss7_rows_per_seg(batch)) >= 2 * g.nlevels;  // (the interleave below needs two blur workgroups per quad-tree problem)
+}
+
+void launch_octree_gauss(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, int4 taps, int sse2_rounding,
+                         const uint32_t* d_cand_lo, int32_t* d_cursor, int32_t* d_fcount, int32_t* d_n_cell_list, uint8_t* d_cell_hi, uint32_t* d_cand_xy,
+                         uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
+                         int32_t* d_sel_count, int batch) {
+  int M, Mp2, pyr_words;
+  const size_t lds = std::max(octree_lds(g, M, Mp2, pyr_words), (size_t)GS_LDS_BYTES);
+  GaussArgs G;
+  G.pyr = d_pyr, G.blur = d_blur, G.pyr_block = pyr_block, G.taps = taps, G.batch = batch;
+  G.rows_per_seg = gauss7_rows_per_seg(batch), G.blocks_x = gauss7_blocks_per_frame(g, G.rows_per_seg);
+  const int n_oct = batch * g.nlevels;
+  const dim3 grid(n_oct + G.blocks_x * batch);
+  if (sse2_rounding)
+    hipLaunchKernelGGL(k_octree_gauss<true>, grid, dim3(256), lds, s, n_oct, G, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), (int)lds,
+                       fast_levels(g, batch), d_cand_lo, d_cursor, d_fcount, d_n_cell_list, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc,
+                       g.sel_block, d_sel_count);
+  else
+    hipLaunchKernelGGL(k_octree_gauss<false>, grid, dim3(256), lds, s, n_oct, G, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), (int)lds,
+                       fast_levels(g, batch), d_cand_lo, d_cursor, d_fcount, d_n_cell_list, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc,
+                       g.sel_block, d_sel_count);
 }
 
 }  // namespace uvo

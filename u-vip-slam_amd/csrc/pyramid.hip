@@ -684,4 +684,12 @@ void launch_pyr_stream(hipStream_t s, const PyrStreamArgs& A, bool fast, int bat
     hipLaunchKernelGGL(k_pyr_stream<false>, dim3(blocks_per_frame * batch), dim3(256), 0, s, A);
 }
 
+
+// development probe: one wavefront that does nothing for `us` microseconds (what does pure latency in a lane cost the step?)
+__global__ void k_probe_delay(int us) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(32);
+}
+void launch_probe_delay(hipStream_t s, int us) { hipLaunchKernelGGL(k_probe_delay, dim3(1), dim3(64), 0, s, us); }
+
 }  // namespace uvo
