@@ -253,6 +253,9 @@ int uvo_extractor_set_pipeline(uvo_extractor* h, int depth);
  *                           Which of the two the reference's binary executes is not decidable without OpenCV 3.4.x at hand
  *                           (tools/pin/ dumps both cases' evidence: the day it runs, this knob's default follows).
  */
+#define UVO_TUNE_LEVEL0_INPLACE 11 /* 1 (default): level 0 is read from the caller's image in place whenever it can be (dword-aligned rows, width a
+                                     multiple of 4, no caller keypoints): cv::copyMakeBorder of src/ORBextractor.cc:996 is never materialised, the
+                                     blur reflects the border it needs on the fly; 0: always copy into a padded plane first */
 #define UVO_TUNE_FUSE_BLUR_TREE 10 /* 1 (default): DistributeOctTree and GaussianBlur share one launch when the batch is large enough for the
                                      256-thread quad-tree form (neither reads what the other writes); 0: two launches */
 #define UVO_TUNE_BLUR_ROUNDING 9

@@ -29,6 +29,7 @@ UVO_TUNE_PYR_BANDS, UVO_TUNE_PYR_WAVES, UVO_TUNE_PYR_ROWS, UVO_TUNE_PYR_MODE, UV
 UVO_PYR_MODE_CHAIN, UVO_PYR_MODE_SPLIT = 0, 1
 UVO_TUNE_BLUR_ROUNDING, UVO_BLUR_ROUNDING_SCALAR, UVO_BLUR_ROUNDING_SSE2 = 9, 0, 1
 UVO_TUNE_FUSE_BLUR_TREE = 10
+UVO_TUNE_LEVEL0_INPLACE = 11
 
 # every symbol include/uvo/uvo.h declares
 ABI_SYMBOLS = [
@@ -478,9 +479,11 @@ class ORBextractor:
         if rc:
             raise UvoError(rc, "uvo_extract_batch_wait")
 
-    def extract_batch_device(self, d_imgs, batch, width, height, d_out_kp, d_out_desc, d_n_out, cap=None):
-        """HBM-resident FullDetect extraction; all arguments are integer device addresses.  Asynchronous."""
-        rc = lib.uvo_extract_batch_device(self._h, batch, d_imgs, width, height, width, width * height, None, None, None, 0, 0, 0, 1, None,
+    def extract_batch_device(self, d_imgs, batch, width, height, d_out_kp, d_out_desc, d_n_out, cap=None, stride=None, frame_stride=None):
+        """HBM-resident FullDetect extraction; all arguments are integer device addresses (rows `stride` bytes apart, frames `frame_stride`;
+        tight by default).  Asynchronous: the images must stay as they are until the batch is complete."""
+        stride = stride or width
+        rc = lib.uvo_extract_batch_device(self._h, batch, d_imgs, width, height, stride, frame_stride or stride * height, None, None, None, 0, 0, 0, 1, None,
                                           d_out_kp, d_out_desc, cap or self.cap, d_n_out)
         if rc:
             raise UvoError(rc, "uvo_extract_batch_device")

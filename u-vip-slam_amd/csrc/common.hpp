@@ -47,6 +47,17 @@ struct LevelGeom {
   int ytab_off;        // same for the row table (ph entries)
 };
 
+// Level 0 read in place: the caller's image instead of the padded plane (cv::copyMakeBorder at :996 is then never materialised).
+// vbase = image - 16 * pitch - 16: the address padded coordinates (row, column) of level 0 would have if the image sat inside a padded
+// plane of row pitch `pitch`; only pixels inside the image may be dereferenced (a reader that needs the 16-pixel border reflects the
+// index itself).  vbase = NULL: level 0 is the padded plane like every other level.
+struct Level0View {
+  const uint8_t* vbase;
+  int64_t frame_stride;
+  int pitch;
+  int pad;
+};
+
 struct CellDesc {  // one FAST cell (src/ORBextractor.cc:773-790)
   int16_t level;
   int16_t x0, y0;    // ROI origin in level coordinates (iniX, iniY)
@@ -104,7 +115,7 @@ int fail(int code, const char* msg);  // records msg for uvo_last_error() and re
 void launch_pad_level0(hipStream_t s, const uint8_t* d_img, int w, int h, int64_t stride, int64_t frame_stride, uint8_t* d_pyr,
                        int64_t pyr_block, const LevelGeom& g0, int batch);
 void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const LevelGeom& src, const LevelGeom& dst, const ResizeCol* d_ctab,
-                         const ResizeRow* d_rtab, int fast_ok, int batch);
+                         const ResizeRow* d_rtab, int fast_ok, int batch, Level0View l0);
 // the fused pyramid kernel's schedule of one band count, on the device (pyr_schedule.hpp)
 struct PyrPlanDev {
   int nbands = 0, nwaves = 0, nslots = 0, nsteps = 0;
@@ -139,12 +150,13 @@ int launch_pyramid(hipStream_t s, const uint8_t* d_img, int64_t stride, int64_t 
                    const int* fast_ok, const PyrPlanDev& plan, const ResizeCol* d_ctab, int batch);
 void launch_probe_delay(hipStream_t s, int us);
 void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g, int4 taps,
-                   int batch, int sse2_rounding);
+                   int batch, int sse2_rounding, Level0View l0);
 void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, int fast_th, const int32_t* d_tpass, uint32_t* d_cor,
-                       uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, uint32_t* d_cand_lo, int64_t cand_block, int32_t* d_cursor, int batch);
+                       uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, uint32_t* d_cand_lo, int64_t cand_block, int32_t* d_cursor, int batch,
+                       Level0View l0);
 void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, const CellDesc* d_cells, const int32_t* d_flag_cell,
                        const int32_t* d_tpass, const uint8_t* d_cell_hi, uint2* d_list, int32_t* d_n_list, uint32_t* d_cand_xy, uint32_t* d_cand_sc,
-                       int64_t cand_block, int32_t* d_cursor, int batch);
+                       int64_t cand_block, int32_t* d_cursor, int batch, Level0View l0);
 void launch_grider(hipStream_t s, const uint8_t* d_img, int w, int h, int64_t stride, int num_features, int grid_x, int grid_y, int threshold,
                    int nms, uint8_t* d_score, uint32_t* d_lists, int32_t* d_counts, uvo_keypoint* d_out, int cap, int32_t* d_n_out);
 int fast_rows_per_seg(int batch);
@@ -159,7 +171,7 @@ bool octree_gauss_applies(const OctLaunchState& st, const Geom& g, int batch);
 void launch_octree_gauss(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, int4 taps, int sse2_rounding,
                          const uint32_t* d_cand_lo, int32_t* d_cursor, int32_t* d_fcount, int32_t* d_n_cell_list, uint8_t* d_cell_hi, uint32_t* d_cand_xy,
                          uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
-                         int32_t* d_sel_count, int batch);
+                         int32_t* d_sel_count, int batch, Level0View l0);
 int prepare_octree(const Geom& g);  // the part of the quad-tree launch that can fail (called before a batch's first kernel)
 int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_lo, int32_t* d_cursor,
                    int32_t* d_fcount, int32_t* d_n_cell_list, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate,
@@ -184,7 +196,7 @@ void launch_medoid(hipStream_t s, const uint8_t* d_desc, const int32_t* d_offset
 void launch_matrix(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, uint16_t* d_dist);
 void launch_describe(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, const uint8_t* d_blur, int64_t pyr_block,
                      const FinalSlot* d_flist, const int32_t* d_n_final, const uvo_keypoint* d_in_kp, int in_cap, const float* d_pattern,
-                     const uint32_t* d_patch, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch);
+                     const uint32_t* d_patch, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch, Level0View l0);
 
 void launch_clahe(hipStream_t s, const uint8_t* d_src, int w, int h, int64_t stride, int64_t frame_stride, int batch, int tiles_x, int tiles_y,
                   int tile_w, int tile_h, int clip_limit, float lut_scale, uint8_t* d_lut, uint8_t* d_dst, int64_t dst_stride,

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * DK_WAVES, UVO_OCC_DESCRIBE) void k_describe(co
                                                   const FinalSlot* __restrict__ flist, int flist_cap, const int32_t* __restrict__ n_final,
                                                   const uvo_keypoint* __restrict__ in_kp, int in_cap, const float* __restrict__ pattern,
                                                   const uint32_t* __restrict__ patch, uvo_keypoint* __restrict__ out_kp,
-                                                  uint8_t* __restrict__ out_desc, int cap, int32_t* __restrict__ n_out) {
+                                                  uint8_t* __restrict__ out_desc, int cap, int32_t* __restrict__ n_out, Level0View l0) {
   // a frame's keypoints stay on one XCD: their 37-row windows overlap heavily (1000 windows cover a level about once), and with
   // round-robin placement every XCD's L2 would fetch the same lines
   const int vb = xcd_contiguous((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
@@ -275,7 +275,8 @@ __global__ __launch_bounds__(64 * DK_WAVES, UVO_OCC_DESCRIBE) void k_describe(co
   uint32_t(*win)[DW_DWORDS] = s_win[wave_in_block()];
   uvo_keypoint kp[DK_PER_WAVE];
   int64_t center_off[DK_PER_WAVE];
-  int pitch[DK_PER_WAVE];
+  int pitch[DK_PER_WAVE], ppitch[DK_PER_WAVE];
+  const uint8_t* pbase[DK_PER_WAVE];
   float scale[DK_PER_WAVE];
   bool rescale[DK_PER_WAVE], live[DK_PER_WAVE];
   uint32_t px[DK_PER_WAVE][4];
@@ -329,22 +330,26 @@ __global__ __launch_bounds__(64 * DK_WAVES, UVO_OCC_DESCRIBE) void k_describe(co
     if (!is_input[k]) kp[k].size = g.patch_size;
     rescale[k] = !is_input[k] && level[k] != 0;
     center_off[k] = f * pyr_block + g.plane_off;  // completed below
+    // level 0 read in place: the orientation patch (rows +-15, columns -16 .. +15 around a keypoint at least 16 pixels inside) lies in the
+    // caller's image -- its own base and row pitch; the blurred window below always comes from the (tiled) blurred plane
+    ppitch[k] = g.pitch, pbase[k] = pyr;
+    if (level[k] == 0 && l0.vbase != nullptr) ppitch[k] = l0.pitch, pbase[k] = l0.vbase, center_off[k] = f * l0.frame_stride;
   }
 #pragma unroll
   for (int k = 0; k < DK_PER_WAVE; ++k) {
     // (every lane holds the same keypoint; saying so puts the addresses below into scalar registers)
     const int cx = __builtin_amdgcn_readfirstlane(cv_round(kp[k].x)), cy = __builtin_amdgcn_readfirstlane(cv_round(kp[k].y));
-    center_off[k] += (int64_t)(cy + kPad) * pitch[k] + (cx + kPad);
+    center_off[k] += (int64_t)(cy + kPad) * ppitch[k] + (cx + kPad);
     // Addresses = a wave-uniform base (18 rows above and 18 bytes left of the keypoint: the corner of the blurred window, which the
     // loads below reach anyway) + a non-negative 32-bit lane offset: one multiply-add per load instead of 64-bit arithmetic per lane.
-    const int64_t corner_off = center_off[k] - (int64_t)18 * pitch[k] - 18;
+    const int64_t corner_off = center_off[k] - (int64_t)18 * ppitch[k] - 18;
     // IC_Angle: the circular patch (rows v in [-15,15], |u| <= umax[|v|]) is read as 31 rows x 8 dwords starting at u = -16;
     // a table masks the bytes outside the circle (slots 248..255 = "row 31" are masked out entirely) -- applied in stage B
-    const uint8_t* pcorner = pyr + corner_off;
+    const uint8_t* pcorner = pbase[k] + corner_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int vr = vv[i] <= 15 ? vv[i] : 15;  // keep the (masked) load of row 31 inside the plane
-      __builtin_memcpy(&px[k][i], pcorner + (uint32_t)((vr + 18) * pitch[k] + (u0[i] + 18)), 4);
+      __builtin_memcpy(&px[k][i], pcorner + (uint32_t)((vr + 18) * ppitch[k] + (u0[i] + 18)), 4);
     }
     // blurred window: whole tiles of the tiled plane.  Window corner in padded coordinates (x0, y0) = (cx + 16 - 18, cy + 16 - 18);
     // tile grid origin (x0 / 16, y0 / 8); tiles beyond the window's last column / row are clamped onto the last one (loaded twice,
@@ -526,10 +531,10 @@ void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, FastAd
 
 void launch_describe(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, const uint8_t* d_blur, int64_t pyr_block,
                      const FinalSlot* d_flist, const int32_t* d_n_final, const uvo_keypoint* d_in_kp, int in_cap, const float* d_pattern,
-                     const uint32_t* d_patch, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch) {
+                     const uint32_t* d_patch, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch, Level0View l0) {
   const int slots = g.flist_cap < cap ? g.flist_cap : cap;
   hipLaunchKernelGGL(k_describe, dim3((slots + DK_WAVES * DK_PER_WAVE - 1) / (DK_WAVES * DK_PER_WAVE), batch), dim3(64 * DK_WAVES), 0, s, d_lv, g.nlevels, d_pyr, d_blur, pyr_block, d_flist,
-                     g.flist_cap, d_n_final, d_in_kp, in_cap, d_pattern, d_patch, d_out_kp, d_out_desc, cap, d_n_out);
+                     g.flist_cap, d_n_final, d_in_kp, in_cap, d_pattern, d_patch, d_out_kp, d_out_desc, cap, d_n_out, l0);
 }
 
 }  // namespace uvo

@@ -74,6 +74,9 @@ struct Lane {
   // only when the lane's last but one has finished, so at most two batches of a lane are ever outstanding.
   hipEvent_t done[2] = {nullptr, nullptr};
   unsigned n_enqueued = 0;
+  // level 0 of the lane's last batch was read in place (no padded plane was written): what uvo_extractor_read_plane needs to make one
+  const uint8_t* l0_src = nullptr;
+  int64_t l0_stride = 0, l0_frame_stride = 0;
 };
 
 struct uvo_matcher;
@@ -121,6 +124,7 @@ struct uvo_extractor {
   int pyr_bands_forced = 0;  // UVO_TUNE_PYR_BANDS: 0 = by batch size
   int pyr_waves = 0;         // UVO_TUNE_PYR_WAVES: at least this many wavefronts per workgroup (0: the smallest shape that holds the roles)
   int pyr_rows = 7;          // level-0 rows per macro-step
+  int level0_inplace = 1;    // UVO_TUNE_LEVEL0_INPLACE: read level 0 from the caller's image instead of copying it into a padded plane (when it can be)
   int fuse_blur_tree = 1;    // UVO_TUNE_FUSE_BLUR_TREE: quad-tree and blur as one launch when the batch takes the 256-thread quad-tree form
   int probe_delay_us = 0;    // development probe (UVO_TUNE 100): an idle single-wavefront kernel of this many microseconds behind the pyramid
   int pyr_mode = UVO_PYR_MODE_CHAIN;  // UVO_TUNE_PYR_MODE (2 = development probe: no pyramid launch at all)
@@ -501,6 +505,17 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   hipEvent_t& done = L.done[L.n_enqueued & 1];  // recorded behind the lane's last but one batch
   if (done) UVO_HIP_CHECK(hipEventSynchronize(done));
   else UVO_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+  // Level 0 in place: every reader of level 0 (the FAST kernels, the blur, the orientation patch, the resize to level 1) takes the caller's
+  // image itself -- the blur reflects its 3-pixel border on the fly -- and cv::copyMakeBorder of :996 (182 MB per 257 frames at 640 x 512)
+  // is never materialised.  Needs dword-aligned rows of a width that is a multiple of 4 (a lane's four pixels are then wholly inside the
+  // image or wholly border), the launch chain, and no caller keypoints (their orientation patch may reach into the border).  The image
+  // must stay unchanged until the batch is complete (it always had to stay valid that long).
+  const bool inplace = h->level0_inplace && h->pyr_mode == UVO_PYR_MODE_CHAIN && width % 4 == 0 && stride % 4 == 0 && frame_stride % 4 == 0 &&
+                       (uintptr_t)d_imgs % 4 == 0 && !(d_in_kp && d_n_in) && width >= 64 && height >= 64;
+  Level0View l0{nullptr, 0, 0, 0};
+  if (inplace) l0 = Level0View{d_imgs - (int64_t)kPad * stride - kPad, (int64_t)frame_stride, (int)stride, 0};
+  L.l0_src = inplace ? d_imgs : nullptr, L.l0_stride = stride, L.l0_frame_stride = frame_stride;
+  const Level0View no_l0{nullptr, 0, 0, 0};
   if (h->pyr_mode == 2) {
     // development probe: no pyramid launch at all (the planes of an earlier batch stay): what the stage costs the step
   } else if (h->pyr_mode == UVO_PYR_MODE_SPLIT) {
@@ -549,14 +564,14 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
         return fail(UVO_E_UNSUPPORTED, "no pyramid kernel for this workgroup shape");
     }
   } else {
-    {
+    if (!inplace) {
       ProfScope p(h, "k_pad_level0");
       launch_pad_level0(s, d_imgs, width, height, stride, frame_stride, L.d_pyr, g.pyr_block, g.lv[0], batch);
     }
     for (int l = 1; l < g.nlevels; ++l) {
       ProfScope p(h, "k_resize_level");
       launch_resize_level(s, L.d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_ctab + g.lv[l].xtab_off, h->d_rtab + g.lv[l].ytab_off, h->resize_fast[l],
-                          batch);
+                          batch, l == 1 ? l0 : no_l0);
     }
   }
   if (h->probe_delay_us > 0) {
@@ -566,14 +581,14 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   {  // the per-cell threshold vote + candidate emit run inside k_octree
     ProfScope p(h, "k_fast_score");
     launch_fast_score(s, L.d_pyr, g.pyr_block, g, h->cfg.fast_th, L.d_tpass, L.d_cor, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, L.d_cand_lo, g.cand_block,
-                      L.d_cursor, batch);
+                      L.d_cursor, batch, l0);
   }
   if (h->cfg.fast_th > 7 && h->fast_mode != UVO_FAST_MODE_SINGLE_PASS) {
     // second call of src/ORBextractor.cc:797 for the cells of threshold-adaptive levels that the pass at fastTh left empty (nearly all
     // wavefronts find nothing to do on textured frames).  With the mode pinned to one pass no level can be adaptive: not launched.
     ProfScope p(h, "k_fast_cells");
     launch_fast_cells(s, L.d_pyr, g.pyr_block, g, h->d_cells, h->d_cell_flag, L.d_tpass, L.d_cell_hi, L.d_cell_list, L.d_fstat + kMaxLevels, L.d_cand_xy,
-                      L.d_cand_sc, g.cand_block, L.d_cursor, batch);
+                      L.d_cand_sc, g.cand_block, L.d_cursor, batch, l0);
   }
   if (h->fuse_blur_tree && octree_gauss_applies(h->oct, g, batch)) {
     // the quad-tree (a chain of dependent phases per (frame, level)) and the blur (a streaming kernel) read nothing of each other:
@@ -581,11 +596,11 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
     ProfScope p(h, "k_octree_gauss");
     launch_octree_gauss(s, h->d_lv, g, L.d_pyr, L.d_blur, g.pyr_block, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), h->blur_rounding, L.d_cand_lo, L.d_cursor,
                         L.d_fcount, L.d_fstat + kMaxLevels, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count, L.d_pstate, L.d_sel_xy, L.d_sel_sc, L.d_sel_count,
-                        batch);
+                        batch, l0);
   } else {
     {
       ProfScope p(h, "k_gauss7");
-      launch_gauss7(s, L.d_pyr, L.d_blur, g.pyr_block, h->d_lv, g, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), batch, h->blur_rounding);
+      launch_gauss7(s, L.d_pyr, L.d_blur, g.pyr_block, h->d_lv, g, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), batch, h->blur_rounding, l0);
     }
     {
       ProfScope p(h, "k_octree");
@@ -603,7 +618,7 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   {
     ProfScope p(h, "k_describe");
     launch_describe(s, h->d_lv, g, L.d_pyr, L.d_blur, g.pyr_block, L.d_flist, L.d_n_final, d_in_kp, h->cfg.max_input_keypoints, h->d_pattern,
-                    h->d_patch, d_out_kp, d_out_desc, cap, d_n_out, batch);
+                    h->d_patch, d_out_kp, d_out_desc, cap, d_n_out, batch, l0);
   }
   UVO_HIP_CHECK(hipGetLastError());
   UVO_HIP_CHECK(hipEventRecord(done, s));
@@ -953,6 +968,9 @@ int uvo_extractor_tune(uvo_extractor* h, int knob, int value) {
     case UVO_TUNE_PYR_RUN:
       if (value < 0 || value > 64) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_RUN takes 0 .. 64");
       h->pyr_blocks_per_item = value;
+      return UVO_OK;
+    case UVO_TUNE_LEVEL0_INPLACE:
+      h->level0_inplace = value != 0;
       return UVO_OK;
     case UVO_TUNE_FUSE_BLUR_TREE:
       h->fuse_blur_tree = value != 0;
@@ -1387,6 +1405,12 @@ int uvo_extractor_read_plane(uvo_extractor* h, int frame, int level, int which, 
   UVO_HIP_CHECK(hipSetDevice(h->device));
   UVO_HIP_CHECK(hipStreamSynchronize(h->lane[h->cur].stream));
   const LevelGeom& L = h->geom.lv[level];
+  Lane& LN = h->lane[h->cur];
+  if (!which && level == 0 && LN.l0_src) {
+    // the batch read level 0 in place: this test tap makes the padded plane it never needed (the caller's images must still be there)
+    launch_pad_level0(LN.stream, LN.l0_src, h->geom.width, h->geom.height, LN.l0_stride, LN.l0_frame_stride, LN.d_pyr, h->geom.pyr_block, h->geom.lv[0], h->last_batch);
+    UVO_HIP_CHECK(hipStreamSynchronize(LN.stream));
+  }
   const uint8_t* src = (which ? h->lane[h->cur].d_blur : h->lane[h->cur].d_pyr) + (size_t)frame * h->geom.pyr_block + L.plane_off;
   if (!which) {
     UVO_HIP_CHECK(hipMemcpy2D(dst, L.pw, src, L.pitch, L.pw, L.ph, hipMemcpyDeviceToHost));

@@ -216,7 +216,7 @@ __device__ __forceinline__ void fast_score_chunk(const uint8_t* rows, uint32_t f
 __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fast_score(const uint8_t* __restrict__ pyr, int64_t pyr_block, FastLevels L, const int32_t* __restrict__ tpass, int fast_th,
                                                     uint32_t* __restrict__ cor, uint8_t* __restrict__ cell_hi, uint32_t* __restrict__ cand_xy,
                                                     uint32_t* __restrict__ cand_sc, uint32_t* __restrict__ cand_lo, int64_t cand_block,
-                                                    int32_t* __restrict__ cursor) {
+                                                    int32_t* __restrict__ cursor, Level0View l0) {
   __shared__ uint32_t s_mem[UVO_FAST_WAVES][FW_DWORDS];
   __shared__ uint32_t s_list[UVO_FAST_WAVES][FL_CAP];
   const int wv = wave_in_block(), lane = threadIdx.x & 63;
@@ -235,7 +235,11 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   uint32_t* list = s_list[wv];
   int ncorner = 0;   // corners in the LDS list
   int nflushed = 0;  // corners already moved to the region's slice in memory
-  const uint8_t* src = pyr + f * pyr_block + g.plane_off;
+  // level 0 may be the caller's image read in place: the detection window and its 3-pixel ring lie inside the image, so only the base,
+  // the pitch and the two clamps change (wave-uniform)
+  const bool ip = level == 0 && l0.vbase != nullptr;
+  const uint8_t* src = ip ? l0.vbase + f * l0.frame_stride : pyr + f * pyr_block + g.plane_off;
+  const int pitch = ip ? l0.pitch : g.pitch;
   // nsub sub-strips side by side (1: the whole wavefront; 2 / 4: 32 / 16 lanes each, consecutive row segments of one narrow strip).
   // Everything that depends on the row is kept relative to the sub-strip's own first row, so the loop below stays uniform.
   const int lps = 64 / nsub;                 // lanes per sub-strip
@@ -244,7 +248,8 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   const int py0l = py0 + sub * L.rows_per_seg;
   const int nrows_l = max(min(py0l + L.rows_per_seg, g.h) - py0l, 0);  // 0: this sub-strip lies below the level
   const int X = X0 + ls * 4;  // padded column of the lane's first pixel; the first and last lane of a sub-strip are its halo
-  const int Xc = X > g.pitch - 4 ? g.pitch - 4 : X;
+  const int x_last = ip ? g.w + kPad - 4 : g.pitch - 4;  // last dword of a row that may be loaded (in place: the image's last four columns)
+  const int Xc = X > x_last ? x_last : X;
   const int nrows = min(py0 + L.rows_per_seg, g.h) - py0;  // sub-strip 0 has the most rows
   const int nsrc = nrows + 8;  // centre rows py0-1 .. py1 need source rows py0-4 .. py1+3
   const int lm = ls > 0 ? lane - 1 : lane, lp = ls < lps - 1 ? lane + 1 : lane;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   const int last_row = g.h + 15;  // last row of the padded plane
   auto load_row = [&](int j) -> uint32_t {
     const int r = min(py0l - 4 + j, last_row);  // rows past the plane belong to a sub-strip below the level: never used
-    return *reinterpret_cast<const uint32_t*>(src + (int64_t)r * g.pitch + Xc);
+    return *reinterpret_cast<const uint32_t*>(src + (int64_t)r * pitch + Xc);
   };
   // queue entry of the lane's pixel K in row u of a block = ent_blk + u * kEntRow + K * kEntPix:
   //   address part: this wavefront's ring + the window's first slot (row j - 6) + the lane's pixel K - 3 columns; xl part; row part
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(64 * FC_WAVES) void k_fast_cells(const uint8_t* __r
                                                             const int32_t* __restrict__ flag_cell, const int32_t* __restrict__ tpass,
                                                             const uint8_t* __restrict__ cell_hi,
                                                             uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc, int64_t cand_block,
-                                                            int32_t* __restrict__ cursor) {
+                                                            int32_t* __restrict__ cursor, Level0View l0) {
   typedef FcGeom<MAXROI> G;
   constexpr int FC_TPITCH = G::TPITCH, FC_ND = G::ND, FC_SPITCH = G::SPITCH, FC_SROWS = G::SROWS, FC_CCAP = G::CCAP;
   __shared__ uint32_t s_tile[FC_WAVES][G::TILE_DW];
@@ -632,7 +637,10 @@ __global__ __launch_bounds__(64 * FC_WAVES) void k_fast_cells(const uint8_t* __r
     (void)ih;
     // ---- the ROI into LDS as aligned dwords: padded plane columns [a0, a0 + 4 nd), `sh` bytes of slack in front ----
     const int px0 = kPad + x0, py0 = kPad + y0, a0 = px0 & ~3, sh = px0 - a0, nd = (sh + rw + 3) >> 2;
-    const uint8_t* src = pyr + f * pyr_block + g.plane_off + (int64_t)py0 * g.pitch + a0;
+    // (a cell's ROI lies inside the detection window, i.e. inside the image: level 0 read in place needs nothing but its own base and pitch)
+    const bool ip = level == 0 && l0.vbase != nullptr;
+    const int pitch = ip ? l0.pitch : g.pitch;
+    const uint8_t* src = (ip ? l0.vbase + f * l0.frame_stride : pyr + f * pyr_block + g.plane_off) + (int64_t)py0 * pitch + a0;
     {
       // dword k * 64 + lane of the ROI's rh x nd dwords, eight loads in flight at a time (the address of a dword past the end is
       // clamped to the last one: unconditional loads, so that the compiler counts them instead of waiting for each)
@@ -646,7 +654,7 @@ __global__ __launch_bounds__(64 * FC_WAVES) void k_fast_cells(const uint8_t* __r
           const int idx = min(k0 + u * 64 + lane, ndw - 1);
           const int r = (int)(((float)idx + 0.5f) * rcp_nd), d = idx - r * nd;
           dst[u] = r * FC_ND + d;
-          w[u] = *reinterpret_cast<const uint32_t*>(src + (int64_t)r * g.pitch + 4 * d);
+          w[u] = *reinterpret_cast<const uint32_t*>(src + (int64_t)r * pitch + 4 * d);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -810,18 +818,19 @@ FastLevels fast_levels(const Geom& g, int batch) {
 // scores + in-cell NMS per region; survivors to the candidate array / the low list of their (frame, level) (the per-cell vote: octree.hip).
 // d_tpass[level] = threshold of the level's streaming pass (the lane's adaptive state, see k_octree)
 void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, int fast_th, const int32_t* d_tpass, uint32_t* d_cor,
-                       uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, uint32_t* d_cand_lo, int64_t cand_block, int32_t* d_cursor, int batch) {
+                       uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, uint32_t* d_cand_lo, int64_t cand_block, int32_t* d_cursor, int batch,
+                       Level0View l0) {
   const FastLevels L = fast_levels(g, batch);
   const dim3 grid((L.items_per_frame + UVO_FAST_WAVES - 1) / UVO_FAST_WAVES, batch);
   hipLaunchKernelGGL(k_fast_score, grid, dim3(64 * UVO_FAST_WAVES), 0, s, d_pyr, pyr_block, L, d_tpass, fast_th, d_cor, d_cell_hi, d_cand_xy, d_cand_sc, d_cand_lo,
-                     cand_block, d_cursor);
+                     cand_block, d_cursor, l0);
 }
 
 // the sparse second pass at the literal 7 over the cells of threshold-adaptive levels that own no survivor (only needed when fastTh > 7):
 // list them, then redo them with a fixed grid of wavefronts (most of which leave at once on textured frames)
 void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, const CellDesc* d_cells, const int32_t* d_flag_cell,
                        const int32_t* d_tpass, const uint8_t* d_cell_hi, uint2* d_list, int32_t* d_n_list, uint32_t* d_cand_xy, uint32_t* d_cand_sc,
-                       int64_t cand_block, int32_t* d_cursor, int batch) {
+                       int64_t cand_block, int32_t* d_cursor, int batch, Level0View l0) {
   const FastLevels L = fast_levels(g, batch);
   int max_roi = 0;
   for (int l = 0; l < g.nlevels; ++l) max_roi = std::max(max_roi, std::max(g.lv[l].wCell, g.lv[l].hCell) + 6);
@@ -830,10 +839,10 @@ void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, c
     const dim3 grid((L.flags_per_frame + FC_WAVES - 1) / FC_WAVES, batch);
     if (small)
       hipLaunchKernelGGL((k_fast_cells<48, true>), grid, dim3(64 * FC_WAVES), 0, s, d_pyr, pyr_block, L, d_cells, d_list, d_n_list, d_flag_cell, d_tpass, d_cell_hi, d_cand_xy,
-                         d_cand_sc, cand_block, d_cursor);
+                         d_cand_sc, cand_block, d_cursor, l0);
     else
       hipLaunchKernelGGL((k_fast_cells<66, true>), grid, dim3(64 * FC_WAVES), 0, s, d_pyr, pyr_block, L, d_cells, d_list, d_n_list, d_flag_cell, d_tpass, d_cell_hi, d_cand_xy,
-                         d_cand_sc, cand_block, d_cursor);
+                         d_cand_sc, cand_block, d_cursor, l0);
     return;
   }
   hipLaunchKernelGGL(k_fast_cells_list, dim3((L.flags_per_frame + FCL_THREADS - 1) / FCL_THREADS, batch), dim3(FCL_THREADS), 0, s, d_flag_cell, L.flags_per_frame,
@@ -844,10 +853,10 @@ void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, c
   const dim3 grid((waves + FC_WAVES - 1) / FC_WAVES);
   if (small)
     hipLaunchKernelGGL((k_fast_cells<48, false>), grid, dim3(64 * FC_WAVES), 0, s, d_pyr, pyr_block, L, d_cells, d_list, d_n_list, d_flag_cell, d_tpass, d_cell_hi, d_cand_xy,
-                       d_cand_sc, cand_block, d_cursor);
+                       d_cand_sc, cand_block, d_cursor, l0);
   else
     hipLaunchKernelGGL((k_fast_cells<66, false>), grid, dim3(64 * FC_WAVES), 0, s, d_pyr, pyr_block, L, d_cells, d_list, d_n_list, d_flag_cell, d_tpass, d_cell_hi, d_cand_xy,
-                       d_cand_sc, cand_block, d_cursor);
+                       d_cand_sc, cand_block, d_cursor, l0);
 }
 
 }  // namespace uvo

@@ -3,6 +3,7 @@
 #pragma once
 #include "common.hpp"
 #include "fast_geom.hpp"
+#include <type_traits>
 
 namespace uvo {
 
@@ -41,7 +42,8 @@ constexpr int GS_LDS_BYTES = 4 * GS_TILE_DW * 4;  // per 4-wavefront workgroup
 // Also run by the workgroups of k_octree_gauss (octree.hip) that are not quad-tree problems.
 template <bool SSE2>
 __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, uint32_t (*s_tile)[GS_TILE_DW], const uint8_t* __restrict__ pyr,
-                                            uint8_t* __restrict__ blur, int64_t pyr_block, const LevelGeom* __restrict__ lv, int nlevels, int4 taps, int rows_per_seg) {
+                                            uint8_t* __restrict__ blur, int64_t pyr_block, const LevelGeom* __restrict__ lv, int nlevels, int4 taps, int rows_per_seg,
+                                            Level0View l0) {
   // work item (one per wavefront) -> (level, strip, segment group); narrow remainder strips hold 2 or 4 row segments side by side
   // (fast_strip_plan), so a level costs about as many wavefront-rows as its width needs
   const int vb = xcd_contiguous(block, blocks_x * batch);
@@ -59,13 +61,28 @@ __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, 
   const LevelGeom g = lv[level];
   int strip_x, seg, nsub;
   fast_strip_item(plan, item, strip_x, seg, nsub);
-  const uint8_t* src = pyr + f * pyr_block + g.plane_off;
+  // The walk, in two instantiations: over a padded plane, or (IP) over level 0 read in place -- the caller's image, whose 16-pixel
+  // REFLECT_101 border (the blur reaches 3 pixels of it, and copies 4 into the blurred plane's ring) is produced by reflecting the row
+  // index and, per lane, the column run: a lane's four pixels are an aligned group of four image columns (the width is a multiple of 4 in
+  // this mode), so a group is wholly inside the image or wholly a reversed run of it -- one load and one byte permute either way.
+  auto walk = [&](auto ip_tag) {
+  constexpr bool IP = decltype(ip_tag)::value;
+  const uint8_t* src = IP ? l0.vbase + f * l0.frame_stride + (int64_t)kPad * l0.pitch + kPad : pyr + f * pyr_block + g.plane_off;  // IP: the image's origin
+  const int spitch = IP ? l0.pitch : g.pitch;
   uint8_t* dst = blur + f * pyr_block + g.plane_off;
 
   const int lps = 64 / nsub, sub = (lane * nsub) >> 6, ls = lane - sub * lps;
   // padded-plane column of this lane's dword; the first lane of a sub-strip is its left halo.  Region = padded cols [12, w+20).
   const int X = 8 + strip_x + ls * 4;
-  const int Xc = X > g.pitch - 4 ? g.pitch - 4 : X;  // clamp loads into the row (only halo / out-of-region lanes)
+  int Xc = X > g.pitch - 4 ? g.pitch - 4 : X;  // clamp loads into the row (only halo / out-of-region lanes)
+  uint32_t csel = 0x03020100u;                 // IP: identity, or byte reversal for a reflected run
+  if (IP) {
+    const int x = X - kPad;                    // image column of the lane's first pixel (a multiple of 4)
+    int run = x;
+    if (x < 0) run = -x - 3, csel = 0x00010203u;                           // columns x .. x+3 = image columns -x .. -x-3
+    else if (x > g.w - 4) run = 2 * (g.w - 1) - x - 3, csel = 0x00010203u;  // columns x .. x+3 = image columns 2(w-1)-x .. 2(w-1)-x-3
+    Xc = run < 0 ? 0 : (run > g.w - 4 ? g.w - 4 : run);                    // (lanes farther out than the border are never used)
+  }
   // padded-plane rows: region rows [12, h+20); the lane's segment rows [py0l, py1l)
   const int py0 = 12 + seg * rows_per_seg;
   const int py0l = py0 + sub * rows_per_seg;
@@ -138,8 +155,16 @@ __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, 
   // without the prefetch every row would expose a full memory round trip.
   auto load_row = [&](int j) -> uint32_t {
     int prow = py0l - 3 + j;
+    if (IP) {
+      int r = prow - kPad;                      // image row; REFLECT_101 above and below
+      r = r < 0 ? -r : r;
+      r = r > g.h - 1 ? 2 * (g.h - 1) - r : r;
+      r = r < 0 ? 0 : r;                        // (rows past the border's reach are never used by a valid output)
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(src + (int64_t)r * spitch + Xc);
+      return __builtin_amdgcn_perm(v, v, csel);
+    }
     prow = prow > g.ph - 1 ? g.ph - 1 : prow;  // rows past the plane are never used by a valid output
-    return *reinterpret_cast<const uint32_t*>(src + (int64_t)prow * g.pitch + Xc);
+    return *reinterpret_cast<const uint32_t*>(src + (int64_t)prow * spitch + Xc);
   };
   // byte offset of sub-strip 0's current output row inside its tile column: tile row * tile_row_bytes + (row % 8) * 16, advanced row by
   // row (one scalar add instead of a 64-bit multiply per row)
@@ -210,6 +235,11 @@ __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, 
     const int py_last = py0 + nsrc - 7;  // last output row of sub-strip 0
     if ((py_last & 7) != 7) flush_tiles(py_last & ~7, py_last & 7, (int64_t)(py_last >> 3) * tile_row_bytes);
   }
+  };  // walk
+  if (level == 0 && l0.vbase != nullptr)
+    walk(std::true_type{});
+  else
+    walk(std::false_type{});
 }
 
 

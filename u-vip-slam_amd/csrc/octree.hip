@@ -232,6 +232,7 @@ struct GaussArgs {
   int64_t pyr_block;
   int4 taps;
   int rows_per_seg, blocks_x, batch;
+  Level0View l0;
 };
 template <bool SSE2>
 __global__ __launch_bounds__(256, 4) void k_octree_gauss(int n_oct, GaussArgs G, const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max, int pyr_words, int box_region,
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256, 4) void k_octree_gauss(int n_oct, GaussArgs G,
     octree_body<256>(lds, o / G.batch, o % G.batch, lv, nlevels, Mmax, Mp2max, pyr_words, box_region, lds_bytes, FL, cand_lo, cursor, fcount, n_cell_list, cell_hi, cand_xy, cand_sc,
                      cand_block, cand_count, pstate, sel_xy, sel_sc, sel_block, sel_count);
   } else {
-    gauss7_body<SSE2>(b, G.blocks_x, G.batch, reinterpret_cast<uint32_t(*)[GS_TILE_DW]>(lds), G.pyr, G.blur, G.pyr_block, lv, nlevels, G.taps, G.rows_per_seg);
+    gauss7_body<SSE2>(b, G.blocks_x, G.batch, reinterpret_cast<uint32_t(*)[GS_TILE_DW]>(lds), G.pyr, G.blur, G.pyr_block, lv, nlevels, G.taps, G.rows_per_seg, G.l0);
   }
 }
 
@@ -342,11 +343,11 @@ bool octree_gauss_applies(const OctLaunchState& st, const Geom& g, int batch) {
 void launch_octree_gauss(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, int4 taps, int sse2_rounding,
                          const uint32_t* d_cand_lo, int32_t* d_cursor, int32_t* d_fcount, int32_t* d_n_cell_list, uint8_t* d_cell_hi, uint32_t* d_cand_xy,
                          uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
-                         int32_t* d_sel_count, int batch) {
+                         int32_t* d_sel_count, int batch, Level0View l0) {
   int M, Mp2, pyr_words;
   const size_t lds = std::max(octree_lds(g, M, Mp2, pyr_words), (size_t)GS_LDS_BYTES);
   GaussArgs G;
-  G.pyr = d_pyr, G.blur = d_blur, G.pyr_block = pyr_block, G.taps = taps, G.batch = batch;
+  G.pyr = d_pyr, G.blur = d_blur, G.pyr_block = pyr_block, G.taps = taps, G.batch = batch, G.l0 = l0;
   G.rows_per_seg = gauss7_rows_per_seg(batch), G.blocks_x = gauss7_blocks_per_frame(g, G.rows_per_seg);
   const int n_oct = batch * g.nlevels;
   const dim3 grid(n_oct + G.blocks_x * batch);

@@ -96,7 +96,7 @@ constexpr int RZ_ROWS = 4;  // output rows per thread: one column-table fetch, R
 __global__ __launch_bounds__(256, UVO_OCC_RESIZE) void k_resize_level(uint8_t* __restrict__ pyr, int64_t pyr_block, int64_t src_off, int src_pitch, int sw,
                                                       int64_t dst_off, int dst_pitch, int dst_ph, int dw, int fast_ok,
                                                       const ResizeCol* __restrict__ ctab, const ResizeRow* __restrict__ rtab,
-                                                      uint32_t nwx_magic) {
+                                                      uint32_t nwx_magic, Level0View l0, int sh) {
   // flat index -> (row group, dword column): rows are a few dozen to 150 dwords long, so a (64 x rows) tiling would leave up to
   // a third of the lanes idle on some levels.  gid / nwx by multiply-high with ceil(2^32 / nwx) (exact for gid < 2^20).
   const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
@@ -106,7 +106,14 @@ __global__ __launch_bounds__(256, UVO_OCC_RESIZE) void k_resize_level(uint8_t* _
   const int py0 = (int)rg * RZ_ROWS;
   const int f = blockIdx.y;
   if (py0 >= dst_ph) return;
-  const uint8_t* S = pyr + f * pyr_block + src_off + (int64_t)kPad * src_pitch + kPad;  // ROI origin of the source level
+  // ROI origin of the source level; level 1 may read the caller's image in place (l0.vbase: the resize only looks at the ROI)
+  const bool ip = l0.vbase != nullptr;
+  if (ip) src_pitch = l0.pitch;
+  const uint8_t* S = ip ? l0.vbase + f * l0.frame_stride + (int64_t)kPad * src_pitch + kPad : pyr + f * pyr_block + src_off + (int64_t)kPad * src_pitch + kPad;
+  // The 12-byte tap window of the last columns reaches up to 8 bytes past the ROI's last pixel (taps of weight zero).  Inside a padded
+  // plane those bytes are the pad; in place they are the next row, and behind the last row of the last frame nothing the caller owns: the
+  // window of that row's last lanes is pulled back into the frame (the bytes it then misses carry no weight: see `edge` below).
+  const int64_t s_end = ip ? (int64_t)(sh - 1) * src_pitch + sw : INT64_MAX;
   const uint4 c01 = reinterpret_cast<const uint4*>(ctab)[wx * 2];      // columns 4wx, 4wx+1
   const uint4 c23 = reinterpret_cast<const uint4*>(ctab)[wx * 2 + 1];  // columns 4wx+2, 4wx+3
   const uint32_t cw[8] = {c01.x, c01.y, c01.z, c01.w, c23.x, c23.y, c23.z, c23.w};
@@ -134,13 +141,24 @@ __global__ __launch_bounds__(256, UVO_OCC_RESIZE) void k_resize_level(uint8_t* _
     rr[j].sy0 = (int16_t)(tw[2 * j] & 0xffffu), rr[j].sy1 = (int16_t)(tw[2 * j] >> 16);
     rr[j].b0 = (int16_t)(tw[2 * j + 1] & 0xffffu), rr[j].b1 = (int16_t)(tw[2 * j + 1] >> 16);
   }
-  if (interior) {
+  if (interior && !ip) {
 #pragma unroll
     for (int j = 0; j < RZ_ROWS; ++j) {
       const uint32_t* p0 = reinterpret_cast<const uint32_t*>(S + (int64_t)rr[j].sy0 * src_pitch + base);
       const uint32_t* p1 = reinterpret_cast<const uint32_t*>(S + (int64_t)rr[j].sy1 * src_pitch + base);
       u[j][0] = p0[0], u[j][1] = p0[1], u[j][2] = p0[2];
       w[j][0] = p1[0], w[j][1] = p1[1], w[j][2] = p1[2];
+    }
+  } else if (interior) {
+#pragma unroll
+    for (int j = 0; j < RZ_ROWS; ++j) {
+      const int64_t o0 = (int64_t)rr[j].sy0 * src_pitch + base, o1 = (int64_t)rr[j].sy1 * src_pitch + base;
+      const uint32_t* p0 = reinterpret_cast<const uint32_t*>(S + o0);
+      const uint32_t* p1 = reinterpret_cast<const uint32_t*>(S + o1);
+      // (a window dword behind the frame's last byte is not loaded: it holds no tap of non-zero weight; rows and the frame end are
+      // dword-aligned in this mode)
+      u[j][0] = p0[0], u[j][1] = o0 + 4 < s_end ? p0[1] : 0u, u[j][2] = o0 + 8 < s_end ? p0[2] : 0u;
+      w[j][0] = p1[0], w[j][1] = o1 + 4 < s_end ? p1[1] : 0u, w[j][2] = o1 + 8 < s_end ? p1[2] : 0u;
     }
   }
 #pragma unroll
@@ -184,13 +202,13 @@ void launch_pad_level0(hipStream_t s, const uint8_t* d_img, int w, int h, int64_
 }
 
 void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const LevelGeom& src, const LevelGeom& dst, const ResizeCol* d_ctab,
-                         const ResizeRow* d_rtab, int fast_ok, int batch) {
+                         const ResizeRow* d_rtab, int fast_ok, int batch, Level0View l0) {
   dim3 block(256);
   const uint32_t nwx = (uint32_t)dst.pitch / 4, groups = ((uint32_t)dst.ph + RZ_ROWS - 1) / RZ_ROWS;
   const uint32_t magic = (uint32_t)((0x100000000ull + nwx - 1) / nwx);
   dim3 grid((nwx * groups + 255) / 256, batch);
   hipLaunchKernelGGL(k_resize_level, grid, block, 0, s, d_pyr, pyr_block, src.plane_off, src.pitch, src.w, dst.plane_off, dst.pitch, dst.ph,
-                     dst.w, fast_ok, d_ctab, d_rtab, magic);
+                     dst.w, fast_ok, d_ctab, d_rtab, magic, l0, src.h);
 }
 
 
