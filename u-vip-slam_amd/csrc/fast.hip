@@ -36,6 +36,7 @@
 // candidates; the parity tests force each (UVO_TUNE_FAST_MODE).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include "common.hpp"
 #include "fast_geom.hpp"
 
@@ -45,7 +46,8 @@ namespace uvo {
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 #ifndef UVO_FAST_SCREEN_SWAR
-#define UVO_FAST_SCREEN_SWAR 1  // 1: the four-pixel 7-bit screen in 32-bit arithmetic; 0: the packed 16-bit screen of rounds 1-3
+#define UVO_FAST_SCREEN_SWAR 2  // 2: the four-pixel 7-bit screen on a register ring of 7-bit rows, neighbours by ds_bpermute (round 4);
+                                // 1: the same screen with 8-bit rows and neighbours from the LDS ring; 0: the packed 16-bit screen of rounds 1-3
 #endif
 #ifndef UVO_FAST_WAVES
 #define UVO_FAST_WAVES 4       // wavefronts (regions) per workgroup
@@ -130,8 +132,7 @@ struct Screen4 {
 };
 constexpr uint32_t kM7 = 0x7f7f7f7fu, kH7 = 0x80808080u;
 __device__ __forceinline__ uint32_t seven(uint32_t x, uint32_t m7) { return (x >> 1) & m7; }
-__device__ __forceinline__ Screen4 screen4_centre(uint32_t c, uint32_t thv, uint32_t m7, uint32_t h7) {
-  const uint32_t v7 = seven(c, m7);
+__device__ __forceinline__ Screen4 screen4_centre7(uint32_t v7, uint32_t thv, uint32_t m7, uint32_t h7) {
   const uint32_t w = v7 + thv;                         // <= 127 + 128: stays in its byte
   const uint32_t wh = w & h7, wl = wh - (wh >> 7);     // 0x7f in the bytes whose bit 7 is set
   const uint32_t u = (v7 | h7) - thv;                  // 128 + v7 - th >= 0
@@ -141,6 +142,7 @@ __device__ __forceinline__ Screen4 screen4_centre(uint32_t c, uint32_t thv, uint
   r.cd = u | (m7 & ~ul);                               // max(u, 127)
   return r;
 }
+__device__ __forceinline__ Screen4 screen4_centre(uint32_t c, uint32_t thv, uint32_t m7, uint32_t h7) { return screen4_centre7(seven(c, m7), thv, m7, h7); }
 
 // LDS row ring of a wavefront.  The streaming loop is unrolled by seven rows (the register ring), so the ring's period is two blocks:
 // a block of parity pb writes its row u to slot 7 pb + u, and the rows of the even blocks are mirrored into slots 14 .. 20.  The seven
@@ -305,10 +307,35 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
     qa -= 256u;
     qold = qold > 256u ? qold - 256u : 0u;
   };
-  uint32_t Cr[7], nxt[7];
+  // one compaction per pixel column: the lanes that pass store their entry behind the queue's end, which moves on by their number
+  // (a scalar byte address: one population count and one shift-add per push)
+#define UVO_FAST_PUSH(COND, ENTRY)                                                                                                      \
+  {                                                                                                                                     \
+    const bool pass = (COND);                                                                                                           \
+    const uint64_t m = ballot64(pass);                                                                                                  \
+    if (pass)                                                                                                                           \
+      *reinterpret_cast<uint32_t*>(lds8 + (qa + 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)))) = \
+          (ENTRY);                                                                                                                      \
+    qa += 4u * (uint32_t)__popcll(m);                                                                                                   \
+  }
+  uint32_t nxt[7];
 #pragma unroll
   for (int u = 0; u < 7; ++u) nxt[u] = load_row(u);  // unconditional (the row index is clamped into the plane): with a branch around a load
                                                      // the compiler cannot count the loads in flight and waits for all of them
+#if UVO_FAST_SCREEN_SWAR == 2
+  // Register rings of the last seven rows, at seven bits per pixel (the screen never looks at bit 0): the row itself and its views two
+  // pixels to the right / left (ring pixels 2, 6 / 14, 10 of the centres two rows above and below).  The neighbour lanes' dwords come
+  // over the LDS crossbar (ds_bpermute: no LDS memory, no vector-ALU slot), from the lanes next to it in the wavefront whatever sub-strip
+  // they belong to (63 and 0 are neighbours): the first lane of a sub-strip screens its pixel 3 and the last its pixel 0, and the bytes
+  // of the views those two read are the lane's own -- V2p of the lane before holds them because ITS right neighbour is this lane.
+  uint32_t S7[7], V2p[7];
+  const int lm4 = ((lane + 63) & 63) * 4, lp4 = ((lane + 1) & 63) * 4;
+  uint32_t mkall = mk0 | mk1 | mk2 | mk3;
+  uint32_t kpix = kEntPix, kentrow = kEntRow;
+  asm volatile("" : "+v"(mkall), "+v"(kpix), "+v"(kentrow));
+#else
+  uint32_t Cr[7];
+#endif
   int pbo = 0;  // 7 * parity of the block
   for (int base = 0; base < nsrc; base += 7, pbo ^= 7) {
     uint32_t cur[7];
@@ -319,22 +346,66 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
     // everything of the block that depends on its parity or its first row, once: the rows below only add compile-time offsets
     uint32_t* wr = rows32 + pbo * FR_PITCH + lane;          // slot 7 pb + u
     uint32_t* wr2 = rows32 + (14 - pbo) * FR_PITCH + lane;  // its mirror 14 + u in an even block (an odd block stores the same slot twice)
-    const uint32_t* wl = rows32 + (8 - pbo) * FR_PITCH + lm;  // row j - 6 of u = 0 in the left / right neighbour's column
-    const uint32_t* wp = rows32 + (8 - pbo) * FR_PITCH + lp;
     const uint32_t rowbits_blk = base ? rowbits >> (base - 6) : rowbits << 6;  // bit u: the lane screens the centre row of loop row base + u
     const uint32_t ent_blk = lane_entry + ((uint32_t)((8 - pbo) * FR_PITCH * 4) + ((uint32_t)(base - 6) << 23));
+#if UVO_FAST_SCREEN_SWAR == 2
+    uint32_t ent_row = ent_blk;  // entry of the lane's pixel 0 in the row at hand
+#else
+    const uint32_t* wl = rows32 + (8 - pbo) * FR_PITCH + lm;  // row j - 6 of u = 0 in the left / right neighbour's column
+    const uint32_t* wp = rows32 + (8 - pbo) * FR_PITCH + lp;
+#endif
 #pragma unroll
     for (int u = 0; u < 7; ++u) {
       const int j = base + u;
       if (j < nsrc) {
         const uint32_t C = cur[u];
-        Cr[u] = C;
         wr[u * FR_PITCH] = C;
         wr2[u * FR_PITCH] = C;
+#if UVO_FAST_SCREEN_SWAR == 2
+        const uint32_t c7 = seven(C, m7);
+        S7[u] = c7;
+        V2p[u] = __builtin_amdgcn_alignbyte((uint32_t)__builtin_amdgcn_ds_bpermute(lp4, (int)c7), c7, 2);
+#else
+        Cr[u] = C;
+#endif
         if (j >= 6) {
           // centre row jc = j - 3, relative to the sub-strip rrp = j - 6 (0 = halo row above, nrows + 1 = halo row below); rows jc-3 .. jc+3
           // sit in register slots (u+1)%7 .. u and in the ring slots the window pointers start at
           const uint32_t rowm = (uint32_t)__builtin_amdgcn_sbfe((int)rowbits_blk, (uint32_t)u, 1u);  // 0 / ~0: this lane screens this row
+#if UVO_FAST_SCREEN_SWAR == 2
+          {
+            const int sm3 = (u + 1) % 7, sm2 = (u + 2) % 7, s0 = (u + 4) % 7, sp2 = (u + 6) % 7, sp3 = u;
+            const uint32_t cc = S7[s0];
+            const uint32_t Lc = (uint32_t)__builtin_amdgcn_ds_bpermute(lm4, (int)cc), Rc = (uint32_t)__builtin_amdgcn_ds_bpermute(lp4, (int)cc);
+            // a lane's view two pixels to the left is its left neighbour's view two pixels to the right
+            const uint32_t q2 = V2p[sp2], q6 = V2p[sm2];
+            const uint32_t q14 = (uint32_t)__builtin_amdgcn_ds_bpermute(lm4, (int)q2), q10 = (uint32_t)__builtin_amdgcn_ds_bpermute(lm4, (int)q6);
+            const Screen4 sc = screen4_centre7(cc, thv, m7, h7);
+            const uint32_t q0_ = S7[sp3], q8 = S7[sm3], q4 = __builtin_amdgcn_alignbyte(Rc, cc, 3), q12 = __builtin_amdgcn_alignbyte(cc, Lc, 1);
+            const uint32_t bright = ((q0_ + sc.cb) | (q8 + sc.cb)) & ((q4 + sc.cb) | (q12 + sc.cb)) & ((q2 + sc.cb) | (q10 + sc.cb)) & ((q6 + sc.cb) | (q14 + sc.cb));
+            const uint32_t dark = ((sc.cd - q0_) | (sc.cd - q8)) & ((sc.cd - q4) | (sc.cd - q12)) & ((sc.cd - q2) | (sc.cd - q10)) & ((sc.cd - q6) | (sc.cd - q14));
+            const uint32_t pm = (bright | dark) & rowm & mkall;  // bit 7 of byte K: the lane's pixel K passes
+            // The flag of pixel K is the sign of byte K: one compare with a sign-extending byte select gives the lane mask, which is used as
+            // it is for the store's EXEC and for the ranks (left to the compiler, `(pm & bit) != 0` becomes two compares and an AND).
+            const uint32_t e1 = ent_row + kpix, e2 = e1 + kpix, e3 = e2 + kpix;
+#define UVO_FAST_PUSHB(BYTE, ENTRY)                                                                                                     \
+  {                                                                                                                                     \
+    uint64_t m;                                                                                                                         \
+    asm("v_cmp_gt_i32_sdwa %0, 0, sext(%1) src0_sel:DWORD src1_sel:BYTE_" #BYTE : "=s"(m) : "v"(pm));                                   \
+    if (__builtin_amdgcn_inverse_ballot_w64(m))                                                                                         \
+      *reinterpret_cast<uint32_t*>(lds8 + (qa + 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)))) = \
+          (ENTRY);                                                                                                                      \
+    qa += 4u * (uint32_t)__popcll(m);                                                                                                   \
+    asm volatile("" : "+s"(qa)); /* the end moves now, on the scalar unit: merged, the second store adds the first count per lane */     \
+  }
+            UVO_FAST_PUSHB(0, ent_row)
+            UVO_FAST_PUSHB(1, e1)
+            while (qa >= q0 + 256u) drain_oldest();  // keeps the queue within FQ_CAP
+            UVO_FAST_PUSHB(2, e2)
+            UVO_FAST_PUSHB(3, e3)
+#undef UVO_FAST_PUSHB
+          }
+#else
           {
             const int sm3 = (u + 1) % 7, sm2 = (u + 2) % 7, s0 = (u + 4) % 7, sp2 = (u + 6) % 7, sp3 = u;
             const uint32_t Cc = Cr[s0], Cu = Cr[sm3], Cd = Cr[sp3], C2 = Cr[sp2], Cm2 = Cr[sm2];
@@ -364,25 +435,15 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
             const uint32_t ro = screen2(Cc, Cd, Cu, P4, P12, P2, P10, P6, P14, t_odd);
             const uint32_t rem = re & rowm, rom = ro & rowm;
 #endif
-            // one compaction per pixel column: the lanes that pass store their entry behind the queue's end, which moves on by their number
-            // (a scalar byte address: one population count and one shift-add per push)
-#define UVO_FAST_PUSH(K, COND)                                                                                                          \
-  {                                                                                                                                     \
-    const bool pass = (COND);                                                                                                           \
-    const uint64_t m = ballot64(pass);                                                                                                  \
-    if (pass)                                                                                                                           \
-      *reinterpret_cast<uint32_t*>(lds8 + (qa + 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)))) = \
-          ent_blk + ((uint32_t)u * kEntRow + (uint32_t)K * kEntPix);                                                                    \
-    qa += 4u * (uint32_t)__popcll(m);                                                                                                   \
-  }
             // (the lane's column flags and the row flag are folded into one AND per pixel: mk0..3 select the pixel's part of the word)
-            UVO_FAST_PUSH(0, (rem & mk0) != 0u)
-            UVO_FAST_PUSH(1, (rom & mk1) != 0u)
+            const uint32_t ent_row = ent_blk + (uint32_t)u * kEntRow;
+            UVO_FAST_PUSH((rem & mk0) != 0u, ent_row)
+            UVO_FAST_PUSH((rom & mk1) != 0u, ent_row + kEntPix)
             while (qa >= q0 + 256u) drain_oldest();  // keeps the queue within FQ_CAP
-            UVO_FAST_PUSH(2, (rem & mk2) != 0u)
-            UVO_FAST_PUSH(3, (rom & mk3) != 0u)
-#undef UVO_FAST_PUSH
+            UVO_FAST_PUSH((rem & mk2) != 0u, ent_row + 2u * kEntPix)
+            UVO_FAST_PUSH((rom & mk3) != 0u, ent_row + 3u * kEntPix)
           }
+#endif
           // ---- drain full batches, oldest first.  What stays behind is younger than what left, and only what has stayed behind for two
           // checkpoints in a row (after rows 2 and 6 of a block: 7 rows apart) is scored as an incomplete batch.  A queued pixel's oldest
           // ring row (j - 6) is overwritten 14 rows after it was written, i.e. 8 rows after the pixel was queued; it waits <= 6.
@@ -397,9 +458,13 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
             qold = qa - q0;
           }
         }
+#if UVO_FAST_SCREEN_SWAR == 2
+        ent_row += kentrow;
+#endif
       }
     }
   }
+#undef UVO_FAST_PUSH
   if (qa > q0) fast_score_chunk(lds8, q0, (int)((qa - q0) >> 2), lane, t_min, list, region, ncorner, nflushed);
 
   // ---- in-cell 3x3 non-max suppression of the region's corners (cv::FAST with nonmaxSuppression on the cell ROI) ----
@@ -527,6 +592,7 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
     emit(list, nkeep);
   }
 }
+
 
 // ---- the sparse second pass of the threshold-adaptive form: FAST(cellROI, 7, nms) for the cells the streaming pass left empty ----
 // src/ORBextractor.cc:792-799: `FAST(cell, kps, fastTh, true); if (kps.empty()) FAST(cell, kps, 7, true);`.  When a level's streaming
