@@ -8,11 +8,12 @@
 // The cells' interiors tile the detection window [16, w-16) x [16, h-16) exactly once and the corner score does not
 // depend on the threshold, so the work is split in two:
 //   k_fast_score  : a streaming pass over each level.  One wavefront owns a (strip, segment) region of 248 x 24 pixels plus a
-//                   one-pixel halo ring and walks down the rows with the last 7 row dwords in a register ring (one aligned
-//                   dword load per lane per row, also kept in a wavefront-private LDS ring of 14 + 7 mirrored rows whose every
-//                   address is a per-block pointer + a compile-time offset) -- no workgroup barriers.  Every pixel is screened
-//                   with four opposite ring pairs (any 9-arc contains one pixel of every opposite pair, of one polarity), four
-//                   pixels per instruction in 32-bit arithmetic at seven bits per pixel (Screen4).  The 7 - 12 % that pass are
+//                   one-pixel halo ring and walks down the rows: one aligned dword load per lane per row, kept at seven bits per pixel
+//                   in a register ring of the last 7 rows (the screen) and as it is in a wavefront-private LDS ring of 14 + 7 mirrored
+//                   rows whose every address is a per-block pointer + a compile-time offset (the exact test) -- no workgroup barriers.
+//                   Every pixel is screened with four opposite ring pairs (any 9-arc contains one pixel of every opposite pair, of one
+//                   polarity), four pixels per instruction in 32-bit arithmetic at seven bits per pixel (Screen4); the neighbour lanes'
+//                   dwords come over the LDS crossbar (ds_bpermute).  The 7 - 12 % that pass are
 //                   compacted into a wavefront-private LDS queue, drained oldest first, and the exact test runs on 64-lane batches:
 //                   max over the 16 arcs of the arc minimum (branch free) is both the corner test (> t_min = min(fastTh, 7))
 //                   and cornerScore + 1.  Corners (3-4 % of the pixels) are appended to a list in the wavefront's LDS -- no
@@ -45,10 +46,6 @@ namespace uvo {
 // the lane mask of a predicate, straight from the compare (HIP's __ballot(int) goes through a 0 / 1 integer and a second compare)
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-#ifndef UVO_FAST_SCREEN_SWAR
-#define UVO_FAST_SCREEN_SWAR 2  // 2: the four-pixel 7-bit screen on a register ring of 7-bit rows, neighbours by ds_bpermute (round 4);
-                                // 1: the same screen with 8-bit rows and neighbours from the LDS ring; 0: the packed 16-bit screen of rounds 1-3
-#endif
 #ifndef UVO_FAST_WAVES
 #define UVO_FAST_WAVES 4       // wavefronts (regions) per workgroup
 #endif
@@ -105,22 +102,9 @@ __device__ __forceinline__ d16 arc9_minmax(const d16* d) {
   return m9[0];
 }
 
-// Screening of two pixels packed as 16-bit halves (see k_fast_score): non-zero half <=> that pixel may be a corner.
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ u16x2 pk(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
-__device__ __forceinline__ uint32_t screen2(uint32_t v, uint32_t p0, uint32_t p8, uint32_t p4, uint32_t p12, uint32_t p2, uint32_t p10,
-                                            uint32_t p6, uint32_t p14, uint32_t t2) {
-  const u16x2 mx = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(pk(p0), pk(p8)), __builtin_elementwise_max(pk(p4), pk(p12))),
-                                             __builtin_elementwise_min(__builtin_elementwise_max(pk(p2), pk(p10)), __builtin_elementwise_max(pk(p6), pk(p14))));
-  const u16x2 mn = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(pk(p0), pk(p8)), __builtin_elementwise_min(pk(p4), pk(p12))),
-                                             __builtin_elementwise_max(__builtin_elementwise_min(pk(p2), pk(p10)), __builtin_elementwise_min(pk(p6), pk(p14))));
-  const u16x2 hi = __builtin_elementwise_add_sat(pk(v), pk(t2)), lo = __builtin_elementwise_sub_sat(pk(v), pk(t2));
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mx, hi)) | __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(lo, mn));
-}
-constexpr uint32_t kEven = 0x00ff00ffu;
-
-// The same screen on all four pixels of a dword at once, in plain 32-bit add / sub / and / or (the instructions gfx950 issues at twice
-// the rate of the packed 16-bit min / max above), at seven bits per pixel: with x7 = x >> 1 and th = (t + 1) >> 1,
+// The screen: any 9-arc holds one pixel of every opposite ring pair, of one polarity -- so a corner has, in each of four opposite pairs,
+// a member brighter than v + t, or in each a member darker than v - t.  Evaluated on all four pixels of a dword at once in plain 32-bit
+// add / sub / and / or (the instructions gfx950 issues at twice the rate of packed 16-bit min / max), at seven bits per pixel: with x7 = x >> 1 and th = (t + 1) >> 1,
 //   p > v + t  =>  p7 >= v7 + th      and      p < v - t  =>  p7 <= v7 - th
 // (floor((a + b) / 2) >= floor(a / 2) + floor(b / 2)), so a test on the 7-bit values passes every pixel the exact test can pass -- and
 // hardly any more (7.23 % instead of 7.19 % of the pixels of the benchmark frames at t = 20, 12.1 % instead of 10.7 % at t = 7).  Seven-bit
@@ -142,7 +126,6 @@ __device__ __forceinline__ Screen4 screen4_centre7(uint32_t v7, uint32_t thv, ui
   r.cd = u | (m7 & ~ul);                               // max(u, 127)
   return r;
 }
-__device__ __forceinline__ Screen4 screen4_centre(uint32_t c, uint32_t thv, uint32_t m7, uint32_t h7) { return screen4_centre7(seven(c, m7), thv, m7, h7); }
 
 // LDS row ring of a wavefront.  The streaming loop is unrolled by seven rows (the register ring), so the ring's period is two blocks:
 // a block of parity pb writes its row u to slot 7 pb + u, and the rows of the even blocks are mirrored into slots 14 .. 20.  The seven
@@ -254,7 +237,6 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   const int Xc = X > x_last ? x_last : X;
   const int nrows = min(py0 + L.rows_per_seg, g.h) - py0;  // sub-strip 0 has the most rows
   const int nsrc = nrows + 8;  // centre rows py0-1 .. py1 need source rows py0-4 .. py1+3
-  const int lm = ls > 0 ? lane - 1 : lane, lp = ls < lps - 1 ? lane + 1 : lane;
   // pixel K of the lane is screened when it lies in the sub-strip or its one-pixel halo and in the detection window
   bool okv[4];
 #pragma unroll
@@ -262,15 +244,8 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
     const int xs = ls * 4 + K;
     okv[K] = nrows_l > 0 && xs >= 3 && xs <= sub_px - 4 && X + K >= 32 && X + K < g.w;
   }
-#if UVO_FAST_SCREEN_SWAR
-  uint32_t mk0 = okv[0] ? 0x00000080u : 0u, mk1 = okv[1] ? 0x00008000u : 0u, mk2 = okv[2] ? 0x00800000u : 0u, mk3 = okv[3] ? 0x80000000u : 0u;
-#else
-  uint32_t mk0 = okv[0] ? 0x0000ffffu : 0u, mk1 = okv[1] ? 0x0000ffffu : 0u, mk2 = okv[2] ? 0xffff0000u : 0u, mk3 = okv[3] ? 0xffff0000u : 0u;
-#endif
-  // (opaque to the optimiser, which would otherwise turn `(x & mk) != 0` back into a compare AND a lane flag -- two mask
-  // operations and a 0 / 1 round trip through a register instead of one AND and one compare)
-  asm volatile("" : "+v"(mk0), "+v"(mk1), "+v"(mk2), "+v"(mk3));
-  const uint32_t t_even = (uint32_t)t_min * 0x00010001u, t_odd = t_even << 8;
+  // bit 7 of byte K: the lane screens its pixel K
+  uint32_t mkall = (okv[0] ? 0x00000080u : 0u) | (okv[1] ? 0x00008000u : 0u) | (okv[2] ? 0x00800000u : 0u) | (okv[3] ? 0x80000000u : 0u);
   // constants of the four-pixel screen, in vector registers (a fast-class instruction that reads a scalar register or a literal is not one)
   uint32_t m7 = kM7, h7 = kH7, thv = (uint32_t)((t_min + 1) >> 1) * 0x01010101u;
   asm volatile("" : "+v"(m7), "+v"(h7), "+v"(thv));
@@ -307,22 +282,10 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
     qa -= 256u;
     qold = qold > 256u ? qold - 256u : 0u;
   };
-  // one compaction per pixel column: the lanes that pass store their entry behind the queue's end, which moves on by their number
-  // (a scalar byte address: one population count and one shift-add per push)
-#define UVO_FAST_PUSH(COND, ENTRY)                                                                                                      \
-  {                                                                                                                                     \
-    const bool pass = (COND);                                                                                                           \
-    const uint64_t m = ballot64(pass);                                                                                                  \
-    if (pass)                                                                                                                           \
-      *reinterpret_cast<uint32_t*>(lds8 + (qa + 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)))) = \
-          (ENTRY);                                                                                                                      \
-    qa += 4u * (uint32_t)__popcll(m);                                                                                                   \
-  }
   uint32_t nxt[7];
 #pragma unroll
   for (int u = 0; u < 7; ++u) nxt[u] = load_row(u);  // unconditional (the row index is clamped into the plane): with a branch around a load
                                                      // the compiler cannot count the loads in flight and waits for all of them
-#if UVO_FAST_SCREEN_SWAR == 2
   // Register rings of the last seven rows, at seven bits per pixel (the screen never looks at bit 0): the row itself and its views two
   // pixels to the right / left (ring pixels 2, 6 / 14, 10 of the centres two rows above and below).  The neighbour lanes' dwords come
   // over the LDS crossbar (ds_bpermute: no LDS memory, no vector-ALU slot), from the lanes next to it in the wavefront whatever sub-strip
@@ -330,12 +293,8 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   // of the views those two read are the lane's own -- V2p of the lane before holds them because ITS right neighbour is this lane.
   uint32_t S7[7], V2p[7];
   const int lm4 = ((lane + 63) & 63) * 4, lp4 = ((lane + 1) & 63) * 4;
-  uint32_t mkall = mk0 | mk1 | mk2 | mk3;
   uint32_t kpix = kEntPix, kentrow = kEntRow;
   asm volatile("" : "+v"(mkall), "+v"(kpix), "+v"(kentrow));
-#else
-  uint32_t Cr[7];
-#endif
   int pbo = 0;  // 7 * parity of the block
   for (int base = 0; base < nsrc; base += 7, pbo ^= 7) {
     uint32_t cur[7];
@@ -348,12 +307,7 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
     uint32_t* wr2 = rows32 + (14 - pbo) * FR_PITCH + lane;  // its mirror 14 + u in an even block (an odd block stores the same slot twice)
     const uint32_t rowbits_blk = base ? rowbits >> (base - 6) : rowbits << 6;  // bit u: the lane screens the centre row of loop row base + u
     const uint32_t ent_blk = lane_entry + ((uint32_t)((8 - pbo) * FR_PITCH * 4) + ((uint32_t)(base - 6) << 23));
-#if UVO_FAST_SCREEN_SWAR == 2
     uint32_t ent_row = ent_blk;  // entry of the lane's pixel 0 in the row at hand
-#else
-    const uint32_t* wl = rows32 + (8 - pbo) * FR_PITCH + lm;  // row j - 6 of u = 0 in the left / right neighbour's column
-    const uint32_t* wp = rows32 + (8 - pbo) * FR_PITCH + lp;
-#endif
 #pragma unroll
     for (int u = 0; u < 7; ++u) {
       const int j = base + u;
@@ -361,18 +315,13 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
         const uint32_t C = cur[u];
         wr[u * FR_PITCH] = C;
         wr2[u * FR_PITCH] = C;
-#if UVO_FAST_SCREEN_SWAR == 2
         const uint32_t c7 = seven(C, m7);
         S7[u] = c7;
         V2p[u] = __builtin_amdgcn_alignbyte((uint32_t)__builtin_amdgcn_ds_bpermute(lp4, (int)c7), c7, 2);
-#else
-        Cr[u] = C;
-#endif
         if (j >= 6) {
           // centre row jc = j - 3, relative to the sub-strip rrp = j - 6 (0 = halo row above, nrows + 1 = halo row below); rows jc-3 .. jc+3
           // sit in register slots (u+1)%7 .. u and in the ring slots the window pointers start at
           const uint32_t rowm = (uint32_t)__builtin_amdgcn_sbfe((int)rowbits_blk, (uint32_t)u, 1u);  // 0 / ~0: this lane screens this row
-#if UVO_FAST_SCREEN_SWAR == 2
           {
             const int sm3 = (u + 1) % 7, sm2 = (u + 2) % 7, s0 = (u + 4) % 7, sp2 = (u + 6) % 7, sp3 = u;
             const uint32_t cc = S7[s0];
@@ -405,45 +354,6 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
             UVO_FAST_PUSHB(3, e3)
 #undef UVO_FAST_PUSHB
           }
-#else
-          {
-            const int sm3 = (u + 1) % 7, sm2 = (u + 2) % 7, s0 = (u + 4) % 7, sp2 = (u + 6) % 7, sp3 = u;
-            const uint32_t Cc = Cr[s0], Cu = Cr[sm3], Cd = Cr[sp3], C2 = Cr[sp2], Cm2 = Cr[sm2];
-            // neighbour dwords of the centre row and of the rows two above / below it from the LDS row ring (written by this wavefront, in order)
-            const uint32_t Lc = wl[(u + 3) * FR_PITCH], Rc = wp[(u + 3) * FR_PITCH], L2 = wl[(u + 5) * FR_PITCH], R2 = wp[(u + 5) * FR_PITCH];
-            const uint32_t Lm2 = wl[(u + 1) * FR_PITCH], Rm2 = wp[(u + 1) * FR_PITCH];
-            // ---- screen the lane's 4 pixels with four opposite ring pairs, queue the ones that pass ----
-            const uint32_t P4 = __builtin_amdgcn_alignbyte(Rc, Cc, 3), P12 = __builtin_amdgcn_alignbyte(Cc, Lc, 1);
-            const uint32_t P2 = __builtin_amdgcn_alignbyte(R2, C2, 2), P14 = __builtin_amdgcn_alignbyte(C2, L2, 2);
-            const uint32_t P6 = __builtin_amdgcn_alignbyte(Rm2, Cm2, 2), P10 = __builtin_amdgcn_alignbyte(Cm2, Lm2, 2);
-#if UVO_FAST_SCREEN_SWAR
-            const Screen4 sc = screen4_centre(Cc, thv, m7, h7);
-            const uint32_t q0_ = seven(Cd, m7), q8 = seven(Cu, m7), q4 = seven(P4, m7), q12 = seven(P12, m7);
-            const uint32_t q2 = seven(P2, m7), q10 = seven(P10, m7), q6 = seven(P6, m7), q14 = seven(P14, m7);
-            const uint32_t bright = ((q0_ + sc.cb) | (q8 + sc.cb)) & ((q4 + sc.cb) | (q12 + sc.cb)) & ((q2 + sc.cb) | (q10 + sc.cb)) & ((q6 + sc.cb) | (q14 + sc.cb));
-            const uint32_t dark = ((sc.cd - q0_) | (sc.cd - q8)) & ((sc.cd - q4) | (sc.cd - q12)) & ((sc.cd - q2) | (sc.cd - q10)) & ((sc.cd - q6) | (sc.cd - q14));
-            const uint32_t rem = (bright | dark) & rowm, rom = rem;  // bit 7 of byte K: pixel K passes
-#else
-            // Packed 16-bit arithmetic, two pixels per instruction: the even bytes of a pixel dword sit in the two 16-bit
-            // halves as they are (x & 0x00ff00ff), the odd bytes scaled by 256 (x & 0xff00ff00); all compares are unsigned.
-            // bright <=> min over the pairs of max(pair) > v + t ; dark <=> max over the pairs of min(pair) < v - t
-            // (saturating add / sub keep v +- t in range; a saturated bound can never be crossed by a pixel value).
-            const uint32_t re = screen2(Cc & kEven, Cd & kEven, Cu & kEven, P4 & kEven, P12 & kEven, P2 & kEven, P10 & kEven, P6 & kEven,
-                                        P14 & kEven, t_even);
-            // odd pixels: unmasked words.  The even byte below the odd one only acts as a tie-breaker between equal odd bytes, which
-            // can let a few more pixels through the screen (harmless: the exact test follows) but never drops one.
-            const uint32_t ro = screen2(Cc, Cd, Cu, P4, P12, P2, P10, P6, P14, t_odd);
-            const uint32_t rem = re & rowm, rom = ro & rowm;
-#endif
-            // (the lane's column flags and the row flag are folded into one AND per pixel: mk0..3 select the pixel's part of the word)
-            const uint32_t ent_row = ent_blk + (uint32_t)u * kEntRow;
-            UVO_FAST_PUSH((rem & mk0) != 0u, ent_row)
-            UVO_FAST_PUSH((rom & mk1) != 0u, ent_row + kEntPix)
-            while (qa >= q0 + 256u) drain_oldest();  // keeps the queue within FQ_CAP
-            UVO_FAST_PUSH((rem & mk2) != 0u, ent_row + 2u * kEntPix)
-            UVO_FAST_PUSH((rom & mk3) != 0u, ent_row + 3u * kEntPix)
-          }
-#endif
           // ---- drain full batches, oldest first.  What stays behind is younger than what left, and only what has stayed behind for two
           // checkpoints in a row (after rows 2 and 6 of a block: 7 rows apart) is scored as an incomplete batch.  A queued pixel's oldest
           // ring row (j - 6) is overwritten 14 rows after it was written, i.e. 8 rows after the pixel was queued; it waits <= 6.
@@ -458,13 +368,10 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
             qold = qa - q0;
           }
         }
-#if UVO_FAST_SCREEN_SWAR == 2
         ent_row += kentrow;
-#endif
       }
     }
   }
-#undef UVO_FAST_PUSH
   if (qa > q0) fast_score_chunk(lds8, q0, (int)((qa - q0) >> 2), lane, t_min, list, region, ncorner, nflushed);
 
   // ---- in-cell 3x3 non-max suppression of the region's corners (cv::FAST with nonmaxSuppression on the cell ROI) ----
