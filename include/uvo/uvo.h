@@ -209,6 +209,9 @@ int uvo_sharder_run(uvo_sharder* s, const uint8_t* imgs, int n_imgs, int imgs_fi
  * d_n_out[b] may exceed `cap`; only the first `cap` records of a frame are written in that case.
  * A pipeline lane keeps at most two batches outstanding: the call first waits (on the host) for the lane's last but one batch, so a
  * caller that enqueues in a loop runs two to four batches ahead of the device and no further.
+ * d_imgs must stay valid AND UNCHANGED until the batch has completed: with dword-aligned rows (d_imgs, stride, frame_stride multiples of
+ * 4, width a multiple of 4) and no caller keypoints, level 0 of the pyramid is the caller's image itself, read in place by every stage
+ * (UVO_TUNE_LEVEL0_INPLACE; cv::copyMakeBorder of src/ORBextractor.cc:996 is never materialised).  Results do not depend on it.
  */
 int uvo_extract_batch_device(uvo_extractor* h, int batch, const uint8_t* d_imgs, int width, int height, ptrdiff_t stride,
                              ptrdiff_t frame_stride, const uvo_keypoint* d_in_kp, const int32_t* d_n_in, int32_t* d_grid2d, int grid_rows,

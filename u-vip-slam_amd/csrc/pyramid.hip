@@ -96,15 +96,21 @@ constexpr int RZ_ROWS = 4;  // output rows per thread: one column-table fetch, R
 __global__ __launch_bounds__(256, UVO_OCC_RESIZE) void k_resize_level(uint8_t* __restrict__ pyr, int64_t pyr_block, int64_t src_off, int src_pitch, int sw,
                                                       int64_t dst_off, int dst_pitch, int dst_ph, int dw, int fast_ok,
                                                       const ResizeCol* __restrict__ ctab, const ResizeRow* __restrict__ rtab,
-                                                      uint32_t nwx_magic, Level0View l0, int sh) {
+                                                      uint32_t nwx_magic, Level0View l0, int sh, uint32_t per_frame, uint32_t per_frame_magic, uint32_t per_xcd,
+                                                      int batch) {
   // flat index -> (row group, dword column): rows are a few dozen to 150 dwords long, so a (64 x rows) tiling would leave up to
   // a third of the lanes idle on some levels.  gid / nwx by multiply-high with ceil(2^32 / nwx) (exact for gid < 2^20).
-  const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+  // (an XCD walks whole frames: neighbouring workgroups read the same source rows -- dealt round-robin, every XCD's L2 fetched its own
+  // copy of them: 1.39 x the algorithmic bytes per launch)
+  // workgroup b runs on XCD b & 7: it takes item (b & 7) * per_xcd + (b >> 3) of the frame-major list of (frame, workgroup of the frame)
+  const uint32_t vb = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (vb >= per_frame * (uint32_t)batch) return;
+  const int f = (int)__umulhi(vb, per_frame_magic);  // vb / per_frame (exact: vb * per_frame < 2^32)
+  const uint32_t gid = (vb - (uint32_t)f * per_frame) * 256u + threadIdx.x;
   const uint32_t nwx = (uint32_t)dst_pitch >> 2;
   const uint32_t rg = __umulhi(gid, nwx_magic);
   const int wx = (int)(gid - rg * nwx);
   const int py0 = (int)rg * RZ_ROWS;
-  const int f = blockIdx.y;
   if (py0 >= dst_ph) return;
   // ROI origin of the source level; level 1 may read the caller's image in place (l0.vbase: the resize only looks at the ROI)
   const bool ip = l0.vbase != nullptr;
@@ -206,9 +212,10 @@ void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const
   dim3 block(256);
   const uint32_t nwx = (uint32_t)dst.pitch / 4, groups = ((uint32_t)dst.ph + RZ_ROWS - 1) / RZ_ROWS;
   const uint32_t magic = (uint32_t)((0x100000000ull + nwx - 1) / nwx);
-  dim3 grid((nwx * groups + 255) / 256, batch);
-  hipLaunchKernelGGL(k_resize_level, grid, block, 0, s, d_pyr, pyr_block, src.plane_off, src.pitch, src.w, dst.plane_off, dst.pitch, dst.ph,
-                     dst.w, fast_ok, d_ctab, d_rtab, magic, l0, src.h);
+  const uint32_t per_frame = (nwx * groups + 255) / 256, per_xcd = (per_frame * (uint32_t)batch + 7) / 8;
+  const uint32_t pf_magic = (uint32_t)((0x100000000ull + per_frame - 1) / per_frame);
+  hipLaunchKernelGGL(k_resize_level, dim3(8 * per_xcd), block, 0, s, d_pyr, pyr_block, src.plane_off, src.pitch, src.w, dst.plane_off, dst.pitch, dst.ph,
+                     dst.w, fast_ok, d_ctab, d_rtab, magic, l0, src.h, per_frame, pf_magic, per_xcd, batch);
 }
 
 
