@@ -230,6 +230,7 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   const int lps = 64 / nsub;                 // lanes per sub-strip
   const int sub = (lane * nsub) >> 6, ls = lane - sub * lps;
   const int sub_px = 4 * lps;                // pixels a sub-strip spans, halo lanes included
+  const int sub_shift = nsub == 1 ? 8 : (nsub == 2 ? 7 : 6);  // sub_px = 1 << sub_shift
   const int py0l = py0 + sub * L.rows_per_seg;
   const int nrows_l = max(min(py0l + L.rows_per_seg, g.h) - py0l, 0);  // 0: this sub-strip lies below the level
   const int X = X0 + ls * 4;  // padded column of the lane's first pixel; the first and last lane of a sub-strip are its halo
@@ -403,34 +404,33 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
         const bool valid = base + 64 * u + lane < ncorner;
         keep[u] = false, out[u] = 0;
         const int xl = (int)(e[u] & 0xff), rrp = (int)((e[u] >> 8) & 0xff), ss = (int)(e[u] >> 16);
-        // the sub-strip the corner belongs to: columns [es * sub_px, (es + 1) * sub_px) of the tile, rows of segment es
-        const int es = (xl * nsub) >> 8;
-        const int xs = xl - es * sub_px, py0e = py0 + es * L.rows_per_seg;
+        // the sub-strip the corner belongs to: columns [es * sub_px, (es + 1) * sub_px) of the tile, rows of segment es (sub_px = 256 / nsub:
+        // shifts and 24-bit multiplies -- a 32-bit integer multiply issues at a quarter of their rate)
+        const int es = xl >> sub_shift;
+        const int xs = xl & (sub_px - 1), py0e = py0 + (int)__umul24((uint32_t)es, (uint32_t)L.rows_per_seg);
         const int nrows_e = min(py0e + L.rows_per_seg, g.h) - py0e;
         const bool owned = valid && xs >= 4 && xs < sub_px - 4 && rrp >= 1 && rrp <= nrows_e;  // not a halo-ring corner
         if (owned) {
           // coordinates relative to (minBorder, minBorder), as the candidate list wants them
           const int xr = X0 + xs - kPad - kMinBorder, yr = py0e + rrp - 1 - kPad - kMinBorder;
-          int cj = (int)__umulhi((uint32_t)(xr - 3), g.inv_wcell), ci = (int)__umulhi((uint32_t)(yr - 3), g.inv_hcell);  // (xr-3)/wCell, (yr-3)/hCell
+          // (xr-3) / wCell, (yr-3) / hCell by a 24-bit multiply with ceil(2^24 / cell): exact for dividends below 4096 and cells of 17 .. 66 pixels
+          int cj = (int)(__umul24((uint32_t)(xr - 3), g.inv_wcell) >> 24), ci = (int)(__umul24((uint32_t)(yr - 3), g.inv_hcell) >> 24);
           cj = cj > g.nCols - 1 ? g.nCols - 1 : cj;
           ci = ci > g.nRows - 1 ? g.nRows - 1 : ci;
           // interior of the owning cell: [j*wCell + 3, min(j*wCell + wCell + 6, bw) - 3) and the same in y.  The corner lies inside it, so
           // a neighbour can only fall outside on the side where the corner touches the interior's edge
-          const int cx0 = cj * g.wCell + 3, cx1 = min(cj * g.wCell + g.wCell + 6, g.bw) - 3;
-          const int cy0 = ci * g.hCell + 3, cy1 = min(ci * g.hCell + g.hCell + 6, g.bh) - 3;
-          const bool okx[3] = {xr > cx0, true, xr + 1 < cx1}, oky[3] = {yr > cy0, true, yr + 1 < cy1};
+          const int cx0 = (int)__umul24((uint32_t)cj, (uint32_t)g.wCell) + 3, cx1 = min(cx0 + g.wCell + 3, g.bw) - 3;
+          const int cy0 = (int)__umul24((uint32_t)ci, (uint32_t)g.hCell) + 3, cy1 = min(cy0 + g.hCell + 3, g.bh) - 3;
+          // all eight neighbours are read (an owned corner's are inside the tile) and the ones beyond the cell's interior masked out: one
+          // EXEC region, eight loads in flight, instead of a predicated load each
+          const uint32_t mL = xr > cx0 ? 0xffu : 0u, mR = xr + 1 < cx1 ? 0xffu : 0u, mU = yr > cy0 ? 0xffu : 0u, mD = yr + 1 < cy1 ? 0xffu : 0u;
           const uint8_t* c = tile + rrp * FT_PITCH + xl;
-          bool k = true;
-#pragma unroll
-          for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-              if (dx == 0 && dy == 0) continue;
-              const int nb = (okx[dx + 1] && oky[dy + 1]) ? (int)c[dy * FT_PITCH + dx] : 0;
-              k = k && ss > nb;
-            }
+          const uint32_t n0 = c[-FT_PITCH - 1], n1 = c[-FT_PITCH], n2 = c[-FT_PITCH + 1], n3 = c[-1], n4 = c[1], n5 = c[FT_PITCH - 1], n6 = c[FT_PITCH],
+                         n7 = c[FT_PITCH + 1];
+          const uint32_t up = max(max(n0 & mL, n1), n2 & mR) & mU, dn = max(max(n5 & mL, n6), n7 & mR) & mD, mid = max(n3 & mL, n4 & mR);
+          const bool k = (uint32_t)ss > max(max(up, mid), dn);
           keep[u] = k;
-          if (k && ss >= fast_th) hi[ci * g.nCols + cj] = 1;  // idempotent plain store: every writer stores the same value
+          if (k && ss >= fast_th) hi[(int)__umul24((uint32_t)ci, (uint32_t)g.nCols) + cj] = 1;  // idempotent plain store: every writer stores the same value
           out[u] = (uint32_t)xr | ((uint32_t)yr << 12) | ((uint32_t)ss << 24);
         }
       }
@@ -774,7 +774,7 @@ FastLevels fast_levels(const Geom& g, int batch) {
       F.plane_off = G.plane_off, F.cand_off = G.cand_off, F.pitch = G.pitch, F.cand_cap = G.cand_cap;
       F.w = G.w, F.h = G.h, F.bw = G.bw, F.bh = G.bh, F.nCols = G.nCols, F.nRows = G.nRows, F.wCell = G.wCell, F.hCell = G.hCell;
       F.flag_base = fb;
-      F.inv_wcell = (uint32_t)((0x100000000ull + G.wCell - 1) / G.wCell), F.inv_hcell = (uint32_t)((0x100000000ull + G.hCell - 1) / G.hCell);
+      F.inv_wcell = (uint32_t)(((1u << 24) + G.wCell - 1) / G.wCell), F.inv_hcell = (uint32_t)(((1u << 24) + G.hCell - 1) / G.hCell);
       fb += G.nRows * G.nCols;
       fast_strip_plan(G.w - 32, G.h - 32, L.rows_per_seg, F);
       F.first_item = first;

@@ -16,7 +16,8 @@ struct FastLevel {  // per-level values of the sparse stages, passed in the kern
   int nCols, nRows, wCell, hCell;
   int flag_base;  // first entry of this level in the per-frame cell-flag array (full nRows x nCols grid)
   int pad;
-  uint32_t inv_wcell, inv_hcell;  // ceil(2^32 / wCell), ceil(2^32 / hCell): n / cell = umulhi(n, inv) for the coordinate range
+  uint32_t inv_wcell, inv_hcell;  // ceil(2^24 / wCell), ceil(2^24 / hCell): n / cell = (n * inv) >> 24 in 24-bit multiplies, exact for n < 4096
+                                  // (n * (inv * cell - 2^24) < 2^24: the excess is below the cell size, at most 66)
   // strips of the detection window (see fast_strip_plan): nfull wavefront-wide strips of FS_COLS columns, then up to two narrow ones
   // in which a wavefront walks `sub[k]` row segments side by side (32 or 16 lanes each)
   int nfull, nseg, items, first_item;

@@ -109,7 +109,7 @@ __device__ __forceinline__ void octree_body(uint8_t* lds, const int level, const
         emit[u] = false;
         if (i < n_lo) {
           const int xr = (int)(e[u] & 0xfff), yr = (int)((e[u] >> 12) & 0xfff), sc = (int)(e[u] >> 24);
-          int cj = (int)__umulhi((uint32_t)(xr - 3), fg.inv_wcell), ci = (int)__umulhi((uint32_t)(yr - 3), fg.inv_hcell);
+          int cj = (int)(__umul24((uint32_t)(xr - 3), fg.inv_wcell) >> 24), ci = (int)(__umul24((uint32_t)(yr - 3), fg.inv_hcell) >> 24);
           cj = cj > fg.nCols - 1 ? fg.nCols - 1 : cj;
           ci = ci > fg.nRows - 1 ? fg.nRows - 1 : ci;
           const uint8_t flag = flag_lds ? s_flag[ci * fg.nCols + cj] : hi[ci * fg.nCols + cj];
