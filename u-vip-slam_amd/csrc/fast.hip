@@ -295,6 +295,8 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   uint32_t S7[7], V2p[7];
   const int lm4 = ((lane + 63) & 63) * 4, lp4 = ((lane + 1) & 63) * 4;
   uint32_t kpix = kEntPix, kentrow = kEntRow;
+  uint32_t qdump = q0 + (uint32_t)(FQ_CAP - 1) * 4u;  // a dword of the queue no entry ever reaches (< 64 + 128 entries at any time)
+  asm volatile("" : "+v"(qdump));
   asm volatile("" : "+v"(mkall), "+v"(kpix), "+v"(kentrow));
   int pbo = 0;  // 7 * parity of the block
   for (int base = 0; base < nsrc; base += 7, pbo ^= 7) {
@@ -342,11 +344,12 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   {                                                                                                                                     \
     uint64_t m;                                                                                                                         \
     asm("v_cmp_gt_i32_sdwa %0, 0, sext(%1) src0_sel:DWORD src1_sel:BYTE_" #BYTE : "=s"(m) : "v"(pm));                                   \
-    if (__builtin_amdgcn_inverse_ballot_w64(m))                                                                                         \
-      *reinterpret_cast<uint32_t*>(lds8 + (qa + 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)))) = \
-          (ENTRY);                                                                                                                      \
-    qa += 4u * (uint32_t)__popcll(m);                                                                                                   \
-    asm volatile("" : "+s"(qa)); /* the end moves now, on the scalar unit: merged, the second store adds the first count per lane */     \
+    /* no EXEC region: the lanes that do not pass store to a dword of the queue no entry ever reaches (a select costs the SIMD less    \
+       than the two scalar instructions that open and close a region: DESIGN.md section 7.2) */                                         \
+    const uint32_t a_ = qa + 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));           \
+    *reinterpret_cast<uint32_t*>(lds8 + (__builtin_amdgcn_inverse_ballot_w64(m) ? a_ : qdump)) = (ENTRY);                               \
+    const uint32_t n_ = (uint32_t)__popcll(m);                                                                                          \
+    asm volatile("s_lshl2_add_u32 %0, %1, %0" : "+s"(qa) : "s"(n_) : "scc"); /* the end moves now, on the scalar unit, in one op */      \
   }
             UVO_FAST_PUSHB(0, ent_row)
             UVO_FAST_PUSHB(1, e1)
@@ -377,7 +380,8 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
 
   // ---- in-cell 3x3 non-max suppression of the region's corners (cv::FAST with nonmaxSuppression on the cell ROI) ----
   uint8_t* tile = reinterpret_cast<uint8_t*>(rows32);  // [row' = row - py0 + 1][xl], FT_PITCH bytes per row; ring and queue are dead
-  for (int i = lane; i < FT_ROWS * FT_PITCH / 4; i += 64) rows32[i] = 0u;
+#pragma unroll
+  for (int i = 0; i < FT_ROWS * FT_PITCH / 4 / 64; ++i) rows32[i * 64 + lane] = 0u;  // 26 stores, no loop bookkeeping on the scalar unit
   uint8_t* hi = cell_hi + (int64_t)f * L.flags_per_frame + g.flag_base;
   // the corner list (in LDS, or in memory once it has spilled) is compacted in place to the NMS survivors: x | y << 12 | score << 24
   // relative to (minBorder, minBorder)
