@@ -98,12 +98,12 @@ def test_fast_atan2_is_within_its_documented_error_of_arctan2(oracle):
     assert got[-1] == 0.0 and (got >= 0).all() and (got < 360.0 + 1e-3).all()
 
 
-def _skimage_probe(img, thresholds, corners):
+def _skimage_probe(img, thresholds, corners, **extra):
     if not os.path.exists(PY39):
         pytest.skip("no /opt/conda/bin/python3.9 (scikit-image) in this image")
     with tempfile.TemporaryDirectory() as td:
         a, b = os.path.join(td, "in.npz"), os.path.join(td, "out.npz")
-        np.savez(a, img=img, thresholds=np.array(thresholds), corners=np.asarray(corners, np.int64))
+        np.savez(a, img=img, thresholds=np.array(thresholds), corners=np.asarray(corners, np.int64), **extra)
         r = subprocess.run([PY39, "-W", "ignore", os.path.join(ROOT, "tests", "crosscheck", "skimage_probe.py"), a, b], capture_output=True, text=True)
         if r.returncode != 0:
             pytest.skip("scikit-image probe failed: " + r.stderr[-300:])
@@ -125,6 +125,24 @@ def test_fast_corner_set_equals_scikit_image(oracle, frames):
             ref[:, :3] = ref[:, -3:] = False
             assert got.sum() > 200
             np.testing.assert_array_equal(got, ref, err_msg="frame %d threshold %d" % (i, t))
+
+
+def test_corner_score_equals_the_largest_threshold_scikit_image_still_calls_a_corner(oracle, frames):
+    """cornerScore<16> (behind cv::FAST's `response`, which drives the 3x3 suppression and every selection after it): "the largest threshold
+    that keeps the pixel a corner" -- evaluated literally with scikit-image's segment test at every threshold 0 .. 200."""
+    img = frames[1]
+    out = _skimage_probe(img, [20], np.zeros((1, 2)), score_upto=np.array(200))
+    ref = out["score"]
+    ref[:3] = ref[-3:] = -1
+    ref[:, :3] = ref[:, -3:] = -1
+    assert ref.max() < 200                                         # the sweep saw every corner die
+    for th in (7, 20):
+        kp = oracle.fast(img, th, nms=False)
+        y, x = kp["y"].astype(int), kp["x"].astype(int)
+        assert len(kp) > 200
+        np.testing.assert_array_equal(kp["response"].astype(int), ref[y, x], err_msg="threshold %d" % th)
+        # and nothing with a score of at least the threshold is missing
+        assert len(kp) == int((ref >= th).sum()), (len(kp), int((ref >= th).sum()))
 
 
 def test_orientation_patch_and_pattern_equal_scikit_images(oracle, frames):
@@ -152,6 +170,31 @@ def test_orientation_patch_and_pattern_equal_scikit_images(oracle, frames):
     pat = oe.pattern().reshape(256, 4)
     np.testing.assert_array_equal(pat[:, :2], out["pos0"])
     np.testing.assert_array_equal(pat[:, 2:], out["pos1"])
+
+
+def test_steered_brief_bits_equal_scikit_images_descriptor_loop(oracle, frames):
+    """computeOrbDescriptor (src/ORBextractor.cc:156-195): which pixel pairs are compared, how they turn with the keypoint's angle, which
+    way the comparison goes and where the bit lands in the 32 bytes -- against scikit-image's ORB descriptor loop, fed with the oracle's own
+    blurred level 0, keypoints and angles.  The two round the rotated sample points differently (cvRound on float32 products: half to
+    even; C round() on float64 products: half away from zero), so a sample point that falls within float32 rounding of a half-integer may
+    be read one pixel apart: a handful of bits per thousand keypoints.  A wrong pair order, steering sign, comparison direction or bit
+    order would flip half of them."""
+    total = bits = 0
+    for img in frames:
+        oe = oracle.extractor(1000, 1.2, 8, 20)
+        kp, desc = oe(img)
+        lv0 = kp["octave"] == 0
+        assert lv0.sum() > 100
+        blurred = oe.level_plane(0, blurred=True)                      # padded by 16
+        rc = np.stack([np.rint(kp["y"][lv0]).astype(np.int64) + 16, np.rint(kp["x"][lv0]).astype(np.int64) + 16], 1)
+        out = _skimage_probe(img, [20], np.zeros((1, 2)), desc_img=blurred, desc_kp=rc, desc_angle=np.radians(kp["angle"][lv0].astype(np.float64)))
+        ref = out["descriptors"].astype(bool)                          # (M, 256): bit j of the descriptor
+        got = np.unpackbits(desc[lv0], axis=1, bitorder="little").astype(bool)
+        diff = got != ref
+        assert diff.sum(1).max() <= 3, diff.sum(1).max()
+        total += int(diff.sum())
+        bits += diff.size
+    assert total <= bits // 2000, (total, bits)                        # measured: 0 of 56 064 bits on the first frame
 
 
 @pytest.mark.parametrize("w", [320, 318, 157])
