@@ -147,7 +147,9 @@ __global__ __launch_bounds__(256, UVO_OCC_RESIZE) void k_resize_level(uint8_t* _
     rr[j].sy0 = (int16_t)(tw[2 * j] & 0xffffu), rr[j].sy1 = (int16_t)(tw[2 * j] >> 16);
     rr[j].b0 = (int16_t)(tw[2 * j + 1] & 0xffffu), rr[j].b1 = (int16_t)(tw[2 * j + 1] >> 16);
   }
-  if (interior && !ip) {
+  // (in place, only a row group that reaches the frame's last source row has to look at the frame's end)
+  const bool guard = ip && max(max((int)rr[0].sy1, (int)rr[1].sy1), max((int)rr[2].sy1, (int)rr[3].sy1)) >= sh - 1;
+  if (interior && !guard) {
 #pragma unroll
     for (int j = 0; j < RZ_ROWS; ++j) {
       const uint32_t* p0 = reinterpret_cast<const uint32_t*>(S + (int64_t)rr[j].sy0 * src_pitch + base);
