@@ -262,7 +262,9 @@ __global__ __launch_bounds__(64 * UVO_FAST_WAVES, UVO_FAST_MIN_BLOCKS) void k_fa
   const int last_row = g.h + 15;  // last row of the padded plane
   auto load_row = [&](int j) -> uint32_t {
     const int r = min(py0l - 4 + j, last_row);  // rows past the plane belong to a sub-strip below the level: never used
-    return *reinterpret_cast<const uint32_t*>(src + (int64_t)r * pitch + Xc);
+    // (a plane is far below 4 GB: wave-uniform base + a 32-bit lane offset by a 24-bit multiply -- the 64-bit multiply-add the pointer
+    // arithmetic asks for issues at a quarter of the rate)
+    return *reinterpret_cast<const uint32_t*>(src + (__umul24((uint32_t)r, (uint32_t)pitch) + (uint32_t)Xc));
   };
   // queue entry of the lane's pixel K in row u of a block = ent_blk + u * kEntRow + K * kEntPix:
   //   address part: this wavefront's ring + the window's first slot (row j - 6) + the lane's pixel K - 3 columns; xl part; row part

@@ -160,11 +160,12 @@ __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, 
       r = r < 0 ? -r : r;
       r = r > g.h - 1 ? 2 * (g.h - 1) - r : r;
       r = r < 0 ? 0 : r;                        // (rows past the border's reach are never used by a valid output)
-      const uint32_t v = *reinterpret_cast<const uint32_t*>(src + (int64_t)r * spitch + Xc);
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(src + (__umul24((uint32_t)r, (uint32_t)spitch) + (uint32_t)Xc));  // (see below)
       return __builtin_amdgcn_perm(v, v, csel);
     }
     prow = prow > g.ph - 1 ? g.ph - 1 : prow;  // rows past the plane are never used by a valid output
-    return *reinterpret_cast<const uint32_t*>(src + (int64_t)prow * spitch + Xc);
+    // wave-uniform base + 32-bit lane offset by a 24-bit multiply (a plane is far below 4 GB; a 64-bit multiply-add issues at a quarter of the rate)
+    return *reinterpret_cast<const uint32_t*>(src + (__umul24((uint32_t)prow, (uint32_t)spitch) + (uint32_t)Xc));
   };
   // byte offset of sub-strip 0's current output row inside its tile column: tile row * tile_row_bytes + (row % 8) * 16, advanced row by
   // row (one scalar add instead of a 64-bit multiply per row)
