@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256, UVO_OCC_RESIZE) void k_resize_level(uint8_t* _
       w[j][0] = p1[0], w[j][1] = o1 + 4 < s_end ? p1[1] : 0u, w[j][2] = o1 + 8 < s_end ? p1[2] : 0u;
     }
   }
+  uint32_t vout[RZ_ROWS];
 #pragma unroll
   for (int j = 0; j < RZ_ROWS; ++j) {
     uint32_t L0, R0, L1, R1;  // left / right taps of the four columns in the two source rows
@@ -193,10 +194,17 @@ __global__ __launch_bounds__(256, UVO_OCC_RESIZE) void k_resize_level(uint8_t* _
     v |= vrow(hrow<1>(L0, R0, a0[1], a1[1]), hrow<1>(L1, R1, a0[1], a1[1]), b0s, b1s) << 8;
     v |= vrow(hrow<2>(L0, R0, a0[2], a1[2]), hrow<2>(L1, R1, a0[2], a1[2]), b0s, b1s) << 16;
     v |= vrow(hrow<3>(L0, R0, a0[3], a1[3]), hrow<3>(L1, R1, a0[3], a1[3]), b0s, b1s) << 24;
-    if (py0 + j < dst_ph) {
-      uint8_t* dst = pyr + f * pyr_block + dst_off + (int64_t)(py0 + j) * dst_pitch;
-      *reinterpret_cast<uint32_t*>(dst + wx * 4) = v;
-    }
+    vout[j] = v;
+  }
+  // all four rows of a group exist except in the plane's last group: one test per thread instead of one per row
+  uint8_t* dst = pyr + f * pyr_block + dst_off + (int64_t)py0 * dst_pitch + wx * 4;
+  if (py0 + RZ_ROWS <= dst_ph) {
+#pragma unroll
+    for (int j = 0; j < RZ_ROWS; ++j) *reinterpret_cast<uint32_t*>(dst + (uint32_t)(j * dst_pitch)) = vout[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < RZ_ROWS; ++j)
+      if (py0 + j < dst_ph) *reinterpret_cast<uint32_t*>(dst + (uint32_t)(j * dst_pitch)) = vout[j];
   }
 }
 
