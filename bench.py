@@ -419,6 +419,8 @@ def main():
         ex.tune(uvo.UVO_TUNE_FUSE_BLUR_TREE, int(os.environ["UVO_BENCH_FUSE"]))
     if os.environ.get("UVO_BENCH_L0"):   # experiment knob: level 0 read in place (1, default) or copied into a padded plane first (0)
         ex.tune(uvo.UVO_TUNE_LEVEL0_INPLACE, int(os.environ["UVO_BENCH_L0"]))
+    if os.environ.get("UVO_BENCH_RING"):   # experiment knob: border pixels the resize launches write around a level (4 default, 0 = all 16)
+        ex.tune(uvo.UVO_TUNE_PYR_RING, int(os.environ["UVO_BENCH_RING"]))
     if os.environ.get("UVO_BENCH_DELAY_US"):   # development probe: an idle kernel of that many microseconds in every lane's batch
         ex.tune(100, int(os.environ["UVO_BENCH_DELAY_US"]))
     if os.environ.get("UVO_BENCH_OCT_WIDE_MAX"):   # experiment knob: quad-tree launch shape (uvo_extractor_tune)

@@ -259,6 +259,9 @@ int uvo_extractor_set_pipeline(uvo_extractor* h, int depth);
 #define UVO_TUNE_LEVEL0_INPLACE 11 /* 1 (default): level 0 is read from the caller's image in place whenever it can be (dword-aligned rows, width a
                                      multiple of 4, no caller keypoints): cv::copyMakeBorder of src/ORBextractor.cc:996 is never materialised, the
                                      blur reflects the border it needs on the fly; 0: always copy into a padded plane first */
+#define UVO_TUNE_PYR_RING 12       /* 4 (default), 8, 12: the resize launches of the pyramid write a level's image and that many pixels of the border around
+                                     it -- no stage reads past four (FAST and the orientation patch stay inside the image, the blur reaches 3 and copies
+                                     4 into the blurred plane's ring); 0: the whole EDGE_THRESHOLD border of src/ORBextractor.cc:988 */
 #define UVO_TUNE_FUSE_BLUR_TREE 10 /* 1 (default): DistributeOctTree and GaussianBlur share one launch when the batch is large enough for the
                                      256-thread quad-tree form (neither reads what the other writes); 0: two launches */
 #define UVO_TUNE_BLUR_ROUNDING 9

@@ -171,3 +171,27 @@ def test_level0_is_read_in_place_from_the_callers_rows(uvo, oracle, synth, W, H,
                 np.testing.assert_array_equal(blur_on[b][l][14:-14, 14:-14], oe.level_plane(l, blurred=True)[14:-14, 14:-14])
     assert (buf.cpu().numpy() == host).all()                 # the caller's buffer is read only
     ex.close()
+
+
+@pytest.mark.parametrize("ring", [0, 4, 8, 12])
+def test_the_resize_launches_may_stop_four_pixels_outside_the_image(uvo, oracle, synth, ring):
+    """UVO_TUNE_PYR_RING: the chain's resize launches write a level's image and `ring` pixels of its border (default 4: nothing reads further
+    out -- the blur reaches 3 and copies 4 into the blurred plane's ring); 0 = the whole 16-pixel border.  Keypoints, descriptors and the
+    blurred planes never depend on it; uvo_extractor_read_plane completes the border of an un-blurred level on demand, for these tests."""
+    for (w, h, nlev) in ((640, 512, 8), (637, 509, 7), (333, 301, 5)):
+        img = synth.make_frame(6300 + w, w, h)
+        oe = oracle.extractor(700, 1.2, nlev, 20)
+        kp_o, de_o = oe(img)
+        ex = uvo.ORBextractor(700, 1.2, nlev, 0, 20, max_width=w, max_height=h)
+        ex.tune(uvo.UVO_TUNE_PYR_RING, ring)
+        for _ in range(2):
+            kp, de = ex(img)
+            assert kp.tobytes() == kp_o.tobytes() and (de == de_o).all()
+            for l in range(nlev):
+                if (kp_o["octave"] == l).any():
+                    np.testing.assert_array_equal(ex.read_plane(l, blurred=True)[12:-12, 12:-12], oe.level_plane(l, blurred=True)[12:-12, 12:-12],
+                                                  err_msg="blurred level %d" % l)
+            _planes_equal(ex, oe, nlev, "%dx%d ring %d" % (w, h, ring))
+        ex.close()
+    with pytest.raises(uvo.UvoError):
+        uvo.ORBextractor(100, 1.2, 4, 0, 20, max_width=320, max_height=240).tune(uvo.UVO_TUNE_PYR_RING, 5)

@@ -30,6 +30,7 @@ UVO_PYR_MODE_CHAIN, UVO_PYR_MODE_SPLIT = 0, 1
 UVO_TUNE_BLUR_ROUNDING, UVO_BLUR_ROUNDING_SCALAR, UVO_BLUR_ROUNDING_SSE2 = 9, 0, 1
 UVO_TUNE_FUSE_BLUR_TREE = 10
 UVO_TUNE_LEVEL0_INPLACE = 11
+UVO_TUNE_PYR_RING = 12
 
 # every symbol include/uvo/uvo.h declares
 ABI_SYMBOLS = [

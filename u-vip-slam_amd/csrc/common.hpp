@@ -115,7 +115,7 @@ int fail(int code, const char* msg);  // records msg for uvo_last_error() and re
 void launch_pad_level0(hipStream_t s, const uint8_t* d_img, int w, int h, int64_t stride, int64_t frame_stride, uint8_t* d_pyr,
                        int64_t pyr_block, const LevelGeom& g0, int batch);
 void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const LevelGeom& src, const LevelGeom& dst, const ResizeCol* d_ctab,
-                         const ResizeRow* d_rtab, int fast_ok, int batch, Level0View l0);
+                         const ResizeRow* d_rtab, int fast_ok, int batch, Level0View l0, int ring);
 // the fused pyramid kernel's schedule of one band count, on the device (pyr_schedule.hpp)
 struct PyrPlanDev {
   int nbands = 0, nwaves = 0, nslots = 0, nsteps = 0;

@@ -124,6 +124,7 @@ struct uvo_extractor {
   int pyr_bands_forced = 0;  // UVO_TUNE_PYR_BANDS: 0 = by batch size
   int pyr_waves = 0;         // UVO_TUNE_PYR_WAVES: at least this many wavefronts per workgroup (0: the smallest shape that holds the roles)
   int pyr_rows = 7;          // level-0 rows per macro-step
+  int pyr_ring = 4;          // UVO_TUNE_PYR_RING: the chain's resize launches write the ROI + this many pixels around it (0: the whole 16-pixel pad)
   int level0_inplace = 1;    // UVO_TUNE_LEVEL0_INPLACE: read level 0 from the caller's image instead of copying it into a padded plane (when it can be)
   int fuse_blur_tree = 1;    // UVO_TUNE_FUSE_BLUR_TREE: quad-tree and blur as one launch when the batch takes the 256-thread quad-tree form
   int probe_delay_us = 0;    // development probe (UVO_TUNE 100): an idle single-wavefront kernel of this many microseconds behind the pyramid
@@ -571,7 +572,7 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
     for (int l = 1; l < g.nlevels; ++l) {
       ProfScope p(h, "k_resize_level");
       launch_resize_level(s, L.d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_ctab + g.lv[l].xtab_off, h->d_rtab + g.lv[l].ytab_off, h->resize_fast[l],
-                          batch, l == 1 ? l0 : no_l0);
+                          batch, l == 1 ? l0 : no_l0, h->pyr_ring);
     }
   }
   if (h->probe_delay_us > 0) {
@@ -968,6 +969,10 @@ int uvo_extractor_tune(uvo_extractor* h, int knob, int value) {
     case UVO_TUNE_PYR_RUN:
       if (value < 0 || value > 64) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_RUN takes 0 .. 64");
       h->pyr_blocks_per_item = value;
+      return UVO_OK;
+    case UVO_TUNE_PYR_RING:
+      if (value != 0 && value != 4 && value != 8 && value != 12) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_RING takes 0, 4, 8 or 12");
+      h->pyr_ring = value;
       return UVO_OK;
     case UVO_TUNE_LEVEL0_INPLACE:
       h->level0_inplace = value != 0;
@@ -1406,6 +1411,16 @@ int uvo_extractor_read_plane(uvo_extractor* h, int frame, int level, int which, 
   UVO_HIP_CHECK(hipStreamSynchronize(h->lane[h->cur].stream));
   const LevelGeom& L = h->geom.lv[level];
   Lane& LN = h->lane[h->cur];
+  if (!which && level >= 1 && h->pyr_ring > 0 && h->pyr_mode == UVO_PYR_MODE_CHAIN) {
+    // the batch wrote the level's ROI and the few pixels around it that a stage reads: this test tap completes the 16-pixel border (the same
+    // launch over the whole padded plane; its source -- the ROI of the level below, or the caller's image -- is still there)
+    const Geom& g = h->geom;
+    Level0View v{nullptr, 0, 0, 0};
+    if (level == 1 && LN.l0_src) v = Level0View{LN.l0_src - (int64_t)kPad * LN.l0_stride - kPad, LN.l0_frame_stride, (int)LN.l0_stride, 0};
+    launch_resize_level(LN.stream, LN.d_pyr, g.pyr_block, g.lv[level - 1], g.lv[level], h->d_ctab + g.lv[level].xtab_off, h->d_rtab + g.lv[level].ytab_off,
+                        h->resize_fast[level], h->last_batch, v, 0);
+    UVO_HIP_CHECK(hipStreamSynchronize(LN.stream));
+  }
   if (!which && level == 0 && LN.l0_src) {
     // the batch read level 0 in place: this test tap makes the padded plane it never needed (the caller's images must still be there)
     launch_pad_level0(LN.stream, LN.l0_src, h->geom.width, h->geom.height, LN.l0_stride, LN.l0_frame_stride, LN.d_pyr, h->geom.pyr_block, h->geom.lv[0], h->last_batch);

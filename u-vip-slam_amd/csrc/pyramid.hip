@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, UVO_OCC_RESIZE) void k_resize_level(uint8_t* _
                                                       int64_t dst_off, int dst_pitch, int dst_ph, int dw, int fast_ok,
                                                       const ResizeCol* __restrict__ ctab, const ResizeRow* __restrict__ rtab,
                                                       uint32_t nwx_magic, Level0View l0, int sh, uint32_t per_frame, uint32_t per_frame_magic, uint32_t per_xcd,
-                                                      int batch) {
+                                                      int batch, uint32_t nwx, int wx0, int rg0, int row_end) {
   // flat index -> (row group, dword column): rows are a few dozen to 150 dwords long, so a (64 x rows) tiling would leave up to
   // a third of the lanes idle on some levels.  gid / nwx by multiply-high with ceil(2^32 / nwx) (exact for gid < 2^20).
   // (an XCD walks whole frames: neighbouring workgroups read the same source rows -- dealt round-robin, every XCD's L2 fetched its own
@@ -107,11 +107,14 @@ __global__ __launch_bounds__(256, UVO_OCC_RESIZE) void k_resize_level(uint8_t* _
   if (vb >= per_frame * (uint32_t)batch) return;
   const int f = (int)__umulhi(vb, per_frame_magic);  // vb / per_frame (exact: vb * per_frame < 2^32)
   const uint32_t gid = (vb - (uint32_t)f * per_frame) * 256u + threadIdx.x;
-  const uint32_t nwx = (uint32_t)dst_pitch >> 2;
-  const uint32_t rg = __umulhi(gid, nwx_magic);
-  const int wx = (int)(gid - rg * nwx);
+  // the launch covers dword columns wx0 .. wx0 + nwx - 1 and rows rg0 * 4 .. row_end - 1 of the padded plane: all of it, or the ROI and the
+  // four pixels around it that anything ever reads (launch_resize_level)
+  const uint32_t rgl = __umulhi(gid, nwx_magic);
+  const int wx = (int)(gid - rgl * nwx) + wx0;
+  const uint32_t rg = rgl + (uint32_t)rg0;
   const int py0 = (int)rg * RZ_ROWS;
-  if (py0 >= dst_ph) return;
+  if (py0 >= row_end) return;
+  dst_ph = row_end;
   // ROI origin of the source level; level 1 may read the caller's image in place (l0.vbase: the resize only looks at the ROI)
   const bool ip = l0.vbase != nullptr;
   if (ip) src_pitch = l0.pitch;
@@ -217,15 +220,23 @@ void launch_pad_level0(hipStream_t s, const uint8_t* d_img, int w, int h, int64_
                      vec_ok);
 }
 
+// ring = 0: the whole padded plane, as cv::copyMakeBorder of src/ORBextractor.cc:988 leaves it.  ring = 4 (the extractor's hot path): the ROI and
+// the four pixels around it -- no stage reads further out (FAST and the orientation patch stay inside the ROI, the blur reaches 3 pixels and
+// copies 4 into the blurred plane's ring, the next level's resize reads the ROI): a sixth fewer pixels to interpolate and to write.
 void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const LevelGeom& src, const LevelGeom& dst, const ResizeCol* d_ctab,
-                         const ResizeRow* d_rtab, int fast_ok, int batch, Level0View l0) {
+                         const ResizeRow* d_rtab, int fast_ok, int batch, Level0View l0, int ring) {
   dim3 block(256);
-  const uint32_t nwx = (uint32_t)dst.pitch / 4, groups = ((uint32_t)dst.ph + RZ_ROWS - 1) / RZ_ROWS;
+  uint32_t nwx = (uint32_t)dst.pitch / 4, groups = ((uint32_t)dst.ph + RZ_ROWS - 1) / RZ_ROWS;
+  int wx0 = 0, rg0 = 0, row_end = dst.ph;
+  if (ring > 0 && ring < kPad && (kPad - ring) % 4 == 0) {
+    wx0 = (kPad - ring) / 4, rg0 = (kPad - ring) / RZ_ROWS, row_end = dst.h + kPad + ring;
+    nwx = (uint32_t)((dst.w + kPad + ring + 3) / 4 - wx0), groups = (uint32_t)((row_end + RZ_ROWS - 1) / RZ_ROWS - rg0);
+  }
   const uint32_t magic = (uint32_t)((0x100000000ull + nwx - 1) / nwx);
   const uint32_t per_frame = (nwx * groups + 255) / 256, per_xcd = (per_frame * (uint32_t)batch + 7) / 8;
   const uint32_t pf_magic = (uint32_t)((0x100000000ull + per_frame - 1) / per_frame);
   hipLaunchKernelGGL(k_resize_level, dim3(8 * per_xcd), block, 0, s, d_pyr, pyr_block, src.plane_off, src.pitch, src.w, dst.plane_off, dst.pitch, dst.ph,
-                     dst.w, fast_ok, d_ctab, d_rtab, magic, l0, src.h, per_frame, pf_magic, per_xcd, batch);
+                     dst.w, fast_ok, d_ctab, d_rtab, magic, l0, src.h, per_frame, pf_magic, per_xcd, batch, nwx, wx0, rg0, row_end);
 }
 
 
