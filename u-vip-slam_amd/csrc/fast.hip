@@ -134,7 +134,7 @@ __device__ __forceinline__ Screen4 screen4_centre7(uint32_t v7, uint32_t thv, ui
 constexpr int FR_SLOTS = 21;
 constexpr int FR_PITCH = 66;        // row pitch in dwords: 64 + 2 so that the same column of consecutive rows hits different banks
 constexpr int FW_RING_DW = FR_SLOTS * FR_PITCH;  // row ring, then the queue: one LDS block per wavefront
-constexpr int FQ_CAP = (FS_ROWS_MAX + 2) * 64 - FW_RING_DW;  // the queue takes what the NMS tile leaves beside the ring
+constexpr int FQ_CAP = (FS_ROWS_MAX + 2) * 64 - FW_RING_DW > 278 ? (FS_ROWS_MAX + 2) * 64 - FW_RING_DW : 278;  // the queue takes what the NMS tile leaves beside the ring (at least what it needs)
 static_assert(FQ_CAP >= 64 + 128 + 16, "queue: < 64 left over + <= 128 pushed per half row (drained in between)");
 constexpr int FW_DWORDS = FW_RING_DW + FQ_CAP;
 constexpr int FT_PITCH = 256, FT_ROWS = FS_ROWS_MAX + 2;      // NMS score tile, laid over ring + queue at the end of the segment

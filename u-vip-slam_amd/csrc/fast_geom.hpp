@@ -6,7 +6,10 @@
 
 namespace uvo {
 
-constexpr int FS_ROWS_MAX = 24;   // rows per (strip, segment) region; bounded by the NMS tile that must fit the wavefront's LDS
+#ifndef UVO_FAST_ROWS
+#define UVO_FAST_ROWS 24
+#endif
+constexpr int FS_ROWS_MAX = UVO_FAST_ROWS;   // rows per (strip, segment) region; bounded by the NMS tile that must fit the wavefront's LDS (and by 30: the row mask is a dword)
 constexpr int FS_REGION_ENTRIES = (FS_COLS + 2) * (FS_ROWS_MAX + 2);  // corner list capacity: the region plus its halo ring
 
 struct FastLevel {  // per-level values of the sparse stages, passed in the kernel argument block (scalar loads)
