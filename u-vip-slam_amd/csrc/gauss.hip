@@ -31,7 +31,10 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
   gauss7_body<SSE2>((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y, s_tile, pyr, blur, pyr_block, lv, nlevels, taps, rows_per_seg, l0);
 }
 
-int gauss7_rows_per_seg(int batch) { return batch >= 16 ? 64 : 16; }  // fewer, longer segments when the batch already fills the chip (6 halo rows are re-read per segment)
+#ifndef UVO_GAUSS_ROWS
+#define UVO_GAUSS_ROWS 64
+#endif
+int gauss7_rows_per_seg(int batch) { return batch >= 16 ? UVO_GAUSS_ROWS : 16; }  // fewer, longer segments when the batch already fills the chip (6 halo rows are re-read per segment)
 int gauss7_blocks_per_frame(const Geom& g, int rows_per_seg) {
   int items = 0;
   for (int l = 0; l < g.nlevels; ++l) {
