@@ -235,6 +235,9 @@ struct GaussArgs {
   Level0View l0;
 };
 template <bool SSE2>
+#ifndef UVO_OCT_EVERY
+#define UVO_OCT_EVERY 3  // every third workgroup of the front of the grid is a quad-tree problem (measured against every second: the same)
+#endif
 __global__ __launch_bounds__(256, 4) void k_octree_gauss(int n_oct, GaussArgs G, const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max, int pyr_words, int box_region,
                                                         int lds_bytes, FastLevels FL, const uint32_t* __restrict__ cand_lo, int32_t* __restrict__ cursor,
                                                         int32_t* __restrict__ fcount, int32_t* __restrict__ n_cell_list, uint8_t* cell_hi,
@@ -246,9 +249,9 @@ __global__ __launch_bounds__(256, 4) void k_octree_gauss(int n_oct, GaussArgs G,
   // every slot of every CU and the blur would start when they are done.  Interleaved -- every third workgroup a quad-tree problem (level-
   // major: the long level-0 problems first), the others the blur -- a CU holds both kinds from the start.
   int b = (int)blockIdx.x, o = -1;
-  if (b < 3 * n_oct) {
-    if (b % 3 == 0) o = b / 3;
-    else b -= b / 3 + 1;
+  if (b < UVO_OCT_EVERY * n_oct) {
+    if (b % UVO_OCT_EVERY == 0) o = b / UVO_OCT_EVERY;
+    else b -= b / UVO_OCT_EVERY + 1;
   } else {
     b -= n_oct;
   }
