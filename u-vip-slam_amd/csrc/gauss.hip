@@ -26,15 +26,23 @@ namespace uvo {
 
 template <bool SSE2>
 __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int64_t pyr_block,
-                                                const LevelGeom* __restrict__ lv, int nlevels, int4 taps, int rows_per_seg, Level0View l0) {
+                                                const LevelGeom* __restrict__ lv, int nlevels, int4 taps, int rows_per_seg, Level0View l0, GaussPlans plans) {
   __shared__ __attribute__((aligned(16))) uint32_t s_tile[4][GS_TILE_DW];
-  gauss7_body<SSE2>((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y, s_tile, pyr, blur, pyr_block, lv, nlevels, taps, rows_per_seg, l0);
+  gauss7_body<SSE2>((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y, s_tile, pyr, blur, pyr_block, lv, nlevels, taps, rows_per_seg, l0, plans);
 }
 
 #ifndef UVO_GAUSS_ROWS
 #define UVO_GAUSS_ROWS 64
 #endif
 int gauss7_rows_per_seg(int batch) { return batch >= 16 ? UVO_GAUSS_ROWS : 16; }  // fewer, longer segments when the batch already fills the chip (6 halo rows are re-read per segment)
+GaussPlans gauss7_plans(const Geom& g, int rows_per_seg) {
+  GaussPlans P;
+  for (int l = 0; l < kMaxLevels; ++l) {
+    P.p[l] = StripPlan{};
+    if (l < g.nlevels) fast_strip_plan(g.lv[l].w + 8, g.lv[l].h + 8, rows_per_seg, P.p[l]);
+  }
+  return P;
+}
 int gauss7_blocks_per_frame(const Geom& g, int rows_per_seg) {
   int items = 0;
   for (int l = 0; l < g.nlevels; ++l) {
@@ -49,9 +57,9 @@ void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t
                    int batch, int sse2_rounding, Level0View l0) {
   const int rows_per_seg = gauss7_rows_per_seg(batch), bx = gauss7_blocks_per_frame(g, rows_per_seg);
   if (sse2_rounding)
-    hipLaunchKernelGGL(k_gauss7<true>, dim3(bx, batch), dim3(256), 0, s, d_pyr, d_blur, pyr_block, d_lv, g.nlevels, taps, rows_per_seg, l0);
+    hipLaunchKernelGGL(k_gauss7<true>, dim3(bx, batch), dim3(256), 0, s, d_pyr, d_blur, pyr_block, d_lv, g.nlevels, taps, rows_per_seg, l0, gauss7_plans(g, rows_per_seg));
   else
-    hipLaunchKernelGGL(k_gauss7<false>, dim3(bx, batch), dim3(256), 0, s, d_pyr, d_blur, pyr_block, d_lv, g.nlevels, taps, rows_per_seg, l0);
+    hipLaunchKernelGGL(k_gauss7<false>, dim3(bx, batch), dim3(256), 0, s, d_pyr, d_blur, pyr_block, d_lv, g.nlevels, taps, rows_per_seg, l0, gauss7_plans(g, rows_per_seg));
 }
 
 }  // namespace uvo

@@ -31,6 +31,14 @@ __device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t 
   h[3] = (float)(uint32_t)gauss_row1<3>(L, C, R, T1, T2);
 }
 
+// the strip plans of a geometry's levels (region = ROI + the 4-pixel ring: (w + 8) x (h + 8)), made on the host once per launch: a
+// wavefront that finds its level by planning every level in front of it spends three integer divisions per level on it
+struct GaussPlans {
+  StripPlan p[kMaxLevels];
+};
+int gauss7_rows_per_seg(int batch);
+int gauss7_blocks_per_frame(const Geom& g, int rows_per_seg);
+GaussPlans gauss7_plans(const Geom& g, int rows_per_seg);
 constexpr int GS_TILES = 16;  // tiles a wavefront collects per 8-row group: 15 of a full strip, 2 x 7 / 4 x 3 of the narrow ones
 // SSE2: the rounding contract of an x86-64 OpenCV build (UVO_TUNE_BLUR_ROUNDING): SymmColumnVec_32s8u's vector body -- image columns
 // 0 .. (w & ~3) - 1 -- converts the exact fp32 column sum with cvtps2dq, i.e. an exact .5 goes to the EVEN neighbour; the last w % 4
@@ -43,7 +51,7 @@ constexpr int GS_LDS_BYTES = 4 * GS_TILE_DW * 4;  // per 4-wavefront workgroup
 template <bool SSE2>
 __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, uint32_t (*s_tile)[GS_TILE_DW], const uint8_t* __restrict__ pyr,
                                             uint8_t* __restrict__ blur, int64_t pyr_block, const LevelGeom* __restrict__ lv, int nlevels, int4 taps, int rows_per_seg,
-                                            Level0View l0) {
+                                            Level0View l0, const GaussPlans& plans) {
   // work item (one per wavefront) -> (level, strip, segment group); narrow remainder strips hold 2 or 4 row segments side by side
   // (fast_strip_plan), so a level costs about as many wavefront-rows as its width needs
   const int vb = xcd_contiguous(block, blocks_x * batch);
@@ -51,13 +59,12 @@ __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, 
   int item = vbx * 4 + wave_in_block();
   const int lane = threadIdx.x & 63;
   int level = 0;
-  StripPlan plan;
   for (;; ++level) {
-    fast_strip_plan(lv[level].w + 8, lv[level].h + 8, rows_per_seg, plan);
-    if (item < plan.items) break;
-    item -= plan.items;
+    if (item < plans.p[level].items) break;
+    item -= plans.p[level].items;
     if (level == nlevels - 1) return;
   }
+  const StripPlan plan = plans.p[level];
   const LevelGeom g = lv[level];
   int strip_x, seg, nsub;
   fast_strip_item(plan, item, strip_x, seg, nsub);

@@ -233,6 +233,7 @@ struct GaussArgs {
   int4 taps;
   int rows_per_seg, blocks_x, batch;
   Level0View l0;
+  GaussPlans plans;
 };
 template <bool SSE2>
 #ifndef UVO_OCT_EVERY
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256, 4) void k_octree_gauss(int n_oct, GaussArgs G,
     octree_body<256>(lds, o / G.batch, o % G.batch, lv, nlevels, Mmax, Mp2max, pyr_words, box_region, lds_bytes, FL, cand_lo, cursor, fcount, n_cell_list, cell_hi, cand_xy, cand_sc,
                      cand_block, cand_count, pstate, sel_xy, sel_sc, sel_block, sel_count);
   } else {
-    gauss7_body<SSE2>(b, G.blocks_x, G.batch, reinterpret_cast<uint32_t(*)[GS_TILE_DW]>(lds), G.pyr, G.blur, G.pyr_block, lv, nlevels, G.taps, G.rows_per_seg, G.l0);
+    gauss7_body<SSE2>(b, G.blocks_x, G.batch, reinterpret_cast<uint32_t(*)[GS_TILE_DW]>(lds), G.pyr, G.blur, G.pyr_block, lv, nlevels, G.taps, G.rows_per_seg, G.l0, G.plans);
   }
 }
 
@@ -352,6 +353,7 @@ void launch_octree_gauss(hipStream_t s, const LevelGeom* d_lv, const Geom& g, co
   GaussArgs G;
   G.pyr = d_pyr, G.blur = d_blur, G.pyr_block = pyr_block, G.taps = taps, G.batch = batch, G.l0 = l0;
   G.rows_per_seg = gauss7_rows_per_seg(batch), G.blocks_x = gauss7_blocks_per_frame(g, G.rows_per_seg);
+  G.plans = gauss7_plans(g, G.rows_per_seg);
   const int n_oct = batch * g.nlevels;
   const dim3 grid(n_oct + G.blocks_x * batch);
   if (sse2_rounding)

@@ -50,7 +50,7 @@ UVO_PLAN_HD inline void fast_strip_item(const PlanT& F, int item, int& strip_x, 
     strip_x = (item % F.nfull) * FS_COLS, seg = item / F.nfull, sub = 1;
   } else {
     item -= F.nfull * F.nseg;
-    const int n0 = F.sub[0] ? (F.nseg + F.sub[0] - 1) / F.sub[0] : 0;
+    const int n0 = F.sub[0] ? (F.nseg + F.sub[0] - 1) >> (F.sub[0] >> 1) : 0;  // sub is 2 or 4: a shift by 1 or 2, not a division
     const int k = item < n0 ? 0 : 1;
     if (k) item -= n0;
     sub = F.sub[k], strip_x = F.x0[k], seg = item * sub;
