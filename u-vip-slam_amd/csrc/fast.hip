@@ -154,11 +154,11 @@ __device__ __forceinline__ int ring_strength(const uint8_t* rm3) {
   d16 d[16];
   d[0] = rp3[3], d[1] = rp3[4], d[2] = rp2[5], d[3] = rp1[6], d[4] = r0[6], d[5] = rm1[6], d[6] = rm2[5], d[7] = rm3[4];
   d[8] = rm3[3], d[9] = rm3[2], d[10] = rm2[1], d[11] = rm1[0], d[12] = r0[0], d[13] = rp1[0], d[14] = rp2[1], d[15] = rp3[2];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) d[k] = (d16)(d[k] - v);
   // corner at t  <=>  some 9-arc has all diffs > t (brighter) or all < -t (darker)  <=>  max(sb, sd) > t;
-  // cornerScore = max(sb, sd) - 1.  No masks, no divergent branches.
-  return max((int)arc9_maxmin(d), -(int)arc9_minmax(d));
+  // cornerScore = max(sb, sd) - 1.  No masks, no divergent branches.  The centre is the same for all sixteen differences, so the arc
+  // minima / maxima are taken over the ring pixels themselves and the centre comes off once: sb = max over arcs of min(p) - v,
+  // sd = v - min over arcs of max(p) -- two subtractions instead of sixteen.
+  return max((int)arc9_maxmin(d) - (int)v, (int)v - (int)arc9_minmax(d));
 }
 
 // Full segment test + cornerScore of the queued pixels [first, first+count), one per lane.  The 16 ring pixels are read
