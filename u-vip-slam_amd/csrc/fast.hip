@@ -46,6 +46,9 @@ namespace uvo {
 // the lane mask of a predicate, straight from the compare (HIP's __ballot(int) goes through a 0 / 1 integer and a second compare)
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+#ifndef UVO_FC_DIRECT_MAX
+#define UVO_FC_DIRECT_MAX 2  // batches up to this many frames redo their fall-back cells without a list (measured against always: see profiles/r04_fast_probes.txt)
+#endif
 #ifndef UVO_FAST_WAVES
 #define UVO_FAST_WAVES 4       // wavefronts (regions) per workgroup
 #endif
@@ -814,7 +817,7 @@ void launch_fast_cells(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, c
   int max_roi = 0;
   for (int l = 0; l < g.nlevels; ++l) max_roi = std::max(max_roi, std::max(g.lv[l].wCell, g.lv[l].hCell) + 6);
   const bool small = max_roi <= 48;
-  if (batch <= 2) {  // a latency call: one launch, a wavefront per flag entry
+  if (batch <= UVO_FC_DIRECT_MAX) {  // a latency call: one launch, a wavefront per flag entry
     const dim3 grid((L.flags_per_frame + FC_WAVES - 1) / FC_WAVES, batch);
     if (small)
       hipLaunchKernelGGL((k_fast_cells<48, true>), grid, dim3(64 * FC_WAVES), 0, s, d_pyr, pyr_block, L, d_cells, d_list, d_n_list, d_flag_cell, d_tpass, d_cell_hi, d_cand_xy,
