@@ -10,25 +10,30 @@ namespace uvo {
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 pk(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
 
-// Row pass for the lane's 4 pixels with the packed-byte dot product (v_dot4_u32_u8): pixel k needs window bytes
-// k+1 .. k+7 of [L C R]; they are fetched as two byte-aligned dwords (v_alignbyte) and multiplied with the taps packed as
-// (t0,t1,t2,t3) and (t2,t1,t0,0).  Exact integer arithmetic, 4 instructions per pixel.
-template <int S>
-__device__ __forceinline__ uint32_t win4(uint32_t L, uint32_t C, uint32_t R) {  // bytes S..S+3 of the 12-byte window
-  if (S < 4) return S == 0 ? L : __builtin_amdgcn_alignbyte(C, L, (uint32_t)S);
-  if (S < 8) return S == 4 ? C : __builtin_amdgcn_alignbyte(R, C, (uint32_t)(S - 4));
-  return R;
+// Row pass for the lane's 4 pixels with the packed-byte dot product (v_dot4_u32_u8).  Pixel k needs window bytes k+1 .. k+7 of [L C R]:
+// instead of aligning the data to the taps (six v_alignbyte + eight dot products) the TAPS are aligned to the data -- every pixel takes the
+// words L, C, R as they are, against tap vectors shifted to its place (wave-uniform constants: scalar operands) -- ten dot products, no byte
+// shuffles.  Exact integer arithmetic.
+//   pixel 0: L.(0,t0,t1,t2) + C.(t3,t2,t1,t0)          pixel 1: L.(0,0,t0,t1) + C.(t2,t3,t2,t1) + R.(t0,0,0,0)
+//   pixel 2: L.(0,0,0,t0) + C.(t1,t2,t3,t2) + R.(t1,t0,0,0)          pixel 3: C.(t0,t1,t2,t3) + R.(t2,t1,t0,0)
+struct GaussRowTaps {
+  uint32_t l0, c0, l1, c1, r1, l2, c2, r2, c3, r3;
+};
+__device__ __forceinline__ GaussRowTaps gauss_row_taps(int4 t) {
+  auto pk4 = [](int a, int b, int c, int d) { return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24); };
+  GaussRowTaps T;
+  T.l0 = pk4(0, t.x, t.y, t.z), T.c0 = pk4(t.w, t.z, t.y, t.x);
+  T.l1 = pk4(0, 0, t.x, t.y), T.c1 = pk4(t.z, t.w, t.z, t.y), T.r1 = pk4(t.x, 0, 0, 0);
+  T.l2 = pk4(0, 0, 0, t.x), T.c2 = pk4(t.y, t.z, t.w, t.z), T.r2 = pk4(t.y, t.x, 0, 0);
+  T.c3 = pk4(t.x, t.y, t.z, t.w), T.r3 = pk4(t.z, t.y, t.x, 0);
+  return T;
 }
-template <int K>
-__device__ __forceinline__ int gauss_row1(uint32_t L, uint32_t C, uint32_t R, uint32_t T1, uint32_t T2) {
-  const uint32_t a = win4<K + 1>(L, C, R), b = win4<K + 5>(L, C, R);
-  return (int)__builtin_amdgcn_udot4(b, T2, __builtin_amdgcn_udot4(a, T1, 0u, false), false);
-}
-__device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t R, uint32_t T1, uint32_t T2, float* h) {
-  h[0] = (float)(uint32_t)gauss_row1<0>(L, C, R, T1, T2);  // < 2^16: exact
-  h[1] = (float)(uint32_t)gauss_row1<1>(L, C, R, T1, T2);
-  h[2] = (float)(uint32_t)gauss_row1<2>(L, C, R, T1, T2);
-  h[3] = (float)(uint32_t)gauss_row1<3>(L, C, R, T1, T2);
+__device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t R, const GaussRowTaps& T, float* h) {
+  const uint32_t s0 = __builtin_amdgcn_udot4(C, T.c0, __builtin_amdgcn_udot4(L, T.l0, 0u, false), false);
+  const uint32_t s1 = __builtin_amdgcn_udot4(R, T.r1, __builtin_amdgcn_udot4(C, T.c1, __builtin_amdgcn_udot4(L, T.l1, 0u, false), false), false);
+  const uint32_t s2 = __builtin_amdgcn_udot4(R, T.r2, __builtin_amdgcn_udot4(C, T.c2, __builtin_amdgcn_udot4(L, T.l2, 0u, false), false), false);
+  const uint32_t s3 = __builtin_amdgcn_udot4(R, T.r3, __builtin_amdgcn_udot4(C, T.c3, 0u, false), false);
+  h[0] = (float)s0, h[1] = (float)s1, h[2] = (float)s2, h[3] = (float)s3;  // < 2^16: exact
 }
 
 // the strip plans of a geometry's levels (region = ROI + the 4-pixel ring: (w + 8) x (h + 8)), made on the host once per launch: a
@@ -149,8 +154,7 @@ __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, 
   const uint32_t j_in0 = (uint32_t)(kPad - py0l + 6), n_in = (uint32_t)g.h;
   const uint32_t j_edge1 = (lane_out && !via_lds) ? (uint32_t)max(py1l - py0l + 6, 0) : 0u;
 
-  const uint32_t T1 = (uint32_t)taps.x | ((uint32_t)taps.y << 8) | ((uint32_t)taps.z << 16) | ((uint32_t)taps.w << 24);
-  const uint32_t T2 = (uint32_t)taps.z | ((uint32_t)taps.y << 8) | ((uint32_t)taps.x << 16);
+  const GaussRowTaps RT = gauss_row_taps(taps);
   // column taps scaled by 2^-16 (exact): the column sum comes out as sum / 65536, and + 0.5 makes its floor the rounded result
   const float c0 = (float)taps.x * (1.0f / 65536.0f), c1 = (float)taps.y * (1.0f / 65536.0f), c2 = (float)taps.z * (1.0f / 65536.0f),
               c3 = (float)taps.w * (1.0f / 65536.0f);
@@ -192,7 +196,7 @@ __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, 
         const uint32_t C = cur[u];
         const uint32_t L = (uint32_t)__builtin_amdgcn_ds_bpermute(lane_up, (int)C);    // the neighbours' dwords: source lanes fixed for the
         const uint32_t R = (uint32_t)__builtin_amdgcn_ds_bpermute(lane_down, (int)C);  // whole strip (__shfl_up / _down recompute them per call)
-        gauss_row_pass(L, C, R, T1, T2, hring[u]);
+        gauss_row_pass(L, C, R, RT, hring[u]);
         cring[u] = C;
         const int phase_now = phase;
         phase = (phase + 1) & 7;
