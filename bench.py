@@ -406,23 +406,12 @@ def main():
     ex.set_pipeline(DEPTH)
     ex.tune(uvo.UVO_TUNE_FAST_MODE, {"adaptive": uvo.UVO_FAST_MODE_ADAPTIVE, "two_pass": uvo.UVO_FAST_MODE_TWO_PASS,
                                      "single_pass": uvo.UVO_FAST_MODE_SINGLE_PASS}[args.fast_mode])
-    if os.environ.get("UVO_BENCH_PYR"):   # experiment knob: pyramid mode: "chain" (default) or the split mode's "tail,bands,run"
-        if os.environ["UVO_BENCH_PYR"] in ("legacy", "chain", "none"):
-            ex.tune(uvo.UVO_TUNE_PYR_MODE, uvo.UVO_PYR_MODE_CHAIN)
-        else:
-            t_, b_, r_ = (int(x) for x in os.environ["UVO_BENCH_PYR"].split(","))
-            ex.tune(uvo.UVO_TUNE_PYR_MODE, uvo.UVO_PYR_MODE_SPLIT)
-            ex.tune(uvo.UVO_TUNE_PYR_TAIL, t_)
-            ex.tune(uvo.UVO_TUNE_PYR_BANDS, b_)
-            ex.tune(uvo.UVO_TUNE_PYR_RUN, r_)
     if os.environ.get("UVO_BENCH_FUSE"):   # experiment knob: quad-tree + blur as one launch (1, default) or two (0)
         ex.tune(uvo.UVO_TUNE_FUSE_BLUR_TREE, int(os.environ["UVO_BENCH_FUSE"]))
     if os.environ.get("UVO_BENCH_L0"):   # experiment knob: level 0 read in place (1, default) or copied into a padded plane first (0)
         ex.tune(uvo.UVO_TUNE_LEVEL0_INPLACE, int(os.environ["UVO_BENCH_L0"]))
     if os.environ.get("UVO_BENCH_RING"):   # experiment knob: border pixels the resize launches write around a level (4 default, 0 = all 16)
         ex.tune(uvo.UVO_TUNE_PYR_RING, int(os.environ["UVO_BENCH_RING"]))
-    if os.environ.get("UVO_BENCH_DELAY_US"):   # development probe: an idle kernel of that many microseconds in every lane's batch
-        ex.tune(100, int(os.environ["UVO_BENCH_DELAY_US"]))
     if os.environ.get("UVO_BENCH_OCT_WIDE_MAX"):   # experiment knob: quad-tree launch shape (uvo_extractor_tune)
         ex.tune(uvo.UVO_TUNE_OCT_WIDE_MAX, int(os.environ["UVO_BENCH_OCT_WIDE_MAX"]))
     torch.cuda.synchronize()
@@ -462,9 +451,6 @@ def main():
     for _ in range(args.warmup + DEPTH):
         step()
     sync_all()
-    if os.environ.get("UVO_BENCH_PYR") == "none":   # development probe: the step without its pyramid launches (planes of the warm-up batches stay)
-        ex.tune(uvo.UVO_TUNE_PYR_MODE, 2)
-
     # Per-kernel durations first, without cross-batch overlap (pipeline depth 1, every launch bracketed by HIP events on the
     # library's stream; 3 untimed steps): they name the dominant kernel.
     ex.set_pipeline(1)

@@ -250,47 +250,19 @@ int uvo_extractor_set_pipeline(uvo_extractor* h, int depth);
  *   UVO_TUNE_BLUR_ROUNDING : the ONE knob that changes results -- which OpenCV build's GaussianBlur (src/ORBextractor.cc:942) is
  *                           reproduced where the two differ: an exact .5 in the column pass of the 7 x 7 blur (about one pixel in
  *                           65 536, by one grey level; descriptors follow).
- *                           UVO_BLUR_ROUNDING_SCALAR (default) the generic C++ column filter: (sum + 2^15) >> 16, half up, on every column;
- *                           UVO_BLUR_ROUNDING_SSE2    x86-64 builds: SymmColumnVec_32s8u's vector body (image columns 0 .. (w & ~3) - 1)
- *                                                     rounds half to even (cvtps2dq), only the last w % 4 columns round half up.
- *                           Which of the two the reference's binary executes is not decidable without OpenCV 3.4.x at hand
- *                           (tools/pin/ dumps both cases' evidence: the day it runs, this knob's default follows).
+ *                           UVO_BLUR_ROUNDING_SSE2   (default) x86-64 builds -- the reference is an x86-64 ROS program: the vector body of
+ *                                                     SymmColumnVec_32s8u (image columns 0 .. (w & ~3) - 1) converts the exact fp32 sum with
+ *                                                     cvtps2dq, half to EVEN; only the last w % 4 columns take the scalar loop, half up;
+ *                           UVO_BLUR_ROUNDING_SCALAR  the generic C++ column filter: (sum + 2^15) >> 16, half up, on every column (builds
+ *                                                     without SIMD).
+ *                           tools/pin/ dumps the evidence that decides it for a given OpenCV binary (the gauss_<k> cases).
  */
 #define UVO_TUNE_LEVEL0_INPLACE 11 /* 1 (default): level 0 is read from the caller's image in place whenever it can be (dword-aligned rows, width a
                                      multiple of 4, no caller keypoints): cv::copyMakeBorder of src/ORBextractor.cc:996 is never materialised, the
                                      blur reflects the border it needs on the fly; 0: always copy into a padded plane first */
-#define UVO_TUNE_PYR_RING 12       /* 4 (default), 8, 12: the resize launches of the pyramid write a level's image and that many pixels of the border around
-                                     it -- no stage reads past four (FAST and the orientation patch stay inside the image, the blur reaches 3 and copies
-                                     4 into the blurred plane's ring); 0: the whole EDGE_THRESHOLD border of src/ORBextractor.cc:988 */
-#define UVO_TUNE_FUSE_BLUR_TREE 10 /* 1 (default): DistributeOctTree and GaussianBlur share one launch when the batch is large enough for the
-                                     256-thread quad-tree form (neither reads what the other writes); 0: two launches */
 #define UVO_TUNE_BLUR_ROUNDING 9
 #define UVO_BLUR_ROUNDING_SCALAR 0
 #define UVO_BLUR_ROUNDING_SSE2 1
-/*
- *   UVO_TUNE_PYR_MODE     : launch shape of ComputePyramid (src/ORBextractor.cc:963-1004); the planes are the same in both.
- *                           UVO_PYR_MODE_CHAIN (default) one launch per level (+ the border copy of level 0): the fastest on the
- *                                                     benchmark's batches;
- *                           UVO_PYR_MODE_SPLIT        the large levels stream over static blocks of 7 source rows with the horizontal
- *                                                     pass shared between output rows (level 1 reads the image in place, the border
- *                                                     copy rides along); the levels from UVO_TUNE_PYR_TAIL on share ONE launch in which
- *                                                     a workgroup walks a (frame, band of rows) through all of them, a barrier per
- *                                                     step (three launches instead of eight, 4 % slower end to end).
- *   UVO_TUNE_PYR_TAIL     : split mode: first level of the shared launch (0: every level; >= nlevels: none; default 3)
- *   UVO_TUNE_PYR_RUN      : split mode: blocks of 7 source rows a wavefront of a streaming launch walks (0: by batch size)
- *   UVO_TUNE_PYR_BANDS    : split mode: bands per frame of the shared launch: 0 (default) = by batch size, or 1 / 2 / 4 / 8 / 16
- *   UVO_TUNE_PYR_WAVES    : split mode: at least this many wavefronts per workgroup of the shared launch (0 (default) = the smallest
- *                           of 4 / 8 / 16 that holds the image's column roles, or 4, 8, 16)
- *   UVO_TUNE_PYR_ROWS     : split mode: level-0 rows a workgroup of the shared launch advances per barrier (1 .. 7, default 7)
- */
-#define UVO_TUNE_PYR_BANDS 3
-#define UVO_TUNE_PYR_WAVES 4
-#define UVO_TUNE_PYR_ROWS 5
-#define UVO_TUNE_PYR_MODE 6
-#define UVO_PYR_MODE_CHAIN 0
-#define UVO_PYR_MODE_SPLIT 1
-#define UVO_TUNE_PYR_TAIL 7
-#define UVO_TUNE_PYR_RUN 8
 int uvo_extractor_tune(uvo_extractor* h, int knob, int value);
 /*
  * State of the adaptive FAST mode after the most recent batch (waits for it): per level the threshold the NEXT batch on that
@@ -723,6 +695,11 @@ int uvo_extractor_wait_matcher(uvo_extractor* h, uvo_matcher* m);
  * most recent batch (calling it again after a batch is harmless).  h = NULL: back to the matcher's own stream.  While attached, calls
  * that wait for the matcher's stream (every host-buffer entry point) wait for that lane.  Either handle may be destroyed first: a
  * destroyed extractor hands its matchers back to their own streams, a destroyed matcher leaves the list.
+ * ORDERING CONTRACT: an attached matcher is ordered behind the MOST RECENT batch only.  With pipeline depth >= 2, work that reads the
+ * results of batch N must be enqueued before batch N + 1 is (extract N, match N, extract N + 1, match N + 1 ...); a caller that
+ * enqueues two batches and then matches the first must order that match itself (uvo_matcher_wait_extractor before batch N + 1, or
+ * uvo_extractor_synchronize).  The handles are not thread-safe against each other: attach / detach / destroy and the batch calls of
+ * one extractor + its matchers belong to one host thread at a time (the follower list itself is locked).
  */
 int uvo_matcher_attach_extractor(uvo_matcher* m, uvo_extractor* h);
 /* per-kernel timing of the matcher, same contract as uvo_extractor_profile / uvo_extractor_kernel_times */

@@ -226,8 +226,8 @@ void gaussian_taps_7_sigma2(int taps[7]) {
 }
 
 // `rounding`: how the column pass rounds an exact .5 (every other sum rounds the same either way).
-//   kBlurRoundScalar (default): (s + 2^15) >> 16 on every column -- FixedPtCastEx<int, uchar>(16), the generic C++ column filter;
-//   kBlurRoundSse2: what an x86-64 OpenCV 3.4.x build executes [OCV-RECALL]: SymmColumnVec_32s8u's vector body takes the columns
+//   kBlurRoundScalar: (s + 2^15) >> 16 on every column -- FixedPtCastEx<int, uchar>(16), the generic C++ column filter;
+//   kBlurRoundSse2 (default): what an x86-64 OpenCV 3.4.x build executes [OCV-RECALL]: SymmColumnVec_32s8u's vector body takes the columns
 //     0 .. (w & ~3) - 1 (16 and then 4 at a time), computes the sum in fp32 -- exact here: every partial sum is a multiple of 2^-16 below
 //     2^8 -- and converts with cvtps2dq, round-half-to-EVEN; only the last w % 4 columns fall to the scalar loop above.
 void gaussian_blur7_roi_inplace(const View& roi, int rounding) {

@@ -55,7 +55,7 @@ void gaussian_taps_7_sigma2(int taps[7]);
 // blur the ROI `roi` (which must sit >= 3 px inside its parent buffer) in place,
 // border taps read the parent's pixels (non-isolated sub-matrix semantics)
 enum { kBlurRoundScalar = 0, kBlurRoundSse2 = 1 };
-void gaussian_blur7_roi_inplace(const View& roi, int rounding = kBlurRoundScalar);
+void gaussian_blur7_roi_inplace(const View& roi, int rounding = kBlurRoundSse2);
 float fast_atan2(float y, float x);
 
 // ---- reference glue ----
@@ -65,7 +65,7 @@ struct Extractor {
   int nfeatures;
   double scaleFactor;  // member is `double` in include/ORBextractor.h:79
   int nlevels, fastTh;
-  int blur_rounding = kBlurRoundScalar;  // which contract the column pass of GaussianBlur rounds exact ties under (orb_oracle.cpp)
+  int blur_rounding = kBlurRoundSse2;  // which contract the column pass of GaussianBlur rounds exact ties under (orb_oracle.cpp)
   std::vector<float> mvScaleFactor, mvInvScaleFactor;
   std::vector<int> mnFeaturesPerLevel;
   std::vector<int> umax;

@@ -665,76 +665,3 @@ def test_undistort_point_models(oracle):
     dpx = np.stack([a * s * fxh + cxh, b * s * fyh + cyh], 1).astype(np.float32)
     und = oracle.undistort_points(dpx, fxh, fyh, cxh, cyh, kk, True)
     assert np.abs(und - np.stack([a * fxh + cxh, b * fyh + cyh], 1)).max() < 2e-3
-
-
-def _pyr_emu():
-    lib = os.path.join(ROOT, "tests", "emu", "libpyr_schedule_emu.so")
-    srcs = [os.path.join(ROOT, "tests", "emu", "pyr_schedule_emu.cpp"), os.path.join(ROOT, "u-vip-slam_amd", "csrc", "pyr_schedule.hpp")]
-    if not os.path.exists(lib) or max(os.path.getmtime(p) for p in srcs) > os.path.getmtime(lib):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", lib, srcs[0]])
-    E = ctypes.CDLL(lib)
-    E.emu_pyr_schedule_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-    return E
-
-
-def _run_pyr_schedule(E, oe, img, nlevels, nbands, nwaves, nslots, r0, first_level=0):
-    dims = [oe.level_dims(l) for l in range(nlevels)]
-    lw = np.array([d[0] for d in dims], np.int32)
-    lh = np.array([d[1] for d in dims], np.int32)
-    pitch = (lw + 32 + 63) // 64 * 64      # kPyrPitchAlign (csrc/pyr_schedule.hpp)
-    planes = np.zeros(int((pitch.astype(np.int64) * (lh + 32)).sum()), np.uint8)
-    off = np.zeros(nlevels, np.int64)
-    pitch_out = np.zeros(nlevels, np.int32)
-    stats = np.zeros(6, np.int32)
-    rc = E.emu_pyr_schedule_run(img.ctypes.data, img.strides[0], first_level, nlevels, lw.ctypes.data, lh.ctypes.data, nbands, nwaves, nslots, r0, planes.ctypes.data,
-                                off.ctypes.data, pitch_out.ctypes.data, stats.ctypes.data)
-    out = []
-    if rc == 0:
-        for l in range(nlevels):
-            out.append(planes[off[l]:off[l] + int(pitch_out[l]) * (int(lh[l]) + 32)].reshape(int(lh[l]) + 32, int(pitch_out[l]))[:, :int(lw[l]) + 32])
-    return rc, out, stats
-
-
-def test_pyramid_schedule_executed_on_the_host_gives_the_oracle_pyramid(oracle, synth):
-    """The fused pyramid kernel (k_pyramid) interprets a schedule compiled on the host (csrc/pyr_schedule.hpp): per (band, macro-step,
-    level) the output rows and the new source rows, a workgroup barrier between steps, every (level, column chunk) the role of one
-    wavefront slot.  tests/emu/pyr_schedule_emu.cpp runs the same table on the host with an independent integer restatement of the two
-    resize passes and checks what the kernel relies on -- a source row is read only in a step AFTER the one in which the same band wrote
-    it, every source row passes a role exactly once and in order, step sizes stay inside the kernel's register budget, every byte of
-    every padded plane is written, bands that overlap agree -- and the planes must equal the oracle's ComputePyramid
-    (src/ORBextractor.cc:963-1004)."""
-    E = _pyr_emu()
-    cases = [((640, 512), 1.2, 8, (1, 2, 8, 16), (8, 2), 7), ((321, 243), 1.2, 8, (1, 4), (8, 2), 7), ((752, 480), 1.2, 8, (1, 2), (8, 3), 5), ((200, 180), 1.1, 6, (1, 8), (8, 2), 7),
-             ((400, 300), 1.5, 4, (1, 4), (4, 2), 3), ((512, 384), 2.0, 3, (1, 2, 16), (8, 2), 7), ((333, 222), 1.33, 5, (1, 4), (16, 2), 1), ((1920, 1080), 1.2, 8, (1, 16), (16, 3), 7),
-             ((4096, 600), 1.2, 4, (1,), (16, 8), 7)]
-    for (w, h), scale, nl, bands, (nw, ns), r0 in cases:
-        img = synth.make_frame(4000 + w, w, h, n_shapes=60)
-        oe = oracle.extractor(500, scale, nl, 20)
-        oe(img)
-        for nb in bands:
-            rc, planes, stats = _run_pyr_schedule(E, oe, img, nl, nb, nw, ns, r0)
-            assert rc == 0, ((w, h), scale, nb, rc)
-            for l in range(nl):
-                np.testing.assert_array_equal(planes[l], oe.level_plane(l), err_msg="%dx%d scale %.2f bands %d level %d" % (w, h, scale, nb, l))
-            if nb == 1:
-                assert stats[3] == stats[4]                      # one band: nothing is computed twice
-            else:
-                assert stats[3] < 1.6 * stats[4], (nb, stats)    # shared rows stay a fraction of the band
-        # the product's split: the levels below `first` as streaming launches over static blocks of 7 source rows (k_pyr_stream), the
-        # rest in the fused launch -- every split point, the last one leaving nothing to the fused launch but the top level
-        for first in range(1, nl):
-            rc, planes, stats = _run_pyr_schedule(E, oe, img, nl, bands[-1], 16, 8, r0, first_level=first)
-            assert rc == 0, ((w, h), scale, first, rc)
-            for l in range(nl):
-                np.testing.assert_array_equal(planes[l], oe.level_plane(l), err_msg="%dx%d scale %.2f first %d level %d" % (w, h, scale, first, l))
-    # the benchmark shape: one band per frame walks 512 / 7 steps + one per level of lag; 13 resize roles on seven wavefronts + one copy
-    # wavefront, the heaviest within 12 % of the mean of the seven
-    img = synth.make_frame(4001, 640, 512)
-    oe = oracle.extractor(1000, 1.2, 8, 20)
-    oe(img)
-    rc, _, stats = _run_pyr_schedule(E, oe, img, 8, 1, 8, 2, 7)
-    assert rc == 0 and stats[0] <= 74 + 8 and stats[1] == 14, stats
-    assert stats[2] <= 1.12 * (stats[5] - 128) / 7, stats
-    # too few slots for the roles: refused, not mis-scheduled
-    assert _run_pyr_schedule(E, oe, img, 8, 1, 4, 2, 7)[0] == 1

@@ -13,7 +13,6 @@
 //   flist    : [frame][flist_cap] final (level, x, y, aux) slots in output order
 #pragma once
 #include "strip_plan.hpp"
-#include "pyr_schedule.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -23,6 +22,7 @@ namespace uvo {
 
 constexpr int kMaxLevels = 16;
 constexpr int kPad = 16;         // EDGE_THRESHOLD, src/ORBextractor.cc:78
+constexpr int kPyrPitchAlign = 64;  // row pitch of the padded planes (128 -- whole cache lines -- grew the planes by 7 %: every stage paid, profiles/r04_pyramid_ab.txt)
 constexpr int kMinBorder = 13;   // EDGE_THRESHOLD-3, src/ORBextractor.cc:756
 constexpr int kMaxOctN = 2000;   // largest per-level quota the quad-tree kernel is sized for (LDS budget)
 
@@ -116,39 +116,6 @@ void launch_pad_level0(hipStream_t s, const uint8_t* d_img, int w, int h, int64_
                        int64_t pyr_block, const LevelGeom& g0, int batch);
 void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const LevelGeom& src, const LevelGeom& dst, const ResizeCol* d_ctab,
                          const ResizeRow* d_rtab, int fast_ok, int batch, Level0View l0, int ring);
-// the fused pyramid kernel's schedule of one band count, on the device (pyr_schedule.hpp)
-struct PyrPlanDev {
-  int nbands = 0, nwaves = 0, nslots = 0, nsteps = 0;
-  PyrRole* d_roles = nullptr;
-  PyrStepLevel* d_steps = nullptr;
-  int32_t* d_band_step = nullptr;
-};
-struct PyrStreamArgs {
-  const uint8_t* src;            // level l - 1: the image (level 1) or the pyramid
-  int64_t src_frame_stride;      // bytes between frames of src
-  int64_t src_origin;            // byte offset of the source ROI origin inside a frame of src
-  int src_pitch, sw, sh;         // source row pitch, ROI size
-  uint32_t src_bytes;            // bytes of a frame of src from the ROI origin on (the buffer resource's range)
-  uint8_t* pyr;
-  int64_t pyr_block, dst_plane_off;
-  int dst_pitch, dst_h;
-  const ResizeCol* ctab;
-  const PyrStepLevel* blocks;
-  int nblocks, blocks_per_item, nchunks, nsegs;  // resize items of a frame = nchunks * nsegs
-  // the copy items that ride along (level 1 only; ncopy_items = 0 otherwise)
-  const uint8_t* img;
-  int64_t img_stride, img_frame_stride;
-  int img_w, img_h, l0_pitch, copy_chunks, copy_segs, copy_rows_per_item;
-  int64_t l0_plane_off;
-  int items_per_frame;           // resize + copy
-};
-
-void launch_pyr_stream(hipStream_t s, const PyrStreamArgs& A, bool fast, int batch);
-// the smallest workgroup shape (of at least min_waves wavefronts) k_pyramid is built for that holds the roles
-bool pyr_shape_for_roles(int nresize, int ncopy, int min_waves, int& nwaves, int& nslots);
-int launch_pyramid(hipStream_t s, const uint8_t* d_img, int64_t stride, int64_t frame_stride, uint8_t* d_pyr, int64_t pyr_block, const Geom& g,
-                   const int* fast_ok, const PyrPlanDev& plan, const ResizeCol* d_ctab, int batch);
-void launch_probe_delay(hipStream_t s, int us);
 void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g, int4 taps,
                    int batch, int sse2_rounding, Level0View l0);
 void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, int fast_th, const int32_t* d_tpass, uint32_t* d_cor,

@@ -7,12 +7,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "common.hpp"
 #include "fast_geom.hpp"
 #include "profiler.hpp"
+#include "tune_internal.h"
 #include "uvo_math.hpp"
 
 namespace uvo {
@@ -45,7 +47,6 @@ using namespace uvo;
 // lanes, so the latency-bound stages of one batch (quad-tree, sparse NMS, small pyramid levels) overlap with the
 // throughput stages of the next.
 constexpr int kMaxLanes = 4;
-constexpr int kPyrPlans = 5;  // band counts 1, 2, 4, 8, 16
 
 struct Lane {
   hipStream_t stream = nullptr;
@@ -85,6 +86,7 @@ extern "C" void uvo_matcher_orphaned_internal(uvo_matcher* m);
 
 struct uvo_extractor {
   uvo_extractor_cfg cfg;
+  std::mutex followers_mu;               // attach / detach may come from the matcher's thread
   std::vector<uvo_matcher*> followers;  // matchers attached to this handle (uvo_matcher_attach_extractor): they enqueue in the current lane's stream
   int device = 0;
   Lane lane[kMaxLanes];
@@ -102,7 +104,7 @@ struct uvo_extractor {
   std::vector<CellDesc> cells;
   std::vector<int32_t> cell_flag;  // per entry of a frame's cell-flag array (the full nRows x nCols grids of all levels): cell | level << 24, -1 = no cell
   int fast_mode = UVO_FAST_MODE_ADAPTIVE;
-  int blur_rounding = UVO_BLUR_ROUNDING_SCALAR;  // UVO_TUNE_BLUR_ROUNDING
+  int blur_rounding = UVO_BLUR_ROUNDING_SSE2;  // UVO_TUNE_BLUR_ROUNDING: what an x86-64 OpenCV 3.4 build (the reference's platform) executes
   // capacities fixed at create time (from max_width x max_height)
   int64_t cap_pyr_block = 0, cap_cand_block = 0;
   int cap_cells = 0, cap_sel_block = 0, cap_flist = 0, cap_xtab = 0, cap_ytab = 0;
@@ -119,22 +121,9 @@ struct uvo_extractor {
   int clahe_w = 0, clahe_h = 0;
   int resize_fast[kMaxLevels] = {0};  // per level: the 12-byte-window path of k_resize_level applies
   ResizeRow* d_rtab = nullptr;
-  // the fused pyramid kernel (pyramid.hip, pyr_schedule.hpp): row tables per ROI row, and one compiled schedule per band count
-  PyrPlanDev pyr_plan[kPyrPlans];
-  int pyr_bands_forced = 0;  // UVO_TUNE_PYR_BANDS: 0 = by batch size
-  int pyr_waves = 0;         // UVO_TUNE_PYR_WAVES: at least this many wavefronts per workgroup (0: the smallest shape that holds the roles)
-  int pyr_rows = 7;          // level-0 rows per macro-step
   int pyr_ring = 4;          // UVO_TUNE_PYR_RING: the chain's resize launches write the ROI + this many pixels around it (0: the whole 16-pixel pad)
   int level0_inplace = 1;    // UVO_TUNE_LEVEL0_INPLACE: read level 0 from the caller's image instead of copying it into a padded plane (when it can be)
   int fuse_blur_tree = 1;    // UVO_TUNE_FUSE_BLUR_TREE: quad-tree and blur as one launch when the batch takes the 256-thread quad-tree form
-  int probe_delay_us = 0;    // development probe (UVO_TUNE 100): an idle single-wavefront kernel of this many microseconds behind the pyramid
-  int pyr_mode = UVO_PYR_MODE_CHAIN;  // UVO_TUNE_PYR_MODE (2 = development probe: no pyramid launch at all)
-  int pyr_tail_from = 3;     // UVO_TUNE_PYR_TAIL: levels below it stream (one launch each), it and the levels above share the fused launch; 0 = everything fused
-  int pyr_blocks_per_item = 0;  // UVO_TUNE_PYR_RUN: blocks of 7 source rows a streaming wavefront walks (0 = by batch size)
-  PyrStepLevel* d_pyr_blocks = nullptr;  // per level >= 1: the static blocks of the streaming form
-  int cap_pyr_blocks = 0;
-  int pyr_block_off[kMaxLevels] = {0}, pyr_nblocks[kMaxLevels] = {0};
-  int pyr_tail_built = -1;   // first level of the fused launch the plans were compiled for
   float* d_pattern = nullptr;   // 256 point pairs (x0, y0, x1, y1) of the rBRIEF pattern as floats
   uint32_t* d_patch = nullptr;  // 256 byte masks: which of the 4 pixels of an orientation-patch dword lie inside the circle
   // staging for the host-buffer entry points
@@ -363,69 +352,6 @@ static int dev_alloc(T** p, size_t n) {
   return UVO_OK;
 }
 
-static void free_pyr_plans(uvo_extractor* h) {
-  for (PyrPlanDev& P : h->pyr_plan) {
-    if (P.d_roles) (void)hipFree(P.d_roles);
-    if (P.d_steps) (void)hipFree(P.d_steps);
-    if (P.d_band_step) (void)hipFree(P.d_band_step);
-    P = PyrPlanDev();
-  }
-}
-
-// Everything the pyramid launches read, for one geometry: the static blocks of the streaming form per level, and one compiled schedule
-// per band count of the fused launch for the levels from pyr_tail_from on (pyr_schedule.hpp).  Called with every lane idle.
-static int build_pyr_plans(uvo_extractor* h, const Geom& g) {
-  std::vector<PyrRow> rows[kMaxLevels];
-  PyrDims dims[kMaxLevels];
-  std::vector<PyrStepLevel> all, one;
-  for (int l = 0; l < g.nlevels; ++l) {
-    dims[l] = PyrDims{g.lv[l].w, g.lv[l].h, g.lv[l].pitch};
-    h->pyr_block_off[l] = (int)all.size(), h->pyr_nblocks[l] = 0;
-    if (l > 0) {
-      pyr_build_rows(g.lv[l - 1].h, g.lv[l].h, rows[l]);
-      if (!pyr_build_blocks(rows[l], dims[l], g.lv[l - 1].h, one)) return fail(UVO_E_UNSUPPORTED, "pyramid blocks: scale factor outside the supported range");
-      h->pyr_nblocks[l] = (int)one.size();
-      all.insert(all.end(), one.begin(), one.end());
-    }
-  }
-  if ((int)all.size() > h->cap_pyr_blocks) return fail(UVO_E_BADARG, "image larger than the handle was sized for");
-  if (!all.empty()) UVO_HIP_CHECK(hipMemcpy(h->d_pyr_blocks, all.data(), all.size() * sizeof(PyrStepLevel), hipMemcpyHostToDevice));
-  free_pyr_plans(h);
-  const int first = std::min(std::max(h->pyr_tail_from, 0), g.nlevels);
-  h->pyr_tail_built = first;
-  if (first >= g.nlevels) return UVO_OK;  // every level streams
-  int nresize, ncopy, nwaves, nslots;
-  pyr_role_count(dims, first, g.nlevels, nresize, ncopy);
-  if (!pyr_shape_for_roles(nresize, ncopy, h->pyr_waves, nwaves, nslots) && !pyr_shape_for_roles(nresize, ncopy, 0, nwaves, nslots))
-    return fail(UVO_E_UNSUPPORTED, "image too wide for the pyramid kernel's workgroup shapes");
-  for (int k = 0; k < kPyrPlans; ++k) {
-    const int nb = 1 << k;
-    if (k > 0 && g.lv[g.nlevels - 1].h / nb < 4) break;  // bands of fewer than four rows of the top level: the shared rows outweigh the owned ones
-    PyrSchedule S;
-    if (!pyr_build_schedule(dims, first, g.nlevels, rows, nb, nwaves, nslots, h->pyr_rows, S)) return fail(UVO_E_UNSUPPORTED, "pyramid schedule: scale factor outside the supported range");
-    PyrPlanDev& P = h->pyr_plan[k];
-    P.nbands = nb, P.nwaves = nwaves, P.nslots = nslots, P.nsteps = (int)S.band_step.back();
-    int rc;
-    if ((rc = dev_alloc(&P.d_roles, S.roles.size())) != UVO_OK || (rc = dev_alloc(&P.d_steps, S.steps.size())) != UVO_OK ||
-        (rc = dev_alloc(&P.d_band_step, S.band_step.size())) != UVO_OK)
-      return rc;
-    UVO_HIP_CHECK(hipMemcpy(P.d_roles, S.roles.data(), S.roles.size() * sizeof(PyrRole), hipMemcpyHostToDevice));
-    UVO_HIP_CHECK(hipMemcpy(P.d_steps, S.steps.data(), S.steps.size() * sizeof(PyrStepLevel), hipMemcpyHostToDevice));
-    UVO_HIP_CHECK(hipMemcpy(P.d_band_step, S.band_step.data(), S.band_step.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  }
-  return UVO_OK;
-}
-
-// band count of a batch: enough workgroups to fill the chip (one per frame when the batch does that by itself; a single frame is cut
-// into up to sixteen bands -- the latency path)
-static const PyrPlanDev& pick_pyr_plan(const uvo_extractor* h, int batch) {
-  int want = h->pyr_bands_forced;
-  if (want <= 0) want = batch >= 256 ? 1 : (batch >= 96 ? 2 : (batch >= 32 ? 4 : (batch >= 8 ? 8 : 16)));
-  int k = 0;
-  while (k + 1 < kPyrPlans && (1 << (k + 1)) <= want && h->pyr_plan[k + 1].nbands) ++k;
-  return h->pyr_plan[k];
-}
-
 static int set_geometry(uvo_extractor* h, int width, int height) {
   if (h->have_geom && h->geom.width == width && h->geom.height == height) return UVO_OK;
   Geom g;
@@ -459,10 +385,6 @@ static int set_geometry(uvo_extractor* h, int width, int height) {
   if (!ctab.empty()) {
     UVO_HIP_CHECK(hipMemcpy(h->d_ctab, ctab.data(), ctab.size() * sizeof(ResizeCol), hipMemcpyHostToDevice));
     UVO_HIP_CHECK(hipMemcpy(h->d_rtab, rtab.data(), rtab.size() * sizeof(ResizeRow), hipMemcpyHostToDevice));
-  }
-  {
-    int rcp = build_pyr_plans(h, g);
-    if (rcp) return rcp;
   }
   h->geom = g;
   h->cells = cells;
@@ -500,7 +422,10 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   h->cur = li;
   Lane& L = h->lane[li];
   hipStream_t s = L.stream;
-  for (uvo_matcher* m : h->followers) uvo_matcher_follow_internal(m, s);  // attached matchers work behind THIS batch
+  {  // attached matchers work behind THIS batch (and only this one: the ordering contract of uvo_matcher_attach_extractor)
+    std::lock_guard<std::mutex> lk(h->followers_mu);
+    for (uvo_matcher* m : h->followers) uvo_matcher_follow_internal(m, s);
+  }
   h->last_batch = batch;
   const Geom& g = h->geom;
   hipEvent_t& done = L.done[L.n_enqueued & 1];  // recorded behind the lane's last but one batch
@@ -511,60 +436,17 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   // is never materialised.  Needs dword-aligned rows of a width that is a multiple of 4 (a lane's four pixels are then wholly inside the
   // image or wholly border), the launch chain, and no caller keypoints (their orientation patch may reach into the border).  The image
   // must stay unchanged until the batch is complete (it always had to stay valid that long).
-  const bool inplace = h->level0_inplace && h->pyr_mode == UVO_PYR_MODE_CHAIN && width % 4 == 0 && stride % 4 == 0 && frame_stride % 4 == 0 &&
-                       (uintptr_t)d_imgs % 4 == 0 && !(d_in_kp && d_n_in) && width >= 64 && height >= 64;
+  const bool inplace = h->level0_inplace && width % 4 == 0 && stride % 4 == 0 && frame_stride % 4 == 0 &&
+                       (uintptr_t)d_imgs % 4 == 0 && !(d_in_kp && d_n_in) && width >= 64 && height >= 64 &&
+                       // the kernels address in-place rows as __umul24(row, pitch) + a 32-bit lane offset: a wider stride (an ROI of a large
+                       // mosaic) takes the padded copy instead
+                       stride <= (1 << 20) && (int64_t)(height + 2 * kPad) * stride < (int64_t)1 << 31;
   Level0View l0{nullptr, 0, 0, 0};
   if (inplace) l0 = Level0View{d_imgs - (int64_t)kPad * stride - kPad, (int64_t)frame_stride, (int)stride, 0};
   L.l0_src = inplace ? d_imgs : nullptr, L.l0_stride = stride, L.l0_frame_stride = frame_stride;
   const Level0View no_l0{nullptr, 0, 0, 0};
-  if (h->pyr_mode == 2) {
-    // development probe: no pyramid launch at all (the planes of an earlier batch stay): what the stage costs the step
-  } else if (h->pyr_mode == UVO_PYR_MODE_SPLIT) {
-    // ComputePyramid (src/ORBextractor.cc:963-1004): the large levels stream (one launch each, the border copy of level 0 riding along
-    // with level 1), the levels from pyr_tail_built on share one row-pipelined launch
-    const int first = h->pyr_tail_built;
-    bool fast = true;
-    for (int l = 1; l < g.nlevels; ++l) fast = fast && h->resize_fast[l];
-    const int bpi = h->pyr_blocks_per_item > 0 ? h->pyr_blocks_per_item : (batch >= 64 ? 5 : (batch >= 8 ? 3 : 2));
-    if (first > 0) {
-      // level 1 reads the caller's image in place when its rows are dword-aligned; otherwise from the padded plane behind a copy-only launch
-      const bool inplace = first > 1 && (uintptr_t)d_imgs % 4 == 0 && stride % 4 == 0 && frame_stride % 4 == 0;
-      for (int l = (inplace ? 1 : 0); l < first; ++l) {
-        ProfScope p(h, l <= 1 ? "k_pyr_stream1" : "k_pyr_stream");
-        PyrStreamArgs A;
-        memset(&A, 0, sizeof(A));
-        A.pyr = L.d_pyr, A.pyr_block = g.pyr_block;
-        if (l >= 1) {
-          const LevelGeom &S = g.lv[l - 1], &D = g.lv[l];
-          if (l == 1 && inplace) {
-            A.src = d_imgs, A.src_frame_stride = frame_stride, A.src_origin = 0, A.src_pitch = (int)stride;
-            A.src_bytes = (uint32_t)(stride * (height - 1) + width);
-          } else {
-            A.src = L.d_pyr, A.src_frame_stride = g.pyr_block, A.src_origin = S.plane_off + (int64_t)kPad * S.pitch + kPad, A.src_pitch = S.pitch;
-            A.src_bytes = (uint32_t)(S.pitch * (S.h + kPad) - kPad);
-          }
-          A.sw = S.w, A.sh = S.h;
-          A.dst_plane_off = D.plane_off, A.dst_pitch = D.pitch, A.dst_h = D.h;
-          A.ctab = h->d_ctab + D.xtab_off, A.blocks = h->d_pyr_blocks + h->pyr_block_off[l];
-          A.nblocks = h->pyr_nblocks[l], A.blocks_per_item = bpi;
-          A.nchunks = (D.pitch / 4 + 63) / 64, A.nsegs = (A.nblocks + bpi - 1) / bpi;
-        }
-        if (l == 0 || (l == 1 && inplace)) {
-          A.img = d_imgs, A.img_stride = stride, A.img_frame_stride = frame_stride, A.img_w = width, A.img_h = height;
-          A.l0_pitch = g.lv[0].pitch, A.l0_plane_off = g.lv[0].plane_off;
-          A.copy_chunks = (g.lv[0].pitch / 16 + 63) / 64, A.copy_rows_per_item = bpi * kPyrMaxSrcRows;
-          A.copy_segs = (height + A.copy_rows_per_item - 1) / A.copy_rows_per_item;
-        }
-        A.items_per_frame = A.nchunks * A.nsegs + A.copy_chunks * A.copy_segs;
-        launch_pyr_stream(s, A, fast, batch);
-      }
-    }
-    if (first < g.nlevels) {
-      ProfScope p(h, "k_pyramid");
-      if (launch_pyramid(s, d_imgs, stride, frame_stride, L.d_pyr, g.pyr_block, g, h->resize_fast, pick_pyr_plan(h, batch), h->d_ctab, batch))
-        return fail(UVO_E_UNSUPPORTED, "no pyramid kernel for this workgroup shape");
-    }
-  } else {
+  {
+    // ComputePyramid (src/ORBextractor.cc:963-1004): one launch per level
     if (!inplace) {
       ProfScope p(h, "k_pad_level0");
       launch_pad_level0(s, d_imgs, width, height, stride, frame_stride, L.d_pyr, g.pyr_block, g.lv[0], batch);
@@ -574,10 +456,6 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
       launch_resize_level(s, L.d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_ctab + g.lv[l].xtab_off, h->d_rtab + g.lv[l].ytab_off, h->resize_fast[l],
                           batch, l == 1 ? l0 : no_l0, h->pyr_ring);
     }
-  }
-  if (h->probe_delay_us > 0) {
-    ProfScope p(h, "k_probe_delay");
-    launch_probe_delay(s, h->probe_delay_us);
   }
   {  // the per-cell threshold vote + candidate emit run inside k_octree
     ProfScope p(h, "k_fast_score");
@@ -720,7 +598,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   h->cap_sel_block = g.sel_block;
   h->cap_flist = g.flist_cap;
   h->cap_xtab = 0, h->cap_ytab = 0;
-  for (int l = 1; l < g.nlevels; ++l) h->cap_xtab += g.lv[l].pitch + 64, h->cap_ytab += g.lv[l].ph + 8, h->cap_pyr_blocks += g.lv[l - 1].h / kPyrMaxSrcRows + 4;  // (row tables are padded to groups of 4 rows; smaller images of the same area have other level heights)
+  for (int l = 1; l < g.nlevels; ++l) h->cap_xtab += g.lv[l].pitch + 64, h->cap_ytab += g.lv[l].ph + 8;  // (row tables are padded to groups of 4 rows; smaller images of the same area have other level heights)
   const size_t B = (size_t)cfg->max_batch;
   hipError_t e = hipSetDevice(h->device);
   if (e != hipSuccess) {
@@ -753,7 +631,6 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   A(dev_alloc(&h->d_cell_flag, h->cap_flags / B + 64));
   A(dev_alloc(&h->d_ctab, (size_t)h->cap_xtab));
   A(dev_alloc(&h->d_rtab, (size_t)h->cap_ytab));
-  A(dev_alloc(&h->d_pyr_blocks, (size_t)h->cap_pyr_blocks));
   A(dev_alloc(&h->d_pattern, (size_t)1024));
   A(dev_alloc(&h->d_patch, (size_t)256));
   // staging for host-buffer calls
@@ -792,8 +669,11 @@ void uvo_extractor_destroy(uvo_extractor* h) {
   (void)hipSetDevice(h->device);
   for (int i = 0; i < kMaxLanes; ++i)
     if (h->lane[i].stream) (void)hipStreamSynchronize(h->lane[i].stream);
-  for (uvo_matcher* m : h->followers) uvo_matcher_orphaned_internal(m);  // their work in these streams is done; they outlive the streams
-  h->followers.clear();
+  {
+    std::lock_guard<std::mutex> lk(h->followers_mu);
+    for (uvo_matcher* m : h->followers) uvo_matcher_orphaned_internal(m);  // their work in these streams is done; they outlive the streams
+    h->followers.clear();
+  }
   for (int i = 0; i < kMaxLanes; ++i) {
     Lane& L = h->lane[i];
     if (L.stream) (void)hipStreamSynchronize(L.stream);
@@ -812,8 +692,6 @@ void uvo_extractor_destroy(uvo_extractor* h) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->h_pin) (void)hipHostFree(h->h_pin);
-  uvo::free_pyr_plans(h);
-  if (h->d_pyr_blocks) (void)hipFree(h->d_pyr_blocks);
   delete h;
 }
 
@@ -944,32 +822,6 @@ int uvo_extractor_tune(uvo_extractor* h, int knob, int value) {
         if (h->lane[i].stream && (rc = set_lane_fast_mode(h, i)) != UVO_OK) return rc;
       return UVO_OK;
     }
-    case UVO_TUNE_PYR_BANDS:
-      if (value < 0 || value > 16 || (value & (value - 1))) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_BANDS takes 0 (by batch size), 1, 2, 4, 8 or 16");
-      h->pyr_bands_forced = value;
-      return UVO_OK;
-    case UVO_TUNE_PYR_WAVES:
-    case UVO_TUNE_PYR_ROWS: {
-      if (knob == UVO_TUNE_PYR_WAVES && value != 0 && value != 4 && value != 8 && value != 16) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_WAVES takes 0, 4, 8 or 16");
-      if (knob == UVO_TUNE_PYR_ROWS && (value < 1 || value > kPyrMaxSrcRows)) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_ROWS takes 1 .. 7");
-      UVO_HIP_CHECK(hipSetDevice(h->device));
-      int rc = sync_all_lanes(h);
-      if (rc) return rc;
-      (knob == UVO_TUNE_PYR_WAVES ? h->pyr_waves : h->pyr_rows) = value;
-      return h->have_geom ? build_pyr_plans(h, h->geom) : UVO_OK;
-    }
-    case UVO_TUNE_PYR_TAIL: {
-      if (value < 0 || value > kMaxLevels) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_TAIL takes 0 .. 16");
-      UVO_HIP_CHECK(hipSetDevice(h->device));
-      int rc = sync_all_lanes(h);
-      if (rc) return rc;
-      h->pyr_tail_from = value;
-      return h->have_geom ? build_pyr_plans(h, h->geom) : UVO_OK;
-    }
-    case UVO_TUNE_PYR_RUN:
-      if (value < 0 || value > 64) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_RUN takes 0 .. 64");
-      h->pyr_blocks_per_item = value;
-      return UVO_OK;
     case UVO_TUNE_PYR_RING:
       if (value != 0 && value != 4 && value != 8 && value != 12) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_RING takes 0, 4, 8 or 12");
       h->pyr_ring = value;
@@ -980,16 +832,9 @@ int uvo_extractor_tune(uvo_extractor* h, int knob, int value) {
     case UVO_TUNE_FUSE_BLUR_TREE:
       h->fuse_blur_tree = value != 0;
       return UVO_OK;
-    case 100:  // development probe
-      h->probe_delay_us = value;
-      return UVO_OK;
     case UVO_TUNE_BLUR_ROUNDING:
       if (value != UVO_BLUR_ROUNDING_SCALAR && value != UVO_BLUR_ROUNDING_SSE2) return fail(UVO_E_BADARG, "UVO_TUNE_BLUR_ROUNDING takes UVO_BLUR_ROUNDING_SCALAR / _SSE2");
       h->blur_rounding = value;
-      return UVO_OK;
-    case UVO_TUNE_PYR_MODE:
-      if (value != UVO_PYR_MODE_CHAIN && value != UVO_PYR_MODE_SPLIT && value != 2) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_MODE takes UVO_PYR_MODE_CHAIN / _SPLIT");
-      h->pyr_mode = value;
       return UVO_OK;
     default:
       return fail(UVO_E_BADARG, "unknown knob");
@@ -1411,7 +1256,7 @@ int uvo_extractor_read_plane(uvo_extractor* h, int frame, int level, int which, 
   UVO_HIP_CHECK(hipStreamSynchronize(h->lane[h->cur].stream));
   const LevelGeom& L = h->geom.lv[level];
   Lane& LN = h->lane[h->cur];
-  if (!which && level >= 1 && h->pyr_ring > 0 && h->pyr_mode == UVO_PYR_MODE_CHAIN) {
+  if (!which && level >= 1 && h->pyr_ring > 0) {
     // the batch wrote the level's ROI and the few pixels around it that a stage reads: this test tap completes the 16-pixel border (the same
     // launch over the whole padded plane; its source -- the ROI of the level below, or the caller's image -- is still there)
     const Geom& g = h->geom;
@@ -1501,9 +1346,11 @@ int uvo_extractor_kernel_times(uvo_extractor* h, char* names, int names_cap, flo
 
 hipStream_t uvo_extractor_stream_internal(uvo_extractor* h) { return h->lane[h->cur].stream; }
 void uvo_extractor_add_follower_internal(uvo_extractor* h, uvo_matcher* m) {
+  std::lock_guard<std::mutex> lk(h->followers_mu);
   if (std::find(h->followers.begin(), h->followers.end(), m) == h->followers.end()) h->followers.push_back(m);
 }
 void uvo_extractor_drop_follower_internal(uvo_extractor* h, uvo_matcher* m) {
+  std::lock_guard<std::mutex> lk(h->followers_mu);
   h->followers.erase(std::remove(h->followers.begin(), h->followers.end(), m), h->followers.end());
 }
 int uvo_extractor_device_internal(uvo_extractor* h) { return h->device; }

@@ -235,10 +235,11 @@ struct GaussArgs {
   Level0View l0;
   GaussPlans plans;
 };
-template <bool SSE2>
 #ifndef UVO_OCT_EVERY
 #define UVO_OCT_EVERY 3  // every third workgroup of the front of the grid is a quad-tree problem (measured against every second: the same)
 #endif
+static_assert(UVO_OCT_EVERY >= 2, "the interleave needs at least one blur workgroup between two quad-tree problems");
+template <bool SSE2>
 __global__ __launch_bounds__(256, 4) void k_octree_gauss(int n_oct, GaussArgs G, const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max, int pyr_words, int box_region,
                                                         int lds_bytes, FastLevels FL, const uint32_t* __restrict__ cand_lo, int32_t* __restrict__ cursor,
                                                         int32_t* __restrict__ fcount, int32_t* __restrict__ n_cell_list, uint8_t* cell_hi,
@@ -341,7 +342,7 @@ int gauss7_blocks_per_frame(const Geom& g, int rows_per_seg);
 bool octree_gauss_applies(const OctLaunchState& st, const Geom& g, int batch) {
   int M, Mp2, pyr_words;
   return batch * g.nlevels > st.wide_max_problems && octree_lds(g, M, Mp2, pyr_words) <= 64 * 1024 &&
-         gauss7_blocks_per_frame(g, gauss7_rows_per_seg(batch)) >= 2 * g.nlevels;  // (the interleave below needs two blur workgroups per quad-tree problem)
+         gauss7_blocks_per_frame(g, gauss7_rows_per_seg(batch)) >= (UVO_OCT_EVERY - 1) * g.nlevels;  // (the interleave needs UVO_OCT_EVERY - 1 blur workgroups per quad-tree problem)
 }
 
 void launch_octree_gauss(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, int4 taps, int sse2_rounding,

@@ -6,7 +6,7 @@
 // aligned dword store, rows are 64-B pitched).  Pad pixels are produced by evaluating the level at the
 // reflected coordinate, so each level is written exactly once and no second border pass exists.
 #include "common.hpp"
-#include "pyr_schedule.hpp"
+#include <algorithm>
 
 namespace uvo {
 
@@ -233,509 +233,19 @@ void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const
     nwx = (uint32_t)((dst.w + kPad + ring + 3) / 4 - wx0), groups = (uint32_t)((row_end + RZ_ROWS - 1) / RZ_ROWS - rg0);
   }
   const uint32_t magic = (uint32_t)((0x100000000ull + nwx - 1) / nwx);
-  const uint32_t per_frame = (nwx * groups + 255) / 256, per_xcd = (per_frame * (uint32_t)batch + 7) / 8;
+  const uint32_t per_frame = (nwx * groups + 255) / 256;
   const uint32_t pf_magic = (uint32_t)((0x100000000ull + per_frame - 1) / per_frame);
-  hipLaunchKernelGGL(k_resize_level, dim3(8 * per_xcd), block, 0, s, d_pyr, pyr_block, src.plane_off, src.pitch, src.w, dst.plane_off, dst.pitch, dst.ph,
-                     dst.w, fast_ok, d_ctab, d_rtab, magic, l0, src.h, per_frame, pf_magic, per_xcd, batch, nwx, wx0, rg0, row_end);
-}
-
-
-// =====================================================================================================================
-// k_pyramid: the whole pyramid of a batch in ONE launch (schedule: pyr_schedule.hpp).
-// Workgroup = (band, frame).  Every wavefront keeps a few ROLES -- (level, 64-lane column chunk) -- for the whole band: the column
-// tables of its lanes and the horizontal pass of the last source row it has seen live in registers.  Per macro-step the workgroup
-// reads what every level does from a table (output rows [lo, hi), new source rows [k_lo, k_hi]), every wavefront streams its roles
-// over those rows, and the workgroup meets at a barrier: rows written before the barrier are read behind it by the same workgroup
-// (same CU: one L1, one L2) -- no LDS, no agent-scope fences, every level is written once and read back out of the L2 it was just
-// written through.  Rows are addressed as buffer resource (the plane) + per-lane byte offset + scalar row offset: no vector address
-// arithmetic per row.
-//
-// Arithmetic of a resize role (cv::resize INTER_LINEAR, 8-bit generic path), on the fp32 pipe with the wavefront's
-// rounding mode at round-toward-zero, every step exact:
-//   horizontal  r16 = L * (a0 << 4) + R * (a1 << 4)            two exact products, sum < 2^24
-//               q   = r >> 4 = floor(r16 / 256)                fma(r16, 2^-8, 2^23) - 2^23: the fma's single rounding truncates at unit size
-//   vertical    t0' = fma(q0, b0 / 65536, 2^23)                = 2^23 + ((b0 * q0) >> 16)
-//               w   = fma(q1, b1 / 65536, t0')                 = 2^23 + t0 + t1   (t0' is an integer: the truncation only hits q1 * b1)
-//               o'  = fma(w, 1/4, 2^23 - 2^21 + 1/2)           = 2^23 + ((t0 + t1 + 2) >> 2): the byte is the low mantissa byte
-// A source row's horizontal pass is computed once and used by the (one or two) output rows that read it.
-struct PyrLevel {
-  int w, h, pitch, ctab_off;
-  int64_t plane_off;
-  int rtab_off, pad;
-};
-struct PyrLevels {
-  PyrLevel l[kMaxLevels];
-};
-
-typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
-__device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t pyr_rsrc(const void* p, uint32_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);  // raw buffer, 32-bit data format
-}
-
-struct PyrConst {
-  float k23, k256, kq, kfin;
-};
-
-// per-slot state of a resize role
-struct PyrResize {
-  float a0[4], a1[4];      // (a << 4) of the lane's four output columns, as floats
-  uint32_t sx[4];          // byte-gather path only: left tap columns
-  uint32_t sel, base;      // tap selector / first byte of the lane's 12-byte source window
-  uint32_t voff_dst;       // byte offset of the lane's dword in a padded destination row
-  float Hp[4];             // q of the last source row seen (the upper tap of the next output row)
-  bool active;
-};
-
-template <bool FAST>
-__device__ __forceinline__ void pyr_resize_init(PyrResize& R, const ResizeCol* __restrict__ ctab, int nwx, int chunk, int lane) {
-  const int wx = chunk * 64 + lane;
-  const int wxc = wx < nwx ? wx : nwx - 1;
-  const uint4 c01 = reinterpret_cast<const uint4*>(ctab)[wxc * 2];      // columns 4wx, 4wx+1
-  const uint4 c23 = reinterpret_cast<const uint4*>(ctab)[wxc * 2 + 1];  // columns 4wx+2, 4wx+3
-  const uint32_t cw[8] = {c01.x, c01.y, c01.z, c01.w, c23.x, c23.y, c23.z, c23.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    R.sx[i] = cw[2 * i] & 0xffffu;
-    R.a0[i] = (float)(cw[2 * i] >> 16);
-    R.a1[i] = (float)(cw[2 * i + 1] & 0xffffu);
-    asm volatile("" : "+v"(R.a0[i]), "+v"(R.a1[i]));  // keep them floats: the products below stay on the fp32 pipe
-    R.Hp[i] = 0.f;
-  }
-  R.base = cw[1] >> 16;
-  R.sel = (cw[3] >> 16) | (cw[5] & 0xffff0000u);
-  R.voff_dst = (uint32_t)wx * 4u;
-  R.active = wx < nwx;
-}
-
-// what a resize role fetches in one step: the new source rows (at most kPyrMaxSrcRows; past the last new row the index is clamped, so
-// the surplus slots repeat the last row: unconditional loads, and slot 6 always ends up holding the last row seen) and the vertical
-// weights of the step's eight slots (every lane reads the same words: they arrive in vector registers, no scalar-to-vector moves)
-struct PyrFetch {
-  uint32_t u[kPyrMaxSrcRows][3];
-};
-template <bool FAST>
-__device__ __forceinline__ void pyr_resize_fetch(PyrFetch& F, const PyrResize& R, __amdgpu_buffer_rsrc_t src, int src_pitch, int sw, int k_lo, int nsrc) {
-#pragma unroll
-  for (int j = 0; j < kPyrMaxSrcRows; ++j) {
-    const int kr = k_lo + (j < nsrc ? j : nsrc - 1);
-    const int soff = kr * src_pitch;
-    if (FAST) {
-      const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(src, (int)R.base, soff, 0);
-      F.u[j][0] = v.x, F.u[j][1] = v.y, F.u[j][2] = v.z;
-    } else {
-      uint32_t Lb = 0, Rb = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t sx1 = R.sx[i] + 1 < (uint32_t)sw ? R.sx[i] + 1 : (uint32_t)sw - 1;
-        Lb |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(src, (int)R.sx[i], soff, 0) << (8 * i);
-        Rb |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(src, (int)sx1, soff, 0) << (8 * i);
-      }
-      F.u[j][0] = Lb, F.u[j][1] = Rb, F.u[j][2] = 0;
-    }
+  // vb / per_frame by multiply-high with ceil(2^32 / per_frame) is exact while (items of the launch) * per_frame < 2^32; a launch beyond that
+  // (4096^2 planes from batch ~500 on) goes out in slices of whole frames that each stay inside the bound
+  const uint32_t max_frames = std::max<uint32_t>(1u, (uint32_t)(0xffffffffull / ((uint64_t)per_frame * per_frame)));
+  for (int f0 = 0; f0 < batch; f0 += (int)max_frames) {
+    const int nb = std::min<int>(batch - f0, (int)max_frames);
+    const uint32_t per_xcd = (per_frame * (uint32_t)nb + 7) / 8;
+    Level0View v = l0;
+    if (v.vbase) v.vbase += (int64_t)f0 * v.frame_stride;
+    hipLaunchKernelGGL(k_resize_level, dim3(8 * per_xcd), block, 0, s, d_pyr + (int64_t)f0 * pyr_block, pyr_block, src.plane_off, src.pitch, src.w, dst.plane_off, dst.pitch,
+                       dst.ph, dst.w, fast_ok, d_ctab, d_rtab, magic, v, src.h, per_frame, pf_magic, per_xcd, nb, nwx, wx0, rg0, row_end);
   }
 }
-
-template <bool FAST>
-__device__ __forceinline__ void pyr_hpass(float* H, const uint32_t* u, const PyrResize& R, const PyrConst& C) {
-  uint32_t L4, R4;
-  if (FAST) {
-    L4 = __builtin_amdgcn_perm(u[1], u[0], R.sel);
-    R4 = __builtin_amdgcn_perm(__builtin_amdgcn_alignbyte(u[2], u[1], 1), __builtin_amdgcn_alignbyte(u[1], u[0], 1), R.sel);
-  } else {
-    L4 = u[0], R4 = u[1];
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float Lf = (float)((L4 >> (8 * i)) & 0xffu), Rf = (float)((R4 >> (8 * i)) & 0xffu);  // v_cvt_f32_ubyte<i>
-    const float r16 = __builtin_fmaf(Rf, R.a1[i], Lf * R.a0[i]);
-    H[i] = __builtin_fmaf(r16, C.k256, C.k23) - C.k23;
-  }
-}
-
-// one output row from the q rows of its two taps (Hu: upper, Hl: lower); soff / dual = kPyrNoStore: the hardware drops the store
-__device__ __forceinline__ void pyr_emit(const PyrResize& R, __amdgpu_buffer_rsrc_t dst, const float* Hu, const float* Hl, float b0, float b1, int soff, int dual,
-                                         const PyrConst& C) {
-  float o[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float t0 = __builtin_fmaf(Hu[i], b0, C.k23);
-    const float w = __builtin_fmaf(Hl[i], b1, t0);
-    o[i] = __builtin_fmaf(w, C.kq, C.kfin);
-  }
-  const uint32_t v = __builtin_amdgcn_perm(f2u(o[1]), f2u(o[0]), 0x0c0c0400u) | __builtin_amdgcn_perm(f2u(o[3]), f2u(o[2]), 0x04000c0cu);
-  // lanes past the row's last dword carry an offset outside the resource too
-  __builtin_amdgcn_raw_buffer_store_b32(v, dst, (int)R.voff_dst, soff, 0);
-  __builtin_amdgcn_raw_buffer_store_b32(v, dst, (int)R.voff_dst, dual, 0);  // the pad row that repeats this one
-}
-
-// Streams the step's source-row slots, straight-line: slot j's q row, the output row it completes (upper tap = the slot before; slot 0:
-// the row carried from the step before), two stores.
-template <bool FAST>
-__device__ __forceinline__ void pyr_resize_run(const PyrFetch& F, PyrResize& R, __amdgpu_buffer_rsrc_t dst, const PyrStepLevel* __restrict__ T, uint32_t vzero,
-                                               const int* soff, const int* dual, uint32_t flags, const PyrConst& C) {
-  // the vertical weights of the step's eight slots: every lane reads the same words, so they arrive in vector registers (an fma that
-  // reads a scalar register issues at half the rate, and a scalar-to-vector move per weight costs as much)
-  float b[16];
-  const uint4* bw = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(T) + 16 + vzero);  // (vzero: an opaque per-lane 0 -- vector loads)
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint4 w = bw[q];
-    b[4 * q] = u2f(w.x), b[4 * q + 1] = u2f(w.y), b[4 * q + 2] = u2f(w.z), b[4 * q + 3] = u2f(w.w);
-  }
-  float H[kPyrMaxSrcRows + 1][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) H[0][i] = R.Hp[i];
-#pragma unroll
-  for (int j = 0; j < kPyrMaxSrcRows; ++j) {
-    pyr_hpass<FAST>(H[j + 1], F.u[j], R, C);
-    if (j == 0 && (flags & 1u)) {  // the level's clamped first row: both taps on its own source row
-      asm volatile("");
-#pragma unroll
-      for (int i = 0; i < 4; ++i) H[0][i] = H[1][i];
-    }
-    pyr_emit(R, dst, H[j], H[j + 1], b[2 * j], b[2 * j + 1], soff[j], dual[j], C);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) R.Hp[i] = H[kPyrMaxSrcRows][i];  // the last row seen (surplus slots repeat it)
-  if (flags & 2u) pyr_emit(R, dst, R.Hp, R.Hp, b[14], b[15], soff[7], dual[7], C);  // the level's clamped last row
-}
-
-// level 0: image rows [lo, hi) -> padded plane (cv::copyMakeBorder REFLECT_101, src/ORBextractor.cc:996); lane = 16 bytes of a padded row.
-// Every lane whose 16 columns lie wholly inside the image or wholly inside a pad takes the same path: four dword loads at per-lane
-// addresses (ascending inside the image, descending for a reflected run) and one byte permute each (identity or reversal) -- no
-// divergent branch between a row's loads, so all rows of a step are in flight together.  Lanes that straddle an image edge (only
-// when the width is no multiple of 16) gather bytes.
-struct PyrCopy {
-  int kind;            // 0: four dwords, 2: byte gather, 3: no column
-  int off[4];          // byte offset of output dword m inside an image row
-  uint32_t sel;        // v_perm selector: identity or byte reversal
-  int x0;
-  uint32_t voff_dst;
-};
-__device__ __forceinline__ void pyr_copy_init(PyrCopy& K, int w, int pitch, int chunk, int lane) {
-  const int qx = chunk * 64 + lane;
-  K.x0 = qx * 16 - kPad;  // image column of byte 0
-  const int r0 = K.x0 + 16 <= 0 ? -(K.x0 + 15) : 2 * (w - 1) - K.x0 - 15;  // first image column of the reversed run of a whole-pad group
-  const bool inside = K.x0 >= 0 && K.x0 + 16 <= w, padrun = (K.x0 + 16 <= 0 || K.x0 >= w) && r0 >= 0 && r0 + 16 <= w;
-  K.kind = qx * 16 >= pitch ? 3 : ((inside || padrun) ? 0 : 2);
-  K.sel = padrun ? 0x00010203u : 0x03020100u;
-#pragma unroll
-  for (int m = 0; m < 4; ++m) K.off[m] = padrun ? r0 + 12 - 4 * m : (inside ? K.x0 + 4 * m : 0);
-  K.voff_dst = (uint32_t)qx * 16u;
-}
-constexpr int kPyrCopyLoads = kPyrMaxSrcRows * 4;  // vector loads a copy wavefront issues per step (constant: the store drain counts past them)
-__device__ __forceinline__ void pyr_copy_fetch(uint32_t (*v)[4], const PyrCopy& K, const uint8_t* __restrict__ imgf, int64_t stride, int lo, int hi) {
-  const int nrows = hi - lo;
-#pragma unroll
-  for (int j = 0; j < kPyrMaxSrcRows; ++j) {
-    const int y = lo + (j < nrows ? j : (nrows > 0 ? nrows - 1 : 0));
-    const uint8_t* src = imgf + (int64_t)y * stride;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) __builtin_memcpy(&v[j][m], src + K.off[m], 4);  // (dword loads need no alignment on this target)
-  }
-}
-__device__ __forceinline__ void pyr_copy_store(const uint32_t (*v)[4], const PyrCopy& K, const uint8_t* __restrict__ imgf, int w, int64_t stride,
-                                               __amdgpu_buffer_rsrc_t dst, int pitch, int h, int lo, int hi) {
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  const int nrows = hi - lo;
-#pragma unroll
-  for (int j = 0; j < kPyrMaxSrcRows; ++j) {
-    if (j < nrows) {
-      const int y = lo + j;
-      u32x4 d;
-      if (K.kind == 2) {  // a group that straddles an image edge: bytes through the reflected index
-        const uint8_t* src = imgf + (int64_t)y * stride;
-        uint32_t t[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          int x = reflect101(K.x0 + k, w);
-          x = x < 0 ? 0 : (x >= w ? w - 1 : x);  // columns past the padded width (row pitch slack) stay in range
-          t[k >> 2] |= (uint32_t)src[x] << (8 * (k & 3));
-        }
-        d = u32x4{t[0], t[1], t[2], t[3]};
-      } else {
-        d = u32x4{__builtin_amdgcn_perm(v[j][0], v[j][0], K.sel), __builtin_amdgcn_perm(v[j][1], v[j][1], K.sel), __builtin_amdgcn_perm(v[j][2], v[j][2], K.sel),
-                  __builtin_amdgcn_perm(v[j][3], v[j][3], K.sel)};
-      }
-      if (K.kind != 3) {
-        __builtin_amdgcn_raw_buffer_store_b128(d, dst, (int)K.voff_dst, (kPad + y) * pitch, 0);
-        if (y >= 1 && y <= kPad) __builtin_amdgcn_raw_buffer_store_b128(d, dst, (int)K.voff_dst, (kPad - y) * pitch, 0);  // top pad: row -y = row y
-        if (y >= h - 1 - kPad && y <= h - 2) __builtin_amdgcn_raw_buffer_store_b128(d, dst, (int)K.voff_dst, (kPad + 2 * (h - 1) - y) * pitch, 0);
-      }
-    }
-  }
-}
-
-template <int NW, int NSLOT, bool FAST>
-__global__ __launch_bounds__(64 * NW, 4) void k_pyramid(const uint8_t* __restrict__ img, int64_t stride, int64_t frame_stride, uint8_t* __restrict__ pyr,
-                                                     int64_t pyr_block, PyrLevels LV, int nlevels, const PyrRole* __restrict__ roles,
-                                                     const PyrStepLevel* __restrict__ steps, const int32_t* __restrict__ band_step,
-                                                     const ResizeCol* __restrict__ ctab) {
-  const int band = blockIdx.x, f = blockIdx.y;
-  const int wv = wave_in_block(), lane = threadIdx.x & 63;
-  const int s0 = band_step[band], s1 = band_step[band + 1];
-  uint8_t* pf = pyr + f * pyr_block;
-  const uint32_t rw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(roles)[wv * NSLOT]);
-  if ((rw0 & 0xffu) == 0u) {
-    // ---- a copy wavefront: image rows -> padded level-0 plane.  The rows of step s + 1 are fetched while those of step s are stored:
-    // image rows depend on nothing, so the HBM round trip never sits between two barriers.  The barrier needs this wavefront's STORES to
-    // have landed, not its prefetch: it waits until all but the youngest kPyrCopyLoads vector-memory operations are done. ----
-    const uint8_t* imgf = img + f * frame_stride;
-    const PyrLevel g = LV.l[0];
-    PyrCopy K;
-    pyr_copy_init(K, g.w, g.pitch, (int)(rw0 >> 16), lane);
-    const __amdgpu_buffer_rsrc_t dst = pyr_rsrc(pf + g.plane_off, (uint32_t)(g.pitch * (g.h + 2 * kPad)));
-    auto rows_of = [&](int s, int& lo, int& hi) {
-      const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(steps + (int64_t)s * nlevels)[0]);
-      lo = (int)(int16_t)(a & 0xffffu), hi = lo + (int)(int16_t)(a >> 16);
-    };
-    uint32_t cur[kPyrMaxSrcRows][4], nxt[kPyrMaxSrcRows][4];
-    int lo, hi, lo_n = 0, hi_n = 0;
-    rows_of(s0, lo, hi);
-    pyr_copy_fetch(cur, K, imgf, stride, lo, hi);
-    for (int s = s0; s < s1; ++s) {
-      if (s + 1 < s1) rows_of(s + 1, lo_n, hi_n);
-      else lo_n = hi_n = lo;
-      pyr_copy_store(cur, K, imgf, g.w, stride, dst, g.pitch, g.h, lo, hi);
-      asm volatile("" ::: "memory");  // the prefetch stays behind the stores: the wait below counts on that order
-      pyr_copy_fetch(nxt, K, imgf, stride, lo_n, hi_n);
-      asm volatile("" ::: "memory");
-      static_assert(kPyrCopyLoads == 28, "the immediate of the wait below");
-      asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int j = 0; j < kPyrMaxSrcRows; ++j)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) cur[j][m] = nxt[j][m];
-      lo = lo_n, hi = hi_n;
-    }
-    return;
-  }
-  __builtin_amdgcn_s_setreg(0x801, 3);  // MODE.fp_round (fp32) = toward zero: see the arithmetic above
-  PyrConst C = {8388608.0f, 1.0f / 256.0f, 0.25f, 6291456.5f};
-  asm volatile("" : "+v"(C.k23), "+v"(C.k256), "+v"(C.kq), "+v"(C.kfin));
-  // ---- a resize wavefront: its roles ----
-  int level[NSLOT];
-  PyrResize R[NSLOT];
-  __amdgpu_buffer_rsrc_t rs_src[NSLOT], rs_dst[NSLOT];
-  int src_pitch[NSLOT], sw[NSLOT];
-  uint32_t vzero = 0;
-  asm volatile("" : "+v"(vzero));
-#pragma unroll
-  for (int i = 0; i < NSLOT; ++i) {
-    const uint32_t rw = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(roles)[wv * NSLOT + i]);
-    level[i] = (int)(rw & 0xffu);
-    const int chunk = (int)(rw >> 16);
-    const int l = level[i] == kPyrNop ? 1 : level[i];
-    const PyrLevel g = LV.l[l], gs = LV.l[l - 1];
-    src_pitch[i] = gs.pitch, sw[i] = gs.w;
-    rs_dst[i] = pyr_rsrc(pf + g.plane_off, (uint32_t)(g.pitch * (g.h + 2 * kPad)));
-    // the source resource starts at the ROI origin of the level below and ends with its plane
-    rs_src[i] = pyr_rsrc(pf + gs.plane_off + (int64_t)kPad * gs.pitch + kPad, (uint32_t)(gs.pitch * (gs.h + kPad) - kPad));
-    pyr_resize_init<FAST>(R[i], ctab + g.ctab_off, g.pitch >> 2, chunk, lane);
-    if (!R[i].active) R[i].voff_dst = 0x3fffff00u;  // outside every resource: the hardware drops the store
-  }
-  for (int s = s0; s < s1; ++s) {
-    const PyrStepLevel* T[NSLOT];
-    int k_lo[NSLOT], nsrc[NSLOT];
-    uint32_t flags[NSLOT];
-#pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
-      T[i] = steps + (int64_t)s * nlevels + (level[i] == kPyrNop ? 0 : level[i]);
-      const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(T[i])[0]);
-      flags[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(T[i])[2]);
-      k_lo[i] = (int)(int16_t)(a & 0xffffu), nsrc[i] = level[i] == kPyrNop ? 0 : (int)(int16_t)(a >> 16);
-    }
-    if (NSLOT <= 2 && NW <= 8) {
-      // every slot's rows in flight before the first one is touched
-      PyrFetch F[NSLOT];
-#pragma unroll
-      for (int i = 0; i < NSLOT; ++i)
-        if (nsrc[i] > 0) pyr_resize_fetch<FAST>(F[i], R[i], rs_src[i], src_pitch[i], sw[i], k_lo[i], nsrc[i]);
-#pragma unroll
-      for (int i = 0; i < NSLOT; ++i)
-        if (nsrc[i] > 0) {
-          int so[8], du[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) so[j] = __builtin_amdgcn_readfirstlane(T[i]->soff[j]), du[j] = __builtin_amdgcn_readfirstlane(T[i]->dual[j]);
-          pyr_resize_run<FAST>(F[i], R[i], rs_dst[i], T[i], vzero, so, du, flags[i], C);
-        }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NSLOT; ++i)
-        if (nsrc[i] > 0) {
-          PyrFetch F;
-          int so[8], du[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) so[j] = __builtin_amdgcn_readfirstlane(T[i]->soff[j]), du[j] = __builtin_amdgcn_readfirstlane(T[i]->dual[j]);
-          pyr_resize_fetch<FAST>(F, R[i], rs_src[i], src_pitch[i], sw[i], k_lo[i], nsrc[i]);
-          pyr_resize_run<FAST>(F, R[i], rs_dst[i], T[i], vzero, so, du, flags[i], C);
-        }
-    }
-    __syncthreads();
-  }
-}
-
-
-// =====================================================================================================================
-// k_pyr_stream: one level of the pyramid as a streaming launch -- the form the large levels take (thousands of independent
-// wavefronts: latency is hidden by occupancy and by register prefetch, no barrier anywhere).  A wavefront owns a 64-lane column chunk
-// of the level and a run of consecutive BLOCKS of kPyrMaxSrcRows source rows (pyr_build_blocks): per block the same straight-line code
-// as a step of k_pyramid, from the same kind of control words; the rows of the next block are in flight while the current one is
-// computed.  Level 1 reads the caller's image in place (a buffer resource of exactly the frame's bytes: the few bytes a tap window
-// reaches past the last row read as zero and carry weight zero); in that launch the copy of the image into the padded level-0 plane
-// rides along as extra work items.
-template <bool FAST>
-__global__ __launch_bounds__(256, 4) void k_pyr_stream(PyrStreamArgs A) {
-  const int lane = threadIdx.x & 63;
-  const int blocks_per_frame = (A.items_per_frame + 3) >> 2;
-  const int vb = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);  // an XCD walks whole frames: neighbouring runs share their rows in one L2
-  const int f = vb / blocks_per_frame;
-  int item = (vb - f * blocks_per_frame) * 4 + wave_in_block();
-  if (item >= A.items_per_frame) return;
-  uint8_t* pf = A.pyr + f * A.pyr_block;
-  const int nres = A.nchunks * A.nsegs;
-  if (item >= nres) {
-    // ---- a copy item: image rows [r0, r1) of one 64-lane column chunk into the padded level-0 plane ----
-    item -= nres;
-    const int chunk = item % A.copy_chunks, seg = item / A.copy_chunks;
-    const int r0 = seg * A.copy_rows_per_item, r1 = min(r0 + A.copy_rows_per_item, A.img_h);
-    const uint8_t* imgf = A.img + f * A.img_frame_stride;
-    PyrCopy K;
-    pyr_copy_init(K, A.img_w, A.l0_pitch, chunk, lane);
-    const __amdgpu_buffer_rsrc_t dst = pyr_rsrc(pf + A.l0_plane_off, (uint32_t)(A.l0_pitch * (A.img_h + 2 * kPad)));
-    uint32_t ca[kPyrMaxSrcRows][4], cb[kPyrMaxSrcRows][4];
-    pyr_copy_fetch(ca, K, imgf, A.img_stride, r0, min(r0 + kPyrMaxSrcRows, r1));
-    for (int r = r0; r < r1; r += 2 * kPyrMaxSrcRows) {
-      const int ra = min(r + kPyrMaxSrcRows, r1), rb = min(ra + kPyrMaxSrcRows, r1), rc = min(rb + kPyrMaxSrcRows, r1);
-      pyr_copy_fetch(cb, K, imgf, A.img_stride, min(ra, r1 - 1), max(rb, min(ra, r1 - 1) + 1));
-      pyr_copy_store(ca, K, imgf, A.img_w, A.img_stride, dst, A.l0_pitch, A.img_h, r, ra);
-      if (ra < r1) {
-        pyr_copy_fetch(ca, K, imgf, A.img_stride, min(rb, r1 - 1), max(rc, min(rb, r1 - 1) + 1));
-        pyr_copy_store(cb, K, imgf, A.img_w, A.img_stride, dst, A.l0_pitch, A.img_h, ra, rb);
-      }
-    }
-    return;
-  }
-  // ---- a resize item: blocks [b0, b1) of one column chunk ----
-  const int chunk = item % A.nchunks, seg = item / A.nchunks;
-  const int b0 = seg * A.blocks_per_item, b1 = min(b0 + A.blocks_per_item, A.nblocks);
-  if (b0 >= b1) return;
-  __builtin_amdgcn_s_setreg(0x801, 3);  // MODE.fp_round (fp32) = toward zero: the arithmetic of k_pyramid
-  PyrConst C = {8388608.0f, 1.0f / 256.0f, 0.25f, 6291456.5f};
-  asm volatile("" : "+v"(C.k23), "+v"(C.k256), "+v"(C.kq), "+v"(C.kfin));
-  uint32_t vzero = 0;
-  asm volatile("" : "+v"(vzero));
-  const __amdgpu_buffer_rsrc_t rs_src = pyr_rsrc(A.src + f * A.src_frame_stride + A.src_origin, A.src_bytes);
-  const __amdgpu_buffer_rsrc_t rs_dst = pyr_rsrc(pf + A.dst_plane_off, (uint32_t)(A.dst_pitch * (A.dst_h + 2 * kPad)));
-  PyrResize R;
-  pyr_resize_init<FAST>(R, A.ctab, A.dst_pitch >> 2, chunk, lane);
-  if (!R.active) R.voff_dst = 0x3fffff00u;  // outside every resource: the hardware drops the store
-  PyrFetch Fa, Fb;
-  auto fetch = [&](PyrFetch& F, int b) {
-    const int bc = min(b, b1 - 1);  // (past the run: a repeat of its last block, never used)
-    const int k_lo = bc * kPyrMaxSrcRows;
-    pyr_resize_fetch<FAST>(F, R, rs_src, A.src_pitch, A.sw, k_lo, min(kPyrMaxSrcRows, A.sh - k_lo));
-  };
-  auto run = [&](const PyrFetch& F, int b) {
-    const PyrStepLevel* T = A.blocks + b;
-    int so[8], du[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) so[j] = __builtin_amdgcn_readfirstlane(T->soff[j]), du[j] = __builtin_amdgcn_readfirstlane(T->dual[j]);
-    const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)T->flags);
-    pyr_resize_run<FAST>(F, R, rs_dst, T, vzero, so, du, flags, C);
-  };
-  fetch(Fa, b0);
-  if (b0 > 0) {  // the row in front of the run: the upper tap of the first block's slot 0
-    uint32_t u[3];
-    const int soff = (b0 * kPyrMaxSrcRows - 1) * A.src_pitch;
-    if (FAST) {
-      const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs_src, (int)R.base, soff, 0);
-      u[0] = v.x, u[1] = v.y, u[2] = v.z;
-    } else {
-      uint32_t Lb = 0, Rb = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t sx1 = R.sx[i] + 1 < (uint32_t)A.sw ? R.sx[i] + 1 : (uint32_t)A.sw - 1;
-        Lb |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs_src, (int)R.sx[i], soff, 0) << (8 * i);
-        Rb |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs_src, (int)sx1, soff, 0) << (8 * i);
-      }
-      u[0] = Lb, u[1] = Rb, u[2] = 0;
-    }
-    pyr_hpass<FAST>(R.Hp, u, R, C);
-  }
-  for (int b = b0; b < b1; b += 2) {
-    fetch(Fb, b + 1);
-    run(Fa, b);
-    if (b + 1 < b1) {
-      fetch(Fa, b + 2);
-      run(Fb, b + 1);
-    }
-  }
-}
-
-template <int NW, int NSLOT>
-static void launch_pyramid_t(hipStream_t s, dim3 grid, bool fast, const uint8_t* d_img, int64_t stride, int64_t frame_stride, uint8_t* d_pyr,
-                             int64_t pyr_block, const PyrLevels& LV, int nlevels, const PyrPlanDev& plan, const ResizeCol* d_ctab) {
-  if (fast)
-    hipLaunchKernelGGL((k_pyramid<NW, NSLOT, true>), grid, dim3(64 * NW), 0, s, d_img, stride, frame_stride, d_pyr, pyr_block, LV, nlevels, plan.d_roles,
-                       plan.d_steps, plan.d_band_step, d_ctab);
-  else
-    hipLaunchKernelGGL((k_pyramid<NW, NSLOT, false>), grid, dim3(64 * NW), 0, s, d_img, stride, frame_stride, d_pyr, pyr_block, LV, nlevels, plan.d_roles,
-                       plan.d_steps, plan.d_band_step, d_ctab);
-}
-
-// workgroup shapes the kernel is built for: (wavefronts, role slots per resize wavefront); every copy role takes a wavefront of its own
-#define UVO_PYR_SHAPES(X) X(4, 2) X(8, 2) X(8, 3) X(16, 2) X(16, 3) X(16, 4) X(16, 6) X(16, 8)
-bool pyr_shape_for_roles(int nresize, int ncopy, int min_waves, int& nwaves, int& nslots) {
-#define UVO_PYR_TRY(NW, NS)                                                     \
-  if (NW >= min_waves && NW > ncopy && nresize <= (NW - ncopy) * NS) {          \
-    nwaves = NW, nslots = NS;                                                   \
-    return true;                                                                \
-  }
-  UVO_PYR_SHAPES(UVO_PYR_TRY)
-#undef UVO_PYR_TRY
-  return false;
-}
-
-int launch_pyramid(hipStream_t s, const uint8_t* d_img, int64_t stride, int64_t frame_stride, uint8_t* d_pyr, int64_t pyr_block, const Geom& g,
-                   const int* fast_ok, const PyrPlanDev& plan, const ResizeCol* d_ctab, int batch) {
-  PyrLevels LV;
-  bool fast = true;
-  for (int l = 0; l < kMaxLevels; ++l) LV.l[l] = PyrLevel{0, 0, 0, 0, 0, 0, 0};
-  for (int l = 0; l < g.nlevels; ++l) {
-    LV.l[l] = PyrLevel{g.lv[l].w, g.lv[l].h, g.lv[l].pitch, g.lv[l].xtab_off, g.lv[l].plane_off, 0, 0};
-    if (l > 0 && !fast_ok[l]) fast = false;  // one level whose taps do not fit the 12-byte window: every level gathers bytes
-  }
-  dim3 grid(plan.nbands, batch);
-#define UVO_PYR_CASE(NW, NS)                                                                                                                        \
-  if (plan.nwaves == NW && plan.nslots == NS) {                                                                                                     \
-    launch_pyramid_t<NW, NS>(s, grid, fast, d_img, stride, frame_stride, d_pyr, pyr_block, LV, g.nlevels, plan, d_ctab);            \
-    return 0;                                                                                                                                       \
-  }
-  UVO_PYR_SHAPES(UVO_PYR_CASE)
-#undef UVO_PYR_CASE
-  return -1;
-}
-
-
-void launch_pyr_stream(hipStream_t s, const PyrStreamArgs& A, bool fast, int batch) {
-  const int blocks_per_frame = (A.items_per_frame + 3) / 4;
-  if (fast)
-    hipLaunchKernelGGL(k_pyr_stream<true>, dim3(blocks_per_frame * batch), dim3(256), 0, s, A);
-  else
-    hipLaunchKernelGGL(k_pyr_stream<false>, dim3(blocks_per_frame * batch), dim3(256), 0, s, A);
-}
-
-
-// development probe: one wavefront that does nothing for `us` microseconds (what does pure latency in a lane cost the step?)
-__global__ void k_probe_delay(int us) {
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(32);
-}
-void launch_probe_delay(hipStream_t s, int us) { hipLaunchKernelGGL(k_probe_delay, dim3(1), dim3(64), 0, s, us); }
 
 }  // namespace uvo
