@@ -64,7 +64,7 @@ def algorithmic_bytes_per_frame(w, h, k):
     return {
         "k_pad_level0": 2 * s[0],                       # not in the survey's model (a design that reads the input in place needs none)
         "k_resize_level": sum(s[:-1]) + sum(s[1:]),     # reads S0..S6, writes S1..S7 (all 7 launches)
-        "k_pyramid_stage": sum(s[:-1]) + sum(s[1:]),    # the same model for the pyramid launches together (k_pyr_stream1 + k_pyr_stream + k_pyramid)
+        "k_pyr_tiles": sum(s[:-1]) + sum(s[1:]),        # the same model for the level-group launches together (they re-read fewer levels than it counts)
         "k_fast_score": tot,                            # reads every level once
         "k_gauss7": 2 * tot,
         "k_octree_gauss": 2 * tot,                      # the quad-tree and the blur as one launch: the blur's bytes
@@ -406,6 +406,13 @@ def main():
     ex.set_pipeline(DEPTH)
     ex.tune(uvo.UVO_TUNE_FAST_MODE, {"adaptive": uvo.UVO_FAST_MODE_ADAPTIVE, "two_pass": uvo.UVO_FAST_MODE_TWO_PASS,
                                      "single_pass": uvo.UVO_FAST_MODE_SINGLE_PASS}[args.fast_mode])
+    if os.environ.get("UVO_BENCH_PYR_FORM"):   # experiment knob: 0 auto / 1 per-level launches / 2 latency tiles / 3 throughput tiles
+        ex.tune(uvo.UVO_TUNE_PYR_FORM, int(os.environ["UVO_BENCH_PYR_FORM"]))
+    if os.environ.get("UVO_BENCH_PYR_GROUPS"):   # experiment knob: forced level groups of k_pyr_tiles, "first:txXty[w],..."
+        for g_ in os.environ["UVO_BENCH_PYR_GROUPS"].split(","):
+            first_, grid_ = g_.split(":")
+            tx_, ty_ = grid_.rstrip("wr").split("x")
+            ex.tune(uvo.UVO_TUNE_PYR_TILE_GROUP, (1 << 24 if grid_.endswith("w") else 0) | (1 << 25 if grid_.endswith("r") else 0) | int(first_) << 16 | int(tx_) << 8 | int(ty_))
     if os.environ.get("UVO_BENCH_FUSE"):   # experiment knob: quad-tree + blur as one launch (1, default) or two (0)
         ex.tune(uvo.UVO_TUNE_FUSE_BLUR_TREE, int(os.environ["UVO_BENCH_FUSE"]))
     if os.environ.get("UVO_BENCH_L0"):   # experiment knob: level 0 read in place (1, default) or copied into a padded plane first (0)
@@ -702,7 +709,7 @@ def main():
         avg_launch_s = dom_ms * 1e-3 / dom_launches
         bytes_per_launch = alg.get(dom, 0) * (B + 1) / launches_per_step
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        total_alg = sum(v for kname, v in alg.items() if kname not in ("k_pad_level0", "k_fast_blur", "k_pyramid_stage", "k_octree_gauss"))
+        total_alg = sum(v for kname, v in alg.items() if kname not in ("k_pad_level0", "k_fast_blur", "k_pyr_tiles", "k_octree_gauss"))
         pmc, pmc_frames, pmc_src = load_pmc(args.config)
         scale = (B + 1) / pmc_frames if pmc_frames else 1.0   # the counters were taken at the config's default batch: per-launch figures scale with the frames
 

@@ -229,7 +229,7 @@ int uvo_extractor_set_pipeline(uvo_extractor* h, int depth);
  * Launch-shape knobs of one handle (speed only -- results never depend on them; the parity tests force each shape).
  *   UVO_TUNE_OCT_WIDE_MAX : batches with at most this many (frame, level) quad-tree problems run DistributeOctTree
  *                           (src/ORBextractor.cc:1006-1230) as 1024-thread workgroups, larger ones as 256-thread workgroups
- *                           (default 256; 0 = always the 256-thread form, a large value = always the 1024-thread form).
+ *                           (default 0 = always the 256-thread form, which shares its launch with the blur; a large value = always the 1024-thread form).
  */
 #define UVO_TUNE_OCT_WIDE_MAX 1
 /*

@@ -12,6 +12,117 @@ def _planes_equal(ex, oe, nlev, msg, frame=0):
         np.testing.assert_array_equal(ex.read_plane(l, frame=frame), oe.level_plane(l), err_msg="%s level %d" % (msg, l))
 
 
+def _group(first, tx, ty, wide=False):
+    """wide: True = 1024-thread workgroups, "r" = 1024 threads and one output row per work item"""
+    return (1 << 25 if wide == "r" else (1 << 24 if wide else 0)) | first << 16 | tx << 8 | ty
+
+
+@pytest.mark.parametrize("form", ["levels", "latency", "throughput"])
+def test_every_pyramid_form_gives_the_oracle_pyramid(uvo, oracle, synth, form):
+    """UVO_TUNE_PYR_FORM: one launch per level (k_resize_level), or a launch per group of levels (k_pyr_tiles) with the latency / throughput
+    set of groups -- planes, keypoints and descriptors never depend on it."""
+    w, h = 640, 512
+    img = synth.make_frame(5150, w, h)
+    oe = oracle.extractor(1000, 1.2, 8, 20)
+    kp_o, de_o = oe(img)
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=w, max_height=h)
+    ex.tune(uvo.UVO_TUNE_PYR_FORM, {"levels": uvo.UVO_PYR_FORM_LEVELS, "latency": uvo.UVO_PYR_FORM_TILES_LATENCY, "throughput": uvo.UVO_PYR_FORM_TILES_THROUGHPUT}[form])
+    for _ in range(2):
+        kp, de = ex(img)
+        _planes_equal(ex, oe, 8, form)
+        assert kp.tobytes() == kp_o.tobytes() and (de == de_o).all()
+    if form != "levels":
+        assert "k_pyr_tiles" in _kernels_of_one_call(ex, img) and "k_resize_level" not in _kernels_of_one_call(ex, img)
+    ex.close()
+
+
+def _kernels_of_one_call(ex, img):
+    ex.profile(True)
+    ex(img)
+    names = set(ex.kernel_times().keys())
+    ex.profile(False)
+    return names
+
+
+@pytest.mark.parametrize("groups", [[(1, 1, 1)], [(1, 2, 2)], [(1, 4, 4)], [(1, 8, 8)], [(1, 16, 16)], [(1, 3, 7)], [(1, 12, 10), (4, 4, 4)], [(1, 4, 4), (3, 2, 2), (5, 1, 1, True)],
+                                    [(l, 3, 2) for l in range(1, 8)], [(1, 8, 8, True), (2, 1, 1, True)], [(1, 5, 5), (7, 2, 1)], [(1, 16, 16, "r")],
+                                    [(1, 12, 10, "r"), (4, 4, 4, "r")], [(1, 4, 4, "r"), (3, 2, 2), (5, 1, 1, "r")]])
+def test_forced_level_groups_and_tile_grids(uvo, oracle, synth, groups):
+    """UVO_TUNE_PYR_TILE_GROUP: any cut of the levels into groups, any tile grid per group, 256- or 1024-thread workgroups (a grid whose tiles
+    do not fit the LDS -- 1 x 1 at 640 x 512 -- silently takes the per-level launches)."""
+    w, h = 640, 512
+    img = synth.make_frame(5160, w, h)
+    oe = oracle.extractor(1000, 1.2, 8, 20)
+    kp_o, de_o = oe(img)
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=w, max_height=h)
+    for g in groups:
+        ex.tune(uvo.UVO_TUNE_PYR_TILE_GROUP, _group(*g))
+    kp, de = ex(img)
+    _planes_equal(ex, oe, 8, str(groups))
+    assert kp.tobytes() == kp_o.tobytes() and (de == de_o).all()
+    names = _kernels_of_one_call(ex, img)
+    fits = groups not in ([(1, 1, 1)], [(1, 8, 8, True), (2, 1, 1, True)])     # (whole levels 1 or 2 of this size do not fit the LDS)
+    assert ("k_pyr_tiles" in names) == fits, names
+    ex.tune(uvo.UVO_TUNE_PYR_TILE_GROUP, 0)     # back to the defaults
+    kp, de = ex(img)
+    _planes_equal(ex, oe, 8, "defaults after " + str(groups))
+    ex.close()
+
+
+@pytest.mark.parametrize("shape,scale,nlev", [((321, 243), 1.2, 8), ((752, 480), 1.2, 8), ((1241, 376), 1.2, 8), ((200, 180), 1.1, 6), ((400, 300), 1.5, 4),
+                                              ((512, 384), 2.0, 3), ((333, 222), 1.33, 5), ((1920, 1080), 1.2, 8), ((97, 131), 1.2, 3), ((640, 512), 1.2, 2),
+                                              ((640, 512), 1.2, 1)])
+def test_other_shapes_and_scale_factors(uvo, oracle, synth, shape, scale, nlev):
+    """Level sizes that leave partial dword columns and row groups, scale factors on both sides of the 12-byte tap window (above ~1.33 the
+    levels gather bytes: per-level launches whatever the form), pyramids of one and two levels."""
+    w, h = shape
+    img = synth.make_frame(5200 + w, w, h, n_shapes=max(40, w * h // 3000))
+    oe = oracle.extractor(500, scale, nlev, 20)
+    kp_o, de_o = oe(img)
+    ex = uvo.ORBextractor(500, scale, nlev, 0, 20, max_width=w, max_height=h)
+    for form in (uvo.UVO_PYR_FORM_AUTO, uvo.UVO_PYR_FORM_TILES_LATENCY, uvo.UVO_PYR_FORM_TILES_THROUGHPUT, uvo.UVO_PYR_FORM_LEVELS):
+        ex.tune(uvo.UVO_TUNE_PYR_FORM, form)
+        kp, de = ex(img)
+        _planes_equal(ex, oe, nlev, "%dx%d scale %.2f form %d" % (w, h, scale, form))
+        assert kp.tobytes() == kp_o.tobytes() and (de == de_o).all()
+    ex.close()
+
+
+def test_batches_of_every_size_in_both_tile_sets(uvo, oracle, synth):
+    """A batch's frames are independent workgroups; the default set of level groups changes with the batch size -- every frame of every
+    batch size gives the oracle's planes in either set."""
+    w, h = 320, 256
+    imgs = synth.make_batch(40, w, h, seed0=5300)
+    oe = oracle.extractor(400, 1.2, 6, 20)
+    ex = uvo.ORBextractor(400, 1.2, 6, 0, 20, max_width=w, max_height=h, max_batch=40)
+    for form in (uvo.UVO_PYR_FORM_AUTO, uvo.UVO_PYR_FORM_TILES_LATENCY, uvo.UVO_PYR_FORM_TILES_THROUGHPUT):
+        ex.tune(uvo.UVO_TUNE_PYR_FORM, form)
+        for n in (1, 3, 9, 33, 40):
+            ex.extract_batch(imgs[:n])
+            for f in sorted({0, n // 2, n - 1}):
+                oe(imgs[f])
+                _planes_equal(ex, oe, 6, "form %d batch %d frame %d" % (form, n, f), frame=f)
+    ex.close()
+
+
+def test_unaligned_rows_and_the_two_lane_pipeline(uvo, oracle, synth):
+    """Image widths that are no multiple of 4 (level 1 cannot read the image in place: the padded copy of level 0 is the source), and the
+    two-lane pipeline (each lane has its own planes)."""
+    for (w, h) in ((637, 509), (333, 301), (636, 500)):
+        img = synth.make_frame(5400 + w, w, h)
+        oe = oracle.extractor(600, 1.2, 7, 20)
+        kp_o, de_o = oe(img)
+        ex = uvo.ORBextractor(600, 1.2, 7, 0, 20, max_width=w, max_height=h)
+        ex.set_pipeline(2)
+        for form in (uvo.UVO_PYR_FORM_TILES_LATENCY, uvo.UVO_PYR_FORM_TILES_THROUGHPUT):
+            ex.tune(uvo.UVO_TUNE_PYR_FORM, form)
+            for _ in range(3):
+                kp, de = ex(img)
+                _planes_equal(ex, oe, 7, "%dx%d" % (w, h))
+                assert kp.tobytes() == kp_o.tobytes() and (de == de_o).all()
+        ex.close()
+
+
 def _device_extract(uvo, ex, torch, buf, off, B, W, H, stride, fstride):
     cap = ex.cap
     kp = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")

@@ -665,3 +665,88 @@ def test_undistort_point_models(oracle):
     dpx = np.stack([a * s * fxh + cxh, b * s * fyh + cyh], 1).astype(np.float32)
     und = oracle.undistort_points(dpx, fxh, fyh, cxh, cyh, kk, True)
     assert np.abs(und - np.stack([a * fxh + cxh, b * fyh + cyh], 1)).max() < 2e-3
+
+
+def _pyr_tiles_emu():
+    lib = os.path.join(ROOT, "tests", "emu", "libpyr_tiles_emu.so")
+    srcs = [os.path.join(ROOT, "tests", "emu", "pyr_tiles_emu.cpp"), os.path.join(ROOT, "u-vip-slam_amd", "csrc", "pyr_tiles.hpp")]
+    if not os.path.exists(lib) or max(os.path.getmtime(p) for p in srcs) > os.path.getmtime(lib):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", lib, srcs[0]])
+    E = ctypes.CDLL(lib)
+    E.emu_pyr_tiles_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    return E
+
+
+def _run_pyr_tiles(E, oe, img, nlevels, groups, ring=4, max_lds=160 * 1024):
+    """groups: [(first level, tx, ty), ...] -- one launch per group; or a (tx, ty) pair: every level in one group."""
+    if not isinstance(groups[0], tuple):
+        groups = [(1, groups[0], groups[1])]
+    dims = [oe.level_dims(l) for l in range(nlevels)]
+    lw = np.array([d[0] for d in dims], np.int32)
+    lh = np.array([d[1] for d in dims], np.int32)
+    pitch = (lw + 32 + 63) // 64 * 64
+    planes = np.full(int((pitch.astype(np.int64) * (lh + 32)).sum()), 0xEE, np.uint8)
+    off = np.zeros(nlevels, np.int64)
+    pitch_out = np.zeros(nlevels, np.int32)
+    stats = np.zeros(3, np.int64)
+    gf, gx, gy = (np.array([g[i] for g in groups], np.int32) for i in range(3))
+    rc = E.emu_pyr_tiles_run(img.ctypes.data, img.strides[0], nlevels, lw.ctypes.data, lh.ctypes.data, ring, len(groups), gf.ctypes.data, gx.ctypes.data, gy.ctypes.data,
+                             max_lds, planes.ctypes.data, off.ctypes.data, pitch_out.ctypes.data, stats.ctypes.data)
+    out = []
+    if rc == 0:
+        for l in range(nlevels):
+            out.append(planes[off[l]:off[l] + int(pitch_out[l]) * (int(lh[l]) + 32)].reshape(int(lh[l]) + 32, int(pitch_out[l]))[:, :int(lw[l]) + 32])
+    return rc, out, stats
+
+
+def test_pyramid_tile_plan_executed_on_the_host_gives_the_oracle_pyramid(oracle, synth):
+    """The fused pyramid launches (k_pyr_tiles, csrc/pyramid.hip) walk plans compiled on the host (csrc/pyr_tiles.hpp): the levels are cut
+    into groups, one launch each; per (tile, level of the group) the region a workgroup computes -- its own cell of a TX x TY partition plus
+    what its cell of the next level reads -- and the LDS tile it keeps for the next level.  tests/emu/pyr_tiles_emu.cpp runs the plans on
+    the host with an independent per-pixel restatement of cv::resize's two 11-bit passes and checks what the kernel relies on: every byte
+    of a level's image and 4-pixel ring is stored by exactly one workgroup, no tap of non-zero weight reads an LDS byte its own workgroup
+    has not written, tap windows and tiles stay inside the LDS allocation, the tiles of consecutive levels do not overlap -- and the planes
+    must equal the oracle's ComputePyramid (src/ORBextractor.cc:963-1004) wherever they are written."""
+    E = _pyr_tiles_emu()
+    one = lambda tx, ty: [(1, tx, ty)]
+    cases = [((640, 512), 1.2, 8, (one(2, 2), one(4, 4), one(8, 8), one(16, 16), one(12, 10), one(3, 7), [(1, 4, 4), (4, 1, 1)], [(1, 8, 8), (3, 4, 4), (5, 2, 2)],
+                                   [(l, 3, 2) for l in range(1, 8)], [(1, 4, 4), (3, 2, 2), (5, 1, 1)])),
+             ((321, 243), 1.2, 8, (one(1, 1), one(5, 4), one(8, 8), [(1, 2, 2), (2, 1, 1)])),
+             ((752, 480), 1.2, 8, (one(4, 4), one(10, 6), [(1, 6, 4), (4, 2, 2)])), ((200, 180), 1.1, 6, (one(1, 1), one(6, 6), [(1, 3, 3), (5, 1, 1)])),
+             ((333, 222), 1.33, 5, (one(2, 3), one(8, 8))), ((1920, 1080), 1.2, 8, (one(8, 4), one(16, 9), [(1, 8, 8), (3, 4, 4), (5, 2, 2)])),
+             ((1241, 376), 1.2, 8, (one(8, 2), one(12, 4))), ((97, 131), 1.2, 3, (one(1, 1), one(4, 4), one(16, 16))), ((4096, 600), 1.2, 4, (one(16, 2),))]
+    for (w, h), scale, nl, plans in cases:
+        img = synth.make_frame(4000 + w, w, h, n_shapes=60)
+        oe = oracle.extractor(500, scale, nl, 20)
+        oe(img)
+        ref = [oe.level_plane(l) for l in range(nl)]
+        for groups in plans:
+            rc, planes, stats = _run_pyr_tiles(E, oe, img, nl, groups)
+            assert rc == 0, ((w, h), scale, groups, rc)
+            for l in range(1, nl):
+                lw, lh = oe.level_dims(l)
+                x1 = (16 + lw + 4 + 3) // 4 * 4
+                np.testing.assert_array_equal(planes[l][12:16 + lh + 4, 12:min(x1, lw + 32)], ref[l][12:16 + lh + 4, 12:min(x1, lw + 32)],
+                                              err_msg="%dx%d scale %.2f groups %s level %d" % (w, h, scale, groups, l))
+                assert (planes[l][:12] == 0xEE).all() and (planes[l][16 + lh + 4:] == 0xEE).all()    # nothing outside the ring is touched
+            if all(g[1:] == (1, 1) for g in groups):
+                assert stats[0] < 1.03 * stats[1], stats      # one tile: nothing is computed twice (row groups of 4 round up)
+    # the benchmark shape: what the halo costs -- deep groups pay for it, shallow groups of large tiles hardly
+    img = synth.make_frame(4001, 640, 512)
+    oe = oracle.extractor(1000, 1.2, 8, 20)
+    oe(img)
+    for groups, worst in ((one(4, 4), 1.6), (one(8, 8), 2.4), ([(1, 4, 4), (3, 2, 2), (5, 1, 1)], 1.15), ([(1, 4, 4), (4, 1, 1)], 1.25)):
+        rc, _, stats = _run_pyr_tiles(E, oe, img, 8, groups, max_lds=160 * 1024)
+        assert rc == 0 and stats[0] < worst * stats[1], (groups, stats, stats[0] / stats[1])
+        print("pyramid tiles", groups, "computed / owned = %.3f" % (stats[0] / stats[1]), "LDS", stats[2])
+    # a scale factor whose taps leave the 12-byte window: refused (the per-level launches gather bytes there)
+    img = synth.make_frame(4002, 512, 384)
+    oe = oracle.extractor(500, 2.0, 3, 20)
+    oe(img)
+    assert _run_pyr_tiles(E, oe, img, 3, (4, 4))[0] == 2
+    # a tile that does not fit the LDS budget: refused
+    img = synth.make_frame(4003, 1920, 1080)
+    oe = oracle.extractor(500, 1.2, 8, 20)
+    oe(img)
+    assert _run_pyr_tiles(E, oe, img, 8, (1, 1), max_lds=64 * 1024)[0] == 3

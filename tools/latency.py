@@ -20,39 +20,67 @@ def main():
     uvo = importlib.import_module("u-vip-slam_amd")
     synth = importlib.import_module("u-vip-slam_amd.synth")
     img = synth.make_frame(1000)
-    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=640, max_height=512, max_batch=1)
+    NB = int(os.environ.get("UVO_LAT_BATCH", "1"))   # frames per device-resident call (the host-buffer loop stays one frame)
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=640, max_height=512, max_batch=NB)
+    # A/B knobs: UVO_LAT_PYR_FORM = 0 auto / 1 per-level launches / 2 latency tiles / 3 throughput tiles; UVO_LAT_PYR_GROUPS = "first:txXty[w],..." forced level groups
+    if os.environ.get("UVO_LAT_PYR_FORM"):
+        ex.tune(uvo.UVO_TUNE_PYR_FORM, int(os.environ["UVO_LAT_PYR_FORM"]))
+    if os.environ.get("UVO_LAT_ZERO_COPY"):
+        ex.tune(uvo.UVO_TUNE_ZERO_COPY_OUT, int(os.environ["UVO_LAT_ZERO_COPY"]))
+    if os.environ.get("UVO_LAT_SPIN"):
+        ex.tune(uvo.UVO_TUNE_SPIN_WAIT, int(os.environ["UVO_LAT_SPIN"]))
+    if os.environ.get("UVO_LAT_OCT_WIDE"):
+        ex.tune(uvo.UVO_TUNE_OCT_WIDE_MAX, int(os.environ["UVO_LAT_OCT_WIDE"]))
+    if os.environ.get("UVO_LAT_FEW"):
+        ex.tune(uvo.UVO_TUNE_FEW_FRAMES, int(os.environ["UVO_LAT_FEW"]))
+    if os.environ.get("UVO_LAT_SIDE_BLUR"):
+        ex.tune(uvo.UVO_TUNE_SIDE_BLUR, int(os.environ["UVO_LAT_SIDE_BLUR"]))
+    if os.environ.get("UVO_LAT_PYR_GROUPS"):
+        for g in os.environ["UVO_LAT_PYR_GROUPS"].split(","):
+            first, grid = g.split(":")
+            wide = (1 << 24 if grid.endswith("w") else 0) | (1 << 25 if grid.endswith("r") else 0)
+            tx, ty = grid.rstrip("wr").split("x")
+            ex.tune(uvo.UVO_TUNE_PYR_TILE_GROUP, wide | int(first) << 16 | int(tx) << 8 | int(ty))
+    trace = bool(os.environ.get("UVO_LAT_TRACE"))   # under rocprofv3 --kernel-trace: the device-resident loop only (tools/latency_trace.py reads the timeline)
     for _ in range(20):
         kp, de = ex(img)
     t = []
-    for _ in range(300):
+    for _ in range(20 if trace else 300):
         t0 = time.perf_counter()
         kp, de = ex(img)
         t.append(time.perf_counter() - t0)
     host = np.array(t) * 1e3
     dev = torch.device("cuda", 0)
-    d_img = torch.from_numpy(img).to(dev)
+    d_img = torch.from_numpy(np.stack([synth.make_frame(1000 + b) for b in range(NB)])).to(dev)
     cap = ex.cap
-    d_kp = torch.zeros((1, cap, 7), dtype=torch.float32, device=dev)
-    d_de = torch.zeros((1, cap, 32), dtype=torch.uint8, device=dev)
-    d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_kp = torch.zeros((NB, cap, 7), dtype=torch.float32, device=dev)
+    d_de = torch.zeros((NB, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(NB, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     for _ in range(20):
-        ex.extract_batch_device(d_img.data_ptr(), 1, 640, 512, d_kp.data_ptr(), d_de.data_ptr(), d_n.data_ptr(), cap)
+        ex.extract_batch_device(d_img.data_ptr(), NB, 640, 512, d_kp.data_ptr(), d_de.data_ptr(), d_n.data_ptr(), cap)
     ex.synchronize()
-    t = []
+    t, tq = [], []
     for _ in range(300):
         t0 = time.perf_counter()
-        ex.extract_batch_device(d_img.data_ptr(), 1, 640, 512, d_kp.data_ptr(), d_de.data_ptr(), d_n.data_ptr(), cap)
+        ex.extract_batch_device(d_img.data_ptr(), NB, 640, 512, d_kp.data_ptr(), d_de.data_ptr(), d_n.data_ptr(), cap)
+        t1 = time.perf_counter()
         ex.synchronize()
         t.append(time.perf_counter() - t0)
+        tq.append(t1 - t0)
     devt = np.array(t) * 1e3
+    enq = np.array(tq) * 1e3      # the host's share: all launches enqueued (the wait for the stream follows)
+    if trace:
+        print(json.dumps({"device_ms_median": round(float(np.median(devt)), 4), "enqueue_ms_median": round(float(np.median(enq)), 4), "host_ms_median": round(float(np.median(host)), 4)}))
+        return
     ex.profile(True)
     for _ in range(50):
-        ex.extract_batch_device(d_img.data_ptr(), 1, 640, 512, d_kp.data_ptr(), d_de.data_ptr(), d_n.data_ptr(), cap)
+        ex.extract_batch_device(d_img.data_ptr(), NB, 640, 512, d_kp.data_ptr(), d_de.data_ptr(), d_n.data_ptr(), cap)
     kt = ex.kernel_times()
     print(json.dumps({"workload": "configs[1]: batch=1, 640x512, 1000 feats, 8 levels, fastTh 20", "keypoints": int(len(kp)),
+                      "pyr_form": os.environ.get("UVO_LAT_PYR_FORM", "0"), "pyr_groups": os.environ.get("UVO_LAT_PYR_GROUPS", ""),
                       "host_ms_median": round(float(np.median(host)), 4), "host_ms_p95": round(float(np.percentile(host, 95)), 4),
-                      "device_ms_median": round(float(np.median(devt)), 4), "device_ms_p95": round(float(np.percentile(devt, 95)), 4),
+                      "device_ms_median": round(float(np.median(devt)), 4), "enqueue_ms_median": round(float(np.median(enq)), 4), "device_ms_p95": round(float(np.percentile(devt, 95)), 4),
                       "kernel_us": {k: round(v[0] / 50 * 1e3, 1) for k, v in sorted(kt.items())}}))
 
 

@@ -13,6 +13,7 @@
 //   flist    : [frame][flist_cap] final (level, x, y, aux) slots in output order
 #pragma once
 #include "strip_plan.hpp"
+#include "pyr_tiles.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -79,14 +80,6 @@ struct Geom {
 // FAST candidates and quad-tree survivors are SoA: xy word = x | y << 16 relative to (minBorder, minBorder),
 // score word = FAST score (cornerScore), 1..254.
 
-// resize coefficient tables, indexed by padded output coordinates (border reflection folded in)
-struct ResizeCol {  // 8 B: left tap column, the two 11-bit weights scaled by 16 (a << 4 <= 32768)
-  uint16_t sx, a0, a1, pad;
-};
-struct ResizeRow {  // 8 B
-  int16_t sy0, sy1, b0, b1;
-};
-
 struct FinalSlot {  // 16 B
   float x, y;       // level coordinates
   int32_t level;    // bit 31 set: caller keypoint, aux = index into in_kp
@@ -116,6 +109,11 @@ void launch_pad_level0(hipStream_t s, const uint8_t* d_img, int w, int h, int64_
                        int64_t pyr_block, const LevelGeom& g0, int batch);
 void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const LevelGeom& src, const LevelGeom& dst, const ResizeCol* d_ctab,
                          const ResizeRow* d_rtab, int fast_ok, int batch, Level0View l0, int ring);
+// a group of consecutive levels in one launch (pyramid.hip: k_pyr_tiles; plan: pyr_tiles.hpp)
+constexpr int kPyrTilesMaxLds = 160 * 1024;
+int prepare_pyr_tiles();
+int launch_pyr_tiles(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const PyrTileLevel* d_plan, const Geom& g, const ResizeCol* d_ctab, const ResizeRow* d_rtab,
+                     Level0View l0, int first, int last, int ntiles, uint32_t lds_bytes, int threads, int rows, int batch);
 void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g, int4 taps,
                    int batch, int sse2_rounding, Level0View l0);
 void launch_fast_score(hipStream_t s, const uint8_t* d_pyr, int64_t pyr_block, const Geom& g, int fast_th, const int32_t* d_tpass, uint32_t* d_cor,
@@ -132,7 +130,7 @@ int fast_flags_per_frame(const Geom& g);
 // Launch shape of the quad-tree kernel, per extractor handle (nothing process-global: handles on several devices and host
 // threads coexist in one process).  wide_max_problems: up to this many (frame, level) problems run as 1024-thread workgroups.
 struct OctLaunchState {
-  int wide_max_problems = 256;
+  int wide_max_problems = 0;  // (with the blur in the same launch the 256-thread form is also the faster one for a single frame: 34 us against 29 + 14)
 };
 bool octree_gauss_applies(const OctLaunchState& st, const Geom& g, int batch);
 void launch_octree_gauss(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, int4 taps, int sse2_rounding,
@@ -164,6 +162,10 @@ void launch_matrix(hipStream_t s, const uint8_t* d_q, int nq, const uint8_t* d_t
 void launch_describe(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, const uint8_t* d_blur, int64_t pyr_block,
                      const FinalSlot* d_flist, const int32_t* d_n_final, const uvo_keypoint* d_in_kp, int in_cap, const float* d_pattern,
                      const uint32_t* d_patch, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch, Level0View l0);
+
+void launch_describe_direct(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, const uint8_t* d_blur, int64_t pyr_block, const uint32_t* d_sel_xy,
+                            const uint32_t* d_sel_sc, const int32_t* d_sel_count, FastAdapt fa, const float* d_pattern, const uint32_t* d_patch,
+                            uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch, Level0View l0);
 
 void launch_clahe(hipStream_t s, const uint8_t* d_src, int w, int h, int64_t stride, int64_t frame_stride, int batch, int tiles_x, int tiles_y,
                   int tile_w, int tile_h, int clip_limit, float lut_scale, uint8_t* d_lut, uint8_t* d_dst, int64_t dst_stride,

@@ -252,19 +252,61 @@ constexpr int DW_TX = 4, DW_TY = 6, DW_PITCH = DW_TX * 16, DW_ROWS = DW_TY * 8, 
                            // four-wavefront workgroup's 49 KB only beside three): +2 % frames/s at 640x512, +-0 at 1920x1080
 #endif
 constexpr int DK_WAVES = UVO_DESC_WAVES;
+// DIRECT (FullDetect, a frame or two): there is no k_assemble launch in front -- the final list of a FullDetect frame is the levels' quad-tree
+// survivors one after the other (src/ORBextractor.cc:915-960), so a wavefront finds its slots' (level, index) from the eight survivor counts
+// itself: one stage less in a chain of latency-bound stages.  (With a batch that fills the chip the slot arithmetic in front of the dependent
+// fetches costs k_describe more than the launch it saves: measured, DESIGN.md.)
+struct DirectSel {
+  const uint32_t* sel_xy;
+  const uint32_t* sel_sc;
+  const int32_t* sel_count;
+  int sel_block;
+  FastAdapt fa;           // the lane's adaptive FAST mode: what k_assemble's workgroup 0 does otherwise
+  int batch;
+};
+template <bool DIRECT>
 __global__ __launch_bounds__(64 * DK_WAVES, UVO_OCC_DESCRIBE) void k_describe(const LevelGeom* __restrict__ lv, int nlevels, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blur, int64_t pyr_block,
                                                   const FinalSlot* __restrict__ flist, int flist_cap, const int32_t* __restrict__ n_final,
                                                   const uvo_keypoint* __restrict__ in_kp, int in_cap, const float* __restrict__ pattern,
                                                   const uint32_t* __restrict__ patch, uvo_keypoint* __restrict__ out_kp,
-                                                  uint8_t* __restrict__ out_desc, int cap, int32_t* __restrict__ n_out, Level0View l0) {
+                                                  uint8_t* __restrict__ out_desc, int cap, int32_t* __restrict__ n_out, Level0View l0, DirectSel ds) {
   // a frame's keypoints stay on one XCD: their 37-row windows overlap heavily (1000 windows cover a level about once), and with
   // round-robin placement every XCD's L2 would fetch the same lines
   const int vb = xcd_contiguous((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
   const int bx = vb % (int)gridDim.x, f = vb / (int)gridDim.x;
   const int lane = threadIdx.x & 63;
   const int slot0 = (bx * DK_WAVES + wave_in_block()) * DK_PER_WAVE;
-  int n = n_final[f];
+  int n;
+  int lcount[kMaxLevels];  // DIRECT: the levels' survivor counts (wave-uniform)
+  if constexpr (DIRECT) {
+    n = 0;
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; ++l) {
+      int c = 0;
+      if (l < nlevels) {
+        c = ds.sel_count[f * nlevels + l];
+        c = c > lv[l].sel_cap ? lv[l].sel_cap : c;
+      }
+      lcount[l] = c, n += c;
+    }
+    if (bx == 0 && f == 0 && (int)threadIdx.x < nlevels) {  // the lane's fall-back statistics and pass thresholds (adapt_fast_mode, for a frame or two)
+      const int l = (int)threadIdx.x;
+      int64_t zc = 0;
+      for (int b = 0; b < ds.batch; ++b) zc += ds.fa.fcount[b * nlevels + l];
+      const int64_t cells = (int64_t)lv[l].n_cells * ds.batch;
+      ds.fa.last[l] = (int32_t)zc;
+      if (ds.fa.adapt && ds.fa.fast_th > 7 && cells > 0) {
+        const int cur_t = ds.fa.tpass[l];
+        if (cur_t > 7 && zc * 100 > cells * 22)
+          ds.fa.tpass[l] = 7;
+        else if (cur_t <= 7 && zc * 100 < cells * 14)
+          ds.fa.tpass[l] = ds.fa.fast_th;
+      }
+    }
+  } else {
+    n = n_final[f];
+  }
   if (bx == 0 && threadIdx.x == 0) n_out[f] = n;
   n = n > flist_cap ? flist_cap : n;
   n = n > cap ? cap : n;
@@ -304,11 +346,36 @@ __global__ __launch_bounds__(64 * DK_WAVES, UVO_OCC_DESCRIBE) void k_describe(co
   // three passes over the group so that the four keypoints' fetches of a pass are in flight together (as one loop over the keypoints
   // the compiler chains them: every scalar load drains the previous keypoint's) ----
   FinalSlot fs[DK_PER_WAVE];
+  if constexpr (DIRECT) {
+    int lvl[DK_PER_WAVE], idx[DK_PER_WAVE];
 #pragma unroll
-  for (int k = 0; k < DK_PER_WAVE; ++k) {
-    live[k] = slot0 + k < n;
-    const int slot = live[k] ? slot0 + k : slot0;  // dead entries repeat the first slot and are never stored
-    fs[k] = flist[(int64_t)f * flist_cap + slot];
+    for (int k = 0; k < DK_PER_WAVE; ++k) {
+      live[k] = slot0 + k < n;
+      lvl[k] = 0, idx[k] = live[k] ? slot0 + k : slot0;  // dead entries repeat the first slot and are never stored
+    }
+#pragma unroll
+    for (int l = 0; l + 1 < kMaxLevels; ++l)
+#pragma unroll
+      for (int k = 0; k < DK_PER_WAVE; ++k)
+        if (lvl[k] == l && idx[k] >= lcount[l]) idx[k] -= lcount[l], lvl[k] = l + 1;
+    uint32_t xy[DK_PER_WAVE], sc[DK_PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < DK_PER_WAVE; ++k) {
+      const int64_t o = (int64_t)f * ds.sel_block + lv[lvl[k]].sel_off + idx[k];
+      xy[k] = ds.sel_xy[o], sc[k] = ds.sel_sc[o];
+    }
+#pragma unroll
+    for (int k = 0; k < DK_PER_WAVE; ++k) {
+      fs[k].x = (float)((int)(xy[k] & 0xffff) + kMinBorder), fs[k].y = (float)((int)(xy[k] >> 16) + kMinBorder);
+      fs[k].level = lvl[k], fs[k].aux = (int32_t)sc[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < DK_PER_WAVE; ++k) {
+      live[k] = slot0 + k < n;
+      const int slot = live[k] ? slot0 + k : slot0;  // dead entries repeat the first slot and are never stored
+      fs[k] = flist[(int64_t)f * flist_cap + slot];
+    }
   }
   int level[DK_PER_WAVE];
   bool is_input[DK_PER_WAVE];
@@ -533,8 +600,18 @@ void launch_describe(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const 
                      const FinalSlot* d_flist, const int32_t* d_n_final, const uvo_keypoint* d_in_kp, int in_cap, const float* d_pattern,
                      const uint32_t* d_patch, uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch, Level0View l0) {
   const int slots = g.flist_cap < cap ? g.flist_cap : cap;
-  hipLaunchKernelGGL(k_describe, dim3((slots + DK_WAVES * DK_PER_WAVE - 1) / (DK_WAVES * DK_PER_WAVE), batch), dim3(64 * DK_WAVES), 0, s, d_lv, g.nlevels, d_pyr, d_blur, pyr_block, d_flist,
-                     g.flist_cap, d_n_final, d_in_kp, in_cap, d_pattern, d_patch, d_out_kp, d_out_desc, cap, d_n_out, l0);
+  hipLaunchKernelGGL(k_describe<false>, dim3((slots + DK_WAVES * DK_PER_WAVE - 1) / (DK_WAVES * DK_PER_WAVE), batch), dim3(64 * DK_WAVES), 0, s, d_lv, g.nlevels, d_pyr, d_blur, pyr_block, d_flist,
+                     g.flist_cap, d_n_final, d_in_kp, in_cap, d_pattern, d_patch, d_out_kp, d_out_desc, cap, d_n_out, l0, DirectSel{});
+}
+
+// FullDetect without k_assemble (a frame or two): k_describe reads the quad-tree survivors itself
+void launch_describe_direct(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, const uint8_t* d_blur, int64_t pyr_block, const uint32_t* d_sel_xy,
+                            const uint32_t* d_sel_sc, const int32_t* d_sel_count, FastAdapt fa, const float* d_pattern, const uint32_t* d_patch,
+                            uvo_keypoint* d_out_kp, uint8_t* d_out_desc, int cap, int32_t* d_n_out, int batch, Level0View l0) {
+  const int slots = g.flist_cap < cap ? g.flist_cap : cap;
+  const DirectSel ds{d_sel_xy, d_sel_sc, d_sel_count, g.sel_block, fa, batch};
+  hipLaunchKernelGGL(k_describe<true>, dim3((slots + DK_WAVES * DK_PER_WAVE - 1) / (DK_WAVES * DK_PER_WAVE), batch), dim3(64 * DK_WAVES), 0, s, d_lv, g.nlevels, d_pyr, d_blur, pyr_block,
+                     (const FinalSlot*)nullptr, g.flist_cap, (const int32_t*)nullptr, (const uvo_keypoint*)nullptr, 0, d_pattern, d_patch, d_out_kp, d_out_desc, cap, d_n_out, l0, ds);
 }
 
 }  // namespace uvo

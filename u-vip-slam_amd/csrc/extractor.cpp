@@ -3,6 +3,7 @@
 // No CPU fallback: every entry point needs a usable HIP device.
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -47,9 +48,14 @@ using namespace uvo;
 // lanes, so the latency-bound stages of one batch (quad-tree, sparse NMS, small pyramid levels) overlap with the
 // throughput stages of the next.
 constexpr int kMaxLanes = 4;
+constexpr int kFewFrames = 2;  // batches up to this size are the latency path (the FAST kernels cut their segments short for them: fast_rows_per_seg)
 
 struct Lane {
   hipStream_t stream = nullptr;
+  // Few frames cannot fill the chip and every stage is a chain of dependent phases: the blur, which reads nothing but the pyramid, runs in a
+  // side stream beside the FAST kernels and the quad-tree (fork behind the pyramid, join in front of k_describe)
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_cand_xy = nullptr, *d_cand_sc = nullptr, *d_cand_lo = nullptr, *d_pstate = nullptr, *d_sel_xy = nullptr, *d_sel_sc = nullptr;
   int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_n_final = nullptr, *d_cor_n = nullptr, *d_cursor = nullptr;
@@ -121,8 +127,25 @@ struct uvo_extractor {
   int clahe_w = 0, clahe_h = 0;
   int resize_fast[kMaxLevels] = {0};  // per level: the 12-byte-window path of k_resize_level applies
   ResizeRow* d_rtab = nullptr;
+  // the fused pyramid launches (pyramid.hip: k_pyr_tiles; plans: pyr_tiles.hpp).  pyr_form: UVO_TUNE_PYR_FORM.  Two sets of level groups per
+  // geometry -- [0] the latency shape (few frames: many small tiles, deep groups), [1] the throughput shape (shallow groups of large tiles) --
+  // or one forced set (UVO_TUNE_PYR_TILE_GROUP); an empty set = the per-level launches
+  struct TileGroup {
+    int first = 0, last = 0, tx = 0, ty = 0, threads = 256, rows = 4;  // rows: output rows per work item (1: only with 1024 threads)
+    uint32_t lds = 0;
+    PyrTileLevel* d_plan = nullptr;
+  };
+  std::vector<TileGroup> tile_groups[2];
+  std::vector<uint32_t> tile_spec;  // forced groups: first << 16 | tx << 8 | ty | (1024 threads) << 24 | (1024 threads, single-row items) << 25, ascending first levels
+  int pyr_form = UVO_PYR_FORM_AUTO;
+  std::vector<ResizeCol> ctab_host;  // the resize tables of the current geometry (the plans are compiled from them)
+  std::vector<ResizeRow> rtab_host;
   int pyr_ring = 4;          // UVO_TUNE_PYR_RING: the chain's resize launches write the ROI + this many pixels around it (0: the whole 16-pixel pad)
   int level0_inplace = 1;    // UVO_TUNE_LEVEL0_INPLACE: read level 0 from the caller's image instead of copying it into a padded plane (when it can be)
+  int zero_copy_out = 1;     // UVO_TUNE_ZERO_COPY_OUT: host-buffer calls of up to 16 frames have k_describe write into page-locked host memory
+  int spin_wait = 1;         // UVO_TUNE_SPIN_WAIT: those calls, and uvo_extractor_synchronize behind a small batch, poll the stream instead of sleeping
+  int few_frames_shape = 1;  // UVO_TUNE_FEW_FRAMES: batches of up to kFewFrames frames take the short launch chain (single FAST pass, FullDetect without k_assemble)
+  int side_blur = 1;         // UVO_TUNE_SIDE_BLUR: small batches run the blur in a side stream beside FAST and the quad-tree
   int fuse_blur_tree = 1;    // UVO_TUNE_FUSE_BLUR_TREE: quad-tree and blur as one launch when the batch takes the 256-thread quad-tree form
   float* d_pattern = nullptr;   // 256 point pairs (x0, y0, x1, y1) of the rBRIEF pattern as floats
   uint32_t* d_patch = nullptr;  // 256 byte masks: which of the 4 pixels of an orientation-patch dword lie inside the circle
@@ -148,6 +171,22 @@ namespace uvo {
 
 static int sync_all_lanes(uvo_extractor* h);
 static int alloc_lane(uvo_extractor* h, int li);
+
+// Waits for a stream.  spin: the latency path -- hipStreamSynchronize gives up its busy wait after a few microseconds and sleeps on an
+// interrupt, whose wake-up costs more than a whole stage of a single frame's chain; polling the stream's state keeps the host on the
+// spot for the ~100 us a frame takes (bounded: after kSpinWaitUs the blocking wait takes over).
+constexpr int kSpinWaitUs = 400;
+static hipError_t wait_stream(hipStream_t s, bool spin) {
+  if (spin) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(s);
+      if (e != hipErrorNotReady) return e;
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > kSpinWaitUs) break;
+    }
+  }
+  return hipStreamSynchronize(s);
+}
 
 // (Re)starts lane li's per-level FAST mode.  Adaptive and two-pass start threshold-adaptive (stream at fastTh, sparse literal-7 pass);
 // single-pass streams at min(fastTh, 7) and votes.  With fastTh <= 7 the second call of src/ORBextractor.cc:797 can find nothing the
@@ -286,59 +325,10 @@ static int build_geom(const uvo_extractor* h, int width, int height, Geom& g, st
   return UVO_OK;
 }
 
-// cv::resize INTER_LINEAR coefficient tables exactly as resizeGeneric_ builds them:
-// fx = (float)((dx+0.5)*scale_x - 0.5), sx = floor(fx), weights saturate_cast<short>(w * 2048); then re-indexed by
-// padded output coordinate with the REFLECT_101 border folded in (copyMakeBorder of the level, src/ORBextractor.cc:988).
-static inline int reflect101_host(int p, int len) {
-  if (len == 1) return 0;
-  while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
-  return p;
-}
-// fast_ok[l]: every output dword of level l finds its eight taps inside one 12-byte aligned source window (true for scale
-// factors up to ~1.33); otherwise the level takes the byte-gather path.
+// cv::resize coefficient tables of every level >= 1 (pyr_tiles.hpp: pyr_build_level_tables), concatenated at the offsets build_geom assigned
 static void build_resize_tables(const Geom& g, std::vector<ResizeCol>& ctab, std::vector<ResizeRow>& rtab, int* fast_ok) {
   ctab.clear(), rtab.clear();
-  for (int l = 1; l < g.nlevels; ++l) {
-    const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h, dw = g.lv[l].w, dh = g.lv[l].h;
-    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
-    std::vector<ResizeCol> col(dw);
-    std::vector<ResizeRow> row(dh);
-    for (int dx = 0; dx < dw; ++dx) {
-      float fx = (float)((dx + 0.5) * scale_x - 0.5);
-      int sx = cv_floor_host(fx);
-      fx -= sx;
-      if (sx < 0) fx = 0, sx = 0;
-      if (sx >= sw - 1) fx = 0, sx = sw - 1;
-      col[dx] = ResizeCol{(uint16_t)sx, (uint16_t)(cv_round_host((1.f - fx) * 2048.f) << 4), (uint16_t)(cv_round_host(fx * 2048.f) << 4), 0};
-    }
-    for (int dy = 0; dy < dh; ++dy) {
-      float fy = (float)((dy + 0.5) * scale_y - 0.5);
-      int sy = cv_floor_host(fy);
-      fy -= sy;
-      const int sy0 = std::min(std::max(sy, 0), sh - 1), sy1 = std::min(std::max(sy + 1, 0), sh - 1);
-      row[dy] = ResizeRow{(int16_t)sy0, (int16_t)sy1, (int16_t)cv_round_host((1.f - fy) * 2048.f), (int16_t)cv_round_host(fy * 2048.f)};
-    }
-    fast_ok[l] = 1;
-    for (int px = 0; px < g.lv[l].pitch; px += 4) {
-      ResizeCol e[4];
-      int lo = 1 << 30;
-      for (int i = 0; i < 4; ++i) {
-        e[i] = col[reflect101_host(px + i - kPad, dw)];  // columns in the pitch slack map to something valid too
-        lo = std::min(lo, (int)e[i].sx);
-      }
-      // per dword: window base (multiple of 4) and the v_perm selector = offsets of the four left taps inside the window
-      const int base = lo & ~3;
-      uint32_t sel = 0;
-      for (int i = 0; i < 4; ++i) {
-        const int o = (int)e[i].sx - base;
-        if (o > 7) fast_ok[l] = 0;
-        sel |= (uint32_t)(o & 0xff) << (8 * i);
-      }
-      e[0].pad = (uint16_t)base, e[1].pad = (uint16_t)(sel & 0xffff), e[2].pad = (uint16_t)(sel >> 16), e[3].pad = 0;
-      for (int i = 0; i < 4; ++i) ctab.push_back(e[i]);
-    }
-    for (int py = 0; py < ((g.lv[l].ph + 3) & ~3); ++py) rtab.push_back(row[reflect101_host(std::min(py, g.lv[l].ph - 1) - kPad, dh)]);  // padded to groups of 4
-  }
+  for (int l = 1; l < g.nlevels; ++l) pyr_build_level_tables(g.lv[l - 1].w, g.lv[l - 1].h, g.lv[l].w, g.lv[l].h, g.lv[l].pitch, ctab, rtab, &fast_ok[l]);
 }
 
 template <class T>
@@ -350,6 +340,82 @@ static int dev_alloc(T** p, size_t n) {
     return e == hipErrorOutOfMemory ? UVO_E_NOMEM : UVO_E_HIP;
   }
   return UVO_OK;
+}
+
+static void free_tile_groups(uvo_extractor* h) {
+  for (auto& set : h->tile_groups) {
+    for (auto& G : set)
+      if (G.d_plan) (void)hipFree(G.d_plan);
+    set.clear();
+  }
+}
+
+// Compiles the plans of one set of level groups ({first level, tx, ty, threads} each, ascending) for geometry g.  A set that cannot be
+// built (a level outside the 12-byte tap window, a tile larger than the LDS) stays empty: the batch then takes the per-level launches.
+static int build_tile_set(uvo_extractor* h, const Geom& g, const std::vector<uint32_t>& spec, std::vector<uvo_extractor::TileGroup>& out) {
+  out.clear();
+  if (spec.empty() || g.nlevels < 2) return UVO_OK;
+  PyrTileDims dims[kMaxLevels];
+  const ResizeCol* cp[kMaxLevels] = {nullptr};
+  const ResizeRow* rp[kMaxLevels] = {nullptr};
+  for (int l = 0; l < g.nlevels; ++l) {
+    dims[l] = PyrTileDims{g.lv[l].w, g.lv[l].h, g.lv[l].pitch};
+    if (l > 0) {
+      if (!h->resize_fast[l]) return UVO_OK;
+      cp[l] = h->ctab_host.data() + g.lv[l].xtab_off, rp[l] = h->rtab_host.data() + g.lv[l].ytab_off;
+    }
+  }
+  std::vector<uvo_extractor::TileGroup> set;
+  for (size_t k = 0; k < spec.size(); ++k) {
+    uvo_extractor::TileGroup G;
+    G.first = (int)((spec[k] >> 16) & 0xff), G.tx = (int)((spec[k] >> 8) & 0xff), G.ty = (int)(spec[k] & 0xff), G.threads = (spec[k] >> 24) & 3 ? 1024 : 256, G.rows = (spec[k] >> 25) & 1 ? 1 : 4;
+    G.last = k + 1 < spec.size() ? (int)((spec[k + 1] >> 16) & 0xff) - 1 : g.nlevels - 1;
+    if (G.first >= g.nlevels) break;  // (a spec written for more levels than this handle has)
+    G.last = std::min(G.last, g.nlevels - 1);
+    PyrTilePlan P;
+    if (G.first < 1 || G.last < G.first || (k == 0 && G.first != 1) || !pyr_tile_plan_build(dims, g.nlevels, G.first, G.last, cp, rp, 4, G.tx, G.ty, kPyrTilesMaxLds, P)) {
+      for (auto& X : set)
+        if (X.d_plan) (void)hipFree(X.d_plan);
+      return UVO_OK;
+    }
+    G.lds = P.lds_bytes;
+    int rc = dev_alloc(&G.d_plan, P.lv.size());
+    if (rc == UVO_OK && hipMemcpy(G.d_plan, P.lv.data(), P.lv.size() * sizeof(PyrTileLevel), hipMemcpyHostToDevice) != hipSuccess) rc = fail(UVO_E_HIP, "plan upload failed");
+    if (rc != UVO_OK) {
+      if (G.d_plan) (void)hipFree(G.d_plan);
+      for (auto& X : set)
+        if (X.d_plan) (void)hipFree(X.d_plan);
+      return rc;
+    }
+    set.push_back(G);
+  }
+  out.swap(set);
+  return UVO_OK;
+}
+
+// number of tiles along an axis of `len` pixels for tiles of about `target` pixels
+static inline uint32_t tiles_for(int len, int target) { return (uint32_t)std::min(255, std::max(1, (len + target / 2) / target)); }
+
+// The two default sets of a geometry.  Latency (a handful of frames cannot fill the chip: as many workgroups as CUs, ONE launch of 1024-thread
+// workgroups with single-row work items -- the halo of a deep group is paid in redundant pixels, which idle CUs have to spare: measured
+// against two and three launches and against 256-thread workgroups, profiles/r05_latency_ab.txt); throughput (shallow groups of large tiles: 4 % redundant
+// pixels at 640 x 512; the small levels as one 1024-thread workgroup per frame -- no halo at all).  All called with every lane idle.
+static int build_tile_groups(uvo_extractor* h, const Geom& g) {
+  free_tile_groups(h);
+  if (!h->tile_spec.empty()) {
+    int rc = build_tile_set(h, g, h->tile_spec, h->tile_groups[0]);
+    if (rc) return rc;
+    return build_tile_set(h, g, h->tile_spec, h->tile_groups[1]);
+  }
+  const int n = g.nlevels;
+  std::vector<uint32_t> lat, thr;
+  lat.push_back(1u << 25 | 1u << 16 | tiles_for(g.lv[1].w, 34) << 8 | tiles_for(g.lv[1].h, 27));  // one launch; 16 x 16 tiles at 640 x 512, single-row items
+  thr.push_back(1u << 16 | tiles_for(g.lv[1].w, 136) << 8 | tiles_for(g.lv[1].h, 108));
+  if (n > 3) thr.push_back(3u << 16 | tiles_for(g.lv[3].w, 186) << 8 | tiles_for(g.lv[3].h, 148));
+  if (n > 5) thr.push_back(1u << 24 | 5u << 16 | tiles_for(g.lv[5].w, 264) << 8 | tiles_for(g.lv[5].h, 212));
+  int rc = build_tile_set(h, g, lat, h->tile_groups[0]);
+  if (rc) return rc;
+  return build_tile_set(h, g, thr, h->tile_groups[1]);
 }
 
 static int set_geometry(uvo_extractor* h, int width, int height) {
@@ -385,6 +451,11 @@ static int set_geometry(uvo_extractor* h, int width, int height) {
   if (!ctab.empty()) {
     UVO_HIP_CHECK(hipMemcpy(h->d_ctab, ctab.data(), ctab.size() * sizeof(ResizeCol), hipMemcpyHostToDevice));
     UVO_HIP_CHECK(hipMemcpy(h->d_rtab, rtab.data(), rtab.size() * sizeof(ResizeRow), hipMemcpyHostToDevice));
+  }
+  h->ctab_host.swap(ctab), h->rtab_host.swap(rtab);
+  {
+    int rct = build_tile_groups(h, g);
+    if (rct) return rct;
   }
   h->geom = g;
   h->cells = cells;
@@ -446,30 +517,64 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   L.l0_src = inplace ? d_imgs : nullptr, L.l0_stride = stride, L.l0_frame_stride = frame_stride;
   const Level0View no_l0{nullptr, 0, 0, 0};
   {
-    // ComputePyramid (src/ORBextractor.cc:963-1004): one launch per level
+    // ComputePyramid (src/ORBextractor.cc:963-1004): a launch per group of levels (k_pyr_tiles), or one per level
     if (!inplace) {
       ProfScope p(h, "k_pad_level0");
       launch_pad_level0(s, d_imgs, width, height, stride, frame_stride, L.d_pyr, g.pyr_block, g.lv[0], batch);
     }
-    for (int l = 1; l < g.nlevels; ++l) {
-      ProfScope p(h, "k_resize_level");
-      launch_resize_level(s, L.d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_ctab + g.lv[l].xtab_off, h->d_rtab + g.lv[l].ytab_off, h->resize_fast[l],
-                          batch, l == 1 ? l0 : no_l0, h->pyr_ring);
+    const std::vector<uvo_extractor::TileGroup>* tiles = nullptr;
+    if (h->pyr_form != UVO_PYR_FORM_LEVELS && h->pyr_ring == 4) {
+      const int set = h->pyr_form == UVO_PYR_FORM_TILES_LATENCY ? 0 : (h->pyr_form == UVO_PYR_FORM_TILES_THROUGHPUT ? 1 : (batch <= 8 ? 0 : 1));
+      if (!h->tile_groups[set].empty()) tiles = &h->tile_groups[set];
+    }
+    if (tiles) {
+      for (const auto& G : *tiles) {
+        ProfScope p(h, "k_pyr_tiles");
+        launch_pyr_tiles(s, L.d_pyr, g.pyr_block, G.d_plan, g, h->d_ctab, h->d_rtab, l0, G.first, G.last, G.tx * G.ty, G.lds, G.threads, G.rows, batch);
+        if (getenv("UVO_DEBUG_PYR")) {
+          hipError_t e1 = hipGetLastError();
+          hipError_t e2 = hipStreamSynchronize(s);
+          fprintf(stderr, "[pyr] group %d..%d tiles %dx%d threads %d lds %u: launch %d sync %d\n", G.first, G.last, G.tx, G.ty, G.threads, G.lds, (int)e1, (int)e2);
+        }
+      }
+    } else {
+      for (int l = 1; l < g.nlevels; ++l) {
+        ProfScope p(h, "k_resize_level");
+        launch_resize_level(s, L.d_pyr, g.pyr_block, g.lv[l - 1], g.lv[l], h->d_ctab + g.lv[l].xtab_off, h->d_rtab + g.lv[l].ytab_off, h->resize_fast[l],
+                            batch, l == 1 ? l0 : no_l0, h->pyr_ring);
+      }
     }
   }
+  const bool fused_tree = h->fuse_blur_tree && octree_gauss_applies(h->oct, g, batch);
+  // (the side stream only where the quad-tree takes its 1024-thread form: a batch that fills the chip has nothing to gain from it)
+  const bool side_blur = !fused_tree && h->side_blur && batch * g.nlevels <= h->oct.wide_max_problems;
+  if (side_blur) UVO_HIP_CHECK(hipEventRecord(L.ev_fork, s));  // (the side stream is fed behind the FAST launches: the main chain first)
+  // A frame or two (the per-frame latency path, src/Tracking.cc:946): every stage is a chain of dependent phases on a nearly empty chip,
+  // so the number of stages is what counts -- a FullDetect call has no k_assemble launch (k_describe finds its slots itself).  (One FAST
+  // pass at 7 with the vote in the quad-tree instead of the sparse second launch: the pass takes 7.7 us longer, the launch it saves 8.)
+  const bool few = batch <= kFewFrames && h->few_frames_shape;
+  const int32_t* tpass = L.d_tpass;
   {  // the per-cell threshold vote + candidate emit run inside k_octree
     ProfScope p(h, "k_fast_score");
-    launch_fast_score(s, L.d_pyr, g.pyr_block, g, h->cfg.fast_th, L.d_tpass, L.d_cor, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, L.d_cand_lo, g.cand_block,
+    launch_fast_score(s, L.d_pyr, g.pyr_block, g, h->cfg.fast_th, tpass, L.d_cor, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, L.d_cand_lo, g.cand_block,
                       L.d_cursor, batch, l0);
   }
   if (h->cfg.fast_th > 7 && h->fast_mode != UVO_FAST_MODE_SINGLE_PASS) {
     // second call of src/ORBextractor.cc:797 for the cells of threshold-adaptive levels that the pass at fastTh left empty (nearly all
     // wavefronts find nothing to do on textured frames).  With the mode pinned to one pass no level can be adaptive: not launched.
     ProfScope p(h, "k_fast_cells");
-    launch_fast_cells(s, L.d_pyr, g.pyr_block, g, h->d_cells, h->d_cell_flag, L.d_tpass, L.d_cell_hi, L.d_cell_list, L.d_fstat + kMaxLevels, L.d_cand_xy,
+    launch_fast_cells(s, L.d_pyr, g.pyr_block, g, h->d_cells, h->d_cell_flag, tpass, L.d_cell_hi, L.d_cell_list, L.d_fstat + kMaxLevels, L.d_cand_xy,
                       L.d_cand_sc, g.cand_block, L.d_cursor, batch, l0);
   }
-  if (h->fuse_blur_tree && octree_gauss_applies(h->oct, g, batch)) {
+  if (side_blur) {
+    UVO_HIP_CHECK(hipStreamWaitEvent(L.aux, L.ev_fork, 0));
+    {
+      Profiler::Scope p(&L.prof, "k_gauss7", L.aux);
+      launch_gauss7(L.aux, L.d_pyr, L.d_blur, g.pyr_block, h->d_lv, g, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), batch, h->blur_rounding, l0);
+    }
+    UVO_HIP_CHECK(hipEventRecord(L.ev_join, L.aux));
+  }
+  if (fused_tree) {
     // the quad-tree (a chain of dependent phases per (frame, level)) and the blur (a streaming kernel) read nothing of each other:
     // one grid, the quad-tree problems first, and the blur fills the issue slots they leave idle
     ProfScope p(h, "k_octree_gauss");
@@ -477,7 +582,7 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
                         L.d_fcount, L.d_fstat + kMaxLevels, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count, L.d_pstate, L.d_sel_xy, L.d_sel_sc, L.d_sel_count,
                         batch, l0);
   } else {
-    {
+    if (!side_blur) {
       ProfScope p(h, "k_gauss7");
       launch_gauss7(s, L.d_pyr, L.d_blur, g.pyr_block, h->d_lv, g, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), batch, h->blur_rounding, l0);
     }
@@ -488,16 +593,22 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
       if (rc) return rc;
     }
   }
-  {
+  const bool direct = few && full_detect && !(d_in_kp && d_n_in);
+  const FastAdapt fa{L.d_fcount, L.d_tpass, L.d_fstat, h->fast_mode == UVO_FAST_MODE_ADAPTIVE ? 1 : 0, h->cfg.fast_th};
+  if (!direct) {
     ProfScope p(h, "k_assemble");
-    const FastAdapt fa{L.d_fcount, L.d_tpass, L.d_fstat, h->fast_mode == UVO_FAST_MODE_ADAPTIVE ? 1 : 0, h->cfg.fast_th};
     launch_assemble(s, h->d_lv, g, fa, L.d_sel_xy, L.d_sel_sc, L.d_sel_count, d_in_kp, d_n_in, h->cfg.max_input_keypoints, d_grid2d, grid_rows, grid_cols,
                     min_px_dist, full_detect, d_nfn, L.d_flist, L.d_n_final, batch);
   }
+  if (side_blur) UVO_HIP_CHECK(hipStreamWaitEvent(s, L.ev_join, 0));  // the descriptors read the blurred planes
   {
     ProfScope p(h, "k_describe");
-    launch_describe(s, h->d_lv, g, L.d_pyr, L.d_blur, g.pyr_block, L.d_flist, L.d_n_final, d_in_kp, h->cfg.max_input_keypoints, h->d_pattern,
-                    h->d_patch, d_out_kp, d_out_desc, cap, d_n_out, batch, l0);
+    if (direct)
+      launch_describe_direct(s, h->d_lv, g, L.d_pyr, L.d_blur, g.pyr_block, L.d_sel_xy, L.d_sel_sc, L.d_sel_count, fa, h->d_pattern, h->d_patch, d_out_kp,
+                             d_out_desc, cap, d_n_out, batch, l0);
+    else
+      launch_describe(s, h->d_lv, g, L.d_pyr, L.d_blur, g.pyr_block, L.d_flist, L.d_n_final, d_in_kp, h->cfg.max_input_keypoints, h->d_pattern,
+                      h->d_patch, d_out_kp, d_out_desc, cap, d_n_out, batch, l0);
   }
   UVO_HIP_CHECK(hipGetLastError());
   UVO_HIP_CHECK(hipEventRecord(done, s));
@@ -513,6 +624,9 @@ static int alloc_lane(uvo_extractor* h, int li) {
   if (L.stream) return UVO_OK;
   const size_t B = (size_t)h->cfg.max_batch;
   hipError_t e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming);
   if (e != hipSuccess) {
     hip_err_set(e, "hipStreamCreate");
     return UVO_E_HIP;
@@ -625,6 +739,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
     h->cap_cor = ce + ce / 8, h->cap_cor_n = cn + cn / 8 + 64;
     h->cap_flags = (size_t)B * ((size_t)fast_flags_per_frame(g) + fast_flags_per_frame(g) / 8 + 64);
   }
+  A(prepare_pyr_tiles());
   A(alloc_lane(h, 0));
   A(dev_alloc(&h->d_lv, (size_t)kMaxLevels));
   A(dev_alloc(&h->d_cells, (size_t)h->cap_cells));
@@ -685,6 +800,9 @@ void uvo_extractor_destroy(uvo_extractor* h) {
     if (L.a_uploaded) (void)hipEventDestroy(L.a_uploaded);
     for (hipEvent_t& e : L.done)
       if (e) (void)hipEventDestroy(e);
+    if (L.aux) (void)hipStreamSynchronize(L.aux), (void)hipStreamDestroy(L.aux);
+    if (L.ev_fork) (void)hipEventDestroy(L.ev_fork);
+    if (L.ev_join) (void)hipEventDestroy(L.ev_join);
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
   void* ptrs[] = {h->d_clahe_lut, h->d_clahe_out, h->d_lv, h->d_cells, h->d_cell_flag, h->d_ctab, h->d_rtab, h->d_pattern, h->d_patch, h->d_imgs, h->d_out_kp,
@@ -692,6 +810,7 @@ void uvo_extractor_destroy(uvo_extractor* h) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->h_pin) (void)hipHostFree(h->h_pin);
+  uvo::free_tile_groups(h);
   delete h;
 }
 
@@ -801,6 +920,11 @@ int uvo_extractor_max_keypoints(const uvo_extractor* h) {
 int uvo_extractor_synchronize(uvo_extractor* h) {
   if (!h) return fail(UVO_E_BADARG, "null handle");
   UVO_HIP_CHECK(hipSetDevice(h->device));
+  if (h->spin_wait && h->last_batch > 0 && h->last_batch <= 16) {  // (behind a small batch the wait is short and its wake-up latency counts)
+    for (int i = 0; i < kMaxLanes; ++i)
+      if (h->lane[i].stream) UVO_HIP_CHECK(wait_stream(h->lane[i].stream, true));
+    return UVO_OK;
+  }
   return sync_all_lanes(h);
 }
 
@@ -822,12 +946,41 @@ int uvo_extractor_tune(uvo_extractor* h, int knob, int value) {
         if (h->lane[i].stream && (rc = set_lane_fast_mode(h, i)) != UVO_OK) return rc;
       return UVO_OK;
     }
+    case UVO_TUNE_PYR_FORM:
+      if (value < UVO_PYR_FORM_AUTO || value > UVO_PYR_FORM_TILES_THROUGHPUT) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_FORM takes UVO_PYR_FORM_AUTO / _LEVELS / _TILES_LATENCY / _TILES_THROUGHPUT");
+      h->pyr_form = value;
+      return UVO_OK;
+    case UVO_TUNE_PYR_TILE_GROUP: {
+      // value = first level << 16 | tx << 8 | ty (| 1 << 24: 1024-thread workgroups, | 1 << 25: 1024 threads and single-row work items); first level 1
+      // starts a new list, 0 returns to the defaults
+      const int first = (value >> 16) & 0xff, tx = (value >> 8) & 0xff, ty = value & 0xff;
+      if (value != 0 && (first < 1 || first >= kMaxLevels || tx < 1 || ty < 1 || (first > 1 && (h->tile_spec.empty() || first <= (int)((h->tile_spec.back() >> 16) & 0xff)))))
+        return fail(UVO_E_BADARG, "UVO_TUNE_PYR_TILE_GROUP takes first << 16 | tx << 8 | ty with ascending first levels starting at 1, or 0");
+      UVO_HIP_CHECK(hipSetDevice(h->device));
+      int rc = sync_all_lanes(h);
+      if (rc) return rc;
+      if (value == 0 || first == 1) h->tile_spec.clear();
+      if (value != 0) h->tile_spec.push_back((uint32_t)value);
+      return h->have_geom ? build_tile_groups(h, h->geom) : UVO_OK;
+    }
     case UVO_TUNE_PYR_RING:
       if (value != 0 && value != 4 && value != 8 && value != 12) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_RING takes 0, 4, 8 or 12");
       h->pyr_ring = value;
       return UVO_OK;
     case UVO_TUNE_LEVEL0_INPLACE:
       h->level0_inplace = value != 0;
+      return UVO_OK;
+    case UVO_TUNE_ZERO_COPY_OUT:
+      h->zero_copy_out = value != 0;
+      return UVO_OK;
+    case UVO_TUNE_SPIN_WAIT:
+      h->spin_wait = value != 0;
+      return UVO_OK;
+    case UVO_TUNE_FEW_FRAMES:
+      h->few_frames_shape = value != 0;
+      return UVO_OK;
+    case UVO_TUNE_SIDE_BLUR:
+      h->side_blur = value != 0;
       return UVO_OK;
     case UVO_TUNE_FUSE_BLUR_TREE:
       h->fuse_blur_tree = value != 0;
@@ -1004,21 +1157,30 @@ static int extract_batch_impl(uvo_extractor* h, int batch, const uint8_t* imgs, 
   }
   if (topup && build_grid && have_in)
     launch_occupancy_grid(s, h->d_in_kp, h->d_n_in, in_cap, min_px_dist, grid_rows, grid_cols, h->d_grid, batch);
+  // Small batches: k_describe writes the counts, keypoints and descriptors straight into the page-locked bounce region (posted writes over the
+  // link: no device-to-host copy -- three DMA start-ups of ~8 us each -- stands between the last kernel and the host)
+  uint8_t* pin_dev = nullptr;
+  if (bounce && h->zero_copy_out && hipHostGetDevicePointer((void**)&pin_dev, h->h_pin, 0) != hipSuccess) pin_dev = nullptr;
+  uvo_keypoint* const o_kp = pin_dev ? (uvo_keypoint*)(pin_dev + off_kp) : h->d_out_kp;
+  uint8_t* const o_desc = pin_dev ? pin_dev + off_kp + (size_t)batch * dcap * sizeof(uvo_keypoint) : h->d_out_desc;
+  int32_t* const o_n = pin_dev ? (int32_t*)pin_dev : h->d_n_out;
   int rc = run_batch_device(h, li, batch, d_frames, width, height, width, (ptrdiff_t)width * height, describe_in ? h->d_in_kp : nullptr,
                             describe_in ? h->d_n_in : nullptr, topup ? h->d_grid : nullptr, grid_rows, grid_cols, min_px_dist, full_detect,
-                            topup ? h->d_nfn : nullptr, h->d_out_kp, h->d_out_desc, dcap, h->d_n_out);
+                            topup ? h->d_nfn : nullptr, o_kp, o_desc, dcap, o_n);
   if (rc) return rc;
   if (bounce) {
-    // Small batches: the counts, the grid and every frame's whole result slice (dcap records: a frame rarely fills less than 90 % of it)
-    // come back in one go -- one synchronisation per call instead of one for the counts and a second for the records they size.
+    // The counts, the grid and every frame's whole result slice (dcap records: a frame rarely fills less than 90 % of it) come back in one
+    // go -- one synchronisation per call instead of one for the counts and a second for the records they size.
     // The stream is in order: the keypoint uploads above were consumed before the outputs land in the same pinned region.
-    UVO_HIP_CHECK(hipMemcpyAsync(pin_i, h->d_n_out, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
-    if (topup && grid2d) UVO_HIP_CHECK(hipMemcpyAsync(h->h_pin + off_grid, h->d_grid, gb, hipMemcpyDeviceToHost, s));
     uint8_t* const pkp = h->h_pin + off_kp;
     uint8_t* const pde = pkp + (size_t)batch * dcap * sizeof(uvo_keypoint);
-    UVO_HIP_CHECK(hipMemcpyAsync(pkp, h->d_out_kp, (size_t)batch * dcap * sizeof(uvo_keypoint), hipMemcpyDeviceToHost, s));
-    UVO_HIP_CHECK(hipMemcpyAsync(pde, h->d_out_desc, (size_t)batch * dcap * 32, hipMemcpyDeviceToHost, s));
-    UVO_HIP_CHECK(hipStreamSynchronize(s));
+    if (topup && grid2d) UVO_HIP_CHECK(hipMemcpyAsync(h->h_pin + off_grid, h->d_grid, gb, hipMemcpyDeviceToHost, s));
+    if (!pin_dev) {
+      UVO_HIP_CHECK(hipMemcpyAsync(pin_i, h->d_n_out, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+      UVO_HIP_CHECK(hipMemcpyAsync(pkp, h->d_out_kp, (size_t)batch * dcap * sizeof(uvo_keypoint), hipMemcpyDeviceToHost, s));
+      UVO_HIP_CHECK(hipMemcpyAsync(pde, h->d_out_desc, (size_t)batch * dcap * 32, hipMemcpyDeviceToHost, s));
+    }
+    UVO_HIP_CHECK(wait_stream(s, h->spin_wait != 0));
     std::memcpy(n_out, pin_i, sizeof(int32_t) * batch);
     if (topup && grid2d) std::memcpy(grid2d, h->h_pin + off_grid, gb);
     int status = UVO_OK;
