@@ -406,13 +406,15 @@ def main():
     ex.set_pipeline(DEPTH)
     ex.tune(uvo.UVO_TUNE_FAST_MODE, {"adaptive": uvo.UVO_FAST_MODE_ADAPTIVE, "two_pass": uvo.UVO_FAST_MODE_TWO_PASS,
                                      "single_pass": uvo.UVO_FAST_MODE_SINGLE_PASS}[args.fast_mode])
-    if os.environ.get("UVO_BENCH_PYR_FORM"):   # experiment knob: 0 auto / 1 per-level launches / 2 latency tiles / 3 throughput tiles
+    if os.environ.get("UVO_BENCH_PYR_FORM"):   # experiment knob: 0 auto / 1 per-level launches / 2 k_pyr_tiles
         ex.tune(uvo.UVO_TUNE_PYR_FORM, int(os.environ["UVO_BENCH_PYR_FORM"]))
     if os.environ.get("UVO_BENCH_PYR_GROUPS"):   # experiment knob: forced level groups of k_pyr_tiles, "first:txXty[w],..."
         for g_ in os.environ["UVO_BENCH_PYR_GROUPS"].split(","):
             first_, grid_ = g_.split(":")
             tx_, ty_ = grid_.rstrip("wr").split("x")
             ex.tune(uvo.UVO_TUNE_PYR_TILE_GROUP, (1 << 24 if grid_.endswith("w") else 0) | (1 << 25 if grid_.endswith("r") else 0) | int(first_) << 16 | int(tx_) << 8 | int(ty_))
+    if os.environ.get("UVO_BENCH_BLUR_ROUNDING"):   # experiment knob: 0 = half up on every column, 1 = the x86-64 contract (default)
+        ex.tune(uvo.UVO_TUNE_BLUR_ROUNDING, int(os.environ["UVO_BENCH_BLUR_ROUNDING"]))
     if os.environ.get("UVO_BENCH_FUSE"):   # experiment knob: quad-tree + blur as one launch (1, default) or two (0)
         ex.tune(uvo.UVO_TUNE_FUSE_BLUR_TREE, int(os.environ["UVO_BENCH_FUSE"]))
     if os.environ.get("UVO_BENCH_L0"):   # experiment knob: level 0 read in place (1, default) or copied into a padded plane first (0)

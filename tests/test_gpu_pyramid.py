@@ -17,16 +17,16 @@ def _group(first, tx, ty, wide=False):
     return (1 << 25 if wide == "r" else (1 << 24 if wide else 0)) | first << 16 | tx << 8 | ty
 
 
-@pytest.mark.parametrize("form", ["levels", "latency", "throughput"])
+@pytest.mark.parametrize("form", ["levels", "tiles", "auto"])
 def test_every_pyramid_form_gives_the_oracle_pyramid(uvo, oracle, synth, form):
-    """UVO_TUNE_PYR_FORM: one launch per level (k_resize_level), or a launch per group of levels (k_pyr_tiles) with the latency / throughput
-    set of groups -- planes, keypoints and descriptors never depend on it."""
+    """UVO_TUNE_PYR_FORM: one launch per level (k_resize_level), or one launch for all of them (k_pyr_tiles: what a single frame takes by
+    default) -- planes, keypoints and descriptors never depend on it."""
     w, h = 640, 512
     img = synth.make_frame(5150, w, h)
     oe = oracle.extractor(1000, 1.2, 8, 20)
     kp_o, de_o = oe(img)
     ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=w, max_height=h)
-    ex.tune(uvo.UVO_TUNE_PYR_FORM, {"levels": uvo.UVO_PYR_FORM_LEVELS, "latency": uvo.UVO_PYR_FORM_TILES_LATENCY, "throughput": uvo.UVO_PYR_FORM_TILES_THROUGHPUT}[form])
+    ex.tune(uvo.UVO_TUNE_PYR_FORM, {"levels": uvo.UVO_PYR_FORM_LEVELS, "tiles": uvo.UVO_PYR_FORM_TILES, "auto": uvo.UVO_PYR_FORM_AUTO}[form])
     for _ in range(2):
         kp, de = ex(img)
         _planes_equal(ex, oe, 8, form)
@@ -80,7 +80,7 @@ def test_other_shapes_and_scale_factors(uvo, oracle, synth, shape, scale, nlev):
     oe = oracle.extractor(500, scale, nlev, 20)
     kp_o, de_o = oe(img)
     ex = uvo.ORBextractor(500, scale, nlev, 0, 20, max_width=w, max_height=h)
-    for form in (uvo.UVO_PYR_FORM_AUTO, uvo.UVO_PYR_FORM_TILES_LATENCY, uvo.UVO_PYR_FORM_TILES_THROUGHPUT, uvo.UVO_PYR_FORM_LEVELS):
+    for form in (uvo.UVO_PYR_FORM_AUTO, uvo.UVO_PYR_FORM_TILES, uvo.UVO_PYR_FORM_LEVELS):
         ex.tune(uvo.UVO_TUNE_PYR_FORM, form)
         kp, de = ex(img)
         _planes_equal(ex, oe, nlev, "%dx%d scale %.2f form %d" % (w, h, scale, form))
@@ -88,14 +88,14 @@ def test_other_shapes_and_scale_factors(uvo, oracle, synth, shape, scale, nlev):
     ex.close()
 
 
-def test_batches_of_every_size_in_both_tile_sets(uvo, oracle, synth):
-    """A batch's frames are independent workgroups; the default set of level groups changes with the batch size -- every frame of every
-    batch size gives the oracle's planes in either set."""
+def test_batches_of_every_size_in_every_form(uvo, oracle, synth):
+    """A batch's frames are independent workgroups; the default form changes with the batch size (tiles up to 8 frames) -- every frame of
+    every batch size gives the oracle's planes in every form."""
     w, h = 320, 256
     imgs = synth.make_batch(40, w, h, seed0=5300)
     oe = oracle.extractor(400, 1.2, 6, 20)
     ex = uvo.ORBextractor(400, 1.2, 6, 0, 20, max_width=w, max_height=h, max_batch=40)
-    for form in (uvo.UVO_PYR_FORM_AUTO, uvo.UVO_PYR_FORM_TILES_LATENCY, uvo.UVO_PYR_FORM_TILES_THROUGHPUT):
+    for form in (uvo.UVO_PYR_FORM_AUTO, uvo.UVO_PYR_FORM_TILES):
         ex.tune(uvo.UVO_TUNE_PYR_FORM, form)
         for n in (1, 3, 9, 33, 40):
             ex.extract_batch(imgs[:n])
@@ -114,7 +114,7 @@ def test_unaligned_rows_and_the_two_lane_pipeline(uvo, oracle, synth):
         kp_o, de_o = oe(img)
         ex = uvo.ORBextractor(600, 1.2, 7, 0, 20, max_width=w, max_height=h)
         ex.set_pipeline(2)
-        for form in (uvo.UVO_PYR_FORM_TILES_LATENCY, uvo.UVO_PYR_FORM_TILES_THROUGHPUT):
+        for form in (uvo.UVO_PYR_FORM_TILES, uvo.UVO_PYR_FORM_LEVELS):
             ex.tune(uvo.UVO_TUNE_PYR_FORM, form)
             for _ in range(3):
                 kp, de = ex(img)

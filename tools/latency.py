@@ -22,7 +22,7 @@ def main():
     img = synth.make_frame(1000)
     NB = int(os.environ.get("UVO_LAT_BATCH", "1"))   # frames per device-resident call (the host-buffer loop stays one frame)
     ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=640, max_height=512, max_batch=NB)
-    # A/B knobs: UVO_LAT_PYR_FORM = 0 auto / 1 per-level launches / 2 latency tiles / 3 throughput tiles; UVO_LAT_PYR_GROUPS = "first:txXty[w],..." forced level groups
+    # A/B knobs: UVO_LAT_PYR_FORM = 0 auto / 1 per-level launches / 2 k_pyr_tiles; UVO_LAT_PYR_GROUPS = "first:txXty[w],..." forced level groups
     if os.environ.get("UVO_LAT_PYR_FORM"):
         ex.tune(uvo.UVO_TUNE_PYR_FORM, int(os.environ["UVO_LAT_PYR_FORM"]))
     if os.environ.get("UVO_LAT_ZERO_COPY"):

@@ -30,7 +30,7 @@ UVO_TUNE_LEVEL0_INPLACE = 11
 # launch-shape knobs outside the public header (csrc/tune_internal.h): the parity tests force each shape through them
 UVO_TUNE_FUSE_BLUR_TREE = 10
 UVO_TUNE_PYR_RING = 12
-UVO_TUNE_PYR_FORM, UVO_PYR_FORM_AUTO, UVO_PYR_FORM_LEVELS, UVO_PYR_FORM_TILES_LATENCY, UVO_PYR_FORM_TILES_THROUGHPUT = 13, 0, 1, 2, 3
+UVO_TUNE_PYR_FORM, UVO_PYR_FORM_AUTO, UVO_PYR_FORM_LEVELS, UVO_PYR_FORM_TILES = 13, 0, 1, 2
 UVO_TUNE_PYR_TILE_GROUP = 14
 UVO_TUNE_SIDE_BLUR = 15
 UVO_TUNE_FEW_FRAMES = 16

@@ -48,6 +48,7 @@ using namespace uvo;
 // lanes, so the latency-bound stages of one batch (quad-tree, sparse NMS, small pyramid levels) overlap with the
 // throughput stages of the next.
 constexpr int kMaxLanes = 4;
+constexpr int kTilePyramidFrames = 8;  // batches up to this size build the pyramid in one k_pyr_tiles launch
 constexpr int kFewFrames = 2;  // batches up to this size are the latency path (the FAST kernels cut their segments short for them: fast_rows_per_seg)
 
 struct Lane {
@@ -127,15 +128,16 @@ struct uvo_extractor {
   int clahe_w = 0, clahe_h = 0;
   int resize_fast[kMaxLevels] = {0};  // per level: the 12-byte-window path of k_resize_level applies
   ResizeRow* d_rtab = nullptr;
-  // the fused pyramid launches (pyramid.hip: k_pyr_tiles; plans: pyr_tiles.hpp).  pyr_form: UVO_TUNE_PYR_FORM.  Two sets of level groups per
-  // geometry -- [0] the latency shape (few frames: many small tiles, deep groups), [1] the throughput shape (shallow groups of large tiles) --
-  // or one forced set (UVO_TUNE_PYR_TILE_GROUP); an empty set = the per-level launches
+  // the fused pyramid launches (pyramid.hip: k_pyr_tiles; plans: pyr_tiles.hpp).  pyr_form: UVO_TUNE_PYR_FORM.  One set of level groups per
+  // geometry -- the latency shape (few frames: one launch of many small tiles), or a forced set (UVO_TUNE_PYR_TILE_GROUP); an empty set = the
+  // per-level launches.  (Batches that fill the chip take the per-level launches: shallow groups of large tiles -- 4 % redundant pixels --
+  // measured 0.26 - 0.31 ms against the launches' 0.16 at 256 frames, profiles/r05_pyr_tiles_ab.txt.)
   struct TileGroup {
     int first = 0, last = 0, tx = 0, ty = 0, threads = 256, rows = 4;  // rows: output rows per work item (1: only with 1024 threads)
     uint32_t lds = 0;
     PyrTileLevel* d_plan = nullptr;
   };
-  std::vector<TileGroup> tile_groups[2];
+  std::vector<TileGroup> tile_groups;
   std::vector<uint32_t> tile_spec;  // forced groups: first << 16 | tx << 8 | ty | (1024 threads) << 24 | (1024 threads, single-row items) << 25, ascending first levels
   int pyr_form = UVO_PYR_FORM_AUTO;
   std::vector<ResizeCol> ctab_host;  // the resize tables of the current geometry (the plans are compiled from them)
@@ -343,11 +345,9 @@ static int dev_alloc(T** p, size_t n) {
 }
 
 static void free_tile_groups(uvo_extractor* h) {
-  for (auto& set : h->tile_groups) {
-    for (auto& G : set)
-      if (G.d_plan) (void)hipFree(G.d_plan);
-    set.clear();
-  }
+  for (auto& G : h->tile_groups)
+    if (G.d_plan) (void)hipFree(G.d_plan);
+  h->tile_groups.clear();
 }
 
 // Compiles the plans of one set of level groups ({first level, tx, ty, threads} each, ascending) for geometry g.  A set that cannot be
@@ -396,26 +396,15 @@ static int build_tile_set(uvo_extractor* h, const Geom& g, const std::vector<uin
 // number of tiles along an axis of `len` pixels for tiles of about `target` pixels
 static inline uint32_t tiles_for(int len, int target) { return (uint32_t)std::min(255, std::max(1, (len + target / 2) / target)); }
 
-// The two default sets of a geometry.  Latency (a handful of frames cannot fill the chip: as many workgroups as CUs, ONE launch of 1024-thread
-// workgroups with single-row work items -- the halo of a deep group is paid in redundant pixels, which idle CUs have to spare: measured
-// against two and three launches and against 256-thread workgroups, profiles/r05_latency_ab.txt); throughput (shallow groups of large tiles: 4 % redundant
-// pixels at 640 x 512; the small levels as one 1024-thread workgroup per frame -- no halo at all).  All called with every lane idle.
+// The default set of a geometry: the latency shape (a handful of frames cannot fill the chip: as many workgroups as CUs, ONE launch of
+// 1024-thread workgroups with single-row work items -- the halo of a deep group is paid in redundant pixels, which idle CUs have to spare:
+// measured against two and three launches and against 256-thread workgroups, profiles/r05_latency_ab.txt).  Called with every lane idle.
 static int build_tile_groups(uvo_extractor* h, const Geom& g) {
   free_tile_groups(h);
-  if (!h->tile_spec.empty()) {
-    int rc = build_tile_set(h, g, h->tile_spec, h->tile_groups[0]);
-    if (rc) return rc;
-    return build_tile_set(h, g, h->tile_spec, h->tile_groups[1]);
-  }
-  const int n = g.nlevels;
-  std::vector<uint32_t> lat, thr;
-  lat.push_back(1u << 25 | 1u << 16 | tiles_for(g.lv[1].w, 34) << 8 | tiles_for(g.lv[1].h, 27));  // one launch; 16 x 16 tiles at 640 x 512, single-row items
-  thr.push_back(1u << 16 | tiles_for(g.lv[1].w, 136) << 8 | tiles_for(g.lv[1].h, 108));
-  if (n > 3) thr.push_back(3u << 16 | tiles_for(g.lv[3].w, 186) << 8 | tiles_for(g.lv[3].h, 148));
-  if (n > 5) thr.push_back(1u << 24 | 5u << 16 | tiles_for(g.lv[5].w, 264) << 8 | tiles_for(g.lv[5].h, 212));
-  int rc = build_tile_set(h, g, lat, h->tile_groups[0]);
-  if (rc) return rc;
-  return build_tile_set(h, g, thr, h->tile_groups[1]);
+  if (!h->tile_spec.empty()) return build_tile_set(h, g, h->tile_spec, h->tile_groups);
+  if (g.nlevels < 2) return UVO_OK;
+  const std::vector<uint32_t> lat{1u << 25 | 1u << 16 | tiles_for(g.lv[1].w, 34) << 8 | tiles_for(g.lv[1].h, 27)};  // 16 x 16 tiles at 640 x 512
+  return build_tile_set(h, g, lat, h->tile_groups);
 }
 
 static int set_geometry(uvo_extractor* h, int width, int height) {
@@ -523,10 +512,8 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
       launch_pad_level0(s, d_imgs, width, height, stride, frame_stride, L.d_pyr, g.pyr_block, g.lv[0], batch);
     }
     const std::vector<uvo_extractor::TileGroup>* tiles = nullptr;
-    if (h->pyr_form != UVO_PYR_FORM_LEVELS && h->pyr_ring == 4) {
-      const int set = h->pyr_form == UVO_PYR_FORM_TILES_LATENCY ? 0 : (h->pyr_form == UVO_PYR_FORM_TILES_THROUGHPUT ? 1 : (batch <= 8 ? 0 : 1));
-      if (!h->tile_groups[set].empty()) tiles = &h->tile_groups[set];
-    }
+    if (h->pyr_ring == 4 && !h->tile_groups.empty() && (h->pyr_form == UVO_PYR_FORM_TILES || (h->pyr_form == UVO_PYR_FORM_AUTO && batch <= kTilePyramidFrames)))
+      tiles = &h->tile_groups;
     if (tiles) {
       for (const auto& G : *tiles) {
         ProfScope p(h, "k_pyr_tiles");
@@ -947,7 +934,7 @@ int uvo_extractor_tune(uvo_extractor* h, int knob, int value) {
       return UVO_OK;
     }
     case UVO_TUNE_PYR_FORM:
-      if (value < UVO_PYR_FORM_AUTO || value > UVO_PYR_FORM_TILES_THROUGHPUT) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_FORM takes UVO_PYR_FORM_AUTO / _LEVELS / _TILES_LATENCY / _TILES_THROUGHPUT");
+      if (value < UVO_PYR_FORM_AUTO || value > UVO_PYR_FORM_TILES) return fail(UVO_E_BADARG, "UVO_TUNE_PYR_FORM takes UVO_PYR_FORM_AUTO / _LEVELS / _TILES");
       h->pyr_form = value;
       return UVO_OK;
     case UVO_TUNE_PYR_TILE_GROUP: {

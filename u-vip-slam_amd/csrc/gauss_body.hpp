@@ -28,12 +28,13 @@ __device__ __forceinline__ GaussRowTaps gauss_row_taps(int4 t) {
   T.c3 = pk4(t.x, t.y, t.z, t.w), T.r3 = pk4(t.z, t.y, t.x, 0);
   return T;
 }
-__device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t R, const GaussRowTaps& T, float* h) {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t R, const GaussRowTaps& T, f32x2* h) {
   const uint32_t s0 = __builtin_amdgcn_udot4(C, T.c0, __builtin_amdgcn_udot4(L, T.l0, 0u, false), false);
   const uint32_t s1 = __builtin_amdgcn_udot4(R, T.r1, __builtin_amdgcn_udot4(C, T.c1, __builtin_amdgcn_udot4(L, T.l1, 0u, false), false), false);
   const uint32_t s2 = __builtin_amdgcn_udot4(R, T.r2, __builtin_amdgcn_udot4(C, T.c2, __builtin_amdgcn_udot4(L, T.l2, 0u, false), false), false);
   const uint32_t s3 = __builtin_amdgcn_udot4(R, T.r3, __builtin_amdgcn_udot4(C, T.c3, 0u, false), false);
-  h[0] = (float)s0, h[1] = (float)s1, h[2] = (float)s2, h[3] = (float)s3;  // < 2^16: exact
+  h[0] = f32x2{(float)s0, (float)s1}, h[1] = f32x2{(float)s2, (float)s3};  // < 2^16: exact; pairs: the column pass runs on the packed fp32 pipe
 }
 
 // the strip plans of a geometry's levels (region = ROI + the 4-pixel ring: (w + 8) x (h + 8)), made on the host once per launch: a
@@ -45,10 +46,12 @@ int gauss7_rows_per_seg(int batch);
 int gauss7_blocks_per_frame(const Geom& g, int rows_per_seg);
 GaussPlans gauss7_plans(const Geom& g, int rows_per_seg);
 constexpr int GS_TILES = 16;  // tiles a wavefront collects per 8-row group: 15 of a full strip, 2 x 7 / 4 x 3 of the narrow ones
-// SSE2: the rounding contract of an x86-64 OpenCV build (UVO_TUNE_BLUR_ROUNDING): SymmColumnVec_32s8u's vector body -- image columns
-// 0 .. (w & ~3) - 1 -- converts the exact fp32 column sum with cvtps2dq, i.e. an exact .5 goes to the EVEN neighbour; the last w % 4
-// columns (its scalar tail) and the default contract round .5 up.  A lane's four pixels are an aligned group of four image columns, so
-// a lane is wholly one or the other.
+// SSE2: the rounding contract of an x86-64 OpenCV build (UVO_TUNE_BLUR_ROUNDING, the default): SymmColumnVec_32s8u's vector body -- image
+// columns 0 .. (w & ~3) - 1 -- converts the exact fp32 column sum with cvtps2dq + two saturating packs, i.e. round to nearest, an exact .5 to
+// the EVEN neighbour, clamp to 255: exactly what v_cvt_pk_u8_f32 does under the wavefront's default rounding mode (tools/ubench/
+// cvt_pk_u8_round.hip), so the conversion IS the contract.  The last w % 4 columns (the scalar tail) round .5 up: floor(sum + .5), in the few
+// wavefronts that hold such columns.  A lane's four pixels are an aligned group of four image columns, so a lane is wholly one or the
+// other.  !SSE2 (a build without SIMD): .5 up on every column -- the wavefront runs in round-toward-zero mode and the conversion is the floor.
 constexpr int GS_TILE_DW = GS_TILES * 32 + 96;   // LDS dwords per wavefront: the tiles + a dword per lane (and row phase) for the lanes that collect nothing
 constexpr int GS_LDS_BYTES = 4 * GS_TILE_DW * 4;  // per 4-wavefront workgroup
 // The body of a k_gauss7 workgroup: `block` of `blocks_x * batch` (frame-major in an XCD-contiguous order), LDS = GS_LDS_BYTES at s_tile.
@@ -77,8 +80,9 @@ __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, 
   // REFLECT_101 border (the blur reaches 3 pixels of it, and copies 4 into the blurred plane's ring) is produced by reflecting the row
   // index and, per lane, the column run: a lane's four pixels are an aligned group of four image columns (the width is a multiple of 4 in
   // this mode), so a group is wholly inside the image or wholly a reversed run of it -- one load and one byte permute either way.
-  auto walk = [&](auto ip_tag) {
+  auto walk = [&](auto ip_tag, auto tail_tag) {
   constexpr bool IP = decltype(ip_tag)::value;
+  constexpr bool TAIL = decltype(tail_tag)::value;  // SSE2 contract: the wavefront holds output columns of the scalar tail (decided once, below: no test in the row loop)
   const uint8_t* src = IP ? l0.vbase + f * l0.frame_stride + (int64_t)kPad * l0.pitch + kPad : pyr + f * pyr_block + g.plane_off;  // IP: the image's origin
   const int spitch = IP ? l0.pitch : g.pitch;
   uint8_t* dst = blur + f * pyr_block + g.plane_off;
@@ -144,7 +148,7 @@ __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, 
     __builtin_amdgcn_wave_barrier();
   };
 
-  const bool even_ties = SSE2 && (X - kPad) < (g.w & ~3);  // the lane's image columns belong to the vector body
+  const bool tail_lane = SSE2 && (g.w & 3) != 0 && (X - kPad) == (g.w & ~3);  // the lane's image columns are the scalar tail (w % 4 of them inside the image)
   uint32_t inmask = 0;  // bytes of the lane's dword that lie inside the image columns
 #pragma unroll
   for (int k = 0; k < 4; ++k) inmask |= (X + k >= kPad && X + k < g.w + kPad) ? 0xffu << (8 * k) : 0u;
@@ -155,12 +159,14 @@ __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, 
   const uint32_t j_edge1 = (lane_out && !via_lds) ? (uint32_t)max(py1l - py0l + 6, 0) : 0u;
 
   const GaussRowTaps RT = gauss_row_taps(taps);
-  // column taps scaled by 2^-16 (exact): the column sum comes out as sum / 65536, and + 0.5 makes its floor the rounded result
-  const float c0 = (float)taps.x * (1.0f / 65536.0f), c1 = (float)taps.y * (1.0f / 65536.0f), c2 = (float)taps.z * (1.0f / 65536.0f),
-              c3 = (float)taps.w * (1.0f / 65536.0f);
-  __builtin_amdgcn_s_setreg(0x801, 3);  // MODE.fp_round[1:0] (fp32) = toward zero: nothing below rounds except the final float -> byte conversion
+  // column taps scaled by 2^-16 (exact): the column sum comes out as sum / 65536 -- every partial sum an exact multiple of 2^-16 below 2^8
+  // (a larger one belongs to a result that saturates anyway), so no operation of the pass rounds, whatever the mode
+  const float c0s = (float)taps.x * (1.0f / 65536.0f), c1s = (float)taps.y * (1.0f / 65536.0f), c2s = (float)taps.z * (1.0f / 65536.0f),
+              c3s = (float)taps.w * (1.0f / 65536.0f);
+  const f32x2 c0{c0s, c0s}, c1{c1s, c1s}, c2{c2s, c2s}, c3{c3s, c3s};
+  if (!SSE2) __builtin_amdgcn_s_setreg(0x801, 3);  // MODE.fp_round[1:0] (fp32) = toward zero: the float -> byte conversion of sum + .5 is the floor
   const int lane_up = (lane > 0 ? lane - 1 : lane) * 4, lane_down = (lane < 63 ? lane + 1 : lane) * 4;  // ds_bpermute byte addresses
-  float hring[7][4];
+  f32x2 hring[7][2];
   uint32_t cring[7];
   // Row loads are issued one unrolled block (7 rows) ahead of their use: a wavefront walks ~70 rows one after another, so
   // without the prefetch every row would expose a full memory round trip.
@@ -202,26 +208,30 @@ __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, 
         phase = (phase + 1) & 7;
         if (j >= 6) {
           // output row py = py0l + j - 6; its 7 source rows sit in ring slots (u+1)%7 .. (u+7)%7
-          const float* r0 = hring[(u + 1) % 7];
-          const float* r1 = hring[(u + 2) % 7];
-          const float* r2 = hring[(u + 3) % 7];
-          const float* r3 = hring[(u + 4) % 7];
-          const float* r4 = hring[(u + 5) % 7];
-          const float* r5 = hring[(u + 6) % 7];
-          const float* r6 = hring[u];
+          const f32x2* r0 = hring[(u + 1) % 7];
+          const f32x2* r1 = hring[(u + 2) % 7];
+          const f32x2* r2 = hring[(u + 3) % 7];
+          const f32x2* r3 = hring[(u + 4) % 7];
+          const f32x2* r4 = hring[(u + 5) % 7];
+          const f32x2* r5 = hring[(u + 6) % 7];
+          const f32x2* r6 = hring[u];
           const uint32_t centre = cring[(u + 4) % 7];
           const bool row_in = (uint32_t)j - j_in0 < n_in;
-          // column pass: sum / 2^16 + 0.5, every partial sum an exact multiple of 2^-16 below 2^8 (a larger one belongs to a result
-          // that saturates anyway); floor, clamp to 255 and the byte insert are the conversion itself
-          uint32_t blurred = 0, ties = 0;
+          // column pass on the packed fp32 pipe (two pixels per instruction: v_pk_add_f32 / v_pk_fma_f32 -- 2.2 / 2.5 cycles per result
+          // against 2.7 / 4.3 of the scalar forms, tools/ubench/pk_f32_rate.hip); clamp to 255 and the byte insert are the conversion itself
+          uint32_t blurred = 0;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float z = __builtin_fmaf(c0, r0[k] + r6[k], __builtin_fmaf(c1, r1[k] + r5[k], __builtin_fmaf(c2, r2[k] + r4[k], __builtin_fmaf(c3, r3[k], 0.5f))));
-            blurred = __builtin_amdgcn_cvt_pk_u8_f32(z, (uint32_t)k, blurred);
-            // sum / 2^16 + 1/2 a whole number: the sum sat exactly between two bytes (and below the saturation edge)
-            if (SSE2) ties |= (__builtin_amdgcn_fractf(z) == 0.0f && z < 256.0f) ? 1u << (8 * k) : 0u;
+          for (int p = 0; p < 2; ++p) {
+            const f32x2 half{0.5f, 0.5f}, zero{0.f, 0.f};
+            f32x2 z = __builtin_elementwise_fma(c0, r0[p] + r6[p], __builtin_elementwise_fma(c1, r1[p] + r5[p], __builtin_elementwise_fma(c2, r2[p] + r4[p],
+                          __builtin_elementwise_fma(c3, r3[p], SSE2 ? zero : half))));
+            if (SSE2 && TAIL) {  // the scalar tail's columns: floor(sum + .5) is a whole number, which the conversion leaves alone
+              const f32x2 up{__builtin_floorf(z.x + 0.5f), __builtin_floorf(z.y + 0.5f)};
+              z = tail_lane ? up : z;
+            }
+            blurred = __builtin_amdgcn_cvt_pk_u8_f32(z.x, (uint32_t)(2 * p), blurred);
+            blurred = __builtin_amdgcn_cvt_pk_u8_f32(z.y, (uint32_t)(2 * p + 1), blurred);
           }
-          if (SSE2 && even_ties) blurred -= ties & blurred;  // half up gave the upper neighbour: where that one is odd, the even one is below it
           // pad ring and anything outside the image: the un-blurred centre pixel (byte mask per lane, rows uniform)
           const uint32_t m = row_in ? inmask : 0u;
           const uint32_t out = (blurred & m) | (centre & ~m);
@@ -248,10 +258,16 @@ __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, 
     if ((py_last & 7) != 7) flush_tiles(py_last & ~7, py_last & 7, (int64_t)(py_last >> 3) * tile_row_bytes);
   }
   };  // walk
+  // SSE2: does this wavefront hold output columns of the scalar tail at all?  Only the last strip of a level whose width is no multiple of 4
+  // (and never level 0 in place, whose width is one): those wavefronts take the instantiation with the fix-up in its column pass.
+  const int x_last = 8 + strip_x + 4 * (64 / nsub - 1);  // first padded column behind the strip's lanes
+  const bool tail_wave = SSE2 && (g.w & 3) != 0 && kPad + (g.w & ~3) >= 8 + strip_x && kPad + (g.w & ~3) < x_last;
   if (level == 0 && l0.vbase != nullptr)
-    walk(std::true_type{});
+    walk(std::true_type{}, std::false_type{});
+  else if (tail_wave)
+    walk(std::false_type{}, std::true_type{});
   else
-    walk(std::false_type{});
+    walk(std::false_type{}, std::false_type{});
 }
 
 

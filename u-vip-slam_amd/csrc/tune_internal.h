@@ -7,11 +7,10 @@
 #define UVO_TUNE_FUSE_BLUR_TREE 10 /* 1 (default): DistributeOctTree and GaussianBlur share one launch when the batch is large enough for the
                                      256-thread quad-tree form (neither reads what the other writes); 0: two launches */
 #define UVO_TUNE_PYR_FORM 13        /* launch shape of ComputePyramid (src/ORBextractor.cc:963-1004); the planes are the same in every form */
-#define UVO_PYR_FORM_AUTO 0              /* (default) by batch size: the latency set of level groups up to 8 frames, the throughput set above; the per-level
-                                            launches where a geometry has no plan (scale factors above ~1.33, UVO_TUNE_PYR_RING != 4) */
+#define UVO_PYR_FORM_AUTO 0              /* (default) up to 8 frames one k_pyr_tiles launch, larger batches one launch per level; the per-level launches also
+                                            where a geometry has no tile plan (scale factors above ~1.33, UVO_TUNE_PYR_RING != 4) */
 #define UVO_PYR_FORM_LEVELS 1            /* one launch per level (k_resize_level) */
-#define UVO_PYR_FORM_TILES_LATENCY 2     /* k_pyr_tiles, the latency set */
-#define UVO_PYR_FORM_TILES_THROUGHPUT 3  /* k_pyr_tiles, the throughput set */
+#define UVO_PYR_FORM_TILES 2             /* k_pyr_tiles for every batch size */
 #define UVO_TUNE_PYR_TILE_GROUP 14  /* forces the level groups of k_pyr_tiles: one call per group, value = first level << 16 | tx << 8 | ty
                                        (| 1 << 24: 1024-thread workgroups; | 1 << 25: 1024 threads, one output row per work item), first level 1 starts a new
                                        list; 0: back to the defaults */
