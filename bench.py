@@ -255,9 +255,22 @@ class SharedHostRegion:
         self.mm = mmap.mmap(fd, nbytes)
         os.close(fd)
         self.buf = np.frombuffer(self.mm, dtype=np.uint8)
+        self.registered = False   # register() follows the ranks' first touch of their own slices
+
+    def register(self, own_slices, dist):
+        """Several ranks: every rank writes its OWN slices of the mapping first (from its thread, which is bound to the CPUs next to its GPU:
+        the pages land on that NUMA node), all ranks meet, and only then is the region page-locked -- registration faults in every page
+        that is still untouched, on the node of whoever registers first."""
+        if self.mm is None:
+            return
+        for a in own_slices:
+            a[...] = 0
+        if dist is not None:
+            dist.barrier()
         try:
-            uvo.host_register(self.buf)
-        except uvo.UvoError:
+            self.uvo.host_register(self.buf)
+            self.registered = True
+        except self.uvo.UvoError:
             self.registered = False   # still correct: the copies just stop being asynchronous
 
     def carve(self, offset, shape, dtype):
@@ -360,6 +373,10 @@ def main():
     uvo = importlib.import_module("u-vip-slam_amd")
     synth = importlib.import_module("u-vip-slam_amd.synth")
     workloads = importlib.import_module("u-vip-slam_amd.workloads")
+    # Host placement before any host buffer exists: this rank's thread goes to the CPUs next to its GPU's PCIe link, so that the frames
+    # it generates below and its slice of the gather region are first touched -- and page-locked -- on that NUMA node (N ranks on a
+    # two-socket host would otherwise all pull their 84 MB per step from wherever the first rank's pages happened to land)
+    numa_bound, numa_node = uvo.host_bind_near_device(local_rank)
     dev = torch.device("cuda", local_rank)
     red_dev = None if dry else dev   # where the tensors of the barrier-side reductions live (gloo: host)
 
@@ -559,6 +576,7 @@ def main():
                 a, off = region.carve(off, s, t)
                 arrs.append(a)
             sets.append(arrs)
+        region.register([a[first:first + B] for arrs in sets for a in arrs], dist)
         g_kp, g_de, g_n, g_i0, g_d0, g_i1, g_d1 = sets[0]
         jobs = [0]
         pending = [None]
@@ -612,6 +630,12 @@ def main():
                "offsets of one page-locked region shared by all ranks (%s)" % ("uvo_host_alloc" if world == 1 else "/dev/shm mapping + uvo_host_register" +
                                                                                   ("" if region.registered else " [registration failed: pageable]")),
                "gathered_equals_hbm_resident": True}
+        nodes = [None] * world
+        if dist is not None:
+            dist.all_gather_object(nodes, {"rank": rank, "numa_node": numa_node, "bound_to_local_cpus": bool(numa_bound)})
+        else:
+            nodes = [{"rank": rank, "numa_node": numa_node, "bound_to_local_cpus": bool(numa_bound)}]
+        h2h["numa"] = nodes   # per rank: the NUMA node of its GPU and whether its thread (frames, gather slice, sharder staging) was bound to that node's CPUs
         sh.close()
         region.close(rank, dist)
 

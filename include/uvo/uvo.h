@@ -144,6 +144,17 @@ int uvo_host_free(void* ptr);
 int uvo_extract_batch_submit(uvo_extractor* h, int batch, const uint8_t* imgs, int width, int height, ptrdiff_t stride, ptrdiff_t frame_stride,
                              uvo_keypoint* out_kp, uint8_t* out_desc, int cap, int32_t* n_out, int* ticket);
 int uvo_extract_batch_wait(uvo_extractor* h, int ticket);
+/*
+ * Placement of the host side next to a GPU (N ranks on a two-socket host: every rank's frames leave over the PCIe link of ITS GPU).
+ * uvo_host_bind_near_device() binds the CALLING THREAD to the CPUs local to `device` (Linux: /sys/bus/pci/devices/<bdf>/local_cpulist,
+ * intersected with the CPUs the process may use) and reports the device's NUMA node (-1: unknown); memory the thread touches first
+ * afterwards -- its frames, its slice of a shared gather region, before uvo_host_register() -- then lands on that node.  Returns 1 when the
+ * thread was bound, 0 when there was nothing to do (no sysfs entry, no usable CPU in the list: the thread stays where it was), < 0 on error.
+ * The sharder's per-shard threads bind themselves this way (environment UVO_NUMA_BIND=0 turns every binding of this library into a no-op:
+ * for hosts that place their processes themselves).  uvo_host_bind_to_cpulist_file() is the same for an explicit cpulist file.
+ */
+int uvo_host_bind_near_device(int device, int32_t* numa_node);
+int uvo_host_bind_to_cpulist_file(const char* cpulist_path);
 /* Page-lock memory the caller already owns (e.g. a shared mapping that several processes gather into); uvo_host_alloc()'s sibling. */
 int uvo_host_register(void* ptr, size_t bytes);
 int uvo_host_unregister(void* ptr);

@@ -1,8 +1,12 @@
 """Host-side pieces that are neither kernels nor oracle: the synthetic workloads of the BASELINE.json configurations and the restated
 IMU preintegration that loads the host in configs[4] (tools/hoststress/imu_preintegrator.cpp; src/IMU/IMUPreintegrator.cpp:81-140)."""
 import importlib
+import os
 
 import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_imu_preintegration_against_closed_forms():
@@ -58,3 +62,43 @@ def test_config4_local_map_is_deterministic_and_consistent():
     assert (d <= a["max_distance"] * 1.0001).all() and (d >= a["min_distance"] * 0.9999).all()
     flips = np.unpackbits(a["mp_desc"] ^ de[a["src"]], axis=1).sum(1)
     assert 5 < flips.mean() < 25                                          # Binomial(256, 0.06)
+
+
+def test_thread_binds_to_a_device_cpulist_and_is_a_noop_without_one(tmp_path):
+    """uvo_host_bind_to_cpulist_file / uvo_host_bind_near_device (N ranks on a two-socket host): the calling thread's affinity
+    mask becomes the device's local_cpulist (intersected with what the process may use); a missing sysfs entry, an empty list or a list of
+    CPUs the process may not use leave the thread where it was.  Runs in a child process: the binding must not leak into the test session."""
+    import subprocess
+    import sys
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        pytest.skip("needs two usable CPUs")
+    want = allowed[:max(1, len(allowed) // 2)]
+    good = tmp_path / "local_cpulist"
+    txt, i = [], 0
+    while i < len(want):            # ranges like sysfs writes them: "0-3,8"
+        j = i
+        while j + 1 < len(want) and want[j + 1] == want[j] + 1:
+            j += 1
+        txt.append("%d-%d" % (want[i], want[j]) if j > i else "%d" % want[i])
+        i = j + 1
+    good.write_text(",".join(txt) + "\n")
+    foreign = tmp_path / "foreign"
+    foreign.write_text("%d-%d\n" % (max(allowed) + 1000, max(allowed) + 1003))
+    empty = tmp_path / "empty"
+    empty.write_text("\n")
+    code = """
+import importlib, os, sys
+sys.path.insert(0, %r)
+uvo = importlib.import_module("u-vip-slam_amd")
+before = sorted(os.sched_getaffinity(0))
+assert uvo.host_bind_to_cpulist_file(%r) is False and sorted(os.sched_getaffinity(0)) == before      # no such file
+assert uvo.host_bind_to_cpulist_file(%r) is False and sorted(os.sched_getaffinity(0)) == before      # CPUs this process may not use
+assert uvo.host_bind_to_cpulist_file(%r) is False and sorted(os.sched_getaffinity(0)) == before      # an empty list
+assert uvo.host_bind_to_cpulist_file(%r) is True
+print(sorted(os.sched_getaffinity(0)))
+""" % (ROOT, str(tmp_path / "missing"), str(foreign), str(empty), str(good))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert eval(out.stdout.strip().splitlines()[-1]) == want
+    assert sorted(os.sched_getaffinity(0)) == allowed

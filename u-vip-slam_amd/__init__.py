@@ -39,7 +39,7 @@ UVO_TUNE_ZERO_COPY_OUT, UVO_TUNE_SPIN_WAIT = 17, 18
 # every symbol include/uvo/uvo.h declares
 ABI_SYMBOLS = [
     "uvo_extractor_create", "uvo_extractor_destroy", "uvo_extractor_levels", "uvo_extractor_max_keypoints", "uvo_extractor_scale_factor", "uvo_extractor_tables",
-    "uvo_extract", "uvo_extract_tracked", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_host_alloc", "uvo_host_free", "uvo_host_register", "uvo_host_unregister", "uvo_shard_plan_make", "uvo_sharder_create", "uvo_sharder_destroy", "uvo_sharder_max_keypoints", "uvo_sharder_run", "uvo_sharder_submit", "uvo_sharder_wait", "uvo_extract_batch_submit", "uvo_extract_batch_wait", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_tune", "uvo_extractor_fast_state", "uvo_extractor_level_dims",
+    "uvo_extract", "uvo_extract_tracked", "uvo_extract_batch", "uvo_extract_batch_device", "uvo_host_alloc", "uvo_host_free", "uvo_host_register", "uvo_host_unregister", "uvo_host_bind_near_device", "uvo_host_bind_to_cpulist_file", "uvo_shard_plan_make", "uvo_sharder_create", "uvo_sharder_destroy", "uvo_sharder_max_keypoints", "uvo_sharder_run", "uvo_sharder_submit", "uvo_sharder_wait", "uvo_extract_batch_submit", "uvo_extract_batch_wait", "uvo_extractor_synchronize", "uvo_extractor_set_pipeline", "uvo_extractor_tune", "uvo_extractor_fast_state", "uvo_extractor_level_dims",
     "uvo_grider_fast", "uvo_clahe", "uvo_clahe_batch_device", "uvo_extractor_read_plane", "uvo_extractor_read_candidates", "uvo_extractor_profile", "uvo_extractor_profile_only", "uvo_extractor_kernel_times",
     "uvo_matcher_create", "uvo_matcher_destroy", "uvo_matcher_synchronize", "uvo_hamming_knn2", "uvo_hamming_knn2_batch_device",
     "uvo_hamming_matrix", "uvo_distinctive_descriptors", "uvo_search_by_projection", "uvo_match_windows", "uvo_match_groups",
@@ -170,6 +170,8 @@ def _load():
     lib.uvo_host_free.argtypes = [vp]
     lib.uvo_host_register.argtypes = [vp, ctypes.c_size_t]
     lib.uvo_host_unregister.argtypes = [vp]
+    lib.uvo_host_bind_near_device.argtypes = [ci, vp]
+    lib.uvo_host_bind_to_cpulist_file.argtypes = [ctypes.c_char_p]
     lib.uvo_shard_plan_make.argtypes = [ci, ci, ci, ci, ctypes.POINTER(ShardPlan)]
     lib.uvo_sharder_create.argtypes = [ctypes.POINTER(SharderCfg), ctypes.POINTER(vp)]
     lib.uvo_sharder_destroy.argtypes = [vp]
@@ -352,6 +354,23 @@ def host_register(arr):
     rc = lib.uvo_host_register(arr.ctypes.data, arr.nbytes)
     if rc:
         raise UvoError(rc, "uvo_host_register")
+
+
+def host_bind_near_device(device):
+    """uvo_host_bind_near_device: binds the calling thread to the CPUs local to `device`; -> (bound, numa_node) -- (False, -1) where the
+    platform says nothing (placement is speed, never correctness)."""
+    node = ctypes.c_int32(-1)
+    rc = lib.uvo_host_bind_near_device(int(device), ctypes.byref(node))
+    if rc < 0:
+        raise UvoError(rc, "uvo_host_bind_near_device")
+    return rc == 1, int(node.value)
+
+
+def host_bind_to_cpulist_file(path):
+    rc = lib.uvo_host_bind_to_cpulist_file(str(path).encode())
+    if rc < 0:
+        raise UvoError(rc, "uvo_host_bind_to_cpulist_file")
+    return rc == 1
 
 
 def host_unregister(arr):

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libuvo.so")
 OBJ = os.path.join(HERE, "build")
 SOURCES = ["pyramid.hip", "gauss.hip", "fast.hip", "octree.hip", "describe.hip", "hamming.hip", "search.hip", "match_engine.hip", "grider.hip", "extractor.cpp", "sharder.cpp", "matcher.cpp",
-           "matcher_search.cpp", "matcher_batch.cpp", "bow.hip", "bow.cpp", "clahe.hip", "klt.hip"]
+           "matcher_search.cpp", "matcher_batch.cpp", "bow.hip", "bow.cpp", "clahe.hip", "klt.hip", "numa.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
          "-fgpu-flush-denormals-to-zero" if False else "-fno-gpu-flush-denormals-to-zero", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-x", "hip"]

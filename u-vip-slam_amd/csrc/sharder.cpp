@@ -51,6 +51,7 @@ struct Shard {
   hipEvent_t kernels_done[2] = {nullptr, nullptr};  // extractor lane: descriptors of the chunk are final
   hipEvent_t rows_sent[2] = {nullptr, nullptr};     // matcher stream: the chunk's rows are on their way to the host
   std::thread worker;
+  int32_t numa_node = -1;  // of the shard's device, once its thread has bound itself (uvo_host_bind_near_device)
 };
 
 struct RunArgs {
@@ -219,6 +220,7 @@ void job_delivered(uvo_sharder* s, const std::shared_ptr<Job>& job, int rc, cons
 void shard_worker(uvo_sharder* s, int shard_index) {
   Shard& sh = s->shards[shard_index];
   (void)hipSetDevice(sh.device);
+  (void)uvo_host_bind_near_device(sh.device, &sh.numa_node);  // the shard's staging and waiting happen next to its GPU's PCIe link
   const int C = s->cfg.chunk_frames, dcap = s->dcap;
   hipStream_t ms = sh.mt ? uvo_matcher_stream_internal(sh.mt) : nullptr;
   std::deque<InFlight> inflight;           // oldest first, at most two
