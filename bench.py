@@ -803,10 +803,8 @@ def main():
                     "whole_path_algorithmic_bytes_per_frame": int(total_alg),
                     "kernel_ms_per_step_in_timed_region": {k: round(v[0] / steps, 4) for k, v in sorted(ktimes.items())},
                     "kernel_ms_per_step_unoverlapped": {k: round(v[0] / 3, 4) for k, v in sorted(serial.items())},
-                    "note": "frac = algorithmic bytes per launch of the dominant kernel / its live launch duration (HIP events on the library's stream, "
-                            "timed region) / 8 TB/s; traffic = HBM bytes per launch from the committed rocprofv3 --pmc passes of this command "
-                            "(fetch factor per kernel: profiles/*_fetch_calibration.json); the kernel is bound by VALU issue, not HBM: see valu / "
-                            "the top-level valu_frac"}
+                    "note": "bound says hbm because frac is the HBM fraction this record format asks for (algorithmic bytes per launch / live launch duration "
+                            "/ 8 TB/s); the kernel itself is bound by instruction issue: issue_roofline"}
         out = {
             "metric": "frames/sec ORB extract+match, %dx%d @%d kp" % (W, H, NFEAT),
             "value": round(value, 1),

@@ -569,18 +569,23 @@ __global__ __launch_bounds__(64 * DK_WAVES, UVO_OCC_DESCRIBE) void k_describe(co
 
 // The occupancy grid the caller of the top-up extraction builds from its tracked keypoints (src/Tracking.cc:896-912): for every
 // keypoint grid_2d((int)(pt.y / min_px_dist), (int)(pt.x / min_px_dist))++ -- Eigen::MatrixXi, column-major, one grid per frame.
-__global__ __launch_bounds__(256) void k_occupancy_grid(const uvo_keypoint* __restrict__ in_kp, const int32_t* __restrict__ n_in, int in_cap, int min_px_dist,
-                                                        int grid_rows, int grid_cols, int32_t* __restrict__ grid) {
-  const int f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_in[f]) return;
-  const uvo_keypoint k = in_kp[(int64_t)f * in_cap + i];
-  const int x = (int)(k.y / (float)min_px_dist), y = (int)(k.x / (float)min_px_dist);
-  if (x >= 0 && x < grid_rows && y >= 0 && y < grid_cols) atomicAdd(&grid[(int64_t)f * grid_rows * grid_cols + (int64_t)y * grid_rows + x], 1);
+// One workgroup per frame: the grid is cleared and filled in the same launch (Eigen::MatrixXi::Zero + the loop of :896-912).
+__global__ __launch_bounds__(1024) void k_occupancy_grid(const uvo_keypoint* __restrict__ in_kp, const int32_t* __restrict__ n_in, int in_cap, int min_px_dist,
+                                                         int grid_rows, int grid_cols, int32_t* __restrict__ grid) {
+  const int f = blockIdx.x;
+  int32_t* G = grid + (int64_t)f * grid_rows * grid_cols;
+  for (int i = threadIdx.x; i < grid_rows * grid_cols; i += blockDim.x) G[i] = 0;
+  __syncthreads();
+  const int n = n_in ? min(n_in[f], in_cap) : 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const uvo_keypoint k = in_kp[(int64_t)f * in_cap + i];
+    const int x = (int)(k.y / (float)min_px_dist), y = (int)(k.x / (float)min_px_dist);
+    if (x >= 0 && x < grid_rows && y >= 0 && y < grid_cols) atomicAdd(&G[(int64_t)y * grid_rows + x], 1);
+  }
 }
 void launch_occupancy_grid(hipStream_t s, const uvo_keypoint* d_in_kp, const int32_t* d_n_in, int in_cap, int min_px_dist, int grid_rows, int grid_cols,
                            int32_t* d_grid, int batch) {
-  if (in_cap < 1) return;
-  hipLaunchKernelGGL(k_occupancy_grid, dim3((in_cap + 255) / 256, batch), dim3(256), 0, s, d_in_kp, d_n_in, in_cap, min_px_dist, grid_rows, grid_cols, d_grid);
+  hipLaunchKernelGGL(k_occupancy_grid, dim3(batch), dim3(1024), 0, s, d_in_kp, in_cap > 0 ? d_n_in : nullptr, in_cap, min_px_dist, grid_rows, grid_cols, d_grid);
 }
 
 void launch_assemble(hipStream_t s, const LevelGeom* d_lv, const Geom& g, FastAdapt fa, const uint32_t* d_sel_xy, const uint32_t* d_sel_sc,

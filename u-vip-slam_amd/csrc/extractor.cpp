@@ -160,6 +160,7 @@ struct uvo_extractor {
   // pinned host staging of the host-buffer entry points' small inputs / outputs (copies to and from pageable caller
   // memory stall the stream once per call; a pinned bounce keeps them asynchronous behind one wait)
   uint8_t* h_pin = nullptr;
+  uint8_t* h_pin_dev = nullptr;  // the same memory as the device addresses it (k_describe writes small batches' results straight into it)
   size_t pin_bytes = 0;
   // asynchronous host form: the event behind the most recent frame upload of ANY lane.  The next upload waits for it, so that uploads
   // follow one another instead of sharing the link: two lanes that upload at the same time finish together, then compute together,
@@ -1090,28 +1091,36 @@ static int extract_batch_impl(uvo_extractor* h, int batch, const uint8_t* imgs, 
   // pinned bounce buffer: [n_out | nfn | n_in : 3*batch ints][grid][keypoints in, later keypoints + descriptors out]
   const size_t kSmallBatch = 16;  // above this the caller-side copies are a small part of the call
   const bool bounce = (size_t)batch <= kSmallBatch;
-  size_t off_grid = 0, off_kp = 0;
+  size_t off_grid = 0, off_in = 0, off_kp = 0;
   if (bounce) {
-    size_t in_total = 0;
-    if (have_in)
-      for (int b = 0; b < batch; ++b) in_total += (size_t)n_in[b];
     off_grid = (((size_t)3 * batch * sizeof(int32_t)) + 63) & ~(size_t)63;
-    off_kp = (off_grid + gb + 63) & ~(size_t)63;
-    const size_t want = off_kp + std::max(in_total * sizeof(uvo_keypoint), (size_t)batch * dcap * (sizeof(uvo_keypoint) + 32));
+    off_in = (off_grid + gb + 63) & ~(size_t)63;  // the caller's keypoints, [frame][in_cap] like the device copy: the kernels may read them here
+    off_kp = (off_in + (have_in ? (size_t)batch * in_cap * sizeof(uvo_keypoint) : 0) + 63) & ~(size_t)63;
+    const size_t want = off_kp + (size_t)batch * dcap * (sizeof(uvo_keypoint) + 32);
     if (want > h->pin_bytes) {
       UVO_HIP_CHECK(hipStreamSynchronize(s));
       if (h->h_pin) (void)hipHostFree(h->h_pin);
-      h->h_pin = nullptr, h->pin_bytes = 0;
+      h->h_pin = nullptr, h->h_pin_dev = nullptr, h->pin_bytes = 0;
       void* p = nullptr;
       if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return fail(UVO_E_NOMEM, "pinned staging allocation failed");
       h->h_pin = (uint8_t*)p, h->pin_bytes = want;
+      void* dp = nullptr;
+      if (hipHostGetDevicePointer(&dp, p, 0) == hipSuccess) h->h_pin_dev = (uint8_t*)dp;
     }
   }
   int32_t* pin_i = (int32_t*)h->h_pin;
+  // Small batches with zero-copy I/O: the kernels read the call's small inputs (feature budget, keypoint counts, the caller's keypoints)
+  // where the host put them, in the page-locked region -- each host-to-device copy of a few bytes costs a DMA start-up in front of the
+  // first kernel; only the image is uploaded
+  uint8_t* const pin_dev = (bounce && h->zero_copy_out) ? h->h_pin_dev : nullptr;
+  const int32_t* i_nfn = h->d_nfn;
+  const int32_t* i_n_in = h->d_n_in;
+  const uvo_keypoint* i_in_kp = h->d_in_kp;
   if (topup) {
     if (bounce) {
       std::memcpy(pin_i + batch, num_feats_needed, sizeof(int32_t) * batch);
-      UVO_HIP_CHECK(hipMemcpyAsync(h->d_nfn, pin_i + batch, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+      if (pin_dev) i_nfn = (const int32_t*)pin_dev + batch;
+      else UVO_HIP_CHECK(hipMemcpyAsync(h->d_nfn, pin_i + batch, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
       if (!build_grid) {
         std::memcpy(h->h_pin + off_grid, grid2d, gb);
         UVO_HIP_CHECK(hipMemcpyAsync(h->d_grid, h->h_pin + off_grid, gb, hipMemcpyHostToDevice, s));
@@ -1120,18 +1129,20 @@ static int extract_batch_impl(uvo_extractor* h, int batch, const uint8_t* imgs, 
       if (!build_grid) UVO_HIP_CHECK(hipMemcpyAsync(h->d_grid, grid2d, gb, hipMemcpyHostToDevice, s));
       UVO_HIP_CHECK(hipMemcpyAsync(h->d_nfn, num_feats_needed, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
     }
-    if (build_grid) UVO_HIP_CHECK(hipMemsetAsync(h->d_grid, 0, gb, s));
     if (have_in) {
       // only the first n_in[b] entries of a frame's slice are ever read on the device
       if (bounce) {
         std::memcpy(pin_i + 2 * batch, n_in, sizeof(int32_t) * batch);
-        UVO_HIP_CHECK(hipMemcpyAsync(h->d_n_in, pin_i + 2 * batch, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
-        uvo_keypoint* pk = (uvo_keypoint*)(h->h_pin + off_kp);
-        for (int b = 0; b < batch; ++b) {
-          if (n_in[b] <= 0) continue;
-          std::memcpy(pk, in_kp + (size_t)b * in_cap, sizeof(uvo_keypoint) * n_in[b]);
-          UVO_HIP_CHECK(hipMemcpyAsync(h->d_in_kp + (size_t)b * in_cap, pk, sizeof(uvo_keypoint) * n_in[b], hipMemcpyHostToDevice, s));
-          pk += n_in[b];
+        uvo_keypoint* pk = (uvo_keypoint*)(h->h_pin + off_in);
+        for (int b = 0; b < batch; ++b)
+          if (n_in[b] > 0) std::memcpy(pk + (size_t)b * in_cap, in_kp + (size_t)b * in_cap, sizeof(uvo_keypoint) * n_in[b]);
+        if (pin_dev) {
+          i_n_in = (const int32_t*)pin_dev + 2 * batch, i_in_kp = (const uvo_keypoint*)(pin_dev + off_in);
+        } else {
+          UVO_HIP_CHECK(hipMemcpyAsync(h->d_n_in, pin_i + 2 * batch, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+          for (int b = 0; b < batch; ++b)
+            if (n_in[b] > 0)
+              UVO_HIP_CHECK(hipMemcpyAsync(h->d_in_kp + (size_t)b * in_cap, pk + (size_t)b * in_cap, sizeof(uvo_keypoint) * n_in[b], hipMemcpyHostToDevice, s));
         }
       } else {
         UVO_HIP_CHECK(hipMemcpyAsync(h->d_n_in, n_in, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
@@ -1142,18 +1153,16 @@ static int extract_batch_impl(uvo_extractor* h, int batch, const uint8_t* imgs, 
       }
     }
   }
-  if (topup && build_grid && have_in)
-    launch_occupancy_grid(s, h->d_in_kp, h->d_n_in, in_cap, min_px_dist, grid_rows, grid_cols, h->d_grid, batch);
+  // build_grid: the occupancy grid is cleared and filled from the tracked keypoints in one launch (no keypoints: cleared)
+  if (topup && build_grid) launch_occupancy_grid(s, i_in_kp, have_in ? i_n_in : nullptr, have_in ? in_cap : 0, min_px_dist, grid_rows, grid_cols, h->d_grid, batch);
   // Small batches: k_describe writes the counts, keypoints and descriptors straight into the page-locked bounce region (posted writes over the
   // link: no device-to-host copy -- three DMA start-ups of ~8 us each -- stands between the last kernel and the host)
-  uint8_t* pin_dev = nullptr;
-  if (bounce && h->zero_copy_out && hipHostGetDevicePointer((void**)&pin_dev, h->h_pin, 0) != hipSuccess) pin_dev = nullptr;
   uvo_keypoint* const o_kp = pin_dev ? (uvo_keypoint*)(pin_dev + off_kp) : h->d_out_kp;
   uint8_t* const o_desc = pin_dev ? pin_dev + off_kp + (size_t)batch * dcap * sizeof(uvo_keypoint) : h->d_out_desc;
   int32_t* const o_n = pin_dev ? (int32_t*)pin_dev : h->d_n_out;
-  int rc = run_batch_device(h, li, batch, d_frames, width, height, width, (ptrdiff_t)width * height, describe_in ? h->d_in_kp : nullptr,
-                            describe_in ? h->d_n_in : nullptr, topup ? h->d_grid : nullptr, grid_rows, grid_cols, min_px_dist, full_detect,
-                            topup ? h->d_nfn : nullptr, o_kp, o_desc, dcap, o_n);
+  int rc = run_batch_device(h, li, batch, d_frames, width, height, width, (ptrdiff_t)width * height, describe_in ? i_in_kp : nullptr,
+                            describe_in ? i_n_in : nullptr, topup ? h->d_grid : nullptr, grid_rows, grid_cols, min_px_dist, full_detect,
+                            topup ? i_nfn : nullptr, o_kp, o_desc, dcap, o_n);
   if (rc) return rc;
   if (bounce) {
     // The counts, the grid and every frame's whole result slice (dcap records: a frame rarely fills less than 90 % of it) come back in one
