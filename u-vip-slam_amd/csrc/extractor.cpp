@@ -85,6 +85,7 @@ struct Lane {
   // level 0 of the lane's last batch was read in place (no padded plane was written): what uvo_extractor_read_plane needs to make one
   const uint8_t* l0_src = nullptr;
   int64_t l0_stride = 0, l0_frame_stride = 0;
+  int ring_used = 0;  // border pixels the lane's last batch wrote around levels >= 1 (what uvo_extractor_read_plane has to complete)
 };
 
 struct uvo_matcher;
@@ -505,6 +506,7 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   Level0View l0{nullptr, 0, 0, 0};
   if (inplace) l0 = Level0View{d_imgs - (int64_t)kPad * stride - kPad, (int64_t)frame_stride, (int)stride, 0};
   L.l0_src = inplace ? d_imgs : nullptr, L.l0_stride = stride, L.l0_frame_stride = frame_stride;
+  L.ring_used = h->pyr_ring;
   const Level0View no_l0{nullptr, 0, 0, 0};
   {
     // ComputePyramid (src/ORBextractor.cc:963-1004): a launch per group of levels (k_pyr_tiles), or one per level
@@ -519,11 +521,6 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
       for (const auto& G : *tiles) {
         ProfScope p(h, "k_pyr_tiles");
         launch_pyr_tiles(s, L.d_pyr, g.pyr_block, G.d_plan, g, h->d_ctab, h->d_rtab, l0, G.first, G.last, G.tx * G.ty, G.lds, G.threads, G.rows, batch);
-        if (getenv("UVO_DEBUG_PYR")) {
-          hipError_t e1 = hipGetLastError();
-          hipError_t e2 = hipStreamSynchronize(s);
-          fprintf(stderr, "[pyr] group %d..%d tiles %dx%d threads %d lds %u: launch %d sync %d\n", G.first, G.last, G.tx, G.ty, G.threads, G.lds, (int)e1, (int)e2);
-        }
       }
     } else {
       for (int l = 1; l < g.nlevels; ++l) {
@@ -1414,7 +1411,7 @@ int uvo_extractor_read_plane(uvo_extractor* h, int frame, int level, int which, 
   UVO_HIP_CHECK(hipStreamSynchronize(h->lane[h->cur].stream));
   const LevelGeom& L = h->geom.lv[level];
   Lane& LN = h->lane[h->cur];
-  if (!which && level >= 1 && h->pyr_ring > 0) {
+  if (!which && level >= 1 && LN.ring_used > 0) {
     // the batch wrote the level's ROI and the few pixels around it that a stage reads: this test tap completes the 16-pixel border (the same
     // launch over the whole padded plane; its source -- the ROI of the level below, or the caller's image -- is still there)
     const Geom& g = h->geom;

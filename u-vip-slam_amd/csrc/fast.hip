@@ -751,9 +751,12 @@ __global__ __launch_bounds__(64 * FC_WAVES) void k_fast_cells(const uint8_t* __r
 
 // Rows per (strip, segment) work item.  A wavefront lives for the whole item, so long segments leave a long under-filled
 // tail at the end of the launch (96 rows: +20 % kernel time over 24..32), and the NMS tile of a region has to fit its LDS.
-// A single frame has only ~160 items of 24 rows for 1024 SIMDs: short segments (8 rows of work under 8 halo rows) spread it over
-// three times as many wavefronts and halve the time of the launch.
-int fast_rows_per_seg(int batch) { return batch <= 2 ? 8 : FS_ROWS_MAX; }
+// A single frame has only ~160 items of 24 rows for 1024 SIMDs: short segments spread it over more wavefronts and shorten the launch.  A
+// wavefront streams its rows + 8 in blocks of 7: 6 rows of work are exactly two blocks (8 rows take three: 20 -> 16 us for one frame).
+#ifndef UVO_FAST_ROWS_FEW
+#define UVO_FAST_ROWS_FEW 6
+#endif
+int fast_rows_per_seg(int batch) { return batch <= 2 ? UVO_FAST_ROWS_FEW : FS_ROWS_MAX; }
 int fast_items_per_frame(const Geom& g, int rows_per_seg) {
   int items = 0;
   for (int l = 0; l < g.nlevels; ++l) {
