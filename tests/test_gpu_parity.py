@@ -1539,3 +1539,49 @@ def test_bow_transform_and_search_on_a_vocabulary_of_orbvoc_shape(uvo, oracle, s
         assert ng == no
     m.close()
     V.close()
+
+
+@pytest.mark.parametrize("knobs", [{}, {"UVO_TUNE_FEW_FRAMES": 0}, {"UVO_TUNE_ZERO_COPY_OUT": 0}, {"UVO_TUNE_SPIN_WAIT": 0}, {"UVO_TUNE_ZERO_COPY_OUT": 0, "UVO_TUNE_SPIN_WAIT": 0},
+                                   {"UVO_TUNE_OCT_WIDE_MAX": 256}, {"UVO_TUNE_OCT_WIDE_MAX": 256, "UVO_TUNE_SIDE_BLUR": 0}, {"UVO_TUNE_PYR_FORM": 1},
+                                   {"UVO_TUNE_FEW_FRAMES": 0, "UVO_TUNE_OCT_WIDE_MAX": 256, "UVO_TUNE_ZERO_COPY_OUT": 0, "UVO_TUNE_PYR_FORM": 1}])
+def test_single_frame_launch_shapes_give_the_same_bytes(uvo, oracle, frames, knobs):
+    """The short launch chain of one or two frames (k_pyr_tiles, the quad-tree sharing its launch with the blur -- or its 1024-thread form
+    with the blur in a side stream --, FullDetect without k_assemble, results written into page-locked memory, small inputs read from it, the
+    bounded busy wait) against the launches of a large batch, knob by knob: FullDetect of one frame and of two, the top-up call with caller
+    keypoints and grid (src/ORBextractor.cc:861-913), and the tracked form (src/Tracking.cc:896-946) -- always the oracle's bytes."""
+    ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=640, max_height=512, max_batch=2, max_input_keypoints=600)
+    for k, v in knobs.items():
+        ex.tune(getattr(uvo, k), v)
+    oe = oracle.extractor(1000, 1.2, 8, 20)
+    rng = np.random.default_rng(23)
+    min_px = 20
+    rows, cols = 512 // min_px + 2, 640 // min_px + 2
+    for rep in range(2):   # the second round runs on the lane state the first left behind
+        for img in frames[:2]:
+            kp_o, de_o = oe(img)
+            kp_g, de_g = ex(img)
+            _assert_same_features(kp_g, de_g, kp_o, de_o, "FullDetect %s" % knobs)
+        both = ex.extract_batch(np.stack(frames[:2]))
+        for b in range(2):
+            kp_o, de_o = oe(frames[b])
+            _assert_same_features(both[b][0], both[b][1], kp_o, de_o, "batch of two, frame %d %s" % (b, knobs))
+        for n_in, need in ((300, 700), (0, 1000), (7, 30)):
+            kin = np.zeros(n_in, uvo.KEYPOINT_DTYPE)
+            kin["x"] = rng.uniform(20, 619, n_in).astype(np.float32)
+            kin["y"] = rng.uniform(20, 491, n_in).astype(np.float32)
+            kin["size"], kin["angle"], kin["response"], kin["octave"], kin["class_id"] = 31, -1, rng.uniform(0, 99, n_in), 0, np.arange(n_in)
+            grid = np.zeros((rows, cols), np.int32, order="F")
+            for k in kin:
+                grid[int(k["y"] / min_px), int(k["x"] / min_px)] += 1
+            g_gpu, g_orc = grid.copy(order="F"), grid.copy(order="F")
+            kp_g, de_g = ex(frames[2], kin.copy(), g_gpu, min_px, False, need)
+            kp_o, de_o = oe(frames[2], kin.copy(), g_orc, min_px, False, need)
+            _assert_same_features(kp_g, de_g, kp_o, de_o, "top-up n_in=%d need=%d %s" % (n_in, need, knobs))
+            np.testing.assert_array_equal(g_gpu, g_orc)
+            # the tracked form: the keypoints only fill the grid, the extractor is called with an empty keypoint vector
+            kq, dq, gq = ex.extract_tracked(frames[2], kin, min_px, need, want_grid=True)
+            g2 = grid.copy(order="F")
+            kp_t, de_t = oe(frames[2], np.zeros(0, uvo.KEYPOINT_DTYPE), g2, min_px, False, need)
+            _assert_same_features(kq, dq, kp_t, de_t, "tracked n_in=%d need=%d %s" % (n_in, need, knobs))
+            np.testing.assert_array_equal(gq, g2)
+    ex.close()
