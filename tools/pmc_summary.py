@@ -54,8 +54,7 @@ def main():
     if calib:
         ff = calib.get("fetch_factor", {})
         width = {"k_pad_level0": "16B", "k_resize_level": "4B", "k_fast_score": "4B", "k_fast_cells": "4B", "k_fast_cells_list": "1B", "k_gauss7": "4B",
-                 "k_describe": "segments_40_of_704", "k_octree": "4B", "k_octree_gauss": "4B", "k_assemble": "4B", "k_knn2_mfma": "16B", "k_pyramid": "4B",
-                 "k_pyr_stream": "4B"}
+                 "k_describe": "segments_40_of_704", "k_octree": "4B", "k_octree_gauss": "4B", "k_assemble": "4B", "k_knn2_mfma": "16B", "k_pyr_tiles": "4B"}
         doc["_fetch_factor"] = {k: ff[w] for k, w in width.items() if w in ff}
         # k_describe reads two planes of equal footprint: the row-major un-blurred one in 32-byte row segments (requests tallied exactly)
         # and the tiled blurred one in whole 128-byte lines (tallied at one half): the mean of the two factors
