@@ -142,3 +142,37 @@ def test_extraction_only_and_bad_arguments(uvo, job):
     with pytest.raises(uvo.UvoError) as ei:
         uvo.Sharder(NFEAT, 1.2, 6, 20, max_width=W, max_height=H, devices=[uvo.UVO_SHARD_REMOTE], chunk_frames=4)
     assert ei.value.code == uvo.UVO_E_BADARG
+
+
+def test_thread_binds_next_to_the_gpu(uvo):
+    """uvo_host_bind_near_device on a real device: the calling thread ends up on CPUs of the device's local_cpulist (where sysfs
+    has one and the process may use them) and the NUMA node reported is the device's; a no-op otherwise.  In a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import importlib, os, sys, glob
+sys.path.insert(0, %r)
+uvo = importlib.import_module("u-vip-slam_amd")
+before = set(os.sched_getaffinity(0))
+bound, node = uvo.host_bind_near_device(0)
+after = set(os.sched_getaffinity(0))
+print(bound, node, len(before), len(after))
+assert after <= before and len(after) > 0
+if not bound:
+    assert after == before
+else:
+    lists = [open(p).read().strip() for p in glob.glob("/sys/bus/pci/devices/*/local_cpulist")]
+    def cpus(txt):
+        out = set()
+        for part in txt.split(","):
+            a, _, b = part.partition("-")
+            out |= set(range(int(a), int(b or a) + 1))
+        return out
+    assert any(after <= cpus(t) for t in lists if t), "the mask is no subset of any device's local_cpulist"
+os.environ["UVO_NUMA_BIND"] = "0"
+""" % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    print("bind_near_device:", out.stdout.strip().splitlines()[-1])
