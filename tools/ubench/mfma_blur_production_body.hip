@@ -19,6 +19,7 @@
 //                floor(sum / 65536 + .5) for the scalar-tail columns and for the half-up contract (gauss_body.hpp).
 // A wavefront owns a strip of 64 columns (two MFMA tiles) and walks down the row blocks; a block's 32 x 64 outputs go through 2 KB of
 // LDS in the tiled layout and leave as whole 128-byte lines.  6 MFMAs + ~7 vector instructions per pixel instead of ~18.
+#if 0  // a record, not a translation unit: the includes below are those of csrc/
 #pragma once
 #include "common.hpp"
 
@@ -213,3 +214,5 @@ __device__ __forceinline__ void gauss_mfma_body(int item, int f, uint32_t* stile
 }
 
 }  // namespace uvo
+
+#endif
