@@ -376,6 +376,7 @@ def main():
     # Host placement before any host buffer exists: this rank's thread goes to the CPUs next to its GPU's PCIe link, so that the frames
     # it generates below and its slice of the gather region are first touched -- and page-locked -- on that NUMA node (N ranks on a
     # two-socket host would otherwise all pull their 84 MB per step from wherever the first rank's pages happened to land)
+    all_cpus = os.sched_getaffinity(0)   # (the CPU baseline at the end runs on every core the process was given, not on one socket)
     numa_bound, numa_node = uvo.host_bind_near_device(local_rank)
     dev = torch.device("cuda", local_rank)
     red_dev = None if dry else dev   # where the tensors of the barrier-side reductions live (gloo: host)
@@ -847,6 +848,7 @@ def main():
             "sub_records": sub,
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
+            os.sched_setaffinity(0, all_cpus)
             out["cpu_baseline"] = cpu_baseline(frames[:B], cfg, c4_cpu)
         print(json.dumps(out))
     if dist is not None:
