@@ -43,6 +43,7 @@ CONFIGS = {
     3: dict(name="BASELINE.json configs[3]", W=1920, H=1080, nfeat=2000, batch=128, n_shapes=2500, steps=30),
 }
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the measured device-copy rate is reported beside it
+PROFILE_TAG = "r06_final"      # the round checkpoint under profiles/ that holds this build's rocprofv3 summaries (tools/round_checkpoint.sh)
 VALU_PEAK_GINSTR = 1228.8        # wave-instructions/s the chip can issue: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 op on a SIMD32
 
 
@@ -69,6 +70,7 @@ def algorithmic_bytes_per_frame(w, h, k):
         "k_gauss7": 2 * tot,
         "k_octree_gauss": 2 * tot,                      # the quad-tree and the blur as one launch: the blur's bytes
         "k_fast_blur": 3 * tot,                         # the fused form: one read serves FAST and the blur, one write
+        "k_fast_score_gauss": 3 * tot,                  # FAST and the blur as one launch (small batches): each reads the levels, the blur writes them
         "k_octree": 0,
         "k_assemble": 0,
         "k_describe": 749 * k + (512 + 32) * k + 20 * k,
@@ -328,6 +330,420 @@ def load_pmc(config):
     return {}, None, None
 
 
+class Ctx:
+    """what every leg of the run needs: the package, torch, the process group and this rank's place in it"""
+
+
+def make_frames(ctx, cfg, B, first, halo, distinct=None):
+    """This rank's B frames of the global synthetic sequence + the halo frame (slot B), in page-locked host memory.  distinct = n: only the
+    first n frames of the block are generated (a 1920x1080 frame takes the generator 0.3 s); the block is filled with them and their three
+    mirror images in turn (left-right, up-down, both: the same corner statistics, different bytes) -- every slot still holds a different image."""
+    uvo, synth = ctx.uvo, ctx.synth
+    W, H = cfg["W"], cfg["H"]
+    frames = uvo.pinned_empty((B + 1, H, W), np.uint8)
+    if distinct is None or distinct >= B:
+        frames[:B] = synth.make_sequence(first, B, W, H, n_shapes=cfg["n_shapes"])
+        frames[B] = synth.make_sequence(halo, 1, W, H, n_shapes=cfg["n_shapes"])[0]
+        return frames
+    base = synth.make_sequence(first, distinct, W, H, n_shapes=cfg["n_shapes"])
+    for i in range(B + 1):
+        a, k = base[i % distinct], (i // distinct) % 4
+        if k & 1:
+            a = a[:, ::-1]
+        if k & 2:
+            a = a[::-1, :]
+        frames[i] = a
+    return frames
+
+
+def link_probe(ctx, nbytes=256 << 20, reps=4):
+    """What this rank's host link can do: page-locked host memory <-> HBM copy rates of one 256 MB buffer (up, down, both directions at
+    once), measured on ALL ranks at the same time behind one barrier -- the rates the ranks get while their neighbours pull too."""
+    torch, dist = ctx.torch, ctx.dist
+    h = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    d = [torch.empty(nbytes, dtype=torch.uint8, device=ctx.dev) for _ in range(2)]
+    st = [torch.cuda.Stream(device=ctx.dev) for _ in range(2)]
+
+    def run(up, down):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            if up:
+                with torch.cuda.stream(st[0]):
+                    d[0].copy_(h[0], non_blocking=True)
+            if down:
+                with torch.cuda.stream(st[1]):
+                    h[1].copy_(d[1], non_blocking=True)
+        torch.cuda.synchronize()
+        return reps * nbytes / (time.perf_counter() - t0) / 1e9
+
+    run(True, True)   # first touch of both buffers
+    out = {"h2d_GBps": round(run(True, False), 2), "d2h_GBps": round(run(False, True), 2), "both_directions_each_GBps": round(run(True, True), 2)}
+    del h, d
+    return out
+
+
+class HbmWorkload:
+    """One rank's share of a configuration, HBM-resident: extractor + matcher handles, the ring of input batches, double-buffered
+    outputs, and the step the benchmark times (uvo_extract_batch_device + uvo_hamming_knn2_batch_device)."""
+    NRING = 4
+
+    def __init__(self, ctx, cfg, B, frames, depth, fast_mode="adaptive", own_stream=False, env_knobs=False):
+        torch, uvo = ctx.torch, ctx.uvo
+        self.ctx, self.cfg, self.B, self.frames, self.DEPTH, self.own_stream = ctx, cfg, B, frames, depth, own_stream
+        W, H, NFEAT = cfg["W"], cfg["H"], cfg["nfeat"]
+        self.W, self.H, self.NFEAT = W, H, NFEAT
+        dev = ctx.dev
+        # four distinct input batches, read in turn by consecutive steps: the sequence and its mirror images (left-right, up-down, both) --
+        # the same corner statistics, different bytes, so that no step finds its input in the Infinity Cache of the step before
+        self.d_ring = [torch.from_numpy(frames).to(dev)]
+        for k in range(1, self.NRING):
+            self.d_ring.append(torch.flip(self.d_ring[0], dims=[d for d, on in ((2, k & 1), (1, k & 2)) if on]).contiguous())
+        self.ex = ex = uvo.ORBextractor(NFEAT, SCALE, NLEVELS, 0, FAST_TH, max_width=W, max_height=H, max_batch=B + 1, device=ctx.local_rank)
+        self.cap = cap = ex.cap
+        self.mt = uvo.ORBmatcher(0.8, max_query=cap, max_train=cap, max_batch=B, device=ctx.local_rank)
+
+        # outputs stay in HBM, double buffered: with pipeline depth 2 the extractor alternates between two scratch sets / streams, so
+        # batch i+1's streaming stages overlap batch i's latency-bound stages and its matching.
+        class Out:
+            def __init__(self):
+                self.kp = torch.zeros((B + 1, cap, 7), dtype=torch.float32, device=dev)
+                self.desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
+                self.n = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+                self.idx0 = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+                self.idx1 = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+                self.d0 = torch.zeros((B, cap), dtype=torch.int16, device=dev)
+                self.d1 = torch.zeros((B, cap), dtype=torch.int16, device=dev)
+
+        self.outs = [Out() for _ in range(depth)]
+        ex.set_pipeline(depth)
+        ex.tune(uvo.UVO_TUNE_FAST_MODE, {"adaptive": uvo.UVO_FAST_MODE_ADAPTIVE, "two_pass": uvo.UVO_FAST_MODE_TWO_PASS,
+                                         "single_pass": uvo.UVO_FAST_MODE_SINGLE_PASS}[fast_mode])
+        if env_knobs:
+            self._env_knobs()
+        torch.cuda.synchronize()
+        self.counter = [0]
+        self.lane_variant = [0] * depth   # which input batch a lane's output buffers hold
+
+    def _env_knobs(self):
+        ex, uvo = self.ex, self.ctx.uvo
+        if os.environ.get("UVO_BENCH_PYR_FORM"):   # experiment knob: 0 auto / 1 per-level launches / 2 k_pyr_tiles
+            ex.tune(uvo.UVO_TUNE_PYR_FORM, int(os.environ["UVO_BENCH_PYR_FORM"]))
+        if os.environ.get("UVO_BENCH_PYR_GROUPS"):   # experiment knob: forced level groups of k_pyr_tiles, "first:txXty[w],..."
+            for g_ in os.environ["UVO_BENCH_PYR_GROUPS"].split(","):
+                first_, grid_ = g_.split(":")
+                tx_, ty_ = grid_.rstrip("wr").split("x")
+                ex.tune(uvo.UVO_TUNE_PYR_TILE_GROUP, (1 << 24 if grid_.endswith("w") else 0) | (1 << 25 if grid_.endswith("r") else 0) | int(first_) << 16 | int(tx_) << 8 | int(ty_))
+        if os.environ.get("UVO_BENCH_BLUR_ROUNDING"):   # experiment knob: 0 = half up on every column, 1 = the x86-64 contract (default)
+            ex.tune(uvo.UVO_TUNE_BLUR_ROUNDING, int(os.environ["UVO_BENCH_BLUR_ROUNDING"]))
+        if os.environ.get("UVO_BENCH_FUSE"):   # experiment knob: quad-tree + blur as one launch (1, default) or two (0)
+            ex.tune(uvo.UVO_TUNE_FUSE_BLUR_TREE, int(os.environ["UVO_BENCH_FUSE"]))
+        if os.environ.get("UVO_BENCH_L0"):   # experiment knob: level 0 read in place (1, default) or copied into a padded plane first (0)
+            ex.tune(uvo.UVO_TUNE_LEVEL0_INPLACE, int(os.environ["UVO_BENCH_L0"]))
+        if os.environ.get("UVO_BENCH_RING"):   # experiment knob: border pixels the resize launches write around a level (4 default, 0 = all 16)
+            ex.tune(uvo.UVO_TUNE_PYR_RING, int(os.environ["UVO_BENCH_RING"]))
+        if os.environ.get("UVO_BENCH_STAGGER"):   # experiment knob: lane stagger classes (bit 0 FAST pass, 1 quad-tree + blur, 2 pyramid)
+            ex.tune(uvo.UVO_TUNE_LANE_STAGGER, int(os.environ["UVO_BENCH_STAGGER"]))
+        if os.environ.get("UVO_BENCH_OCT_WIDE_MAX"):   # experiment knob: quad-tree launch shape (uvo_extractor_tune)
+            ex.tune(uvo.UVO_TUNE_OCT_WIDE_MAX, int(os.environ["UVO_BENCH_OCT_WIDE_MAX"]))
+
+    def host_variant(self, k):
+        a = self.frames
+        if k & 1:
+            a = a[:, :, ::-1]
+        if k & 2:
+            a = a[:, ::-1, :]
+        return np.ascontiguousarray(a)
+
+    def extract_only(self):
+        li, k = self.counter[0] % self.DEPTH, self.counter[0] % self.NRING
+        o = self.outs[li]
+        self.lane_variant[li] = k
+        self.counter[0] += 1
+        self.ex.extract_batch_device(self.d_ring[k].data_ptr(), self.B + 1, self.W, self.H, o.kp.data_ptr(), o.desc.data_ptr(), o.n.data_ptr(), self.cap)
+        return o
+
+    # The matching of a batch runs in the stream of the pipeline lane that extracted it (uvo_matcher_attach_extractor); with
+    # --matcher-stream own it runs in the matcher's own stream behind an event, and the lane waits for another event before its next batch
+    # (two hand-offs between queues per batch: the lane idles 0.3 ms around a 0.13 ms kernel, tools/step_trace_summary.py).
+    def step(self):
+        o, mt, ex, B, cap = self.extract_only(), self.mt, self.ex, self.B, self.cap
+        if self.own_stream:
+            mt.wait_extractor(ex)
+        else:
+            mt.attach(ex)
+        # pair p = (frame p, frame p + 1), p < B; pair B-1's partner is the halo frame in slot B
+        mt.knn2_batch_device(B, o.desc.data_ptr(), o.n.data_ptr(), cap, o.desc.data_ptr() + cap * 32, o.n.data_ptr() + 4, cap,
+                             o.idx0.data_ptr(), o.d0.data_ptr(), o.idx1.data_ptr(), o.d1.data_ptr())
+        if self.own_stream:
+            mt.release_to_extractor(ex)
+
+    def sync_all(self):
+        self.ex.synchronize()
+        self.mt.synchronize()
+        self.ctx.torch.cuda.synchronize()
+
+    def kernel_times(self):
+        """{kernel: (ms, launches)}, {kernel: spread rows} of both handles since profiling was switched on"""
+        kt = dict(self.ex.kernel_times())
+        sp = dict(self.ex.last_spread)
+        kt.update(self.mt.kernel_times())
+        sp.update(self.mt.last_spread)
+        return kt, sp
+
+    def profile(self, on, only=None):
+        if not on:
+            self.ex.profile(False)
+            self.mt.profile(False)
+        elif only is None:
+            self.ex.profile(True)
+            self.mt.profile(True)
+        elif only == "k_knn2":
+            self.mt.profile(True)
+        else:
+            self.ex.profile(True, only=only)
+
+    def measure(self, steps, warmup, n_serial=3):
+        """warm-up; the per-kernel durations at pipeline depth 1 (they name the dominant kernel); then the TIMED region: exactly `steps`
+        steps between barrier + device sync on both sides, only the dominant kernel's launches carrying events.  -> dict"""
+        ctx = self.ctx
+        for _ in range(warmup + self.DEPTH):
+            self.step()
+        self.sync_all()
+        serial = {}
+        dom = "k_fast_score"
+        if os.environ.get("UVO_BENCH_SKIP_SERIAL") != "1":   # (profile collection: a run that holds launches of ONE pipeline depth only)
+            # Per-kernel durations first, without cross-batch overlap (pipeline depth 1, every launch bracketed by HIP events on the
+            # library's stream; untimed steps): they name the dominant kernel.
+            self.ex.set_pipeline(1)
+            self.profile(True)
+            for _ in range(n_serial):
+                self.step()
+            self.sync_all()
+            serial, _ = self.kernel_times()
+            self.profile(False)
+            self.ex.set_pipeline(self.DEPTH)
+            for _ in range(self.DEPTH):
+                self.step()
+            self.sync_all()
+            dom = max(serial.items(), key=lambda kv: kv[1][0])[0]
+        # Timed region: only the dominant kernel's launches carry events (two event records around each of the ~14 launches of a
+        # step cost 3 % of the throughput; the roofline needs the live duration of this one kernel only).
+        self.profile(True, only=dom)
+        dt = timed_steps(self.step, self.sync_all, steps, ctx.dist, ctx.red_dev)
+        ktimes, spread = self.kernel_times()
+        self.profile(False)
+        return {"dt": dt, "dom": dom, "serial": serial, "n_serial": n_serial, "ktimes": ktimes, "spread": spread.get(dom, {}), "timed_variants": list(self.lane_variant)}
+
+    def live_pass(self, n_live):
+        """the same pipelined step with every launch bracketed by events (outside the timed region: the event records cost 3 % of the
+        throughput) -- what each kernel takes with the other lane's kernels beside it"""
+        self.profile(True)
+        for _ in range(n_live):
+            self.step()
+        self.sync_all()
+        live, _ = self.kernel_times()
+        self.profile(False)
+        return live
+
+    def download(self, o):
+        B, cap = self.B, self.cap
+        return dict(n=o.n.cpu().numpy(), kp=o.kp.cpu().numpy().view(np.uint8).reshape(B + 1, cap, 28), de=o.desc.cpu().numpy(), i0=o.idx0.cpu().numpy(),
+                    i1=o.idx1.cpu().numpy(), d0=o.d0.cpu().numpy().astype(np.uint16), d1=o.d1.cpu().numpy().astype(np.uint16))
+
+    def verify(self, host, timed_variants, pairs):
+        """outputs of the timed buffers (both lanes' last results, already on the host) against the CPU oracle; a mismatch fails the run"""
+        import oracle_lib
+        orc = oracle_lib.Oracle()
+        oe = orc.extractor(self.NFEAT, SCALE, NLEVELS, FAST_TH)
+        need = sorted(set(pairs) | set(p + 1 for p in pairs))
+        for li, hb in enumerate(host):
+            hv = self.host_variant(timed_variants[li])
+            ref = {f: oe(hv[f]) for f in need}
+            for f in need:
+                kp_o, de_o = ref[f]
+                n = int(hb["n"][f])
+                if n != len(kp_o) or hb["kp"][f, :n].tobytes() != kp_o.tobytes() or not (hb["de"][f, :n] == de_o).all():
+                    raise SystemExit("bench.py: VERIFICATION FAILED -- %s lane %d frame %d of the timed buffers differs from the oracle" % (self.cfg["name"], li, f))
+            for p in pairs:
+                r = orc.knn2(ref[p][1], ref[p + 1][1])
+                nq = len(ref[p][1])
+                got = (hb["i0"][p, :nq], hb["d0"][p, :nq].astype(np.int32), hb["i1"][p, :nq], hb["d1"][p, :nq].astype(np.int32))
+                if not all((g == e).all() for g, e in zip(got, r)):
+                    raise SystemExit("bench.py: VERIFICATION FAILED -- %s lane %d knn-2 rows of pair %d differ from the oracle" % (self.cfg["name"], li, p))
+        return {"frames": len(need) * len(host), "distinct_frames": need, "knn2_pairs": list(pairs), "lanes": len(host), "input_batches_of_the_lanes": timed_variants,
+                "against": "CPU oracle (this repo's restatement of the reference; parity unpinned), byte for byte"}
+
+    def close(self):
+        self.ex.close()
+        self.mt.close()
+        self.d_ring, self.outs = None, None
+
+
+def step_spread(m, steps, depth=2):
+    """min / median / max of the step's period inside the timed region, from the HIP events around the dominant kernel's launches (one per
+    step): with two pipeline lanes taking the steps in turn, half the start-to-start time of launches two apart (one lane's period per
+    step); `lane_offset_ms` = start-to-start of consecutive launches (the phase between the lanes); and that kernel's own launch duration"""
+    sp = m["spread"]
+    key = "period2_" if depth >= 2 else "period_"
+    if key + "p50" not in sp:
+        return None
+    out = {"ms_min": round(sp[key + "min"], 4), "ms_median": round(sp[key + "p50"], 4), "ms_max": round(sp[key + "max"], 4), "samples": steps - (2 if depth >= 2 else 1),
+           "what": "%s of %s launches inside the timed region (one per step, HIP events on the lanes' streams, enqueue order); `ms_per_step` is the mean "
+                   "over the whole region on the host clock" % ("half the start-to-start time of launches two apart (= one pipeline lane's period per step)" if depth >= 2
+                                                                 else "start-to-start time of consecutive", m["dom"]),
+           "dominant_kernel_launch_ms": {"min": round(sp["min"], 4), "median": round(sp["p50"], 4), "max": round(sp["max"], 4)}}
+    if depth >= 2 and "period_p50" in sp:
+        out["lane_offset_ms"] = {"min": round(sp["period_min"], 4), "median": round(sp["period_p50"], 4), "max": round(sp["period_max"], 4),
+                                 "what": "start-to-start of consecutive launches (alternating lanes): how far apart the two lanes run the same stage"}
+    return out
+
+
+def host_to_host_leg(ctx, wl, first, steps, link):
+    """The sharder (uploads from page-locked frames, results gathered into ONE host region shared by all ranks): north_star's "extract +
+    match with a final pinned hipMemcpyAsync gather".  The gathered region is compared with the HBM-resident outputs of the same frames."""
+    uvo, torch, dist, rank, world = ctx.uvo, ctx.torch, ctx.dist, ctx.rank, ctx.world
+    B, W, H, NFEAT, frames, cap = wl.B, wl.W, wl.H, wl.NFEAT, wl.frames, wl.cap
+    total = world * B
+    chunk = max(B // int(os.environ.get("UVO_BENCH_CHUNKS", "2")), 1)   # chunks per rank and job, two in flight: the upload of one under the kernels of the other
+    devices = [uvo.UVO_SHARD_REMOTE] * world
+    devices[rank] = ctx.local_rank
+    sh = uvo.Sharder(NFEAT, SCALE, NLEVELS, FAST_TH, max_width=W, max_height=H, devices=devices, chunk_frames=chunk, match=True)
+    scap = sh.cap
+    assert scap == cap
+    sizes = [((total, scap), uvo.KEYPOINT_DTYPE), ((total, scap, 32), np.uint8), ((total,), np.int32), ((total, scap), np.int32),
+             ((total, scap), np.uint16), ((total, scap), np.int32), ((total, scap), np.uint16)]
+    nbytes = sum(int(np.prod(s)) * np.dtype(t).itemsize + 256 for s, t in sizes)
+    # two gather regions: a stream of jobs keeps two in flight (job k+1 is submitted before job k is waited for), each gathers into its own
+    region = SharedHostRegion(uvo, 2 * nbytes, rank, world, dist)
+    sets, off = [], 0
+    for _ in range(2):
+        arrs = []
+        for s, t in sizes:
+            a, off = region.carve(off, s, t)
+            arrs.append(a)
+        sets.append(arrs)
+    region.register([a[first:first + B] for arrs in sets for a in arrs], dist)
+    g_kp, g_de, g_n, g_i0, g_d0, g_i1, g_d1 = sets[0]
+    jobs = [0]
+    pending = [None]
+
+    def h2h_run():
+        # frames of this rank start at global index `first`; its halo frame sits right behind them in `frames` (for the last
+        # rank the job simply ends there: the wrap-around pair exists only in the HBM-resident leg).  One call = one job submitted;
+        # the job before it is waited for afterwards, so two are in flight and the lanes never drain.
+        t = sh.submit(frames, first, total, *sets[jobs[0] % 2])
+        jobs[0] += 1
+        if pending[0] is not None:
+            sh.wait(pending[0])
+        pending[0] = t
+
+    def h2h_drain():
+        if pending[0] is not None:
+            sh.wait(pending[0])
+            pending[0] = None
+
+    for _ in range(3):
+        h2h_run()
+    h2h_drain()
+    reps = max(6, min(30, steps // 4))
+    dth = timed_steps(h2h_run, h2h_drain, reps, dist, ctx.red_dev)
+    # the gathered region must hold exactly what the HBM-resident leg produces for the same frames (input batch 0 of the ring;
+    # this rank's block; pair B-1 only where the halo is the true next frame)
+    wl.counter[0] = 0
+    wl.step()
+    wl.sync_all()
+    hb = wl.download(wl.outs[0])
+    ok = (g_n[first:first + B] == hb["n"][:B]).all()
+    for f in range(B):
+        n = int(hb["n"][f])
+        ok = ok and g_kp[first + f, :n].tobytes() == hb["kp"][f, :n].tobytes() and (g_de[first + f, :n] == hb["de"][f, :n]).all()
+    npairs = B if first + B < total else B - 1
+    for p in range(npairs):
+        nq = int(hb["n"][p])
+        ok = ok and (g_i0[first + p, :nq] == hb["i0"][p, :nq]).all() and (g_d0[first + p, :nq] == hb["d0"][p, :nq]).all() and \
+            (g_i1[first + p, :nq] == hb["i1"][p, :nq]).all() and (g_d1[first + p, :nq] == hb["d1"][p, :nq]).all()
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctx.red_dev if ctx.red_dev is not None else "cpu")
+    if dist is not None:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        raise SystemExit("bench.py: VERIFICATION FAILED -- %s: the gathered host region differs from the HBM-resident outputs" % wl.cfg["name"])
+    if rank == 0 and world > 1:   # rank 0 sees every rank's block in the one region
+        assert (g_n[:total] > 0).all(), "a rank's block is missing from the gathered region"
+    up = B * W * H + (W * H if first + B < total else 0)
+    down = B * scap * (28 + 32) + B * 4 + npairs * scap * 12
+    job_s = dth / reps
+    h2h = {"value": round(total * reps / dth, 1), "unit": "frames/s", "ms_per_job": round(job_s * 1e3, 3), "frames_per_job": total,
+           "chunk_frames": chunk, "jobs_in_flight": 2, "pcie_bytes_up_per_rank": up, "pcie_bytes_down_per_rank": down, "gather": "device-to-host copies at precomputed "
+           "offsets of one page-locked region shared by all ranks (%s)" % ("uvo_host_alloc" if world == 1 else "/dev/shm mapping + uvo_host_register" +
+                                                                              ("" if region.registered else " [registration failed: pageable]")),
+           "gathered_equals_hbm_resident": True}
+    # what the leg does against what the rank's link can do: the upload is the long direction (PCIe is full duplex: the gather rides the
+    # other one), so h2h_frac = upload bytes / (job time x the link's measured host-to-device rate)
+    mine = {"rank": rank, "numa_node": ctx.numa_node, "bound_to_local_cpus": bool(ctx.numa_bound), "up_GBps_in_the_leg": round(up / job_s / 1e9, 2),
+            "down_GBps_in_the_leg": round(down / job_s / 1e9, 2)}
+    if link is not None:
+        mine["link_GBps"] = link
+        mine["h2h_frac"] = round(up / job_s / 1e9 / link["h2d_GBps"], 4) if link["h2d_GBps"] > 0 else None
+    per_rank = [None] * world
+    if dist is not None:
+        dist.all_gather_object(per_rank, mine)
+    else:
+        per_rank = [mine]
+    h2h["numa"] = per_rank   # per rank: the NUMA node of its GPU, whether its thread (frames, gather slice, sharder staging) was bound to that node's CPUs,
+    #                          the measured link rates (all ranks copying at once) and the share of the link the leg's upload reaches
+    if link is not None:
+        h2h["link_GBps"] = per_rank[0]["link_GBps"]
+        fr = [r["h2h_frac"] for r in per_rank if r.get("h2h_frac") is not None]
+        h2h["h2h_frac"] = round(min(fr), 4) if fr else None
+        h2h["h2h_frac_note"] = "upload bytes per job / (job time x the rank's measured page-locked host-to-device rate; all ranks probe their links at the same time); min over ranks"
+    sh.close()
+    region.close(rank, dist)
+    return h2h
+
+
+def config3_record(ctx, steps, link):
+    """configs[3] on this run's clock: one GPU's share (batch 128 @ 1920x1080, 2000 feats) HBM-resident, verified against the oracle; with
+    several ranks also the real shape -- world x 128 frames through the sharder with the host gather (src/Tracking.cc:946 per frame)."""
+    cfg = CONFIGS[3]
+    B = int(os.environ.get("UVO_BENCH_C3_BATCH", cfg["batch"]))
+    first, halo = shard_frames(ctx.rank, ctx.world, B)
+    frames = make_frames(ctx, cfg, B, first, halo, distinct=32)
+    wl = HbmWorkload(ctx, cfg, B, frames, 2)
+    m = wl.measure(steps, 2, n_serial=2)
+    host = [wl.download(o) for o in wl.outs]
+    rec = None
+    if ctx.rank == 0:
+        value = B * steps * ctx.world / m["dt"]
+        n_kp = host[0]["n"][:B]
+        alg = algorithmic_bytes_per_frame(cfg["W"], cfg["H"], float(n_kp.mean()))
+        total_alg = sum(v for k, v in alg.items() if k not in ("k_pad_level0", "k_fast_blur", "k_fast_score_gauss", "k_pyr_tiles", "k_octree_gauss"))
+        dom = m["dom"]
+        dom_ms, dom_launches = m["ktimes"][dom]
+        per_launch = alg.get(dom, 0) * (B + 1) / (dom_launches / steps)
+        live_s = dom_ms * 1e-3 / dom_launches
+        rec = {"value": round(value, 1), "unit": "frames/s", "n_gpus": ctx.world, "steps": steps, "ms_per_step": round(m["dt"] / steps * 1e3, 4),
+               "workload": "%s share of one GPU: batch=%d synthetic %dx%d frames per rank (+1 halo), %d feats, %d levels, fastTh %d, extract + all-pairs knn-2 of "
+                           "consecutive frames, HBM-resident I/O; frames = a 32-frame chain of the generator and its three mirror images"
+                           % (cfg["name"], B, cfg["W"], cfg["H"], cfg["nfeat"], NLEVELS, FAST_TH),
+               "mean_keypoints_per_frame": round(float(n_kp.mean()), 1), "step_spread": step_spread(m, steps),
+               "whole_path_frac": round(total_alg * value / ctx.world / 1e9 / HBM_PEAK_GBS, 5),
+               "whole_path_algorithmic_bytes_per_frame": int(total_alg),
+               "roofline": {"bound": "hbm", "kernel": dom, "avg_launch_ms": round(live_s * 1e3, 5), "algorithmic_bytes_per_launch": int(per_launch),
+                            "achieved": round(per_launch / live_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(per_launch / live_s / 1e9 / HBM_PEAK_GBS, 5),
+                            "kernel_ms_per_step_unoverlapped": {k: round(v[0] / m["n_serial"], 4) for k, v in sorted(m["serial"].items())}},
+               "verification": wl.verify(host, m["timed_variants"], [0, B - 1])}
+        rec["verified_frames"] = rec["verification"]["frames"]
+    if ctx.world > 1:   # the real shape: world x 128 frames, host in, host gather
+        h2h = host_to_host_leg(ctx, wl, first, steps, link)
+        if rec is not None:
+            rec["host_to_host"] = h2h
+    wl.close()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -339,6 +755,7 @@ def main():
     ap.add_argument("--no-subrecords", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--h2h", action="store_true", help="run the host-to-host sharder leg even with --no-subrecords")
+    ap.add_argument("--c3", action="store_true", help="run the configs[3] record even with --no-subrecords")
     ap.add_argument("--matcher-stream", choices=["lane", "own"], default="lane",
                     help="where the matching of a batch is enqueued: in the extracting lane's stream (default) or in the matcher's own stream behind events")
     ap.add_argument("--fast-mode", choices=["adaptive", "two_pass", "single_pass"], default="adaptive",
@@ -379,270 +796,54 @@ def main():
     all_cpus = os.sched_getaffinity(0)   # (the CPU baseline at the end runs on every core the process was given, not on one socket)
     numa_bound, numa_node = uvo.host_bind_near_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    red_dev = None if dry else dev   # where the tensors of the barrier-side reductions live (gloo: host)
+    ctx = Ctx()
+    ctx.uvo, ctx.synth, ctx.torch, ctx.dist, ctx.rank, ctx.local_rank, ctx.world, ctx.dev, ctx.dry = uvo, synth, torch, dist, rank, local_rank, world, dev, dry
+    ctx.red_dev = None if dry else dev   # where the tensors of the barrier-side reductions live (gloo: host)
+    ctx.numa_bound, ctx.numa_node = numa_bound, numa_node
 
     # this rank's shard of the global sequence + the neighbour's first frame, in page-locked host memory (the host-to-host leg uploads
     # from here); slot B of the device copy is the halo
     first, halo = shard_frames(rank, world, B)
-    frames = uvo.pinned_empty((B + 1, H, W), np.uint8)
-    frames[:B] = synth.make_sequence(first, B, W, H, n_shapes=cfg["n_shapes"])
-    frames[B] = synth.make_sequence(halo, 1, W, H, n_shapes=cfg["n_shapes"])[0]
-    # four distinct input batches, read in turn by consecutive steps: the sequence and its mirror images (left-right, up-down, both) --
-    # the same corner statistics, different bytes, so that no step finds its 84 MB of input in the Infinity Cache of the step before
-    NRING = 4
-    d_ring = [torch.from_numpy(frames).to(dev)]
-    for k in range(1, NRING):
-        d_ring.append(torch.flip(d_ring[0], dims=[d for d, on in ((2, k & 1), (1, k & 2)) if on]).contiguous())
-    d_imgs = d_ring[0]
-
-    def host_variant(k):
-        a = frames
-        if k & 1:
-            a = a[:, :, ::-1]
-        if k & 2:
-            a = a[:, ::-1, :]
-        return np.ascontiguousarray(a)
-
-    ex = uvo.ORBextractor(NFEAT, SCALE, NLEVELS, 0, FAST_TH, max_width=W, max_height=H, max_batch=B + 1, device=local_rank)
-    cap = ex.cap
-    mt = uvo.ORBmatcher(0.8, max_query=cap, max_train=cap, max_batch=B, device=local_rank)
-
-    # outputs stay in HBM, double buffered: with pipeline depth 2 the extractor alternates between two scratch sets / streams, so
-    # batch i+1's streaming stages overlap batch i's latency-bound stages and its matching.
-    class Out:
-        def __init__(self):
-            self.kp = torch.zeros((B + 1, cap, 7), dtype=torch.float32, device=dev)
-            self.desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
-            self.n = torch.zeros(B + 1, dtype=torch.int32, device=dev)
-            self.idx0 = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-            self.idx1 = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-            self.d0 = torch.zeros((B, cap), dtype=torch.int16, device=dev)
-            self.d1 = torch.zeros((B, cap), dtype=torch.int16, device=dev)
-
+    frames = make_frames(ctx, cfg, B, first, halo, distinct=32 if (args.config == 3 and os.environ.get("UVO_BENCH_C3_DISTINCT", "1") == "1") else None)
     DEPTH = int(os.environ.get("UVO_PIPELINE_DEPTH", "2"))
-    outs = [Out() for _ in range(DEPTH)]
-    ex.set_pipeline(DEPTH)
-    ex.tune(uvo.UVO_TUNE_FAST_MODE, {"adaptive": uvo.UVO_FAST_MODE_ADAPTIVE, "two_pass": uvo.UVO_FAST_MODE_TWO_PASS,
-                                     "single_pass": uvo.UVO_FAST_MODE_SINGLE_PASS}[args.fast_mode])
-    if os.environ.get("UVO_BENCH_PYR_FORM"):   # experiment knob: 0 auto / 1 per-level launches / 2 k_pyr_tiles
-        ex.tune(uvo.UVO_TUNE_PYR_FORM, int(os.environ["UVO_BENCH_PYR_FORM"]))
-    if os.environ.get("UVO_BENCH_PYR_GROUPS"):   # experiment knob: forced level groups of k_pyr_tiles, "first:txXty[w],..."
-        for g_ in os.environ["UVO_BENCH_PYR_GROUPS"].split(","):
-            first_, grid_ = g_.split(":")
-            tx_, ty_ = grid_.rstrip("wr").split("x")
-            ex.tune(uvo.UVO_TUNE_PYR_TILE_GROUP, (1 << 24 if grid_.endswith("w") else 0) | (1 << 25 if grid_.endswith("r") else 0) | int(first_) << 16 | int(tx_) << 8 | int(ty_))
-    if os.environ.get("UVO_BENCH_BLUR_ROUNDING"):   # experiment knob: 0 = half up on every column, 1 = the x86-64 contract (default)
-        ex.tune(uvo.UVO_TUNE_BLUR_ROUNDING, int(os.environ["UVO_BENCH_BLUR_ROUNDING"]))
-    if os.environ.get("UVO_BENCH_FUSE"):   # experiment knob: quad-tree + blur as one launch (1, default) or two (0)
-        ex.tune(uvo.UVO_TUNE_FUSE_BLUR_TREE, int(os.environ["UVO_BENCH_FUSE"]))
-    if os.environ.get("UVO_BENCH_L0"):   # experiment knob: level 0 read in place (1, default) or copied into a padded plane first (0)
-        ex.tune(uvo.UVO_TUNE_LEVEL0_INPLACE, int(os.environ["UVO_BENCH_L0"]))
-    if os.environ.get("UVO_BENCH_RING"):   # experiment knob: border pixels the resize launches write around a level (4 default, 0 = all 16)
-        ex.tune(uvo.UVO_TUNE_PYR_RING, int(os.environ["UVO_BENCH_RING"]))
-    if os.environ.get("UVO_BENCH_OCT_WIDE_MAX"):   # experiment knob: quad-tree launch shape (uvo_extractor_tune)
-        ex.tune(uvo.UVO_TUNE_OCT_WIDE_MAX, int(os.environ["UVO_BENCH_OCT_WIDE_MAX"]))
-    torch.cuda.synchronize()
-    counter = [0]
-    lane_variant = [0] * DEPTH   # which input batch a lane's output buffers hold
+    wl = HbmWorkload(ctx, cfg, B, frames, DEPTH, fast_mode=args.fast_mode, own_stream=args.matcher_stream == "own", env_knobs=True)
+    ex, cap, d_imgs, d_ring, NRING = wl.ex, wl.cap, wl.d_ring[0], wl.d_ring, wl.NRING
+    step, extract_only, sync_all = wl.step, wl.extract_only, wl.sync_all
 
-    def extract_only():
-        li, k = counter[0] % DEPTH, counter[0] % NRING
-        o = outs[li]
-        lane_variant[li] = k
-        counter[0] += 1
-        ex.extract_batch_device(d_ring[k].data_ptr(), B + 1, W, H, o.kp.data_ptr(), o.desc.data_ptr(), o.n.data_ptr(), cap)
-        return o
-
-    # The matching of a batch runs in the stream of the pipeline lane that extracted it (uvo_matcher_attach_extractor); with
-    # --matcher-stream own it runs in the matcher's own stream behind an event, and the lane waits for another event before its next batch
-    # (two hand-offs between queues per batch: the lane idles 0.3 ms around a 0.13 ms kernel, tools/step_trace_summary.py).
-    own_stream = args.matcher_stream == "own"
-
-    def step():
-        o = extract_only()
-        if own_stream:
-            mt.wait_extractor(ex)
-        else:
-            mt.attach(ex)
-        # pair p = (frame p, frame p + 1), p < B; pair B-1's partner is the halo frame in slot B
-        mt.knn2_batch_device(B, o.desc.data_ptr(), o.n.data_ptr(), cap, o.desc.data_ptr() + cap * 32, o.n.data_ptr() + 4, cap,
-                             o.idx0.data_ptr(), o.d0.data_ptr(), o.idx1.data_ptr(), o.d1.data_ptr())
-        if own_stream:
-            mt.release_to_extractor(ex)
-
-    def sync_all():
-        ex.synchronize()
-        mt.synchronize()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup + DEPTH):
-        step()
-    sync_all()
-    # Per-kernel durations first, without cross-batch overlap (pipeline depth 1, every launch bracketed by HIP events on the
-    # library's stream; 3 untimed steps): they name the dominant kernel.
-    ex.set_pipeline(1)
-    ex.profile(True)
-    mt.profile(True)
-    for _ in range(3):
-        step()
-    sync_all()
-    serial = dict(ex.kernel_times())
-    serial.update(mt.kernel_times())
-    ex.profile(False)
-    mt.profile(False)
-    ex.set_pipeline(DEPTH)
-    for _ in range(DEPTH):
-        step()
-    sync_all()
-    dom = max(serial.items(), key=lambda kv: kv[1][0])[0]
-    # Timed region: only the dominant kernel's launches carry events (two event records around each of the ~14 launches of a
-    # step cost 3 % of the throughput; the roofline needs the live duration of this one kernel only).
-    if dom == "k_knn2":
-        mt.profile(True)
-    else:
-        ex.profile(True, only=dom)
-    dt = timed_steps(step, sync_all, steps, dist, red_dev)
-    ktimes = dict(ex.kernel_times())
-    ktimes.update(mt.kernel_times())
-    ex.profile(False)
-    mt.profile(False)
-
+    m = wl.measure(steps, args.warmup)
+    dt, dom, serial, ktimes = m["dt"], m["dom"], m["serial"], m["ktimes"]
     # ---- the timed buffers, on the host (both lanes' last results) ----
-    def download(o):
-        return dict(n=o.n.cpu().numpy(), kp=o.kp.cpu().numpy().view(np.uint8).reshape(B + 1, cap, 28), de=o.desc.cpu().numpy(), i0=o.idx0.cpu().numpy(),
-                    i1=o.idx1.cpu().numpy(), d0=o.d0.cpu().numpy().astype(np.uint16), d1=o.d1.cpu().numpy().astype(np.uint16))
-
-    host = [download(o) for o in outs]
-    timed_variants = list(lane_variant)
-
-    # ---- live per-kernel durations: the same pipelined step with every launch bracketed by events (outside the timed region: the
-    # event records cost 3 % of the throughput) -- what each kernel takes with the other lane's kernels beside it ----
-    ex.profile(True)
-    mt.profile(True)
+    host = [wl.download(o) for o in wl.outs]
     n_live = max(8, min(20, steps // 4))
-    for _ in range(n_live):
-        step()
-    sync_all()
-    live = dict(ex.kernel_times())
-    live.update(mt.kernel_times())
-    ex.profile(False)
-    mt.profile(False)
+    live = wl.live_pass(n_live)
     n_kp = host[0]["n"][:B]
 
     # ---- verification of the timed outputs against the CPU oracle (rank 0; a mismatch fails the run) ----
     verified = None
     if rank == 0 and not args.no_verify:
-        import oracle_lib
-        orc = oracle_lib.Oracle()
-        oe = orc.extractor(NFEAT, SCALE, NLEVELS, FAST_TH)
-        pairs = sorted(set([0, B // 4, B // 2 - 1, B - 2, B - 1]))   # (p, p + 1); B - 1 pairs with the halo frame
-        need = sorted(set(pairs) | set(p + 1 for p in pairs))
-        for li, hb in enumerate(host):
-            hv = host_variant(timed_variants[li])
-            ref = {f: oe(hv[f]) for f in need}
-            for f in need:
-                kp_o, de_o = ref[f]
-                n = int(hb["n"][f])
-                if n != len(kp_o) or hb["kp"][f, :n].tobytes() != kp_o.tobytes() or not (hb["de"][f, :n] == de_o).all():
-                    raise SystemExit("bench.py: VERIFICATION FAILED -- lane %d frame %d of the timed buffers differs from the oracle" % (li, f))
-            for p in pairs:
-                r = orc.knn2(ref[p][1], ref[p + 1][1])
-                nq = len(ref[p][1])
-                got = (hb["i0"][p, :nq], hb["d0"][p, :nq].astype(np.int32), hb["i1"][p, :nq], hb["d1"][p, :nq].astype(np.int32))
-                if not all((g == e).all() for g, e in zip(got, r)):
-                    raise SystemExit("bench.py: VERIFICATION FAILED -- lane %d knn-2 rows of pair %d differ from the oracle" % (li, p))
-        verified = {"frames": len(need) * len(host), "distinct_frames": need, "knn2_pairs": pairs, "lanes": len(host), "input_batches_of_the_lanes": timed_variants,
-                    "against": "CPU oracle (this repo's restatement of the reference; parity unpinned), byte for byte"}
+        verified = wl.verify(host, m["timed_variants"], sorted(set([0, B // 4, B // 2 - 1, B - 2, B - 1])))   # (p, p + 1); B - 1 pairs with the halo frame
 
-    # ---- host-to-host leg: the sharder (uploads from page-locked frames, results gathered into ONE host region shared by all ranks) ----
+    # ---- what each rank's host link can do (all ranks at once), then the host-to-host leg ----
     sub = {}
     h2h = None
+    link = None
+    if not args.no_subrecords or args.h2h or args.c3:
+        link = link_probe(ctx)
     if not args.no_subrecords or args.h2h:
-        total = world * B
-        chunk = max(B // int(os.environ.get("UVO_BENCH_CHUNKS", "2")), 1)   # chunks per rank and job, two in flight: the upload of one under the kernels of the other
-        devices = [uvo.UVO_SHARD_REMOTE] * world
-        devices[rank] = local_rank
-        sh = uvo.Sharder(NFEAT, SCALE, NLEVELS, FAST_TH, max_width=W, max_height=H, devices=devices, chunk_frames=chunk, match=True)
-        scap = sh.cap
-        assert scap == cap
-        sizes = [((total, scap), uvo.KEYPOINT_DTYPE), ((total, scap, 32), np.uint8), ((total,), np.int32), ((total, scap), np.int32),
-                 ((total, scap), np.uint16), ((total, scap), np.int32), ((total, scap), np.uint16)]
-        nbytes = sum(int(np.prod(s)) * np.dtype(t).itemsize + 256 for s, t in sizes)
-        # two gather regions: a stream of jobs keeps two in flight (job k+1 is submitted before job k is waited for), each gathers into its own
-        region = SharedHostRegion(uvo, 2 * nbytes, rank, world, dist)
-        sets, off = [], 0
-        for _ in range(2):
-            arrs = []
-            for s, t in sizes:
-                a, off = region.carve(off, s, t)
-                arrs.append(a)
-            sets.append(arrs)
-        region.register([a[first:first + B] for arrs in sets for a in arrs], dist)
-        g_kp, g_de, g_n, g_i0, g_d0, g_i1, g_d1 = sets[0]
-        jobs = [0]
-        pending = [None]
+        h2h = host_to_host_leg(ctx, wl, first, steps, link)
 
-        def h2h_run():
-            # frames of this rank start at global index `first`; its halo frame sits right behind them in `frames` (for the last
-            # rank the job simply ends there: the wrap-around pair exists only in the HBM-resident leg).  One call = one job submitted;
-            # the job before it is waited for afterwards, so two are in flight and the lanes never drain.
-            t = sh.submit(frames, first, total, *sets[jobs[0] % 2])
-            jobs[0] += 1
-            if pending[0] is not None:
-                sh.wait(pending[0])
-            pending[0] = t
-
-        def h2h_drain():
-            if pending[0] is not None:
-                sh.wait(pending[0])
-                pending[0] = None
-
-        for _ in range(3):
-            h2h_run()
-        h2h_drain()
-        reps = max(6, min(30, steps // 4))
-        dth = timed_steps(h2h_run, h2h_drain, reps, dist, red_dev)
-        # the gathered region must hold exactly what the HBM-resident leg produces for the same frames (input batch 0 of the ring;
-        # this rank's block; pair B-1 only where the halo is the true next frame)
-        counter[0] = 0
-        step()
-        sync_all()
-        hb = download(outs[0])
-        ok = (g_n[first:first + B] == hb["n"][:B]).all()
-        for f in range(B):
-            n = int(hb["n"][f])
-            ok = ok and g_kp[first + f, :n].tobytes() == hb["kp"][f, :n].tobytes() and (g_de[first + f, :n] == hb["de"][f, :n]).all()
-        npairs = B if first + B < total else B - 1
-        for p in range(npairs):
-            nq = int(hb["n"][p])
-            ok = ok and (g_i0[first + p, :nq] == hb["i0"][p, :nq]).all() and (g_d0[first + p, :nq] == hb["d0"][p, :nq]).all() and \
-                (g_i1[first + p, :nq] == hb["i1"][p, :nq]).all() and (g_d1[first + p, :nq] == hb["d1"][p, :nq]).all()
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev if red_dev is not None else "cpu")
-        if dist is not None:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) != 1:
-            raise SystemExit("bench.py: VERIFICATION FAILED -- the gathered host region differs from the HBM-resident outputs")
-        if rank == 0 and world > 1:   # rank 0 sees every rank's block in the one region
-            assert (g_n[:total] > 0).all(), "a rank's block is missing from the gathered region"
-        up = B * W * H + (W * H if first + B < total else 0)
-        down = B * scap * (28 + 32) + B * 4 + npairs * scap * 12
-        h2h = {"value": round(total * reps / dth, 1), "unit": "frames/s", "ms_per_job": round(dth / reps * 1e3, 3), "frames_per_job": total,
-               "chunk_frames": chunk, "jobs_in_flight": 2, "pcie_bytes_up_per_rank": up, "pcie_bytes_down_per_rank": down, "gather": "device-to-host copies at precomputed "
-               "offsets of one page-locked region shared by all ranks (%s)" % ("uvo_host_alloc" if world == 1 else "/dev/shm mapping + uvo_host_register" +
-                                                                                  ("" if region.registered else " [registration failed: pageable]")),
-               "gathered_equals_hbm_resident": True}
-        nodes = [None] * world
-        if dist is not None:
-            dist.all_gather_object(nodes, {"rank": rank, "numa_node": numa_node, "bound_to_local_cpus": bool(numa_bound)})
-        else:
-            nodes = [{"rank": rank, "numa_node": numa_node, "bound_to_local_cpus": bool(numa_bound)}]
-        h2h["numa"] = nodes   # per rank: the NUMA node of its GPU and whether its thread (frames, gather slice, sharder staging) was bound to that node's CPUs
-        sh.close()
-        region.close(rank, dist)
+    # ---- configs[3] on this run's clock: one GPU's share as a sub-record (rank 0 alone); with several ranks every rank runs its share and
+    # the sharder gathers world x 128 frames ----
+    c3 = None
+    if args.config == 2 and (not args.no_subrecords or args.c3) and os.environ.get("UVO_BENCH_C3", "1") == "1":
+        c3 = config3_record(ctx, max(8, min(12, steps)), link)
+        if rank == 0:
+            sub["configs[3] per-GPU share" if world == 1 else "configs[3] over %d GPUs" % world] = c3
 
     # ---- sub-records on rank 0 (the other ranks idle at the barrier below) ----
     c4_cpu = None
     if rank == 0 and not args.no_subrecords:
+        counter = wl.counter
         # extract only
         for _ in range(DEPTH):
             extract_only()
@@ -747,7 +948,7 @@ def main():
         avg_launch_s = dom_ms * 1e-3 / dom_launches
         bytes_per_launch = alg.get(dom, 0) * (B + 1) / launches_per_step
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        total_alg = sum(v for kname, v in alg.items() if kname not in ("k_pad_level0", "k_fast_blur", "k_pyr_tiles", "k_octree_gauss"))
+        total_alg = sum(v for kname, v in alg.items() if kname not in ("k_pad_level0", "k_fast_blur", "k_fast_score_gauss", "k_pyr_tiles", "k_octree_gauss"))
         pmc, pmc_frames, pmc_src = load_pmc(args.config)
         scale = (B + 1) / pmc_frames if pmc_frames else 1.0   # the counters were taken at the config's default batch: per-launch figures scale with the frames
 
@@ -766,19 +967,22 @@ def main():
         for kname in sorted(set(live) | set(serial)):
             ab = int(alg.get(kname, 0) * (B + 1))
             live_ms = live[kname][0] / n_live if kname in live else None
-            alone_ms = serial[kname][0] / 3 if kname in serial else None
+            alone_ms = serial[kname][0] / m["n_serial"] if kname in serial else None
             if kname == dom:   # the dominant kernel's live duration comes from the timed region itself
                 live_ms = ktimes[dom][0] / steps
             tr, _ = pmc_of(kname)
             if tr is not None and kname == "k_resize_level":
                 tr *= 7    # the counter file holds the mean over its 7 launches
             gbps = ab / (live_ms * 1e-3) / 1e9 if live_ms and ab else None
+            gbps_alone = ab / (alone_ms * 1e-3) / 1e9 if alone_ms and ab else None
             per_kernel[kname] = {"alg_bytes": ab, "live_ms": round(live_ms, 5) if live_ms is not None else None,
                                  "alone_ms": round(alone_ms, 5) if alone_ms is not None else None, "GBps": round(gbps, 1) if gbps else None,
-                                 "frac": round(gbps / HBM_PEAK_GBS, 5) if gbps else None, "counter_bytes": tr,
+                                 "frac": round(gbps / HBM_PEAK_GBS, 5) if gbps else None,
+                                 "frac_alone": round(gbps_alone / HBM_PEAK_GBS, 5) if gbps_alone else None, "counter_bytes": tr,
                                  "ratio": round(tr / ab, 3) if tr and ab else None}
         traffic, valu_instr = pmc_of(dom)
         hbm_frac = achieved / HBM_PEAK_GBS
+        alone_launch_s = serial[dom][0] / m["n_serial"] * 1e-3 / launches_per_step if dom in serial and serial[dom][0] > 0 else None
         roof_valu = None
         if valu_instr:
             ginstr = valu_instr / avg_launch_s / 1e9
@@ -789,10 +993,9 @@ def main():
             # of its instructions belong to: on gfx950 only plain two-operand 32-bit / 16-bit ALU ops and fp32 add / mul / fma issue every
             # 2 cycles per SIMD; packed, three-operand, compare, 32-bit min / max, integer multiply and conversion instructions take 4
             # (measured: tools/ubench/valu_rate3.hip)
-            if dom in serial and serial[dom][0] > 0:
-                alone_s = serial[dom][0] / 3 * 1e-3 / launches_per_step
-                g1 = valu_instr / alone_s / 1e9
-                roof_valu["alone_on_the_chip"] = {"launch_ms": round(alone_s * 1e3, 5), "achieved": round(g1, 2), "frac": round(g1 / VALU_PEAK_GINSTR, 5),
+            if alone_launch_s:
+                g1 = valu_instr / alone_launch_s / 1e9
+                roof_valu["alone_on_the_chip"] = {"launch_ms": round(alone_launch_s * 1e3, 5), "achieved": round(g1, 2), "frac": round(g1 / VALU_PEAK_GINSTR, 5),
                                                   "frac_of_4_cycle_class_peak": round(g1 / (VALU_PEAK_GINSTR / 2), 5)}
         # the roof that actually binds the dominant kernel: instruction issue.  VALU + SALU wavefront-instructions per launch (counters)
         # / live launch duration, against the chip's issue peak of the 2-cycle class (and of the 4-cycle class most stencil arithmetic is in)
@@ -808,13 +1011,23 @@ def main():
                                       "convert and integer-multiply instructions issue every 4 cycles (tools/ubench/valu_rate3.hip), and the CU's one scalar "
                                       "unit makes a scalar instruction cost a vector slot at this density (tools/ubench/valu_issue.hip)"}
         whole_path_frac = total_alg * value / world / 1e9 / HBM_PEAK_GBS
+        prof_tag = PROFILE_TAG if args.config == 2 else PROFILE_TAG + "_hd"
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 5), "traffic": traffic,
                     "kernel": dom, "avg_launch_ms": round(avg_launch_s * 1e3, 5), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                    # the two operating points of the same launch: `frac` / `avg_launch_ms` = frac_live (HIP events inside the timed region, pipeline
+                    # depth %d: the other lane's kernels run beside it); frac_alone = the launch alone on the chip (pipeline depth 1, untimed steps)
+                    "avg_launch_ms_is": "live (pipeline depth %d, inside the timed region)" % DEPTH,
+                    "frac_live": round(hbm_frac, 5),
+                    "frac_alone": round(bytes_per_launch / alone_launch_s / 1e9 / HBM_PEAK_GBS, 5) if alone_launch_s else None,
+                    "avg_launch_ms_alone": round(alone_launch_s * 1e3, 5) if alone_launch_s else None,
+                    "rocprof_csv": {"alone": "profiles/%s_kernel_stats_depth1.csv" % prof_tag, "live": "profiles/%s_kernel_stats_depth2.csv" % prof_tag,
+                                    "note": "rocprofv3 --kernel-trace --stats of this command with UVO_PIPELINE_DEPTH=1 resp. 2 and UVO_BENCH_SKIP_SERIAL=1 (every launch "
+                                            "of a file ran at that one depth); AverageNs of the kernel's row x launches per step = avg_launch_ms_alone resp. avg_launch_ms"},
                     "traffic_source": pmc_src, "measured_device_copy_GBps": sub.get("device_copy_GBps"),
                     "per_kernel": per_kernel, "valu": roof_valu, "whole_path_GBps": round(total_alg * value / world / 1e9, 2),
                     "whole_path_algorithmic_bytes_per_frame": int(total_alg),
                     "kernel_ms_per_step_in_timed_region": {k: round(v[0] / steps, 4) for k, v in sorted(ktimes.items())},
-                    "kernel_ms_per_step_unoverlapped": {k: round(v[0] / 3, 4) for k, v in sorted(serial.items())},
+                    "kernel_ms_per_step_unoverlapped": {k: round(v[0] / m["n_serial"], 4) for k, v in sorted(serial.items())},
                     "note": "bound says hbm because frac is the HBM fraction this record format asks for (algorithmic bytes per launch / live launch duration "
                             "/ 8 TB/s); the kernel itself is bound by instruction issue: issue_roofline"}
         out = {
@@ -825,6 +1038,7 @@ def main():
             "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / steps * 1e3, 4),
+            "step_spread": step_spread(m, steps, DEPTH),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

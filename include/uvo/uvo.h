@@ -320,7 +320,12 @@ int uvo_extractor_read_candidates(uvo_extractor* h, int frame, int level, int32_
  * profiling is enabled (uvo_extractor_profile(h, 1); adds two event records per launch).
  * uvo_extractor_kernel_times() waits for the stream, then reports and clears what was recorded:
  * names: '\n'-separated kernel names into `names` (cap bytes); ms[i]: summed duration of that kernel's launches;
- * launches[i]: number of launches.
+ * launches[i]: number of launches.  Behind the kernels' rows, while `cap` allows, follow spread rows for every kernel with two or more
+ * launches: "name:min" / "name:p50" / "name:max" = shortest / median / longest single launch (ms), and "name:period_min" / ":period_p50" /
+ * ":period_max" = start-to-start time of consecutive launches in enqueue order across the pipeline lanes (for a kernel launched once per
+ * batch: the step period as the device saw it), and "name:period2_min" / ":period2_p50" / ":period2_max" = half the start-to-start time of
+ * launches two apart (two pipeline lanes take the batches in turn: one lane's period per step, whatever the phase between the lanes);
+ * launches[i] of a spread row = the number of samples behind it.
  */
 int uvo_extractor_profile(uvo_extractor* h, int enable);
 /* restricts the timing to launches of one kernel (name as reported by uvo_extractor_kernel_times; NULL or "" = all kernels) */

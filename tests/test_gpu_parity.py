@@ -1542,7 +1542,7 @@ def test_bow_transform_and_search_on_a_vocabulary_of_orbvoc_shape(uvo, oracle, s
 
 
 @pytest.mark.parametrize("knobs", [{}, {"UVO_TUNE_FEW_FRAMES": 0}, {"UVO_TUNE_ZERO_COPY_OUT": 0}, {"UVO_TUNE_SPIN_WAIT": 0}, {"UVO_TUNE_ZERO_COPY_OUT": 0, "UVO_TUNE_SPIN_WAIT": 0},
-                                   {"UVO_TUNE_OCT_WIDE_MAX": 256}, {"UVO_TUNE_OCT_WIDE_MAX": 256, "UVO_TUNE_SIDE_BLUR": 0}, {"UVO_TUNE_PYR_FORM": 1},
+                                   {"UVO_TUNE_OCT_WIDE_MAX": 256}, {"UVO_TUNE_PYR_FORM": 1},
                                    {"UVO_TUNE_FEW_FRAMES": 0, "UVO_TUNE_OCT_WIDE_MAX": 256, "UVO_TUNE_ZERO_COPY_OUT": 0, "UVO_TUNE_PYR_FORM": 1}])
 def test_single_frame_launch_shapes_give_the_same_bytes(uvo, oracle, frames, knobs):
     """The short launch chain of one or two frames (k_pyr_tiles, the quad-tree sharing its launch with the blur -- or its 1024-thread form

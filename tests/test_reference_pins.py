@@ -205,6 +205,28 @@ def test_oracle_primitives_equal_reference(oracle):
         np.testing.assert_array_equal(im, ref[21:-21, 21:-21] if ref.shape != im.shape else ref)
         refd = pins["klt_deriv_L%d" % l]
         np.testing.assert_array_equal(der, refd[21:-21, 21:-21] if refd.shape[:2] != der.shape[:2] else refd)
+    check_klt_tracker_against(pins, lambda pa, pb, pts: oracle.klt_track_ex(pa, pb, pts, pts, (21, 21), 5, sum_mode=0)[:3], oracle, mi, "oracle (raster order)")
+
+
+def check_klt_tracker_against(pins, track, oracle, mi, who):
+    """cv::calcOpticalFlowPyrLK (src/Tracking.cc:1046-1047) is the one stage of the path whose contract is a TOLERANCE against any OpenCV
+    build: its window sums are fp32 accumulations over 441 products, and the generic loop, the SSE2, the AVX2 and the
+    NEON bodies of LKTrackerInvoker each add them in another order.  Stated tolerance: the same status wherever the decision (minimum
+    eigenvalue against its threshold, the point against the image border) does not sit within 1e-3 (relative) of its threshold; positions
+    within 0.01 px, median below 1e-3 px; the pyramid and the Scharr derivatives above are integers and must be equal."""
+    if "klt_pts1" not in pins:
+        return
+    fr = mi.frames()
+    pa, pb = oracle.klt_pyramid(fr["c2_f0"][0], (21, 21), 5), oracle.klt_pyramid(fr["c2_f1"][0], (21, 21), 5)
+    pts = pins["klt_pts0"]
+    nxt, st, err = track(pa, pb, pts)
+    _, r_st, _, r_mg = oracle.klt_track_ex(pa, pb, pts, pts, (21, 21), 5, sum_mode=0)   # (the margins of the decisions, from the raster-order run)
+    ref_st, ref_next = pins["klt_status"], pins["klt_pts1"]
+    assert ((st == ref_st) | (r_mg < 1e-3)).all(), who + ": tracker status differs from the reference away from every threshold"
+    both = (st > 0) & (ref_st > 0)
+    if both.any():
+        d = np.abs(nxt[both] - ref_next[both]).max(axis=1)
+        assert np.median(d) < 1e-3 and (d[r_mg[both] > 0.1] < 0.01).all(), who + ": tracked positions differ from the reference by more than the stated tolerance"
 
 
 # ---- the HIP path against the reference (MI355X) ----
@@ -231,6 +253,18 @@ def test_hip_extractor_equals_reference(oracle):
         ex.close()
         return r
     check_topup_against(pins, topup, "HIP")
+
+    mi = _cases()
+
+    def hip_track(pa, pb, pts):   # the HIP tracker on the same two frames (its own pyramids), initial flow = the previous positions
+        fr = mi.frames()
+        h, w = fr["c2_f0"][0].shape
+        k = uvo.KLT(w, h, (21, 21), 5, max_points=max(len(pts), 1), slots=2)
+        k.build_pyramid(0, fr["c2_f0"][0]), k.build_pyramid(1, fr["c2_f1"][0])
+        r = k.track(0, 1, pts, pts)
+        k.close()
+        return r
+    check_klt_tracker_against(pins, hip_track, oracle, mi, "HIP")
 
 
 @pytest.mark.parametrize("contract", [0, 1])
@@ -330,6 +364,10 @@ def test_kit_round_trip_with_an_emulated_dumper(oracle, tmp_path, monkeypatch, c
             for l in range(p0.levels):
                 im, der = p0.level(l)
                 put("klt_pyr_L%d" % l, "u1", im), put("klt_deriv_L%d" % l, "i2", der)
+            p1 = oracle.klt_pyramid(frames[t[2]][0], (int(t[3]), int(t[4])), int(t[5]))
+            pts = np.fromfile(indir / t[10], np.float32).reshape(int(t[9]), 2)
+            nxt, st, err = oracle.klt_track(p0, p1, pts, pts, (int(t[3]), int(t[4])), int(t[5]), int(t[6]), float(t[7]), float(t[8]))
+            put("klt_pts0", "f4", pts), put("klt_pts1", "f4", nxt), put("klt_status", "u1", st), put("klt_err", "f4", err)
     (outdir / "manifest.txt").write_text("\n".join(manifest) + "\n")
     (outdir / "build_info.txt").write_text("General configuration for OpenCV (emulated by the oracle: pins nothing)\n")
     npz = tmp_path / "pins.npz"

@@ -33,8 +33,6 @@ def main():
         ex.tune(uvo.UVO_TUNE_OCT_WIDE_MAX, int(os.environ["UVO_LAT_OCT_WIDE"]))
     if os.environ.get("UVO_LAT_FEW"):
         ex.tune(uvo.UVO_TUNE_FEW_FRAMES, int(os.environ["UVO_LAT_FEW"]))
-    if os.environ.get("UVO_LAT_SIDE_BLUR"):
-        ex.tune(uvo.UVO_TUNE_SIDE_BLUR, int(os.environ["UVO_LAT_SIDE_BLUR"]))
     if os.environ.get("UVO_LAT_PYR_GROUPS"):
         for g in os.environ["UVO_LAT_PYR_GROUPS"].split(","):
             first, grid = g.split(":")

@@ -32,7 +32,7 @@ UVO_TUNE_FUSE_BLUR_TREE = 10
 UVO_TUNE_PYR_RING = 12
 UVO_TUNE_PYR_FORM, UVO_PYR_FORM_AUTO, UVO_PYR_FORM_LEVELS, UVO_PYR_FORM_TILES = 13, 0, 1, 2
 UVO_TUNE_PYR_TILE_GROUP = 14
-UVO_TUNE_SIDE_BLUR = 15
+UVO_TUNE_LANE_STAGGER = 15
 UVO_TUNE_FEW_FRAMES = 16
 UVO_TUNE_ZERO_COPY_OUT, UVO_TUNE_SPIN_WAIT = 17, 18
 
@@ -379,6 +379,16 @@ def host_unregister(arr):
         raise UvoError(rc, "uvo_host_unregister")
 
 
+def _spread_rows(names, ms):
+    """the "kernel:stat" pseudo-rows of a uvo_*_kernel_times report -> {kernel: {stat: ms}}"""
+    out = {}
+    for i, nm in enumerate(names):
+        if ":" in nm:
+            k, stat = nm.split(":", 1)
+            out.setdefault(k, {})[stat] = float(ms[i])
+    return out
+
+
 class ORBextractor:
     """Mirror of USLAM::ORBextractor (include/ORBextractor.h:47-95).
 
@@ -600,15 +610,18 @@ class ORBextractor:
         lib.uvo_extractor_profile(self._h, 1 if enable else 0)
 
     def kernel_times(self):
-        names = ctypes.create_string_buffer(4096)
-        ms = np.zeros(64, np.float32)
-        launches = np.zeros(64, np.int32)
+        """{kernel: (summed ms, launches)}; the per-launch spread rows of the same report ("name:min" ...) are kept in self.last_spread
+        as {kernel: {"min" | "p50" | "max" | "period_min" | "period_p50" | "period_max": ms}}."""
+        names = ctypes.create_string_buffer(16384)
+        ms = np.zeros(256, np.float32)
+        launches = np.zeros(256, np.int32)
         n = ctypes.c_int()
-        rc = lib.uvo_extractor_kernel_times(self._h, names, 4096, ms.ctypes.data, launches.ctypes.data, 64, ctypes.byref(n))
+        rc = lib.uvo_extractor_kernel_times(self._h, names, 16384, ms.ctypes.data, launches.ctypes.data, 256, ctypes.byref(n))
         if rc:
             raise UvoError(rc, "uvo_extractor_kernel_times")
         nm = names.value.decode().split("\n")[:n.value]
-        return {nm[i]: (float(ms[i]), int(launches[i])) for i in range(n.value)}
+        self.last_spread = _spread_rows(nm, ms)
+        return {nm[i]: (float(ms[i]), int(launches[i])) for i in range(n.value) if ":" not in nm[i]}
 
 
 class ORBmatcher:
@@ -709,15 +722,18 @@ class ORBmatcher:
         lib.uvo_matcher_profile(self._h, 1 if enable else 0)
 
     def kernel_times(self):
-        names = ctypes.create_string_buffer(4096)
-        ms = np.zeros(64, np.float32)
-        launches = np.zeros(64, np.int32)
+        """{kernel: (summed ms, launches)}; the per-launch spread rows of the same report ("name:min" ...) are kept in self.last_spread
+        as {kernel: {"min" | "p50" | "max" | "period_min" | "period_p50" | "period_max": ms}}."""
+        names = ctypes.create_string_buffer(16384)
+        ms = np.zeros(256, np.float32)
+        launches = np.zeros(256, np.int32)
         n = ctypes.c_int()
-        rc = lib.uvo_matcher_kernel_times(self._h, names, 4096, ms.ctypes.data, launches.ctypes.data, 64, ctypes.byref(n))
+        rc = lib.uvo_matcher_kernel_times(self._h, names, 16384, ms.ctypes.data, launches.ctypes.data, 256, ctypes.byref(n))
         if rc:
             raise UvoError(rc, "uvo_matcher_kernel_times")
         nm = names.value.decode().split("\n")[:n.value]
-        return {nm[i]: (float(ms[i]), int(launches[i])) for i in range(n.value)}
+        self.last_spread = _spread_rows(nm, ms)
+        return {nm[i]: (float(ms[i]), int(launches[i])) for i in range(n.value) if ":" not in nm[i]}
 
     def SearchByProjection(self, kp, desc, bounds, assigned, proj_x, proj_y, level, view_cos, in_view, mp_desc, scale_factors, th=1.0):
         """SearchByProjection(FrameKTL&, vector<MapPoint*>&, th) (src/ORBmatcher.cc:49-125).

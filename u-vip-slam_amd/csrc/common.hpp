@@ -111,7 +111,7 @@ void launch_resize_level(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const
                          const ResizeRow* d_rtab, int fast_ok, int batch, Level0View l0, int ring);
 // a group of consecutive levels in one launch (pyramid.hip: k_pyr_tiles; plan: pyr_tiles.hpp)
 constexpr int kPyrTilesMaxLds = 160 * 1024;
-int prepare_pyr_tiles();
+int prepare_pyr_tiles(uint32_t* max_lds);  // *max_lds: bytes of LDS a tile plan may use on the current device
 int launch_pyr_tiles(hipStream_t s, uint8_t* d_pyr, int64_t pyr_block, const PyrTileLevel* d_plan, const Geom& g, const ResizeCol* d_ctab, const ResizeRow* d_rtab,
                      Level0View l0, int first, int last, int ntiles, uint32_t lds_bytes, int threads, int rows, int batch);
 void launch_gauss7(hipStream_t s, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, const LevelGeom* d_lv, const Geom& g, int4 taps,
@@ -130,7 +130,7 @@ int fast_flags_per_frame(const Geom& g);
 // Launch shape of the quad-tree kernel, per extractor handle (nothing process-global: handles on several devices and host
 // threads coexist in one process).  wide_max_problems: up to this many (frame, level) problems run as 1024-thread workgroups.
 struct OctLaunchState {
-  int wide_max_problems = 0;  // (with the blur in the same launch the 256-thread form is also the faster one for a single frame: 34 us against 29 + 14)
+  int wide_max_problems = 0;  // UVO_TUNE_OCT_WIDE_MAX (extractor.cpp sets the default)
 };
 bool octree_gauss_applies(const OctLaunchState& st, const Geom& g, int batch);
 void launch_octree_gauss(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, int4 taps, int sse2_rounding,

@@ -52,11 +52,9 @@ constexpr int kTilePyramidFrames = 8;  // batches up to this size build the pyra
 constexpr int kFewFrames = 2;  // batches up to this size are the latency path (the FAST kernels cut their segments short for them: fast_rows_per_seg)
 
 struct Lane {
-  hipStream_t stream = nullptr;
-  // Few frames cannot fill the chip and every stage is a chain of dependent phases: the blur, which reads nothing but the pyramid, runs in a
-  // side stream beside the FAST kernels and the quad-tree (fork behind the pyramid, join in front of k_describe)
-  hipStream_t aux = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t stream = nullptr;  // everything of a batch runs in this ONE in-order stream (no side streams: an error return leaves nothing to join)
+  hipEvent_t ev_class[3] = {nullptr, nullptr, nullptr};  // recorded behind the lane's last launch of a class (lane stagger)
+  bool ev_class_set[3] = {false, false, false};
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_cand_xy = nullptr, *d_cand_sc = nullptr, *d_cand_lo = nullptr, *d_pstate = nullptr, *d_sel_xy = nullptr, *d_sel_sc = nullptr;
   int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_n_final = nullptr, *d_cor_n = nullptr, *d_cursor = nullptr;
@@ -139,6 +137,7 @@ struct uvo_extractor {
     PyrTileLevel* d_plan = nullptr;
   };
   std::vector<TileGroup> tile_groups;
+  uint32_t pyr_tiles_max_lds = 64 * 1024;  // LDS a tile plan may use on this device (prepare_pyr_tiles); plans that need more fall back to the per-level launches
   std::vector<uint32_t> tile_spec;  // forced groups: first << 16 | tx << 8 | ty | (1024 threads) << 24 | (1024 threads, single-row items) << 25, ascending first levels
   int pyr_form = UVO_PYR_FORM_AUTO;
   std::vector<ResizeCol> ctab_host;  // the resize tables of the current geometry (the plans are compiled from them)
@@ -147,8 +146,8 @@ struct uvo_extractor {
   int level0_inplace = 1;    // UVO_TUNE_LEVEL0_INPLACE: read level 0 from the caller's image instead of copying it into a padded plane (when it can be)
   int zero_copy_out = 1;     // UVO_TUNE_ZERO_COPY_OUT: host-buffer calls of up to 16 frames have k_describe write into page-locked host memory
   int spin_wait = 1;         // UVO_TUNE_SPIN_WAIT: those calls, and uvo_extractor_synchronize behind a small batch, poll the stream instead of sleeping
-  int few_frames_shape = 1;  // UVO_TUNE_FEW_FRAMES: batches of up to kFewFrames frames take the short launch chain (single FAST pass, FullDetect without k_assemble)
-  int side_blur = 1;         // UVO_TUNE_SIDE_BLUR: small batches run the blur in a side stream beside FAST and the quad-tree
+  int few_frames_shape = 1;  // UVO_TUNE_FEW_FRAMES: FullDetect batches of up to kFewFrames frames take the short launch chain (no k_assemble: k_describe finds its slots itself)
+  int lane_stagger = 0;      // UVO_TUNE_LANE_STAGGER: bit mask of the launch classes of which only one pipeline lane runs at a time (0 FAST pass, 1 quad-tree + blur, 2 pyramid)
   int fuse_blur_tree = 1;    // UVO_TUNE_FUSE_BLUR_TREE: quad-tree and blur as one launch when the batch takes the 256-thread quad-tree form
   float* d_pattern = nullptr;   // 256 point pairs (x0, y0, x1, y1) of the rBRIEF pattern as floats
   uint32_t* d_patch = nullptr;  // 256 byte masks: which of the 4 pixels of an orientation-patch dword lie inside the circle
@@ -375,7 +374,7 @@ static int build_tile_set(uvo_extractor* h, const Geom& g, const std::vector<uin
     if (G.first >= g.nlevels) break;  // (a spec written for more levels than this handle has)
     G.last = std::min(G.last, g.nlevels - 1);
     PyrTilePlan P;
-    if (G.first < 1 || G.last < G.first || (k == 0 && G.first != 1) || !pyr_tile_plan_build(dims, g.nlevels, G.first, G.last, cp, rp, 4, G.tx, G.ty, kPyrTilesMaxLds, P)) {
+    if (G.first < 1 || G.last < G.first || (k == 0 && G.first != 1) || !pyr_tile_plan_build(dims, g.nlevels, G.first, G.last, cp, rp, 4, G.tx, G.ty, h->pyr_tiles_max_lds, P)) {
       for (auto& X : set)
         if (X.d_plan) (void)hipFree(X.d_plan);
       return UVO_OK;
@@ -510,6 +509,9 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   const Level0View no_l0{nullptr, 0, 0, 0};
   {
     // ComputePyramid (src/ORBextractor.cc:963-1004): a launch per group of levels (k_pyr_tiles), or one per level
+    if (h->lane_stagger >> 2 & 1 && h->nlanes > 1)
+      for (int o = 0; o < h->nlanes; ++o)
+        if (o != li && h->lane[o].ev_class_set[2]) UVO_HIP_CHECK(hipStreamWaitEvent(s, h->lane[o].ev_class[2], 0));
     if (!inplace) {
       ProfScope p(h, "k_pad_level0");
       launch_pad_level0(s, d_imgs, width, height, stride, frame_stride, L.d_pyr, g.pyr_block, g.lv[0], batch);
@@ -530,20 +532,42 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
       }
     }
   }
+  if (h->lane_stagger >> 2 & 1 && h->nlanes > 1) {
+    if (!L.ev_class[2]) UVO_HIP_CHECK(hipEventCreateWithFlags(&L.ev_class[2], hipEventDisableTiming));
+    UVO_HIP_CHECK(hipEventRecord(L.ev_class[2], s));
+    L.ev_class_set[2] = true;
+  }
   const bool fused_tree = h->fuse_blur_tree && octree_gauss_applies(h->oct, g, batch);
-  // (the side stream only where the quad-tree takes its 1024-thread form: a batch that fills the chip has nothing to gain from it)
-  const bool side_blur = !fused_tree && h->side_blur && batch * g.nlevels <= h->oct.wide_max_problems;
-  if (side_blur) UVO_HIP_CHECK(hipEventRecord(L.ev_fork, s));  // (the side stream is fed behind the FAST launches: the main chain first)
   // A frame or two (the per-frame latency path, src/Tracking.cc:946): every stage is a chain of dependent phases on a nearly empty chip,
   // so the number of stages is what counts -- a FullDetect call has no k_assemble launch (k_describe finds its slots itself).  (One FAST
   // pass at 7 with the vote in the quad-tree instead of the sparse second launch: the pass takes 7.7 us longer, the launch it saves 8.)
   const bool few = batch <= kFewFrames && h->few_frames_shape;
   const int32_t* tpass = L.d_tpass;
+  const int4 gtaps = make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]);
+  // Lane stagger (UVO_TUNE_LANE_STAGGER): two lanes that run the same launch sequence drift into phase -- both streaming their FAST pass at
+  // the same time, then both waiting in their latency-bound stages.  Bit 0 makes the FAST pass of a batch wait for the FAST pass of the
+  // batch before it (the other lane's): the lanes then run half a batch apart, the issue-bound pass of one beside the memory- and
+  // latency-bound stages of the other.  Bits 1 / 2: the same for the quad-tree + blur launch / the pyramid launches.
+  auto stagger_wait = [&](int cls) -> int {
+    if (!(h->lane_stagger >> cls & 1) || h->nlanes < 2) return UVO_OK;
+    for (int o = 0; o < h->nlanes; ++o)
+      if (o != li && h->lane[o].ev_class_set[cls]) UVO_HIP_CHECK(hipStreamWaitEvent(s, h->lane[o].ev_class[cls], 0));
+    return UVO_OK;
+  };
+  auto stagger_mark = [&](int cls) -> int {
+    if (!(h->lane_stagger >> cls & 1) || h->nlanes < 2) return UVO_OK;
+    if (!L.ev_class[cls]) UVO_HIP_CHECK(hipEventCreateWithFlags(&L.ev_class[cls], hipEventDisableTiming));
+    UVO_HIP_CHECK(hipEventRecord(L.ev_class[cls], s));
+    L.ev_class_set[cls] = true;
+    return UVO_OK;
+  };
+  if ((rc = stagger_wait(0)) != UVO_OK) return rc;
   {  // the per-cell threshold vote + candidate emit run inside k_octree
     ProfScope p(h, "k_fast_score");
     launch_fast_score(s, L.d_pyr, g.pyr_block, g, h->cfg.fast_th, tpass, L.d_cor, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, L.d_cand_lo, g.cand_block,
                       L.d_cursor, batch, l0);
   }
+  if ((rc = stagger_mark(0)) != UVO_OK) return rc;
   if (h->cfg.fast_th > 7 && h->fast_mode != UVO_FAST_MODE_SINGLE_PASS) {
     // second call of src/ORBextractor.cc:797 for the cells of threshold-adaptive levels that the pass at fastTh left empty (nearly all
     // wavefronts find nothing to do on textured frames).  With the mode pinned to one pass no level can be adaptive: not launched.
@@ -551,25 +575,19 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
     launch_fast_cells(s, L.d_pyr, g.pyr_block, g, h->d_cells, h->d_cell_flag, tpass, L.d_cell_hi, L.d_cell_list, L.d_fstat + kMaxLevels, L.d_cand_xy,
                       L.d_cand_sc, g.cand_block, L.d_cursor, batch, l0);
   }
-  if (side_blur) {
-    UVO_HIP_CHECK(hipStreamWaitEvent(L.aux, L.ev_fork, 0));
-    {
-      Profiler::Scope p(&L.prof, "k_gauss7", L.aux);
-      launch_gauss7(L.aux, L.d_pyr, L.d_blur, g.pyr_block, h->d_lv, g, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), batch, h->blur_rounding, l0);
-    }
-    UVO_HIP_CHECK(hipEventRecord(L.ev_join, L.aux));
-  }
   if (fused_tree) {
     // the quad-tree (a chain of dependent phases per (frame, level)) and the blur (a streaming kernel) read nothing of each other:
     // one grid, the quad-tree problems first, and the blur fills the issue slots they leave idle
+    if ((rc = stagger_wait(1)) != UVO_OK) return rc;
     ProfScope p(h, "k_octree_gauss");
-    launch_octree_gauss(s, h->d_lv, g, L.d_pyr, L.d_blur, g.pyr_block, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), h->blur_rounding, L.d_cand_lo, L.d_cursor,
+    launch_octree_gauss(s, h->d_lv, g, L.d_pyr, L.d_blur, g.pyr_block, gtaps, h->blur_rounding, L.d_cand_lo, L.d_cursor,
                         L.d_fcount, L.d_fstat + kMaxLevels, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count, L.d_pstate, L.d_sel_xy, L.d_sel_sc, L.d_sel_count,
                         batch, l0);
   } else {
-    if (!side_blur) {
+    if ((rc = stagger_wait(1)) != UVO_OK) return rc;
+    {
       ProfScope p(h, "k_gauss7");
-      launch_gauss7(s, L.d_pyr, L.d_blur, g.pyr_block, h->d_lv, g, make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]), batch, h->blur_rounding, l0);
+      launch_gauss7(s, L.d_pyr, L.d_blur, g.pyr_block, h->d_lv, g, gtaps, batch, h->blur_rounding, l0);
     }
     {
       ProfScope p(h, "k_octree");
@@ -578,6 +596,7 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
       if (rc) return rc;
     }
   }
+  if ((rc = stagger_mark(1)) != UVO_OK) return rc;
   const bool direct = few && full_detect && !(d_in_kp && d_n_in);
   const FastAdapt fa{L.d_fcount, L.d_tpass, L.d_fstat, h->fast_mode == UVO_FAST_MODE_ADAPTIVE ? 1 : 0, h->cfg.fast_th};
   if (!direct) {
@@ -585,7 +604,6 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
     launch_assemble(s, h->d_lv, g, fa, L.d_sel_xy, L.d_sel_sc, L.d_sel_count, d_in_kp, d_n_in, h->cfg.max_input_keypoints, d_grid2d, grid_rows, grid_cols,
                     min_px_dist, full_detect, d_nfn, L.d_flist, L.d_n_final, batch);
   }
-  if (side_blur) UVO_HIP_CHECK(hipStreamWaitEvent(s, L.ev_join, 0));  // the descriptors read the blurred planes
   {
     ProfScope p(h, "k_describe");
     if (direct)
@@ -609,9 +627,6 @@ static int alloc_lane(uvo_extractor* h, int li) {
   if (L.stream) return UVO_OK;
   const size_t B = (size_t)h->cfg.max_batch;
   hipError_t e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming);
   if (e != hipSuccess) {
     hip_err_set(e, "hipStreamCreate");
     return UVO_E_HIP;
@@ -724,7 +739,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
     h->cap_cor = ce + ce / 8, h->cap_cor_n = cn + cn / 8 + 64;
     h->cap_flags = (size_t)B * ((size_t)fast_flags_per_frame(g) + fast_flags_per_frame(g) / 8 + 64);
   }
-  A(prepare_pyr_tiles());
+  A(prepare_pyr_tiles(&h->pyr_tiles_max_lds));
   A(alloc_lane(h, 0));
   A(dev_alloc(&h->d_lv, (size_t)kMaxLevels));
   A(dev_alloc(&h->d_cells, (size_t)h->cap_cells));
@@ -783,11 +798,10 @@ void uvo_extractor_destroy(uvo_extractor* h) {
     for (void* p : lp)
       if (p) (void)hipFree(p);
     if (L.a_uploaded) (void)hipEventDestroy(L.a_uploaded);
+    for (hipEvent_t& e : L.ev_class)
+      if (e) (void)hipEventDestroy(e);
     for (hipEvent_t& e : L.done)
       if (e) (void)hipEventDestroy(e);
-    if (L.aux) (void)hipStreamSynchronize(L.aux), (void)hipStreamDestroy(L.aux);
-    if (L.ev_fork) (void)hipEventDestroy(L.ev_fork);
-    if (L.ev_join) (void)hipEventDestroy(L.ev_join);
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
   void* ptrs[] = {h->d_clahe_lut, h->d_clahe_out, h->d_lv, h->d_cells, h->d_cell_flag, h->d_ctab, h->d_rtab, h->d_pattern, h->d_patch, h->d_imgs, h->d_out_kp,
@@ -964,8 +978,8 @@ int uvo_extractor_tune(uvo_extractor* h, int knob, int value) {
     case UVO_TUNE_FEW_FRAMES:
       h->few_frames_shape = value != 0;
       return UVO_OK;
-    case UVO_TUNE_SIDE_BLUR:
-      h->side_blur = value != 0;
+    case UVO_TUNE_LANE_STAGGER:
+      h->lane_stagger = value & 7;
       return UVO_OK;
     case UVO_TUNE_FUSE_BLUR_TREE:
       h->fuse_blur_tree = value != 0;

@@ -453,19 +453,25 @@ __global__ __launch_bounds__(THREADS) void k_pyr_tiles(PyrTilesArgs A) {
 }
 
 // the tiles of a plan may take up to kPyrTilesMaxLds bytes of LDS: the kernels' limit is raised to it once per device (hipFuncSetAttribute
-// sets the limit on the current device)
-int prepare_pyr_tiles() {
+// sets the limit on the current device).  A device or runtime that refuses leaves the kernels at the 64 KB every launch may ask for: the
+// tile pyramid is an optional launch shape, so *max_lds reports what plans may use and build_tile_set falls back to the per-level launches
+// for plans that do not fit -- the extractor itself never fails over it.
+int prepare_pyr_tiles(uint32_t* max_lds) {
   static std::mutex mu;
-  static bool done[64] = {false};
+  static uint32_t limit[64] = {0};
   int dev = 0;
   UVO_HIP_CHECK(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(mu);
-  if (dev < 0 || dev >= 64 || !done[dev]) {
-    UVO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_tiles<256, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kPyrTilesMaxLds));
-    UVO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_tiles<1024, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kPyrTilesMaxLds));
-    UVO_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_tiles<1024, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kPyrTilesMaxLds));
-    if (dev >= 0 && dev < 64) done[dev] = true;
+  uint32_t got = dev >= 0 && dev < 64 ? limit[dev] : 0;
+  if (!got) {
+    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_tiles<256, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kPyrTilesMaxLds) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_tiles<1024, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kPyrTilesMaxLds) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_tiles<1024, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kPyrTilesMaxLds) == hipSuccess;
+    if (!ok) (void)hipGetLastError();  // (not an error of the extractor: the plans are just held to the default limit)
+    got = ok ? (uint32_t)kPyrTilesMaxLds : 64u * 1024u;
+    if (dev >= 0 && dev < 64) limit[dev] = got;
   }
+  if (max_lds) *max_lds = got;
   return UVO_OK;
 }
 
