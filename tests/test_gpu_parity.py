@@ -1541,6 +1541,26 @@ def test_bow_transform_and_search_on_a_vocabulary_of_orbvoc_shape(uvo, oracle, s
     V.close()
 
 
+def test_adaptive_fast_state_is_the_same_with_and_without_the_short_single_frame_chain(uvo, synth):
+    """The lane's adaptive FAST state (per level: the threshold the next batch streams at, the fall-back cells of the last batch) is decided
+    in k_assemble for ordinary batches and in k_describe<DIRECT> for the frame or two of a latency call (UVO_TUNE_FEW_FRAMES): both go
+    through one helper (describe.hip: decide_fast_pass) and must leave the same state after the same sequence of frames -- the keypoints
+    cannot show a drift, both modes of a level give the same candidates (src/ORBextractor.cc:792-799)."""
+    seq = [img for _, img in _fast_mode_images(synth)] * 2   # textured / low-contrast / flat ...: levels switch mode back and forth
+    states = []
+    for few in (1, 0):
+        ex = uvo.ORBextractor(1000, 1.2, 8, 0, 20, max_width=640, max_height=512)
+        ex.tune(uvo.UVO_TUNE_FEW_FRAMES, few)
+        st = []
+        for img in seq:
+            ex(img)
+            st.append(tuple(tuple(a.tolist()) for a in ex.fast_state()))
+        states.append(st)
+        ex.close()
+    assert states[0] == states[1]
+    assert len(set(s[0] for s in states[0])) > 1, "the sequence must make at least one level change its mode"
+
+
 @pytest.mark.parametrize("knobs", [{}, {"UVO_TUNE_FEW_FRAMES": 0}, {"UVO_TUNE_ZERO_COPY_OUT": 0}, {"UVO_TUNE_SPIN_WAIT": 0}, {"UVO_TUNE_ZERO_COPY_OUT": 0, "UVO_TUNE_SPIN_WAIT": 0},
                                    {"UVO_TUNE_OCT_WIDE_MAX": 256}, {"UVO_TUNE_PYR_FORM": 1},
                                    {"UVO_TUNE_FEW_FRAMES": 0, "UVO_TUNE_OCT_WIDE_MAX": 256, "UVO_TUNE_ZERO_COPY_OUT": 0, "UVO_TUNE_PYR_FORM": 1}])

@@ -32,7 +32,6 @@ UVO_TUNE_FUSE_BLUR_TREE = 10
 UVO_TUNE_PYR_RING = 12
 UVO_TUNE_PYR_FORM, UVO_PYR_FORM_AUTO, UVO_PYR_FORM_LEVELS, UVO_PYR_FORM_TILES = 13, 0, 1, 2
 UVO_TUNE_PYR_TILE_GROUP = 14
-UVO_TUNE_LANE_STAGGER = 15
 UVO_TUNE_FEW_FRAMES = 16
 UVO_TUNE_ZERO_COPY_OUT, UVO_TUNE_SPIN_WAIT = 17, 18
 

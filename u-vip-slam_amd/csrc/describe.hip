@@ -22,6 +22,20 @@ namespace uvo {
 // below 14 % the two-pass form (measured break-even: a fall-back cell costs 5.5 x what the two-pass form saves per cell, 18 %).
 // Both forms give the same candidates.  Stream order makes the new values visible to this lane's next k_fast_score; no other lane
 // reads them.
+// the ONE place a level's next streaming threshold is decided from its batch's count of fall-back cells (called by adapt_fast_mode for
+// large batches and by k_describe<DIRECT> for the frame or two of a latency call)
+__device__ __forceinline__ void decide_fast_pass(const LevelGeom* __restrict__ lv, int l, int batch, int64_t zc, const FastAdapt& fa) {
+  const int64_t cells = (int64_t)lv[l].n_cells * batch;
+  fa.last[l] = (int32_t)zc;
+  if (fa.adapt && fa.fast_th > 7 && cells > 0) {
+    const int cur_t = fa.tpass[l];
+    if (cur_t > 7 && zc * 100 > cells * 22)
+      fa.tpass[l] = 7;
+    else if (cur_t <= 7 && zc * 100 < cells * 14)
+      fa.tpass[l] = fa.fast_th;
+  }
+}
+
 __device__ __forceinline__ void adapt_fast_mode(const LevelGeom* __restrict__ lv, int nlevels, int batch, const FastAdapt& fa) {
   __shared__ int s_sum[kMaxLevels];
   if (threadIdx.x < kMaxLevels) s_sum[threadIdx.x] = 0;
@@ -34,18 +48,7 @@ __device__ __forceinline__ void adapt_fast_mode(const LevelGeom* __restrict__ lv
     if ((threadIdx.x & 63) == 0 && z) atomicAdd(&s_sum[l], z);
   }
   __syncthreads();
-  if ((int)threadIdx.x < nlevels) {
-    const int l = threadIdx.x;
-    const int64_t zc = s_sum[l], cells = (int64_t)lv[l].n_cells * batch;
-    fa.last[l] = (int32_t)zc;
-    if (fa.adapt && fa.fast_th > 7 && cells > 0) {
-      const int cur_t = fa.tpass[l];
-      if (cur_t > 7 && zc * 100 > cells * 22)
-        fa.tpass[l] = 7;
-      else if (cur_t <= 7 && zc * 100 < cells * 14)
-        fa.tpass[l] = fa.fast_th;
-    }
-  }
+  if ((int)threadIdx.x < nlevels) decide_fast_pass(lv, (int)threadIdx.x, batch, s_sum[threadIdx.x], fa);
 }
 
 template <bool TOPUP>
@@ -294,15 +297,7 @@ __global__ __launch_bounds__(64 * DK_WAVES, UVO_OCC_DESCRIBE) void k_describe(co
       const int l = (int)threadIdx.x;
       int64_t zc = 0;
       for (int b = 0; b < ds.batch; ++b) zc += ds.fa.fcount[b * nlevels + l];
-      const int64_t cells = (int64_t)lv[l].n_cells * ds.batch;
-      ds.fa.last[l] = (int32_t)zc;
-      if (ds.fa.adapt && ds.fa.fast_th > 7 && cells > 0) {
-        const int cur_t = ds.fa.tpass[l];
-        if (cur_t > 7 && zc * 100 > cells * 22)
-          ds.fa.tpass[l] = 7;
-        else if (cur_t <= 7 && zc * 100 < cells * 14)
-          ds.fa.tpass[l] = ds.fa.fast_th;
-      }
+      decide_fast_pass(lv, l, ds.batch, zc, ds.fa);
     }
   } else {
     n = n_final[f];

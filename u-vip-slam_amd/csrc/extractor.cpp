@@ -53,8 +53,6 @@ constexpr int kFewFrames = 2;  // batches up to this size are the latency path (
 
 struct Lane {
   hipStream_t stream = nullptr;  // everything of a batch runs in this ONE in-order stream (no side streams: an error return leaves nothing to join)
-  hipEvent_t ev_class[3] = {nullptr, nullptr, nullptr};  // recorded behind the lane's last launch of a class (lane stagger)
-  bool ev_class_set[3] = {false, false, false};
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_cand_xy = nullptr, *d_cand_sc = nullptr, *d_cand_lo = nullptr, *d_pstate = nullptr, *d_sel_xy = nullptr, *d_sel_sc = nullptr;
   int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_n_final = nullptr, *d_cor_n = nullptr, *d_cursor = nullptr;
@@ -147,7 +145,6 @@ struct uvo_extractor {
   int zero_copy_out = 1;     // UVO_TUNE_ZERO_COPY_OUT: host-buffer calls of up to 16 frames have k_describe write into page-locked host memory
   int spin_wait = 1;         // UVO_TUNE_SPIN_WAIT: those calls, and uvo_extractor_synchronize behind a small batch, poll the stream instead of sleeping
   int few_frames_shape = 1;  // UVO_TUNE_FEW_FRAMES: FullDetect batches of up to kFewFrames frames take the short launch chain (no k_assemble: k_describe finds its slots itself)
-  int lane_stagger = 0;      // UVO_TUNE_LANE_STAGGER: bit mask of the launch classes of which only one pipeline lane runs at a time (0 FAST pass, 1 quad-tree + blur, 2 pyramid)
   int fuse_blur_tree = 1;    // UVO_TUNE_FUSE_BLUR_TREE: quad-tree and blur as one launch when the batch takes the 256-thread quad-tree form
   float* d_pattern = nullptr;   // 256 point pairs (x0, y0, x1, y1) of the rBRIEF pattern as floats
   uint32_t* d_patch = nullptr;  // 256 byte masks: which of the 4 pixels of an orientation-patch dword lie inside the circle
@@ -509,9 +506,6 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   const Level0View no_l0{nullptr, 0, 0, 0};
   {
     // ComputePyramid (src/ORBextractor.cc:963-1004): a launch per group of levels (k_pyr_tiles), or one per level
-    if (h->lane_stagger >> 2 & 1 && h->nlanes > 1)
-      for (int o = 0; o < h->nlanes; ++o)
-        if (o != li && h->lane[o].ev_class_set[2]) UVO_HIP_CHECK(hipStreamWaitEvent(s, h->lane[o].ev_class[2], 0));
     if (!inplace) {
       ProfScope p(h, "k_pad_level0");
       launch_pad_level0(s, d_imgs, width, height, stride, frame_stride, L.d_pyr, g.pyr_block, g.lv[0], batch);
@@ -532,11 +526,6 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
       }
     }
   }
-  if (h->lane_stagger >> 2 & 1 && h->nlanes > 1) {
-    if (!L.ev_class[2]) UVO_HIP_CHECK(hipEventCreateWithFlags(&L.ev_class[2], hipEventDisableTiming));
-    UVO_HIP_CHECK(hipEventRecord(L.ev_class[2], s));
-    L.ev_class_set[2] = true;
-  }
   const bool fused_tree = h->fuse_blur_tree && octree_gauss_applies(h->oct, g, batch);
   // A frame or two (the per-frame latency path, src/Tracking.cc:946): every stage is a chain of dependent phases on a nearly empty chip,
   // so the number of stages is what counts -- a FullDetect call has no k_assemble launch (k_describe finds its slots itself).  (One FAST
@@ -544,30 +533,11 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   const bool few = batch <= kFewFrames && h->few_frames_shape;
   const int32_t* tpass = L.d_tpass;
   const int4 gtaps = make_int4(h->gtaps[0], h->gtaps[1], h->gtaps[2], h->gtaps[3]);
-  // Lane stagger (UVO_TUNE_LANE_STAGGER): two lanes that run the same launch sequence drift into phase -- both streaming their FAST pass at
-  // the same time, then both waiting in their latency-bound stages.  Bit 0 makes the FAST pass of a batch wait for the FAST pass of the
-  // batch before it (the other lane's): the lanes then run half a batch apart, the issue-bound pass of one beside the memory- and
-  // latency-bound stages of the other.  Bits 1 / 2: the same for the quad-tree + blur launch / the pyramid launches.
-  auto stagger_wait = [&](int cls) -> int {
-    if (!(h->lane_stagger >> cls & 1) || h->nlanes < 2) return UVO_OK;
-    for (int o = 0; o < h->nlanes; ++o)
-      if (o != li && h->lane[o].ev_class_set[cls]) UVO_HIP_CHECK(hipStreamWaitEvent(s, h->lane[o].ev_class[cls], 0));
-    return UVO_OK;
-  };
-  auto stagger_mark = [&](int cls) -> int {
-    if (!(h->lane_stagger >> cls & 1) || h->nlanes < 2) return UVO_OK;
-    if (!L.ev_class[cls]) UVO_HIP_CHECK(hipEventCreateWithFlags(&L.ev_class[cls], hipEventDisableTiming));
-    UVO_HIP_CHECK(hipEventRecord(L.ev_class[cls], s));
-    L.ev_class_set[cls] = true;
-    return UVO_OK;
-  };
-  if ((rc = stagger_wait(0)) != UVO_OK) return rc;
   {  // the per-cell threshold vote + candidate emit run inside k_octree
     ProfScope p(h, "k_fast_score");
     launch_fast_score(s, L.d_pyr, g.pyr_block, g, h->cfg.fast_th, tpass, L.d_cor, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, L.d_cand_lo, g.cand_block,
                       L.d_cursor, batch, l0);
   }
-  if ((rc = stagger_mark(0)) != UVO_OK) return rc;
   if (h->cfg.fast_th > 7 && h->fast_mode != UVO_FAST_MODE_SINGLE_PASS) {
     // second call of src/ORBextractor.cc:797 for the cells of threshold-adaptive levels that the pass at fastTh left empty (nearly all
     // wavefronts find nothing to do on textured frames).  With the mode pinned to one pass no level can be adaptive: not launched.
@@ -578,13 +548,11 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
   if (fused_tree) {
     // the quad-tree (a chain of dependent phases per (frame, level)) and the blur (a streaming kernel) read nothing of each other:
     // one grid, the quad-tree problems first, and the blur fills the issue slots they leave idle
-    if ((rc = stagger_wait(1)) != UVO_OK) return rc;
     ProfScope p(h, "k_octree_gauss");
     launch_octree_gauss(s, h->d_lv, g, L.d_pyr, L.d_blur, g.pyr_block, gtaps, h->blur_rounding, L.d_cand_lo, L.d_cursor,
                         L.d_fcount, L.d_fstat + kMaxLevels, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count, L.d_pstate, L.d_sel_xy, L.d_sel_sc, L.d_sel_count,
                         batch, l0);
   } else {
-    if ((rc = stagger_wait(1)) != UVO_OK) return rc;
     {
       ProfScope p(h, "k_gauss7");
       launch_gauss7(s, L.d_pyr, L.d_blur, g.pyr_block, h->d_lv, g, gtaps, batch, h->blur_rounding, l0);
@@ -596,7 +564,6 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
       if (rc) return rc;
     }
   }
-  if ((rc = stagger_mark(1)) != UVO_OK) return rc;
   const bool direct = few && full_detect && !(d_in_kp && d_n_in);
   const FastAdapt fa{L.d_fcount, L.d_tpass, L.d_fstat, h->fast_mode == UVO_FAST_MODE_ADAPTIVE ? 1 : 0, h->cfg.fast_th};
   if (!direct) {
@@ -798,8 +765,6 @@ void uvo_extractor_destroy(uvo_extractor* h) {
     for (void* p : lp)
       if (p) (void)hipFree(p);
     if (L.a_uploaded) (void)hipEventDestroy(L.a_uploaded);
-    for (hipEvent_t& e : L.ev_class)
-      if (e) (void)hipEventDestroy(e);
     for (hipEvent_t& e : L.done)
       if (e) (void)hipEventDestroy(e);
     if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -977,9 +942,6 @@ int uvo_extractor_tune(uvo_extractor* h, int knob, int value) {
       return UVO_OK;
     case UVO_TUNE_FEW_FRAMES:
       h->few_frames_shape = value != 0;
-      return UVO_OK;
-    case UVO_TUNE_LANE_STAGGER:
-      h->lane_stagger = value & 7;
       return UVO_OK;
     case UVO_TUNE_FUSE_BLUR_TREE:
       h->fuse_blur_tree = value != 0;

@@ -28,13 +28,12 @@ __device__ __forceinline__ GaussRowTaps gauss_row_taps(int4 t) {
   T.c3 = pk4(t.x, t.y, t.z, t.w), T.r3 = pk4(t.z, t.y, t.x, 0);
   return T;
 }
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t R, const GaussRowTaps& T, f32x2* h) {
+__device__ __forceinline__ void gauss_row_pass(uint32_t L, uint32_t C, uint32_t R, const GaussRowTaps& T, float* h) {
   const uint32_t s0 = __builtin_amdgcn_udot4(C, T.c0, __builtin_amdgcn_udot4(L, T.l0, 0u, false), false);
   const uint32_t s1 = __builtin_amdgcn_udot4(R, T.r1, __builtin_amdgcn_udot4(C, T.c1, __builtin_amdgcn_udot4(L, T.l1, 0u, false), false), false);
   const uint32_t s2 = __builtin_amdgcn_udot4(R, T.r2, __builtin_amdgcn_udot4(C, T.c2, __builtin_amdgcn_udot4(L, T.l2, 0u, false), false), false);
   const uint32_t s3 = __builtin_amdgcn_udot4(R, T.r3, __builtin_amdgcn_udot4(C, T.c3, 0u, false), false);
-  h[0] = f32x2{(float)s0, (float)s1}, h[1] = f32x2{(float)s2, (float)s3};  // < 2^16: exact; pairs: the column pass runs on the packed fp32 pipe
+  h[0] = (float)s0, h[1] = (float)s1, h[2] = (float)s2, h[3] = (float)s3;  // < 2^16: exact
 }
 
 // the strip plans of a geometry's levels (region = ROI + the 4-pixel ring: (w + 8) x (h + 8)), made on the host once per launch: a
@@ -161,12 +160,11 @@ __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, 
   const GaussRowTaps RT = gauss_row_taps(taps);
   // column taps scaled by 2^-16 (exact): the column sum comes out as sum / 65536 -- every partial sum an exact multiple of 2^-16 below 2^8
   // (a larger one belongs to a result that saturates anyway), so no operation of the pass rounds, whatever the mode
-  const float c0s = (float)taps.x * (1.0f / 65536.0f), c1s = (float)taps.y * (1.0f / 65536.0f), c2s = (float)taps.z * (1.0f / 65536.0f),
-              c3s = (float)taps.w * (1.0f / 65536.0f);
-  const f32x2 c0{c0s, c0s}, c1{c1s, c1s}, c2{c2s, c2s}, c3{c3s, c3s};
+  const float c0 = (float)taps.x * (1.0f / 65536.0f), c1 = (float)taps.y * (1.0f / 65536.0f), c2 = (float)taps.z * (1.0f / 65536.0f),
+              c3 = (float)taps.w * (1.0f / 65536.0f);
   if (!SSE2) __builtin_amdgcn_s_setreg(0x801, 3);  // MODE.fp_round[1:0] (fp32) = toward zero: the float -> byte conversion of sum + .5 is the floor
   const int lane_up = (lane > 0 ? lane - 1 : lane) * 4, lane_down = (lane < 63 ? lane + 1 : lane) * 4;  // ds_bpermute byte addresses
-  f32x2 hring[7][2];
+  float hring[7][4];
   uint32_t cring[7];
   // Row loads are issued one unrolled block (7 rows) ahead of their use: a wavefront walks ~70 rows one after another, so
   // without the prefetch every row would expose a full memory round trip.
@@ -208,29 +206,25 @@ __device__ __forceinline__ void gauss7_body(int block, int blocks_x, int batch, 
         phase = (phase + 1) & 7;
         if (j >= 6) {
           // output row py = py0l + j - 6; its 7 source rows sit in ring slots (u+1)%7 .. (u+7)%7
-          const f32x2* r0 = hring[(u + 1) % 7];
-          const f32x2* r1 = hring[(u + 2) % 7];
-          const f32x2* r2 = hring[(u + 3) % 7];
-          const f32x2* r3 = hring[(u + 4) % 7];
-          const f32x2* r4 = hring[(u + 5) % 7];
-          const f32x2* r5 = hring[(u + 6) % 7];
-          const f32x2* r6 = hring[u];
+          const float* r0 = hring[(u + 1) % 7];
+          const float* r1 = hring[(u + 2) % 7];
+          const float* r2 = hring[(u + 3) % 7];
+          const float* r3 = hring[(u + 4) % 7];
+          const float* r4 = hring[(u + 5) % 7];
+          const float* r5 = hring[(u + 6) % 7];
+          const float* r6 = hring[u];
           const uint32_t centre = cring[(u + 4) % 7];
           const bool row_in = (uint32_t)j - j_in0 < n_in;
-          // column pass on the packed fp32 pipe (two pixels per instruction: v_pk_add_f32 / v_pk_fma_f32 -- 2.2 / 2.5 cycles per result
-          // against 2.7 / 4.3 of the scalar forms, tools/ubench/pk_f32_rate.hip); clamp to 255 and the byte insert are the conversion itself
+          // column pass in fp32, one pixel per instruction (v_add_f32 / v_fma_f32); clamp to 255 and the byte insert are the conversion
+          // itself.  (Round 5's packed form -- v_pk_add_f32 / v_pk_fma_f32 on pixel pairs -- issues fewer instructions and wins the
+          // micro-benchmark, tools/ubench/pk_f32_rate.hip, but needs more registers: 0.238 - 0.246 against 0.229 - 0.231 ms per 257-frame
+          // launch at the same occupancy, profiles/r06_blur_occupancy_ab.txt.)
           uint32_t blurred = 0;
 #pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            const f32x2 half{0.5f, 0.5f}, zero{0.f, 0.f};
-            f32x2 z = __builtin_elementwise_fma(c0, r0[p] + r6[p], __builtin_elementwise_fma(c1, r1[p] + r5[p], __builtin_elementwise_fma(c2, r2[p] + r4[p],
-                          __builtin_elementwise_fma(c3, r3[p], SSE2 ? zero : half))));
-            if (SSE2 && TAIL) {  // the scalar tail's columns: floor(sum + .5) is a whole number, which the conversion leaves alone
-              const f32x2 up{__builtin_floorf(z.x + 0.5f), __builtin_floorf(z.y + 0.5f)};
-              z = tail_lane ? up : z;
-            }
-            blurred = __builtin_amdgcn_cvt_pk_u8_f32(z.x, (uint32_t)(2 * p), blurred);
-            blurred = __builtin_amdgcn_cvt_pk_u8_f32(z.y, (uint32_t)(2 * p + 1), blurred);
+          for (int k = 0; k < 4; ++k) {
+            float z = __builtin_fmaf(c0, r0[k] + r6[k], __builtin_fmaf(c1, r1[k] + r5[k], __builtin_fmaf(c2, r2[k] + r4[k], __builtin_fmaf(c3, r3[k], SSE2 ? 0.0f : 0.5f))));
+            if (SSE2 && TAIL) z = tail_lane ? __builtin_floorf(z + 0.5f) : z;  // the scalar tail's columns: floor(sum + .5) is a whole number, which the conversion leaves alone
+            blurred = __builtin_amdgcn_cvt_pk_u8_f32(z, (uint32_t)k, blurred);
           }
           // pad ring and anything outside the image: the un-blurred centre pixel (byte mask per lane, rows uniform)
           const uint32_t m = row_in ? inmask : 0u;

@@ -239,8 +239,12 @@ struct GaussArgs {
 #define UVO_OCT_EVERY 3  // every third workgroup of the front of the grid is a quad-tree problem (measured against every second: the same)
 #endif
 static_assert(UVO_OCT_EVERY >= 2, "the interleave needs at least one blur workgroup between two quad-tree problems");
+#ifndef UVO_OCT_GAUSS_OCC
+#define UVO_OCT_GAUSS_OCC 5  // workgroups per CU the register allocation is held to: 96 VGPRs, five wavefronts per SIMD.  At 4 the SSE2 instantiation takes
+                             // 100 registers and falls to four wavefronts per SIMD: 0.251 against 0.229 ms per 257-frame launch (profiles/r06_blur_occupancy_ab.txt)
+#endif
 template <bool SSE2>
-__global__ __launch_bounds__(256, 4) void k_octree_gauss(int n_oct, GaussArgs G, const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max, int pyr_words, int box_region,
+__global__ __launch_bounds__(256, UVO_OCT_GAUSS_OCC) void k_octree_gauss(int n_oct, GaussArgs G, const LevelGeom* __restrict__ lv, int nlevels, int Mmax, int Mp2max, int pyr_words, int box_region,
                                                         int lds_bytes, FastLevels FL, const uint32_t* __restrict__ cand_lo, int32_t* __restrict__ cursor,
                                                         int32_t* __restrict__ fcount, int32_t* __restrict__ n_cell_list, uint8_t* cell_hi,
                                                         uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc, int64_t cand_block,

@@ -14,9 +14,7 @@
 #define UVO_TUNE_PYR_TILE_GROUP 14  /* forces the level groups of k_pyr_tiles: one call per group, value = first level << 16 | tx << 8 | ty
                                        (| 1 << 24: 1024-thread workgroups; | 1 << 25: 1024 threads, one output row per work item), first level 1 starts a new
                                        list; 0: back to the defaults */
-#define UVO_TUNE_LANE_STAGGER 15    /* pipeline depth > 1: bit mask of the launch classes of which only ONE lane runs at a time (device-side events between the
-                                       lanes' streams): bit 0 the FAST pass, bit 1 the quad-tree + blur launch, bit 2 the pyramid launches.  Lanes that run the same
-                                       sequence drift into phase; staggered, the issue-bound pass of one runs beside the memory-bound stages of the other */
+/* (15: the side-stream blur of round 5, removed in round 6 -- a batch runs in ONE in-order stream) */
 #define UVO_TUNE_FEW_FRAMES 16      /* 1 (default): FullDetect batches of one or two frames run without k_assemble (k_describe reads the quad-tree's survivors
                                        itself: one launch less in a chain of latency-bound launches); 0: the same launches as large batches */
 #define UVO_TUNE_ZERO_COPY_OUT 17   /* 1 (default): host-buffer calls of up to 16 frames let k_describe write counts, keypoints and descriptors straight into
