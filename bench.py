@@ -13,11 +13,14 @@ the NEIGHBOURING rank's first frame, recomputed locally as a 1-frame halo: weak 
 `value` is the HBM-resident rate; consecutive steps read four DISTINCT input batches in turn (the sequence and its three mirror
 images: same statistics, 4 x 84 MB, more than the 256 MB Infinity Cache keeps).  The same line carries: `roofline` = the HBM
 roofline of the dominant kernel (algorithmic bytes per launch / its live launch duration, HIP events on the library's stream inside
-the timed region, against 8 TB/s) with `roofline.per_kernel` for every kernel of the step, top-level `whole_path_frac` (the step's
+the timed region, against 8 TB/s; `frac` = `frac_live`, with `frac_alone` = the same launch at pipeline depth 1 and both recomputed from
+the committed rocprofv3 files `roofline.rocprof_csv` names) with `roofline.per_kernel` for every kernel of the step; `step_spread` (the
+step's period inside the timed region, min / median / max, from the events of the dominant kernel's launches); top-level `whole_path_frac` (the step's
 algorithmic bytes x frames/s against 8 TB/s) and `valu_frac` (the dominant kernel's VALU issue rate against the chip's issue peak --
 what actually bounds it); the host-to-host rate through uvo_sharder (uploads of page-locked frames + the gather of all ranks'
-results into one page-locked host region, `host_to_host`); sub-records for configs[1] (batch-1 latency), extract-only and
-configs[4] (fused frustum search); a measured device-copy bandwidth next to the 8 TB/s spec; `verified_frames` (outputs of the TIMED
+results into one page-locked host region, `host_to_host`, with every rank's measured link rates and `h2h_frac` = what the leg does
+against what the link can do); sub-records for configs[1] (batch-1 latency), configs[3] (1920x1080 @ 2000 features: one GPU's share,
+verified; with N ranks its real shape, N x 128 frames with the host gather), extract-only and configs[4] (fused frustum search); a measured device-copy bandwidth next to the 8 TB/s spec; `verified_frames` (outputs of the TIMED
 buffers compared with the CPU oracle after the timed region; a mismatch fails the run; the oracle is this repo's restatement of the
 reference -- parity unpinned) and `cpu_baseline` (the same oracle timed on this host's cores on bounded
 samples).  Prints ONE JSON line on rank 0.
@@ -304,6 +307,23 @@ def device_copy_gbps(torch, dev):
     dt = time.perf_counter() - t0
     del a, b
     return 2.0 * n * 10 / dt / 1e9
+
+
+def rocprof_avg_ms(csv_path, kernel):
+    """AverageNs x calls-per-step of a kernel's row(s) in a committed `rocprofv3 --kernel-trace --stats` summary (the device kernels behind a
+    profiler name: k_knn2 -> k_knn2_mfma, k_fast_cells -> + _list); -> (ms per launch averaged over the file's launches, launches) or None"""
+    import csv
+    try:
+        rows = list(csv.DictReader(open(os.path.join(ROOT, csv_path))))
+    except OSError:
+        return None
+    tot, calls = 0.0, 0
+    for r in rows:
+        nm = r["Name"].replace("void ", "").replace("uvo::", "").split("(")[0].split("<")[0]
+        if nm == kernel or nm.startswith(kernel + "_"):
+            tot += float(r["TotalDurationNs"])
+            calls = max(calls, int(r["Calls"]))
+    return (tot / calls / 1e6, calls) if calls else None
 
 
 def load_pmc(config):
@@ -1011,6 +1031,12 @@ def main():
                                       "unit makes a scalar instruction cost a vector slot at this density (tools/ubench/valu_issue.hip)"}
         whole_path_frac = total_alg * value / world / 1e9 / HBM_PEAK_GBS
         prof_tag = PROFILE_TAG if args.config == 2 else PROFILE_TAG + "_hd"
+        csv_fracs = {}
+        for key_, depth_ in (("alone", 1), ("live", 2)):
+            got = rocprof_avg_ms("profiles/%s_kernel_stats_depth%d.csv" % (prof_tag, depth_), dom)
+            if got:   # (the files were taken at the configuration's default batch)
+                csv_bytes = alg.get(dom, 0) * (cfg["batch"] + 1) / launches_per_step
+                csv_fracs[key_] = {"avg_launch_ms": round(got[0], 5), "launches_in_file": got[1], "frac": round(csv_bytes / (got[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 5), "traffic": traffic,
                     "kernel": dom, "avg_launch_ms": round(avg_launch_s * 1e3, 5), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                     # the two operating points of the same launch: `frac` / `avg_launch_ms` = frac_live (HIP events inside the timed region, pipeline
@@ -1020,6 +1046,9 @@ def main():
                     "frac_alone": round(bytes_per_launch / alone_launch_s / 1e9 / HBM_PEAK_GBS, 5) if alone_launch_s else None,
                     "avg_launch_ms_alone": round(alone_launch_s * 1e3, 5) if alone_launch_s else None,
                     "rocprof_csv": {"alone": "profiles/%s_kernel_stats_depth1.csv" % prof_tag, "live": "profiles/%s_kernel_stats_depth2.csv" % prof_tag,
+                                    # the same two fractions recomputed from the committed files (taken on the builder's box; pure kernel execution
+                                    # time -- the HIP events of this run also see each launch's dispatch)
+                                    "from_the_files": csv_fracs,
                                     "note": "rocprofv3 --kernel-trace --stats of this command with UVO_PIPELINE_DEPTH=1 resp. 2 and UVO_BENCH_SKIP_SERIAL=1 (every launch "
                                             "of a file ran at that one depth); AverageNs of the kernel's row x launches per step = avg_launch_ms_alone resp. avg_launch_ms"},
                     "traffic_source": pmc_src, "measured_device_copy_GBps": sub.get("device_copy_GBps"),

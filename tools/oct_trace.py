@@ -50,7 +50,12 @@ def main():
     for t in (10, 50, 100, 200, 300, 400):
         print("  resident at %d us: %d" % (t, int(((st <= t) & (en > t)).sum())))
     rows = buf[: 2 * n].reshape(n, 2)
+    if n == 0:
+        print("no marks recorded")
+        return
     t0 = rows[0, 1]
+    if os.environ.get("SEQ"):   # the marks in the order they were taken (octree_core.hpp / octree_pyramid.hpp / octree.hip line : microseconds since the mark before)
+        print("sequence:", " ".join("%d:%.2f" % (int(l), (int(t) - int(rows[i - 1, 1] if i else t0)) / 100.0) for i, (l, t) in enumerate(rows)))
     prev = t0
     agg = {}
     for line, t in rows:

@@ -45,7 +45,7 @@ __device__ unsigned long long g_oct_blocks[4096];
     const int tid = threadIdx.x;
 #ifdef UVO_OCT_TRACE  // developer build only (UVO_EXTRA_FLAGS=-DUVO_OCT_TRACE): per-phase time stamps of one workgroup
 #define OCT_TRACE_MARK()                                                                              \
-  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && g_oct_trace_n < 1024) { \
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x == (gridDim.y > 1 ? gridDim.x / 2 : 0) && g_oct_trace_n < 1024) { /* k_octree: level 0 of the middle frame; k_octree_gauss: problem 0 */ \
     g_oct_trace[2 * g_oct_trace_n] = __LINE__;                                                        \
     g_oct_trace[2 * g_oct_trace_n + 1] = wall_clock64();                                              \
     ++g_oct_trace_n;                                                                                  \
@@ -127,7 +127,8 @@ struct Work {
   uint32_t* pyr;         // [pyramid_words(nIni)]
   int* stat;             // [16]
   uint16_t* tab;         // path tables of the closed-form path (x part, then y part), tab_cap entries; on the device they share the
-  int tab_cap;           // bytes of ccnt / ccnt2 behind the first 2M words (free whenever the tables are live)
+  int tab_cap;           // bytes of ccnt / ccnt2 behind the first 2M words (free whenever the tables are live) ...
+  bool tab_private;      // ... or, where the workgroup's LDS has room, bytes of their own: the sorts do not run over them and nothing is rebuilt
 };
 
 enum { SC_NA = 0, SC_NOUT, SC_NEXP, SC_NPROC, SC_T, SC_NTOEXP, SC_M, SC_TMP };

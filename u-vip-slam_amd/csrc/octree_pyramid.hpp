@@ -340,7 +340,7 @@ OCT_FN int run_pyramid(const Params& pr, const Work& w, const uint32_t* cand_xy,
     best[i] = 0;
   }
   OCT_PHASE_END
-  if (use_tab) {  // the sorts above went through the tables' bytes: build them again (the sort buffer is dead now)
+  if (use_tab && !w.tab_private) {  // the sorts above went through the tables' bytes: build them again (the sort buffer is dead now)
     OCT_PHASE_BEGIN
     for (int x = tid; x < pr.W; x += OCT_NT) xs[x] = (uint16_t)path_xbits(pr, G, x);
     for (int y = tid; y < pr.H; y += OCT_NT) ys[y] = (uint16_t)path_ybits(pr, G, y);
@@ -349,6 +349,11 @@ OCT_FN int run_pyramid(const Params& pr, const Work& w, const uint32_t* cand_xy,
   // ---- per final node the best response, first in candidate order on ties (:1208-1226).  The candidate order of the reference
   //      (cell-major, raster inside a cell) is unique per candidate and invertible, so the winner's coordinates come back out of the
   //      word that won: (score << 32) | ~order ----
+  // (x - 3) / wCell and (y - 3) / hCell by a multiplication with ceil(2^24 / cell): exact for dividends below 4096 and the cell sizes
+  // build_geom accepts (17 .. 66 pixels; fast_geom.hpp) -- an integer division is forty instructions, and this pass does two per candidate
+  const bool by_mul = pr.W < 4096 && pr.H < 4096 && pr.wCell >= 17 && pr.wCell <= 66 && pr.hCell >= 17 && pr.hCell <= 66;
+  const uint32_t inv_w = by_mul ? (0x1000000u + (uint32_t)pr.wCell - 1u) / (uint32_t)pr.wCell : 0u;
+  const uint32_t inv_h = by_mul ? (0x1000000u + (uint32_t)pr.hCell - 1u) / (uint32_t)pr.hCell : 0u;
   OCT_PHASE_BEGIN
   for (int p0 = tid; p0 < P; p0 += 8 * OCT_NT) {
     uint32_t xys[8], scs[8];
@@ -371,7 +376,8 @@ OCT_FN int run_pyramid(const Params& pr, const Work& w, const uint32_t* cand_xy,
         if (v & PYR_FINAL) slot = v & 0x7FFFFFFFu;
       }
       const int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
-      int j = (x - 3) / pr.wCell, i = (y - 3) / pr.hCell;
+      int j = by_mul ? (int)(((uint32_t)(x - 3) * inv_w) >> 24) : (x - 3) / pr.wCell;  // (a candidate lies inside a cell's interior: x, y >= 3)
+      int i = by_mul ? (int)(((uint32_t)(y - 3) * inv_h) >> 24) : (y - 3) / pr.hCell;
       j = j > pr.nCols - 1 ? pr.nCols - 1 : j;
       i = i > pr.nRows - 1 ? pr.nRows - 1 : i;
       const uint32_t ord = ((uint32_t)(i * pr.nCols + j) * 128u + (uint32_t)(y - i * pr.hCell)) * 128u + (uint32_t)(x - j * pr.wCell);

@@ -26,12 +26,27 @@ struct Profiler {
   std::vector<Rec> recs;
   bool wants(const char* name) const { return on && (only.empty() || only == name); }
 
-  void clear() {
-    for (auto& r : recs) {
-      (void)hipEventDestroy(r.a);
-      (void)hipEventDestroy(r.b);
+  // events are kept and used again: creating a pair per launch keeps the host busy long enough to starve a stream of short kernels, and the
+  // idle time in front of a launch then counts as its duration
+  std::vector<hipEvent_t> pool;
+  hipEvent_t take() {
+    if (!pool.empty()) {
+      hipEvent_t e = pool.back();
+      pool.pop_back();
+      return e;
     }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void clear() {
+    for (auto& r : recs) pool.push_back(r.a), pool.push_back(r.b);
     recs.clear();
+    while (pool.size() > 4096) (void)hipEventDestroy(pool.back()), pool.pop_back();
+  }
+  ~Profiler() {
+    clear();
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
   }
   struct Scope {
     Profiler* p;
@@ -44,8 +59,8 @@ struct Profiler {
       r.seq = 0;
       if (active) {
         r.seq = next_seq();
-        (void)hipEventCreate(&r.a);
-        (void)hipEventCreate(&r.b);
+        r.a = p->take();
+        r.b = p->take();
         (void)hipEventRecord(r.a, s);
       }
     }
