@@ -198,3 +198,24 @@ def test_the_resize_launches_may_stop_four_pixels_outside_the_image(uvo, oracle,
         ex.close()
     with pytest.raises(uvo.UvoError):
         uvo.ORBextractor(100, 1.2, 4, 0, 20, max_width=320, max_height=240).tune(uvo.UVO_TUNE_PYR_RING, 5)
+
+
+def test_kernel_times_report_the_spread_of_the_launches(uvo, synth):
+    """uvo_extractor_kernel_times: behind the kernels' rows the spread rows of every kernel with two or more launches -- shortest / median /
+    longest launch, start-to-start period of consecutive launches and half the period of launches two apart (bench.py's `step_spread`)."""
+    img = synth.make_frame(5400, 320, 256)
+    ex = uvo.ORBextractor(300, 1.2, 4, 0, 20, max_width=320, max_height=256)
+    ex.profile(True)
+    for _ in range(6):
+        ex(img)
+    kt = ex.kernel_times()
+    sp = ex.last_spread
+    ex.profile(False)
+    assert all(":" not in k for k in kt) and "k_fast_score" in kt and kt["k_fast_score"][1] == 6
+    s = sp["k_fast_score"]
+    assert set(s) == {"min", "p50", "max", "period_min", "period_p50", "period_max", "period2_min", "period2_p50", "period2_max"}
+    assert 0 < s["min"] <= s["p50"] <= s["max"] and abs(kt["k_fast_score"][0] - 6 * s["p50"]) < 6 * (s["max"] - s["min"]) + 1e-3
+    assert s["period_min"] >= s["min"] * 0.5 and s["period_min"] <= s["period_p50"] <= s["period_max"]   # a call's launches are a chain: the next FAST pass starts a whole call later
+    assert s["period2_min"] <= s["period2_p50"] <= s["period2_max"]
+    assert ex.kernel_times() == {} and ex.last_spread == {}    # reported and cleared
+    ex.close()
