@@ -607,7 +607,8 @@ def step_spread(m, steps, depth=2):
     step); `lane_offset_ms` = start-to-start of consecutive launches (the phase between the lanes); and that kernel's own launch duration"""
     sp = m["spread"]
     key = "period2_" if depth >= 2 else "period_"
-    if key + "p50" not in sp:
+    launches = m["ktimes"].get(m["dom"], (0, 0))[1]
+    if key + "p50" not in sp or launches != steps:   # (needs three or more steps, and a dominant kernel that is launched once per step: not k_resize_level)
         return None
     out = {"ms_min": round(sp[key + "min"], 4), "ms_median": round(sp[key + "p50"], 4), "ms_max": round(sp[key + "max"], 4), "samples": steps - (2 if depth >= 2 else 1),
            "what": "%s of %s launches inside the timed region (one per step, HIP events on the lanes' streams, enqueue order); `ms_per_step` is the mean "

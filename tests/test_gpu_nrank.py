@@ -39,7 +39,7 @@ def test_two_ranks_run_the_configs3_record_with_its_host_gather():
     (here 2 ranks x 6 frames on device 0)."""
     env = dict(os.environ, UVO_BENCH_DRYRUN_ONE_GPU="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", UVO_BENCH_C3_BATCH="6")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29585",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-subrecords", "--c3"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "16", "--steps", "6", "--warmup", "1", "--no-cpu-baseline", "--no-subrecords", "--c3"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, "bench.py --gpus 2 --c3 failed:\n%s\n%s" % (r.stdout[-3000:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -47,8 +47,10 @@ def test_two_ranks_run_the_configs3_record_with_its_host_gather():
     d = json.loads(lines[0])
     c3 = d["sub_records"]["configs[3] over 2 GPUs"]
     assert c3["n_gpus"] == 2 and c3["value"] > 0 and c3["verified_frames"] > 0
-    assert "1920x1080" in c3["workload"] and c3["step_spread"] is not None
+    assert "1920x1080" in c3["workload"]
     h = c3["host_to_host"]
     assert h["gathered_equals_hbm_resident"] is True and h["frames_per_job"] == 12 and "/dev/shm" in h["gather"]
     assert len(h["numa"]) == 2 and all("link_GBps" in r_ and r_["h2h_frac"] > 0 for r_ in h["numa"])
-    assert d["step_spread"] is not None and d["step_spread"]["ms_min"] <= d["step_spread"]["ms_median"] <= d["step_spread"]["ms_max"]
+    for sp in (d["step_spread"], c3["step_spread"]):   # (None when the dominant kernel of so small a batch is one that is launched per level)
+        assert sp is None or 0 < sp["ms_min"] <= sp["ms_median"] <= sp["ms_max"]
+    assert d["step_spread"] is not None or d["roofline"]["kernel"] == "k_resize_level"

@@ -16,7 +16,7 @@ namespace uvo {
 
 static inline int oct_capacity(int N, int nIni) {
   int m = N > 4 * nIni ? N : 4 * nIni;
-  return m + 8;
+  return (m + 8 + 3) & ~3;  // a multiple of 4: every node table of the LDS carve then starts on a 16-byte boundary (rank_below reads keys four at a time)
 }
 // OctLaunchState::wide_max_problems: at most this many (frame, level) problems run as 1024-thread workgroups (one per CU: beyond
 // 256 problems the chip is full either way, and four independent 256-thread problems per CU use it better).  Measured, 640x512 /
@@ -41,11 +41,6 @@ static inline size_t oct_lds_bytes(int M, int Mp2, int pyr_words) {
   b += (size_t)4 * Mp2;                     // sortbuf
   b += (size_t)4 * (32 + 16);               // part (one partial per wavefront on the device), sc
   return b;
-}
-// + the path tables' own bytes (2 bytes per column and row of the largest level) where that keeps five workgroups on a CU (32 KB each)
-static inline size_t oct_lds_with_tables(size_t b, int max_w_plus_h) {
-  const size_t t = (b + 2 * (size_t)max_w_plus_h + 15) & ~(size_t)15;
-  return t <= 32 * 1024 ? t : b;
 }
 
 template <int NT>
@@ -194,15 +189,9 @@ __device__ __forceinline__ void octree_body(uint8_t* lds, const int level, const
   w.sortbuf = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * Mp2max;
   w.part = reinterpret_cast<uint32_t*>(p), p += (size_t)4 * 32;
   w.sc = reinterpret_cast<int*>(p), p += (size_t)4 * 16;
-  // path tables of the closed form: bytes of their own behind the node tables where the launch reserved them (lds_bytes says so), else
-  // the bytes of ccnt / ccnt2 behind the first 2 * Mmax words (`best` lives in front of them), rebuilt behind the sorts
-  if ((int)(p - lds) + 2 * (pr.W + pr.H) <= lds_bytes) {
-    w.tab = reinterpret_cast<uint16_t*>(p), w.tab_cap = (lds_bytes - (int)(p - lds)) / 2, w.tab_private = true;
-  } else {
-    w.tab = reinterpret_cast<uint16_t*>(w.ccnt + 2 * Mmax);
-    w.tab_cap = 12 * Mmax;  // 24 * Mmax bytes of 2-byte entries
-    w.tab_private = false;
-  }
+  // path tables of the closed form: the bytes of ccnt / ccnt2 behind the first 2 * Mmax words (`best` lives in front of them)
+  w.tab = reinterpret_cast<uint16_t*>(w.ccnt + 2 * Mmax);
+  w.tab_cap = 12 * Mmax;  // 24 * Mmax bytes of 2-byte entries
 
   const int64_t so = (int64_t)f * sel_block + g.sel_off;
   // First the closed form over the count pyramid (no pass over the candidates per generation, no per-candidate state).  Trees deeper
@@ -289,9 +278,8 @@ static size_t octree_lds(const Geom& g, int& M, int& Mp2, int& pyr_words) {
   }
   Mp2 = pow2_ge(M);
   pyr_words = 0;
-  int wh = 0;
-  for (int l = 0; l < g.nlevels; ++l) pyr_words = std::max(pyr_words, oct::pyramid_words(g.lv[l].nIni)), wh = std::max(wh, g.lv[l].bw + g.lv[l].bh);
-  return oct_lds_with_tables(oct_lds_bytes(M, Mp2, pyr_words), wh);
+  for (int l = 0; l < g.nlevels; ++l) pyr_words = std::max(pyr_words, oct::pyramid_words(g.lv[l].nIni));
+  return oct_lds_bytes(M, Mp2, pyr_words);
 }
 
 // Everything about the quad-tree launch that can fail, done BEFORE the batch's first kernel is enqueued: k_octree is also what zeroes

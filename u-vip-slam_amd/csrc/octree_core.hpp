@@ -24,6 +24,7 @@
 // the CPU (threads of a phase executed one after another) against that checker; on the GPU a phase ends in a
 // workgroup barrier.
 #pragma once
+#include <cstring>
 #include <stdint.h>
 
 #ifndef OCT_THREADS
@@ -127,8 +128,7 @@ struct Work {
   uint32_t* pyr;         // [pyramid_words(nIni)]
   int* stat;             // [16]
   uint16_t* tab;         // path tables of the closed-form path (x part, then y part), tab_cap entries; on the device they share the
-  int tab_cap;           // bytes of ccnt / ccnt2 behind the first 2M words (free whenever the tables are live) ...
-  bool tab_private;      // ... or, where the workgroup's LDS has room, bytes of their own: the sorts do not run over them and nothing is rebuilt
+  int tab_cap;           // bytes of ccnt / ccnt2 behind the first 2M words (the closed form writes nothing there: `best` lives in front of them)
 };
 
 enum { SC_NA = 0, SC_NOUT, SC_NEXP, SC_NPROC, SC_T, SC_NTOEXP, SC_M, SC_TMP };
@@ -213,15 +213,41 @@ OCT_FN uint32_t block_scan_excl(uint32_t* a, int n, uint32_t* part, int* sc) {
 // ascending sort of the n distinct keys a[0..n); a[n..n2) must be padded with the maximum value (n2 = power of two).
 // Device: rank sort (every key counts the keys below it -- LDS broadcast reads, one pass, two barriers);
 // host emulation: bitonic network.  tmp holds n elements.
+// number of keys of a[0..n) below x; a is 16-byte aligned (the node tables are: oct_capacity rounds M to a multiple of 4), so the keys come
+// four per LDS read (every thread reads the same address: a broadcast)
+struct alignas(16) Key4 {
+  uint32_t x, y, z, w;
+};
+OCT_FN int rank_below(const uint32_t* a, int n, uint32_t x) {
+  int rank = 0, j = 0;
+#if OCT_DEVICE
+#pragma unroll 4  // four reads in flight: one wavefront per SIMD runs this, nothing else hides an LDS round trip
+#endif
+  for (; j + 4 <= n; j += 4) {
+#if OCT_DEVICE
+    const Key4 k = *reinterpret_cast<const Key4*>(a + j);
+#else
+    Key4 k;
+    memcpy(&k, a + j, sizeof(k));
+#endif
+    rank += (k.x < x ? 1 : 0) + (k.y < x ? 1 : 0) + (k.z < x ? 1 : 0) + (k.w < x ? 1 : 0);
+  }
+  for (; j < n; ++j) rank += a[j] < x ? 1 : 0;
+  return rank;
+}
+template <class T>
+OCT_FN int rank_below(const T* a, int n, T x) {
+  int rank = 0;
+  for (int j = 0; j < n; ++j) rank += a[j] < x;
+  return rank;
+}
 template <class T>
 OCT_FN void block_sort(T* a, int n, int n2, T* tmp) {
 #if OCT_DEVICE
   (void)n2;
   for (int i = threadIdx.x; i < n; i += OCT_NT) {
     const T x = a[i];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) rank += a[j] < x;
-    tmp[rank] = x;
+    tmp[rank_below(a, n, x)] = x;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += OCT_NT) a[i] = tmp[i];

@@ -100,6 +100,31 @@ OCT_FN void stat_add(int* dst, bool pred) {
 #endif
 }
 
+// adds every thread's pair of small counts (e | f << 16) to two LDS counters: one wavefront reduction, one atomic per counter and wavefront
+// (every thread of a wavefront must call it; host emulation: plain adds)
+OCT_FN void stat_add_pair(int* dst_e, int* dst_f, uint32_t ef) {
+#if OCT_DEVICE
+  // wavefront sum on the DPP path (no LDS round trips): pairs, quads, half rows, rows, then row 0 -> 1 and 2 -> 3, rows 0 - 1 -> 2 - 3;
+  // lane 63 holds the total
+  int v = (int)ef;
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);   // quad_perm:[1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm:[2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);  // row_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+  ef = (uint32_t)v;
+  if ((threadIdx.x & 63) == 63) {
+    if (ef & 0xffffu) atomicAdd(dst_e, (int)(ef & 0xffffu));
+    if (ef >> 16) atomicAdd(dst_f, (int)(ef >> 16));
+  }
+#else
+  *dst_e += (int)(ef & 0xffffu);
+  *dst_f += (int)(ef >> 16);
+#endif
+}
+OCT_FN uint32_t stat_ef(uint32_t c) { return c > 1 ? 1u : (c == 1 ? 0x10000u : 0u); }  // a node with c points: expandable / single-point
+
 // returns the number of selected points, or -1 when the tree is deeper than the pyramid (caller falls back to oct::run).
 // No per-candidate state: both passes over the candidates recompute the path from the coordinates (a few dozen integer
 // operations), so the kernel's register budget is set by the node-level phases alone.
@@ -143,55 +168,61 @@ OCT_FN int run_pyramid(const Params& pr, const Work& w, const uint32_t* cand_xy,
   }
   OCT_PHASE_END
   OCT_PHASE_BEGIN
-  // (the candidates are read eight at a time: the pass is bound by the latency of these loads, not by arithmetic)
-  for (int p0 = tid; p0 < P; p0 += 8 * OCT_NT) {
-    uint32_t xy[8];
+  // (the candidates are read eight at a time, the next eight while these are counted: the pass is bound by the latency of these loads,
+  // not by arithmetic; indices past the list are clamped into it so that every load is unconditional)
+  {
+    uint32_t cur[8], nxt[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) xy[u] = p0 + u * OCT_NT < P ? cand_xy[p0 + u * OCT_NT] : 0u;
+    for (int u = 0; u < 8; ++u) cur[u] = cand_xy[tid + u * OCT_NT < P ? tid + u * OCT_NT : P - 1];
+    for (int p0 = tid; p0 < P; p0 += 8 * OCT_NT) {
+      const int pn = p0 + 8 * OCT_NT;
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (p0 + u * OCT_NT < P) OCT_ATOMIC_ADD(&pyr[base[G] + (int)tbin_of(xy[u])], 1u);
+      for (int u = 0; u < 8; ++u) nxt[u] = cand_xy[pn + u * OCT_NT < P ? pn + u * OCT_NT : P - 1];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (p0 + u * OCT_NT < P) OCT_ATOMIC_ADD(&pyr[base[G] + (int)tbin_of(cur[u])], 1u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+    }
   }
   OCT_PHASE_END
-  // ---- counts of the shallower nodes: sums of four, two levels per phase ----
+  // ---- counts of the shallower nodes: sums of four, two levels per phase -- and, while the counts pass by, per depth how many nodes
+  //      EXIST (they hold points and their parent holds more than one, i.e. was split) with more than one point / with exactly one:
+  //      a phase sees every node it sums together with its parent's count ----
   for (int g = G; g > 0;) {
     const bool two = g >= 2;
     OCT_PHASE_BEGIN
+    uint32_t ef_g = 0, ef_g1 = 0, ef_top = 0;  // (e | f << 16) of depth g, of depth g - 1, and of depth 0 when this phase reaches it
     if (two) {
       for (int b = tid; b < nb[g - 2]; b += OCT_NT) {
-        uint32_t s = 0;
+        uint32_t s = 0, s1v[4];
         for (int c = 0; c < 4; ++c) {
           const uint32_t* q = &pyr[base[g] + 16 * b + 4 * c];
           const uint32_t s1 = q[0] + q[1] + q[2] + q[3];
           pyr[base[g - 1] + 4 * b + c] = s1;
+          ef_g += (s1 > 1 ? ~0u : 0u) & (stat_ef(q[0]) + stat_ef(q[1]) + stat_ef(q[2]) + stat_ef(q[3]));  // (branch free: the sixteen reads stay in flight together)
+          s1v[c] = s1;
           s += s1;
         }
         pyr[base[g - 2] + b] = s;
+        ef_g1 += (s > 1 ? ~0u : 0u) & (stat_ef(s1v[0]) + stat_ef(s1v[1]) + stat_ef(s1v[2]) + stat_ef(s1v[3]));
+        ef_top += g == 2 ? stat_ef(s) : 0u;
       }
     } else {
       for (int b = tid; b < nb[g - 1]; b += OCT_NT) {
         const uint32_t* q = &pyr[base[g] + 4 * b];
-        pyr[base[g - 1] + b] = q[0] + q[1] + q[2] + q[3];
+        const uint32_t p = q[0] + q[1] + q[2] + q[3];
+        pyr[base[g - 1] + b] = p;
+        ef_g += (p > 1 ? ~0u : 0u) & (stat_ef(q[0]) + stat_ef(q[1]) + stat_ef(q[2]) + stat_ef(q[3]));
+        ef_top += g == 1 ? stat_ef(p) : 0u;
       }
     }
+    stat_add_pair(&stat[PYR_STAT_E + g], &stat[PYR_STAT_F + g], ef_g);
+    if (two) stat_add_pair(&stat[PYR_STAT_E + g - 1], &stat[PYR_STAT_F + g - 1], ef_g1);
+    if ((two && g == 2) || (!two && g == 1)) stat_add_pair(&stat[PYR_STAT_E], &stat[PYR_STAT_F], ef_top);
     OCT_PHASE_END
     g -= two ? 2 : 1;
   }
-  // ---- per depth: how many nodes exist (parent was split) with more than one point / with exactly one ----
-  OCT_PHASE_BEGIN
-  for (int g = 0; g <= G; ++g) {
-    for (int b0 = 0; b0 < nb[g]; b0 += OCT_NT) {  // whole wavefronts take part in every ballot
-      const int b = b0 + tid;
-      uint32_t c = 0;
-      if (b < nb[g]) {
-        c = pyr[base[g] + b];
-        if (g > 0 && pyr[base[g - 1] + (b >> 2)] <= 1) c = 0;
-      }
-      stat_add(&stat[PYR_STAT_E + g], c > 1);
-      stat_add(&stat[PYR_STAT_F + g], c == 1);
-    }
-  }
-  OCT_PHASE_END
   // ---- the full passes, on counts alone (every thread walks the same few numbers) ----
   int g = 0;
   int size = stat[PYR_STAT_E] + stat[PYR_STAT_F];
@@ -212,20 +243,24 @@ OCT_FN int run_pyramid(const Params& pr, const Work& w, const uint32_t* cand_xy,
   if (careful && g == G) return -1;  // a careful round reads the children's counts
   // ---- nodes of the pass-made generations: single-point nodes are final where they were born; the multi-point nodes of generation g
   //      are final too, or become the first careful round's candidates ----
+  // (the levels lie one behind the other in the pyramid: ONE index space over all the bins of generations 0 .. g, so that the few bins of
+  // the shallow levels do not each cost the first threads a dependent trip of their own)
   OCT_PHASE_BEGIN
-  for (int k = 0; k <= g; ++k) {
-    for (int b = tid; b < nb[k]; b += OCT_NT) {
-      const uint32_t c = pyr[base[k] + b];
-      if (c == 0 || (k > 0 && pyr[base[k - 1] + (b >> 2)] <= 1)) continue;
-      const uint32_t pos = (uint32_t)((k & 1) ? nb[k] - 1 - b : b);
-      if (c == 1 || (k == g && !careful)) {
-        const int slot = OCT_ATOMIC_ADD(&sc[SC_NOUT], 1);
-        w.outKey[slot] = ((uint32_t)(GEN_MAX - k) << 16) | pos;
-        w.outPt[slot] = ((uint32_t)k << 16) | (uint32_t)b;
-      } else if (k == g) {
-        const int slot = OCT_ATOMIC_ADD(&sc[SC_NA], 1);
-        keys_in[slot] = ((0xFFFFFu - (c > 0xFFFFFu ? 0xFFFFFu : c)) << 12) | pos;
-      }
+  for (int i = tid; i < base[g] + nb[g]; i += OCT_NT) {
+    int k = 0;
+#pragma unroll
+    for (int d = 1; d <= PYR_MAX_DEPTH; ++d) k += (d <= g && i >= base[d]) ? 1 : 0;
+    const int b = i - base[k];
+    const uint32_t c = pyr[i];
+    if (c == 0 || (k > 0 && pyr[base[k - 1] + (b >> 2)] <= 1)) continue;
+    const uint32_t pos = (uint32_t)((k & 1) ? nb[k] - 1 - b : b);
+    if (c == 1 || (k == g && !careful)) {
+      const int slot = OCT_ATOMIC_ADD(&sc[SC_NOUT], 1);
+      w.outKey[slot] = ((uint32_t)(GEN_MAX - k) << 16) | pos;
+      w.outPt[slot] = ((uint32_t)k << 16) | (uint32_t)b;
+    } else if (k == g) {
+      const int slot = OCT_ATOMIC_ADD(&sc[SC_NA], 1);
+      keys_in[slot] = ((0xFFFFFu - (c > 0xFFFFFu ? 0xFFFFFu : c)) << 12) | pos;
     }
   }
   OCT_PHASE_END
@@ -323,29 +358,19 @@ OCT_FN int run_pyramid(const Params& pr, const Work& w, const uint32_t* cand_xy,
     OCT_PHASE_END
   }
 
-  // ---- list order = (generation desc, position asc): the output slot of every final node ----
+  // ---- list order = (generation desc, position asc): the output slot of every final node is the RANK of its key among the (distinct) keys
+  //      -- every node counts the keys below its own (broadcast reads) and takes that slot: no sorted array is ever written, and the path
+  //      tables (which share bytes with the sort buffer of the fall-back form) stay as they are ----
   const int nOut = oct_bcast(&sc[SC_NOUT]);
-  uint64_t* srt = reinterpret_cast<uint64_t*>(w.ccnt2);
   uint64_t* best = reinterpret_cast<uint64_t*>(w.ccnt);
-  int n2 = 1;
-  while (n2 < nOut) n2 <<= 1;
-  OCT_PHASE_BEGIN
-  for (int i = tid; i < n2; i += OCT_NT) srt[i] = i < nOut ? (((uint64_t)w.outKey[i] << 32) | w.outPt[i]) : ~0ull;
-  OCT_PHASE_END
-  block_sort(srt, nOut, n2, best);
   OCT_PHASE_BEGIN
   for (int i = tid; i < nOut; i += OCT_NT) {
-    const uint32_t ref = (uint32_t)(srt[i] & 0xffffffffu);
-    pyr[base[ref >> 16] + (int)(ref & 0xffffu)] = PYR_FINAL | (uint32_t)i;
-    best[i] = 0;
+    const uint32_t key = w.outKey[i], ref = w.outPt[i];
+    const int rank = rank_below(w.outKey, nOut, key);
+    pyr[base[ref >> 16] + (int)(ref & 0xffffu)] = PYR_FINAL | (uint32_t)rank;
+    best[rank] = 0;
   }
   OCT_PHASE_END
-  if (use_tab && !w.tab_private) {  // the sorts above went through the tables' bytes: build them again (the sort buffer is dead now)
-    OCT_PHASE_BEGIN
-    for (int x = tid; x < pr.W; x += OCT_NT) xs[x] = (uint16_t)path_xbits(pr, G, x);
-    for (int y = tid; y < pr.H; y += OCT_NT) ys[y] = (uint16_t)path_ybits(pr, G, y);
-    OCT_PHASE_END
-  }
   // ---- per final node the best response, first in candidate order on ties (:1208-1226).  The candidate order of the reference
   //      (cell-major, raster inside a cell) is unique per candidate and invertible, so the winner's coordinates come back out of the
   //      word that won: (score << 32) | ~order ----
@@ -354,34 +379,51 @@ OCT_FN int run_pyramid(const Params& pr, const Work& w, const uint32_t* cand_xy,
   const bool by_mul = pr.W < 4096 && pr.H < 4096 && pr.wCell >= 17 && pr.wCell <= 66 && pr.hCell >= 17 && pr.hCell <= 66;
   const uint32_t inv_w = by_mul ? (0x1000000u + (uint32_t)pr.wCell - 1u) / (uint32_t)pr.wCell : 0u;
   const uint32_t inv_h = by_mul ? (0x1000000u + (uint32_t)pr.hCell - 1u) / (uint32_t)pr.hCell : 0u;
+  // every depth-G bin learns the slot of the final node on its path (a path crosses exactly one; deepest first so that the shallowest
+  // wins), in place of its own count -- nobody else reads that word, the shallower levels stay as they are: the pass over the candidates
+  // then takes one read per candidate instead of one per depth
   OCT_PHASE_BEGIN
-  for (int p0 = tid; p0 < P; p0 += 8 * OCT_NT) {
-    uint32_t xys[8], scs[8];
+  for (int b = tid; b < nb[G]; b += OCT_NT) {
+    uint32_t slot = 0xFFFFFFFFu;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const bool in = p0 + u * OCT_NT < P;
-      xys[u] = in ? cand_xy[p0 + u * OCT_NT] : 0u;
-      scs[u] = in ? cand_score[p0 + u * OCT_NT] : 0u;
+    for (int d = PYR_MAX_DEPTH; d >= 0; --d) {
+      if (d > G) continue;
+      const uint32_t v = pyr[base[d] + (b >> (2 * (G - d)))];
+      if (v & PYR_FINAL) slot = v & 0x7FFFFFFFu;
     }
+    pyr[base[G] + b] = slot;
+  }
+  OCT_PHASE_END
+  OCT_PHASE_BEGIN
+  {
+    uint32_t cx[8], cs[8], nx[8], ns[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      if (p0 + u * OCT_NT >= P) continue;
-      const uint32_t xy = xys[u];
-      const uint32_t tb = tbin_of(xy);
-      uint32_t slot = 0xFFFFFFFFu;
+      const int q = tid + u * OCT_NT < P ? tid + u * OCT_NT : P - 1;
+      cx[u] = cand_xy[q], cs[u] = cand_score[q];
+    }
+    for (int p0 = tid; p0 < P; p0 += 8 * OCT_NT) {
+      const int pn = p0 + 8 * OCT_NT;
 #pragma unroll
-      for (int d = PYR_MAX_DEPTH; d >= 0; --d) {  // a path crosses exactly one final node; deepest first so that the shallowest wins
-        if (d > G) continue;
-        const uint32_t v = pyr[base[d] + (int)(tb >> (2 * (G - d)))];
-        if (v & PYR_FINAL) slot = v & 0x7FFFFFFFu;
+      for (int u = 0; u < 8; ++u) {  // the next eight while these are placed (unconditional loads: indices clamped into the list)
+        const int q = pn + u * OCT_NT < P ? pn + u * OCT_NT : P - 1;
+        nx[u] = cand_xy[q], ns[u] = cand_score[q];
       }
-      const int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
-      int j = by_mul ? (int)(((uint32_t)(x - 3) * inv_w) >> 24) : (x - 3) / pr.wCell;  // (a candidate lies inside a cell's interior: x, y >= 3)
-      int i = by_mul ? (int)(((uint32_t)(y - 3) * inv_h) >> 24) : (y - 3) / pr.hCell;
-      j = j > pr.nCols - 1 ? pr.nCols - 1 : j;
-      i = i > pr.nRows - 1 ? pr.nRows - 1 : i;
-      const uint32_t ord = ((uint32_t)(i * pr.nCols + j) * 128u + (uint32_t)(y - i * pr.hCell)) * 128u + (uint32_t)(x - j * pr.wCell);
-      if (slot != 0xFFFFFFFFu) OCT_ATOMIC_MAX64(&best[slot], ((uint64_t)scs[u] << 32) | (uint64_t)(0xFFFFFFFFu - ord));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (p0 + u * OCT_NT >= P) continue;
+        const uint32_t xy = cx[u];
+        const uint32_t slot = pyr[base[G] + (int)tbin_of(xy)];
+        const int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
+        int j = by_mul ? (int)(((uint32_t)(x - 3) * inv_w) >> 24) : (x - 3) / pr.wCell;  // (a candidate lies inside a cell's interior: x, y >= 3)
+        int i = by_mul ? (int)(((uint32_t)(y - 3) * inv_h) >> 24) : (y - 3) / pr.hCell;
+        j = j > pr.nCols - 1 ? pr.nCols - 1 : j;
+        i = i > pr.nRows - 1 ? pr.nRows - 1 : i;
+        const uint32_t ord = ((uint32_t)(i * pr.nCols + j) * 128u + (uint32_t)(y - i * pr.hCell)) * 128u + (uint32_t)(x - j * pr.wCell);
+        if (slot != 0xFFFFFFFFu) OCT_ATOMIC_MAX64(&best[slot], ((uint64_t)cs[u] << 32) | (uint64_t)(0xFFFFFFFFu - ord));
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cx[u] = nx[u], cs[u] = ns[u];
     }
   }
   OCT_PHASE_END
