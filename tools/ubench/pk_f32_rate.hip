@@ -24,6 +24,12 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a0) {
       if (OP == 6) asm volatile("v_fract_f32 %0, %0" : "+v"(s[r % 8]));
       if (OP == 7) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[r % 8]) : "v"(b));
       if (OP == 8) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(acc) : "v"(__builtin_bit_cast(uint32_t, s[r % 8])), "v"(0x01020304u));
+      if (OP == 9) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(s[r % 8]) : "v"(b.x), "v"(c.x));            // VOP2: D += S0 * S1, two vector sources
+      if (OP == 10) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(s[r % 8]) : "s"(a0), "v"(c.x));             // ... one of them scalar (the blur's tap)
+      if (OP == 11) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s[r % 8]) : "s"(a0), "v"(c.x));          // VOP3 with the same operands
+      if (OP == 12) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(s[r % 8]) : "v"(b.x));
+      if (OP == 13) asm volatile("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(acc) : "v"(__builtin_bit_cast(uint32_t, s[r % 8])), "v"(0x37u));
+      if (OP == 14) asm volatile("v_dot2_u32_u16 %0, %1, %2, %0" : "+v"(acc) : "v"(__builtin_bit_cast(uint32_t, s[r % 8])), "v"(0x00370031u));
     }
   }
   float t = (float)acc;
@@ -53,6 +59,7 @@ int main() {
   for (int w : {1, 4, 8}) {
     run<0>("v_fma_f32", w), run<1>("v_pk_fma_f32", w), run<2>("v_add_f32", w), run<3>("v_pk_add_f32", w), run<7>("v_pk_mul_f32", w);
     run<4>("v_cvt_f32_u32", w), run<5>("v_cvt_pk_u8_f32", w), run<6>("v_fract_f32", w), run<8>("v_dot4_u32_u8", w);
+    run<9>("v_fmac_f32 vv", w), run<10>("v_fmac_f32 sv", w), run<11>("v_fma_f32 svv", w), run<12>("v_mul_f32", w), run<13>("v_mad_u32_u24", w), run<14>("v_dot2_u32_u16", w);
   }
   return 0;
 }

@@ -218,20 +218,24 @@ OCT_FN uint32_t block_scan_excl(uint32_t* a, int n, uint32_t* part, int* sc) {
 struct alignas(16) Key4 {
   uint32_t x, y, z, w;
 };
+OCT_FN Key4 key4_at(const uint32_t* p) {
+#if OCT_DEVICE
+  return *reinterpret_cast<const Key4*>(p);
+#else
+  Key4 k;
+  memcpy(&k, p, sizeof(k));
+  return k;
+#endif
+}
+OCT_FN int key4_below(const Key4& k, uint32_t x) { return (k.x < x ? 1 : 0) + (k.y < x ? 1 : 0) + (k.z < x ? 1 : 0) + (k.w < x ? 1 : 0); }
 OCT_FN int rank_below(const uint32_t* a, int n, uint32_t x) {
   int rank = 0, j = 0;
-#if OCT_DEVICE
-#pragma unroll 4  // four reads in flight: one wavefront per SIMD runs this, nothing else hides an LDS round trip
-#endif
-  for (; j + 4 <= n; j += 4) {
-#if OCT_DEVICE
-    const Key4 k = *reinterpret_cast<const Key4*>(a + j);
-#else
-    Key4 k;
-    memcpy(&k, a + j, sizeof(k));
-#endif
-    rank += (k.x < x ? 1 : 0) + (k.y < x ? 1 : 0) + (k.z < x ? 1 : 0) + (k.w < x ? 1 : 0);
+  // sixteen keys per trip, their four reads in flight together: one wavefront per SIMD runs this, nothing else hides an LDS round trip
+  for (; j + 16 <= n; j += 16) {
+    const Key4 k0 = key4_at(a + j), k1 = key4_at(a + j + 4), k2 = key4_at(a + j + 8), k3 = key4_at(a + j + 12);
+    rank += key4_below(k0, x) + key4_below(k1, x) + key4_below(k2, x) + key4_below(k3, x);
   }
+  for (; j + 4 <= n; j += 4) rank += key4_below(key4_at(a + j), x);
   for (; j < n; ++j) rank += a[j] < x ? 1 : 0;
   return rank;
 }
