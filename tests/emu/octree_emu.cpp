@@ -39,7 +39,7 @@ extern "C" int emu_octree_algo(const uint32_t* cand_xy, const uint32_t* cand_sco
   w.nodeOfRank = nodeOfRank.data(), w.baseOfRank = baseOfRank.data(), w.sortbuf = sortbuf.data();
   w.outKey = outKey.data(), w.outPt = outPt.data(), w.part = part.data(), w.sc = sc.data();
   w.pyr = pyr.data(), w.stat = stat.data();
-  w.tab = tab.data(), w.tab_cap = (int)tab.size();
+  w.tab = tab.data(), w.tab_cap = (int)tab.size(), w.tab_src = nullptr;
   if (k_regs < 0) k_regs = P <= 8 * OCT_THREADS ? 8 : (P <= 32 * OCT_THREADS ? 32 : 0);
   if (k_regs > 0 && P > k_regs * OCT_THREADS) return -1;
   int n = -1;

@@ -46,6 +46,8 @@ struct LevelGeom {
   float patch_size;    // (float)(int)(31*scale)
   int xtab_off;        // element offset of this level's column resize table (level >= 1; one entry per padded column, pitch entries)
   int ytab_off;        // same for the row table (ph entries)
+  int oct_tab_off;     // element offset of this level's quad-tree path tables (bw column entries, then bh row entries; octree_fill_path_tables)
+  int pad_;
 };
 
 // Level 0 read in place: the caller's image instead of the padded plane (cv::copyMakeBorder at :996 is then never materialised).
@@ -136,11 +138,15 @@ bool octree_gauss_applies(const OctLaunchState& st, const Geom& g, int batch);
 void launch_octree_gauss(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, int4 taps, int sse2_rounding,
                          const uint32_t* d_cand_lo, int32_t* d_cursor, int32_t* d_fcount, int32_t* d_n_cell_list, uint8_t* d_cell_hi, uint32_t* d_cand_xy,
                          uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
-                         int32_t* d_sel_count, int batch, Level0View l0);
+                         int32_t* d_sel_count, int batch, Level0View l0, const uint16_t* d_oct_tab);
 int prepare_octree(const Geom& g);  // the part of the quad-tree launch that can fail (called before a batch's first kernel)
+// the path tables of the closed-form quad-tree (octree_pyramid.hpp: path_xbits / path_ybits) are a constant of a level's geometry: built on the
+// host once per geometry, g.lv[l].oct_tab_off entries into dst (uint16 each); the kernels copy a level's table into LDS instead of computing
+// it per (frame, level) problem
+void octree_fill_path_tables(const Geom& g, uint16_t* dst);
 int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_lo, int32_t* d_cursor,
                    int32_t* d_fcount, int32_t* d_n_cell_list, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate,
-                   uint32_t* d_sel_xy, uint32_t* d_sel_sc, int32_t* d_sel_count, int batch);
+                   uint32_t* d_sel_xy, uint32_t* d_sel_sc, int32_t* d_sel_count, int batch, const uint16_t* d_oct_tab);
 // FAST mode feedback handed to k_assemble (its workgroup 0 sums the batch's fall-back cells and re-decides each level's mode)
 struct FastAdapt {
   const int32_t* fcount;  // [batch][nlevels] fall-back cells per (frame, level), written by k_octree

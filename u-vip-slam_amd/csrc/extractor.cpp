@@ -116,6 +116,8 @@ struct uvo_extractor {
   int last_batch = 0;
   // shared read-only tables
   LevelGeom* d_lv = nullptr;
+  uint16_t* d_oct_tab = nullptr;  // the quad-tree's path tables of the current geometry (octree_fill_path_tables), per level at LevelGeom::oct_tab_off
+  int cap_oct_tab = 0;
   CellDesc* d_cells = nullptr;
   int32_t* d_cell_flag = nullptr;
   ResizeCol* d_ctab = nullptr;
@@ -250,7 +252,7 @@ static int build_geom(const uvo_extractor* h, int width, int height, Geom& g, st
   cells.clear();
   if (cell_flag) cell_flag->clear();
   int64_t off = 0, coff = 0;
-  int soff = 0, xt = 0, yt = 0, flag_base = 0;
+  int soff = 0, xt = 0, yt = 0, ot = 0, flag_base = 0;
   for (int l = 0; l < nl; ++l) {
     LevelGeom& L = g.lv[l];
     L.w = cv_round_host((float)width * h->inv_scale[l]);
@@ -316,6 +318,8 @@ static int build_geom(const uvo_extractor* h, int width, int height, Geom& g, st
     L.patch_size = (float)(int)(31 * h->scale[l]);
     L.xtab_off = xt, L.ytab_off = yt;
     if (l > 0) xt += L.pitch, yt += (L.ph + 3) & ~3;  // row tables are padded to whole groups of 4 rows (k_resize_level reads a group at once)
+    L.oct_tab_off = ot, L.pad_ = 0;
+    ot += (L.bw + L.bh + 1) & ~1;  // (an even number of 2-byte entries: the kernels copy a table as dwords)
   }
   g.total_cells = (int)cells.size();
   g.pyr_block = off;
@@ -431,6 +435,14 @@ static int set_geometry(uvo_extractor* h, int width, int height) {
   {
     int rcs = sync_all_lanes(h);
     if (rcs) return rcs;
+  }
+  {
+    const LevelGeom& last = g.lv[g.nlevels - 1];
+    const int n_oct = last.oct_tab_off + ((last.bw + last.bh + 1) & ~1);
+    if (n_oct > h->cap_oct_tab) return fail(UVO_E_BADARG, "image larger than the handle was sized for");
+    std::vector<uint16_t> oct_tab((size_t)n_oct, 0);
+    octree_fill_path_tables(g, oct_tab.data());
+    UVO_HIP_CHECK(hipMemcpy(h->d_oct_tab, oct_tab.data(), oct_tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
   UVO_HIP_CHECK(hipMemcpy(h->d_lv, g.lv, sizeof(LevelGeom) * g.nlevels, hipMemcpyHostToDevice));
   UVO_HIP_CHECK(hipMemcpy(h->d_cells, cells.data(), sizeof(CellDesc) * cells.size(), hipMemcpyHostToDevice));
@@ -551,7 +563,7 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
     ProfScope p(h, "k_octree_gauss");
     launch_octree_gauss(s, h->d_lv, g, L.d_pyr, L.d_blur, g.pyr_block, gtaps, h->blur_rounding, L.d_cand_lo, L.d_cursor,
                         L.d_fcount, L.d_fstat + kMaxLevels, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count, L.d_pstate, L.d_sel_xy, L.d_sel_sc, L.d_sel_count,
-                        batch, l0);
+                        batch, l0, h->d_oct_tab);
   } else {
     {
       ProfScope p(h, "k_gauss7");
@@ -560,7 +572,7 @@ static int run_batch_device(uvo_extractor* h, int li, int batch, const uint8_t* 
     {
       ProfScope p(h, "k_octree");
       rc = launch_octree(s, h->oct, h->d_lv, g, L.d_cand_lo, L.d_cursor, L.d_fcount, L.d_fstat + kMaxLevels, L.d_cell_hi, L.d_cand_xy, L.d_cand_sc, g.cand_block, L.d_cand_count,
-                         L.d_pstate, L.d_sel_xy, L.d_sel_sc, L.d_sel_count, batch);
+                         L.d_pstate, L.d_sel_xy, L.d_sel_sc, L.d_sel_count, batch, h->d_oct_tab);
       if (rc) return rc;
     }
   }
@@ -680,6 +692,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   h->cap_flist = g.flist_cap;
   h->cap_xtab = 0, h->cap_ytab = 0;
   for (int l = 1; l < g.nlevels; ++l) h->cap_xtab += g.lv[l].pitch + 64, h->cap_ytab += g.lv[l].ph + 8;  // (row tables are padded to groups of 4 rows; smaller images of the same area have other level heights)
+  h->cap_oct_tab = 2 * g.nlevels * (cfg->max_width + cfg->max_height + 2) + 64;  // (a level's window is never wider / higher than the image; x 2: other shapes of the same area)
   const size_t B = (size_t)cfg->max_batch;
   hipError_t e = hipSetDevice(h->device);
   if (e != hipSuccess) {
@@ -711,6 +724,7 @@ int uvo_extractor_create(const uvo_extractor_cfg* cfg, uvo_extractor** out) {
   A(dev_alloc(&h->d_lv, (size_t)kMaxLevels));
   A(dev_alloc(&h->d_cells, (size_t)h->cap_cells));
   A(dev_alloc(&h->d_cell_flag, h->cap_flags / B + 64));
+  A(dev_alloc(&h->d_oct_tab, (size_t)h->cap_oct_tab));
   A(dev_alloc(&h->d_ctab, (size_t)h->cap_xtab));
   A(dev_alloc(&h->d_rtab, (size_t)h->cap_ytab));
   A(dev_alloc(&h->d_pattern, (size_t)1024));
@@ -769,7 +783,7 @@ void uvo_extractor_destroy(uvo_extractor* h) {
       if (e) (void)hipEventDestroy(e);
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
-  void* ptrs[] = {h->d_clahe_lut, h->d_clahe_out, h->d_lv, h->d_cells, h->d_cell_flag, h->d_ctab, h->d_rtab, h->d_pattern, h->d_patch, h->d_imgs, h->d_out_kp,
+  void* ptrs[] = {h->d_oct_tab, h->d_clahe_lut, h->d_clahe_out, h->d_lv, h->d_cells, h->d_cell_flag, h->d_ctab, h->d_rtab, h->d_pattern, h->d_patch, h->d_imgs, h->d_out_kp,
                   h->d_out_desc, h->d_n_out, h->d_in_kp, h->d_n_in, h->d_nfn, h->d_grid, h->d_grid_score};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include "common.hpp"
 #include "gauss_body.hpp"
@@ -49,7 +50,7 @@ __device__ __forceinline__ void octree_body(uint8_t* lds, const int level, const
                                             int32_t* __restrict__ cursor, int32_t* __restrict__ fcount, int32_t* __restrict__ n_cell_list, uint8_t* cell_hi,
                                             uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc, int64_t cand_block, int32_t* __restrict__ cand_count,
                                             uint32_t* __restrict__ pstate, uint32_t* __restrict__ sel_xy, uint32_t* __restrict__ sel_sc, int sel_block,
-                                            int32_t* __restrict__ sel_count) {
+                                            int32_t* __restrict__ sel_count, const uint16_t* __restrict__ oct_tab) {
 #ifdef UVO_OCT_TRACE
   const unsigned long long t_begin = wall_clock64();
   struct Stamp {
@@ -192,6 +193,7 @@ __device__ __forceinline__ void octree_body(uint8_t* lds, const int level, const
   // path tables of the closed form: the bytes of ccnt / ccnt2 behind the first 2 * Mmax words (`best` lives in front of them)
   w.tab = reinterpret_cast<uint16_t*>(w.ccnt + 2 * Mmax);
   w.tab_cap = 12 * Mmax;  // 24 * Mmax bytes of 2-byte entries
+  w.tab_src = oct_tab != nullptr && g.oct_tab_off >= 0 ? oct_tab + g.oct_tab_off : nullptr;
 
   const int64_t so = (int64_t)f * sel_block + g.sel_off;
   // First the closed form over the count pyramid (no pass over the candidates per generation, no per-candidate state).  Trees deeper
@@ -214,11 +216,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 1) void k_octree(const LevelGeo
                                                         uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc,
                                                         int64_t cand_block, int32_t* __restrict__ cand_count,
                                                         uint32_t* __restrict__ pstate, uint32_t* __restrict__ sel_xy,
-                                                        uint32_t* __restrict__ sel_sc, int sel_block, int32_t* __restrict__ sel_count) {
+                                                        uint32_t* __restrict__ sel_sc, int sel_block, int32_t* __restrict__ sel_count, const uint16_t* __restrict__ oct_tab) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   // level-major dispatch: the long level-0 problems start first
   octree_body<NT>(lds, (int)blockIdx.y, (int)blockIdx.x, lv, nlevels, Mmax, Mp2max, pyr_words, box_region, lds_bytes, FL, cand_lo, cursor, fcount, n_cell_list, cell_hi, cand_xy,
-                  cand_sc, cand_block, cand_count, pstate, sel_xy, sel_sc, sel_block, sel_count);
+                  cand_sc, cand_block, cand_count, pstate, sel_xy, sel_sc, sel_block, sel_count, oct_tab);
 }
 
 // DistributeOctTree and GaussianBlur in ONE launch (src/ORBextractor.cc:1006-1287 and :942: neither reads what the other writes).  The
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256, UVO_OCT_GAUSS_OCC) void k_octree_gauss(int n_o
                                                         int32_t* __restrict__ fcount, int32_t* __restrict__ n_cell_list, uint8_t* cell_hi,
                                                         uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sc, int64_t cand_block,
                                                         int32_t* __restrict__ cand_count, uint32_t* __restrict__ pstate, uint32_t* __restrict__ sel_xy,
-                                                        uint32_t* __restrict__ sel_sc, int sel_block, int32_t* __restrict__ sel_count) {
+                                                        uint32_t* __restrict__ sel_sc, int sel_block, int32_t* __restrict__ sel_count, const uint16_t* __restrict__ oct_tab) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   // Workgroups are dispatched in index order, and all of them reserve the same LDS: with the quad-tree problems in front they would take
   // every slot of every CU and the blur would start when they are done.  Interleaved -- every third workgroup a quad-tree problem (level-
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256, UVO_OCT_GAUSS_OCC) void k_octree_gauss(int n_o
   }
   if (o >= 0) {
     octree_body<256>(lds, o / G.batch, o % G.batch, lv, nlevels, Mmax, Mp2max, pyr_words, box_region, lds_bytes, FL, cand_lo, cursor, fcount, n_cell_list, cell_hi, cand_xy, cand_sc,
-                     cand_block, cand_count, pstate, sel_xy, sel_sc, sel_block, sel_count);
+                     cand_block, cand_count, pstate, sel_xy, sel_sc, sel_block, sel_count, oct_tab);
   } else {
     gauss7_body<SSE2>(b, G.blocks_x, G.batch, reinterpret_cast<uint32_t(*)[GS_TILE_DW]>(lds), G.pyr, G.blur, G.pyr_block, lv, nlevels, G.taps, G.rows_per_seg, G.l0, G.plans);
   }
@@ -307,7 +309,7 @@ int prepare_octree(const Geom& g) {
 
 int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, const Geom& g, const uint32_t* d_cand_lo, int32_t* d_cursor,
                    int32_t* d_fcount, int32_t* d_n_cell_list, uint8_t* d_cell_hi, uint32_t* d_cand_xy, uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
-                   int32_t* d_sel_count, int batch) {
+                   int32_t* d_sel_count, int batch, const uint16_t* d_oct_tab) {
   int M, Mp2, pyr_words;
   const size_t lds = octree_lds(g, M, Mp2, pyr_words);  // (prepare_octree has raised the kernel's limit for it)
   // The kernel is latency bound (a few dozen dependent phases per problem): the per-candidate state lives in registers,
@@ -329,11 +331,11 @@ int launch_octree(hipStream_t s, OctLaunchState& st, const LevelGeom* d_lv, cons
 #endif
   if (wide)
     hipLaunchKernelGGL(k_octree<1024>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), (int)lds, fast_levels(g, batch), d_cand_lo,
-                       d_cursor, d_fcount, d_n_cell_list, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count);
+                       d_cursor, d_fcount, d_n_cell_list, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block, d_sel_count, d_oct_tab);
   else
     hipLaunchKernelGGL(k_octree<OCT_THREADS>, dim3(batch, g.nlevels), dim3(threads), lds, s, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), (int)lds, fast_levels(g, batch),
                        d_cand_lo, d_cursor, d_fcount, d_n_cell_list, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc, g.sel_block,
-                       d_sel_count);
+                       d_sel_count, d_oct_tab);
   return UVO_OK;
 }
 
@@ -352,7 +354,7 @@ bool octree_gauss_applies(const OctLaunchState& st, const Geom& g, int batch) {
 void launch_octree_gauss(hipStream_t s, const LevelGeom* d_lv, const Geom& g, const uint8_t* d_pyr, uint8_t* d_blur, int64_t pyr_block, int4 taps, int sse2_rounding,
                          const uint32_t* d_cand_lo, int32_t* d_cursor, int32_t* d_fcount, int32_t* d_n_cell_list, uint8_t* d_cell_hi, uint32_t* d_cand_xy,
                          uint32_t* d_cand_sc, int64_t cand_block, int32_t* d_cand_count, uint32_t* d_pstate, uint32_t* d_sel_xy, uint32_t* d_sel_sc,
-                         int32_t* d_sel_count, int batch, Level0View l0) {
+                         int32_t* d_sel_count, int batch, Level0View l0, const uint16_t* d_oct_tab) {
   int M, Mp2, pyr_words;
   const size_t lds = std::max(octree_lds(g, M, Mp2, pyr_words), (size_t)GS_LDS_BYTES);
   GaussArgs G;
@@ -364,11 +366,27 @@ void launch_octree_gauss(hipStream_t s, const LevelGeom* d_lv, const Geom& g, co
   if (sse2_rounding)
     hipLaunchKernelGGL(k_octree_gauss<true>, grid, dim3(256), lds, s, n_oct, G, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), (int)lds,
                        fast_levels(g, batch), d_cand_lo, d_cursor, d_fcount, d_n_cell_list, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc,
-                       g.sel_block, d_sel_count);
+                       g.sel_block, d_sel_count, d_oct_tab);
   else
     hipLaunchKernelGGL(k_octree_gauss<false>, grid, dim3(256), lds, s, n_oct, G, d_lv, g.nlevels, M, Mp2, pyr_words, (int)oct_box_region_bytes(M, pyr_words), (int)lds,
                        fast_levels(g, batch), d_cand_lo, d_cursor, d_fcount, d_n_cell_list, d_cell_hi, d_cand_xy, d_cand_sc, cand_block, d_cand_count, d_pstate, d_sel_xy, d_sel_sc,
-                       g.sel_block, d_sel_count);
+                       g.sel_block, d_sel_count, d_oct_tab);
+}
+
+// the levels' path tables as the closed form builds them (octree_pyramid.hpp), for the kernels to copy
+void octree_fill_path_tables(const Geom& g, uint16_t* dst) {
+  for (int l = 0; l < g.nlevels; ++l) {
+    const LevelGeom& L = g.lv[l];
+    const int G = oct::pyramid_depth(L.nIni);
+    if (L.oct_tab_off < 0 || G == 0) continue;
+    oct::Params pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.W = L.bw, pr.H = L.bh, pr.nIni = L.nIni, pr.hX = L.hX;
+    uint16_t* xs = dst + L.oct_tab_off;
+    uint16_t* ys = xs + L.bw;
+    for (int x = 0; x < L.bw; ++x) xs[x] = (uint16_t)oct::path_xbits(pr, G, x);
+    for (int y = 0; y < L.bh; ++y) ys[y] = (uint16_t)oct::path_ybits(pr, G, y);
+  }
 }
 
 }  // namespace uvo

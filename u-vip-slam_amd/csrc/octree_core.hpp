@@ -129,6 +129,7 @@ struct Work {
   int* stat;             // [16]
   uint16_t* tab;         // path tables of the closed-form path (x part, then y part), tab_cap entries; on the device they share the
   int tab_cap;           // bytes of ccnt / ccnt2 behind the first 2M words (the closed form writes nothing there: `best` lives in front of them)
+  const uint16_t* tab_src;  // the same tables ready-made in memory (a constant of the level's geometry: the kernel copies them), or null: computed here
 };
 
 enum { SC_NA = 0, SC_NOUT, SC_NEXP, SC_NPROC, SC_T, SC_NTOEXP, SC_M, SC_TMP };

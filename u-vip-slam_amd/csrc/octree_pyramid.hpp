@@ -162,7 +162,11 @@ OCT_FN int run_pyramid(const Params& pr, const Work& w, const uint32_t* cand_xy,
   for (int i = tid; i < total; i += OCT_NT) pyr[i] = 0;
   if (tid < 16) stat[tid] = 0;
   if (tid == 0) sc[SC_NOUT] = 0, sc[SC_NA] = 0;
-  if (use_tab) {
+  if (use_tab && w.tab_src != nullptr) {  // ready-made (octree_fill_path_tables): two entries per load, both ends 4-byte aligned
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(w.tab_src);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(w.tab);
+    for (int i = tid; i < (pr.W + pr.H + 1) / 2; i += OCT_NT) dst[i] = src[i];
+  } else if (use_tab) {
     for (int x = tid; x < pr.W; x += OCT_NT) xs[x] = (uint16_t)path_xbits(pr, G, x);
     for (int y = tid; y < pr.H; y += OCT_NT) ys[y] = (uint16_t)path_ybits(pr, G, y);
   }
