@@ -18,3 +18,5 @@ UVO_BENCH_DRYRUN_ONE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-pe
 timeout 900 python tools/soak_parity.py 60 7 > $O/soak_parity.log 2>&1; tail -1 $O/soak_parity.log
 timeout 600 python tools/soak_matcher.py > $O/soak_matcher.log 2>&1; tail -1 $O/soak_matcher.log
 timeout 600 python tools/soak_misc.py > $O/soak_misc.log 2>&1; tail -1 $O/soak_misc.log
+# a longer randomized parity soak of the final build (UVO_SOAK_LONG=n trials)
+if [ -n "$UVO_SOAK_LONG" ]; then timeout 1500 python tools/soak_parity.py $UVO_SOAK_LONG 23 > $O/soak_parity_long.log 2>&1; tail -1 $O/soak_parity_long.log; fi
