@@ -827,7 +827,7 @@ def main():
     frames = make_frames(ctx, cfg, B, first, halo, distinct=32 if (args.config == 3 and os.environ.get("UVO_BENCH_C3_DISTINCT", "1") == "1") else None)
     DEPTH = int(os.environ.get("UVO_PIPELINE_DEPTH", "2"))
     wl = HbmWorkload(ctx, cfg, B, frames, DEPTH, fast_mode=args.fast_mode, own_stream=args.matcher_stream == "own", env_knobs=True)
-    ex, cap, d_imgs, d_ring, NRING = wl.ex, wl.cap, wl.d_ring[0], wl.d_ring, wl.NRING
+    d_imgs, d_ring, NRING = wl.d_ring[0], wl.d_ring, wl.NRING
     step, extract_only, sync_all = wl.step, wl.extract_only, wl.sync_all
 
     m = wl.measure(steps, args.warmup)
@@ -863,7 +863,6 @@ def main():
     # ---- sub-records on rank 0 (the other ranks idle at the barrier below) ----
     c4_cpu = None
     if rank == 0 and not args.no_subrecords:
-        counter = wl.counter
         # extract only
         for _ in range(DEPTH):
             extract_only()
